@@ -1,0 +1,158 @@
+/*
+ * uzu_model_desc.h -- plain-C description of a decoder-only language model as uzu's
+ * `encodable_block` layer sees it after `Engine::load_language_model`
+ * (crates/backend-uzu/src/engine/language_model/mod.rs:58-116).
+ *
+ * It is the in-memory equivalent of `config.json` + `model.safetensors`: the same numbers the
+ * reference's `config/**` structs carry, and host pointers to tensors in the reference's on-disk
+ * layouts.  Both the HIP engine (include/uzu_hip_engine.h) and the CPU
+ * oracle (oracle/) consume this struct, so a parity test hands the SAME bytes to both.
+ *
+ * All pointers are HOST pointers, owned by the caller, and only need to stay valid for the
+ * duration of the `*_model_create` call that receives them.
+ */
+#ifndef UZU_MODEL_DESC_H
+#define UZU_MODEL_DESC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* backends/common/gpu_types/quantization_method.rs:4-9 */
+typedef enum {
+    UZU_QUANT_SCALE_BIAS = 0,       /* MLXSpec: deq = scale*q + bias                  */
+    UZU_QUANT_SCALE_ZERO_POINT = 1, /* IntSpec asymmetric: deq = scale*q - scale*zp   */
+    UZU_QUANT_SCALE_SYMMETRIC = 2,  /* IntSpec symmetric: deq = scale*q - scale*2^(b-1) */
+    UZU_QUANT_NONE = 3              /* FullPrecisionSpec: bf16 weights [n,k]          */
+} uzu_quant_method;
+
+/* backends/common/gpu_types/activation_type.rs:8-14 */
+typedef enum {
+    UZU_ACT_SILU = 0,
+    UZU_ACT_GELU_APPROX = 1,
+    UZU_ACT_GELU_EXACT = 2,
+    UZU_ACT_IDENTITY = 3,
+    UZU_ACT_SOFTPLUS = 4
+} uzu_activation_type;
+
+/*
+ * One `Linear` (encodable_block/linear/matmul.rs:39-47) = WeightMatrix in Layout::OutputInput
+ * (encodable_block/weight_matrix.rs:101-162):
+ *   weights      u8  [n, k/pack]            pack = 2 (4 bit, low nibble = even k) or 1 (8 bit)
+ *   scales       bf16 [n, ceil(k/group)]
+ *   biases       bf16 [n, ceil(k/group)]                  (ScaleBias only)
+ *   zero_points  u8  [n, ceil(groups/pack)]               (ScaleZeroPoint only; 4 bit: nibble packed)
+ *   out_biases   bf16 [n]                                 (Linear `biases`, optional)
+ * method == UZU_QUANT_NONE: weights is bf16 [n,k], bits == 16, everything else NULL.
+ */
+typedef struct {
+    uint32_t n;          /* output_dim */
+    uint32_t k;          /* input_dim */
+    uint32_t bits;       /* 4, 8 or 16 */
+    uint32_t group_size; /* 0 for full precision */
+    uint32_t method;     /* uzu_quant_method */
+    uint32_t reserved;
+    const void* weights;
+    const uint16_t* scales;
+    const uint16_t* biases;
+    const uint8_t* zero_points;
+    const uint16_t* out_biases;
+} uzu_linear_desc;
+
+/* config/normalization.rs:10-18 + tensor `scales` f32 [dim] (encodable_block/normalization.rs:67-74) */
+typedef struct {
+    uint32_t present;       /* 0 => this optional norm is absent */
+    uint32_t full_layer;    /* UpcastMode::FullLayer (1) vs OnlyNormalization (0) */
+    uint32_t subtract_mean; /* LayerNorm-style mean subtraction */
+    uint32_t reserved;
+    float epsilon;
+    float scale_offset;     /* Option<f32>::unwrap_or(0.0) */
+    const float* scales;    /* f32 [dim] or NULL (has_scale == false) */
+    const float* biases;    /* f32 [dim] or NULL */
+} uzu_norm_desc;
+
+typedef enum { UZU_MIXER_ATTENTION = 0, UZU_MIXER_DELTA_NET = 1 } uzu_mixer_kind;
+
+/* config/rope/*.rs -- Unscaled and Llama-3 scaling (encodable_block/mixer/attention/rope.rs:13-114) */
+typedef enum { UZU_ROPE_NONE = 0, UZU_ROPE_UNSCALED = 1, UZU_ROPE_LLAMA = 2, UZU_ROPE_LINEAR = 3 } uzu_rope_kind;
+
+typedef struct {
+    uint32_t kind;                    /* uzu_rope_kind */
+    uint32_t head_dim;                /* rope dim (may be < attention head_dim: partial rotary) */
+    uint32_t max_sequence_length;
+    uint32_t original_context_length; /* Llama */
+    float base;
+    float scaling_factor;             /* Llama / Linear */
+    float low_frequency_factor;       /* Llama */
+    float high_frequency_factor;      /* Llama */
+} uzu_rope_desc;
+
+/* config/transformer_layer.rs:8-21 with AttentionConfig / DeltaNetConfig and a DenseMLPConfig */
+typedef struct {
+    uint32_t mixer_kind; /* uzu_mixer_kind */
+    uint32_t hidden_dim; /* MLP hidden (up projection has 2*hidden rows: [up ; gate]) */
+    uint32_t activation; /* uzu_activation_type of the gated MLP */
+    uint32_t reserved;
+
+    uzu_norm_desc pre_mixer_norm;
+    uzu_norm_desc post_mixer_norm;
+    uzu_norm_desc pre_mlp_norm;
+    uzu_norm_desc post_mlp_norm;
+
+    /* --- attention (config/token_mixer/attention.rs:9-29) --- */
+    uint32_t num_heads;
+    uint32_t num_groups; /* kv heads */
+    uint32_t head_dim;
+    uint32_t has_gate;   /* gate_projection_config.is_some() */
+    float attention_scale; /* 0 => 1/sqrt(head_dim) */
+    uint32_t use_rope;
+    uzu_linear_desc qkv_projection;  /* n = (heads + 2*groups) * head_dim */
+    uzu_linear_desc gate_projection; /* n = heads*head_dim */
+    uzu_linear_desc out_projection;  /* k = heads*head_dim */
+    uzu_norm_desc query_norm;        /* scales f32 [head_dim] */
+    uzu_norm_desc key_norm;
+
+    /* --- gated delta net (config/token_mixer/delta_net.rs) --- */
+    uint32_t dn_num_heads;      /* value heads Hv */
+    uint32_t dn_num_groups;     /* key heads Hk */
+    uint32_t dn_head_dim;       /* Dk (128) */
+    uint32_t dn_value_head_dim; /* Dv (128) */
+    uint32_t dn_kernel_size;
+    float dn_norm_epsilon;
+    uzu_linear_desc dn_in_proj;  /* n = 2*Hk*Dk + 2*Hv*Dv + 2*Hv */
+    uzu_linear_desc dn_out_proj; /* k = Hv*Dv */
+    const float* dn_conv_weights; /* f32 [conv_dim, kernel_size] */
+    const float* dn_conv_biases;  /* f32 [conv_dim] or NULL */
+    const float* dn_a_log;        /* f32 [Hv] */
+    const float* dn_dt_bias;      /* f32 [Hv] */
+    const float* dn_norm_scales;  /* f32 [Dv] */
+
+    /* --- dense MLP (encodable_block/mlp/dense.rs) --- */
+    uzu_linear_desc up_projection;   /* n = 2*hidden: rows [0,h) = up, [h,2h) = gate */
+    uzu_linear_desc down_projection; /* k = hidden */
+} uzu_layer_desc;
+
+typedef struct {
+    uint32_t vocab_size;
+    uint32_t model_dim;
+    uint32_t num_layers;
+    uint32_t tied_embeddings;
+    float input_scale;   /* embedding input_scale, default 1 */
+    float logit_scale;   /* default 1 */
+    float logit_soft_cap; /* 0 => none */
+    uint32_t max_context_length; /* KV cache capacity = max_context_length + 1024 rows (attention/state.rs:108-122) */
+    uzu_rope_desc rope;
+    /* embedding table, Layout::InputOutput => stored [vocab, dim/pack]; described here with
+     * n = vocab, k = model_dim exactly like the readout matmul sees it (embedding.rs:374-456). */
+    uzu_linear_desc embedding;
+    uzu_linear_desc output_embedding; /* untied readout; ignored when tied */
+    uzu_norm_desc output_norm;
+    const uzu_layer_desc* layers;
+} uzu_model_desc;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZU_MODEL_DESC_H */

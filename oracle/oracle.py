@@ -1,0 +1,169 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (uzu_amd/) must never import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+BF16, F32 = 0, 2
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("uzu_oracle_kernels.c", "uzu_oracle_model.c", "uzu_oracle.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "uzu_model_desc.h"))
+    stale = not os.path.exists(_LIB_PATH) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class MatmulArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("a_dtype", C.c_uint32),
+        ("b", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p), ("zero_points", C.c_void_p),
+        ("w_dtype", C.c_uint32), ("method", C.c_uint32), ("bits", C.c_uint32), ("group_size", C.c_uint32),
+        ("signed_codes", C.c_uint32), ("b_transpose", C.c_uint32), ("b_leading_dimension", C.c_uint32),
+        ("d", C.c_void_p), ("d_dtype", C.c_uint32), ("ab_scale", C.c_float), ("accumulate", C.c_uint32),
+        ("bias", C.c_void_p), ("has_soft_cap", C.c_uint32), ("soft_cap", C.c_float),
+        ("gather_indices", C.c_void_p), ("m", C.c_uint32), ("n", C.c_uint32), ("k", C.c_uint32),
+    ]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [
+        ("input", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p), ("output", C.c_void_p),
+        ("shortcut", C.c_void_p), ("io_dtype", C.c_uint32), ("affine_dtype", C.c_uint32),
+        ("batch_size", C.c_uint32), ("element_count", C.c_uint32),
+        ("epsilon", C.c_float), ("scale_offset", C.c_float), ("post_layer_scalar", C.c_float),
+        ("subtract_mean", C.c_uint32), ("full_layer", C.c_uint32), ("copy_to_shortcut", C.c_uint32),
+        ("residual_add", C.c_uint32), ("scale_residual_sum", C.c_uint32), ("scale_output", C.c_uint32),
+    ]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [
+        ("queries", C.c_void_p), ("keys", C.c_void_p), ("values", C.c_void_p), ("dtype", C.c_uint32),
+        ("head_dim", C.c_uint32), ("gqa_factor", C.c_uint32), ("sequence_length", C.c_uint32),
+        ("k_head_stride", C.c_uint32), ("k_seq_stride", C.c_uint32), ("v_head_stride", C.c_uint32),
+        ("v_seq_stride", C.c_uint32),
+        ("is_kv_cache_ring", C.c_uint32), ("ring_offset", C.c_uint32), ("ring_length", C.c_uint32),
+        ("scale", C.c_float), ("is_sliding_window", C.c_uint32), ("sliding_window_size", C.c_uint32),
+        ("sinks", C.c_void_p), ("num_heads", C.c_uint32), ("suffix_length", C.c_uint32), ("is_causal", C.c_uint32),
+    ]
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_model_create.restype = C.c_void_p
+        _lib.orc_model_create.argtypes = [C.c_void_p]
+        _lib.orc_model_destroy.argtypes = [C.c_void_p]
+        _lib.orc_model_reset.argtypes = [C.c_void_p]
+        _lib.orc_model_context_length.argtypes = [C.c_void_p]
+        _lib.orc_model_context_length.restype = C.c_uint32
+        _lib.orc_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.orc_model_forward.restype = C.c_uint32
+        _lib.orc_model_layer_output.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.orc_model_layer_output.restype = C.c_void_p
+        _lib.orc_model_final_hidden.argtypes = [C.c_void_p]
+        _lib.orc_model_final_hidden.restype = C.c_void_p
+        _lib.orc_f32_to_bf16.argtypes = [C.c_float]
+        _lib.orc_f32_to_bf16.restype = C.c_uint16
+        _lib.orc_activate.argtypes = [C.c_uint32, C.c_float, C.c_uint32]
+        _lib.orc_activate.restype = C.c_float
+        _lib.orc_get_max_threads.restype = C.c_int
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(C.c_int(n))
+
+
+def p(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle needs contiguous arrays"
+    return C.c_void_p(a.ctypes.data)
+
+
+def call(name: str, *args):
+    """Call a void oracle kernel; numpy arrays are passed as pointers, ints as u32, floats as f32."""
+    conv = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            conv.append(p(a))
+        elif a is None:
+            conv.append(None)
+        elif isinstance(a, (float, np.floating)):
+            conv.append(C.c_float(float(a)))
+        elif isinstance(a, (bool, int, np.integer)):
+            conv.append(C.c_uint32(int(a)))
+        else:
+            conv.append(a)
+    getattr(lib(), name)(*conv)
+
+
+class OracleModel:
+    """orc_model_* : Decoder::encode + greedy sampling + accept for one sequence."""
+
+    def __init__(self, bundle):
+        self.bundle = bundle
+        self._desc = bundle.desc()
+        self._h = lib().orc_model_create(C.byref(self._desc))
+        self.vocab_size = bundle.vocab_size
+        self.model_dim = bundle.model_dim
+
+    def close(self):
+        if self._h:
+            lib().orc_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        lib().orc_model_reset(self._h)
+
+    @property
+    def context_length(self) -> int:
+        return lib().orc_model_context_length(self._h)
+
+    def forward(self, tokens, want_logits: bool = False):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        logits = np.empty(self.vocab_size, dtype=np.uint16) if want_logits else None
+        tok = lib().orc_model_forward(self._h, p(tokens), C.c_uint32(tokens.size), p(logits))
+        return (int(tok), logits) if want_logits else int(tok)
+
+    def prefill(self, tokens, want_logits: bool = False):
+        """LanguageModelStream::new: chunks of <= 1024 tokens (stream.rs:194-195)."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        out = None
+        for s in range(0, tokens.size, 1024):
+            out = self.forward(tokens[s:s + 1024], want_logits)
+        return out
+
+    def layer_output(self, layer: int) -> np.ndarray:
+        rows = C.c_uint32(0)
+        ptr = lib().orc_model_layer_output(self._h, C.c_uint32(layer), C.byref(rows))
+        n = rows.value * self.model_dim
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(n,)).copy().reshape(rows.value, -1)
+
+    def final_hidden(self) -> np.ndarray:
+        ptr = lib().orc_model_final_hidden(self._h)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(self.model_dim,)).copy()

@@ -1,0 +1,200 @@
+/*
+ * uzu_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * A plain-C restatement of the reference's CPU backend kernels on the transformer forward path
+ * (crates/backend-uzu/src/backends/cpu/kernel/**) and of the op order of
+ * crates/backend-uzu/src/encodable_block/**.  Same loops, same f32 accumulation order, bf16
+ * round-to-nearest-even at every store (`half` 2.7 `bf16::from_f32`), glibc libm for
+ * exp/log/tanh/sin/cos/pow (what Rust's `f32::*` lowers to on Linux).
+ *
+ * PARITY STATUS: the reference is Rust 1.94 (no toolchain in this environment, no network) and
+ * ships no golden vectors for this path, so this oracle cannot be checked against outputs of the
+ * reference itself: **parity unpinned** except for (a) the one literal known-answer test in the
+ * reference tree (gated_act_mul_test.rs:139-160) and (b) independent float64 NumPy references of
+ * the same math, mirroring the reference's own `reference_attention` style checks
+ * (tests/test_oracle_*.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
+ * The product (uzu_amd/) never does.
+ *
+ * Build: `make -C oracle` -> oracle/_build/liboracle.so  (gcc -O2 -ffp-contract=off: Rust never
+ * contracts a*b+c into an FMA, so neither may we).
+ */
+#ifndef UZU_ORACLE_H
+#define UZU_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/uzu_model_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types a kernel can be instantiated with (data_type.rs:5-35, subset used by the LM path) */
+typedef enum { ORC_BF16 = 0, ORC_F32 = 2 } orc_dtype;
+
+void orc_set_threads(int n); /* OpenMP threads over independent outputs; results are bit-identical for any n */
+int orc_get_max_threads(void);
+
+/* half::bf16 conversions */
+uint16_t orc_f32_to_bf16(float v);
+float orc_bf16_to_f32(uint16_t v);
+void orc_f32_to_bf16_array(const float* src, uint16_t* dst, size_t n);
+void orc_bf16_to_f32_array(const uint16_t* src, float* dst, size_t n);
+
+/* ---- MatmulKernel (cpu/kernel/matmul/kernel.rs:56-307) ---- */
+typedef struct {
+    /* A: MatmulA::FullPrecision { values, offset } */
+    const void* a;
+    uint32_t a_dtype; /* input_data_type */
+    /* B */
+    const void* b;             /* codes (u8 / u32 words) or full-precision [n,k] */
+    const void* scales;        /* weights_data_type [n, groups] */
+    const void* biases;        /* weights_data_type [n, groups]  (ScaleBias) */
+    const uint8_t* zero_points; /* (ScaleZeroPoint) */
+    uint32_t w_dtype;          /* weights_data_type */
+    uint32_t method;           /* uzu_quant_method */
+    uint32_t bits;             /* 4 / 8 (quantized) */
+    uint32_t group_size;
+    uint32_t signed_codes;
+    uint32_t b_transpose;      /* full precision only */
+    uint32_t b_leading_dimension; /* 0 => default */
+    /* D + MatmulDOps */
+    void* d;
+    uint32_t d_dtype; /* output_data_type */
+    float ab_scale;
+    uint32_t accumulate;
+    const void* bias; /* weights_data_type [n] or NULL */
+    uint32_t has_soft_cap;
+    float soft_cap;
+    const uint32_t* gather_indices; /* [m,n] or NULL */
+    uint32_t m, n, k;
+} orc_matmul_args;
+void orc_matmul(const orc_matmul_args* args);
+
+/* ---- Normalization (cpu/kernel/normalization/normalization.rs:7-126) ---- */
+typedef struct {
+    const void* input; /* NULL => in place (reads output) */
+    const void* scales; /* affine dtype */
+    const void* biases;
+    void* output;
+    void* shortcut; /* copy_to_shortcut */
+    uint32_t io_dtype;     /* InputT == OutputT */
+    uint32_t affine_dtype; /* AffineT */
+    uint32_t batch_size, element_count;
+    float epsilon, scale_offset, post_layer_scalar;
+    uint32_t subtract_mean, full_layer, copy_to_shortcut, residual_add;
+    uint32_t scale_residual_sum, scale_output;
+} orc_norm_args;
+void orc_normalization(const orc_norm_args* args);
+
+/* ---- QKVNorm (cpu/kernel/attention/qkv_norm.rs:7-77), in place ---- */
+void orc_qkv_norm(void* qkv, uint32_t dtype, const float* scales /* may be NULL */, uint32_t batch_size,
+                  uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset, uint32_t head_offset,
+                  uint32_t head_count, uint32_t full_layer);
+
+/* ---- host RoPE table (encodable_block/mixer/attention/rope.rs:13-114); out f32 [n_pos, head_dim] ---- */
+void orc_rope_tables(const uzu_rope_desc* rope, const uint32_t* token_positions, uint32_t n_pos, float* cosines,
+                     float* sines);
+
+/* ---- AttentionPrepare (cpu/kernel/attention/attention_prepare.rs:7-126), ElementT = bf16 ---- */
+void orc_attention_prepare(const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
+                           const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
+                           uint32_t head_dim, uint32_t rope_dim /* 0 => no rope */, uint32_t kv_token_offset,
+                           uint32_t batch_dim, uint32_t has_kv);
+
+/* ---- attention cores (attention_single_pass.rs / attention_two_pass.rs / mask.rs), non-trie ---- */
+typedef struct {
+    const void* queries; /* [heads, suffix, hd] */
+    const void* keys;
+    const void* values;
+    uint32_t dtype;
+    uint32_t head_dim, gqa_factor, sequence_length;
+    uint32_t k_head_stride, k_seq_stride, v_head_stride, v_seq_stride;
+    uint32_t is_kv_cache_ring, ring_offset, ring_length;
+    float scale;
+    uint32_t is_sliding_window, sliding_window_size;
+    const void* sinks; /* dtype [heads] or NULL */
+    uint32_t num_heads, suffix_length, is_causal;
+} orc_attention_args;
+void orc_attention_single_pass(const orc_attention_args* a, void* out /* [suffix, heads, hd] */);
+void orc_attention_two_pass1(const orc_attention_args* a, float* partials, float* sums, float* maxs);
+void orc_attention_two_pass2(const float* partials, const float* sums, const float* maxs, void* out, uint32_t dtype,
+                             uint32_t head_dim, uint32_t num_heads, uint32_t suffix_length);
+
+/* ---- small ops ---- */
+typedef struct { uint32_t source, destination; } orc_copy;
+void orc_kv_cache_update(void* keys, void* values, uint32_t dtype, const orc_copy* copies, uint32_t copy_count,
+                         uint32_t element_dim);                                             /* kv_cache_update.rs */
+void orc_sigmoid_gate(const void* gate, void* output, uint32_t dtype, uint32_t total);     /* sigmoid_gate.rs */
+float orc_activate(uint32_t act_type, float x, uint32_t dtype);                             /* activation_type.rs */
+void orc_gated_act_mul(const void* act_operand, const void* value_operand, void* fp_out, uint32_t dtype,
+                       uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
+                       uint32_t act_type, uint32_t interleaved);                            /* gated_act_mul.rs */
+void orc_quantized_embedding_lookup(const uint32_t* token_ids, const uint8_t* weights, const void* scales,
+                                    const uint8_t* zero_points, const void* biases, void* output, uint32_t dtype,
+                                    uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim, float input_scale,
+                                    uint32_t group_size, uint32_t bits, uint32_t method); /* quant_embedding.rs */
+void orc_full_precision_embedding_lookup(const uint32_t* token_ids, const void* weights, void* output, uint32_t dtype,
+                                         uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                         float input_scale);
+void orc_logit_transform(void* logits, uint32_t dtype, uint32_t length, float scale, float soft_cap,
+                         uint32_t has_soft_cap);
+void orc_tensor_add_bias(const void* input, const void* bias, void* output, uint32_t dtype, uint32_t bias_dtype,
+                         uint32_t num_cols, uint32_t length);
+void orc_tensor_add_scale(const void* input, const void* bias, void* output, uint32_t dtype, uint32_t num_cols,
+                          uint32_t length, float scale);
+void orc_tensor_add_swap(void* skip, void* main_buf, uint32_t dtype, uint32_t length);
+void orc_tensor_copy(const void* src, void* dst, uint32_t dtype, uint32_t length);
+void orc_argmax(const void* logits, uint32_t dtype, uint32_t* output, uint32_t vocab_size,
+                uint32_t batch_size); /* unified_sampling.rs greedy: ties -> lowest index */
+
+/* ---- Gated DeltaNet (cpu/kernel/gdn/{conv_update,update,conv_scan,prefill_prep,prefill,norm_gate}.rs,
+ *      ssm/conv1d.rs Conv1dPack) with the Metal kernels' buffer types: T = bf16 activations,
+ *      f32 a_log / dt_bias / norm_weight / conv + ssm state (metal/kernel/gdn/update.metal:19-31;
+ *      SURVEY.md F5) ---- */
+void orc_delta_net_conv_update(const float* conv_weight, const float* bias, uint16_t* in_out, float* state,
+                               uint32_t kernel_size, uint32_t conv_dim, uint32_t state_stride);
+void orc_delta_net_update(const uint16_t* in_proj, const float* a_log, const float* dt_bias,
+                          const float* norm_weight, float* state, uint16_t* out, uint32_t num_v_heads,
+                          uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
+                          uint32_t value_dim, float norm_epsilon);
+void orc_conv1d_pack(const float* state_in, const uint16_t* x, float* padded, uint32_t state_stride,
+                     uint32_t row_stride, uint32_t suffix_len, uint32_t num_channels);
+void orc_delta_net_conv_scan(const float* conv_padded, const float* conv_weight, const float* bias, uint16_t* in_proj,
+                             float* state_out, uint32_t suffix_len, uint32_t kernel_size, uint32_t row_stride,
+                             uint32_t state_stride, uint32_t conv_dim, uint32_t out_stride);
+void orc_delta_net_prefill_prep(const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out,
+                                float* k_norm_out, float* beta_out, float* decay_out, uint32_t num_v_heads,
+                                uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim, uint32_t value_dim,
+                                uint32_t suffix_len);
+void orc_delta_net_prefill(const float* q_norm, const float* k_norm, const float* beta_buf, const float* decay_buf,
+                           const uint16_t* in_proj, float* state, uint16_t* out, uint32_t num_v_heads,
+                           uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
+                           uint32_t value_dim, uint32_t suffix_len);
+void orc_delta_net_norm_gate(uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
+                             uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
+                             uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
+
+/* ---- model driver: Decoder::encode + greedy Sampling + encode_accept
+ *      (decoder.rs:138-203, transformer.rs:226-329, transformer_layer.rs:194-238,
+ *       engine/language_model/stream/stream.rs:190-345,593-751) ---- */
+typedef struct orc_model orc_model;
+orc_model* orc_model_create(const uzu_model_desc* desc); /* keeps the desc's pointers: caller keeps them alive */
+void orc_model_destroy(orc_model* m);
+void orc_model_reset(orc_model* m);
+uint32_t orc_model_context_length(const orc_model* m);
+/* One forward pass over `count` tokens of one sequence (count <= 1024) appended at the current context
+ * length; writes logits (bf16 [vocab]) of the LAST row if logits_out != NULL, returns greedy token of the
+ * last row.  This is one prefill chunk (count > 1) or one decode step (count == 1). */
+uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t count, uint16_t* logits_out);
+/* Debug taps: copy the last forward's per-layer outputs (bf16 [count, model_dim]) */
+const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint32_t* rows);
+const uint16_t* orc_model_final_hidden(const orc_model* m); /* output_norm of last row, bf16 [model_dim] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,369 @@
+/*
+ * uzu_oracle_model.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT).  See uzu_oracle.h.
+ *
+ * Restates the op ORDER of the reference's model graph for one sequence:
+ *   Decoder::encode            BU/src/encodable_block/decoder.rs:138-203
+ *   Transformer::encode        BU/src/encodable_block/transformer.rs:226-329
+ *   TransformerLayer::encode   BU/src/encodable_block/transformer_layer.rs:194-238
+ *   Attention::attend          BU/src/encodable_block/mixer/attention/mode.rs:45-144
+ *   AttentionCores::encode     BU/src/encodable_block/mixer/attention/core/mod.rs:81-93
+ *                              (CPU backend: no GEMM core => two-pass iff prefix+suffix > 1024)
+ *   DeltaNet::encode           BU/src/encodable_block/mixer/delta_net.rs:473-645
+ *   DenseMlp::encode           BU/src/encodable_block/mlp/dense.rs:32-48
+ *   Embedding::encode_readout  BU/src/encodable_block/embedding.rs:374-456
+ *   Sampling (greedy)          BU/src/backends/cpu/kernel/sampling/unified_sampling.rs:90-98
+ *   encode_accept              BU/src/encodable_block/mixer/attention/state.rs:174-236 (Full cache, flat
+ *                              full accept => no copies, length += n)
+ * on top of the kernels in uzu_oracle_kernels.c.  Activations are bf16 (LanguageModel hard-codes
+ * BF16, BU/src/engine/language_model/mod.rs:74).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "uzu_oracle.h"
+
+#define ATTENTION_SUFFIX_CAPACITY 1024u /* mixer/attention/state.rs:14 */
+
+typedef struct {
+    uint16_t* keys;   /* bf16 [max_ctx + 1024, kv_heads*hd] */
+    uint16_t* values;
+    uint32_t length;  /* AttentionStateType::Full { length } */
+    float* conv_state; /* f32 [conv_dim, k-1] */
+    float* ssm_state;  /* f32 [Hv, Dv, Dk] */
+} layer_state;
+
+struct orc_model {
+    uzu_model_desc desc;
+    uzu_layer_desc* layers;
+    layer_state* states;
+    uint32_t context_length;
+    uint16_t** layer_outputs; /* debug taps: per layer [rows, d] of the last forward */
+    uint32_t last_rows;
+    uint16_t* final_hidden;
+};
+
+static void* xcalloc(size_t n, size_t sz) {
+    void* p = calloc(n ? n : 1, sz);
+    if (!p) {
+        fprintf(stderr, "oracle: out of memory (%zu x %zu)\n", n, sz);
+        abort();
+    }
+    return p;
+}
+
+orc_model* orc_model_create(const uzu_model_desc* desc) {
+    orc_model* m = (orc_model*)xcalloc(1, sizeof(orc_model));
+    m->desc = *desc;
+    m->layers = (uzu_layer_desc*)xcalloc(desc->num_layers, sizeof(uzu_layer_desc));
+    memcpy(m->layers, desc->layers, sizeof(uzu_layer_desc) * desc->num_layers);
+    m->desc.layers = m->layers;
+    m->states = (layer_state*)xcalloc(desc->num_layers, sizeof(layer_state));
+    m->layer_outputs = (uint16_t**)xcalloc(desc->num_layers, sizeof(uint16_t*));
+    m->final_hidden = (uint16_t*)xcalloc(desc->model_dim, 2);
+    const size_t max_elements = (size_t)desc->max_context_length + ATTENTION_SUFFIX_CAPACITY;
+    for (uint32_t l = 0; l < desc->num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        if (L->mixer_kind == UZU_MIXER_ATTENTION) {
+            const size_t element_size = (size_t)L->num_groups * L->head_dim;
+            m->states[l].keys = (uint16_t*)xcalloc(max_elements * element_size, 2);
+            m->states[l].values = (uint16_t*)xcalloc(max_elements * element_size, 2);
+        } else {
+            const size_t key_dim = (size_t)L->dn_num_groups * L->dn_head_dim;
+            const size_t value_dim = (size_t)L->dn_num_heads * L->dn_value_head_dim;
+            const size_t conv_dim = 2 * key_dim + value_dim;
+            m->states[l].conv_state = (float*)xcalloc(conv_dim * (L->dn_kernel_size - 1), 4);
+            m->states[l].ssm_state = (float*)xcalloc((size_t)L->dn_num_heads * L->dn_value_head_dim * L->dn_head_dim, 4);
+        }
+    }
+    return m;
+}
+
+void orc_model_reset(orc_model* m) {
+    m->context_length = 0;
+    for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        m->states[l].length = 0;
+        if (L->mixer_kind == UZU_MIXER_DELTA_NET) {
+            const size_t key_dim = (size_t)L->dn_num_groups * L->dn_head_dim;
+            const size_t value_dim = (size_t)L->dn_num_heads * L->dn_value_head_dim;
+            memset(m->states[l].conv_state, 0, (2 * key_dim + value_dim) * (L->dn_kernel_size - 1) * 4);
+            memset(m->states[l].ssm_state, 0, (size_t)L->dn_num_heads * L->dn_value_head_dim * L->dn_head_dim * 4);
+        }
+    }
+}
+
+void orc_model_destroy(orc_model* m) {
+    if (!m) return;
+    for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
+        free(m->states[l].keys);
+        free(m->states[l].values);
+        free(m->states[l].conv_state);
+        free(m->states[l].ssm_state);
+        free(m->layer_outputs[l]);
+    }
+    free(m->layer_outputs);
+    free(m->final_hidden);
+    free(m->states);
+    free(m->layers);
+    free(m);
+}
+
+uint32_t orc_model_context_length(const orc_model* m) { return m->context_length; }
+const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint32_t* rows) {
+    if (rows) *rows = m->last_rows;
+    return m->layer_outputs[layer];
+}
+const uint16_t* orc_model_final_hidden(const orc_model* m) { return m->final_hidden; }
+
+/* Linear::encode -> MatmulKernel::encode with b_transpose = true (linear/matmul.rs:122-148) */
+static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) {
+    uint16_t* out = (uint16_t*)xcalloc((size_t)batch * lin->n, 2);
+    orc_matmul_args g;
+    memset(&g, 0, sizeof(g));
+    g.a = input;
+    g.a_dtype = ORC_BF16;
+    g.b = lin->weights;
+    g.scales = lin->scales;
+    g.biases = lin->biases;
+    g.zero_points = lin->zero_points;
+    g.w_dtype = ORC_BF16;
+    g.method = lin->method;
+    g.bits = lin->bits;
+    g.group_size = lin->group_size;
+    g.b_transpose = 1;
+    g.d = out;
+    g.d_dtype = ORC_BF16;
+    g.ab_scale = 1.0f;
+    g.bias = lin->out_biases;
+    g.m = batch;
+    g.n = lin->n;
+    g.k = lin->k;
+    orc_matmul(&g);
+    return out;
+}
+
+/* Normalization::encode (encodable_block/normalization.rs:114-146); mode: 0 none, 1 copy, 2 add */
+static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows,
+                      uint32_t dim) {
+    uint16_t* out = (uint16_t*)xcalloc((size_t)rows * dim, 2);
+    orc_norm_args g;
+    memset(&g, 0, sizeof(g));
+    g.input = input;
+    g.scales = nd->scales;
+    g.biases = nd->biases;
+    g.output = out;
+    g.shortcut = mode ? shortcut : NULL;
+    g.io_dtype = ORC_BF16;
+    g.affine_dtype = ORC_F32;
+    g.batch_size = rows;
+    g.element_count = dim;
+    g.epsilon = nd->epsilon;
+    g.scale_offset = nd->scale_offset;
+    g.post_layer_scalar = 1.0f;
+    g.subtract_mean = nd->subtract_mean;
+    g.full_layer = nd->full_layer;
+    g.copy_to_shortcut = mode != 0;
+    g.residual_add = mode == 2;
+    orc_normalization(&g);
+    return out;
+}
+
+static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch, const float* cosines,
+                                 const float* sines) {
+    const uzu_layer_desc* L = &m->layers[l];
+    layer_state* st = &m->states[l];
+    const uint32_t hd = L->head_dim, nq = L->num_heads, nkv = L->num_groups;
+    /* gate projection first, from a copy of hidden (mode.rs:54-61) */
+    uint16_t* gate = NULL;
+    if (L->has_gate) gate = linear(&L->gate_projection, hidden, batch);
+    uint16_t* qkv = linear(&L->qkv_projection, hidden, batch);
+    const uint32_t total_heads = nq + 2 * nkv;
+    /* QKVNorm::encode_packed (qkv_norm.rs:137-175) */
+    if (L->query_norm.present)
+        orc_qkv_norm(qkv, ORC_BF16, L->query_norm.scales, batch, total_heads, hd, L->query_norm.epsilon,
+                     L->query_norm.scale_offset, 0, nq, L->query_norm.full_layer);
+    if (L->key_norm.present)
+        orc_qkv_norm(qkv, ORC_BF16, L->key_norm.scales, batch, total_heads, hd, L->key_norm.epsilon,
+                     L->key_norm.scale_offset, nq, nkv, L->key_norm.full_layer);
+    /* prepare_kv_and_queries (mode.rs:200-232): kv_token_offset = physical_prefix_length */
+    uint16_t* queries = (uint16_t*)xcalloc((size_t)nq * batch * hd, 2);
+    const uint32_t rope_dim = L->use_rope ? m->desc.rope.head_dim : 0;
+    orc_attention_prepare(qkv, queries, st->keys, st->values, cosines, sines, nq, nkv, hd, rope_dim, st->length, batch, 1);
+    free(qkv);
+    /* AttentionCores::encode (core/mod.rs:81-93) */
+    orc_attention_args a;
+    memset(&a, 0, sizeof(a));
+    a.queries = queries;
+    a.keys = st->keys;
+    a.values = st->values;
+    a.dtype = ORC_BF16;
+    a.head_dim = hd;
+    a.gqa_factor = nq / nkv;
+    a.sequence_length = st->length + batch;
+    a.k_head_stride = hd;
+    a.k_seq_stride = nkv * hd;
+    a.v_head_stride = hd;
+    a.v_seq_stride = nkv * hd;
+    a.scale = L->attention_scale != 0.0f ? L->attention_scale : 1.0f / sqrtf((float)hd);
+    a.num_heads = nq;
+    a.suffix_length = batch;
+    a.is_causal = 1;
+    uint16_t* out = (uint16_t*)xcalloc((size_t)batch * nq * hd, 2);
+    if (st->length + batch > 1024) {
+        const size_t rows = (size_t)batch * nq;
+        float* partials = (float*)xcalloc(rows * 32 * hd, 4);
+        float* sums = (float*)xcalloc(rows * 32, 4);
+        float* maxs = (float*)xcalloc(rows * 32, 4);
+        orc_attention_two_pass1(&a, partials, sums, maxs);
+        orc_attention_two_pass2(partials, sums, maxs, out, ORC_BF16, hd, nq, batch);
+        free(partials);
+        free(sums);
+        free(maxs);
+    } else {
+        orc_attention_single_pass(&a, out);
+    }
+    free(queries);
+    if (gate) {
+        orc_sigmoid_gate(gate, out, ORC_BF16, batch * nq * hd);
+        free(gate);
+    }
+    uint16_t* projected = linear(&L->out_projection, out, batch);
+    free(out);
+    return projected;
+}
+
+static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch) {
+    const uzu_layer_desc* L = &m->layers[l];
+    layer_state* st = &m->states[l];
+    const uint32_t Hv = L->dn_num_heads, Hk = L->dn_num_groups, Dk = L->dn_head_dim, Dv = L->dn_value_head_dim;
+    const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
+    const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv;
+    const uint32_t ks = L->dn_kernel_size;
+    uint16_t* in_projected = linear(&L->dn_in_proj, hidden, batch);
+    uint16_t* delta_output = (uint16_t*)xcalloc((size_t)batch * value_dim, 2);
+    if (batch == 1) {
+        orc_delta_net_conv_update(L->dn_conv_weights, L->dn_conv_biases, in_projected, st->conv_state, ks, conv_dim, ks - 1);
+        orc_delta_net_update(in_projected, L->dn_a_log, L->dn_dt_bias, L->dn_norm_scales, st->ssm_state, delta_output, Hv,
+                             Hk, Dk, Dv, key_dim, value_dim, L->dn_norm_epsilon);
+    } else {
+        /* delta_net.rs:533-636: conv_pack -> conv_scan -> prefill_prep -> prefill -> norm_gate.
+         * NB: `padded` rows are total_proj_dim wide; only the first conv_dim channels are packed. */
+        float* padded = (float*)xcalloc((size_t)(batch + ks - 1) * total_proj_dim, 4);
+        orc_conv1d_pack(st->conv_state, in_projected, padded, ks - 1, total_proj_dim, batch, conv_dim);
+        orc_delta_net_conv_scan(padded, L->dn_conv_weights, L->dn_conv_biases, in_projected, st->conv_state, batch, ks,
+                                total_proj_dim, ks - 1, conv_dim, total_proj_dim);
+        free(padded);
+        float* qn = (float*)xcalloc((size_t)batch * key_dim, 4);
+        float* kn = (float*)xcalloc((size_t)batch * key_dim, 4);
+        float* beta = (float*)xcalloc((size_t)batch * Hv, 4);
+        float* decay = (float*)xcalloc((size_t)batch * Hv, 4);
+        orc_delta_net_prefill_prep(in_projected, L->dn_a_log, L->dn_dt_bias, qn, kn, beta, decay, Hv, Hk, Dk, key_dim,
+                                   value_dim, batch);
+        orc_delta_net_prefill(qn, kn, beta, decay, in_projected, st->ssm_state, delta_output, Hv, Hk, Dk, Dv, key_dim,
+                              value_dim, batch);
+        free(qn);
+        free(kn);
+        free(beta);
+        free(decay);
+        orc_delta_net_norm_gate(delta_output, in_projected, L->dn_norm_scales, Hv, Dv, value_dim, conv_dim, total_proj_dim,
+                                L->dn_norm_epsilon, batch);
+    }
+    free(in_projected);
+    uint16_t* projected = linear(&L->dn_out_proj, delta_output, batch);
+    free(delta_output);
+    return projected;
+}
+
+uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t count, uint16_t* logits_out) {
+    const uzu_model_desc* D = &m->desc;
+    const uint32_t d = D->model_dim;
+    if (count == 0 || count > ATTENTION_SUFFIX_CAPACITY) {
+        fprintf(stderr, "oracle: forward chunk must be 1..1024 tokens\n");
+        abort();
+    }
+    /* Embedding::encode_lookup (embedding.rs:345-372) */
+    uint16_t* hidden = (uint16_t*)xcalloc((size_t)count * d, 2);
+    if (D->embedding.method == UZU_QUANT_NONE)
+        orc_full_precision_embedding_lookup(token_ids, D->embedding.weights, hidden, ORC_BF16, count, D->vocab_size, d,
+                                            D->input_scale);
+    else
+        orc_quantized_embedding_lookup(token_ids, (const uint8_t*)D->embedding.weights, D->embedding.scales,
+                                       D->embedding.zero_points, D->embedding.biases, hidden, ORC_BF16, count,
+                                       D->vocab_size, d, D->input_scale, D->embedding.group_size, D->embedding.bits,
+                                       D->embedding.method);
+    uint16_t* shortcut = (uint16_t*)xcalloc((size_t)count * d, 2);
+    /* host RoPE tables for this pass (transformer.rs:247-254) */
+    float *cosines = NULL, *sines = NULL;
+    if (D->rope.kind != UZU_ROPE_NONE) {
+        uint32_t* pos = (uint32_t*)xcalloc(count, 4);
+        for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + i;
+        cosines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
+        sines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
+        orc_rope_tables(&D->rope, pos, count, cosines, sines);
+        free(pos);
+    }
+    m->last_rows = count;
+    for (uint32_t l = 0; l < D->num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        uint16_t* h;
+        if (L->pre_mixer_norm.present) {
+            h = norm(&L->pre_mixer_norm, hidden, shortcut, l > 0 ? 2 : 1, count, d);
+            free(hidden);
+        } else {
+            memcpy(shortcut, hidden, (size_t)count * d * 2);
+            h = hidden;
+        }
+        uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines)
+                                                               : delta_net_mixer(m, l, h, count);
+        free(h);
+        if (L->post_mixer_norm.present) {
+            uint16_t* t = norm(&L->post_mixer_norm, mixed, NULL, 0, count, d);
+            free(mixed);
+            mixed = t;
+        }
+        uint16_t* mlp_in = norm(&L->pre_mlp_norm, mixed, shortcut, 2, count, d);
+        free(mixed);
+        /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
+        uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
+        free(mlp_in);
+        uint16_t* gated = (uint16_t*)xcalloc((size_t)count * L->hidden_dim, 2);
+        orc_gated_act_mul(fused_up, NULL, gated, ORC_BF16, L->hidden_dim, count, 0, 0, L->activation, 1);
+        free(fused_up);
+        uint16_t* down = linear(&L->down_projection, gated, count);
+        free(gated);
+        if (L->post_mlp_norm.present) {
+            uint16_t* t = norm(&L->post_mlp_norm, down, NULL, 0, count, d);
+            free(down);
+            down = t;
+        }
+        hidden = down;
+        free(m->layer_outputs[l]);
+        m->layer_outputs[l] = (uint16_t*)xcalloc((size_t)count * d, 2);
+        memcpy(m->layer_outputs[l], hidden, (size_t)count * d * 2);
+    }
+    free(cosines);
+    free(sines);
+    /* output_norm over the last row only, shortcut add (transformer.rs:317-323) */
+    const size_t last = (size_t)(count - 1) * d;
+    uint16_t* normed = norm(&D->output_norm, hidden + last, shortcut + last, 2, 1, d);
+    memcpy(m->final_hidden, normed, (size_t)d * 2);
+    free(hidden);
+    free(shortcut);
+    /* readout (embedding.rs:374-456) */
+    const uzu_linear_desc* ro = D->tied_embeddings ? &D->embedding : &D->output_embedding;
+    uint16_t* logits = linear(ro, normed, 1);
+    free(normed);
+    if (D->logit_scale != 1.0f || D->logit_soft_cap != 0.0f)
+        orc_logit_transform(logits, ORC_BF16, D->vocab_size, D->logit_scale, D->logit_soft_cap, D->logit_soft_cap != 0.0f);
+    uint32_t token = 0;
+    orc_argmax(logits, ORC_BF16, &token, D->vocab_size, 1);
+    if (logits_out) memcpy(logits_out, logits, (size_t)D->vocab_size * 2);
+    free(logits);
+    /* encode_accept: flat full accept on a Full cache */
+    for (uint32_t l = 0; l < D->num_layers; ++l)
+        if (m->layers[l].mixer_kind == UZU_MIXER_ATTENTION) m->states[l].length += count;
+    m->context_length += count;
+    return token;
+}

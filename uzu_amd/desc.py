@@ -1,0 +1,267 @@
+"""ctypes mirror of ``include/uzu_model_desc.h`` plus NumPy-backed builders.
+
+The structs here are byte-for-byte the C structs; `ModelBundle` keeps every NumPy array alive
+for as long as the descriptor is in use (the C side only borrows the host pointers).
+
+Reference schema these fields come from: crates/backend-uzu/src/config/** (decoder.rs,
+transformer_layer.rs, token_mixer/{attention,delta_net}.rs, normalization.rs, rope/*.rs,
+weight_matrix/*.rs) and the tensor layouts in encodable_block/weight_matrix.rs:101-162.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+# enums (uzu_model_desc.h)
+QUANT_SCALE_BIAS, QUANT_SCALE_ZERO_POINT, QUANT_SCALE_SYMMETRIC, QUANT_NONE = 0, 1, 2, 3
+ACT_SILU, ACT_GELU_APPROX, ACT_GELU_EXACT, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+MIXER_ATTENTION, MIXER_DELTA_NET = 0, 1
+ROPE_NONE, ROPE_UNSCALED, ROPE_LLAMA, ROPE_LINEAR = 0, 1, 2, 3
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("k", C.c_uint32), ("bits", C.c_uint32), ("group_size", C.c_uint32),
+        ("method", C.c_uint32), ("reserved", C.c_uint32),
+        ("weights", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p),
+        ("zero_points", C.c_void_p), ("out_biases", C.c_void_p),
+    ]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [
+        ("present", C.c_uint32), ("full_layer", C.c_uint32), ("subtract_mean", C.c_uint32), ("reserved", C.c_uint32),
+        ("epsilon", C.c_float), ("scale_offset", C.c_float),
+        ("scales", C.c_void_p), ("biases", C.c_void_p),
+    ]
+
+
+class RopeDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32), ("head_dim", C.c_uint32), ("max_sequence_length", C.c_uint32),
+        ("original_context_length", C.c_uint32),
+        ("base", C.c_float), ("scaling_factor", C.c_float), ("low_frequency_factor", C.c_float),
+        ("high_frequency_factor", C.c_float),
+    ]
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [
+        ("mixer_kind", C.c_uint32), ("hidden_dim", C.c_uint32), ("activation", C.c_uint32), ("reserved", C.c_uint32),
+        ("pre_mixer_norm", NormDesc), ("post_mixer_norm", NormDesc), ("pre_mlp_norm", NormDesc),
+        ("post_mlp_norm", NormDesc),
+        ("num_heads", C.c_uint32), ("num_groups", C.c_uint32), ("head_dim", C.c_uint32), ("has_gate", C.c_uint32),
+        ("attention_scale", C.c_float), ("use_rope", C.c_uint32),
+        ("qkv_projection", LinearDesc), ("gate_projection", LinearDesc), ("out_projection", LinearDesc),
+        ("query_norm", NormDesc), ("key_norm", NormDesc),
+        ("dn_num_heads", C.c_uint32), ("dn_num_groups", C.c_uint32), ("dn_head_dim", C.c_uint32),
+        ("dn_value_head_dim", C.c_uint32), ("dn_kernel_size", C.c_uint32), ("dn_norm_epsilon", C.c_float),
+        ("dn_in_proj", LinearDesc), ("dn_out_proj", LinearDesc),
+        ("dn_conv_weights", C.c_void_p), ("dn_conv_biases", C.c_void_p), ("dn_a_log", C.c_void_p),
+        ("dn_dt_bias", C.c_void_p), ("dn_norm_scales", C.c_void_p),
+        ("up_projection", LinearDesc), ("down_projection", LinearDesc),
+    ]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_uint32), ("model_dim", C.c_uint32), ("num_layers", C.c_uint32),
+        ("tied_embeddings", C.c_uint32),
+        ("input_scale", C.c_float), ("logit_scale", C.c_float), ("logit_soft_cap", C.c_float),
+        ("max_context_length", C.c_uint32),
+        ("rope", RopeDesc),
+        ("embedding", LinearDesc), ("output_embedding", LinearDesc),
+        ("output_norm", NormDesc),
+        ("layers", C.POINTER(LayerDesc)),
+    ]
+
+
+def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+@dataclass
+class LinearWeights:
+    """One WeightMatrix (+ optional Linear biases) as NumPy arrays in the reference's layout."""
+    n: int
+    k: int
+    bits: int                 # 4 / 8 / 16
+    group_size: int
+    method: int               # QUANT_*
+    weights: np.ndarray       # u8 [n, k*bits/8]  or uint16(bf16) [n,k]
+    scales: Optional[np.ndarray] = None       # uint16 (bf16 bits) [n, groups]
+    biases: Optional[np.ndarray] = None       # uint16 [n, groups]
+    zero_points: Optional[np.ndarray] = None  # u8
+    out_biases: Optional[np.ndarray] = None   # uint16 [n]
+
+    def desc(self) -> LinearDesc:
+        return LinearDesc(self.n, self.k, self.bits, self.group_size, self.method, 0, _ptr(self.weights),
+                          _ptr(self.scales), _ptr(self.biases), _ptr(self.zero_points), _ptr(self.out_biases))
+
+    def nbytes(self) -> int:
+        return sum(a.nbytes for a in (self.weights, self.scales, self.biases, self.zero_points, self.out_biases)
+                   if a is not None)
+
+    def rows(self, lo: int, hi: int) -> "LinearWeights":
+        """Column-parallel shard: output rows [lo, hi) (any split is layout-safe, groups run along k)."""
+        sl = slice(lo, hi)
+        cp = lambda a: None if a is None else np.ascontiguousarray(a[sl])
+        return LinearWeights(hi - lo, self.k, self.bits, self.group_size, self.method, cp(self.weights),
+                             cp(self.scales), cp(self.biases), cp(self.zero_points), cp(self.out_biases))
+
+
+@dataclass
+class NormWeights:
+    present: bool = True
+    full_layer: bool = False
+    subtract_mean: bool = False
+    epsilon: float = 1e-6
+    scale_offset: float = 0.0
+    scales: Optional[np.ndarray] = None  # f32 [dim]
+    biases: Optional[np.ndarray] = None
+
+    def desc(self) -> NormDesc:
+        return NormDesc(int(self.present), int(self.full_layer), int(self.subtract_mean), 0, self.epsilon,
+                        self.scale_offset, _ptr(self.scales), _ptr(self.biases))
+
+
+ABSENT_NORM = NormWeights(present=False)
+
+
+@dataclass
+class LayerWeights:
+    mixer_kind: int
+    hidden_dim: int
+    activation: int
+    pre_mixer_norm: NormWeights
+    pre_mlp_norm: NormWeights
+    up_projection: LinearWeights
+    down_projection: LinearWeights
+    post_mixer_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    post_mlp_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    # attention
+    num_heads: int = 0
+    num_groups: int = 0
+    head_dim: int = 0
+    has_gate: bool = False
+    attention_scale: float = 0.0
+    use_rope: bool = False
+    qkv_projection: Optional[LinearWeights] = None
+    gate_projection: Optional[LinearWeights] = None
+    out_projection: Optional[LinearWeights] = None
+    query_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    key_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    # delta net
+    dn_num_heads: int = 0
+    dn_num_groups: int = 0
+    dn_head_dim: int = 0
+    dn_value_head_dim: int = 0
+    dn_kernel_size: int = 0
+    dn_norm_epsilon: float = 1e-6
+    dn_in_proj: Optional[LinearWeights] = None
+    dn_out_proj: Optional[LinearWeights] = None
+    dn_conv_weights: Optional[np.ndarray] = None
+    dn_conv_biases: Optional[np.ndarray] = None
+    dn_a_log: Optional[np.ndarray] = None
+    dn_dt_bias: Optional[np.ndarray] = None
+    dn_norm_scales: Optional[np.ndarray] = None
+
+    def desc(self) -> LayerDesc:
+        empty = LinearDesc()
+        ld = lambda w: w.desc() if w is not None else empty
+        return LayerDesc(
+            self.mixer_kind, self.hidden_dim, self.activation, 0,
+            self.pre_mixer_norm.desc(), self.post_mixer_norm.desc(), self.pre_mlp_norm.desc(),
+            self.post_mlp_norm.desc(),
+            self.num_heads, self.num_groups, self.head_dim, int(self.has_gate), self.attention_scale,
+            int(self.use_rope),
+            ld(self.qkv_projection), ld(self.gate_projection), ld(self.out_projection),
+            self.query_norm.desc(), self.key_norm.desc(),
+            self.dn_num_heads, self.dn_num_groups, self.dn_head_dim, self.dn_value_head_dim, self.dn_kernel_size,
+            self.dn_norm_epsilon,
+            ld(self.dn_in_proj), ld(self.dn_out_proj),
+            _ptr(self.dn_conv_weights), _ptr(self.dn_conv_biases), _ptr(self.dn_a_log), _ptr(self.dn_dt_bias),
+            _ptr(self.dn_norm_scales),
+            ld(self.up_projection), ld(self.down_projection),
+        )
+
+    def linears(self):
+        names = ("qkv_projection", "gate_projection", "out_projection", "dn_in_proj", "dn_out_proj", "up_projection",
+                 "down_projection")
+        return [(n, getattr(self, n)) for n in names if getattr(self, n) is not None]
+
+
+@dataclass
+class RopeConfig:
+    kind: int = ROPE_NONE
+    head_dim: int = 0
+    max_sequence_length: int = 0
+    base: float = 10000.0
+    scaling_factor: float = 1.0
+    original_context_length: int = 0
+    low_frequency_factor: float = 1.0
+    high_frequency_factor: float = 1.0
+
+    def desc(self) -> RopeDesc:
+        return RopeDesc(self.kind, self.head_dim, self.max_sequence_length, self.original_context_length, self.base,
+                        self.scaling_factor, self.low_frequency_factor, self.high_frequency_factor)
+
+
+@dataclass
+class ModelBundle:
+    """A whole model: config + weights.  `desc()` returns a ctypes ModelDesc that borrows from self."""
+    name: str
+    vocab_size: int
+    model_dim: int
+    max_context_length: int
+    rope: RopeConfig
+    embedding: LinearWeights
+    output_norm: NormWeights
+    layers: List[LayerWeights]
+    tied_embeddings: bool = True
+    output_embedding: Optional[LinearWeights] = None
+    input_scale: float = 1.0
+    logit_scale: float = 1.0
+    logit_soft_cap: float = 0.0
+    _keep: list = field(default_factory=list, repr=False)
+
+    def desc(self) -> ModelDesc:
+        arr = (LayerDesc * len(self.layers))(*[l.desc() for l in self.layers])
+        self._keep.append(arr)
+        out_emb = self.output_embedding.desc() if self.output_embedding is not None else LinearDesc()
+        return ModelDesc(self.vocab_size, self.model_dim, len(self.layers), int(self.tied_embeddings),
+                         self.input_scale, self.logit_scale, self.logit_soft_cap, self.max_context_length,
+                         self.rope.desc(), self.embedding.desc(), out_emb, self.output_norm.desc(),
+                         C.cast(arr, C.POINTER(LayerDesc)))
+
+    # ---- algorithmic bytes per decoded token (SURVEY.md §8d formula) ----
+    def weight_stream_bytes(self) -> int:
+        total = 0
+        for l in self.layers:
+            for _, w in l.linears():
+                total += w.nbytes()
+        readout = self.embedding if self.tied_embeddings else self.output_embedding
+        total += readout.nbytes()
+        return total
+
+    def state_bytes_per_token(self, context: int) -> int:
+        total = 0
+        for l in self.layers:
+            if l.mixer_kind == MIXER_ATTENTION:
+                total += 2 * context * l.num_groups * l.head_dim * 2          # K and V rows, bf16
+            else:
+                total += 2 * l.dn_num_heads * l.dn_value_head_dim * l.dn_head_dim * 4  # f32 state read + write
+                conv_dim = 2 * l.dn_num_groups * l.dn_head_dim + l.dn_num_heads * l.dn_value_head_dim
+                total += 2 * conv_dim * (l.dn_kernel_size - 1) * 4            # conv state read + write
+                total += conv_dim * l.dn_kernel_size * 4                      # conv taps
+        return total
+
+    def decode_bytes_per_token(self, context: int) -> int:
+        emb_row = self.embedding.nbytes() // self.vocab_size
+        return self.weight_stream_bytes() + self.state_bytes_per_token(context) + emb_row

@@ -1,0 +1,233 @@
+"""Synthetic, format-exact model generator (there is no network for checkpoints).
+
+Weights are random but laid out exactly as a lalamo-exported uzu checkpoint stores them
+(encodable_block/weight_matrix.rs:101-162): packed int4/int8 codes
+``[N, K/pack]`` low-nibble-first, bf16 scales/biases ``[N, K/g]``, nibble-packed zero points,
+f32 norm scales.  Value ranges follow the reference's own test-input generators
+(crates/backend-uzu/src/tests/matmul/quant.rs:58-110), rescaled by 1/sqrt(K) so that a 24-48 layer
+stack stays inside bf16 range.
+
+Shapes: Qwen3.5-0.8B layer shapes are the reference's benchmark table
+(crates/backend-uzu/src/tests/matmul/shape.rs:82-100); layer count / vocab / conv kernel are the
+public model-card values.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field, replace
+from typing import List, Optional
+
+import numpy as np
+
+from . import desc as D
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """half::bf16::from_f32 (round to nearest even) on an array; returns uint16 bit patterns."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    rounding = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + rounding) >> np.uint32(16)).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    vocab_size: int
+    model_dim: int
+    hidden_dim: int
+    layer_kinds: List[int]                 # MIXER_* per layer
+    # attention
+    num_heads: int
+    num_groups: int
+    head_dim: int
+    has_gate: bool = False
+    qk_norm: bool = False
+    rope: D.RopeConfig = field(default_factory=D.RopeConfig)
+    # delta net
+    dn_num_heads: int = 0
+    dn_num_groups: int = 0
+    dn_head_dim: int = 128
+    dn_value_head_dim: int = 128
+    dn_kernel_size: int = 4
+    # norms
+    norm_epsilon: float = 1e-6
+    norm_scale_offset: float = 0.0
+    norm_full_layer: bool = False
+    # quantisation of every linear + embedding
+    bits: int = 4
+    group_size: int = 128
+    method: int = D.QUANT_SCALE_BIAS
+    tied_embeddings: bool = True
+    max_context_length: int = 4096
+    seed: int = 42
+    logit_row_sigma: float = 0.6   # log-normal spread of per-token readout row norms (peaked logits)
+
+    @property
+    def num_layers(self) -> int:
+        return len(self.layer_kinds)
+
+
+def qwen35_0p8b(max_context_length: int = 4096, **kw) -> ModelConfig:
+    """Qwen3.5-0.8B: 24 layers = 6 x [DeltaNet, DeltaNet, DeltaNet, gated attention]."""
+    kinds = ([D.MIXER_DELTA_NET] * 3 + [D.MIXER_ATTENTION]) * 6
+    cfg = ModelConfig(
+        name="qwen3.5-0.8b", vocab_size=248320, model_dim=1024, hidden_dim=3584, layer_kinds=kinds,
+        num_heads=8, num_groups=2, head_dim=256, has_gate=True, qk_norm=True,
+        rope=D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=64, max_sequence_length=262144, base=10000000.0),
+        dn_num_heads=16, dn_num_groups=16, dn_head_dim=128, dn_value_head_dim=128, dn_kernel_size=4,
+        norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
+        bits=4, group_size=128, method=D.QUANT_SCALE_BIAS, tied_embeddings=True,
+        max_context_length=max_context_length)
+    return replace(cfg, **kw)
+
+
+def llama3_8b(max_context_length: int = 4096, **kw) -> ModelConfig:
+    cfg = ModelConfig(
+        name="llama-3-8b", vocab_size=128256, model_dim=4096, hidden_dim=14336,
+        layer_kinds=[D.MIXER_ATTENTION] * 32, num_heads=32, num_groups=8, head_dim=128,
+        rope=D.RopeConfig(kind=D.ROPE_LLAMA, head_dim=128, max_sequence_length=131072, base=500000.0,
+                          scaling_factor=8.0, original_context_length=8192, low_frequency_factor=1.0,
+                          high_frequency_factor=4.0),
+        norm_epsilon=1e-5, norm_scale_offset=0.0, norm_full_layer=False,
+        bits=4, group_size=128, method=D.QUANT_SCALE_BIAS, tied_embeddings=False,
+        max_context_length=max_context_length)
+    return replace(cfg, **kw)
+
+
+def tiny_qwen(**kw) -> ModelConfig:
+    """Same topology as Qwen3.5 (DeltaNet x3 + gated attention with q/k norm, partial rotary) at toy size."""
+    cfg = ModelConfig(
+        name="tiny-qwen", vocab_size=2048, model_dim=256, hidden_dim=512,
+        layer_kinds=[D.MIXER_DELTA_NET, D.MIXER_DELTA_NET, D.MIXER_DELTA_NET, D.MIXER_ATTENTION],
+        num_heads=4, num_groups=2, head_dim=64, has_gate=True, qk_norm=True,
+        rope=D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=16, max_sequence_length=8192, base=10000000.0),
+        dn_num_heads=4, dn_num_groups=2, dn_head_dim=128, dn_value_head_dim=128, dn_kernel_size=4,
+        norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
+        bits=4, group_size=64, method=D.QUANT_SCALE_BIAS, tied_embeddings=True, max_context_length=2048)
+    return replace(cfg, **kw)
+
+
+def tiny_llama(**kw) -> ModelConfig:
+    cfg = ModelConfig(
+        name="tiny-llama", vocab_size=1024, model_dim=256, hidden_dim=768,
+        layer_kinds=[D.MIXER_ATTENTION] * 3, num_heads=4, num_groups=2, head_dim=64,
+        rope=D.RopeConfig(kind=D.ROPE_LLAMA, head_dim=64, max_sequence_length=8192, base=500000.0,
+                          scaling_factor=8.0, original_context_length=1024, low_frequency_factor=1.0,
+                          high_frequency_factor=4.0),
+        norm_epsilon=1e-5, bits=4, group_size=32, method=D.QUANT_SCALE_ZERO_POINT, tied_embeddings=False,
+        max_context_length=2048)
+    return replace(cfg, **kw)
+
+
+PRESETS = {"qwen3.5-0.8b": qwen35_0p8b, "llama-3-8b": llama3_8b, "tiny-qwen": tiny_qwen, "tiny-llama": tiny_llama}
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def make_linear(cfg: ModelConfig, name: str, n: int, k: int, gain: float = 1.0,
+                row_mult: Optional[np.ndarray] = None, out_bias: bool = False) -> D.LinearWeights:
+    """Random quantised [n,k] matrix whose dequantised entries have std ~= gain/sqrt(k)."""
+    rng = _rng(cfg.seed, name)
+    bits, g, method = cfg.bits, cfg.group_size, cfg.method
+    assert k % g == 0 and (k * bits) % 8 == 0
+    groups = k // g
+    if bits == 4:
+        codes = rng.integers(0, 256, size=(n, k // 2), dtype=np.uint8)
+        levels = 16
+    else:
+        codes = rng.integers(0, 256, size=(n, k), dtype=np.uint8)
+        levels = 256
+    code_std = np.sqrt((levels * levels - 1) / 12.0)
+    base = gain / (np.sqrt(k) * code_std)
+    scales = (base * rng.uniform(0.6, 1.4, size=(n, groups))).astype(np.float32)
+    if row_mult is not None:
+        scales *= row_mult.astype(np.float32)[:, None]
+    scales_b = f32_to_bf16_bits(scales)
+    biases_b = zero_points = None
+    mid = (levels - 1) / 2.0
+    if method == D.QUANT_SCALE_BIAS:
+        sf = bf16_bits_to_f32(scales_b)
+        biases = -mid * sf + rng.uniform(-0.03, 0.03, size=(n, groups)).astype(np.float32) * sf * 4.0
+        biases_b = f32_to_bf16_bits(biases)
+    elif method == D.QUANT_SCALE_ZERO_POINT:
+        if bits == 4:
+            zp = rng.integers(6, 10, size=(n, (groups + 1) // 2 * 2), dtype=np.uint8)
+            zero_points = np.ascontiguousarray((zp[:, 0::2] | (zp[:, 1::2] << 4)).astype(np.uint8))
+        else:
+            zero_points = rng.integers(120, 136, size=(n, groups), dtype=np.uint8)
+    ob = None
+    if out_bias:
+        ob = f32_to_bf16_bits(rng.uniform(-0.1, 0.1, size=(n,)).astype(np.float32))
+    return D.LinearWeights(n, k, bits, g, method, codes, scales_b, biases_b, zero_points, ob)
+
+
+def make_norm(cfg: ModelConfig, name: str, dim: int) -> D.NormWeights:
+    rng = _rng(cfg.seed, name)
+    centre = 0.0 if cfg.norm_scale_offset != 0.0 else 1.0
+    scales = (centre + rng.uniform(-0.1, 0.1, size=(dim,))).astype(np.float32)
+    return D.NormWeights(True, cfg.norm_full_layer, False, cfg.norm_epsilon, cfg.norm_scale_offset, scales, None)
+
+
+def build_model(cfg: ModelConfig) -> D.ModelBundle:
+    d = cfg.model_dim
+    rng = _rng(cfg.seed, "row_mult")
+    row_mult = np.exp(rng.normal(0.0, cfg.logit_row_sigma, size=(cfg.vocab_size,)))
+    embedding = make_linear(cfg, "embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
+    output_embedding = None
+    if not cfg.tied_embeddings:
+        output_embedding = make_linear(cfg, "output_embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
+    layers: List[D.LayerWeights] = []
+    for li, kind in enumerate(cfg.layer_kinds):
+        p = f"layers.{li}."
+        lw = D.LayerWeights(
+            mixer_kind=kind, hidden_dim=cfg.hidden_dim, activation=D.ACT_SILU,
+            pre_mixer_norm=make_norm(cfg, p + "pre_mixer_norm", d),
+            pre_mlp_norm=make_norm(cfg, p + "pre_mlp_norm", d),
+            up_projection=make_linear(cfg, p + "mlp.up_projection", 2 * cfg.hidden_dim, d, gain=1.0),
+            down_projection=make_linear(cfg, p + "mlp.down_projection", d, cfg.hidden_dim, gain=1.5),
+        )
+        if kind == D.MIXER_ATTENTION:
+            q_dim = cfg.num_heads * cfg.head_dim
+            kv_dim = cfg.num_groups * cfg.head_dim
+            lw.num_heads, lw.num_groups, lw.head_dim = cfg.num_heads, cfg.num_groups, cfg.head_dim
+            lw.has_gate = cfg.has_gate
+            lw.use_rope = cfg.rope.kind != D.ROPE_NONE
+            lw.qkv_projection = make_linear(cfg, p + "mixer.qkv_projection", q_dim + 2 * kv_dim, d, gain=1.0)
+            if cfg.has_gate:
+                lw.gate_projection = make_linear(cfg, p + "mixer.gate_projection", q_dim, d, gain=1.0)
+            lw.out_projection = make_linear(cfg, p + "mixer.out_projection", d, q_dim, gain=1.0)
+            if cfg.qk_norm:
+                lw.query_norm = make_norm(cfg, p + "mixer.query_norm", cfg.head_dim)
+                lw.key_norm = make_norm(cfg, p + "mixer.key_norm", cfg.head_dim)
+        else:
+            Hv, Hk, Dk, Dv = cfg.dn_num_heads, cfg.dn_num_groups, cfg.dn_head_dim, cfg.dn_value_head_dim
+            key_dim, value_dim = Hk * Dk, Hv * Dv
+            conv_dim = 2 * key_dim + value_dim
+            r = _rng(cfg.seed, p + "mixer.dn")
+            lw.dn_num_heads, lw.dn_num_groups, lw.dn_head_dim, lw.dn_value_head_dim = Hv, Hk, Dk, Dv
+            lw.dn_kernel_size = cfg.dn_kernel_size
+            lw.dn_norm_epsilon = cfg.norm_epsilon
+            lw.dn_in_proj = make_linear(cfg, p + "mixer.in_proj", conv_dim + value_dim + 2 * Hv, d, gain=1.0)
+            lw.dn_out_proj = make_linear(cfg, p + "mixer.out_proj", d, value_dim, gain=1.0)
+            lw.dn_conv_weights = r.uniform(-0.6, 0.6, size=(conv_dim, cfg.dn_kernel_size)).astype(np.float32)
+            lw.dn_conv_biases = None
+            lw.dn_a_log = r.uniform(-1.0, 1.0, size=(Hv,)).astype(np.float32)
+            lw.dn_dt_bias = r.uniform(-1.0, 1.0, size=(Hv,)).astype(np.float32)
+            lw.dn_norm_scales = (1.0 + r.uniform(-0.1, 0.1, size=(Dv,))).astype(np.float32)
+        layers.append(lw)
+    return D.ModelBundle(
+        name=cfg.name, vocab_size=cfg.vocab_size, model_dim=d, max_context_length=cfg.max_context_length,
+        rope=cfg.rope, embedding=embedding, output_norm=make_norm(cfg, "output_norm", d), layers=layers,
+        tied_embeddings=cfg.tied_embeddings, output_embedding=output_embedding)
+
+
+def synthetic_prompt(length: int, vocab_size: int) -> np.ndarray:
+    """token ids = (i*7919 + 13) mod vocab."""
+    i = np.arange(length, dtype=np.int64)
+    return ((i * 7919 + 13) % vocab_size).astype(np.uint32)
