@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the uzu forward path on MI355X (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[1] -- Qwen3.5-0.8B int4 (ScaleBias, group 128), batch-1 greedy decode at
+seq_len 2048 on one MI355X.  A "step" is one decoded token (one replay of the captured decode graph: 24 layers
++ readout + argmax, the sampled token chained to the next step on the device).  Synthetic, format-exact weights
+and the synthetic prompt of SURVEY.md §8d; all inputs are resident in HBM when the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (the int4 GEMV family) : algorithmic bytes / HIP-event time, vs 8 TB/s HBM
+  cpu_baseline -- the CPU oracle (port of the reference's single-threaded CPU backend) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="qwen3.5-0.8b")
+    ap.add_argument("--context", type=int, default=2048, help="context length at which the timed decode starts")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(bundle, cfg, decode_tokens):
+    """Time the CPU oracle (oracle/ = port of the reference's CPU backend, which is single-threaded by
+    construction: backends/cpu/context.rs:20-33) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    om = O.OracleModel(bundle)
+    O.set_threads(1)
+    from uzu_amd import synthetic as S
+    prompt = S.synthetic_prompt(2, cfg.vocab_size)
+    tok = om.prefill(prompt)
+    t0 = time.perf_counter()
+    for _ in range(decode_tokens):
+        tok = om.forward([tok])
+    dt = time.perf_counter() - t0
+    one = decode_tokens / dt
+    # courtesy figure: OpenMP over independent output rows (bit-identical results), all host cores
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    t0 = time.perf_counter()
+    for _ in range(decode_tokens):
+        tok = om.forward([tok])
+    allc = decode_tokens / (time.perf_counter() - t0)
+    om.close()
+    return {"value": round(one, 4), "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{decode_tokens} greedy decode tokens at context 2..{2 + decode_tokens} after a 2-token prompt, same weights, "
+                      f"1 thread (the reference CPU backend is single-threaded); weights dominate cost at this context",
+            "all_cores_value": round(allc, 4), "all_cores": cores}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from uzu_amd import synthetic as S
+    from uzu_amd.backend import Context
+    from uzu_amd.engine import MODEL_DEFAULT, MODEL_NO_GRAPH, HipModel
+
+    total_positions = args.context + args.warmup + args.steps + 8
+    cfg = S.PRESETS[args.model](max_context_length=total_positions)
+    bundle = S.build_model(cfg)
+    ctx = Context.new(local_rank)
+    model = HipModel(ctx, bundle, MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT)
+
+    # fill the context: prompt = context - warmup tokens, then `warmup` untimed decode steps reach `context`
+    prompt_len = max(args.context - args.warmup, 1)
+    prompt = S.synthetic_prompt(prompt_len, cfg.vocab_size)
+    t0 = time.perf_counter()
+    model.prefill(prompt)
+    ctx.synchronize()
+    prefill_s = time.perf_counter() - t0
+    if args.warmup:
+        model.decode(args.warmup)
+    start_ctx = model.context_length
+
+    def sync():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    sync()
+    t0 = time.perf_counter()
+    toks, gpu_ms = model.decode(args.steps)  # K graph replays, chained on the device; returns after the last one
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    end_ctx = model.context_length
+    mean_ctx = (start_ctx + end_ctx - 1) / 2.0
+
+    tokens_per_s = world * args.steps / elapsed
+    bytes_per_token = bundle.decode_bytes_per_token(int(round(mean_ctx)))
+    step_gbps = bytes_per_token * (args.steps / elapsed) / 1e9
+
+    # per-kernel roofline of the dominant kernel: one extra decode step with HIP events around every launch
+    prof = model.profile_decode_step()
+    agg = {}
+    for name, nbytes, ms in prof:
+        a = agg.setdefault(name, [0, 0, 0.0])
+        a[0] += 1
+        a[1] += nbytes
+        a[2] += ms
+    gemv = {k: v for k, v in agg.items() if k.startswith("gemv_q")}
+    dom_name = max(gemv, key=lambda k: gemv[k][2]) if gemv else max(agg, key=lambda k: agg[k][2])
+    calls, dbytes, dms = agg[dom_name]
+    achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    gemv_bytes = sum(v[1] for v in gemv.values())
+    gemv_ms = sum(v[2] for v in gemv.values())
+    roofline = {
+        "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "launches_per_step": calls, "bytes_per_launch": int(dbytes / max(calls, 1)), "avg_launch_us": round(dms * 1e3 / max(calls, 1), 3),
+        "all_gemv": {"launches_per_step": sum(v[0] for v in gemv.values()), "achieved": round(gemv_bytes / max(gemv_ms, 1e-9) / 1e6, 1),
+                     "unit": "GB/s", "sum_us": round(gemv_ms * 1e3, 1)},
+        "decode_step": {"algorithmic_bytes_per_token": int(bytes_per_token), "achieved": round(step_gbps, 1), "unit": "GB/s",
+                        "frac": round(step_gbps / HBM_PEAK_GBPS, 4), "kernels_per_step": len(prof),
+                        "sum_kernel_us": round(sum(p[2] for p in prof) * 1e3, 1)},
+        "method": "HIP events on the context stream around every kernel of one decode step (uzu_hip_model_profile_decode_step)",
+    }
+    per_kernel = {k: {"calls": v[0], "us": round(v[2] * 1e3, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+
+    result = {
+        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)",
+        "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak" if world > 1 else "weak", "vs_baseline": None, "dtype": "int4 weights x bf16 activations, f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"{cfg.name} int4 ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
+                   "prompt_tokens": prompt_len, "graph": not args.no_graph,
+                   "parallelism": "1 GPU" if world == 1 else f"{world} independent sequences (one per GPU)"},
+        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
+        "prefill_tokens_per_s": round(prompt_len / prefill_s, 1),
+        "roofline": roofline,
+        "kernel_us_per_step": per_kernel,
+        "device": ctx.device_name(),
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(bundle, cfg, args.cpu_baseline_tokens)
+    if rank == 0:
+        print(json.dumps(result))
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

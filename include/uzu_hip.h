@@ -1,0 +1,308 @@
+/*
+ * uzu_hip.h -- C ABI of the MI355X (gfx950) backend for uzu's transformer forward path.
+ *
+ * This is the drop-in boundary: every entry point replaces one item of the Rust trait surface in
+ * /root/reference/crates/backend-uzu/src/backends/common (cited per declaration as BU/...).  A Rust
+ * `backends/hip` shim implements `Backend / Context / CommandBuffer / DenseBuffer / Kernels` by
+ * forwarding to these functions (see INTEGRATION.md for the binding).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns uzu_status (0 = ok); uzu_hip_last_error() gives the thread-local message
+ *    (the reference's `Result<_, B::Error>`; kernel-argument asserts become UZU_ERR_INVALID_ARGUMENT).
+ *  - a buffer argument is the reference's `BufferArg = (buffer, byte_offset)`; `buffer == NULL`
+ *    means the `#[optional]` argument is absent.
+ *  - encode order = execution order: one in-order HIP stream per context (the reference CPU backend
+ *    runs command buffers on one worker thread, BU/../cpu/context.rs:20-33).
+ *  - element types are DataType values (uzu_dtype); the LM path uses BF16 activations, F32 norm
+ *    scales / rope tables / DeltaNet state.
+ */
+#ifndef UZU_HIP_H
+#define UZU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t uzu_status;
+enum {
+    UZU_OK = 0,
+    UZU_ERR_INVALID_ARGUMENT = 1,
+    UZU_ERR_UNSUPPORTED = 2,   /* MatmulError::Unsupported* (BU/kernel/matmul/error.rs:9-30) */
+    UZU_ERR_HIP = 3,           /* a HIP runtime call failed */
+    UZU_ERR_OUT_OF_MEMORY = 4,
+    UZU_ERR_STATE = 5          /* command-buffer typestate violated */
+};
+const char* uzu_hip_last_error(void);
+
+/* crates/backend-uzu/src/data_type.rs:5-35 (declaration order) */
+typedef enum {
+    UZU_BF16 = 0, UZU_F16 = 1, UZU_F32 = 2, UZU_F64 = 3, UZU_I4 = 4, UZU_U4 = 5, UZU_I8 = 6, UZU_U8 = 7,
+    UZU_I16 = 8, UZU_U16 = 9, UZU_I32 = 10, UZU_U32 = 11, UZU_I64 = 12, UZU_U64 = 13
+} uzu_dtype;
+/* BU/gpu_types/quantization.rs:8-15 */
+typedef enum { UZU_QMODE_U4 = 0, UZU_QMODE_I8 = 1, UZU_QMODE_U8 = 2 } uzu_quant_mode;
+
+/* Backend associated consts (BU/backend.rs:13-17) */
+#define UZU_HIP_BACKEND_NAME "hip"
+#define UZU_HIP_MIN_ALLOCATION_ALIGNMENT 256
+#define UZU_HIP_MAX_ALLOCATION_ALIGNMENT 256
+#define UZU_HIP_ALLOCATION_GRANULARITY (8u << 20)
+#define UZU_HIP_MAX_INLINE_BYTES 4096
+
+typedef struct uzu_hip_context uzu_hip_context;
+typedef struct uzu_hip_buffer uzu_hip_buffer;
+typedef struct uzu_hip_cmdbuf uzu_hip_cmdbuf;
+typedef struct uzu_hip_kernel uzu_hip_kernel;
+
+typedef struct { uzu_hip_buffer* buffer; size_t offset; } uzu_buf;
+
+/* ---------------------------------------------------------------- Context (BU/context.rs:5-48) */
+uzu_status uzu_hip_context_create(int32_t device_ordinal, uzu_hip_context** out);   /* Context::new */
+void uzu_hip_context_destroy(uzu_hip_context* ctx);
+uzu_status uzu_hip_context_peak_memory_usage(uzu_hip_context* ctx, size_t* out);   /* peak_memory_usage */
+uzu_status uzu_hip_context_device_name(uzu_hip_context* ctx, char* out, size_t cap);
+uzu_status uzu_hip_context_synchronize(uzu_hip_context* ctx);
+void* uzu_hip_context_stream(uzu_hip_context* ctx); /* hipStream_t, for interop (rocprof / RCCL) */
+
+/* ------------------------------------------- Buffer / DenseBuffer (BU/buffer/mod.rs:11-17, dense.rs:5-7)
+ * Device memory is hipMalloc'ed (never host-mapped: SURVEY.md H3).  `cpu_ptr` semantics are provided
+ * by a lazily allocated pinned host mirror plus explicit upload/download (what `Allocation::copyin /
+ * as_slice` and `ParameterLeaf::read_allocation` need, BU/allocator/allocator.rs:29-56). */
+uzu_status uzu_hip_buffer_create(uzu_hip_context* ctx, size_t size, uzu_hip_buffer** out); /* Context::create_buffer */
+void uzu_hip_buffer_destroy(uzu_hip_buffer* buf);
+uint64_t uzu_hip_buffer_gpu_ptr(const uzu_hip_buffer* buf);   /* Buffer::gpu_ptr */
+size_t uzu_hip_buffer_size(const uzu_hip_buffer* buf);        /* Buffer::size */
+uzu_status uzu_hip_buffer_cpu_ptr(uzu_hip_buffer* buf, void** out);  /* DenseBuffer::cpu_ptr (pinned mirror) */
+uzu_status uzu_hip_buffer_flush_to_device(uzu_hip_buffer* buf, size_t offset, size_t size);  /* mirror -> device */
+uzu_status uzu_hip_buffer_fetch_from_device(uzu_hip_buffer* buf, size_t offset, size_t size); /* device -> mirror (syncs) */
+uzu_status uzu_hip_buffer_upload(uzu_hip_buffer* buf, size_t offset, const void* src, size_t size);   /* stream-ordered, staged */
+uzu_status uzu_hip_buffer_download(uzu_hip_buffer* buf, size_t offset, void* dst, size_t size);       /* waits for the stream */
+
+/* ------------------------------------- CommandBuffer typestate (BU/command_buffer.rs:5-125)
+ * Initial -> Encoding -> Executable -> Pending -> Completed, checked at run time.
+ * UZU_CMDBUF_GRAPH: encoded work is captured into a hipGraph at end_encoding and launched by submit
+ * (and may be re-submitted: an extension used for launch-bound decode loops); otherwise kernels are
+ * enqueued on the context stream as they are encoded and submit only records the end event. */
+enum { UZU_CMDBUF_EAGER = 0, UZU_CMDBUF_GRAPH = 1 };
+uzu_status uzu_hip_cmdbuf_create(uzu_hip_context* ctx, const char* name, uint32_t flags, uzu_hip_cmdbuf** out);
+uzu_status uzu_hip_cmdbuf_start_encoding(uzu_hip_cmdbuf* cb);
+uzu_status uzu_hip_cmdbuf_encode_copy(uzu_hip_cmdbuf* cb, uzu_buf src, uzu_buf dst, size_t size);
+uzu_status uzu_hip_cmdbuf_encode_fill(uzu_hip_cmdbuf* cb, uzu_buf dst, size_t size, uint8_t value);
+uzu_status uzu_hip_cmdbuf_encode_barrier(uzu_hip_cmdbuf* cb); /* no-op: in-order stream (as cpu/metal do) */
+uzu_status uzu_hip_cmdbuf_push_debug_group(uzu_hip_cmdbuf* cb, const char* name);
+uzu_status uzu_hip_cmdbuf_pop_debug_group(uzu_hip_cmdbuf* cb);
+uzu_status uzu_hip_cmdbuf_end_encoding(uzu_hip_cmdbuf* cb);
+uzu_status uzu_hip_cmdbuf_submit(uzu_hip_cmdbuf* cb);
+uzu_status uzu_hip_cmdbuf_wait_until_completed(uzu_hip_cmdbuf* cb);
+uzu_status uzu_hip_cmdbuf_gpu_execution_time_ns(uzu_hip_cmdbuf* cb, uint64_t* out); /* CommandBufferCompleted */
+void uzu_hip_cmdbuf_destroy(uzu_hip_cmdbuf* cb);
+
+void uzu_hip_kernel_destroy(uzu_hip_kernel* k);
+
+/* ================================================================= Kernels (BU/kernel/mod.rs:16-25)
+ * `_create` = `XxxKernel::new(context, <type params as DataType>, <#[specialize] params>)`
+ * `_encode` = `XxxKernel::encode(<args in declaration order>, encoder)`  (SURVEY.md Appendix A). */
+
+/* ---- MatmulKernel (BU/kernel/matmul/kernel.rs:12-43; arguments.rs:4-15; matmul_a.rs; matmul_b.rs; d_ops.rs) */
+typedef enum { UZU_MATMUL_B_FULL_PRECISION = 0, UZU_MATMUL_B_SCALE_BIAS = 1, UZU_MATMUL_B_SCALE_ZERO_POINT = 2,
+               UZU_MATMUL_B_SCALE_SYMMETRIC = 3 } uzu_matmul_b_kind;
+typedef struct {
+    /* MatmulA::FullPrecision { values, offset(elements) }  (Int8Symmetric: UZU_ERR_UNSUPPORTED, "next") */
+    uzu_buf a;
+    size_t a_offset_elements;
+    /* MatmulB */
+    uint32_t b_kind;          /* uzu_matmul_b_kind */
+    uzu_buf b;                /* codes [n, k/pack] or full precision */
+    uzu_buf scales;           /* weights dtype [n, ceil(k/g)] */
+    uzu_buf biases;           /* ScaleBias */
+    uzu_buf zero_points;      /* ScaleZeroPoint */
+    uint32_t mode;            /* uzu_quant_mode */
+    uint32_t group_size;
+    uint32_t signed_codes;
+    uint32_t has_b_leading_dimension, b_leading_dimension;
+    uint32_t b_transpose;
+    uzu_buf d;
+    /* MatmulDOps */
+    float ab_scale;
+    uint32_t accumulate;
+    uzu_buf bias;             /* weights dtype [n] */
+    uzu_buf rht_factors;      /* UZU_ERR_UNSUPPORTED if present ("next") */
+    uint32_t has_soft_cap;
+    float soft_cap;
+    uzu_buf gather_indices;   /* u32 [m,n] */
+    uint32_t m, n, k;
+} uzu_matmul_arguments;
+uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint32_t input_dt, uint32_t output_dt,
+                                 uzu_hip_kernel** out);
+uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* args);
+
+/* ---- Normalization (BU/../cpu/kernel/normalization/normalization.rs:7-39) */
+uzu_status uzu_hip_normalization_create(uzu_hip_context* ctx, uint32_t input_t, uint32_t affine_t, uint32_t output_t,
+                                        uint32_t accum_t, uint32_t in_place, uint32_t subtract_mean,
+                                        uint32_t full_layer, uint32_t copy_to_shortcut, uint32_t residual_add,
+                                        uint32_t use_hadamard, uint32_t scale_residual_sum, uint32_t scale_output,
+                                        uint32_t has_biases, uint32_t has_scales, uzu_hip_kernel** out);
+uzu_status uzu_hip_normalization_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf scales,
+                                        uzu_buf biases, uzu_buf output, uzu_buf shortcut, uzu_buf hadamard_factors,
+                                        uint32_t batch_size, uint32_t element_count, float epsilon,
+                                        float scale_offset, float post_layer_scalar);
+
+/* ---- QKVNorm (cpu/kernel/attention/qkv_norm.rs:7-31) */
+uzu_status uzu_hip_qkv_norm_create(uzu_hip_context* ctx, uint32_t input_t, uint32_t scale_t, uint32_t output_t,
+                                   uint32_t accum_t, uint32_t in_place, uint32_t has_scales, uzu_hip_kernel** out);
+uzu_status uzu_hip_qkv_norm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf qkv_input, uzu_buf scales,
+                                   uzu_buf qkv_output, uint32_t batch_size, uint32_t total_heads, uint32_t head_dim,
+                                   float epsilon, float scale_offset, uint32_t head_offset, uint32_t head_count,
+                                   uint32_t full_layer);
+
+/* ---- AttentionPrepare (cpu/kernel/attention/attention_prepare.rs:34-52) */
+uzu_status uzu_hip_attention_prepare_create(uzu_hip_context* ctx, uint32_t element_t, uint32_t rope_t,
+                                            uint32_t has_kv, uint32_t has_rope, uzu_hip_kernel** out);
+uzu_status uzu_hip_attention_prepare_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf qkv, uzu_buf queries,
+                                            uzu_buf keys, uzu_buf values, uzu_buf cosines, uzu_buf sines,
+                                            uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                                            uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim);
+
+/* ---- AttentionSinglePass / TwoPass1 / TwoPass2 (cpu/kernel/attention/attention_{single,two}_pass.rs)
+ * trie (speculative tree) variants: UZU_ERR_UNSUPPORTED. */
+typedef struct { uint32_t ring_offset, ring_length; } uzu_ring_params; /* BU/gpu_types/ring.rs */
+uzu_status uzu_hip_attention_single_pass_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim,
+                                                uint32_t has_sinks, uint32_t is_kv_cache_ring, uint32_t is_causal,
+                                                uint32_t is_trie, uint32_t is_sliding_window, uzu_hip_kernel** out);
+uzu_status uzu_hip_attention_single_pass_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys,
+                                                uzu_buf values, uzu_buf out, uint32_t gqa_factor,
+                                                uint32_t sequence_length, uint32_t k_head_stride,
+                                                uint32_t k_seq_stride, uint32_t v_head_stride, uint32_t v_seq_stride,
+                                                uzu_ring_params ring_params, float scale, uzu_buf trie,
+                                                uint32_t sliding_window_size, uzu_buf sinks, uint32_t num_heads,
+                                                uint32_t suffix_length);
+uzu_status uzu_hip_attention_two_pass1_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim, uint32_t has_sinks,
+                                              uint32_t is_kv_cache_ring, uint32_t is_causal, uint32_t is_trie,
+                                              uint32_t is_sliding_window, uzu_hip_kernel** out);
+uzu_status uzu_hip_attention_two_pass1_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys,
+                                              uzu_buf values, uzu_buf out_partials, uzu_buf sums, uzu_buf maxs,
+                                              uint32_t gqa_factor, uint32_t sequence_length, uint32_t k_head_stride,
+                                              uint32_t k_seq_stride, uint32_t v_head_stride, uint32_t v_seq_stride,
+                                              uzu_ring_params ring_params, float scale, uint32_t num_heads,
+                                              uint32_t suffix_length, uzu_buf trie, uint32_t sliding_window_size,
+                                              uzu_buf sinks);
+uzu_status uzu_hip_attention_two_pass2_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim,
+                                              uzu_hip_kernel** out);
+uzu_status uzu_hip_attention_two_pass2_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf partials, uzu_buf sums,
+                                              uzu_buf maxs, uzu_buf out, uint32_t num_heads, uint32_t suffix_length);
+
+/* ---- KVCacheUpdate (cpu/kernel/attention/kv_cache_update.rs:7-15); copies are inline constants */
+typedef struct { uint32_t source, destination; } uzu_kv_copy; /* BU/gpu_types/kv_cache_update.rs */
+uzu_status uzu_hip_kv_cache_update_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_kv_cache_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_place_keys,
+                                          uzu_buf in_place_values, const uzu_kv_copy* copies, uint32_t copy_count,
+                                          uint32_t element_dim);
+
+/* ---- SigmoidGate (cpu/kernel/attention/sigmoid_gate.rs:7-12) */
+uzu_status uzu_hip_sigmoid_gate_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_sigmoid_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf gate, uzu_buf output,
+                                       uint32_t total_elements);
+
+/* ---- GatedActMul (cpu/kernel/gated_act_mul/gated_act_mul.rs:13-35); ops != FullPrecision or
+ *      use_hadamard: UZU_ERR_UNSUPPORTED ("next": RHT / A8 path) */
+uzu_status uzu_hip_gated_act_mul_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t interleaved,
+                                        uint32_t use_hadamard, uint32_t activation_scale_group_size,
+                                        uint32_t sum_group_size, uzu_hip_kernel** out);
+uzu_status uzu_hip_gated_act_mul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf act_operand,
+                                        uzu_buf value_operand, uzu_buf fp_out, uzu_buf q_out, uzu_buf scales_out,
+                                        uzu_buf group_sums_out, uzu_buf hadamard_factors, uint32_t gated_dim,
+                                        uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
+                                        uint32_t act_type);
+
+/* ---- embeddings (cpu/kernel/embedding/{quant_embedding,full_precision_embedding}.rs) */
+uzu_status uzu_hip_quantized_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uint32_t group_size,
+                                                     uint32_t quantization_mode, uint32_t quantization_method,
+                                                     uint32_t use_hadamard, uzu_hip_kernel** out);
+uzu_status uzu_hip_quantized_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf token_ids,
+                                                     uzu_buf weights, uzu_buf scales, uzu_buf zero_points,
+                                                     uzu_buf biases, uzu_buf output, uzu_buf output_hadamard_factors,
+                                                     uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                                     float input_scale);
+uzu_status uzu_hip_full_precision_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_full_precision_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf token_ids,
+                                                          uzu_buf weights, uzu_buf output, uint32_t batch_size,
+                                                          uint32_t vocab_size, uint32_t model_dim, float input_scale);
+
+/* ---- LogitTransform / TensorAddBias / TensorAddScale / TensorAddSwap / TensorCopy */
+uzu_status uzu_hip_logit_transform_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_soft_cap,
+                                          uzu_hip_kernel** out);
+uzu_status uzu_hip_logit_transform_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf logits, uint32_t length,
+                                          float scale, float soft_cap);
+uzu_status uzu_hip_tensor_add_bias_create(uzu_hip_context* ctx, uint32_t t, uint32_t bias_t, uint32_t in_place,
+                                          uzu_hip_kernel** out);
+uzu_status uzu_hip_tensor_add_bias_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf bias,
+                                          uzu_buf output, uint32_t num_cols, uint32_t length);
+uzu_status uzu_hip_tensor_add_scale_create(uzu_hip_context* ctx, uint32_t t, uint32_t in_place, uzu_hip_kernel** out);
+uzu_status uzu_hip_tensor_add_scale_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf bias,
+                                           uzu_buf output, uint32_t num_cols, uint32_t length, float scale);
+uzu_status uzu_hip_tensor_add_swap_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_tensor_add_swap_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf skip, uzu_buf main_buffer,
+                                          uint32_t length);
+uzu_status uzu_hip_tensor_copy_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_tensor_copy_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf src, uzu_buf dst,
+                                      uint32_t length);
+
+/* ---- UnifiedSampling (cpu/kernel/sampling/unified_sampling.rs:13-32); greedy (argmax, ties -> lowest id)
+ *      only: stochastic / top-k / top-p / min-p / temperature / bitmask: UZU_ERR_UNSUPPORTED */
+uzu_status uzu_hip_unified_sampling_create(uzu_hip_context* ctx, uint32_t t, uint32_t is_stochastic,
+                                           uint32_t has_bitmask, uint32_t has_temperature, uint32_t has_top_k,
+                                           uint32_t has_top_p, uint32_t has_min_p, uzu_hip_kernel** out);
+uzu_status uzu_hip_unified_sampling_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf logits, uzu_buf output,
+                                           uzu_buf seeds, uzu_buf bitmask, float temperature, uint32_t top_k,
+                                           float top_p, float min_p, uint32_t vocab_size, uint32_t batch_size);
+
+/* ---- Gated DeltaNet (cpu/kernel/gdn/*.rs with the Metal buffer types, metal/kernel/gdn/update.metal:19-31) */
+uzu_status uzu_hip_delta_net_conv_update_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_bias,
+                                                uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_conv_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf conv_weight,
+                                                uzu_buf bias, uzu_buf in_out, uzu_buf state, uint32_t kernel_size,
+                                                uint32_t conv_dim, uint32_t state_stride);
+uzu_status uzu_hip_delta_net_update_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim,
+                                           uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf a_log,
+                                           uzu_buf dt_bias, uzu_buf norm_weight, uzu_buf state, uzu_buf out,
+                                           uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                           uint32_t key_dim, uint32_t value_dim, float norm_epsilon);
+uzu_status uzu_hip_conv1d_pack_create(uzu_hip_context* ctx, uint32_t state_t, uint32_t input_t, uzu_hip_kernel** out);
+uzu_status uzu_hip_conv1d_pack_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf state_in, uzu_buf x,
+                                      uzu_buf padded, uint32_t state_stride, uint32_t row_stride, uint32_t suffix_len,
+                                      uint32_t num_channels);
+uzu_status uzu_hip_delta_net_conv_scan_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_bias,
+                                              uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_conv_scan_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf conv_padded,
+                                              uzu_buf conv_weight, uzu_buf bias, uzu_buf in_proj, uzu_buf state_out,
+                                              uint32_t suffix_len, uint32_t kernel_size, uint32_t row_stride,
+                                              uint32_t state_stride, uint32_t conv_dim, uint32_t out_stride);
+uzu_status uzu_hip_delta_net_prefill_prep_create(uzu_hip_context* ctx, uint32_t t, uint32_t qk_t, uint32_t head_k_dim,
+                                                 uint32_t write_log_decay, uint32_t write_compact_v,
+                                                 uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_prefill_prep_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf a_log,
+                                                 uzu_buf dt_bias, uzu_buf q_norm_out, uzu_buf k_norm_out,
+                                                 uzu_buf compact_v_out, uzu_buf beta_out, uzu_buf decay_out,
+                                                 uint32_t num_v_heads, uint32_t num_k_heads, uint32_t key_dim,
+                                                 uint32_t value_dim, uint32_t suffix_len);
+uzu_status uzu_hip_delta_net_prefill_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim,
+                                            uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_prefill_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf q_norm, uzu_buf k_norm,
+                                            uzu_buf beta, uzu_buf decay, uzu_buf in_proj, uzu_buf state, uzu_buf out,
+                                            uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                            uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len,
+                                            uint32_t num_dv_groups);
+uzu_status uzu_hip_delta_net_norm_gate_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_norm_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_out, uzu_buf in_proj,
+                                              uzu_buf norm_weight, uint32_t num_v_heads, uint32_t head_v_dim,
+                                              uint32_t value_dim, uint32_t conv_dim, uint32_t total_proj_dim,
+                                              float norm_epsilon, uint32_t suffix_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZU_HIP_H */

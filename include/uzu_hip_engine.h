@@ -1,0 +1,74 @@
+/*
+ * uzu_hip_engine.h -- C ABI of the model driver that sits ABOVE the kernel boundary (include/uzu_hip.h).
+ *
+ * In the reference this layer is Rust and backend-generic: `Decoder::encode`
+ * (crates/backend-uzu/src/encodable_block/decoder.rs:138-203), `Transformer::encode` (transformer.rs:226-329),
+ * `TransformerLayer::encode` (transformer_layer.rs:194-238) and the prefill / chained-decode loop of
+ * `LanguageModelStream` (engine/language_model/stream/stream.rs:131-361, 363-782).  Once the Rust
+ * `backends/hip` shim exists, the reference's own engine drives the kernels and this driver is not
+ * needed for production; it exists so that parity tests and bench.py can run the full forward path
+ * today (no Rust toolchain in this environment), and it is where the MI355X-specific execution
+ * strategy lives: weights resident in HBM, one captured hipGraph per decode step, the sampled token
+ * fed to the next step on the device (the reference's `encode_copy(prev.output_tokens -> token_ids)`
+ * chaining, stream.rs:598-615), position-dependent scalars read from device memory.
+ */
+#ifndef UZU_HIP_ENGINE_H
+#define UZU_HIP_ENGINE_H
+
+#include "uzu_hip.h"
+#include "uzu_model_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uzu_hip_model uzu_hip_model;
+
+enum {
+    UZU_MODEL_DEFAULT = 0,
+    UZU_MODEL_NO_GRAPH = 1,   /* decode with plain stream launches instead of hipGraph replay */
+    UZU_MODEL_NO_FUSION = 2,  /* one kernel per reference kernel (no fused prologues / epilogues) */
+    UZU_MODEL_DEBUG_TAPS = 4  /* keep every layer's output of the last forward pass for inspection */
+};
+
+/* Uploads every tensor of `desc` into HBM (the desc's host pointers are not retained). */
+uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out);
+void uzu_hip_model_destroy(uzu_hip_model* m);
+/* LanguageModelState reset: context length 0, DeltaNet conv / SSM state zeroed. */
+uzu_status uzu_hip_model_reset(uzu_hip_model* m);
+uint32_t uzu_hip_model_context_length(const uzu_hip_model* m);
+size_t uzu_hip_model_weight_bytes(const uzu_hip_model* m);
+
+/* LanguageModelStream::new: append `count` prompt tokens in chunks of <= 1024 (stream.rs:194-195),
+ * sample greedily from the last row; the sampled token becomes the input of the next decode step. */
+uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, uint32_t count, uint32_t* first_token);
+/* `steps` chained greedy decode steps (Iterator::next x steps).  out_tokens[i] is the token sampled by step i
+ * (the input of step 0 is the token sampled by the previous prefill / decode call).  Blocks until done;
+ * gpu_ms (optional) receives the GPU time between the first and the last step measured with HIP events. */
+uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_tokens, float* gpu_ms);
+/* Asynchronous form used by bench.py: enqueue `steps` decode steps, do not wait. */
+uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps);
+uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, uint32_t count, uint32_t* out_tokens);
+/* Teacher forcing for parity tests: overwrite the next input token. */
+uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
+
+/* bf16 logits [vocab] of the last sampled row. */
+uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out);
+/* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass. */
+uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uint16_t* out, uint32_t* rows);
+/* Runs ONE decode step with plain launches and a HIP event pair around every kernel on the context stream;
+ * returns per launch: kernel label (static string), algorithmic bytes (0 where not meaningful), duration in ms.
+ * Used by bench.py for the per-kernel roofline of the dominant kernel. */
+uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity, const char** names, uint64_t* bytes, float* ms,
+                                             uint32_t* count);
+/* Diagnostic switch: route every matmul through the reference-order kernel (one thread per output, the
+ * reference CPU loop order) so that results can be compared BIT-EXACTLY with the CPU path.  Also enabled by
+ * the environment variable UZU_HIP_EXACT=1.  Slow; never used for measurements. */
+void uzu_hip_set_exact_matmul(int32_t enabled);
+/* Number of kernel launches / graph nodes of one decode step (reported by bench.py). */
+uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

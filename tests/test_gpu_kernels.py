@@ -1,0 +1,526 @@
+"""GPU parity tests, kernel level: every HIP kernel called THROUGH THE C ABI (uzu_amd.backend mirrors the
+reference's `XxxKernel::{new,encode}`) against the CPU oracle on the same seeded inputs.
+
+Pattern = the reference's own kernel tests (crates/backend-uzu/tests/unit/backends/common/kernel/**):
+procedural inputs -> CPU kernel as oracle -> compare.  Bars:
+  * element-wise kernels (rope/KV scatter, activations, gather, conv update, tensor ops, argmax, pass-2 merge):
+    BIT-EXACT;
+  * kernels with a parallel reduction (matmul, norms, attention, delta-rule): tolerance stated per test in
+    bf16 ulps -- far tighter than the reference's own CPU-vs-Metal tolerances (gemv_test.rs:149,
+    quant_dispatch_test.rs:124, attention_single_pass_test.rs:132-136), which are quoted next to each.
+  * matmul in reference-order mode (uzu_hip_set_exact_matmul): BIT-EXACT.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import bf16, f32, quant_matrix, ulp_diff_bf16
+from oracle import oracle as O
+from uzu_amd import _ffi
+from uzu_amd import backend as B
+
+pytestmark = pytest.mark.gpu
+
+
+def run(ctx, fn):
+    cb = ctx.create_command_buffer("test").start_encoding()
+    fn(cb)
+    cb.end_encoding().submit().wait_until_completed()
+    return cb
+
+
+# ------------------------------------------------------------------------------------------ matmul
+def oracle_matmul(a_bits, q, m, bias=None, ab_scale=1.0, accumulate_d=None, soft_cap=None, gather=None, n_out=None):
+    n = n_out if n_out is not None else q["n"]
+    d = np.zeros((m, n), dtype=np.uint16) if accumulate_d is None else accumulate_d.copy()
+    args = O.MatmulArgs()
+    args.a, args.a_dtype = a_bits.ctypes.data, O.BF16
+    args.b = q["weights"].ctypes.data
+    args.scales = q["scales"].ctypes.data
+    args.biases = q["biases"].ctypes.data if q["biases"] is not None else None
+    args.zero_points = q["zero_points"].ctypes.data if q["zero_points"] is not None else None
+    args.w_dtype, args.method, args.bits, args.group_size = O.BF16, q["method"], q["bits"], q["group_size"]
+    args.signed_codes = int(q.get("signed_codes", False))
+    args.b_transpose = 1
+    args.d, args.d_dtype = d.ctypes.data, O.BF16
+    args.ab_scale, args.accumulate = ab_scale, int(accumulate_d is not None)
+    args.bias = bias.ctypes.data if bias is not None else None
+    args.has_soft_cap, args.soft_cap = int(soft_cap is not None), soft_cap or 0.0
+    args.gather_indices = gather.ctypes.data if gather is not None else None
+    args.m, args.n, args.k = m, n, q["k"]
+    O.lib().orc_matmul(C.byref(args))
+    return d
+
+
+def hip_matmul(ctx, a_bits, q, m, bias=None, ab_scale=1.0, accumulate_d=None, soft_cap=None, gather=None, n_out=None):
+    n = n_out if n_out is not None else q["n"]
+    kern = B.MatmulKernel.new(ctx, B.BF16, B.BF16, B.BF16)
+    ba, bw, bs = ctx.buffer_from(a_bits), ctx.buffer_from(q["weights"]), ctx.buffer_from(q["scales"])
+    bb = ctx.buffer_from(q["biases"]) if q["biases"] is not None else None
+    bz = ctx.buffer_from(q["zero_points"]) if q["zero_points"] is not None else None
+    bd = ctx.buffer_from(accumulate_d if accumulate_d is not None else np.zeros((m, n), dtype=np.uint16))
+    bbias = ctx.buffer_from(bias) if bias is not None else None
+    bg = ctx.buffer_from(gather) if gather is not None else None
+    kind = {0: B.B_SCALE_BIAS, 1: B.B_SCALE_ZERO_POINT, 2: B.B_SCALE_SYMMETRIC}[q["method"]]
+    run(ctx, lambda cb: kern.encode(cb, a=ba, b=bw, d=bd, m=m, n=n, k=q["k"], b_kind=kind, scales=bs, biases=bb, zero_points=bz,
+                                     mode=B.QMODE_U4 if q["bits"] == 4 else B.QMODE_U8, group_size=q["group_size"],
+                                     signed_codes=q.get("signed_codes", False), ab_scale=ab_scale, accumulate=accumulate_d is not None,
+                                     bias=bbias, soft_cap=soft_cap, gather_indices=bg))
+    return bd.download(np.uint16, m * n).reshape(m, n)
+
+
+def activations(rng, m, k):
+    return bf16(rng.uniform(-1.0, 1.0, size=(m, k)))
+
+
+# Shapes: the reference's Qwen3.5-0.8B layer table (crates/backend-uzu/src/tests/matmul/shape.rs:82-100)
+QWEN_SHAPES = [(3072, 1024), (1024, 2048), (2048, 1024), (7168, 1024), (1024, 3584), (8224, 1024)]
+
+
+@pytest.mark.parametrize("n,k", QWEN_SHAPES)
+def test_gemv_int4_scale_bias_qwen_shapes(hip_ctx, n, k):
+    """int4 ScaleBias g=128, M=1 (decode GEMV).  Reference tolerance bf16 rel 0.05 / abs 0.4
+    (quant_dispatch_test.rs:124); ours: <= 1 bf16 ulp per element, >= 99% of elements bit-identical."""
+    rng = np.random.default_rng(n * 7 + k)
+    q = quant_matrix(rng, n, k, 4, 128, 0)
+    a = activations(rng, 1, k)
+    want, got = oracle_matmul(a, q, 1), hip_matmul(hip_ctx, a, q, 1)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.99
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("group_size", [32, 64, 128])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8])
+def test_gemv_quant_variants(hip_ctx, bits, method, group_size, m):
+    """bits x {ScaleBias, ScaleZeroPoint, ScaleSymmetric} x group x M<=8 (quant_dispatch_test.rs:103-168)."""
+    rng = np.random.default_rng(bits * 1000 + method * 100 + group_size + m)
+    n, k = 384, 768
+    q = quant_matrix(rng, n, k, bits, group_size, method)
+    a = activations(rng, m, k)
+    want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.98
+
+
+def test_gemv_epilogue_and_ragged(hip_ctx):
+    """ab_scale + accumulate + bias + soft-cap epilogue, N not a multiple of the tile, signed codes, gather."""
+    rng = np.random.default_rng(5)
+    n, k, m = 1000, 512, 3
+    q = quant_matrix(rng, n, k, 4, 64, 2)
+    q["signed_codes"] = True
+    a = activations(rng, m, k)
+    bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
+    d0 = bf16(rng.uniform(-1, 1, size=(m, n)))
+    want = oracle_matmul(a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    got = hip_matmul(hip_ctx, a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+    # gather (embedding.rs encode_readout_sparse): out[r][j] = dense[r][ids[r][j]]
+    ids = rng.integers(0, n, size=(m, 17)).astype(np.uint32)
+    want = oracle_matmul(a, q, m, gather=ids, n_out=17)
+    got = hip_matmul(hip_ctx, a, q, m, gather=ids, n_out=17)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+
+
+def test_matmul_reference_order_is_bit_exact(hip_ctx):
+    """With the reference-order kernel the GPU reproduces the CPU path bit for bit (any shape, incl. K % 32 != 0)."""
+    rng = np.random.default_rng(11)
+    _ffi.lib().uzu_hip_set_exact_matmul(1)
+    try:
+        for (n, k, bits, g, method, m) in [(96, 200, 8, 40, 0, 2), (130, 256, 4, 64, 1, 3), (64, 1024, 4, 128, 2, 1)]:
+            q = quant_matrix(rng, n, k, bits, g, method)
+            a = activations(rng, m, k)
+            want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+            assert np.array_equal(want, got)
+    finally:
+        _ffi.lib().uzu_hip_set_exact_matmul(0)
+
+
+def test_matmul_errors(hip_ctx):
+    """MatmulError paths become status codes (kernel/matmul/error.rs:9-30)."""
+    with pytest.raises(B.UzuHipError) as e:
+        B.MatmulKernel.new(hip_ctx, B.F16, B.BF16, B.BF16)
+    assert e.value.status == 2
+    kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
+    buf = hip_ctx.create_buffer(1024)
+    cb = hip_ctx.create_command_buffer("err").start_encoding()
+    with pytest.raises(B.UzuHipError) as e:  # quantized B without scales
+        kern.encode(cb, a=buf, b=buf, d=buf, m=1, n=4, k=32, b_kind=B.B_SCALE_BIAS, group_size=32)
+    assert e.value.status == 1
+    with pytest.raises(B.UzuHipError) as e:  # RHT epilogue: unsupported D op
+        kern.encode(cb, a=buf, b=buf, d=buf, m=1, n=4, k=32, b_kind=B.B_SCALE_SYMMETRIC, scales=buf, group_size=32, rht_factors=buf)
+    assert e.value.status == 2
+    cb.end_encoding().submit().wait_until_completed()
+    with pytest.raises(B.UzuHipError) as e:  # typestate: encode after end_encoding
+        kern.encode(cb, a=buf, b=buf, d=buf, m=1, n=4, k=32, b_kind=B.B_SCALE_SYMMETRIC, scales=buf, group_size=32)
+    assert e.value.status == 5
+
+
+# ------------------------------------------------------------------------------------------ normalization
+@pytest.mark.parametrize("full_layer", [0, 1])
+@pytest.mark.parametrize("mode", ["none", "copy", "add"])
+@pytest.mark.parametrize("dim,rows", [(1024, 1), (4096, 3), (1000, 5)])
+def test_normalization(hip_ctx, full_layer, mode, dim, rows):
+    """RMSNorm with the shortcut protocol (normalization_test.rs:87-128; reference tol 1e-2 bf16).
+    Ours: shortcut write-back bit-exact, output <= 1 bf16 ulp."""
+    rng = np.random.default_rng(dim + rows)
+    x = bf16(rng.normal(0, 1.5, size=(rows, dim)))
+    sc = bf16(rng.normal(0, 1.5, size=(rows, dim)))
+    scales = rng.uniform(-0.2, 0.2, size=(dim,)).astype(np.float32)
+    copy, add = mode != "none", mode == "add"
+    want, want_sc = np.zeros_like(x), sc.copy()
+    args = O.NormArgs(x.ctypes.data, scales.ctypes.data, None, want.ctypes.data, want_sc.ctypes.data if copy else None, O.BF16, O.F32,
+                      rows, dim, 1e-6, 1.0, 1.0, 0, full_layer, int(copy), int(add), 0, 0)
+    O.lib().orc_normalization(C.byref(args))
+    kern = B.NormalizationKernel.new(hip_ctx, B.BF16, B.F32, B.BF16, B.F32, 0, 0, full_layer, int(copy), int(add), 0, 0, 0, 0, 1)
+    bx, bs, bo, bsc = hip_ctx.buffer_from(x), hip_ctx.buffer_from(scales), hip_ctx.create_buffer(x.nbytes), hip_ctx.buffer_from(sc)
+    run(hip_ctx, lambda cb: kern.encode(bx, bs, None, bo, bsc if copy else None, None, rows, dim, 1e-6, 1.0, 1.0, cb))
+    got = bo.download(np.uint16, rows * dim).reshape(rows, dim)
+    if copy:
+        assert np.array_equal(bsc.download(np.uint16, rows * dim).reshape(rows, dim), want_sc)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+    assert (want == got).mean() >= 0.99
+
+
+def test_qkv_norm(hip_ctx):
+    """Per-head RMSNorm in place on packed QKV (qkv_norm_test.rs:52-186)."""
+    rng = np.random.default_rng(3)
+    batch, nq, nkv, hd = 3, 8, 2, 256
+    total = nq + 2 * nkv
+    qkv = bf16(rng.normal(0, 2, size=(batch, total * hd)))
+    scales = rng.uniform(-0.2, 0.2, size=(hd,)).astype(np.float32)
+    want = qkv.copy()
+    O.call("orc_qkv_norm", want, O.BF16, scales, batch, total, hd, 1e-6, 1.0, nq, nkv, 1)
+    kern = B.QKVNormKernel.new(hip_ctx, B.BF16, B.F32, B.BF16, B.F32, 1, 1)
+    b, bs = hip_ctx.buffer_from(qkv), hip_ctx.buffer_from(scales)
+    run(hip_ctx, lambda cb: kern.encode(None, bs, b, batch, total, hd, 1e-6, 1.0, nq, nkv, 1, cb))
+    got = b.download(np.uint16, qkv.size).reshape(qkv.shape)
+    assert np.array_equal(got[:, : nq * hd], qkv[:, : nq * hd])  # heads outside the range untouched
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------ bit-exact element-wise kernels
+def test_attention_prepare_bit_exact(hip_ctx):
+    """Split + half-rotation RoPE (partial rotary) + KV scatter at kv_token_offset."""
+    rng = np.random.default_rng(4)
+    batch, nq, nkv, hd, rope_dim, off, cap = 5, 8, 2, 256, 64, 7, 32
+    qkv = bf16(rng.normal(0, 1, size=(batch, (nq + 2 * nkv) * hd)))
+    cos = rng.uniform(-1, 1, size=(batch, rope_dim)).astype(np.float32)
+    sin = rng.uniform(-1, 1, size=(batch, rope_dim)).astype(np.float32)
+    wq = np.zeros((nq, batch, hd), np.uint16)
+    wk = np.full((cap, nkv * hd), 0x1234, np.uint16)
+    wv = wk.copy()
+    O.call("orc_attention_prepare", qkv, wq, wk, wv, cos, sin, nq, nkv, hd, rope_dim, off, batch, 1)
+    kern = B.AttentionPrepareKernel.new(hip_ctx, B.BF16, B.F32, 1, 1)
+    bq, bk, bv = hip_ctx.create_buffer(wq.nbytes), hip_ctx.buffer_from(np.full((cap, nkv * hd), 0x1234, np.uint16)), hip_ctx.buffer_from(np.full((cap, nkv * hd), 0x1234, np.uint16))
+    bqkv, bc, bs = hip_ctx.buffer_from(qkv), hip_ctx.buffer_from(cos), hip_ctx.buffer_from(sin)
+    run(hip_ctx, lambda cb: kern.encode(bqkv, bq, bk, bv, bc, bs, nq, nkv, hd, rope_dim, off, batch, cb))
+    assert np.array_equal(bq.download(np.uint16, wq.size).reshape(wq.shape), wq)
+    assert np.array_equal(bk.download(np.uint16, wk.size).reshape(wk.shape), wk)
+    assert np.array_equal(bv.download(np.uint16, wv.size).reshape(wv.shape), wv)
+
+
+def test_gated_act_mul_reference_kat_and_bit_exact(hip_ctx):
+    """(a) the one literal known-answer test of the reference tree (gated_act_mul_test.rs:139-160):
+    non-interleaved, IDENTITY, gate [1,2,3,4], value rows with offset 2 / stride 6 -> [10,40,150,240];
+    (b) SiLU interleaved (the MLP path) bit-exact vs the oracle on random data."""
+    gate = np.array([1, 2, 3, 4], np.float32)
+    value = np.array([0, 0, 10, 20, 30, 40, 0, 0, 50, 60, 70, 80], np.float32)
+    kern = B.GatedActMulKernel.new(hip_ctx, B.F32, 0, 0, 0, 0, 0)
+    bg, bv, bo = hip_ctx.buffer_from(gate), hip_ctx.buffer_from(value), hip_ctx.create_buffer(16)
+    run(hip_ctx, lambda cb: kern.encode(bg, bv, bo, None, None, None, None, 2, 2, 2, 6, B.IDENTITY, cb))
+    assert bo.download(np.float32, 4).tolist() == [10.0, 40.0, 150.0, 240.0]
+    rng = np.random.default_rng(6)
+    batch, h = 3, 3584
+    fused = bf16(rng.normal(0, 2, size=(batch, 2 * h)))
+    want = np.zeros((batch, h), np.uint16)
+    O.call("orc_gated_act_mul", fused, None, want, O.BF16, h, batch, 0, 0, B.SILU, 1)
+    kern = B.GatedActMulKernel.new(hip_ctx, B.BF16, 0, 1, 0, 0, 0)
+    bf, bo = hip_ctx.buffer_from(fused), hip_ctx.create_buffer(want.nbytes)
+    run(hip_ctx, lambda cb: kern.encode(bf, None, bo, None, None, None, None, h, batch, 0, 0, B.SILU, cb))
+    assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
+
+
+def test_sigmoid_gate_and_tensor_ops_bit_exact(hip_ctx):
+    rng = np.random.default_rng(8)
+    n = 5000
+    g, o = bf16(rng.normal(0, 3, size=n)), bf16(rng.normal(0, 1, size=n))
+    want = o.copy()
+    O.call("orc_sigmoid_gate", g, want, O.BF16, n)
+    kern = B.SigmoidGateKernel.new(hip_ctx, B.BF16)
+    bg, bo = hip_ctx.buffer_from(g), hip_ctx.buffer_from(o)
+    run(hip_ctx, lambda cb: kern.encode(bg, bo, n, cb))
+    assert np.array_equal(bo.download(np.uint16, n), want)
+    # TensorAddSwap / TensorAddBias / TensorAddScale / TensorCopy / LogitTransform
+    a, b = bf16(rng.normal(0, 1, size=n)), bf16(rng.normal(0, 1, size=n))
+    wa, wb = a.copy(), b.copy()
+    O.call("orc_tensor_add_swap", wa, wb, O.BF16, n)
+    ba, bb = hip_ctx.buffer_from(a), hip_ctx.buffer_from(b)
+    k1 = B.TensorAddSwapKernel.new(hip_ctx, B.BF16)
+    run(hip_ctx, lambda cb: k1.encode(ba, bb, n, cb))
+    assert np.array_equal(ba.download(np.uint16, n), wa) and np.array_equal(bb.download(np.uint16, n), wb)
+    cols = 50
+    bias = bf16(rng.normal(0, 1, size=cols))
+    want = np.zeros(n, np.uint16)
+    O.call("orc_tensor_add_bias", a, bias, want, O.BF16, O.BF16, cols, n)
+    k2 = B.TensorAddBiasKernel.new(hip_ctx, B.BF16, B.BF16, 0)
+    bi, bbias, bo = hip_ctx.buffer_from(a), hip_ctx.buffer_from(bias), hip_ctx.create_buffer(n * 2)
+    run(hip_ctx, lambda cb: k2.encode(bi, bbias, bo, cols, n, cb))
+    assert np.array_equal(bo.download(np.uint16, n), want)
+    O.call("orc_tensor_add_scale", a, bias, want, O.BF16, cols, n, 0.37)
+    k3 = B.TensorAddScaleKernel.new(hip_ctx, B.BF16, 0)
+    run(hip_ctx, lambda cb: k3.encode(bi, bbias, bo, cols, n, 0.37, cb))
+    assert np.array_equal(bo.download(np.uint16, n), want)
+    k4 = B.TensorCopyKernel.new(hip_ctx, B.BF16)
+    run(hip_ctx, lambda cb: k4.encode(bi, bo, n, cb))
+    assert np.array_equal(bo.download(np.uint16, n), a)
+    want = a.copy()
+    O.call("orc_logit_transform", want, O.BF16, n, 0.6, 0.0, 0)
+    k5 = B.LogitTransformKernel.new(hip_ctx, B.BF16, 0)
+    bl = hip_ctx.buffer_from(a)
+    run(hip_ctx, lambda cb: k5.encode(bl, n, 0.6, 0.0, cb))
+    assert np.array_equal(bl.download(np.uint16, n), want)
+
+
+@pytest.mark.parametrize("bits,method", [(4, 0), (4, 1), (4, 2), (8, 0), (8, 1)])
+def test_quantized_embedding_lookup_bit_exact(hip_ctx, bits, method):
+    """Row gather with dequant, out-of-range ids -> zeros (quant_embedding_test.rs)."""
+    rng = np.random.default_rng(9 + bits + method)
+    vocab, dim, g = 300, 256, 64
+    q = quant_matrix(rng, vocab, dim, bits, g, method, scale_mag=1.0)
+    ids = np.array([0, 299, 17, 300, 5, 4000000000], np.uint32)
+    want = np.zeros((ids.size, dim), np.uint16)
+    O.call("orc_quantized_embedding_lookup", ids, q["weights"], q["scales"], q["zero_points"], q["biases"], want, O.BF16, ids.size, vocab, dim,
+           1.5, g, bits, method)
+    kern = B.QuantizedEmbeddingLookupKernel.new(hip_ctx, B.BF16, g, B.QMODE_U4 if bits == 4 else B.QMODE_U8, method, 0)
+    bid, bw, bs = hip_ctx.buffer_from(ids), hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"])
+    bz = hip_ctx.buffer_from(q["zero_points"]) if q["zero_points"] is not None else None
+    bb = hip_ctx.buffer_from(q["biases"]) if q["biases"] is not None else None
+    bo = hip_ctx.create_buffer(want.nbytes)
+    run(hip_ctx, lambda cb: kern.encode(bid, bw, bs, bz, bb, bo, None, ids.size, vocab, dim, 1.5, cb))
+    assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
+
+
+def test_argmax_exact_with_ties(hip_ctx):
+    """Greedy UnifiedSampling: ties -> lowest index (unified_sampling.rs:90-95); vocab not a multiple of anything."""
+    rng = np.random.default_rng(10)
+    vocab, batch = 248320, 3
+    logits = bf16(rng.normal(0, 2, size=(batch, vocab)))
+    top = bf16(np.array([9.0]))[0]
+    logits[0, [100000, 777, 200001]] = top  # three-way tie -> 777
+    logits[1, vocab - 1] = top
+    logits[2, 0] = top
+    want = np.zeros(batch, np.uint32)
+    O.call("orc_argmax", logits, O.BF16, want, vocab, batch)
+    assert want.tolist() == [777, vocab - 1, 0]
+    kern = B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 0, 0, 0, 0, 0, 0)
+    bl, bo = hip_ctx.buffer_from(logits), hip_ctx.create_buffer(batch * 4)
+    run(hip_ctx, lambda cb: kern.encode(bl, bo, None, None, None, None, None, None, vocab, batch, cb))
+    assert bo.download(np.uint32, batch).tolist() == want.tolist()
+    with pytest.raises(B.UzuHipError):
+        B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 1, 0, 0, 0, 0, 0)  # stochastic: unsupported, loudly
+
+
+def test_kv_cache_update(hip_ctx):
+    rng = np.random.default_rng(12)
+    rows, dim = 40, 512
+    k, v = bf16(rng.normal(size=(rows, dim))), bf16(rng.normal(size=(rows, dim)))
+    copies = [(30, 2), (31, 3), (35, 4)]
+    wk, wv = k.copy(), v.copy()
+    arr = (O.C.c_uint32 * 6)(*[x for c in copies for x in c])
+    O.lib().orc_kv_cache_update(O.p(wk), O.p(wv), O.C.c_uint32(O.BF16), arr, O.C.c_uint32(3), O.C.c_uint32(dim))
+    kern = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16)
+    bk, bv = hip_ctx.buffer_from(k), hip_ctx.buffer_from(v)
+    run(hip_ctx, lambda cb: kern.encode(bk, bv, copies, 3, dim, cb))
+    assert np.array_equal(bk.download(np.uint16, k.size).reshape(k.shape), wk)
+    assert np.array_equal(bv.download(np.uint16, v.size).reshape(v.shape), wv)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention_case(rng, heads, kv_heads, hd, seq, suffix, cap):
+    q = bf16(rng.normal(0, 1, size=(heads, suffix, hd)))
+    k = bf16(rng.normal(0, 1, size=(cap, kv_heads * hd)))
+    v = bf16(rng.normal(0, 1, size=(cap, kv_heads * hd)))
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd,
+                        0, 0, 0, 1.0 / np.sqrt(hd), 0, 0, None, heads, suffix, 1)
+    return q, k, v, a
+
+
+@pytest.mark.parametrize("heads,kv_heads,hd", [(8, 2, 256), (32, 8, 128), (4, 4, 64), (10, 2, 128)])
+@pytest.mark.parametrize("seq,suffix", [(1, 1), (100, 1), (1024, 1), (300, 7)])
+def test_attention_single_pass(hip_ctx, heads, kv_heads, hd, seq, suffix):
+    """Reference tolerance 1e-2 (bf16) (attention_single_pass_test.rs:132-136); ours <= 2 bf16 ulps."""
+    rng = np.random.default_rng(heads * hd + seq)
+    q, k, v, a = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    kern = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 0, 0)
+    bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
+    run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, 1.0 / np.sqrt(hd),
+                                        None, None, None, heads, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+
+
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(8, 2, 256, 2048, 1), (32, 8, 128, 1500, 1), (8, 2, 256, 1100, 3), (4, 2, 64, 40, 1)])
+def test_attention_two_pass(hip_ctx, heads, kv_heads, hd, seq, suffix):
+    """Split-KV: pass 1 partials have the reference's meaning (block b = keys b, b+32, ...), pass 2 is bit-exact
+    given identical partials, end-to-end <= 2 bf16 ulps (attention_two_pass_test.rs)."""
+    rng = np.random.default_rng(seq + hd)
+    q, k, v, a = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    rows = suffix * heads
+    wp, ws, wm = np.zeros((rows, 32, hd), np.float32), np.zeros((rows, 32), np.float32), np.zeros((rows, 32), np.float32)
+    O.lib().orc_attention_two_pass1(C.byref(a), O.p(wp), O.p(ws), O.p(wm))
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.call("orc_attention_two_pass2", wp, ws, wm, want, O.BF16, hd, heads, suffix)
+    k1 = B.AttentionTwoPass1Kernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 0, 0)
+    k2 = B.AttentionTwoPass2Kernel.new(hip_ctx, B.BF16, hd)
+    bq, bk, bv = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v)
+    bp, bs, bm, bo = hip_ctx.create_buffer(wp.nbytes), hip_ctx.create_buffer(ws.nbytes), hip_ctx.create_buffer(wm.nbytes), hip_ctx.create_buffer(want.nbytes)
+
+    def enc(cb):
+        k1.encode(bq, bk, bv, bp, bs, bm, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, 1.0 / np.sqrt(hd), heads, suffix,
+                  None, None, None, cb)
+        k2.encode(bp, bs, bm, bo, heads, suffix, cb)
+    run(hip_ctx, enc)
+    gm = bm.download(np.float32, wm.size).reshape(wm.shape)
+    gs = bs.download(np.float32, ws.size).reshape(ws.shape)
+    np.testing.assert_allclose(gm, wm, rtol=1e-5, atol=1e-5)     # per-block maxima (empty blocks: -1e9 both)
+    np.testing.assert_allclose(gs, ws, rtol=1e-4, atol=1e-6)
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    assert np.abs(f32(want) - f32(got)).max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or np.abs(f32(want) - f32(got)).max() <= 2e-3
+    # pass 2 alone on the ORACLE's partials: bit-exact
+    bp2, bs2, bm2 = hip_ctx.buffer_from(wp), hip_ctx.buffer_from(ws), hip_ctx.buffer_from(wm)
+    run(hip_ctx, lambda cb: k2.encode(bp2, bs2, bm2, bo, heads, suffix, cb))
+    assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
+
+
+# ------------------------------------------------------------------------------------------ gated delta net
+def test_delta_net_conv_update_bit_exact(hip_ctx):
+    rng = np.random.default_rng(13)
+    conv_dim, ks = 6144, 4
+    w = rng.uniform(-0.6, 0.6, size=(conv_dim, ks)).astype(np.float32)
+    bias = rng.uniform(-0.1, 0.1, size=(conv_dim,)).astype(np.float32)
+    x = bf16(rng.normal(0, 1, size=(conv_dim + 40,)))
+    st = rng.normal(0, 1, size=(conv_dim, ks - 1)).astype(np.float32)
+    wx, wst = x.copy(), st.copy()
+    O.call("orc_delta_net_conv_update", w, bias, wx, wst, ks, conv_dim, ks - 1)
+    kern = B.DeltaNetConvUpdateKernel.new(hip_ctx, B.BF16, 1)
+    bw, bb, bx, bs = hip_ctx.buffer_from(w), hip_ctx.buffer_from(bias), hip_ctx.buffer_from(x), hip_ctx.buffer_from(st)
+    run(hip_ctx, lambda cb: kern.encode(bw, bb, bx, bs, ks, conv_dim, ks - 1, cb))
+    assert np.array_equal(bx.download(np.uint16, x.size), wx)
+    assert np.array_equal(bs.download(np.float32, st.size).reshape(st.shape), wst)
+
+
+def test_delta_net_update(hip_ctx):
+    """Delta-rule decode step, Qwen3.5 shape (Hv = Hk = 16, Dk = Dv = 128); gdn/delta_net_test.rs compares
+    CPU vs Metal with 1e-2-class tolerances.  Ours: state <= 1e-5 abs, output <= 2 bf16 ulps."""
+    rng = np.random.default_rng(14)
+    Hv, Hk, Dk, Dv = 16, 16, 128, 128
+    key_dim, value_dim = Hk * Dk, Hv * Dv
+    total = 2 * key_dim + 2 * value_dim + 2 * Hv
+    in_proj = bf16(rng.normal(0, 1, size=(total,)))
+    a_log, dt_bias = rng.uniform(-1, 1, Hv).astype(np.float32), rng.uniform(-1, 1, Hv).astype(np.float32)
+    nw = (1 + rng.uniform(-0.1, 0.1, Dv)).astype(np.float32)
+    state = rng.normal(0, 0.3, size=(Hv, Dv, Dk)).astype(np.float32)
+    wst, want = state.copy(), np.zeros(value_dim, np.uint16)
+    O.call("orc_delta_net_update", in_proj, a_log, dt_bias, nw, wst, want, Hv, Hk, Dk, Dv, key_dim, value_dim, 1e-6)
+    kern = B.DeltaNetUpdateKernel.new(hip_ctx, B.BF16, 128)
+    bi, ba, bd, bn, bs, bo = (hip_ctx.buffer_from(z) for z in (in_proj, a_log, dt_bias, nw, state, want))
+    run(hip_ctx, lambda cb: kern.encode(bi, ba, bd, bn, bs, bo, Hv, Hk, Dv, key_dim, value_dim, 1e-6, cb))
+    gst = bs.download(np.float32, state.size).reshape(state.shape)
+    np.testing.assert_allclose(gst, wst, rtol=1e-5, atol=1e-5)
+    got = bo.download(np.uint16, value_dim)
+    assert ulp_diff_bf16(want, got).max() <= 2.0
+
+
+def test_delta_net_prefill_path(hip_ctx):
+    """conv_pack -> conv_scan -> prefill_prep -> prefill -> norm_gate against the oracle (GQA-style Hv = 2 Hk)."""
+    rng = np.random.default_rng(15)
+    Hv, Hk, Dk, Dv, ks, T = 4, 2, 128, 128, 4, 37
+    key_dim, value_dim = Hk * Dk, Hv * Dv
+    conv_dim = 2 * key_dim + value_dim
+    total = conv_dim + value_dim + 2 * Hv
+    in_proj = bf16(rng.normal(0, 1, size=(T, total)))
+    conv_w = rng.uniform(-0.6, 0.6, size=(conv_dim, ks)).astype(np.float32)
+    conv_state = rng.normal(0, 1, size=(conv_dim, ks - 1)).astype(np.float32)
+    a_log, dt_bias = rng.uniform(-1, 1, Hv).astype(np.float32), rng.uniform(-1, 1, Hv).astype(np.float32)
+    nw = (1 + rng.uniform(-0.1, 0.1, Dv)).astype(np.float32)
+    state = rng.normal(0, 0.3, size=(Hv, Dv, Dk)).astype(np.float32)
+    # oracle
+    w_in, w_cs, w_st = in_proj.copy(), conv_state.copy(), state.copy()
+    padded = np.zeros((T + ks - 1, total), np.float32)
+    O.call("orc_conv1d_pack", w_cs, w_in, padded, ks - 1, total, T, conv_dim)
+    O.call("orc_delta_net_conv_scan", padded, conv_w, None, w_in, w_cs, T, ks, total, ks - 1, conv_dim, total)
+    qn, kn = np.zeros((T, key_dim), np.float32), np.zeros((T, key_dim), np.float32)
+    beta, decay = np.zeros((T, Hv), np.float32), np.zeros((T, Hv), np.float32)
+    O.call("orc_delta_net_prefill_prep", w_in, a_log, dt_bias, qn, kn, beta, decay, Hv, Hk, Dk, key_dim, value_dim, T)
+    w_out = np.zeros((T, value_dim), np.uint16)
+    O.call("orc_delta_net_prefill", qn, kn, beta, decay, w_in, w_st, w_out, Hv, Hk, Dk, Dv, key_dim, value_dim, T)
+    O.call("orc_delta_net_norm_gate", w_out, w_in, nw, Hv, Dv, value_dim, conv_dim, total, 1e-6, T)
+    # hip
+    k_pack = B.Conv1dPackKernel.new(hip_ctx, B.F32, B.BF16)
+    k_scan = B.DeltaNetConvScanKernel.new(hip_ctx, B.BF16, 0)
+    k_prep = B.DeltaNetPrefillPrepKernel.new(hip_ctx, B.BF16, B.F32, 128, 0, 0)
+    k_pre = B.DeltaNetPrefillKernel.new(hip_ctx, B.BF16, 128)
+    k_ng = B.DeltaNetNormGateKernel.new(hip_ctx, B.BF16)
+    b_in, b_cw, b_cs, b_al, b_dt, b_nw, b_st = (hip_ctx.buffer_from(z) for z in (in_proj, conv_w, conv_state, a_log, dt_bias, nw, state))
+    b_pad = hip_ctx.create_buffer(padded.nbytes)
+    b_qn, b_kn, b_be, b_de = (hip_ctx.create_buffer(z.nbytes) for z in (qn, kn, beta, decay))
+    b_out = hip_ctx.create_buffer(w_out.nbytes)
+
+    def enc(cb):
+        k_pack.encode(b_cs, b_in, b_pad, ks - 1, total, T, conv_dim, cb)
+        k_scan.encode(b_pad, b_cw, None, b_in, b_cs, T, ks, total, ks - 1, conv_dim, total, cb)
+        k_prep.encode(b_in, b_al, b_dt, b_qn, b_kn, None, b_be, b_de, Hv, Hk, key_dim, value_dim, T, cb)
+        k_pre.encode(b_qn, b_kn, b_be, b_de, b_in, b_st, b_out, Hv, Hk, Dv, key_dim, value_dim, T, (Dv + 15) // 16, cb)
+        k_ng.encode(b_out, b_in, b_nw, Hv, Dv, value_dim, conv_dim, total, 1e-6, T, cb)
+    run(hip_ctx, enc)
+    assert np.array_equal(b_in.download(np.uint16, in_proj.size).reshape(in_proj.shape), w_in)      # conv + SiLU: bit-exact
+    assert np.array_equal(b_cs.download(np.float32, conv_state.size).reshape(conv_state.shape), w_cs)
+    np.testing.assert_allclose(b_qn.download(np.float32, qn.size).reshape(qn.shape), qn, rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(b_be.download(np.float32, beta.size).reshape(beta.shape), beta)   # exp/log: glibc-exact
+    np.testing.assert_array_equal(b_de.download(np.float32, decay.size).reshape(decay.shape), decay)
+    np.testing.assert_allclose(b_st.download(np.float32, state.size).reshape(state.shape), w_st, rtol=1e-4, atol=1e-4)
+    got = b_out.download(np.uint16, w_out.size).reshape(w_out.shape)
+    assert np.abs(f32(got) - f32(w_out)).max() <= 2e-2 and (ulp_diff_bf16(w_out, got) <= 2).mean() > 0.99
+
+
+# ------------------------------------------------------------------------------------------ command buffer
+def test_command_buffer_typestate_copy_fill_graph(hip_ctx):
+    """CommandBuffer states, encode_copy / encode_fill, gpu_execution_time, and graph replay (re-submit)."""
+    a = np.arange(1024, dtype=np.uint8)
+    ba, bb = hip_ctx.buffer_from(a), hip_ctx.create_buffer(1024)
+    cb = hip_ctx.create_command_buffer("typestate")
+    with pytest.raises(B.UzuHipError):
+        cb.encode_fill(bb, 16, 1)  # not encoding yet
+    cb.start_encoding()
+    cb.push_debug_group("copy+fill")
+    cb.encode_copy((ba, 100), (bb, 0), 200)
+    cb.encode_fill((bb, 200), 824, 0xAB)
+    cb.pop_debug_group()
+    cb.encode_barrier()
+    with pytest.raises(B.UzuHipError):
+        cb.submit()  # not executable yet
+    cb.end_encoding().submit().wait_until_completed()
+    assert cb.gpu_execution_time() >= 0.0
+    got = bb.download(np.uint8, 1024)
+    assert np.array_equal(got[:200], a[100:300]) and (got[200:] == 0xAB).all()
+    # graph command buffer: encoded once, submitted three times
+    counter = hip_ctx.buffer_from(np.zeros(4, np.float32))
+    one = hip_ctx.buffer_from(np.ones(4, np.float32))
+    k = B.TensorAddBiasKernel.new(hip_ctx, B.F32, B.F32, 1)
+    g = hip_ctx.create_command_buffer("graph", graph=True).start_encoding()
+    k.encode(None, one, counter, 4, 4, g)
+    g.end_encoding()
+    for _ in range(3):
+        g.submit().wait_until_completed()
+    assert counter.download(np.float32, 4).tolist() == [3.0] * 4
+    assert hip_ctx.peak_memory_usage() > 0 and "gfx950" in hip_ctx.device_name()

@@ -1,0 +1,576 @@
+// capi_kernels.hip -- C-ABI `_create` / `_encode` entry points for every kernel on the forward path
+// (include/uzu_hip.h).  `_create` mirrors `XxxKernel::new` (validates the type / specialisation
+// parameters and remembers them), `_encode` mirrors `XxxKernel::encode` (argument checks that are
+// `assert!`s in the reference become UZU_ERR_INVALID_ARGUMENT) and enqueues the gfx950 kernel on the
+// command buffer's stream.
+#include "internal.h"
+#include "kernels.h"
+
+using namespace uzu;
+
+namespace {
+
+enum KernelKind : uint32_t {
+    KK_MATMUL = 1, KK_NORMALIZATION, KK_QKV_NORM, KK_ATTENTION_PREPARE, KK_ATTENTION_SINGLE_PASS, KK_ATTENTION_TWO_PASS1,
+    KK_ATTENTION_TWO_PASS2, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
+    KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
+    KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
+};
+
+bool is_float_dt(uint32_t dt) { return dt == UZU_BF16 || dt == UZU_F32; }
+
+uzu_status make_kernel(uzu_hip_context* ctx, uint32_t kind, uzu_hip_kernel** out, uzu_hip_kernel** created) {
+    if (!ctx || !out) {
+        set_error("kernel create: null argument");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    auto* k = new uzu_hip_kernel();
+    k->ctx = ctx;
+    k->kind = kind;
+    *out = k;
+    *created = k;
+    return UZU_OK;
+}
+
+uzu_status check(uzu_hip_kernel* k, uint32_t kind, uzu_hip_cmdbuf* cb) {
+    if (!k || k->kind != kind) {
+        set_error("encode: kernel handle is null or of the wrong kind");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    return cmdbuf_check_encoding(cb);
+}
+
+#define REQ_DT(dt, what) UZU_UNSUPPORTED(!is_float_dt(dt), what ": unsupported data type %u (BF16 / F32 only)", (unsigned)(dt))
+
+} // namespace
+
+namespace uzu { namespace k {
+uzu_status matmul_full_precision(hipStream_t s, const MatmulParams& p, uint32_t b_transpose, uint32_t ld);
+} }
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------- Matmul
+uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint32_t input_dt, uint32_t output_dt, uzu_hip_kernel** out) {
+    // MatmulError::UnsupportedDataType (cpu/kernel/matmul/kernel.rs:36-40; LinearMatmul allows BF16 / F32)
+    REQ_DT(weights_dt, "matmul");
+    REQ_DT(input_dt, "matmul");
+    REQ_DT(output_dt, "matmul");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_MATMUL, out, &k));
+    k->t[0] = weights_dt, k->t[1] = input_dt, k->t[2] = output_dt;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* a) {
+    UZU_PROPAGATE(check(k, KK_MATMUL, cb));
+    UZU_REQUIRE(a && a->a.buffer && a->b.buffer && a->d.buffer, "matmul: a, b and d are required");
+    UZU_UNSUPPORTED(a->rht_factors.buffer != nullptr, "matmul: output-RHT epilogue (UnsupportedDOp RHT) is not implemented on the hip path yet");
+    k::MatmulParams p{};
+    const size_t in_sz = k->t[1] == UZU_F32 ? 4 : 2;
+    p.a = (const char*)bptr(a->a) + a->a_offset_elements * in_sz;
+    p.b = bptr(a->b);
+    p.scales = bptr(a->scales);
+    p.biases = bptr(a->biases);
+    p.zero_points = (const uint8_t*)bptr(a->zero_points);
+    p.d = bptr(a->d);
+    p.bias = bptr(a->bias);
+    p.gather = (const uint32_t*)bptr(a->gather_indices);
+    p.w_dt = k->t[0], p.a_dt = k->t[1], p.d_dt = k->t[2];
+    p.b_kind = a->b_kind;
+    p.group_size = a->group_size;
+    p.signed_codes = a->signed_codes;
+    p.ab_scale = a->ab_scale;
+    p.accumulate = a->accumulate;
+    p.has_soft_cap = a->has_soft_cap;
+    p.soft_cap = a->soft_cap;
+    p.m = a->m, p.n = a->n, p.k = a->k;
+    if (a->b_kind == UZU_MATMUL_B_FULL_PRECISION) {
+        const uint32_t ld = a->has_b_leading_dimension ? a->b_leading_dimension : (a->b_transpose ? a->k : a->n);
+        return k::matmul_full_precision(cb_stream(cb), p, a->b_transpose, ld);
+    }
+    UZU_REQUIRE(a->b_transpose, "matmul: quantized B requires b_transpose (MatmulError::UnsupportedLayout)");
+    UZU_REQUIRE(a->scales.buffer, "matmul: quantized B requires scales");
+    UZU_REQUIRE(a->b_kind != UZU_MATMUL_B_SCALE_BIAS || a->biases.buffer, "matmul: ScaleBias requires biases");
+    UZU_REQUIRE(a->b_kind != UZU_MATMUL_B_SCALE_ZERO_POINT || a->zero_points.buffer, "matmul: ScaleZeroPoint requires zero_points");
+    UZU_UNSUPPORTED(a->mode == UZU_QMODE_I8, "matmul: I8 quantization mode is not a weight-matrix mode (weight_matrix.rs:60-68)");
+    p.bits = a->mode == UZU_QMODE_U4 ? 4 : 8;
+    UZU_UNSUPPORTED(a->group_size == 0, "matmul: group size must be non-zero (MatmulError::UnsupportedGroupSize)");
+    return k::matmul(cb_stream(cb), p, cb->ctx->num_cus);
+}
+
+// ------------------------------------------------------------------------------------- Normalization
+uzu_status uzu_hip_normalization_create(uzu_hip_context* ctx, uint32_t input_t, uint32_t affine_t, uint32_t output_t, uint32_t accum_t,
+                                        uint32_t in_place, uint32_t subtract_mean, uint32_t full_layer, uint32_t copy_to_shortcut,
+                                        uint32_t residual_add, uint32_t use_hadamard, uint32_t scale_residual_sum, uint32_t scale_output,
+                                        uint32_t has_biases, uint32_t has_scales, uzu_hip_kernel** out) {
+    REQ_DT(input_t, "normalization");
+    REQ_DT(affine_t, "normalization");
+    UZU_UNSUPPORTED(input_t != output_t, "normalization: InputT != OutputT is not instantiated");
+    UZU_UNSUPPORTED(accum_t != UZU_F32, "normalization: AccumT must be F32");
+    UZU_UNSUPPORTED(use_hadamard, "normalization: fused Hadamard (RHT checkpoints) is not implemented yet");
+    UZU_REQUIRE(copy_to_shortcut || !residual_add, "normalization: residual_add requires copy_to_shortcut");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_NORMALIZATION, out, &k));
+    k->t[0] = input_t, k->t[1] = affine_t;
+    const uint32_t f[] = {in_place, subtract_mean, full_layer, copy_to_shortcut, residual_add, scale_residual_sum, scale_output, has_biases, has_scales};
+    for (int i = 0; i < 9; ++i) k->f[i] = f[i];
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_normalization_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf scales, uzu_buf biases, uzu_buf output,
+                                        uzu_buf shortcut, uzu_buf hadamard_factors, uint32_t batch_size, uint32_t element_count, float epsilon,
+                                        float scale_offset, float post_layer_scalar) {
+    UZU_PROPAGATE(check(k, KK_NORMALIZATION, cb));
+    const bool in_place = k->f[0], copy_to_shortcut = k->f[3], has_biases = k->f[7], has_scales = k->f[8];
+    UZU_REQUIRE(output.buffer, "normalization: output is required");
+    UZU_REQUIRE((input.buffer == nullptr) == in_place, "normalization: input presence must equal !in_place");
+    UZU_REQUIRE((shortcut.buffer != nullptr) == copy_to_shortcut, "normalization: shortcut presence must equal copy_to_shortcut");
+    UZU_REQUIRE((biases.buffer != nullptr) == has_biases, "normalization: biases presence must equal has_biases");
+    UZU_REQUIRE((scales.buffer != nullptr) == has_scales, "normalization: scales presence must equal has_scales");
+    UZU_REQUIRE(hadamard_factors.buffer == nullptr, "normalization: hadamard_factors given but use_hadamard is false");
+    k::NormParams p{};
+    p.input = bptr(input), p.scales = bptr(scales), p.biases = bptr(biases), p.output = bptr(output), p.shortcut = bptr(shortcut);
+    p.io_dt = k->t[0], p.affine_dt = k->t[1];
+    p.batch_size = batch_size, p.element_count = element_count;
+    p.epsilon = epsilon, p.scale_offset = scale_offset, p.post_layer_scalar = post_layer_scalar;
+    p.subtract_mean = k->f[1], p.full_layer = k->f[2], p.copy_to_shortcut = k->f[3], p.residual_add = k->f[4];
+    p.scale_residual_sum = k->f[5], p.scale_output = k->f[6];
+    return k::normalization(cb_stream(cb), p);
+}
+
+// ------------------------------------------------------------------------------------- QKVNorm
+uzu_status uzu_hip_qkv_norm_create(uzu_hip_context* ctx, uint32_t input_t, uint32_t scale_t, uint32_t output_t, uint32_t accum_t,
+                                   uint32_t in_place, uint32_t has_scales, uzu_hip_kernel** out) {
+    REQ_DT(input_t, "qkv_norm");
+    UZU_UNSUPPORTED(input_t != output_t || scale_t != UZU_F32 || accum_t != UZU_F32 || !in_place,
+                    "qkv_norm: only in-place (T, F32 scales, F32 accum) is instantiated (the LM path, qkv_norm.rs:113-121)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_QKV_NORM, out, &k));
+    k->t[0] = input_t;
+    k->f[0] = has_scales;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_qkv_norm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf qkv_input, uzu_buf scales, uzu_buf qkv_output,
+                                   uint32_t batch_size, uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset,
+                                   uint32_t head_offset, uint32_t head_count, uint32_t full_layer) {
+    UZU_PROPAGATE(check(k, KK_QKV_NORM, cb));
+    UZU_REQUIRE(qkv_input.buffer == nullptr && qkv_output.buffer, "qkv_norm: in-place kernel takes qkv_output only");
+    UZU_REQUIRE((scales.buffer != nullptr) == (k->f[0] != 0), "qkv_norm: scales presence must equal has_scales");
+    UZU_REQUIRE(head_offset + head_count <= total_heads, "qkv_norm: head range exceeds total_heads");
+    return k::qkv_norm(cb_stream(cb), bptr(qkv_output), k->t[0], (const float*)bptr(scales), batch_size, total_heads, head_dim, epsilon,
+                       scale_offset, head_offset, head_count, full_layer);
+}
+
+// ------------------------------------------------------------------------------------- AttentionPrepare
+uzu_status uzu_hip_attention_prepare_create(uzu_hip_context* ctx, uint32_t element_t, uint32_t rope_t, uint32_t has_kv, uint32_t has_rope,
+                                            uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(element_t != UZU_BF16 || rope_t != UZU_F32, "attention_prepare: variants are (ElementT = BF16, RopeT = F32) only (attention_prepare.rs:31-33)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_ATTENTION_PREPARE, out, &k));
+    k->f[0] = has_kv, k->f[1] = has_rope;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_attention_prepare_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf qkv, uzu_buf queries, uzu_buf keys, uzu_buf values,
+                                            uzu_buf cosines, uzu_buf sines, uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                                            uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_PREPARE, cb));
+    const bool has_kv = k->f[0], has_rope = k->f[1];
+    UZU_REQUIRE(qkv.buffer && queries.buffer, "attention_prepare: qkv and queries are required");
+    UZU_REQUIRE(num_q_heads > 0 || has_kv, "attention prepare without KV requires at least one query head");
+    UZU_REQUIRE(head_dim > 0, "attention prepare requires nonzero head_dim");
+    UZU_REQUIRE((keys.buffer != nullptr) == has_kv && (values.buffer != nullptr) == has_kv, "attention prepare keys/values presence mismatch");
+    UZU_REQUIRE(!has_kv || num_kv_heads > 0, "attention prepare has_kv requires nonzero num_kv_heads");
+    UZU_REQUIRE((cosines.buffer != nullptr) == has_rope && (sines.buffer != nullptr) == has_rope, "attention prepare cosines/sines presence mismatch");
+    if (has_rope) {
+        UZU_REQUIRE(rope_dim > 0 && rope_dim <= head_dim && rope_dim % 2 == 0, "attention prepare: rope_dim must be even, nonzero and <= head_dim");
+    }
+    return k::attention_prepare(cb_stream(cb), (const uint16_t*)bptr(qkv), (uint16_t*)bptr(queries), (uint16_t*)bptr(keys), (uint16_t*)bptr(values),
+                                (const float*)bptr(cosines), (const float*)bptr(sines), num_q_heads, num_kv_heads, head_dim,
+                                has_rope ? rope_dim : 0, kv_token_offset, batch_dim, has_kv, nullptr);
+}
+
+// ------------------------------------------------------------------------------------- Attention cores
+static uzu_status attention_core_create(uzu_hip_context* ctx, uint32_t kind, uint32_t t, uint32_t head_dim, uint32_t has_sinks,
+                                        uint32_t is_kv_cache_ring, uint32_t is_causal, uint32_t is_trie, uint32_t is_sliding_window,
+                                        uzu_hip_kernel** out) {
+    REQ_DT(t, "attention");
+    UZU_UNSUPPORTED(!(head_dim == 64 || head_dim == 128 || head_dim == 256 || head_dim == 512), "attention: HEAD_DIM variants are 64/128/256/512");
+    UZU_UNSUPPORTED(is_trie, "attention: trie (speculative tree) masks are not implemented on the hip path");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, kind, out, &k));
+    k->t[0] = t;
+    k->f[0] = head_dim, k->f[1] = has_sinks, k->f[2] = is_kv_cache_ring, k->f[3] = is_causal, k->f[4] = is_sliding_window;
+    return UZU_OK;
+}
+
+static k::AttentionParams attention_params(uzu_hip_kernel* k, uzu_buf queries, uzu_buf keys, uzu_buf values, uint32_t gqa_factor,
+                                           uint32_t sequence_length, uint32_t k_head_stride, uint32_t k_seq_stride, uint32_t v_head_stride,
+                                           uint32_t v_seq_stride, uzu_ring_params ring, float scale, uint32_t sliding_window_size, uzu_buf sinks,
+                                           uint32_t num_heads, uint32_t suffix_length) {
+    k::AttentionParams a{};
+    a.queries = bptr(queries), a.keys = bptr(keys), a.values = bptr(values);
+    a.dt = k->t[0];
+    a.head_dim = k->f[0];
+    a.gqa_factor = gqa_factor, a.sequence_length = sequence_length;
+    a.k_head_stride = k_head_stride, a.k_seq_stride = k_seq_stride, a.v_head_stride = v_head_stride, a.v_seq_stride = v_seq_stride;
+    a.is_kv_cache_ring = k->f[2], a.ring_offset = ring.ring_offset, a.ring_length = ring.ring_length;
+    a.scale = scale;
+    a.is_sliding_window = k->f[4], a.sliding_window_size = sliding_window_size;
+    a.sinks = bptr(sinks);
+    a.num_heads = num_heads, a.suffix_length = suffix_length, a.is_causal = k->f[3];
+    a.dyn = nullptr;
+    return a;
+}
+
+uzu_status uzu_hip_attention_single_pass_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim, uint32_t has_sinks, uint32_t is_kv_cache_ring,
+                                                uint32_t is_causal, uint32_t is_trie, uint32_t is_sliding_window, uzu_hip_kernel** out) {
+    return attention_core_create(ctx, KK_ATTENTION_SINGLE_PASS, t, head_dim, has_sinks, is_kv_cache_ring, is_causal, is_trie, is_sliding_window, out);
+}
+
+uzu_status uzu_hip_attention_single_pass_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out,
+                                                uint32_t gqa_factor, uint32_t sequence_length, uint32_t k_head_stride, uint32_t k_seq_stride,
+                                                uint32_t v_head_stride, uint32_t v_seq_stride, uzu_ring_params ring_params, float scale, uzu_buf trie,
+                                                uint32_t sliding_window_size, uzu_buf sinks, uint32_t num_heads, uint32_t suffix_length) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_SINGLE_PASS, cb));
+    UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out.buffer, "attention_single_pass: queries/keys/values/out are required");
+    UZU_REQUIRE(trie.buffer == nullptr, "attention_single_pass: trie given but is_trie is false");
+    UZU_REQUIRE((sinks.buffer != nullptr) == (k->f[1] != 0), "attention_single_pass: sinks presence must equal has_sinks");
+    UZU_REQUIRE(sequence_length >= suffix_length, "attention_single_pass: sequence_length < suffix_length");
+    const k::AttentionParams a = attention_params(k, queries, keys, values, gqa_factor, sequence_length, k_head_stride, k_seq_stride, v_head_stride,
+                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length);
+    return k::attention_single_pass(cb_stream(cb), a, bptr(out));
+}
+
+uzu_status uzu_hip_attention_two_pass1_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim, uint32_t has_sinks, uint32_t is_kv_cache_ring,
+                                              uint32_t is_causal, uint32_t is_trie, uint32_t is_sliding_window, uzu_hip_kernel** out) {
+    return attention_core_create(ctx, KK_ATTENTION_TWO_PASS1, t, head_dim, has_sinks, is_kv_cache_ring, is_causal, is_trie, is_sliding_window, out);
+}
+
+uzu_status uzu_hip_attention_two_pass1_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out_partials,
+                                              uzu_buf sums, uzu_buf maxs, uint32_t gqa_factor, uint32_t sequence_length, uint32_t k_head_stride,
+                                              uint32_t k_seq_stride, uint32_t v_head_stride, uint32_t v_seq_stride, uzu_ring_params ring_params,
+                                              float scale, uint32_t num_heads, uint32_t suffix_length, uzu_buf trie, uint32_t sliding_window_size,
+                                              uzu_buf sinks) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_TWO_PASS1, cb));
+    UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out_partials.buffer && sums.buffer && maxs.buffer,
+                "attention_two_pass1: queries/keys/values/out/sums/maxs are required");
+    UZU_REQUIRE(trie.buffer == nullptr, "attention_two_pass1: trie given but is_trie is false");
+    UZU_REQUIRE((sinks.buffer != nullptr) == (k->f[1] != 0), "attention_two_pass1: sinks presence must equal has_sinks");
+    UZU_REQUIRE(sequence_length >= suffix_length, "attention_two_pass1: sequence_length < suffix_length");
+    const k::AttentionParams a = attention_params(k, queries, keys, values, gqa_factor, sequence_length, k_head_stride, k_seq_stride, v_head_stride,
+                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length);
+    return k::attention_two_pass1(cb_stream(cb), a, (float*)bptr(out_partials), (float*)bptr(sums), (float*)bptr(maxs));
+}
+
+uzu_status uzu_hip_attention_two_pass2_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim, uzu_hip_kernel** out) {
+    REQ_DT(t, "attention_two_pass2");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_ATTENTION_TWO_PASS2, out, &k));
+    k->t[0] = t;
+    k->f[0] = head_dim;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_attention_two_pass2_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf partials, uzu_buf sums, uzu_buf maxs, uzu_buf out,
+                                              uint32_t num_heads, uint32_t suffix_length) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_TWO_PASS2, cb));
+    UZU_REQUIRE(partials.buffer && sums.buffer && maxs.buffer && out.buffer, "attention_two_pass2: all buffers are required");
+    return k::attention_two_pass2(cb_stream(cb), (const float*)bptr(partials), (const float*)bptr(sums), (const float*)bptr(maxs), bptr(out), k->t[0],
+                                  k->f[0], num_heads, suffix_length);
+}
+
+// ------------------------------------------------------------------------------------- KVCacheUpdate / SigmoidGate / GatedActMul
+uzu_status uzu_hip_kv_cache_update_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_DT(t, "kv_cache_update");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_KV_CACHE_UPDATE, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_kv_cache_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_place_keys, uzu_buf in_place_values,
+                                          const uzu_kv_copy* copies, uint32_t copy_count, uint32_t element_dim) {
+    UZU_PROPAGATE(check(k, KK_KV_CACHE_UPDATE, cb));
+    UZU_REQUIRE(in_place_keys.buffer && in_place_values.buffer && (copies || !copy_count), "kv_cache_update: null argument");
+    return k::kv_cache_update(cb_stream(cb), bptr(in_place_keys), bptr(in_place_values), k->t[0], copies, copy_count, element_dim);
+}
+
+uzu_status uzu_hip_sigmoid_gate_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_DT(t, "sigmoid_gate");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_SIGMOID_GATE, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_sigmoid_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf gate, uzu_buf output, uint32_t total_elements) {
+    UZU_PROPAGATE(check(k, KK_SIGMOID_GATE, cb));
+    UZU_REQUIRE(gate.buffer && output.buffer, "sigmoid_gate: null buffer");
+    return k::sigmoid_gate(cb_stream(cb), bptr(gate), bptr(output), k->t[0], total_elements);
+}
+
+uzu_status uzu_hip_gated_act_mul_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t interleaved, uint32_t use_hadamard,
+                                        uint32_t activation_scale_group_size, uint32_t sum_group_size, uzu_hip_kernel** out) {
+    REQ_DT(t, "gated_act_mul");
+    UZU_UNSUPPORTED(ops != 0 || use_hadamard, "gated_act_mul: quantizing / RHT variants (A8 path) are not implemented on the hip path yet");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_GATED_ACT_MUL, out, &k));
+    k->t[0] = t;
+    k->f[0] = interleaved;
+    (void)activation_scale_group_size;
+    (void)sum_group_size;
+    return UZU_OK;
+}
+uzu_status uzu_hip_gated_act_mul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf act_operand, uzu_buf value_operand, uzu_buf fp_out, uzu_buf q_out,
+                                        uzu_buf scales_out, uzu_buf group_sums_out, uzu_buf hadamard_factors, uint32_t gated_dim, uint32_t batch_dim,
+                                        uint32_t value_offset, uint32_t value_row_stride, uint32_t act_type) {
+    UZU_PROPAGATE(check(k, KK_GATED_ACT_MUL, cb));
+    const bool interleaved = k->f[0];
+    UZU_REQUIRE(act_operand.buffer && fp_out.buffer, "FP gate activation requires fp_out");
+    UZU_REQUIRE((value_operand.buffer == nullptr) == interleaved, "gated_act_mul: value_operand presence must equal !interleaved");
+    UZU_REQUIRE(!q_out.buffer && !scales_out.buffer && !group_sums_out.buffer && !hadamard_factors.buffer, "gated_act_mul: quantized outputs given to the FullPrecision kernel");
+    UZU_REQUIRE(act_type <= 4, "gated_act_mul: unknown activation type %u", act_type);
+    return k::gated_act_mul(cb_stream(cb), bptr(act_operand), bptr(value_operand), bptr(fp_out), k->t[0], gated_dim, batch_dim, value_offset,
+                            value_row_stride, act_type, interleaved);
+}
+
+// ------------------------------------------------------------------------------------- Embeddings
+uzu_status uzu_hip_quantized_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uint32_t group_size, uint32_t quantization_mode,
+                                                     uint32_t quantization_method, uint32_t use_hadamard, uzu_hip_kernel** out) {
+    REQ_DT(t, "quantized_embedding_lookup");
+    UZU_UNSUPPORTED(use_hadamard, "quantized_embedding_lookup: output Hadamard is not implemented (the CPU reference rejects it too, quant_embedding.rs:32-34)");
+    UZU_UNSUPPORTED(quantization_mode == UZU_QMODE_I8, "quantized_embedding_lookup: I8 mode is not produced by weight matrices");
+    UZU_REQUIRE(group_size > 0 && quantization_method <= 2, "quantized_embedding_lookup: bad group size / method");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_QUANT_EMBEDDING, out, &k));
+    k->t[0] = t;
+    k->f[0] = group_size, k->f[1] = quantization_mode == UZU_QMODE_U4 ? 4 : 8, k->f[2] = quantization_method;
+    return UZU_OK;
+}
+uzu_status uzu_hip_quantized_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf token_ids, uzu_buf weights, uzu_buf scales,
+                                                     uzu_buf zero_points, uzu_buf biases, uzu_buf output, uzu_buf output_hadamard_factors,
+                                                     uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim, float input_scale) {
+    UZU_PROPAGATE(check(k, KK_QUANT_EMBEDDING, cb));
+    UZU_REQUIRE(token_ids.buffer && weights.buffer && scales.buffer && output.buffer, "quantized_embedding_lookup: null buffer");
+    UZU_REQUIRE((zero_points.buffer != nullptr) == (k->f[2] == 1), "ScaleZeroPoint quantized embedding requires zero_points");
+    UZU_REQUIRE((biases.buffer != nullptr) == (k->f[2] == 0), "ScaleBias quantized embedding requires biases");
+    UZU_REQUIRE(!output_hadamard_factors.buffer, "quantized_embedding_lookup: hadamard factors given but use_hadamard is false");
+    return k::quantized_embedding_lookup(cb_stream(cb), (const uint32_t*)bptr(token_ids), (const uint8_t*)bptr(weights), bptr(scales),
+                                         (const uint8_t*)bptr(zero_points), bptr(biases), bptr(output), k->t[0], batch_size, vocab_size, model_dim,
+                                         input_scale, k->f[0], k->f[1], k->f[2]);
+}
+uzu_status uzu_hip_full_precision_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_DT(t, "full_precision_embedding_lookup");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_FP_EMBEDDING, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_full_precision_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf token_ids, uzu_buf weights, uzu_buf output,
+                                                          uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim, float input_scale) {
+    UZU_PROPAGATE(check(k, KK_FP_EMBEDDING, cb));
+    UZU_REQUIRE(token_ids.buffer && weights.buffer && output.buffer, "full_precision_embedding_lookup: null buffer");
+    return k::full_precision_embedding_lookup(cb_stream(cb), (const uint32_t*)bptr(token_ids), bptr(weights), bptr(output), k->t[0], batch_size,
+                                              vocab_size, model_dim, input_scale);
+}
+
+// ------------------------------------------------------------------------------------- LogitTransform / Tensor*
+uzu_status uzu_hip_logit_transform_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_soft_cap, uzu_hip_kernel** out) {
+    REQ_DT(t, "logit_transform");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_LOGIT_TRANSFORM, out, &k));
+    k->t[0] = t, k->f[0] = has_soft_cap;
+    return UZU_OK;
+}
+uzu_status uzu_hip_logit_transform_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf logits, uint32_t length, float scale, float soft_cap) {
+    UZU_PROPAGATE(check(k, KK_LOGIT_TRANSFORM, cb));
+    UZU_REQUIRE(logits.buffer, "logit_transform: null buffer");
+    return k::logit_transform(cb_stream(cb), bptr(logits), k->t[0], length, scale, soft_cap, k->f[0]);
+}
+uzu_status uzu_hip_tensor_add_bias_create(uzu_hip_context* ctx, uint32_t t, uint32_t bias_t, uint32_t in_place, uzu_hip_kernel** out) {
+    REQ_DT(t, "tensor_add_bias");
+    REQ_DT(bias_t, "tensor_add_bias");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_TENSOR_ADD_BIAS, out, &k));
+    k->t[0] = t, k->t[1] = bias_t, k->f[0] = in_place;
+    return UZU_OK;
+}
+uzu_status uzu_hip_tensor_add_bias_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf bias, uzu_buf output, uint32_t num_cols, uint32_t length) {
+    UZU_PROPAGATE(check(k, KK_TENSOR_ADD_BIAS, cb));
+    UZU_REQUIRE((input.buffer == nullptr) == (k->f[0] != 0), "tensor_add_bias: input presence must equal !in_place");
+    UZU_REQUIRE(bias.buffer && output.buffer && num_cols, "tensor_add_bias: null argument");
+    return k::tensor_add_bias(cb_stream(cb), bptr(input), bptr(bias), bptr(output), k->t[0], k->t[1], num_cols, length);
+}
+uzu_status uzu_hip_tensor_add_scale_create(uzu_hip_context* ctx, uint32_t t, uint32_t in_place, uzu_hip_kernel** out) {
+    REQ_DT(t, "tensor_add_scale");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_TENSOR_ADD_SCALE, out, &k));
+    k->t[0] = t, k->f[0] = in_place;
+    return UZU_OK;
+}
+uzu_status uzu_hip_tensor_add_scale_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf bias, uzu_buf output, uint32_t num_cols,
+                                           uint32_t length, float scale) {
+    UZU_PROPAGATE(check(k, KK_TENSOR_ADD_SCALE, cb));
+    UZU_REQUIRE(bias.buffer && output.buffer && num_cols, "tensor_add_scale: null argument");
+    return k::tensor_add_scale(cb_stream(cb), bptr(input), bptr(bias), bptr(output), k->t[0], num_cols, length, scale);
+}
+uzu_status uzu_hip_tensor_add_swap_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_DT(t, "tensor_add_swap");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_TENSOR_ADD_SWAP, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_tensor_add_swap_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf skip, uzu_buf main_buffer, uint32_t length) {
+    UZU_PROPAGATE(check(k, KK_TENSOR_ADD_SWAP, cb));
+    UZU_REQUIRE(skip.buffer && main_buffer.buffer, "tensor_add_swap: null buffer");
+    return k::tensor_add_swap(cb_stream(cb), bptr(skip), bptr(main_buffer), k->t[0], length);
+}
+uzu_status uzu_hip_tensor_copy_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_DT(t, "tensor_copy");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_TENSOR_COPY, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_tensor_copy_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf src, uzu_buf dst, uint32_t length) {
+    UZU_PROPAGATE(check(k, KK_TENSOR_COPY, cb));
+    UZU_REQUIRE(src.buffer && dst.buffer, "tensor_copy: null buffer");
+    return k::tensor_copy(cb_stream(cb), bptr(src), bptr(dst), k->t[0], length);
+}
+
+// ------------------------------------------------------------------------------------- UnifiedSampling (greedy)
+uzu_status uzu_hip_unified_sampling_create(uzu_hip_context* ctx, uint32_t t, uint32_t is_stochastic, uint32_t has_bitmask, uint32_t has_temperature,
+                                           uint32_t has_top_k, uint32_t has_top_p, uint32_t has_min_p, uzu_hip_kernel** out) {
+    REQ_DT(t, "unified_sampling");
+    UZU_UNSUPPORTED(is_stochastic || has_bitmask || has_temperature || has_top_k || has_top_p || has_min_p,
+                    "unified_sampling: only greedy (argmax) sampling is implemented on the hip path");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_UNIFIED_SAMPLING, out, &k));
+    k->t[0] = t;
+    return UZU_OK;
+}
+uzu_status uzu_hip_unified_sampling_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf logits, uzu_buf output, uzu_buf seeds, uzu_buf bitmask,
+                                           float temperature, uint32_t top_k, float top_p, float min_p, uint32_t vocab_size, uint32_t batch_size) {
+    UZU_PROPAGATE(check(k, KK_UNIFIED_SAMPLING, cb));
+    UZU_REQUIRE(logits.buffer && output.buffer && !seeds.buffer && !bitmask.buffer, "unified_sampling: greedy kernel takes logits and output only");
+    (void)temperature, (void)top_k, (void)top_p, (void)min_p;
+    // scratch for the two-level reduction: a transient device allocation freed in stream order
+    void* scratch = nullptr;
+    UZU_HIP_TRY(hipMallocAsync(&scratch, k::argmax_scratch_bytes(batch_size), cb_stream(cb)));
+    uzu_status st = k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    UZU_HIP_TRY(hipFreeAsync(scratch, cb_stream(cb)));
+    return st;
+}
+
+// ------------------------------------------------------------------------------------- Gated DeltaNet
+uzu_status uzu_hip_delta_net_conv_update_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_bias, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16, "delta_net_conv_update: only T = BF16 is instantiated (LanguageModel data type)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_DN_CONV_UPDATE, out, &k));
+    k->f[0] = has_bias;
+    return UZU_OK;
+}
+uzu_status uzu_hip_delta_net_conv_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf conv_weight, uzu_buf bias, uzu_buf in_out, uzu_buf state,
+                                                uint32_t kernel_size, uint32_t conv_dim, uint32_t state_stride) {
+    UZU_PROPAGATE(check(k, KK_DN_CONV_UPDATE, cb));
+    UZU_REQUIRE(conv_weight.buffer && in_out.buffer && state.buffer, "delta_net_conv_update: null buffer");
+    UZU_REQUIRE((bias.buffer != nullptr) == (k->f[0] != 0), "delta_net_conv_update: bias presence must equal has_bias");
+    UZU_REQUIRE(kernel_size >= 2, "delta_net_conv_update: kernel_size must be >= 2");
+    return k::delta_net_conv_update(cb_stream(cb), (const float*)bptr(conv_weight), (const float*)bptr(bias), (uint16_t*)bptr(in_out),
+                                    (float*)bptr(state), kernel_size, conv_dim, state_stride);
+}
+uzu_status uzu_hip_delta_net_update_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16 || head_k_dim != 128, "delta_net_update: variants are (T = BF16, HEAD_K_DIM = 128)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_DN_UPDATE, out, &k));
+    k->f[0] = head_k_dim;
+    return UZU_OK;
+}
+uzu_status uzu_hip_delta_net_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf a_log, uzu_buf dt_bias, uzu_buf norm_weight,
+                                           uzu_buf state, uzu_buf out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                           uint32_t key_dim, uint32_t value_dim, float norm_epsilon) {
+    UZU_PROPAGATE(check(k, KK_DN_UPDATE, cb));
+    UZU_REQUIRE(in_proj.buffer && a_log.buffer && dt_bias.buffer && norm_weight.buffer && state.buffer && out.buffer, "delta_net_update: null buffer");
+    return k::delta_net_update(cb_stream(cb), (const uint16_t*)bptr(in_proj), (const float*)bptr(a_log), (const float*)bptr(dt_bias),
+                               (const float*)bptr(norm_weight), (float*)bptr(state), (uint16_t*)bptr(out), num_v_heads, num_k_heads, k->f[0], head_v_dim,
+                               key_dim, value_dim, norm_epsilon);
+}
+uzu_status uzu_hip_conv1d_pack_create(uzu_hip_context* ctx, uint32_t state_t, uint32_t input_t, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(state_t != UZU_F32 || input_t != UZU_BF16, "conv1d_pack: only (StateT = F32, InputT = BF16) is instantiated (delta_net.rs:216-217)");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_CONV1D_PACK, out, &k);
+}
+uzu_status uzu_hip_conv1d_pack_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf state_in, uzu_buf x, uzu_buf padded, uint32_t state_stride,
+                                      uint32_t row_stride, uint32_t suffix_len, uint32_t num_channels) {
+    UZU_PROPAGATE(check(k, KK_CONV1D_PACK, cb));
+    UZU_REQUIRE(state_in.buffer && x.buffer && padded.buffer, "conv1d_pack: null buffer");
+    return k::conv1d_pack(cb_stream(cb), (const float*)bptr(state_in), (const uint16_t*)bptr(x), (float*)bptr(padded), state_stride, row_stride,
+                          suffix_len, num_channels);
+}
+uzu_status uzu_hip_delta_net_conv_scan_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_bias, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16, "delta_net_conv_scan: only T = BF16 is instantiated");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_DN_CONV_SCAN, out, &k));
+    k->f[0] = has_bias;
+    return UZU_OK;
+}
+uzu_status uzu_hip_delta_net_conv_scan_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf conv_padded, uzu_buf conv_weight, uzu_buf bias,
+                                              uzu_buf in_proj, uzu_buf state_out, uint32_t suffix_len, uint32_t kernel_size, uint32_t row_stride,
+                                              uint32_t state_stride, uint32_t conv_dim, uint32_t out_stride) {
+    UZU_PROPAGATE(check(k, KK_DN_CONV_SCAN, cb));
+    UZU_REQUIRE(conv_padded.buffer && conv_weight.buffer && in_proj.buffer && state_out.buffer, "delta_net_conv_scan: null buffer");
+    UZU_REQUIRE((bias.buffer != nullptr) == (k->f[0] != 0), "delta_net_conv_scan: bias presence must equal has_bias");
+    return k::delta_net_conv_scan(cb_stream(cb), (const float*)bptr(conv_padded), (const float*)bptr(conv_weight), (const float*)bptr(bias),
+                                  (uint16_t*)bptr(in_proj), (float*)bptr(state_out), suffix_len, kernel_size, row_stride, state_stride, conv_dim,
+                                  out_stride);
+}
+uzu_status uzu_hip_delta_net_prefill_prep_create(uzu_hip_context* ctx, uint32_t t, uint32_t qk_t, uint32_t head_k_dim, uint32_t write_log_decay,
+                                                 uint32_t write_compact_v, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16 || qk_t != UZU_F32 || head_k_dim != 128 || write_log_decay || write_compact_v,
+                    "delta_net_prefill_prep: only the flat-prefill variant (T = BF16, QKT = F32, decay, no compact V) is implemented");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_DN_PREFILL_PREP, out, &k);
+}
+uzu_status uzu_hip_delta_net_prefill_prep_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf a_log, uzu_buf dt_bias, uzu_buf q_norm_out,
+                                                 uzu_buf k_norm_out, uzu_buf compact_v_out, uzu_buf beta_out, uzu_buf decay_out, uint32_t num_v_heads,
+                                                 uint32_t num_k_heads, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
+    UZU_PROPAGATE(check(k, KK_DN_PREFILL_PREP, cb));
+    UZU_REQUIRE(in_proj.buffer && a_log.buffer && dt_bias.buffer && q_norm_out.buffer && k_norm_out.buffer && beta_out.buffer && decay_out.buffer,
+                "delta_net_prefill_prep: null buffer");
+    UZU_REQUIRE(!compact_v_out.buffer, "compact V output presence mismatch");
+    return k::delta_net_prefill_prep(cb_stream(cb), (const uint16_t*)bptr(in_proj), (const float*)bptr(a_log), (const float*)bptr(dt_bias),
+                                     (float*)bptr(q_norm_out), (float*)bptr(k_norm_out), (float*)bptr(beta_out), (float*)bptr(decay_out), num_v_heads,
+                                     num_k_heads, 128, key_dim, value_dim, suffix_len);
+}
+uzu_status uzu_hip_delta_net_prefill_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16 || head_k_dim != 128, "delta_net_prefill: variants are (T = BF16, HEAD_K_DIM = 128)");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_DN_PREFILL, out, &k);
+}
+uzu_status uzu_hip_delta_net_prefill_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf q_norm, uzu_buf k_norm, uzu_buf beta, uzu_buf decay,
+                                            uzu_buf in_proj, uzu_buf state, uzu_buf out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                            uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len, uint32_t num_dv_groups) {
+    UZU_PROPAGATE(check(k, KK_DN_PREFILL, cb));
+    UZU_REQUIRE(q_norm.buffer && k_norm.buffer && beta.buffer && decay.buffer && in_proj.buffer && state.buffer && out.buffer, "delta_net_prefill: null buffer");
+    (void)num_dv_groups;
+    return k::delta_net_prefill(cb_stream(cb), (const float*)bptr(q_norm), (const float*)bptr(k_norm), (const float*)bptr(beta), (const float*)bptr(decay),
+                                (const uint16_t*)bptr(in_proj), (float*)bptr(state), (uint16_t*)bptr(out), num_v_heads, num_k_heads, 128, head_v_dim,
+                                key_dim, value_dim, suffix_len);
+}
+uzu_status uzu_hip_delta_net_norm_gate_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16, "delta_net_norm_gate: only T = BF16 is instantiated");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_DN_NORM_GATE, out, &k);
+}
+uzu_status uzu_hip_delta_net_norm_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_out, uzu_buf in_proj, uzu_buf norm_weight,
+                                              uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim, uint32_t total_proj_dim,
+                                              float norm_epsilon, uint32_t suffix_len) {
+    UZU_PROPAGATE(check(k, KK_DN_NORM_GATE, cb));
+    UZU_REQUIRE(in_out.buffer && in_proj.buffer && norm_weight.buffer, "delta_net_norm_gate: null buffer");
+    return k::delta_net_norm_gate(cb_stream(cb), (uint16_t*)bptr(in_out), (const uint16_t*)bptr(in_proj), (const float*)bptr(norm_weight), num_v_heads,
+                                  head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
+}
+
+} // extern "C"

@@ -1,0 +1,83 @@
+// device_utils.h -- gfx950 device-side helpers: typed load/store, wave64 and workgroup reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "internal.h"
+#include "uzu_math.h"
+
+namespace uzu {
+
+struct bf16_t {
+    uint16_t v;
+};
+
+template <class T> __device__ __forceinline__ float ld(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i].v); }
+template <> __device__ __forceinline__ float ld<float>(const float* p, size_t i) { return p[i]; }
+
+template <class T> __device__ __forceinline__ void st(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, size_t i, float v) { p[i].v = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void st<float>(float* p, size_t i, float v) { p[i] = v; }
+
+// value of `T::from(x)` kept in an f32 register
+template <class T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return round_bf16(v); }
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+
+constexpr int kWave = 64; // CDNA wavefront
+
+// butterfly sum over the `width` (power of two <= 64) consecutive lanes that contain this lane
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ float group_sum_rt(float v, int width) {
+    for (int off = width / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// workgroup sum (blockDim.x multiple of 64, <= 1024); `red` = 16 floats of LDS; result broadcast
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads(); // protect `red` from a previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i]; // fixed order => deterministic
+    return t;
+}
+
+template <class F> uzu_status launch_check(F&& f, const char* what) {
+    f();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
+
+#define UZU_DISPATCH_T(dt, ...)                                   \
+    [&]() -> uzu_status {                                          \
+        if ((dt) == UZU_BF16) {                                    \
+            using T = ::uzu::bf16_t;                               \
+            return __VA_ARGS__();                                  \
+        } else if ((dt) == UZU_F32) {                              \
+            using T = float;                                       \
+            return __VA_ARGS__();                                  \
+        }                                                          \
+        ::uzu::set_error("unsupported data type %u", (unsigned)(dt)); \
+        return UZU_ERR_UNSUPPORTED;                                \
+    }()
+
+} // namespace uzu

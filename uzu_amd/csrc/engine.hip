@@ -1,0 +1,700 @@
+// engine.hip -- model driver above the kernel boundary (include/uzu_hip_engine.h).
+//
+// Restates, for one sequence, the op order of the reference's backend-generic graph code:
+//   Decoder::encode            BU/../encodable_block/decoder.rs:138-203
+//   Transformer::encode        BU/../encodable_block/transformer.rs:226-329
+//   TransformerLayer::encode   BU/../encodable_block/transformer_layer.rs:194-238
+//   Attention::attend          BU/../encodable_block/mixer/attention/mode.rs:45-144
+//   AttentionCores::encode     BU/../encodable_block/mixer/attention/core/mod.rs:81-93
+//   DeltaNet::encode           BU/../encodable_block/mixer/delta_net.rs:473-645
+//   DenseMlp::encode           BU/../encodable_block/mlp/dense.rs:32-48
+//   Embedding::encode_readout  BU/../encodable_block/embedding.rs:374-456
+//   LanguageModelStream        BU/../engine/language_model/stream/stream.rs:190-345 (prefill), 593-751 (decode)
+// MI355X execution strategy: weights, KV cache and DeltaNet state resident in HBM; the context length,
+// the next input token and the sampled-token history live in device memory, so ONE captured hipGraph is
+// replayed for every decode step and steps are chained without a host round trip.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/uzu_hip_engine.h"
+#include "internal.h"
+#include "kernels.h"
+
+using namespace uzu;
+
+namespace {
+
+constexpr uint32_t kSuffixCapacity = 1024; // ATTENTION_SUFFIX_CAPACITY, mixer/attention/state.rs:14
+
+struct DLinear {
+    uint32_t n = 0, k = 0, bits = 0, group = 0, method = UZU_QUANT_NONE;
+    void* w = nullptr;
+    void* scales = nullptr;
+    void* biases = nullptr;
+    uint8_t* zp = nullptr;
+    void* out_biases = nullptr;
+};
+struct DNorm {
+    bool present = false;
+    uint32_t full_layer = 0, subtract_mean = 0;
+    float eps = 0.f, offset = 0.f;
+    float* scales = nullptr;
+    float* biases = nullptr;
+};
+struct DLayer {
+    uzu_layer_desc d; // scalars only (pointers are host pointers: never dereferenced after create)
+    DNorm pre_mixer, post_mixer, pre_mlp, post_mlp, qn, kn;
+    DLinear qkv, gate, out, in_proj, out_proj, up, down;
+    float *conv_w = nullptr, *conv_b = nullptr, *a_log = nullptr, *dt_bias = nullptr, *dn_norm = nullptr;
+    uint16_t *keys = nullptr, *values = nullptr;
+    float *conv_state = nullptr, *ssm_state = nullptr;
+    size_t conv_state_bytes = 0, ssm_state_bytes = 0;
+};
+
+} // namespace
+
+struct uzu_hip_model {
+    uzu_hip_context* ctx = nullptr;
+    uint32_t flags = 0;
+    uzu_model_desc d; // scalars only
+    std::vector<DLayer> layers;
+    DLinear embedding, output_embedding;
+    DNorm output_norm;
+    std::vector<void*> allocations;
+    size_t weight_bytes = 0;
+
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    // device-resident sequence state
+    uint32_t* d_ctx_len = nullptr;  // current context length
+    uint32_t* d_tokens = nullptr;   // [1024] input token ids of the pass
+    uint32_t* d_out_token = nullptr;
+    uint32_t* d_sampled = nullptr;  // [max positions] token sampled from the row at absolute position p
+    uint32_t context_length = 0;    // host mirror of *d_ctx_len
+    uint32_t max_positions = 0;
+
+    // scratch (sized for one 1024-token chunk)
+    uint16_t *hidden = nullptr, *normed = nullptr, *mixed = nullptr, *shortcut = nullptr;
+    uint16_t *qkv = nullptr, *gate = nullptr, *queries = nullptr, *attn_out = nullptr;
+    uint16_t *up = nullptr, *gated = nullptr;
+    uint16_t *in_proj = nullptr, *delta_out = nullptr;
+    float *padded = nullptr, *qn = nullptr, *kn = nullptr, *beta = nullptr, *decay = nullptr;
+    float *partials = nullptr, *sums = nullptr, *maxs = nullptr;
+    uint32_t partial_rows = 0;
+    uint16_t *last_normed = nullptr, *logits = nullptr;
+    void* argmax_scratch = nullptr;
+    uint16_t* taps = nullptr; // [layers][1024][d]
+    uint32_t tap_rows = 0;
+
+    hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t launches = 0; // kernel launches of the last encoded forward
+    void* prof_sink = nullptr; // std::vector<ProfEntry>* while profiling one step
+    int regime_override = -1; // graph capture: 0 = single-pass attention, 1 = two-pass (else decided by context_length)
+};
+
+namespace {
+
+#define HIPCHK(expr) UZU_HIP_TRY(expr)
+
+uzu_status dev_alloc(uzu_hip_model* m, size_t bytes, void** out, bool zero = false) {
+    void* p = nullptr;
+    const size_t alloc = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+    hipError_t e = hipMalloc(&p, alloc);
+    if (e != hipSuccess) {
+        set_error("engine: hipMalloc(%zu) failed: %s", alloc, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
+    }
+    m->allocations.push_back(p);
+    m->ctx->current_bytes += alloc;
+    if (m->ctx->current_bytes > m->ctx->peak_bytes) m->ctx->peak_bytes = m->ctx->current_bytes;
+    if (zero) HIPCHK(hipMemset(p, 0, alloc));
+    *out = p;
+    return UZU_OK;
+}
+
+template <class T> uzu_status upload(uzu_hip_model* m, const void* host, size_t bytes, T** out) {
+    if (!host) {
+        *out = nullptr;
+        return UZU_OK;
+    }
+    void* p;
+    UZU_PROPAGATE(dev_alloc(m, bytes, &p));
+    HIPCHK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    m->weight_bytes += bytes;
+    *out = (T*)p;
+    return UZU_OK;
+}
+
+uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o) {
+    o->n = h.n, o->k = h.k, o->bits = h.bits, o->group = h.group_size, o->method = h.method;
+    if (!h.weights) return UZU_OK;
+    if (h.method == UZU_QUANT_NONE) {
+        UZU_PROPAGATE(upload(m, h.weights, (size_t)h.n * h.k * 2, &o->w));
+    } else {
+        UZU_REQUIRE(h.bits == 4 || h.bits == 8, "engine: linear with %u-bit codes", h.bits);
+        UZU_REQUIRE(h.group_size > 0, "engine: quantized linear with group_size 0");
+        const size_t groups = (h.k + h.group_size - 1) / h.group_size;
+        UZU_PROPAGATE(upload(m, h.weights, (size_t)h.n * h.k * h.bits / 8, &o->w));
+        UZU_PROPAGATE(upload(m, h.scales, (size_t)h.n * groups * 2, &o->scales));
+        if (h.method == UZU_QUANT_SCALE_BIAS) UZU_PROPAGATE(upload(m, h.biases, (size_t)h.n * groups * 2, &o->biases));
+        if (h.method == UZU_QUANT_SCALE_ZERO_POINT)
+            UZU_PROPAGATE(upload(m, h.zero_points, (size_t)h.n * (h.bits == 4 ? (groups + 1) / 2 : groups), &o->zp));
+    }
+    UZU_PROPAGATE(upload(m, h.out_biases, (size_t)h.n * 2, &o->out_biases));
+    return UZU_OK;
+}
+
+uzu_status upload_norm(uzu_hip_model* m, const uzu_norm_desc& h, uint32_t dim, DNorm* o) {
+    o->present = h.present != 0;
+    o->full_layer = h.full_layer, o->subtract_mean = h.subtract_mean, o->eps = h.epsilon, o->offset = h.scale_offset;
+    if (!o->present) return UZU_OK;
+    UZU_PROPAGATE(upload(m, h.scales, (size_t)dim * 4, &o->scales));
+    UZU_PROPAGATE(upload(m, h.biases, (size_t)dim * 4, &o->biases));
+    return UZU_OK;
+}
+
+// host RoPE table: encodable_block/mixer/attention/rope.rs:13-114 (Unscaled / Linear / Llama-3), computed
+// with the platform libm exactly as the reference does per pass, but once for all positions.
+void rope_tables(const uzu_rope_desc& r, uint32_t n_pos, std::vector<float>& cosines, std::vector<float>& sines) {
+    const uint32_t head_dim = r.head_dim, half_dim = head_dim / 2;
+    cosines.assign((size_t)n_pos * head_dim, 0.f);
+    sines.assign((size_t)n_pos * head_dim, 0.f);
+    for (uint32_t pair_index = 0; pair_index < half_dim; ++pair_index) {
+        const uint32_t channel_index = pair_index * 2;
+        float inverse_frequency = 1.0f / powf(r.base, (float)channel_index / (float)head_dim);
+        if (r.kind == UZU_ROPE_LINEAR) {
+            inverse_frequency = inverse_frequency / r.scaling_factor;
+        } else if (r.kind == UZU_ROPE_LLAMA) {
+            const float low_frequency_wavelength = (float)r.original_context_length / r.low_frequency_factor;
+            const float high_frequency_wavelength = (float)r.original_context_length / r.high_frequency_factor;
+            const float wavelength = 2.0f * 3.14159265358979323846f / inverse_frequency;
+            const float scaled_frequency = inverse_frequency / r.scaling_factor;
+            if (wavelength < high_frequency_wavelength) {
+            } else if (wavelength > low_frequency_wavelength) {
+                inverse_frequency = scaled_frequency;
+            } else {
+                float smoothing_factor = (float)r.original_context_length / wavelength - r.low_frequency_factor;
+                smoothing_factor = smoothing_factor / (r.high_frequency_factor - r.low_frequency_factor);
+                inverse_frequency = smoothing_factor * inverse_frequency + (1.0f - smoothing_factor) * scaled_frequency;
+            }
+        }
+        for (uint32_t pos = 0; pos < n_pos; ++pos) {
+            const float embedding = (float)pos * inverse_frequency;
+            const float sine = sinf(embedding), cosine = cosf(embedding);
+            const size_t o = (size_t)pos * head_dim + pair_index;
+            sines[o] = sine, sines[o + half_dim] = sine, cosines[o] = cosine, cosines[o + half_dim] = cosine;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- encoding helpers
+struct ProfEntry {
+    const char* name;
+    size_t bytes;
+    hipEvent_t e0, e1;
+};
+struct Enc {
+    uzu_hip_model* m;
+    hipStream_t s;
+    uzu_status st = UZU_OK;
+    std::vector<ProfEntry>* prof = nullptr;
+    hipEvent_t pending = nullptr;
+    // begin(): called before a launch when profiling; run(): after it
+    void begin() {
+        if (!prof) return;
+        (void)hipEventCreate(&pending);
+        (void)hipEventRecord(pending, s);
+    }
+    void run(uzu_status r, const char* name = "other", size_t bytes = 0) {
+        if (st == UZU_OK) st = r;
+        ++m->launches;
+        if (prof && pending) {
+            hipEvent_t e1;
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e1, s);
+            prof->push_back({name, bytes, pending, e1});
+            pending = nullptr;
+        }
+    }
+};
+
+#define RUN(name, bytes, expr) do { e.begin(); e.run((expr), name, bytes); } while (0)
+
+void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch) {
+    k::MatmulParams p{};
+    p.a = input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = output, p.bias = L.out_biases;
+    p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    p.b_kind = L.method == UZU_QUANT_NONE ? UZU_MATMUL_B_FULL_PRECISION
+             : L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS
+             : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+    p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f;
+    p.m = batch, p.n = L.n, p.k = L.k;
+    const char* variant = "matmul";
+    e.begin();
+    const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
+    e.run(r, variant, k::matmul_algorithmic_bytes(p));
+}
+
+// mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
+void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim) {
+    k::NormParams p{};
+    p.input = input, p.scales = N.scales, p.biases = N.biases, p.output = output, p.shortcut = mode ? shortcut : nullptr;
+    p.io_dt = UZU_BF16, p.affine_dt = UZU_F32;
+    p.batch_size = rows, p.element_count = dim;
+    p.epsilon = N.eps, p.scale_offset = N.offset, p.post_layer_scalar = 1.0f;
+    p.subtract_mean = N.subtract_mean, p.full_layer = N.full_layer;
+    p.copy_to_shortcut = mode != 0, p.residual_add = mode == 2;
+    RUN("normalization", 0, k::normalization(e.s, p));
+}
+
+uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
+    if (rows <= m->partial_rows) return UZU_OK;
+    void* p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)rows * 32 * head_dim * 4, &p));
+    m->partials = (float*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)rows * 32 * 4, &p));
+    m->sums = (float*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)rows * 32 * 4, &p));
+    m->maxs = (float*)p;
+    m->partial_rows = rows;
+    return UZU_OK;
+}
+
+void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, uint32_t batch) {
+    uzu_hip_model* m = e.m;
+    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
+    if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, batch);
+    linear(e, L.qkv, hidden, m->qkv, batch);
+    if (L.qn.present)
+        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, batch, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
+    if (L.kn.present)
+        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.kn.scales, batch, total_heads, hd, L.kn.eps, L.kn.offset, nq, nkv, L.kn.full_layer));
+    const uint32_t rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
+    RUN("attention_prepare", 0, k::attention_prepare(e.s, m->qkv, m->queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, 0, batch, 1,
+                               m->d_ctx_len));
+    k::AttentionParams a{};
+    a.queries = m->queries, a.keys = L.keys, a.values = L.values;
+    a.dt = UZU_BF16, a.head_dim = hd, a.gqa_factor = nq / nkv;
+    a.sequence_length = batch; // + *d_ctx_len on the device
+    a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;
+    a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
+    a.num_heads = nq, a.suffix_length = batch, a.is_causal = 1;
+    a.dyn = m->d_ctx_len;
+    const size_t kv_bytes = (size_t)2 * (m->context_length + batch) * nkv * hd * 2; // K and V rows read once
+    const bool two_pass = m->regime_override >= 0 ? m->regime_override == 1 : m->context_length + batch > 1024;
+    if (two_pass) { // core/mod.rs:89-92
+        RUN("attention_two_pass1", kv_bytes, k::attention_two_pass1(e.s, a, m->partials, m->sums, m->maxs));
+        RUN("attention_two_pass2", 0, k::attention_two_pass2(e.s, m->partials, m->sums, m->maxs, m->attn_out, UZU_BF16, hd, nq, batch));
+    } else {
+        RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, m->attn_out));
+    }
+    if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, batch * nq * hd));
+    linear(e, L.out, m->attn_out, out, batch);
+}
+
+void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, uint32_t batch) {
+    uzu_hip_model* m = e.m;
+    const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
+    const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
+    const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv, ks = L.d.dn_kernel_size;
+    linear(e, L.in_proj, hidden, m->in_proj, batch);
+    if (batch == 1) {
+        RUN("delta_net_conv_update", 0, k::delta_net_conv_update(e.s, L.conv_w, L.conv_b, m->in_proj, L.conv_state, ks, conv_dim, ks - 1));
+        RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, m->in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
+                                  L.d.dn_norm_epsilon));
+    } else {
+        RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, m->in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
+        RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, m->in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
+                                     total_proj_dim));
+        RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, m->in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
+        RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
+        RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
+    }
+    linear(e, L.out_proj, m->delta_out, out, batch);
+}
+
+__global__ void commit_kernel(uint32_t* ctx_len, uint32_t* tokens, const uint32_t* out_token, uint32_t* sampled, uint32_t count, uint32_t has_token) {
+    const uint32_t len = *ctx_len;
+    if (has_token) {
+        const uint32_t t = *out_token;
+        sampled[len + count - 1] = t;
+        tokens[0] = t;
+    }
+    *ctx_len = len + count;
+}
+
+// One forward pass over `count` tokens already in m->d_tokens; `sample` => output norm + readout + argmax.
+uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool sample) {
+    Enc e{m, s};
+    e.prof = (std::vector<ProfEntry>*)m->prof_sink;
+    m->launches = 0;
+    const uint32_t d = m->d.model_dim;
+    uint16_t* hidden = m->hidden;
+    if (m->embedding.method == UZU_QUANT_NONE)
+        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, m->d_tokens, m->embedding.w, hidden, UZU_BF16, count, m->d.vocab_size, d, m->d.input_scale));
+    else
+        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, m->d_tokens, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
+                                            hidden, UZU_BF16, count, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits,
+                                            m->embedding.method));
+    for (uint32_t l = 0; l < m->d.num_layers; ++l) {
+        DLayer& L = m->layers[l];
+        const uint16_t* h = hidden;
+        if (L.pre_mixer.present) {
+            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, count, d);
+            h = m->normed;
+        } else {
+            RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, count * d));
+        }
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
+            attention_mixer(e, L, h, m->mixed, count);
+        else
+            delta_net_mixer(e, L, h, m->mixed, count);
+        const uint16_t* mixed = m->mixed;
+        if (L.post_mixer.present) {
+            norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, count, d);
+            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, count * d));
+        }
+        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, count, d);
+        linear(e, L.up, m->normed, m->up, count);
+        RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, count, 0, 0, L.d.activation, 1));
+        linear(e, L.down, m->gated, hidden, count);
+        if (L.post_mlp.present) {
+            norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, count, d);
+            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, count * d));
+        }
+        if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, count * d));
+    }
+    m->tap_rows = count;
+    if (sample) {
+        const size_t last = (size_t)(count - 1) * d;
+        norm(e, m->output_norm, hidden + last, m->last_normed, m->shortcut + last, 2, 1, d);
+        const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+        linear(e, ro, m->last_normed, m->logits, 1);
+        if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
+            RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, m->d.vocab_size, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
+        RUN("argmax", (size_t)m->d.vocab_size * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, m->d.vocab_size, 1, m->argmax_scratch));
+    }
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1), 0, s, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, count, sample ? 1u : 0u);
+    ++m->launches;
+    if (e.st != UZU_OK) return e.st;
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        set_error("engine: forward launch failed: %s", hipGetErrorString(err));
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
+
+uzu_status build_decode_graph(uzu_hip_model* m, hipGraphExec_t* out, bool two_pass) {
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    m->regime_override = two_pass ? 1 : 0;
+    uzu_status st = encode_forward(m, s, 1, true);
+    m->regime_override = -1;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (st != UZU_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return st;
+    }
+    if (e != hipSuccess) {
+        set_error("engine: graph capture failed: %s", hipGetErrorString(e));
+        return UZU_ERR_HIP;
+    }
+    HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g));
+    return UZU_OK;
+}
+
+uzu_status enqueue_decode(uzu_hip_model* m, uint32_t steps) {
+    for (uint32_t i = 0; i < steps; ++i) {
+        UZU_REQUIRE(m->context_length + 1 <= m->d.max_context_length, "decode: context length %u exceeds max_context_length %u", m->context_length + 1,
+                    m->d.max_context_length);
+        if (m->flags & UZU_MODEL_NO_GRAPH) {
+            UZU_PROPAGATE(encode_forward(m, m->ctx->stream, 1, true));
+        } else {
+            const bool two = m->context_length + 1 > 1024;
+            hipGraphExec_t* g = two ? &m->graph_two : &m->graph_single;
+            if (!*g) UZU_PROPAGATE(build_decode_graph(m, g, two));
+            HIPCHK(hipGraphLaunch(*g, m->ctx->stream));
+        }
+        m->context_length += 1;
+    }
+    return UZU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out) {
+    UZU_REQUIRE(ctx && desc && out, "model_create: null argument");
+    UZU_REQUIRE(desc->num_layers > 0 && desc->layers, "model_create: no layers");
+    (void)hipSetDevice(ctx->device);
+    auto* m = new uzu_hip_model();
+    m->ctx = ctx;
+    m->flags = flags;
+    m->d = *desc;
+    m->d.layers = nullptr;
+    const uint32_t d = desc->model_dim;
+    uzu_status st = UZU_OK;
+    auto fail = [&](uzu_status s) {
+        uzu_hip_model_destroy(m);
+        return s;
+    };
+#define TRY(x) do { st = (x); if (st != UZU_OK) return fail(st); } while (0)
+    TRY(upload_linear(m, desc->embedding, &m->embedding));
+    if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding));
+    TRY(upload_norm(m, desc->output_norm, d, &m->output_norm));
+    m->max_positions = desc->max_context_length + kSuffixCapacity;
+    m->layers.resize(desc->num_layers);
+    uint32_t max_qkv = 0, max_qdim = 0, max_hidden = 0, max_proj = 0, max_value = 0, max_key = 0, max_hv = 0, max_hd = 0, max_heads = 0;
+    for (uint32_t l = 0; l < desc->num_layers; ++l) {
+        const uzu_layer_desc& h = desc->layers[l];
+        DLayer& L = m->layers[l];
+        L.d = h;
+        TRY(upload_norm(m, h.pre_mixer_norm, d, &L.pre_mixer));
+        TRY(upload_norm(m, h.post_mixer_norm, d, &L.post_mixer));
+        TRY(upload_norm(m, h.pre_mlp_norm, d, &L.pre_mlp));
+        TRY(upload_norm(m, h.post_mlp_norm, d, &L.post_mlp));
+        if (!L.pre_mlp.present) {
+            set_error("model_create: layer %u has no pre_mlp_norm", l);
+            return fail(UZU_ERR_INVALID_ARGUMENT);
+        }
+        TRY(upload_linear(m, h.up_projection, &L.up));
+        TRY(upload_linear(m, h.down_projection, &L.down));
+        if (h.up_projection.n != 2 * h.hidden_dim || h.down_projection.k != h.hidden_dim) {
+            set_error("model_create: layer %u MLP shapes inconsistent", l);
+            return fail(UZU_ERR_INVALID_ARGUMENT);
+        }
+        max_hidden = max_hidden > h.hidden_dim ? max_hidden : h.hidden_dim;
+        if (h.mixer_kind == UZU_MIXER_ATTENTION) {
+            TRY(upload_linear(m, h.qkv_projection, &L.qkv));
+            if (h.has_gate) TRY(upload_linear(m, h.gate_projection, &L.gate));
+            TRY(upload_linear(m, h.out_projection, &L.out));
+            TRY(upload_norm(m, h.query_norm, h.head_dim, &L.qn));
+            TRY(upload_norm(m, h.key_norm, h.head_dim, &L.kn));
+            const size_t kv_bytes = (size_t)m->max_positions * h.num_groups * h.head_dim * 2;
+            void* p;
+            TRY(dev_alloc(m, kv_bytes, &p, true));
+            L.keys = (uint16_t*)p;
+            TRY(dev_alloc(m, kv_bytes, &p, true));
+            L.values = (uint16_t*)p;
+            const uint32_t qdim = h.num_heads * h.head_dim;
+            max_qkv = max_qkv > h.qkv_projection.n ? max_qkv : h.qkv_projection.n;
+            max_qdim = max_qdim > qdim ? max_qdim : qdim;
+            max_hd = max_hd > h.head_dim ? max_hd : h.head_dim;
+            max_heads = max_heads > h.num_heads ? max_heads : h.num_heads;
+        } else {
+            TRY(upload_linear(m, h.dn_in_proj, &L.in_proj));
+            TRY(upload_linear(m, h.dn_out_proj, &L.out_proj));
+            const uint32_t key_dim = h.dn_num_groups * h.dn_head_dim, value_dim = h.dn_num_heads * h.dn_value_head_dim;
+            const uint32_t conv_dim = 2 * key_dim + value_dim;
+            TRY(upload(m, h.dn_conv_weights, (size_t)conv_dim * h.dn_kernel_size * 4, &L.conv_w));
+            TRY(upload(m, h.dn_conv_biases, (size_t)conv_dim * 4, &L.conv_b));
+            TRY(upload(m, h.dn_a_log, (size_t)h.dn_num_heads * 4, &L.a_log));
+            TRY(upload(m, h.dn_dt_bias, (size_t)h.dn_num_heads * 4, &L.dt_bias));
+            TRY(upload(m, h.dn_norm_scales, (size_t)h.dn_value_head_dim * 4, &L.dn_norm));
+            L.conv_state_bytes = (size_t)conv_dim * (h.dn_kernel_size - 1) * 4;
+            L.ssm_state_bytes = (size_t)h.dn_num_heads * h.dn_value_head_dim * h.dn_head_dim * 4;
+            void* p;
+            TRY(dev_alloc(m, L.conv_state_bytes, &p, true));
+            L.conv_state = (float*)p;
+            TRY(dev_alloc(m, L.ssm_state_bytes, &p, true));
+            L.ssm_state = (float*)p;
+            const uint32_t proj = conv_dim + value_dim + 2 * h.dn_num_heads;
+            max_proj = max_proj > proj ? max_proj : proj;
+            max_value = max_value > value_dim ? max_value : value_dim;
+            max_key = max_key > key_dim ? max_key : key_dim;
+            max_hv = max_hv > h.dn_num_heads ? max_hv : h.dn_num_heads;
+        }
+    }
+    if (desc->rope.kind != UZU_ROPE_NONE) {
+        std::vector<float> c, sn;
+        rope_tables(desc->rope, m->max_positions, c, sn);
+        size_t saved = m->weight_bytes;
+        TRY(upload(m, c.data(), c.size() * 4, &m->rope_cos));
+        TRY(upload(m, sn.data(), sn.size() * 4, &m->rope_sin));
+        m->weight_bytes = saved;
+    }
+    void* p;
+    const size_t C = kSuffixCapacity;
+#define ALLOC(field, type, elems) do { TRY(dev_alloc(m, (size_t)(elems) * sizeof(type), &p, true)); m->field = (type*)p; } while (0)
+    ALLOC(d_ctx_len, uint32_t, 1);
+    ALLOC(d_tokens, uint32_t, C);
+    ALLOC(d_out_token, uint32_t, 1);
+    ALLOC(d_sampled, uint32_t, m->max_positions);
+    ALLOC(hidden, uint16_t, C * d);
+    ALLOC(normed, uint16_t, C * d);
+    ALLOC(mixed, uint16_t, C * d);
+    ALLOC(shortcut, uint16_t, C * d);
+    if (max_qkv) {
+        ALLOC(qkv, uint16_t, C * max_qkv);
+        ALLOC(gate, uint16_t, C * max_qdim);
+        ALLOC(queries, uint16_t, C * max_qdim);
+        ALLOC(attn_out, uint16_t, C * max_qdim);
+        TRY(ensure_partials(m, max_heads, max_hd)); // decode rows; prefill grows it on demand
+    }
+    ALLOC(up, uint16_t, C * 2 * max_hidden);
+    ALLOC(gated, uint16_t, C * max_hidden);
+    if (max_proj) {
+        ALLOC(in_proj, uint16_t, C * max_proj);
+        ALLOC(delta_out, uint16_t, C * max_value);
+        ALLOC(padded, float, (C + 8) * max_proj);
+        ALLOC(qn, float, C * max_key);
+        ALLOC(kn, float, C * max_key);
+        ALLOC(beta, float, C * max_hv);
+        ALLOC(decay, float, C * max_hv);
+    }
+    ALLOC(last_normed, uint16_t, d);
+    ALLOC(logits, uint16_t, desc->vocab_size);
+    TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
+    if (flags & UZU_MODEL_DEBUG_TAPS) ALLOC(taps, uint16_t, (size_t)desc->num_layers * C * d);
+#undef ALLOC
+#undef TRY
+    if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) {
+        set_error("model_create: hipEventCreate failed");
+        return fail(UZU_ERR_HIP);
+    }
+    *out = m;
+    return UZU_OK;
+}
+
+void uzu_hip_model_destroy(uzu_hip_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->graph_single) (void)hipGraphExecDestroy(m->graph_single);
+    if (m->graph_two) (void)hipGraphExecDestroy(m->graph_two);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    for (void* p : m->allocations) (void)hipFree(p);
+    delete m;
+}
+
+uzu_status uzu_hip_model_reset(uzu_hip_model* m) {
+    UZU_REQUIRE(m, "model_reset: null model");
+    hipStream_t s = m->ctx->stream;
+    HIPCHK(hipMemsetAsync(m->d_ctx_len, 0, 4, s));
+    for (auto& L : m->layers) {
+        if (L.conv_state) HIPCHK(hipMemsetAsync(L.conv_state, 0, L.conv_state_bytes, s));
+        if (L.ssm_state) HIPCHK(hipMemsetAsync(L.ssm_state, 0, L.ssm_state_bytes, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    m->context_length = 0;
+    return UZU_OK;
+}
+
+uint32_t uzu_hip_model_context_length(const uzu_hip_model* m) { return m ? m->context_length : 0; }
+size_t uzu_hip_model_weight_bytes(const uzu_hip_model* m) { return m ? m->weight_bytes : 0; }
+uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m) { return m ? m->launches : 0; }
+
+uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, uint32_t count, uint32_t* first_token) {
+    UZU_REQUIRE(m && token_ids && count > 0, "model_prefill: null / empty input");
+    UZU_REQUIRE(m->context_length + count <= m->d.max_context_length, "model_prefill: %u + %u tokens exceed max_context_length %u",
+                m->context_length, count, m->d.max_context_length);
+    hipStream_t s = m->ctx->stream;
+    for (uint32_t start = 0; start < count; start += kSuffixCapacity) {
+        const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
+        const bool last = start + n == count;
+        HIPCHK(hipMemcpyAsync(m->d_tokens, token_ids + start, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        if (m->context_length + n > 1024) {
+            uint32_t max_heads = 0, max_hd = 0;
+            for (auto& L : m->layers)
+                if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+                    max_heads = max_heads > L.d.num_heads ? max_heads : L.d.num_heads;
+                    max_hd = max_hd > L.d.head_dim ? max_hd : L.d.head_dim;
+                }
+            if (max_heads) UZU_PROPAGATE(ensure_partials(m, n * max_heads, max_hd));
+        }
+        UZU_PROPAGATE(encode_forward(m, s, n, last));
+        HIPCHK(hipStreamSynchronize(s)); // token_ids is caller memory; also surfaces kernel faults per chunk
+        m->context_length += n;
+    }
+    if (first_token) HIPCHK(hipMemcpy(first_token, m->d_out_token, 4, hipMemcpyDeviceToHost));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps) {
+    UZU_REQUIRE(m, "model_decode: null model");
+    UZU_REQUIRE(m->context_length > 0, "model_decode: prefill first (no input token)");
+    return enqueue_decode(m, steps);
+}
+
+uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, uint32_t count, uint32_t* out_tokens) {
+    UZU_REQUIRE(m && out_tokens, "model_read_tokens: null argument");
+    UZU_REQUIRE(first_position + count <= m->max_positions, "model_read_tokens: range out of bounds");
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(hipMemcpy(out_tokens, m->d_sampled + first_position, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_tokens, float* gpu_ms) {
+    UZU_REQUIRE(m, "model_decode: null model");
+    if (!steps) return UZU_OK;
+    // make sure graph construction is not inside the timed region
+    if (!(m->flags & UZU_MODEL_NO_GRAPH)) {
+        if (m->context_length + 1 <= 1024 && !m->graph_single) UZU_PROPAGATE(build_decode_graph(m, &m->graph_single, false));
+        if (m->context_length + steps > 1024 && !m->graph_two) UZU_PROPAGATE(build_decode_graph(m, &m->graph_two, true));
+    }
+    const uint32_t first = m->context_length;
+    HIPCHK(hipEventRecord(m->ev0, m->ctx->stream));
+    UZU_PROPAGATE(uzu_hip_model_decode_enqueue(m, steps));
+    HIPCHK(hipEventRecord(m->ev1, m->ctx->stream));
+    HIPCHK(hipEventSynchronize(m->ev1));
+    if (gpu_ms) HIPCHK(hipEventElapsedTime(gpu_ms, m->ev0, m->ev1));
+    if (out_tokens) UZU_PROPAGATE(uzu_hip_model_read_tokens(m, first, steps, out_tokens));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity, const char** names, uint64_t* bytes, float* ms, uint32_t* count) {
+    UZU_REQUIRE(m && names && bytes && ms && count, "model_profile_decode_step: null argument");
+    UZU_REQUIRE(m->context_length > 0 && m->context_length + 1 <= m->d.max_context_length, "model_profile_decode_step: bad context length");
+    std::vector<ProfEntry> prof;
+    m->prof_sink = &prof;
+    uzu_status st = encode_forward(m, m->ctx->stream, 1, true);
+    m->prof_sink = nullptr;
+    hipError_t e = hipStreamSynchronize(m->ctx->stream);
+    if (st == UZU_OK && e != hipSuccess) {
+        set_error("model_profile_decode_step: %s", hipGetErrorString(e));
+        st = UZU_ERR_HIP;
+    }
+    if (st == UZU_OK) m->context_length += 1;
+    uint32_t n = 0;
+    for (auto& p : prof) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, p.e0, p.e1);
+        if (n < capacity) names[n] = p.name, bytes[n] = p.bytes, ms[n] = t, ++n;
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    *count = n;
+    return st;
+}
+
+uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token) {
+    UZU_REQUIRE(m, "model_set_next_token: null model");
+    HIPCHK(hipMemcpyAsync(m->d_tokens, &token, 4, hipMemcpyHostToDevice, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out) {
+    UZU_REQUIRE(m && logits_out, "model_read_logits: null argument");
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(hipMemcpy(logits_out, m->logits, (size_t)m->d.vocab_size * 2, hipMemcpyDeviceToHost));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uint16_t* out, uint32_t* rows) {
+    UZU_REQUIRE(m && out && layer < m->d.num_layers, "model_read_layer_output: bad argument");
+    UZU_REQUIRE(m->taps, "model_read_layer_output: model was not created with UZU_MODEL_DEBUG_TAPS");
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(hipMemcpy(out, m->taps + (size_t)layer * kSuffixCapacity * m->d.model_dim, (size_t)m->tap_rows * m->d.model_dim * 2, hipMemcpyDeviceToHost));
+    if (rows) *rows = m->tap_rows;
+    return UZU_OK;
+}
+
+} // extern "C"

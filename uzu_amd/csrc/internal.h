@@ -1,0 +1,97 @@
+// internal.h -- shared host-side declarations of the HIP backend library (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/uzu_hip.h"
+
+namespace uzu {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define UZU_HIP_TRY(expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            ::uzu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return _e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;                        \
+        }                                                                                                  \
+    } while (0)
+
+#define UZU_REQUIRE(cond, ...)               \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::uzu::set_error(__VA_ARGS__);   \
+            return UZU_ERR_INVALID_ARGUMENT; \
+        }                                    \
+    } while (0)
+
+#define UZU_UNSUPPORTED(cond, ...)           \
+    do {                                     \
+        if (cond) {                          \
+            ::uzu::set_error(__VA_ARGS__);   \
+            return UZU_ERR_UNSUPPORTED;      \
+        }                                    \
+    } while (0)
+
+#define UZU_PROPAGATE(expr)            \
+    do {                               \
+        uzu_status _s = (expr);        \
+        if (_s != UZU_OK) return _s;   \
+    } while (0)
+
+} // namespace uzu
+
+struct uzu_hip_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t current_bytes = 0;
+    size_t peak_bytes = 0;
+    void* staging = nullptr; // pinned bounce buffer for uploads
+    size_t staging_size = 0;
+    int num_cus = 0;
+    char name[128] = {0};
+};
+
+struct uzu_hip_buffer {
+    uzu_hip_context* ctx = nullptr;
+    void* dptr = nullptr;
+    size_t size = 0;
+    void* mirror = nullptr; // pinned host mirror (cpu_ptr)
+};
+
+enum class CmdbufState { Initial, Encoding, Executable, Pending, Completed };
+
+struct uzu_hip_cmdbuf {
+    uzu_hip_context* ctx = nullptr;
+    std::string name;
+    uint32_t flags = 0;
+    CmdbufState state = CmdbufState::Initial;
+    hipEvent_t ev_start = nullptr, ev_end = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<std::string> debug_groups;
+    float last_ms = 0.f;
+};
+
+struct uzu_hip_kernel {
+    uzu_hip_context* ctx = nullptr;
+    uint32_t kind = 0;   // KernelKind
+    uint32_t t[4] = {0}; // data types
+    uint32_t f[12] = {0}; // specialization flags / consts
+};
+
+namespace uzu {
+
+inline void* bptr(const uzu_buf& b) { return b.buffer ? (void*)((char*)b.buffer->dptr + b.offset) : nullptr; }
+inline hipStream_t cb_stream(uzu_hip_cmdbuf* cb) { return cb->ctx->stream; }
+uzu_status cmdbuf_check_encoding(uzu_hip_cmdbuf* cb);
+uzu_status check_launch(const char* what);
+
+} // namespace uzu

@@ -1,0 +1,360 @@
+// k_deltanet.hip -- Gated DeltaNet (linear attention) kernels for gfx950: decode step (conv update +
+// delta-rule state update) and the sequential prefill path.
+//
+// Reference semantics: BU/cpu/kernel/gdn/{conv_update,update,conv_scan,prefill_prep,prefill,norm_gate}.rs and
+// BU/cpu/kernel/ssm/conv1d.rs (Conv1dPack), with the buffer types of the Metal kernels
+// (BU/metal/kernel/gdn/update.metal:19-31): bf16 activations, f32 a_log / dt_bias / norm weights, f32
+// conv and SSM state.
+//
+// State layout [Hv, Dv, Dk] f32 (1 MiB per layer for Qwen3.5): a row (one dv) is 512 contiguous
+// bytes; half a wave (32 lanes x 16 B) reads/writes one row with dwordx4 accesses, so the 2 MiB of
+// state traffic per layer per token is fully coalesced.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+// ---------------------------------------------------------------- DeltaNetConvUpdate (conv_update.rs:17-55)
+__global__ void __launch_bounds__(256) delta_net_conv_update_kernel(const float* conv_weight, const float* bias,
+                                                                    uint16_t* in_out, float* state,
+                                                                    uint32_t kernel_size, uint32_t conv_dim,
+                                                                    uint32_t state_stride) {
+    const uint32_t channel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (channel >= conv_dim) return;
+    const uint32_t tap_count = kernel_size - 1;
+    float* st_row = state + (size_t)channel * state_stride;
+    const float* w = conv_weight + (size_t)channel * kernel_size;
+    const float x = bf16_to_f32(in_out[channel]);
+    float acc = bias ? bias[channel] : 0.0f;
+    for (uint32_t tap = 0; tap < tap_count; ++tap) acc += st_row[tap] * w[tap];
+    acc += x * w[tap_count];
+    in_out[channel] = f32_to_bf16(silu_f32(acc));
+    for (uint32_t tap = 1; tap < tap_count; ++tap) st_row[tap - 1] = st_row[tap];
+    st_row[tap_count - 1] = x;
+}
+uzu_status delta_net_conv_update(hipStream_t s, const float* conv_weight, const float* bias, uint16_t* in_out,
+                                 float* state, uint32_t kernel_size, uint32_t conv_dim, uint32_t state_stride) {
+    if (!conv_dim) return UZU_OK;
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_conv_update_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, s, conv_weight, bias, in_out,
+                           state, kernel_size, conv_dim, state_stride);
+    }, "delta_net_conv_update");
+}
+
+// ---------------------------------------------------------------- DeltaNetUpdate (update.rs:30-143), Dk = 128
+// One workgroup (512 threads = 8 waves) per value head; a half-wave owns one state row at a time.
+__global__ void __launch_bounds__(512) delta_net_update_kernel(const uint16_t* in_proj, const float* a_log,
+                                                               const float* dt_bias, const float* norm_weight,
+                                                               float* state, uint16_t* out, uint32_t num_v_heads,
+                                                               uint32_t num_k_heads, uint32_t head_v_dim,
+                                                               uint32_t key_dim, uint32_t value_dim, float norm_epsilon) {
+    constexpr int DK = 128;
+    __shared__ float s_o[512];
+    __shared__ float s_red[16];
+    const uint32_t hv = blockIdx.x;
+    const uint32_t hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane & 31, half = lane >> 5;
+
+    float q[4], kk[4];
+    float q_sq = 0.f, k_sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        q[e] = bf16_to_f32(in_proj[hk * DK + sl * 4 + e]);
+        kk[e] = bf16_to_f32(in_proj[key_dim + hk * DK + sl * 4 + e]);
+        q_sq += q[e] * q[e];
+        k_sq += kk[e] * kk[e];
+    }
+    q_sq = group_sum<32>(q_sq);
+    k_sq = group_sum<32>(k_sq);
+    const float q_inv_norm = 1.0f / sqrtf(q_sq + 1e-6f);
+    const float k_inv_norm = 1.0f / sqrtf(k_sq + 1e-6f);
+    const float q_scale = 1.0f / sqrtf((float)DK);
+    float kq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        q[e] = (q[e] * q_inv_norm) * q_scale;
+        kk[e] = kk[e] * k_inv_norm;
+        kq += kk[e] * q[e];
+    }
+    const float kq_dot = group_sum<32>(kq);
+
+    const float beta_raw = bf16_to_f32(in_proj[conv_dim + value_dim + hv]);
+    const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
+    const float a_raw = bf16_to_f32(in_proj[conv_dim + value_dim + num_v_heads + hv]);
+    const float sp_input = a_raw + dt_bias[hv];
+    const float sp = sp_input > 20.0f ? sp_input : logf_glibc(1.0f + expf_glibc(sp_input));
+    const float g = -expf_glibc(a_log[hv]) * sp;
+    const float decay = expf_glibc(g);
+
+    const uint32_t rows_per_pass = (blockDim.x >> 6) * 2;
+    for (uint32_t i0 = 0; i0 < head_v_dim; i0 += rows_per_pass) {
+        const uint32_t i = i0 + wave * 2 + half;
+        if (i < head_v_dim) {
+            const float v_i = bf16_to_f32(in_proj[2 * key_dim + hv * head_v_dim + i]);
+            float4* srow = (float4*)(state + ((size_t)hv * head_v_dim + i) * DK) + sl;
+            const float4 sv = *srow;
+            const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+            float sq = 0.f, sk = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sq = fmaf(s4[e], q[e], sq);
+                sk = fmaf(s4[e], kk[e], sk);
+            }
+            sq = group_sum<32>(sq);
+            sk = group_sum<32>(sk);
+            const float retrieved_i = decay * sk;
+            const float delta_i = beta * (v_i - retrieved_i);
+            const float o_i = decay * sq + delta_i * kq_dot;
+            float4 ns;
+            ns.x = decay * s4[0] + kk[0] * delta_i;
+            ns.y = decay * s4[1] + kk[1] * delta_i;
+            ns.z = decay * s4[2] + kk[2] * delta_i;
+            ns.w = decay * s4[3] + kk[3] * delta_i;
+            *srow = ns;
+            if (sl == 0) s_o[i] = o_i;
+        }
+    }
+    __syncthreads();
+    float o_sq = 0.f;
+    for (uint32_t i = threadIdx.x; i < head_v_dim; i += blockDim.x) o_sq += s_o[i] * s_o[i];
+    const float sumsq = block_sum(o_sq, s_red);
+    const float inv_rms = 1.0f / sqrtf(sumsq / (float)head_v_dim + norm_epsilon);
+    for (uint32_t i = threadIdx.x; i < head_v_dim; i += blockDim.x) {
+        const float z_i = bf16_to_f32(in_proj[conv_dim + hv * head_v_dim + i]);
+        const float final_val = s_o[i] * inv_rms * norm_weight[i] * silu_f32(z_i);
+        out[hv * head_v_dim + i] = f32_to_bf16(final_val);
+    }
+}
+uzu_status delta_net_update(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias,
+                            const float* norm_weight, float* state, uint16_t* out, uint32_t num_v_heads,
+                            uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
+                            uint32_t value_dim, float norm_epsilon) {
+    if (head_k_dim != 128 || head_v_dim > 512 || num_k_heads == 0 || num_v_heads % num_k_heads) {
+        set_error("delta_net_update: needs head_k_dim == 128, head_v_dim <= 512, Hv %% Hk == 0");
+        return UZU_ERR_UNSUPPORTED;
+    }
+    if (!num_v_heads) return UZU_OK;
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_update_kernel, dim3(num_v_heads), dim3(512), 0, s, in_proj, a_log, dt_bias, norm_weight, state,
+                           out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, norm_epsilon);
+    }, "delta_net_update");
+}
+
+// ---------------------------------------------------------------- Conv1dPack (ssm/conv1d.rs:10-40)
+__global__ void __launch_bounds__(256) conv1d_pack_kernel(const float* state_in, const uint16_t* x, float* padded,
+                                                          uint32_t state_stride, uint32_t row_stride,
+                                                          uint32_t suffix_len, uint32_t num_channels) {
+    const size_t total = (size_t)(state_stride + suffix_len) * num_channels;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t c = idx % num_channels, row = idx / num_channels;
+        const size_t pi = (size_t)row * row_stride + c;
+        if (row < state_stride)
+            padded[pi] = state_in[(size_t)c * state_stride + row];
+        else
+            padded[pi] = bf16_to_f32(x[(size_t)(row - state_stride) * row_stride + c]);
+    }
+}
+uzu_status conv1d_pack(hipStream_t s, const float* state_in, const uint16_t* x, float* padded, uint32_t state_stride,
+                       uint32_t row_stride, uint32_t suffix_len, uint32_t num_channels) {
+    const size_t total = (size_t)(state_stride + suffix_len) * num_channels;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    return launch_check([&] {
+        hipLaunchKernelGGL(conv1d_pack_kernel, dim3(blocks), dim3(256), 0, s, state_in, x, padded, state_stride, row_stride, suffix_len, num_channels);
+    }, "conv1d_pack");
+}
+
+// ---------------------------------------------------------------- DeltaNetConvScan (conv_scan.rs:32-73)
+__global__ void __launch_bounds__(256) delta_net_conv_scan_kernel(const float* conv_padded, const float* conv_weight,
+                                                                  const float* bias, uint16_t* in_proj, float* state_out,
+                                                                  uint32_t suffix_len, uint32_t kernel_size,
+                                                                  uint32_t row_stride, uint32_t state_stride,
+                                                                  uint32_t conv_dim, uint32_t out_stride) {
+    const size_t total = (size_t)suffix_len * conv_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t channel = idx % conv_dim, token = idx / conv_dim;
+        float acc = bias ? bias[channel] : 0.0f;
+        for (uint32_t tap = 0; tap < kernel_size; ++tap)
+            acc += conv_weight[(size_t)channel * kernel_size + tap] * conv_padded[(size_t)(token + tap) * row_stride + channel];
+        in_proj[(size_t)token * out_stride + channel] = f32_to_bf16(silu_f32(acc));
+    }
+    const size_t total_state = (size_t)conv_dim * state_stride;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_state; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t tap = idx % state_stride, channel = idx / state_stride;
+        state_out[idx] = conv_padded[(size_t)(suffix_len + tap) * row_stride + channel];
+    }
+}
+uzu_status delta_net_conv_scan(hipStream_t s, const float* conv_padded, const float* conv_weight, const float* bias,
+                               uint16_t* in_proj, float* state_out, uint32_t suffix_len, uint32_t kernel_size,
+                               uint32_t row_stride, uint32_t state_stride, uint32_t conv_dim, uint32_t out_stride) {
+    const size_t total = (size_t)suffix_len * conv_dim;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_conv_scan_kernel, dim3(blocks), dim3(256), 0, s, conv_padded, conv_weight, bias, in_proj, state_out,
+                           suffix_len, kernel_size, row_stride, state_stride, conv_dim, out_stride);
+    }, "delta_net_conv_scan");
+}
+
+// ---------------------------------------------------------------- DeltaNetPrefillPrep (prefill_prep.rs:30-113)
+// one wave per (token, k-head): 128 elements = 2 per lane
+__global__ void __launch_bounds__(256) delta_net_prefill_prep_kernel(const uint16_t* in_proj, const float* a_log,
+                                                                     const float* dt_bias, float* q_norm_out,
+                                                                     float* k_norm_out, float* beta_out, float* decay_out,
+                                                                     uint32_t num_v_heads, uint32_t num_k_heads,
+                                                                     uint32_t key_dim, uint32_t value_dim,
+                                                                     uint32_t suffix_len) {
+    constexpr int DK = 128;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= suffix_len * num_k_heads) return;
+    const uint32_t token = wave / num_k_heads, hk = wave % num_k_heads;
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    const size_t tok_offset = (size_t)token * total_proj_dim;
+    const uint32_t groups_per_head = num_v_heads / num_k_heads;
+    float qv[2], kv[2];
+    float q_sq = 0.f, k_sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        qv[e] = bf16_to_f32(in_proj[tok_offset + hk * DK + lane * 2 + e]);
+        kv[e] = bf16_to_f32(in_proj[tok_offset + key_dim + hk * DK + lane * 2 + e]);
+        q_sq += qv[e] * qv[e];
+        k_sq += kv[e] * kv[e];
+    }
+    q_sq = wave_sum(q_sq);
+    k_sq = wave_sum(k_sq);
+    const float q_inv = 1.0f / sqrtf(q_sq + 1e-6f);
+    const float q_scale = 1.0f / sqrtf((float)DK);
+    const float k_inv = 1.0f / sqrtf(k_sq + 1e-6f);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        q_norm_out[(size_t)token * key_dim + hk * DK + lane * 2 + e] = qv[e] * q_inv * q_scale;
+        k_norm_out[(size_t)token * key_dim + hk * DK + lane * 2 + e] = kv[e] * k_inv;
+    }
+    if (lane < groups_per_head) {
+        const uint32_t hv = hk * groups_per_head + lane;
+        const float beta_raw = bf16_to_f32(in_proj[tok_offset + conv_dim + value_dim + hv]);
+        const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
+        const float a_raw = bf16_to_f32(in_proj[tok_offset + conv_dim + value_dim + num_v_heads + hv]);
+        const float sp_in = a_raw + dt_bias[hv];
+        const float sp = sp_in > 20.0f ? sp_in : logf_glibc(1.0f + expf_glibc(sp_in));
+        const float log_decay = -expf_glibc(a_log[hv]) * sp;
+        beta_out[(size_t)token * num_v_heads + hv] = beta;
+        decay_out[(size_t)token * num_v_heads + hv] = expf_glibc(log_decay);
+    }
+}
+uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias,
+                                  float* q_norm_out, float* k_norm_out, float* beta_out, float* decay_out,
+                                  uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim,
+                                  uint32_t value_dim, uint32_t suffix_len) {
+    if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads || num_v_heads / num_k_heads > 64) {
+        set_error("delta_net_prefill_prep: needs head_k_dim == 128 and Hv/Hk <= 64");
+        return UZU_ERR_UNSUPPORTED;
+    }
+    const uint32_t waves = suffix_len * num_k_heads;
+    if (!waves) return UZU_OK;
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_prefill_prep_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in_proj, a_log, dt_bias, q_norm_out,
+                           k_norm_out, beta_out, decay_out, num_v_heads, num_k_heads, key_dim, value_dim, suffix_len);
+    }, "delta_net_prefill_prep");
+}
+
+// ---------------------------------------------------------------- DeltaNetPrefill (prefill.rs:39-80)
+// Sequential scan over tokens with the state row held in registers: half a wave per (hv, dv) row.
+__global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_norm, const float* k_norm,
+                                                                const float* beta_buf, const float* decay_buf,
+                                                                const uint16_t* in_proj, float* state, uint16_t* out,
+                                                                uint32_t num_v_heads, uint32_t num_k_heads,
+                                                                uint32_t head_v_dim, uint32_t key_dim,
+                                                                uint32_t value_dim, uint32_t suffix_len) {
+    constexpr int DK = 128;
+    const uint32_t row = ((blockIdx.x * blockDim.x + threadIdx.x) >> 5); // global (hv, dv) row index
+    const int sl = threadIdx.x & 31;
+    if (row >= num_v_heads * head_v_dim) return;
+    const uint32_t hv = row / head_v_dim, i = row % head_v_dim;
+    const uint32_t hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    float4* srow = (float4*)(state + (size_t)row * DK) + sl;
+    float4 sv = *srow;
+    float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+    for (uint32_t token = 0; token < suffix_len; ++token) {
+        const size_t qk_off = (size_t)token * key_dim + hk * DK + sl * 4;
+        const float4 k4 = *(const float4*)(k_norm + qk_off);
+        const float4 q4 = *(const float4*)(q_norm + qk_off);
+        const float kf[4] = {k4.x, k4.y, k4.z, k4.w}, qf[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float decay = decay_buf[(size_t)token * num_v_heads + hv];
+        const float beta = beta_buf[(size_t)token * num_v_heads + hv];
+        float kv_mem = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kv_mem = fmaf(decay * s4[e], kf[e], kv_mem);
+        kv_mem = group_sum<32>(kv_mem);
+        const float v_val = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + 2 * key_dim + hv * head_v_dim + i]);
+        const float delta = beta * (v_val - kv_mem);
+        float o_val = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s4[e] = decay * s4[e] + kf[e] * delta;
+            o_val = fmaf(s4[e], qf[e], o_val);
+        }
+        o_val = group_sum<32>(o_val);
+        if (sl == 0) out[(size_t)token * value_dim + hv * head_v_dim + i] = f32_to_bf16(o_val);
+    }
+    sv.x = s4[0], sv.y = s4[1], sv.z = s4[2], sv.w = s4[3];
+    *srow = sv;
+}
+uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta,
+                             const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
+                             uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
+                             uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
+    if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads) {
+        set_error("delta_net_prefill: needs head_k_dim == 128");
+        return UZU_ERR_UNSUPPORTED;
+    }
+    const uint32_t rows = num_v_heads * head_v_dim;
+    if (!rows || !suffix_len) return UZU_OK;
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_prefill_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, q_norm, k_norm, beta, decay, in_proj,
+                           state, out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+    }, "delta_net_prefill");
+}
+
+// ---------------------------------------------------------------- DeltaNetNormGate (norm_gate.rs:32-66)
+__global__ void __launch_bounds__(256) delta_net_norm_gate_kernel(uint16_t* in_out, const uint16_t* in_proj,
+                                                                  const float* norm_weight, uint32_t num_v_heads,
+                                                                  uint32_t head_v_dim, uint32_t value_dim,
+                                                                  uint32_t conv_dim, uint32_t total_proj_dim,
+                                                                  float norm_epsilon, uint32_t suffix_len) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= suffix_len * num_v_heads) return;
+    const uint32_t token = wave / num_v_heads, hv = wave % num_v_heads;
+    const size_t base = (size_t)token * value_dim + (size_t)hv * head_v_dim;
+    float sumsq = 0.f;
+    for (uint32_t i = lane; i < head_v_dim; i += 64) {
+        const float v = bf16_to_f32(in_out[base + i]);
+        sumsq += v * v;
+    }
+    sumsq = wave_sum(sumsq);
+    const float inv_rms = 1.0f / sqrtf(sumsq / (float)head_v_dim + norm_epsilon);
+    for (uint32_t i = lane; i < head_v_dim; i += 64) {
+        const float o_i = bf16_to_f32(in_out[base + i]);
+        const float z_i = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + conv_dim + hv * head_v_dim + i]);
+        in_out[base + i] = f32_to_bf16(o_i * inv_rms * norm_weight[i] * silu_f32(z_i));
+    }
+}
+uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
+                               uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
+                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len) {
+    const uint32_t waves = suffix_len * num_v_heads;
+    if (!waves) return UZU_OK;
+    return launch_check([&] {
+        hipLaunchKernelGGL(delta_net_norm_gate_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in_out, in_proj, norm_weight, num_v_heads,
+                           head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
+    }, "delta_net_norm_gate");
+}
+
+} // namespace k
+} // namespace uzu

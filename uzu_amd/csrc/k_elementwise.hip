@@ -1,0 +1,535 @@
+// k_elementwise.hip -- normalisation, rope/KV scatter, activations, embedding gather, sampling and the
+// other bandwidth-trivial kernels of the forward path.  Each kernel states the reference kernel it
+// re-implements (BU = crates/backend-uzu/src/backends).  Element-wise kernels reproduce the reference's
+// rounding points exactly (compiled with -ffp-contract=off, glibc-exact expf), so they are BIT-EXACT
+// against the CPU path; kernels with a reduction (norms, argmax is exact) use fixed-order trees.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+// =============================================================== Normalization
+// BU/cpu/kernel/normalization/normalization.rs:56-125.  One workgroup per row; the (residual-added)
+// row is staged in LDS as f32 between the statistics pass and the scaling pass.
+template <class T, class TA>
+__global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* row = smem;                   // [element_count]
+    float* red = smem + p.element_count; // [16]
+    const uint32_t n = p.element_count;
+    const size_t off = (size_t)blockIdx.x * n;
+    const T* input = p.input ? (const T*)p.input : (const T*)p.output;
+    T* shortcut = (T*)p.shortcut;
+    float sum = 0.f, sum_sq = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float val = ld(input, off + i);
+        if (p.copy_to_shortcut) {
+            if (p.residual_add) {
+                val = rnd<T>(val + ld(shortcut, off + i));
+                if (p.scale_residual_sum) val = rnd<T>(val * p.post_layer_scalar);
+            }
+            st(shortcut, off + i, val);
+        }
+        row[i] = val;
+        if (p.subtract_mean) sum += val;
+        sum_sq += val * val;
+    }
+    const float cnt = (float)n;
+    float mean = 0.f;
+    if (p.subtract_mean) mean = block_sum(sum, red) / cnt;
+    const float variance = block_sum(sum_sq, red) / cnt - mean * mean;
+    const float rms_inv = 1.0f / sqrtf(variance + p.epsilon);
+    T* out = (T*)p.output;
+    const TA* scales = (const TA*)p.scales;
+    const TA* biases = (const TA*)p.biases;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float normalized = (row[i] - mean) * rms_inv;
+        float result;
+        if (scales) {
+            const float scale_val = ld(scales, i);
+            if (p.full_layer)
+                result = rnd<T>(normalized * (scale_val + p.scale_offset));
+            else
+                result = rnd<T>(rnd<T>(normalized) * rnd<T>(scale_val + p.scale_offset));
+        } else {
+            result = rnd<T>(normalized);
+        }
+        if (biases) result = rnd<T>(result + ld(biases, i));
+        if (p.scale_output) result = rnd<T>(result * rnd<T>(p.post_layer_scalar));
+        st(out, off + i, result);
+    }
+}
+
+uzu_status normalization(hipStream_t s, const NormParams& p) {
+    if (p.batch_size == 0) return UZU_OK;
+    const size_t lds = ((size_t)p.element_count + 16) * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("normalization: element_count %u exceeds the LDS staging limit", p.element_count);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
+        if (p.affine_dt == UZU_F32)
+            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, float>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization");
+        if (p.affine_dt == UZU_BF16)
+            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, bf16_t>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization");
+        set_error("normalization: unsupported affine dtype %u", p.affine_dt);
+        return UZU_ERR_UNSUPPORTED;
+    });
+}
+
+// =============================================================== QKVNorm
+// BU/cpu/kernel/attention/qkv_norm.rs:32-77: one wave per (token, head), in place.
+template <class T>
+__global__ void __launch_bounds__(256) qkv_norm_kernel(T* qkv, const float* scales, uint32_t batch_size,
+                                                       uint32_t total_heads, uint32_t head_dim, float epsilon,
+                                                       float scale_offset, uint32_t head_offset, uint32_t head_count,
+                                                       uint32_t full_layer) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= batch_size * head_count) return;
+    const uint32_t batch = wave / head_count, head = wave % head_count;
+    const size_t offset = (size_t)batch * total_heads * head_dim + (size_t)(head_offset + head) * head_dim;
+    float total = 0.f;
+    for (uint32_t i = lane; i < head_dim; i += 64) {
+        const float v = ld(qkv, offset + i);
+        total += v * v;
+    }
+    total = wave_sum(total);
+    const float rms_norm = 1.0f / sqrtf(total / (float)head_dim + epsilon);
+    for (uint32_t i = lane; i < head_dim; i += 64) {
+        const float normalized = ld(qkv, offset + i) * rms_norm;
+        float result;
+        if (!scales)
+            result = rnd<T>(normalized);
+        else if (full_layer)
+            result = rnd<T>(normalized * (scales[i] + scale_offset));
+        else
+            result = rnd<T>(rnd<T>(normalized) * rnd<T>(scales[i] + scale_offset));
+        st(qkv, offset + i, result);
+    }
+}
+uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, uint32_t batch_size,
+                    uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset, uint32_t head_offset,
+                    uint32_t head_count, uint32_t full_layer) {
+    const uint32_t waves = batch_size * head_count;
+    if (!waves) return UZU_OK;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] {
+            hipLaunchKernelGGL((qkv_norm_kernel<T>), dim3((waves + 3) / 4), dim3(256), 0, s, (T*)qkv, scales, batch_size,
+                               total_heads, head_dim, epsilon, scale_offset, head_offset, head_count, full_layer);
+        }, "qkv_norm");
+    });
+}
+
+// =============================================================== AttentionPrepare
+// BU/cpu/kernel/attention/attention_prepare.rs:7-126: split packed QKV, half-rotation RoPE on Q and K,
+// Q -> [heads, batch, hd], K/V -> cache rows kv_token_offset + batch_idx, layout [tokens, kv_heads, hd].
+__global__ void __launch_bounds__(256) attention_prepare_kernel(
+    const uint16_t* __restrict__ qkv, uint16_t* __restrict__ queries, uint16_t* __restrict__ keys,
+    uint16_t* __restrict__ values, const float* __restrict__ cosines, const float* __restrict__ sines,
+    uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset,
+    uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn) {
+    const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
+    const size_t total = (size_t)batch_dim * total_heads * head_dim;
+    const uint32_t pos0 = dyn ? *dyn : 0u;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t d = idx % head_dim;
+        const uint32_t head_idx = (idx / head_dim) % total_heads;
+        const uint32_t batch_idx = idx / ((size_t)head_dim * total_heads);
+        const uint16_t* head = qkv + (size_t)batch_idx * total_heads * head_dim + (size_t)head_idx * head_dim;
+        const bool is_query = !has_kv || head_idx < num_q_heads;
+        const bool is_key = has_kv && head_idx >= num_q_heads && head_idx < num_q_heads + num_kv_heads;
+        uint16_t element = head[d];
+        if (rope_dim && d < rope_dim && (is_query || is_key)) {
+            const uint32_t half = rope_dim / 2;
+            const uint32_t paired_idx = d < half ? d + half : d - half;
+            const float input = bf16_to_f32(head[d]);
+            const float paired = bf16_to_f32(head[paired_idx]);
+            const float signed_paired = d < half ? -paired : paired;
+            const size_t r = (size_t)(batch_idx + pos0) * rope_dim + d;
+            element = f32_to_bf16(input * cosines[r] + signed_paired * sines[r]);
+        }
+        if (is_query) {
+            queries[(size_t)head_idx * batch_dim * head_dim + (size_t)batch_idx * head_dim + d] = element;
+        } else if (is_key) {
+            keys[(size_t)(kv_token_offset + pos0 + batch_idx) * num_kv_heads * head_dim +
+                 (size_t)(head_idx - num_q_heads) * head_dim + d] = element;
+        } else {
+            values[(size_t)(kv_token_offset + pos0 + batch_idx) * num_kv_heads * head_dim +
+                   (size_t)(head_idx - num_q_heads - num_kv_heads) * head_dim + d] = element;
+        }
+    }
+}
+uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
+                             const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
+                             uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
+                             uint32_t has_kv, const uint32_t* dyn) {
+    const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
+    const size_t total = (size_t)batch_dim * total_heads * head_dim;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    return launch_check([&] {
+        hipLaunchKernelGGL(attention_prepare_kernel, dim3(blocks), dim3(256), 0, s, qkv, queries, keys, values, cosines,
+                           sines, num_q_heads, num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn);
+    }, "attention_prepare");
+}
+
+// =============================================================== KVCacheUpdate
+// BU/cpu/kernel/attention/kv_cache_update.rs:9-28.  The reference executes copies sequentially per
+// element column; copy lists on this path never chain (ring insert / accept compaction read rows of the
+// suffix region and write rows of the prefix region), so one thread per (copy, element) is equivalent.
+// Copies arrive as inline constants (<= MAX_INLINE_BYTES) and travel in the kernel argument buffer.
+struct CopyList {
+    uzu_kv_copy c[UZU_HIP_MAX_INLINE_BYTES / sizeof(uzu_kv_copy) / 2];
+};
+template <class T>
+__global__ void kv_cache_update_kernel(T* keys, T* values, CopyList list, uint32_t copy_count, uint32_t element_dim) {
+    const size_t total = (size_t)copy_count * element_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t e = idx % element_dim, i = idx / element_dim;
+        const size_t sidx = (size_t)list.c[i].source * element_dim + e, didx = (size_t)list.c[i].destination * element_dim + e;
+        keys[didx] = keys[sidx];
+        values[didx] = values[sidx];
+    }
+}
+uzu_status kv_cache_update(hipStream_t s, void* keys, void* values, uint32_t dt, const uzu_kv_copy* copies,
+                           uint32_t copy_count, uint32_t element_dim) {
+    constexpr uint32_t kMax = sizeof(CopyList) / sizeof(uzu_kv_copy);
+    for (uint32_t base = 0; base < copy_count; base += kMax) {
+        const uint32_t n = copy_count - base < kMax ? copy_count - base : kMax;
+        CopyList list;
+        for (uint32_t i = 0; i < n; ++i) list.c[i] = copies[base + i];
+        // a destination that is a later source would need the reference's sequential order
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = i + 1; j < n; ++j)
+                if (list.c[j].source == list.c[i].destination || list.c[j].destination == list.c[i].destination) {
+                    set_error("kv_cache_update: chained copy list is not supported");
+                    return UZU_ERR_UNSUPPORTED;
+                }
+        const size_t total = (size_t)n * element_dim;
+        const uint32_t blocks = (uint32_t)((total + 255) / 256);
+        uzu_status st = UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+            return launch_check([&] {
+                hipLaunchKernelGGL((kv_cache_update_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)keys, (T*)values, list, n, element_dim);
+            }, "kv_cache_update");
+        });
+        if (st != UZU_OK) return st;
+    }
+    return UZU_OK;
+}
+
+// =============================================================== SigmoidGate (sigmoid_gate.rs:9-22)
+template <class T> __global__ void sigmoid_gate_kernel(const T* gate, T* output, uint32_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = ld(gate, i);
+        const float sigmoid = 1.0f / (1.0f + expf_glibc(-g));
+        st(output, i, ld(output, i) * sigmoid);
+    }
+}
+uzu_status sigmoid_gate(hipStream_t s, const void* gate, void* output, uint32_t dt, uint32_t total) {
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((sigmoid_gate_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)gate, (T*)output, total); }, "sigmoid_gate");
+    });
+}
+
+// =============================================================== activations (gpu_types/activation_type.rs:16-65)
+template <class T> __device__ __forceinline__ float activate(uint32_t act, float x) {
+    switch (act) {
+    case 0: return rnd<T>(x / (1.0f + expf_glibc(-1.0f * x)));                                         // SILU
+    case 1: return rnd<T>(0.5f * x * (1.0f + tanhf(0.7978846f * (x + 0.044715f * x * x * x))));       // GELUApprox
+    case 2: return rnd<T>(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));                      // GELUExact
+    case 3: return x;                                                                                  // IDENTITY
+    case 4: return x > 20.0f ? x : rnd<T>(logf_glibc(1.0f + expf_glibc(x)));                           // SOFTPLUS
+    default: return x;
+    }
+}
+
+// =============================================================== GatedActMul (gated_act_mul.rs:36-70, mod.rs:5-12)
+template <class T>
+__global__ void gated_act_mul_kernel(const T* act_operand, const T* value_operand, T* fp_out, uint32_t gated_dim,
+                                     uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
+                                     uint32_t act_type, uint32_t interleaved) {
+    const size_t total = (size_t)gated_dim * batch_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t batch = idx / gated_dim, gated = idx % gated_dim;
+        size_t act_index;
+        float value;
+        if (interleaved) {
+            const size_t base = batch * 2 * gated_dim;
+            act_index = base + gated_dim + gated;
+            value = ld(act_operand, base + gated);
+        } else {
+            act_index = batch * gated_dim + gated;
+            value = ld(value_operand, batch * value_row_stride + value_offset + gated);
+        }
+        const float gate = ld(act_operand, act_index);
+        st(fp_out, idx, rnd<T>(value * activate<T>(act_type, gate)));
+    }
+}
+uzu_status gated_act_mul(hipStream_t s, const void* act_operand, const void* value_operand, void* fp_out, uint32_t dt,
+                         uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
+                         uint32_t act_type, uint32_t interleaved) {
+    const size_t total = (size_t)gated_dim * batch_dim;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] {
+            hipLaunchKernelGGL((gated_act_mul_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)act_operand, (const T*)value_operand,
+                               (T*)fp_out, gated_dim, batch_dim, value_offset, value_row_stride, act_type, interleaved);
+        }, "gated_act_mul");
+    });
+}
+
+// =============================================================== embedding lookups (quant_embedding.rs:36-116)
+template <class T>
+__global__ void quantized_embedding_lookup_kernel(const uint32_t* token_ids, const uint8_t* weights, const T* scales,
+                                                  const uint8_t* zero_points, const T* biases, T* output,
+                                                  uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                                  float input_scale, uint32_t group_size, uint32_t bits, uint32_t method) {
+    const uint32_t packing_divisor = 8 / bits;
+    const size_t weights_stride = model_dim / packing_divisor;
+    const size_t num_groups = (model_dim + group_size - 1) / group_size;
+    const size_t zero_points_stride = bits == 4 ? (num_groups + 1) / 2 : num_groups;
+    const size_t total = (size_t)batch_size * model_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / model_dim, dim_idx = idx % model_dim;
+        const uint32_t token_id = token_ids[b];
+        if (token_id >= vocab_size) {
+            st(output, idx, 0.0f);
+            continue;
+        }
+        const size_t group_idx = dim_idx / group_size;
+        const float scale = ld(scales, (size_t)token_id * num_groups + group_idx);
+        int quantized_value;
+        if (bits == 4) {
+            const uint8_t packed = weights[(size_t)token_id * weights_stride + dim_idx / 2];
+            quantized_value = (dim_idx & 1) == 0 ? (packed & 0x0F) : ((packed >> 4) & 0x0F);
+        } else {
+            quantized_value = weights[(size_t)token_id * weights_stride + dim_idx];
+        }
+        float bias;
+        if (method == 0) {
+            bias = ld(biases, (size_t)token_id * num_groups + group_idx);
+        } else if (method == 1) {
+            uint8_t zero_point;
+            if (bits == 4) {
+                const uint8_t packed = zero_points[(size_t)token_id * zero_points_stride + group_idx / 2];
+                zero_point = (group_idx & 1) == 0 ? (packed & 0x0F) : ((packed >> 4) & 0x0F);
+            } else {
+                zero_point = zero_points[(size_t)token_id * zero_points_stride + group_idx];
+            }
+            bias = -scale * (float)zero_point;
+        } else {
+            bias = -scale * (float)(1 << (bits - 1));
+        }
+        float out_f = scale * (float)quantized_value + bias;
+        out_f = out_f * input_scale;
+        st(output, idx, out_f);
+    }
+}
+uzu_status quantized_embedding_lookup(hipStream_t s, const uint32_t* token_ids, const uint8_t* weights,
+                                      const void* scales, const uint8_t* zero_points, const void* biases, void* output,
+                                      uint32_t dt, uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                      float input_scale, uint32_t group_size, uint32_t bits, uint32_t method) {
+    const size_t total = (size_t)batch_size * model_dim;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] {
+            hipLaunchKernelGGL((quantized_embedding_lookup_kernel<T>), dim3(blocks), dim3(256), 0, s, token_ids, weights, (const T*)scales,
+                               zero_points, (const T*)biases, (T*)output, batch_size, vocab_size, model_dim, input_scale,
+                               group_size, bits, method);
+        }, "quantized_embedding_lookup");
+    });
+}
+
+template <class T>
+__global__ void full_precision_embedding_lookup_kernel(const uint32_t* token_ids, const T* weights, T* output,
+                                                       uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                                       float input_scale) {
+    const size_t total = (size_t)batch_size * model_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / model_dim, d = idx % model_dim;
+        const uint32_t token_id = token_ids[b];
+        if (token_id >= vocab_size)
+            st(output, idx, 0.0f);
+        else
+            st(output, idx, ld(weights, (size_t)token_id * model_dim + d) * rnd<T>(input_scale));
+    }
+}
+uzu_status full_precision_embedding_lookup(hipStream_t s, const uint32_t* token_ids, const void* weights, void* output,
+                                           uint32_t dt, uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                           float input_scale) {
+    const size_t total = (size_t)batch_size * model_dim;
+    if (!total) return UZU_OK;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] {
+            hipLaunchKernelGGL((full_precision_embedding_lookup_kernel<T>), dim3(blocks), dim3(256), 0, s, token_ids, (const T*)weights,
+                               (T*)output, batch_size, vocab_size, model_dim, input_scale);
+        }, "full_precision_embedding_lookup");
+    });
+}
+
+// =============================================================== LogitTransform / Tensor*
+template <class T>
+__global__ void logit_transform_kernel(T* logits, uint32_t length, float scale, float soft_cap, uint32_t has_soft_cap) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (size_t)gridDim.x * blockDim.x) {
+        float value = ld(logits, i) * scale;
+        if (has_soft_cap) value = tanhf(value / soft_cap) * soft_cap; // NB: ocml tanhf, <= 1 ulp from glibc
+        st(logits, i, value);
+    }
+}
+uzu_status logit_transform(hipStream_t s, void* logits, uint32_t dt, uint32_t length, float scale, float soft_cap,
+                           uint32_t has_soft_cap) {
+    if (!length) return UZU_OK;
+    const uint32_t blocks = (length + 255) / 256 > 4096 ? 4096 : (length + 255) / 256;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((logit_transform_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)logits, length, scale, soft_cap, has_soft_cap); }, "logit_transform");
+    });
+}
+
+template <class T, class TB>
+__global__ void tensor_add_bias_kernel(const T* input, const TB* bias, T* output, uint32_t num_cols, uint32_t length) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (size_t)gridDim.x * blockDim.x)
+        st(output, i, ld(input, i) + ld(bias, i % num_cols));
+}
+uzu_status tensor_add_bias(hipStream_t s, const void* input, const void* bias, void* output, uint32_t dt,
+                           uint32_t bias_dt, uint32_t num_cols, uint32_t length) {
+    if (!length) return UZU_OK;
+    const void* in = input ? input : output;
+    const uint32_t blocks = (length + 255) / 256 > 4096 ? 4096 : (length + 255) / 256;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        if (bias_dt == UZU_F32)
+            return launch_check([&] { hipLaunchKernelGGL((tensor_add_bias_kernel<T, float>), dim3(blocks), dim3(256), 0, s, (const T*)in, (const float*)bias, (T*)output, num_cols, length); }, "tensor_add_bias");
+        return launch_check([&] { hipLaunchKernelGGL((tensor_add_bias_kernel<T, bf16_t>), dim3(blocks), dim3(256), 0, s, (const T*)in, (const bf16_t*)bias, (T*)output, num_cols, length); }, "tensor_add_bias");
+    });
+}
+template <class T>
+__global__ void tensor_add_scale_kernel(const T* input, const T* bias, T* output, uint32_t num_cols, uint32_t length, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (size_t)gridDim.x * blockDim.x)
+        st(output, i, (ld(input, i) + ld(bias, i % num_cols)) * scale);
+}
+uzu_status tensor_add_scale(hipStream_t s, const void* input, const void* bias, void* output, uint32_t dt,
+                            uint32_t num_cols, uint32_t length, float scale) {
+    if (!length) return UZU_OK;
+    const void* in = input ? input : output;
+    const uint32_t blocks = (length + 255) / 256 > 4096 ? 4096 : (length + 255) / 256;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((tensor_add_scale_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)in, (const T*)bias, (T*)output, num_cols, length, scale); }, "tensor_add_scale");
+    });
+}
+template <class T> __global__ void tensor_add_swap_kernel(T* skip, T* main_buf, uint32_t length) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (size_t)gridDim.x * blockDim.x) {
+        const float r = rnd<T>(ld(skip, i) + ld(main_buf, i));
+        st(skip, i, r);
+        st(main_buf, i, r);
+    }
+}
+uzu_status tensor_add_swap(hipStream_t s, void* skip, void* main_buf, uint32_t dt, uint32_t length) {
+    if (!length) return UZU_OK;
+    const uint32_t blocks = (length + 255) / 256 > 4096 ? 4096 : (length + 255) / 256;
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((tensor_add_swap_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)skip, (T*)main_buf, length); }, "tensor_add_swap");
+    });
+}
+uzu_status tensor_copy(hipStream_t s, const void* src, void* dst, uint32_t dt, uint32_t length) {
+    const size_t bytes = (size_t)length * (dt == UZU_F32 ? 4 : 2);
+    if (!bytes) return UZU_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) {
+        set_error("tensor_copy: %s", hipGetErrorString(e));
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
+
+// =============================================================== greedy UnifiedSampling
+// BU/cpu/kernel/sampling/unified_sampling.rs:90-98: arg-max, ties -> lowest index.  Two passes:
+// up to 1024 workgroups reduce strided slices to (value, index) pairs, one workgroup finishes.
+// (value, index) order: larger value wins; equal value -> smaller index wins; NaN never wins.
+__device__ __forceinline__ void amax_combine(float& bv, uint32_t& bi, float v, uint32_t i) {
+    if (v > bv || (v == bv && i < bi)) {
+        bv = v;
+        bi = i;
+    }
+}
+template <class T>
+__global__ void __launch_bounds__(256) argmax_pass1(const T* logits, uint32_t vocab_size, float* pv, uint32_t* pi) {
+    __shared__ float sv[4];
+    __shared__ uint32_t si[4];
+    const uint32_t row = blockIdx.y;
+    const T* l = logits + (size_t)row * vocab_size;
+    // element 0 is the initial candidate exactly as in the reference's fold
+    float bv = ld(l, 0);
+    uint32_t bi = 0;
+    if (!(bv == bv)) bv = INFINITY; // reference fold: a NaN first element is never replaced (partial_cmp -> Equal -> keep)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < vocab_size; i += gridDim.x * blockDim.x)
+        amax_combine(bv, bi, ld(l, i), i);
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const uint32_t oi = __shfl_xor(bi, off, 64);
+        amax_combine(bv, bi, ov, oi);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sv[wave] = bv, si[wave] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_combine(bv, bi, sv[w], si[w]);
+        pv[(size_t)row * gridDim.x + blockIdx.x] = bv;
+        pi[(size_t)row * gridDim.x + blockIdx.x] = bi;
+    }
+}
+__global__ void __launch_bounds__(256) argmax_pass2(const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* output) {
+    __shared__ float sv[4];
+    __shared__ uint32_t si[4];
+    const uint32_t row = blockIdx.x;
+    float bv = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < parts; i += blockDim.x) amax_combine(bv, bi, pv[(size_t)row * parts + i], pi[(size_t)row * parts + i]);
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const uint32_t oi = __shfl_xor(bi, off, 64);
+        amax_combine(bv, bi, ov, oi);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sv[wave] = bv, si[wave] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_combine(bv, bi, sv[w], si[w]);
+        output[row] = bi == 0xFFFFFFFFu ? 0u : bi;
+    }
+}
+static constexpr uint32_t kArgmaxParts = 256;
+size_t argmax_scratch_bytes(uint32_t batch_size) { return (size_t)batch_size * kArgmaxParts * 8; }
+uzu_status argmax(hipStream_t s, const void* logits, uint32_t dt, uint32_t* output, uint32_t vocab_size,
+                  uint32_t batch_size, void* scratch) {
+    if (!batch_size) return UZU_OK;
+    float* pv = (float*)scratch;
+    uint32_t* pi = (uint32_t*)((char*)scratch + (size_t)batch_size * kArgmaxParts * 4);
+    uint32_t parts = (vocab_size + 1023) / 1024;
+    if (parts > kArgmaxParts) parts = kArgmaxParts;
+    if (parts == 0) parts = 1;
+    UZU_PROPAGATE(UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((argmax_pass1<T>), dim3(parts, batch_size), dim3(256), 0, s, (const T*)logits, vocab_size, pv, pi); }, "argmax_pass1");
+    }));
+    return launch_check([&] { hipLaunchKernelGGL(argmax_pass2, dim3(batch_size), dim3(256), 0, s, pv, pi, parts, output); }, "argmax_pass2");
+}
+
+// =============================================================== engine helpers
+__global__ void advance_u32_kernel(uint32_t* counter, uint32_t amount) { *counter += amount; }
+uzu_status advance_u32(hipStream_t s, uint32_t* counter, uint32_t amount) {
+    return launch_check([&] { hipLaunchKernelGGL(advance_u32_kernel, dim3(1), dim3(1), 0, s, counter, amount); }, "advance_u32");
+}
+__global__ void fill_u32_kernel(uint32_t* dst, uint32_t value, uint32_t count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) dst[i] = value;
+}
+uzu_status fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, uint32_t count) {
+    if (!count) return UZU_OK;
+    return launch_check([&] { hipLaunchKernelGGL(fill_u32_kernel, dim3((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256), dim3(256), 0, s, dst, value, count); }, "fill_u32");
+}
+
+} // namespace k
+} // namespace uzu

@@ -1,0 +1,146 @@
+// kernels.h -- launch interface of the gfx950 kernels (raw device pointers + stream).
+// Used by the C-ABI wrappers (capi_kernels.cpp) and by the model driver (engine.cpp).
+//
+// `dyn` arguments: optional device pointer to the sequence's current context length (u32).  When
+// non-null the kernel adds *dyn to the position-like scalar it documents.  This is what lets one
+// captured hipGraph be replayed for every decode step (SURVEY.md build-plan step 6): the only thing
+// that changes between steps lives in device memory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uzu_hip.h"
+
+namespace uzu {
+namespace k {
+
+enum DT : uint32_t { BF16 = UZU_BF16, F32 = UZU_F32 };
+
+// ---------------------------------------------------------------- matmul (quantised / full-precision B)
+struct MatmulParams {
+    const void* a;      // [m,k] input dtype
+    const void* b;      // codes [n, k*bits/8] or full precision [n,k]
+    const void* scales; // weights dtype [n, groups]
+    const void* biases; // weights dtype [n, groups] (ScaleBias)
+    const uint8_t* zero_points;
+    void* d;            // [m,n] output dtype
+    const void* bias;   // weights dtype [n]
+    const uint32_t* gather; // [m,n] or null
+    uint32_t w_dt, a_dt, d_dt;
+    uint32_t b_kind;    // uzu_matmul_b_kind
+    uint32_t bits;      // 4 / 8 (quantised)
+    uint32_t group_size;
+    uint32_t signed_codes;
+    float ab_scale;
+    uint32_t accumulate;
+    uint32_t has_soft_cap;
+    float soft_cap;
+    uint32_t m, n, k;
+    // ---- fused prologue / epilogue options used by the engine (all 0 through the C ABI) ----
+    uint32_t act_mul;   // epilogue: rows [0,n/2) = up, [n/2,n) = gate; writes d[m, n/2] = up * act(gate)
+    uint32_t act_type;
+};
+// `variant` (optional) receives a short label of the kernel instance chosen (for per-kernel profiles)
+uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char** variant = nullptr);
+size_t matmul_algorithmic_bytes(const MatmulParams& p); // codes + scales + correction + A + D, SURVEY.md §8d
+
+// ---------------------------------------------------------------- normalization
+struct NormParams {
+    const void* input; // null => in place
+    const void* scales;
+    const void* biases;
+    void* output;
+    void* shortcut;
+    uint32_t io_dt, affine_dt;
+    uint32_t batch_size, element_count;
+    float epsilon, scale_offset, post_layer_scalar;
+    uint32_t subtract_mean, full_layer, copy_to_shortcut, residual_add, scale_residual_sum, scale_output;
+};
+uzu_status normalization(hipStream_t s, const NormParams& p);
+
+uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, uint32_t batch_size,
+                    uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset, uint32_t head_offset,
+                    uint32_t head_count, uint32_t full_layer);
+
+// dyn: kv_token_offset += *dyn; cos/sin row index += *dyn (tables indexed by absolute position)
+uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
+                             const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
+                             uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
+                             uint32_t has_kv, const uint32_t* dyn);
+
+struct AttentionParams {
+    const void* queries;
+    const void* keys;
+    const void* values;
+    uint32_t dt;
+    uint32_t head_dim, gqa_factor, sequence_length; // dyn: sequence_length += *dyn
+    uint32_t k_head_stride, k_seq_stride, v_head_stride, v_seq_stride;
+    uint32_t is_kv_cache_ring, ring_offset, ring_length;
+    float scale;
+    uint32_t is_sliding_window, sliding_window_size;
+    const void* sinks;
+    uint32_t num_heads, suffix_length, is_causal;
+    const uint32_t* dyn;
+};
+uzu_status attention_single_pass(hipStream_t s, const AttentionParams& p, void* out);
+uzu_status attention_two_pass1(hipStream_t s, const AttentionParams& p, float* partials, float* sums, float* maxs);
+uzu_status attention_two_pass2(hipStream_t s, const float* partials, const float* sums, const float* maxs, void* out,
+                               uint32_t dt, uint32_t head_dim, uint32_t num_heads, uint32_t suffix_length);
+
+uzu_status kv_cache_update(hipStream_t s, void* keys, void* values, uint32_t dt, const uzu_kv_copy* copies_host,
+                           uint32_t copy_count, uint32_t element_dim);
+uzu_status sigmoid_gate(hipStream_t s, const void* gate, void* output, uint32_t dt, uint32_t total);
+uzu_status gated_act_mul(hipStream_t s, const void* act_operand, const void* value_operand, void* fp_out, uint32_t dt,
+                         uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
+                         uint32_t act_type, uint32_t interleaved);
+uzu_status quantized_embedding_lookup(hipStream_t s, const uint32_t* token_ids, const uint8_t* weights,
+                                      const void* scales, const uint8_t* zero_points, const void* biases, void* output,
+                                      uint32_t dt, uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                      float input_scale, uint32_t group_size, uint32_t bits, uint32_t method);
+uzu_status full_precision_embedding_lookup(hipStream_t s, const uint32_t* token_ids, const void* weights, void* output,
+                                           uint32_t dt, uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
+                                           float input_scale);
+uzu_status logit_transform(hipStream_t s, void* logits, uint32_t dt, uint32_t length, float scale, float soft_cap,
+                           uint32_t has_soft_cap);
+uzu_status tensor_add_bias(hipStream_t s, const void* input, const void* bias, void* output, uint32_t dt,
+                           uint32_t bias_dt, uint32_t num_cols, uint32_t length);
+uzu_status tensor_add_scale(hipStream_t s, const void* input, const void* bias, void* output, uint32_t dt,
+                            uint32_t num_cols, uint32_t length, float scale);
+uzu_status tensor_add_swap(hipStream_t s, void* skip, void* main_buf, uint32_t dt, uint32_t length);
+uzu_status tensor_copy(hipStream_t s, const void* src, void* dst, uint32_t dt, uint32_t length);
+// greedy UnifiedSampling; scratch: >= 2 * batch * 1024 u32 words (device)
+uzu_status argmax(hipStream_t s, const void* logits, uint32_t dt, uint32_t* output, uint32_t vocab_size,
+                  uint32_t batch_size, void* scratch);
+size_t argmax_scratch_bytes(uint32_t batch_size);
+
+// ---------------------------------------------------------------- gated delta net
+uzu_status delta_net_conv_update(hipStream_t s, const float* conv_weight, const float* bias, uint16_t* in_out,
+                                 float* state, uint32_t kernel_size, uint32_t conv_dim, uint32_t state_stride);
+uzu_status delta_net_update(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias,
+                            const float* norm_weight, float* state, uint16_t* out, uint32_t num_v_heads,
+                            uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
+                            uint32_t value_dim, float norm_epsilon);
+uzu_status conv1d_pack(hipStream_t s, const float* state_in, const uint16_t* x, float* padded, uint32_t state_stride,
+                       uint32_t row_stride, uint32_t suffix_len, uint32_t num_channels);
+uzu_status delta_net_conv_scan(hipStream_t s, const float* conv_padded, const float* conv_weight, const float* bias,
+                               uint16_t* in_proj, float* state_out, uint32_t suffix_len, uint32_t kernel_size,
+                               uint32_t row_stride, uint32_t state_stride, uint32_t conv_dim, uint32_t out_stride);
+uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias,
+                                  float* q_norm_out, float* k_norm_out, float* beta_out, float* decay_out,
+                                  uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim,
+                                  uint32_t value_dim, uint32_t suffix_len);
+uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta,
+                             const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
+                             uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
+                             uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
+                               uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
+                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
+
+// ---------------------------------------------------------------- engine helpers
+uzu_status advance_u32(hipStream_t s, uint32_t* counter, uint32_t amount); // *counter += amount
+uzu_status fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, uint32_t count);
+
+} // namespace k
+} // namespace uzu

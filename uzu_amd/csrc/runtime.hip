@@ -1,0 +1,324 @@
+// runtime.hip -- Context / Buffer / CommandBuffer of the HIP backend (C ABI, include/uzu_hip.h).
+//
+// Mirrors BU/backends/common/{context.rs,buffer/*.rs,command_buffer.rs}.  MI355X-native choices:
+//   * device memory is plain hipMalloc (HBM); host visibility is an explicit pinned mirror + async copies
+//     on the context stream (never host-mapped device memory on the kernel path);
+//   * one in-order HIP stream per context = the reference's "command buffers execute in submission order";
+//   * a command buffer is either eager (kernels are enqueued as they are encoded) or a captured hipGraph
+//     that submit() launches -- the launch-latency answer for decode loops.
+#include <string.h>
+
+#include <mutex>
+
+#include "internal.h"
+
+namespace uzu {
+
+static thread_local char g_error[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+uzu_status cmdbuf_check_encoding(uzu_hip_cmdbuf* cb) {
+    if (!cb) {
+        set_error("null command buffer");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    if (cb->state != CmdbufState::Encoding) {
+        set_error("command buffer '%s' is not in the Encoding state", cb->name.c_str());
+        return UZU_ERR_STATE;
+    }
+    return UZU_OK;
+}
+
+} // namespace uzu
+
+using namespace uzu;
+
+extern "C" {
+
+const char* uzu_hip_last_error(void) { return g_error; }
+
+// ---------------------------------------------------------------------------------- Context
+uzu_status uzu_hip_context_create(int32_t device_ordinal, uzu_hip_context** out) {
+    UZU_REQUIRE(out != nullptr, "context_create: out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        set_error("no HIP device available (%s): the uzu HIP backend needs an AMD GPU, there is no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return UZU_ERR_HIP;
+    }
+    UZU_REQUIRE(device_ordinal >= 0 && device_ordinal < count, "context_create: device %d out of range (0..%d)", device_ordinal, count - 1);
+    UZU_HIP_TRY(hipSetDevice(device_ordinal));
+    auto* ctx = new uzu_hip_context();
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop;
+    UZU_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    ctx->num_cus = prop.multiProcessorCount;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    UZU_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->staging_size = 64u << 20;
+    UZU_HIP_TRY(hipHostMalloc(&ctx->staging, ctx->staging_size, hipHostMallocDefault));
+    *out = ctx;
+    return UZU_OK;
+}
+
+void uzu_hip_context_destroy(uzu_hip_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->staging) (void)hipHostFree(ctx->staging);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+uzu_status uzu_hip_context_peak_memory_usage(uzu_hip_context* ctx, size_t* out) {
+    UZU_REQUIRE(ctx && out, "peak_memory_usage: null argument");
+    *out = ctx->peak_bytes;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_context_device_name(uzu_hip_context* ctx, char* out, size_t cap) {
+    UZU_REQUIRE(ctx && out && cap, "device_name: null argument");
+    snprintf(out, cap, "%s", ctx->name);
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_context_synchronize(uzu_hip_context* ctx) {
+    UZU_REQUIRE(ctx, "synchronize: null context");
+    UZU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return UZU_OK;
+}
+
+void* uzu_hip_context_stream(uzu_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------- Buffer
+uzu_status uzu_hip_buffer_create(uzu_hip_context* ctx, size_t size, uzu_hip_buffer** out) {
+    UZU_REQUIRE(ctx && out, "buffer_create: null argument");
+    (void)hipSetDevice(ctx->device);
+    auto* b = new uzu_hip_buffer();
+    b->ctx = ctx;
+    b->size = size;
+    const size_t alloc = size ? (size + 255) & ~(size_t)255 : 256;
+    hipError_t e = hipMalloc(&b->dptr, alloc);
+    if (e != hipSuccess) {
+        delete b;
+        set_error("hipMalloc(%zu) failed: %s", alloc, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
+    }
+    ctx->current_bytes += alloc;
+    if (ctx->current_bytes > ctx->peak_bytes) ctx->peak_bytes = ctx->current_bytes;
+    *out = b;
+    return UZU_OK;
+}
+
+void uzu_hip_buffer_destroy(uzu_hip_buffer* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream); // work encoded against this buffer may still be in flight
+    if (b->mirror) (void)hipHostFree(b->mirror);
+    if (b->dptr) (void)hipFree(b->dptr);
+    const size_t alloc = b->size ? (b->size + 255) & ~(size_t)255 : 256;
+    b->ctx->current_bytes -= alloc;
+    delete b;
+}
+
+uint64_t uzu_hip_buffer_gpu_ptr(const uzu_hip_buffer* b) { return b ? (uint64_t)(uintptr_t)b->dptr : 0; }
+size_t uzu_hip_buffer_size(const uzu_hip_buffer* b) { return b ? b->size : 0; }
+
+uzu_status uzu_hip_buffer_cpu_ptr(uzu_hip_buffer* b, void** out) {
+    UZU_REQUIRE(b && out, "buffer_cpu_ptr: null argument");
+    if (!b->mirror) {
+        UZU_HIP_TRY(hipHostMalloc(&b->mirror, b->size ? b->size : 1, hipHostMallocDefault));
+        memset(b->mirror, 0, b->size);
+    }
+    *out = b->mirror;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_buffer_flush_to_device(uzu_hip_buffer* b, size_t offset, size_t size) {
+    UZU_REQUIRE(b && b->mirror, "flush_to_device: buffer has no host mirror");
+    UZU_REQUIRE(offset + size <= b->size, "flush_to_device: range out of bounds");
+    UZU_HIP_TRY(hipMemcpyAsync((char*)b->dptr + offset, (char*)b->mirror + offset, size, hipMemcpyHostToDevice, b->ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_buffer_fetch_from_device(uzu_hip_buffer* b, size_t offset, size_t size) {
+    UZU_REQUIRE(b, "fetch_from_device: null buffer");
+    void* p;
+    UZU_PROPAGATE(uzu_hip_buffer_cpu_ptr(b, &p));
+    UZU_REQUIRE(offset + size <= b->size, "fetch_from_device: range out of bounds");
+    UZU_HIP_TRY(hipMemcpyAsync((char*)b->mirror + offset, (char*)b->dptr + offset, size, hipMemcpyDeviceToHost, b->ctx->stream));
+    UZU_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_buffer_upload(uzu_hip_buffer* b, size_t offset, const void* src, size_t size) {
+    UZU_REQUIRE(b && (src || !size), "buffer_upload: null argument");
+    UZU_REQUIRE(offset + size <= b->size, "buffer_upload: range [%zu,+%zu) exceeds buffer size %zu", offset, size, b->size);
+    uzu_hip_context* ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    // pageable source: bounce through the pinned staging buffer in stream order
+    size_t done = 0;
+    while (done < size) {
+        const size_t n = size - done < ctx->staging_size ? size - done : ctx->staging_size;
+        UZU_HIP_TRY(hipStreamSynchronize(ctx->stream)); // staging buffer is reused
+        memcpy(ctx->staging, (const char*)src + done, n);
+        UZU_HIP_TRY(hipMemcpyAsync((char*)b->dptr + offset + done, ctx->staging, n, hipMemcpyHostToDevice, ctx->stream));
+        done += n;
+    }
+    UZU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_buffer_download(uzu_hip_buffer* b, size_t offset, void* dst, size_t size) {
+    UZU_REQUIRE(b && (dst || !size), "buffer_download: null argument");
+    UZU_REQUIRE(offset + size <= b->size, "buffer_download: range [%zu,+%zu) exceeds buffer size %zu", offset, size, b->size);
+    uzu_hip_context* ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    size_t done = 0;
+    while (done < size) {
+        const size_t n = size - done < ctx->staging_size ? size - done : ctx->staging_size;
+        UZU_HIP_TRY(hipMemcpyAsync(ctx->staging, (char*)b->dptr + offset + done, n, hipMemcpyDeviceToHost, ctx->stream));
+        UZU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy((char*)dst + done, ctx->staging, n);
+        done += n;
+    }
+    return UZU_OK;
+}
+
+// ---------------------------------------------------------------------------------- CommandBuffer
+uzu_status uzu_hip_cmdbuf_create(uzu_hip_context* ctx, const char* name, uint32_t flags, uzu_hip_cmdbuf** out) {
+    UZU_REQUIRE(ctx && out, "cmdbuf_create: null argument");
+    (void)hipSetDevice(ctx->device);
+    auto* cb = new uzu_hip_cmdbuf();
+    cb->ctx = ctx;
+    cb->name = name ? name : "";
+    cb->flags = flags;
+    UZU_HIP_TRY(hipEventCreate(&cb->ev_start));
+    UZU_HIP_TRY(hipEventCreate(&cb->ev_end));
+    *out = cb;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_start_encoding(uzu_hip_cmdbuf* cb) {
+    UZU_REQUIRE(cb, "start_encoding: null command buffer");
+    if (cb->state != CmdbufState::Initial) {
+        set_error("start_encoding: command buffer '%s' is not Initial", cb->name.c_str());
+        return UZU_ERR_STATE;
+    }
+    if (cb->flags & UZU_CMDBUF_GRAPH) {
+        UZU_HIP_TRY(hipStreamBeginCapture(cb->ctx->stream, hipStreamCaptureModeThreadLocal));
+    } else {
+        UZU_HIP_TRY(hipEventRecord(cb->ev_start, cb->ctx->stream));
+    }
+    cb->state = CmdbufState::Encoding;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_encode_copy(uzu_hip_cmdbuf* cb, uzu_buf src, uzu_buf dst, size_t size) {
+    UZU_PROPAGATE(cmdbuf_check_encoding(cb));
+    UZU_REQUIRE(src.buffer && dst.buffer, "encode_copy: null buffer");
+    UZU_REQUIRE(src.offset + size <= src.buffer->size && dst.offset + size <= dst.buffer->size, "encode_copy: range out of bounds");
+    if (!size) return UZU_OK;
+    UZU_HIP_TRY(hipMemcpyAsync(bptr(dst), bptr(src), size, hipMemcpyDeviceToDevice, cb->ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_encode_fill(uzu_hip_cmdbuf* cb, uzu_buf dst, size_t size, uint8_t value) {
+    UZU_PROPAGATE(cmdbuf_check_encoding(cb));
+    UZU_REQUIRE(dst.buffer, "encode_fill: null buffer");
+    UZU_REQUIRE(dst.offset + size <= dst.buffer->size, "encode_fill: range out of bounds");
+    if (!size) return UZU_OK;
+    UZU_HIP_TRY(hipMemsetAsync(bptr(dst), value, size, cb->ctx->stream));
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_encode_barrier(uzu_hip_cmdbuf* cb) { return cmdbuf_check_encoding(cb); }
+
+uzu_status uzu_hip_cmdbuf_push_debug_group(uzu_hip_cmdbuf* cb, const char* name) {
+    UZU_PROPAGATE(cmdbuf_check_encoding(cb));
+    cb->debug_groups.push_back(name ? name : "");
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_pop_debug_group(uzu_hip_cmdbuf* cb) {
+    UZU_PROPAGATE(cmdbuf_check_encoding(cb));
+    UZU_REQUIRE(!cb->debug_groups.empty(), "pop_debug_group: no open group");
+    cb->debug_groups.pop_back();
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_end_encoding(uzu_hip_cmdbuf* cb) {
+    UZU_PROPAGATE(cmdbuf_check_encoding(cb));
+    if (cb->flags & UZU_CMDBUF_GRAPH) {
+        UZU_HIP_TRY(hipStreamEndCapture(cb->ctx->stream, &cb->graph));
+        UZU_HIP_TRY(hipGraphInstantiate(&cb->graph_exec, cb->graph, nullptr, nullptr, 0));
+    }
+    cb->state = CmdbufState::Executable;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_submit(uzu_hip_cmdbuf* cb) {
+    UZU_REQUIRE(cb, "submit: null command buffer");
+    const bool graph = (cb->flags & UZU_CMDBUF_GRAPH) != 0;
+    // a graph command buffer may be re-submitted after completion (replay)
+    if (!(cb->state == CmdbufState::Executable || (graph && cb->state == CmdbufState::Completed))) {
+        set_error("submit: command buffer '%s' is not Executable", cb->name.c_str());
+        return UZU_ERR_STATE;
+    }
+    if (graph) {
+        UZU_HIP_TRY(hipEventRecord(cb->ev_start, cb->ctx->stream));
+        UZU_HIP_TRY(hipGraphLaunch(cb->graph_exec, cb->ctx->stream));
+    }
+    UZU_HIP_TRY(hipEventRecord(cb->ev_end, cb->ctx->stream));
+    cb->state = CmdbufState::Pending;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_wait_until_completed(uzu_hip_cmdbuf* cb) {
+    UZU_REQUIRE(cb, "wait_until_completed: null command buffer");
+    if (cb->state != CmdbufState::Pending) {
+        set_error("wait_until_completed: command buffer '%s' is not Pending", cb->name.c_str());
+        return UZU_ERR_STATE;
+    }
+    UZU_HIP_TRY(hipEventSynchronize(cb->ev_end));
+    UZU_HIP_TRY(hipEventElapsedTime(&cb->last_ms, cb->ev_start, cb->ev_end));
+    cb->state = CmdbufState::Completed;
+    return UZU_OK;
+}
+
+uzu_status uzu_hip_cmdbuf_gpu_execution_time_ns(uzu_hip_cmdbuf* cb, uint64_t* out) {
+    UZU_REQUIRE(cb && out, "gpu_execution_time: null argument");
+    if (cb->state != CmdbufState::Completed) {
+        set_error("gpu_execution_time: command buffer '%s' is not Completed", cb->name.c_str());
+        return UZU_ERR_STATE;
+    }
+    *out = (uint64_t)((double)cb->last_ms * 1e6);
+    return UZU_OK;
+}
+
+void uzu_hip_cmdbuf_destroy(uzu_hip_cmdbuf* cb) {
+    if (!cb) return;
+    (void)hipSetDevice(cb->ctx->device);
+    if (cb->state == CmdbufState::Encoding && (cb->flags & UZU_CMDBUF_GRAPH)) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(cb->ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+    }
+    if (cb->state == CmdbufState::Pending) (void)hipEventSynchronize(cb->ev_end);
+    if (cb->graph_exec) (void)hipGraphExecDestroy(cb->graph_exec);
+    if (cb->graph) (void)hipGraphDestroy(cb->graph);
+    (void)hipEventDestroy(cb->ev_start);
+    (void)hipEventDestroy(cb->ev_end);
+    delete cb;
+}
+
+void uzu_hip_kernel_destroy(uzu_hip_kernel* k) { delete k; }
+
+} // extern "C"

@@ -1,0 +1,100 @@
+"""Python handle on the C++ model driver (include/uzu_hip_engine.h): HipModel.
+
+Plays the role of ``LanguageModel`` + ``LanguageModelState`` + ``LanguageModelStream`` for one sequence
+(crates/backend-uzu/src/engine/language_model/{mod.rs,state.rs,stream/stream.rs}): prefill in chunks of
+<= 1024 tokens, then chained greedy decode.  All compute runs in libuzu_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import call
+from .backend import Context
+from .desc import ModelBundle
+
+MODEL_DEFAULT, MODEL_NO_GRAPH, MODEL_NO_FUSION, MODEL_DEBUG_TAPS = 0, 1, 2, 4
+
+
+class HipModel:
+    def __init__(self, ctx: Context, bundle: ModelBundle, flags: int = MODEL_DEFAULT):
+        self.ctx = ctx
+        self.vocab_size = bundle.vocab_size
+        self.model_dim = bundle.model_dim
+        self.num_layers = len(bundle.layers)
+        desc = bundle.desc()
+        self._h = C.c_void_p()
+        call("uzu_hip_model_create", ctx._h, C.byref(desc), C.c_uint32(flags), C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            _ffi.lib().uzu_hip_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        call("uzu_hip_model_reset", self._h)
+
+    @property
+    def context_length(self) -> int:
+        return _ffi.lib().uzu_hip_model_context_length(self._h)
+
+    @property
+    def weight_bytes(self) -> int:
+        return _ffi.lib().uzu_hip_model_weight_bytes(self._h)
+
+    @property
+    def decode_launch_count(self) -> int:
+        return _ffi.lib().uzu_hip_model_decode_launch_count(self._h)
+
+    def prefill(self, tokens) -> int:
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        first = C.c_uint32()
+        call("uzu_hip_model_prefill", self._h, C.c_void_p(tokens.ctypes.data), C.c_uint32(tokens.size), C.byref(first))
+        return first.value
+
+    def decode(self, steps: int) -> Tuple[np.ndarray, float]:
+        out = np.empty(steps, dtype=np.uint32)
+        ms = C.c_float()
+        call("uzu_hip_model_decode", self._h, C.c_uint32(steps), C.c_void_p(out.ctypes.data), C.byref(ms))
+        return out, ms.value
+
+    def decode_enqueue(self, steps: int):
+        call("uzu_hip_model_decode_enqueue", self._h, C.c_uint32(steps))
+
+    def read_tokens(self, first_position: int, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.uint32)
+        call("uzu_hip_model_read_tokens", self._h, C.c_uint32(first_position), C.c_uint32(count), C.c_void_p(out.ctypes.data))
+        return out
+
+    def set_next_token(self, token: int):
+        call("uzu_hip_model_set_next_token", self._h, C.c_uint32(int(token)))
+
+    def read_logits(self) -> np.ndarray:
+        out = np.empty(self.vocab_size, dtype=np.uint16)
+        call("uzu_hip_model_read_logits", self._h, C.c_void_p(out.ctypes.data))
+        return out
+
+    def read_layer_output(self, layer: int) -> np.ndarray:
+        out = np.empty(1024 * self.model_dim, dtype=np.uint16)
+        rows = C.c_uint32()
+        call("uzu_hip_model_read_layer_output", self._h, C.c_uint32(layer), C.c_void_p(out.ctypes.data), C.byref(rows))
+        return out[: rows.value * self.model_dim].reshape(rows.value, self.model_dim).copy()
+
+    def profile_decode_step(self, capacity: int = 4096):
+        """One eager decode step with HIP events around every kernel -> list of (label, algorithmic_bytes, ms)."""
+        names = (C.c_char_p * capacity)()
+        nbytes = (C.c_uint64 * capacity)()
+        ms = (C.c_float * capacity)()
+        count = C.c_uint32()
+        call("uzu_hip_model_profile_decode_step", self._h, C.c_uint32(capacity), names, nbytes, ms, C.byref(count))
+        return [(names[i].decode(), int(nbytes[i]), float(ms[i])) for i in range(count.value)]
