@@ -54,7 +54,7 @@ def cpu_baseline(bundle, cfg, decode_tokens):
     dt = time.perf_counter() - t0
     one = decode_tokens / dt
     # courtesy figure: OpenMP over independent output rows (bit-identical results), all host cores
-    cores = os.cpu_count() or 1
+    cores = O.default_threads()
     O.set_threads(cores)
     t0 = time.perf_counter()
     for _ in range(decode_tokens):

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP workers sleep instead of spinning
 
 BF16, F32 = 0, 2
 
@@ -88,7 +89,22 @@ def lib() -> C.CDLL:
         _lib.orc_activate.argtypes = [C.c_uint32, C.c_float, C.c_uint32]
         _lib.orc_activate.restype = C.c_float
         _lib.orc_get_max_threads.restype = C.c_int
+        _lib.orc_set_threads(C.c_int(default_threads()))
     return _lib
+
+
+def default_threads() -> int:
+    """Threads the oracle may use: CPU affinity, capped by the cgroup CPU quota and by 16.  (A GPU box can
+    expose 256 logical CPUs to a container that is only allowed a few: an OpenMP team of 256 spinning threads
+    then makes every parallel region crawl.)  Results never depend on the thread count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
 
 
 def set_threads(n: int) -> None:

@@ -81,7 +81,7 @@ void orc_matmul(const orc_matmul_args* g) {
     size_t ld = g->b_leading_dimension ? g->b_leading_dimension : (g->b_transpose ? k : n);
 
     for (size_t row = 0; row < m; ++row) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * k >= 262144)
         for (size_t col = 0; col < n; ++col) {
             const size_t b_col = g->gather_indices ? g->gather_indices[row * n + col] : col;
             float accumulator = 0.0f;
@@ -140,7 +140,7 @@ void orc_normalization(const orc_norm_args* g) {
     const void* input = g->input ? g->input : g->output;
     const size_t element_count = g->element_count;
     const float element_count_accum = (float)element_count;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g->batch_size >= 16)
     for (size_t batch = 0; batch < g->batch_size; ++batch) {
         const size_t off = batch * element_count;
         float sum = 0.0f, sum_sq = 0.0f;
@@ -478,7 +478,7 @@ float orc_activate(uint32_t act, float x, uint32_t dt) {
 void orc_gated_act_mul(const void* act_operand, const void* value_operand, void* fp_out, uint32_t dt,
                        uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
                        uint32_t act_type, uint32_t interleaved) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (batch_dim >= 16)
     for (size_t batch = 0; batch < batch_dim; ++batch)
         for (size_t gated = 0; gated < gated_dim; ++gated) {
             size_t act_index;

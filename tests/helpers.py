@@ -14,10 +14,16 @@ def f32(b):
     return bf16_bits_to_f32(np.asarray(b, dtype=np.uint16))
 
 
-def ulp_diff_bf16(a_bits, b_bits):
-    """|a-b| measured in bf16 ulps of the larger magnitude (0 when bit-identical)."""
+def ulp_diff_bf16(a_bits, b_bits, floor=None):
+    """|a-b| measured in bf16 ulps of the larger magnitude (0 when bit-identical).
+
+    `floor`: magnitude below which the ulp is not shrunk any further.  Outputs of a reduction that happen to
+    cancel to ~0 carry the absolute f32 accumulation noise of the whole sum, so their error is judged against
+    the ulp of a typical output (default: rms(a)/8), not against their own tiny ulp."""
     a, b = f32(a_bits).astype(np.float64), f32(b_bits).astype(np.float64)
-    mag = np.maximum(np.abs(a), np.abs(b))
+    if floor is None:
+        floor = float(np.sqrt(np.mean(a * a))) / 8.0 if a.size else 0.0
+    mag = np.maximum(np.maximum(np.abs(a), np.abs(b)), floor)
     exp = np.floor(np.log2(np.maximum(mag, 1e-30)))
     ulp = 2.0 ** (exp - 7)
     return np.abs(a - b) / ulp

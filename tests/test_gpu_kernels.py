@@ -182,7 +182,9 @@ def test_normalization(hip_ctx, full_layer, mode, dim, rows):
     got = bo.download(np.uint16, rows * dim).reshape(rows, dim)
     if copy:
         assert np.array_equal(bsc.download(np.uint16, rows * dim).reshape(rows, dim), want_sc)
-    assert ulp_diff_bf16(want, got).max() <= 1.0
+    # OnlyNormalization rounds `normalized` to bf16 BEFORE the scale multiply: a 1-ulp-f32 difference that
+    # crosses a bf16 rounding boundary becomes 1 bf16 ulp of the factor and up to 2 of the product
+    assert ulp_diff_bf16(want, got).max() <= (1.0 if full_layer else 2.0)
     assert (want == got).mean() >= 0.99
 
 
@@ -310,7 +312,7 @@ def test_argmax_exact_with_ties(hip_ctx):
     rng = np.random.default_rng(10)
     vocab, batch = 248320, 3
     logits = bf16(rng.normal(0, 2, size=(batch, vocab)))
-    top = bf16(np.array([9.0]))[0]
+    top = bf16(np.array([20.0]))[0]
     logits[0, [100000, 777, 200001]] = top  # three-way tie -> 777
     logits[1, vocab - 1] = top
     logits[2, 0] = top
