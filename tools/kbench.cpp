@@ -1,0 +1,100 @@
+// kbench.cpp -- per-kernel timing of the fused decode kernels in a captured graph (what the engine replays).
+// build: hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/kbench.cpp -Luzu_amd/lib -luzu_hip -Wl,-rpath,$PWD/uzu_amd/lib -o tools/kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include "../uzu_amd/csrc/kernels.h"
+#include "../uzu_amd/csrc/kernels_decode.h"
+using namespace uzu::k;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+extern "C" const char* uzu_hip_last_error(void);
+static hipStream_t s;
+template <class T> T* dalloc(size_t n, int fill = 0x11) { T* p; CK(hipMalloc(&p, n * sizeof(T) + 256)); CK(hipMemset(p, fill, n * sizeof(T))); return p; }
+static double time_graph(const char* name, size_t bytes, int reps, const std::function<uzu_status(int)>& launch) {
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < reps; ++i) if (launch(i) != UZU_OK) { printf("%s: launch failed: %s\n", name, uzu_hip_last_error()); exit(1); }
+    CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s)); for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / (5.0 * reps);
+    printf("%-34s %8.2f us/launch  %8.1f GB/s\n", name, us, bytes / us / 1e3);
+    return us;
+}
+int main(int argc, char** argv) {
+    CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int reps = 64, NBUF = 8; // rotate weight buffers so weights come from HBM, not L2/MALL
+    auto bench_gemv = [&](const char* name, uint32_t n, uint32_t k, bool norm, bool act, bool amax, uint32_t n2 = 0, uint32_t debug = 0) {
+        const uint32_t g = 128, groups = k / g;
+        std::vector<uint8_t*> w(NBUF); std::vector<uint16_t*> sc(NBUF), bi(NBUF);
+        const uint32_t nt = n + n2;
+        for (int i = 0; i < NBUF; ++i) { w[i] = dalloc<uint8_t>((size_t)nt * k / 2, 0x53); sc[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); bi[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); }
+        uint16_t* x = dalloc<uint16_t>(k, 0x3f); uint16_t* sh = dalloc<uint16_t>(k, 0x3f); uint16_t* sho = dalloc<uint16_t>(k);
+        float* ns = dalloc<float>(k, 0); uint16_t* out = dalloc<uint16_t>(nt); float* pv = dalloc<float>(8192); uint32_t* pi = dalloc<uint32_t>(8192);
+        const size_t bytes = (size_t)nt * k / 2 + (size_t)nt * groups * 4 + nt * 2 + k * 2;
+        time_graph(name, bytes, reps, [&](int i) {
+            DecGemvParams p{};
+            p.w[0] = w[i % NBUF], p.scales[0] = sc[i % NBUF], p.biases[0] = bi[i % NBUF], p.out[0] = out, p.n[0] = n;
+            if (n2) { p.w[1] = w[i % NBUF] + (size_t)n * k / 2, p.scales[1] = sc[i % NBUF] + (size_t)n * groups, p.biases[1] = bi[i % NBUF] + (size_t)n * groups, p.out[1] = out + n, p.n[1] = n2; }
+            p.k = k, p.bits = 4, p.group_size = g, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.x = x;
+            if (norm) { p.norm_scales = ns, p.norm_eps = 1e-6f, p.norm_offset = 1.f, p.norm_full_layer = 1, p.residual_add = 1, p.shortcut_in = sh, p.shortcut_out = sho; }
+            if (act) p.act_mul = 1;
+            if (amax) p.part_val = pv, p.part_idx = pi;
+            p.debug = debug;
+            return gemv_dec(s, p, cus, nullptr);
+        });
+    };
+    bench_gemv("gemv_dec in_proj 8224x1024 +norm", 8224, 1024, true, false, false);
+    bench_gemv("gemv_dec in_proj 8224x1024", 8224, 1024, false, false, false);
+    bench_gemv("  .. prologue only (no rows)", 8224, 1024, false, false, false, 0, 1);
+    bench_gemv("  .. rows only (no prologue)", 8224, 1024, false, false, false, 0, 2);
+    bench_gemv("  .. neither", 8224, 1024, false, false, false, 0, 3);
+    bench_gemv("  .. rows only, no store", 8224, 1024, false, false, false, 0, 2 | 4);
+    bench_gemv("  .. rows only, no weight loads", 8224, 1024, false, false, false, 0, 2 | 8);
+    bench_gemv("  .. rows only, no loads no store", 8224, 1024, false, false, false, 0, 2 | 4 | 8);
+    bench_gemv("  .. +norm prologue only", 8224, 1024, true, false, false, 0, 1);
+    bench_gemv("gemv_dec out_proj 1024x2048", 1024, 2048, false, false, false);
+    bench_gemv("gemv_dec up+act 7168x1024 +norm", 7168, 1024, true, true, false);
+    bench_gemv("gemv_dec down 1024x3584", 1024, 3584, false, false, false);
+    bench_gemv("gemv_dec qkv+gate 5120x1024 +norm", 3072, 1024, true, false, false, 2048);
+    bench_gemv("gemv_dec readout 248320x1024 +norm", 248320, 1024, true, false, true);
+    {   // unfused reference: plain GEMV kernel through k::matmul
+        const uint32_t n = 248320, k = 1024, g = 128;
+        uint8_t* w = dalloc<uint8_t>((size_t)n * k / 2, 0x53); uint16_t* sc = dalloc<uint16_t>((size_t)n * 8, 0x3c); uint16_t* bi = dalloc<uint16_t>((size_t)n * 8, 0x3c);
+        uint16_t* x = dalloc<uint16_t>(k, 0x3f); uint16_t* out = dalloc<uint16_t>(n);
+        time_graph("gemv_q (unfused) 248320x1024", (size_t)n * k / 2 + n * 32, 16, [&](int) {
+            MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi, p.d = out; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
+            p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = 1, p.n = n, p.k = k; return matmul(s, p, cus); });
+    }
+    {   // delta_dec, Qwen3.5-0.8B shape
+        const uint32_t Hv = 16, Dk = 128, Dv = 128, key_dim = 2048, value_dim = 2048, conv_dim = 6144, total = conv_dim + value_dim + 32;
+        uint16_t* in_proj = dalloc<uint16_t>(total, 0x3c); float* cw = dalloc<float>(conv_dim * 4, 0); float* cs = dalloc<float>(conv_dim * 3, 0);
+        float* al = dalloc<float>(Hv, 0); float* dt = dalloc<float>(Hv, 0); float* nw = dalloc<float>(Dv, 0); uint16_t* out = dalloc<uint16_t>(value_dim);
+        std::vector<float*> st(NBUF); for (auto& p : st) p = dalloc<float>((size_t)Hv * Dv * Dk, 0);
+        time_graph("delta_dec 16x128x128", (size_t)2 * Hv * Dv * Dk * 4, reps, [&](int i) {
+            DeltaDecParams p{}; p.in_proj = in_proj, p.conv_w = cw, p.conv_state = cs, p.a_log = al, p.dt_bias = dt, p.norm_weight = nw, p.state = st[i % NBUF], p.out = out;
+            p.num_v_heads = Hv, p.num_k_heads = 16, p.head_v_dim = Dv, p.key_dim = key_dim, p.value_dim = value_dim, p.kernel_size = 4, p.norm_epsilon = 1e-6f; return delta_dec(s, p); });
+    }
+    {   // attn_dec + merge, Qwen3.5-0.8B shape at ctx 2048
+        const uint32_t nq = 8, nkv = 2, hd = 256, ctx = 2048, splits = 64;
+        uint16_t* qkv = dalloc<uint16_t>((nq + 2 * nkv) * hd, 0x3c); float* cosr = dalloc<float>((size_t)(ctx + 8) * 64, 0); float* sinr = dalloc<float>((size_t)(ctx + 8) * 64, 0);
+        uint32_t* len = dalloc<uint32_t>(1, 0); uint32_t h = ctx; CK(hipMemcpy(len, &h, 4, hipMemcpyHostToDevice));
+        float* qs = dalloc<float>(hd, 0); float* parts = dalloc<float>((size_t)nq * splits * hd); float* sums = dalloc<float>(nq * splits); float* maxs = dalloc<float>(nq * splits);
+        uint16_t* gate = dalloc<uint16_t>(nq * hd, 0x3c); uint16_t* out = dalloc<uint16_t>(nq * hd);
+        std::vector<uint16_t*> K(NBUF), V(NBUF); for (int i = 0; i < NBUF; ++i) { K[i] = dalloc<uint16_t>((size_t)(ctx + 8) * nkv * hd, 0x3c); V[i] = dalloc<uint16_t>((size_t)(ctx + 8) * nkv * hd, 0x3c); }
+        for (uint32_t sp : {32u, 64u, 128u})
+            time_graph(sp == 32 ? "attn_dec ctx2048 S=32" : sp == 64 ? "attn_dec ctx2048 S=64" : "attn_dec ctx2048 S=128", (size_t)2 * ctx * nkv * hd * 2, reps, [&](int i) {
+                AttnDecParams p{}; p.qkv = qkv, p.keys = K[i % NBUF], p.values = V[i % NBUF], p.cosines = cosr, p.sines = sinr, p.ctx_len = len;
+                p.q_norm = {1, 1, 1e-6f, 1.f, qs}; p.k_norm = {1, 1, 1e-6f, 1.f, qs}; p.num_heads = nq, p.gqa_factor = 4, p.head_dim = hd, p.rope_dim = 64, p.scale = 0.0625f;
+                p.partials = parts, p.sums = sums, p.maxs = maxs; return attn_dec(s, p, sp > 64 ? 64 : sp); });
+        time_graph("attn_merge S=64", (size_t)nq * 64 * hd * 4, reps, [&](int) { return attn_merge(s, parts, sums, maxs, gate, out, nq, hd, 64); });
+    }
+    return 0;
+}

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemv_core.h"
 #include "internal.h"
 #include "uzu_math.h"
 
@@ -29,21 +30,14 @@ template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 constexpr int kWave = 64; // CDNA wavefront
 
 // butterfly sum over the `width` (power of two <= 64) consecutive lanes that contain this lane
-template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) { return k::row_sum_rt(v, WIDTH); }
+__device__ __forceinline__ float wave_sum(float v) { return k::row_sum_rt(v, 64); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
     return v;
 }
-__device__ __forceinline__ float group_sum_rt(float v, int width) {
-    for (int off = width / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
+__device__ __forceinline__ float group_sum_rt(float v, int width) { return k::row_sum_rt(v, width); }
 
 // workgroup sum (blockDim.x multiple of 64, <= 1024); `red` = 16 floats of LDS; result broadcast
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -21,6 +21,7 @@
 #include "../../include/uzu_hip_engine.h"
 #include "internal.h"
 #include "kernels.h"
+#include "kernels_decode.h"
 
 using namespace uzu;
 
@@ -86,6 +87,14 @@ struct uzu_hip_model {
     void* argmax_scratch = nullptr;
     uint16_t* taps = nullptr; // [layers][1024][d]
     uint32_t tap_rows = 0;
+
+    // fused decode path
+    bool fusable = false;
+    uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
+    float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
+    uint32_t dec_splits = 0;
+    float* amax_val = nullptr;
+    uint32_t* amax_idx = nullptr;
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -387,11 +396,163 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     return UZU_OK;
 }
 
+// ---------------------------------------------------------------------------------- fused decode step
+k::DecGemvParams dec_gemv_base(const DLinear& L, const uint16_t* x, uint16_t* out) {
+    k::DecGemvParams p{};
+    p.w[0] = (const uint8_t*)L.w, p.scales[0] = (const uint16_t*)L.scales, p.biases[0] = (const uint16_t*)L.biases, p.zp[0] = L.zp;
+    p.out_bias[0] = (const uint16_t*)L.out_biases, p.out[0] = out, p.n[0] = L.n;
+    p.k = L.k, p.bits = L.bits, p.group_size = L.group;
+    p.b_kind = L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS
+             : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+    p.x = x;
+    return p;
+}
+void dec_add_second(k::DecGemvParams& p, const DLinear& L, uint16_t* out) {
+    p.w[1] = (const uint8_t*)L.w, p.scales[1] = (const uint16_t*)L.scales, p.biases[1] = (const uint16_t*)L.biases, p.zp[1] = L.zp;
+    p.out_bias[1] = (const uint16_t*)L.out_biases, p.out[1] = out, p.n[1] = L.n;
+}
+// mode: 1 copy, 2 add
+void dec_add_norm(k::DecGemvParams& p, const DNorm& N, int mode, const uint16_t* sc_in, uint16_t* sc_out) {
+    p.norm_scales = N.scales;
+    p.norm_plain = N.scales == nullptr;
+    p.norm_eps = N.eps, p.norm_offset = N.offset, p.norm_full_layer = N.full_layer;
+    p.residual_add = mode == 2;
+    p.shortcut_in = mode == 2 ? sc_in : nullptr;
+    p.shortcut_out = sc_out;
+}
+size_t dec_gemv_bytes(const k::DecGemvParams& p) {
+    size_t b = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (!p.n[i]) continue;
+        const size_t groups = (p.k + p.group_size - 1) / p.group_size;
+        b += (size_t)p.n[i] * p.k * p.bits / 8 + (size_t)p.n[i] * groups * 2;
+        if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) b += (size_t)p.n[i] * groups * 2;
+        if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) b += (size_t)p.n[i] * (p.bits == 4 ? (groups + 1) / 2 : groups);
+        b += (size_t)p.n[i] * 2;
+    }
+    return b + (size_t)p.k * 2;
+}
+void dec_gemv(Enc& e, const k::DecGemvParams& p, const char* name, uint32_t* grid_out = nullptr) {
+    e.begin();
+    e.run(k::gemv_dec(e.s, p, e.m->ctx->num_cus, grid_out), name, dec_gemv_bytes(p));
+}
+
+bool linear_fusable(const DLinear& L) {
+    if (!L.w) return false;
+    if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
+    const uint32_t wpc = 128 / L.bits;
+    return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
+}
+bool norm_fusable(const DNorm& N) { return N.present && !N.subtract_mean && !N.biases; }
+// the fused Normalization prologue needs model_dim % 1024 == 0 and <= 8192 (k_decode.hip)
+bool dim_fusable(uint32_t d) { return d % 1024 == 0 && d <= 8192; }
+
+bool model_fusable(const uzu_hip_model* m) {
+    if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f) return false;
+    if (!dim_fusable(m->d.model_dim)) return false;
+    if (!norm_fusable(m->output_norm)) return false;
+    if (!linear_fusable(m->d.tied_embeddings ? m->embedding : m->output_embedding)) return false;
+    for (const DLayer& L : m->layers) {
+        if (!norm_fusable(L.pre_mixer) || !norm_fusable(L.pre_mlp) || L.post_mixer.present || L.post_mlp.present) return false;
+        if (!linear_fusable(L.up) || !linear_fusable(L.down)) return false;
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+            if (!linear_fusable(L.qkv) || !linear_fusable(L.out)) return false;
+            if (L.d.has_gate && (!linear_fusable(L.gate) || L.gate.bits != L.qkv.bits || L.gate.group != L.qkv.group || L.gate.method != L.qkv.method)) return false;
+            if (!(L.d.head_dim == 64 || L.d.head_dim == 128 || L.d.head_dim == 256)) return false;
+            if ((L.qn.present && (L.qn.subtract_mean || L.qn.biases)) || (L.kn.present && (L.kn.subtract_mean || L.kn.biases))) return false;
+        } else {
+            if (!linear_fusable(L.in_proj) || !linear_fusable(L.out_proj)) return false;
+            if (L.d.dn_head_dim != 128 || L.d.dn_value_head_dim > 512 || L.d.dn_kernel_size > 9) return false;
+        }
+    }
+    return true;
+}
+
+// One decode step (count == 1, sampling) with the fused kernels of k_decode.hip.
+uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
+    Enc e{m, s};
+    e.prof = (std::vector<ProfEntry>*)m->prof_sink;
+    m->launches = 0;
+    const uint32_t d = m->d.model_dim;
+    uint16_t* hidden = m->hidden;
+    if (m->embedding.method == UZU_QUANT_NONE)
+        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, m->d_tokens, m->embedding.w, hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale));
+    else
+        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, m->d_tokens, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
+                                            hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits, m->embedding.method));
+    uint16_t* sc[2] = {m->shortcut, m->shortcut_b};
+    int cur = 1; // the first norm (copy mode) writes sc[0]
+    auto next_norm = [&](k::DecGemvParams& p, const DNorm& N, int mode) {
+        dec_add_norm(p, N, mode, sc[cur], sc[cur ^ 1]);
+        cur ^= 1;
+    };
+    for (uint32_t l = 0; l < m->d.num_layers; ++l) {
+        DLayer& L = m->layers[l];
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+            const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups;
+            k::DecGemvParams p = dec_gemv_base(L.qkv, hidden, m->qkv);
+            if (L.d.has_gate) dec_add_second(p, L.gate, m->gate);
+            next_norm(p, L.pre_mixer, l > 0 ? 2 : 1);
+            dec_gemv(e, p, "gemv_dec[norm+qkv+gate]");
+            k::AttnDecParams a{};
+            a.qkv = m->qkv, a.keys = L.keys, a.values = L.values, a.cosines = m->rope_cos, a.sines = m->rope_sin, a.ctx_len = m->d_ctx_len;
+            a.q_norm = {L.qn.present, L.qn.full_layer, L.qn.eps, L.qn.offset, L.qn.scales};
+            a.k_norm = {L.kn.present, L.kn.full_layer, L.kn.eps, L.kn.offset, L.kn.scales};
+            a.num_heads = nq, a.gqa_factor = nq / nkv, a.head_dim = hd, a.rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
+            a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
+            a.partials = m->dec_partials, a.sums = m->dec_sums, a.maxs = m->dec_maxs;
+            const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
+            RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
+            RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
+            dec_gemv(e, dec_gemv_base(L.out, m->attn_out, m->mixed), "gemv_dec[out_proj]");
+        } else {
+            const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
+            k::DecGemvParams p = dec_gemv_base(L.in_proj, hidden, m->in_proj);
+            next_norm(p, L.pre_mixer, l > 0 ? 2 : 1);
+            dec_gemv(e, p, "gemv_dec[norm+in_proj]");
+            k::DeltaDecParams q{};
+            q.in_proj = m->in_proj, q.conv_w = L.conv_w, q.conv_b = L.conv_b, q.conv_state = L.conv_state, q.a_log = L.a_log, q.dt_bias = L.dt_bias;
+            q.norm_weight = L.dn_norm, q.state = L.ssm_state, q.out = m->delta_out;
+            q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv, q.kernel_size = L.d.dn_kernel_size;
+            q.norm_epsilon = L.d.dn_norm_epsilon;
+            RUN("delta_dec", (size_t)2 * Hv * Dv * Dk * 4, k::delta_dec(s, q));
+            dec_gemv(e, dec_gemv_base(L.out_proj, m->delta_out, m->mixed), "gemv_dec[out_proj]");
+        }
+        k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
+        next_norm(up, L.pre_mlp, 2);
+        up.act_mul = 1, up.act_type = L.d.activation;
+        dec_gemv(e, up, "gemv_dec[norm+up+act]");
+        dec_gemv(e, dec_gemv_base(L.down, m->gated, hidden), "gemv_dec[down]");
+        if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, d));
+    }
+    m->tap_rows = 1;
+    const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+    k::DecGemvParams r = dec_gemv_base(ro, hidden, m->logits);
+    next_norm(r, m->output_norm, 2);
+    r.normed_out = m->last_normed;
+    r.part_val = m->amax_val, r.part_idx = m->amax_idx;
+    uint32_t grid = 0;
+    dec_gemv(e, r, "gemv_dec[norm+readout+argmax]", &grid);
+    RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
+    if (e.st != UZU_OK) return e.st;
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        set_error("engine: fused decode launch failed: %s", hipGetErrorString(err));
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
+
+uzu_status encode_decode(uzu_hip_model* m, hipStream_t s) {
+    if (m->fusable && !(m->flags & UZU_MODEL_NO_FUSION)) return encode_decode_fused(m, s);
+    return encode_forward(m, s, 1, true);
+}
+
 uzu_status build_decode_graph(uzu_hip_model* m, hipGraphExec_t* out, bool two_pass) {
     hipStream_t s = m->ctx->stream;
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     m->regime_override = two_pass ? 1 : 0;
-    uzu_status st = encode_forward(m, s, 1, true);
+    uzu_status st = encode_decode(m, s);
     m->regime_override = -1;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(s, &g);
@@ -413,7 +574,7 @@ uzu_status enqueue_decode(uzu_hip_model* m, uint32_t steps) {
         UZU_REQUIRE(m->context_length + 1 <= m->d.max_context_length, "decode: context length %u exceeds max_context_length %u", m->context_length + 1,
                     m->d.max_context_length);
         if (m->flags & UZU_MODEL_NO_GRAPH) {
-            UZU_PROPAGATE(encode_forward(m, m->ctx->stream, 1, true));
+            UZU_PROPAGATE(encode_decode(m, m->ctx->stream));
         } else {
             const bool two = m->context_length + 1 > 1024;
             hipGraphExec_t* g = two ? &m->graph_two : &m->graph_single;
@@ -548,12 +709,33 @@ uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc
         ALLOC(beta, float, C * max_hv);
         ALLOC(decay, float, C * max_hv);
     }
+    ALLOC(shortcut_b, uint16_t, C * d);
+    ALLOC(amax_val, float, 4096);
+    ALLOC(amax_idx, uint32_t, 4096);
+    if (max_qkv) {
+        uint32_t wgs = 1; // kv_heads * head-subgroups of the widest attention layer
+        for (auto& L : m->layers)
+            if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+                const uint32_t gqa = L.d.num_heads / L.d.num_groups, cap = L.d.head_dim >= 256 ? 4 : 8;
+                uint32_t gs = 1;
+                for (uint32_t c = cap; c >= 1; c >>= 1)
+                    if (gqa % c == 0) { gs = c; break; }
+                const uint32_t w = L.d.num_groups * (gqa / gs);
+                wgs = wgs > w ? wgs : w;
+            }
+        uint32_t splits = 128 / wgs;
+        m->dec_splits = splits < 8 ? 8 : (splits > 128 ? 128 : splits);
+        ALLOC(dec_partials, float, (size_t)max_heads * m->dec_splits * max_hd);
+        ALLOC(dec_sums, float, (size_t)max_heads * m->dec_splits);
+        ALLOC(dec_maxs, float, (size_t)max_heads * m->dec_splits);
+    }
     ALLOC(last_normed, uint16_t, d);
     ALLOC(logits, uint16_t, desc->vocab_size);
     TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
     if (flags & UZU_MODEL_DEBUG_TAPS) ALLOC(taps, uint16_t, (size_t)desc->num_layers * C * d);
 #undef ALLOC
 #undef TRY
+    m->fusable = model_fusable(m);
     if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) {
         set_error("model_create: hipEventCreate failed");
         return fail(UZU_ERR_HIP);
@@ -654,7 +836,7 @@ uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity
     UZU_REQUIRE(m->context_length > 0 && m->context_length + 1 <= m->d.max_context_length, "model_profile_decode_step: bad context length");
     std::vector<ProfEntry> prof;
     m->prof_sink = &prof;
-    uzu_status st = encode_forward(m, m->ctx->stream, 1, true);
+    uzu_status st = encode_decode(m, m->ctx->stream);
     m->prof_sink = nullptr;
     hipError_t e = hipStreamSynchronize(m->ctx->stream);
     if (st == UZU_OK && e != hipSuccess) {

@@ -1,0 +1,775 @@
+// k_decode.hip -- fused batch-1 decode kernels for gfx950.
+//
+// Batch-1 decode of a small model is launch/latency bound on MI355X: a dependent kernel boundary costs
+// ~1.5 us and every kernel pays ~1 us of dependent memory latency, while a whole Qwen3.5-0.8B layer streams
+// only ~20 MB (3 us at HBM speed).  The engine therefore runs a layer as 5-6 kernels instead of the
+// reference's 9-14 encodes (transformer_layer.rs:194-238), by moving the reference's small kernels into
+// prologues/epilogues of the weight-streaming kernels:
+//
+//   gemv_dec       [residual add + RMSNorm prologue] -> int4/int8 GEMV over one or two weight matrices
+//                  -> [SiLU(gate)*up | arg-max partial] epilogue
+//                  = Normalization + MatmulKernel (+ second MatmulKernel) (+ GatedActMul | UnifiedSampling pass 1)
+//   delta_dec      conv update + SiLU, delta-rule state update, RMSNorm * SiLU(z) gate
+//                  = DeltaNetConvUpdate + DeltaNetUpdate
+//   attn_dec       per-head q/k RMSNorm + RoPE + KV-cache append + split-KV attention pass 1
+//                  = QKVNorm x2 + AttentionPrepare + AttentionTwoPass1 (own split count)
+//   attn_merge     split merge + sigmoid gate = AttentionTwoPass2 + SigmoidGate
+//   argmax_commit  arg-max pass 2 + token commit (next input token, history, context length)
+//
+// Arithmetic is the SAME as in the stand-alone kernels (same per-lane element assignment, same reduction
+// trees, same rounding points): gemv_dec / delta_dec results are bit-identical to the unfused chain
+// (tests/test_gpu_model.py::test_fused_decode_matches_unfused).  attn_dec uses its own KV split (more
+// workgroups than the reference's 32 blocks) and is tolerance-equal.
+#include <stdlib.h>
+
+#include "device_utils.h"
+#include "gemv_core.h"
+#include "kernels.h"
+#include "kernels_decode.h"
+
+namespace uzu {
+namespace k {
+
+// ---------------------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ float act_bf16(uint32_t act, float x) { // activation_type.rs, T = bf16
+    switch (act) {
+    case 0: return round_bf16(x / (1.0f + expf_glibc(-1.0f * x)));
+    case 1: return round_bf16(0.5f * x * (1.0f + tanhf(0.7978846f * (x + 0.044715f * x * x * x))));
+    case 2: return round_bf16(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
+    case 3: return x;
+    default: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc(x)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- gemv_dec
+// No LDS, no workgroup barrier: a wave is self-sufficient.
+//   * lane mapping / arithmetic of gemv_core.h: lane `sl` of the row's lpr lanes owns the 32-element steps
+//     sl + lpr*j, j < CPL, of the activation row and keeps them in registers for the whole kernel (CPL <= 4,
+//     i.e. K <= 8192; larger K re-reads x per step, CPL == 0);
+//   * optional Normalization prologue: each lane loads ITS steps of x / shortcut / norm scales, the sum of
+//     squares is reduced over the lpr lanes (same tree as the stand-alone kernel), the lane normalises its own
+//     steps in registers -- no redistribution, no second memory round trip;
+//   * all global loads of the first row batch (codes, scales, offsets) are issued BEFORE the prologue, the
+//     next batch is prefetched while the current one is computed (tools/microbench2: a kernel boundary costs
+//     1.6 us, a dependent HBM round trip 0.3-0.5 us: the kernel should pay exactly one of the latter);
+//   * epilogues: plain store | SiLU(gate)*up | arg-max partial per workgroup.
+template <int BITS, int CPLT, int R, bool ACT>
+__global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_log2) {
+    using Codes = typename CodesT<BITS>::type;
+    constexpr int STEP_BYTES = 4 * BITS;
+    constexpr int NPHYS = ACT ? 2 : 1;
+    constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t K = p.k;
+    const int lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
+    const int sl = lane & (lpr - 1), rsub = lane >> lpr_log2;
+    const uint32_t C = K / 32;
+    const uint32_t row_bytes = K * BITS / 8;
+    const uint32_t G = (K + p.group_size - 1) / p.group_size;
+    const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
+    const uint32_t rows_per_batch = R * rpw;
+    const uint32_t n_log0 = ACT ? p.n[0] / 2 : p.n[0];
+    const uint32_t batches0 = (n_log0 + rows_per_batch - 1) / rows_per_batch;
+    const uint32_t batches1 = ACT ? 0 : (p.n[1] + rows_per_batch - 1) / rows_per_batch;
+    const uint32_t num_batches = batches0 + batches1;
+    const uint32_t total_waves = gridDim.x * 4;
+    const uint32_t steps_per_lane = CPLT == 0 ? (C + lpr - 1) / lpr : CPL;
+    const uint32_t gshift = 31 - __builtin_clz(p.group_size); // group_size is a power of two (checked at launch)
+
+    struct Item {
+        Codes w[R][NPHYS];
+        uint16_t s[R][NPHYS], o[R][NPHYS];
+    };
+    // wave-uniform matrix selection: batches [0, batches0) belong to matrix 0, the rest to matrix 1
+    auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
+        const uint32_t c = sl + lpr * j;
+        if (b >= num_batches || c >= C || (p.debug & 8)) return;
+        const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
+        const uint32_t lb = mat ? b - batches0 : b;
+        const uint32_t nl = mat ? p.n[1] : n_log0;
+        const uint8_t* wp = p.w[mat];
+        const uint16_t* sp = p.scales[mat];
+        const uint16_t* bp = p.biases[mat];
+        const uint8_t* zp = p.zp[mat];
+        const uint32_t grp = (c * 32) >> gshift;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t lr = lb * rows_per_batch + r * rpw + rsub;
+            if (lr >= nl) lr = 0;
+#pragma unroll
+            for (int h = 0; h < NPHYS; ++h) {
+                const uint32_t prow = ACT ? lr + (h ? p.n[0] / 2 : 0) : lr;
+                load_codes(it.w[r][h], wp + (size_t)prow * row_bytes + (size_t)c * STEP_BYTES);
+                it.s[r][h] = sp[(size_t)prow * G + grp];
+                if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) it.o[r][h] = bp[(size_t)prow * G + grp];
+                else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) it.o[r][h] = BITS == 4 ? zp[(size_t)prow * zp_stride + (grp >> 1)] : zp[(size_t)prow * zp_stride + grp];
+            }
+        }
+    };
+
+    const uint32_t b0 = blockIdx.x * 4 + wave;
+    Item cur, nxt;
+    if (!(p.debug & 1)) load_item(b0, 0, cur); // in flight during the whole prologue
+
+    // ---- prologue ---------------------------------------------------------------------------------------
+    float xf[CPL][32];
+    float xsm[CPL];
+    if (CPLT != 0 && !(p.debug & 2)) {
+        const bool normed = p.norm_scales || p.norm_plain;
+        if (!normed) { // plain activation row: every lane fetches its own steps
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const uint32_t c = sl + lpr * j;
+                if (c < C) load32_bf16(p.x + (size_t)c * 32, xf[j]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                }
+            }
+        } else {
+            // Normalization (normalization.rs:56-125) once per workgroup through LDS; element/thread mapping and
+            // reduction order of normalization_kernel: thread t owns elements [t*E, t*E+E), E = K/256 (K % 1024 == 0).
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            float* xs = smem;                       // C slots of 36 floats (16-byte pad => conflict-free b128 reads)
+            float* red = smem + (size_t)C * 36;     // [4]
+            const uint32_t E = K / 256;
+            float ss = 0.f;
+            for (uint32_t q = 0; q < E; q += 4) {
+                const uint32_t e = tid * E + q;
+                const uint2 xr = *(const uint2*)(p.x + e);
+                float v[4] = {bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u)};
+                if (p.residual_add) {
+                    const uint2 sr = *(const uint2*)(p.shortcut_in + e);
+                    const float sc[4] = {bits_to_f32(sr.x << 16), bits_to_f32(sr.x & 0xFFFF0000u), bits_to_f32(sr.y << 16), bits_to_f32(sr.y & 0xFFFF0000u)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = round_bf16(v[i] + sc[i]);
+                }
+                if (p.shortcut_out && blockIdx.x == 0) {
+                    uint2 o;
+                    o.x = (f32_to_bits(v[0]) >> 16) | (f32_to_bits(v[1]) & 0xFFFF0000u);
+                    o.y = (f32_to_bits(v[2]) >> 16) | (f32_to_bits(v[3]) & 0xFFFF0000u);
+                    *(uint2*)(p.shortcut_out + e) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss = fmaf(v[i], v[i], ss);
+                *(float4*)(xs + (size_t)(e / 32) * 36 + e % 32) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            const float total = ((red[0] + red[1]) + red[2]) + red[3];
+            const float variance = total / (float)K - 0.0f * 0.0f;
+            const float rms_inv = 1.0f / sqrtf(variance + p.norm_eps);
+            for (uint32_t q = 0; q < E; q += 4) {
+                const uint32_t e = tid * E + q;
+                float* slot = xs + (size_t)(e / 32) * 36 + e % 32;
+                const float4 vv = *(const float4*)slot; // own elements: no barrier needed
+                float v[4] = {vv.x, vv.y, vv.z, vv.w};
+                float scl[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.norm_scales) {
+                    const float4 t = *(const float4*)(p.norm_scales + e);
+                    scl[0] = t.x, scl[1] = t.y, scl[2] = t.z, scl[3] = t.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float normalized = (v[i] - 0.0f) * rms_inv;
+                    if (!p.norm_scales) v[i] = round_bf16(normalized);
+                    else if (p.norm_full_layer) v[i] = round_bf16(normalized * (scl[i] + p.norm_offset));
+                    else v[i] = round_bf16(round_bf16(normalized) * round_bf16(scl[i] + p.norm_offset));
+                }
+                *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.normed_out && blockIdx.x == 0) {
+                    uint2 o;
+                    o.x = (f32_to_bits(v[0]) >> 16) | (f32_to_bits(v[1]) & 0xFFFF0000u);
+                    o.y = (f32_to_bits(v[2]) >> 16) | (f32_to_bits(v[3]) & 0xFFFF0000u);
+                    *(uint2*)(p.normed_out + e) = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const uint32_t c = sl + lpr * j;
+                if (c < C) {
+                    const float4* xv = (const float4*)(xs + (size_t)c * 36);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 t = xv[i];
+                        xf[j][4 * i] = t.x, xf[j][4 * i + 1] = t.y, xf[j][4 * i + 2] = t.z, xf[j][4 * i + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) xsm[j] = sum32(xf[j]);
+    }
+
+    // ---- row loop, software pipelined over (batch, step) items ---------------------------------------------
+    float best_v = -INFINITY; // arg-max epilogue state (lane-local)
+    uint32_t best_i = 0xFFFFFFFFu;
+    if (!(p.debug & 1))
+    for (uint32_t b = b0; b < num_batches; b += total_waves) {
+        float acc[R][NPHYS];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int h = 0; h < NPHYS; ++h) acc[r][h] = 0.f;
+        auto compute = [&](const Item& it, uint32_t c, const float (&x)[32], float xs) {
+            const uint32_t grp = (c * 32) >> gshift;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int h = 0; h < NPHYS; ++h) {
+                    const float sc = bf16_to_f32(it.s[r][h]);
+                    float of;
+                    if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(it.o[r][h]);
+                    else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                        const uint32_t zpv = BITS == 4 ? ((grp & 1) ? (it.o[r][h] >> 4) : (it.o[r][h] & 0x0F)) : it.o[r][h];
+                        of = -sc * (float)zpv;
+                    } else of = -sc * (float)(1u << (BITS - 1));
+                    const float dq = dot32(it.w[r][h], x);
+                    acc[r][h] = fmaf(sc, dq, fmaf(of, xs, acc[r][h]));
+                }
+        };
+        if (CPLT != 0) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const bool last = j + 1 == CPL;
+                load_item(last ? b + total_waves : b, last ? 0 : j + 1, nxt);
+                const uint32_t c = sl + lpr * j;
+                if (c < C) compute(cur, c, xf[j], xsm[j]);
+                cur = nxt;
+            }
+        } else {
+            for (uint32_t j = 0; j < steps_per_lane; ++j) {
+                const bool last = j + 1 == steps_per_lane;
+                load_item(last ? b + total_waves : b, last ? 0 : j + 1, nxt);
+                const uint32_t c = sl + lpr * j;
+                if (c < C) {
+                    float x[32];
+                    load32_bf16(p.x + (size_t)c * 32, x);
+                    compute(cur, c, x, sum32(x));
+                }
+                cur = nxt;
+            }
+        }
+        const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
+        const uint32_t lb = mat ? b - batches0 : b;
+        const uint32_t nl = mat ? p.n[1] : n_log0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float v0 = row_sum_rt(acc[r][0], lpr);
+            const float v1 = ACT ? row_sum_rt(acc[r][NPHYS - 1], lpr) : 0.f;
+            const uint32_t lrow = lb * rows_per_batch + r * rpw + rsub;
+            if (sl == 0 && lrow < nl && !((p.debug & 4) && v0 != 123.f)) {
+                // MatmulKernel epilogue with ab_scale = 1, no accumulate / soft-cap (kernel.rs:281-292)
+                float value = 1.0f * v0;
+                if (p.out_bias[mat]) value += bf16_to_f32(p.out_bias[mat][lrow]);
+                if (ACT) {
+                    float gate = 1.0f * v1;
+                    if (p.out_bias[0]) gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
+                    const float up_b = round_bf16(value), gate_b = round_bf16(gate);
+                    // GatedActMul (gated_act_mul/mod.rs:5-12): (up * act(gate)) in bf16
+                    p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b)));
+                } else {
+                    const uint16_t ob = f32_to_bf16(value);
+                    p.out[mat][lrow] = ob;
+                    if (p.part_val) {
+                        const float lv = bf16_to_f32(ob);
+                        if (lv > best_v || (lv == best_v && lrow < best_i)) best_v = lv, best_i = lrow;
+                    }
+                }
+            }
+        }
+    }
+    if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
+        __shared__ float sv[4];
+        __shared__ uint32_t si[4];
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best_v, off, 64);
+            const uint32_t oi = __shfl_xor(best_i, off, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+        }
+        if (lane == 0) sv[wave] = best_v, si[wave] = best_i;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (sv[w2] > best_v || (sv[w2] == best_v && si[w2] < best_i)) best_v = sv[w2], best_i = si[w2];
+            p.part_val[blockIdx.x] = best_v;
+            p.part_idx[blockIdx.x] = best_i;
+        }
+    }
+}
+
+uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2_out, int* R_out) {
+    const int lpr_log2 = gemv_lpr_log2(p.k);
+    const int rpw = 64 >> lpr_log2;
+    const uint32_t n_log0 = p.act_mul ? p.n[0] / 2 : p.n[0];
+    static int force_r = -1, tw = -1, capw = -1;
+    if (force_r < 0) {
+        const char* e = getenv("UZU_DEC_R");
+        force_r = e ? atoi(e) : 0;
+        const char* t = getenv("UZU_DEC_TW");
+        tw = t ? atoi(t) : 8;
+        const char* c = getenv("UZU_DEC_CAP");
+        capw = c ? atoi(c) : 6;
+    }
+    int R = p.act_mul ? 2 : 4;
+    const uint32_t target_waves = (uint32_t)num_cus * tw;
+    auto nb = [&](int rr) { return (n_log0 + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw) + (p.n[1] + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw); };
+    while (R > 1 && nb(R) < target_waves) R >>= 1;
+    if (force_r > 0) R = p.act_mul && force_r > 2 ? 2 : force_r;
+    {
+        const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
+        if (cpl > 2 && R > 2 && (p.norm_scales || p.norm_plain)) R = 2; // the 4-step register path is instantiated for R <= 2
+    }
+    uint32_t grid = (nb(R) + 3) / 4;
+    const uint32_t cap = (uint32_t)num_cus * capw; // persistent beyond that many workgroups per CU
+    if (grid > cap) grid = cap;
+    *lpr_log2_out = lpr_log2;
+    *R_out = R;
+    return grid;
+}
+
+template <int BITS, int CPLT, bool ACT>
+static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t grid, int lpr_log2, int R) {
+    const size_t lds = (p.norm_scales || p.norm_plain) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
+#define UZU_LAUNCH(RR) return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec")
+    if (!ACT && R == 4) UZU_LAUNCH(ACT ? 2 : 4);
+    if (R >= 2) UZU_LAUNCH(2);
+    UZU_LAUNCH(1);
+#undef UZU_LAUNCH
+}
+template <int BITS, bool ACT>
+static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uint32_t grid, int lpr_log2, int R) {
+    const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
+    if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, grid, lpr_log2, R);
+    if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, grid, lpr_log2, R);
+    if (cpl <= 4 && (p.norm_scales || p.norm_plain)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, grid, lpr_log2, R);
+    if (p.norm_scales || p.norm_plain) {
+        set_error("gemv_dec: Normalization prologue supports K <= 8192, K %% 1024 == 0 (got %u)", p.k);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    return launch_gemv_dec_r<BITS, 0, ACT>(s, p, grid, lpr_log2, R);
+}
+
+uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out) {
+    if ((p.bits != 4 && p.bits != 8) || p.k % 32 || p.group_size % 32 || (p.group_size & (p.group_size - 1)) || ((p.norm_scales || p.norm_plain) && p.k % 1024)) {
+        set_error("gemv_dec: unsupported shape (bits %u, k %u, group %u)", p.bits, p.k, p.group_size);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    int lpr_log2, R;
+    uint32_t grid = gemv_dec_grid(p, num_cus, &lpr_log2, &R);
+    if (grid_out) *grid_out = grid;
+    if (p.act_mul) {
+        if (p.bits == 4) return launch_gemv_dec_cpl<4, true>(s, p, grid, lpr_log2, R);
+        return launch_gemv_dec_cpl<8, true>(s, p, grid, lpr_log2, R);
+    }
+    if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, grid, lpr_log2, R);
+    return launch_gemv_dec_cpl<8, false>(s, p, grid, lpr_log2, R);
+}
+
+// ---------------------------------------------------------------------------------------------- argmax_commit
+__global__ void __launch_bounds__(256) argmax_commit_kernel(const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len,
+                                                            uint32_t* tokens, uint32_t* out_token, uint32_t* sampled) {
+    __shared__ float sv[4];
+    __shared__ uint32_t si[4];
+    float bv = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < parts; i += 256) {
+        const float v = pv[i];
+        const uint32_t ix = pi[i];
+        if (v > bv || (v == bv && ix < bi)) bv = v, bi = ix;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const uint32_t oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sv[wave] = bv, si[wave] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) bv = sv[w], bi = si[w];
+        const uint32_t t = bi == 0xFFFFFFFFu ? 0u : bi;
+        const uint32_t len = *ctx_len;
+        *out_token = t;
+        sampled[len] = t;
+        tokens[0] = t;
+        *ctx_len = len + 1;
+    }
+}
+uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len, uint32_t* tokens,
+                         uint32_t* out_token, uint32_t* sampled) {
+    return launch_check([&] { hipLaunchKernelGGL(argmax_commit_kernel, dim3(1), dim3(256), 0, s, pv, pi, parts, ctx_len, tokens, out_token, sampled); },
+                        "argmax_commit");
+}
+
+// ---------------------------------------------------------------------------------------------- delta_dec
+// DeltaNetConvUpdate (conv_update.rs:17-55) + DeltaNetUpdate (update.rs:30-143) for one token.
+// One workgroup (1024 threads) per value head; half a wave owns one state row per pass.
+__global__ void __launch_bounds__(1024) delta_dec_kernel(DeltaDecParams p) {
+    constexpr int DK = 128;
+    __shared__ float s_q[DK], s_k[DK], s_v[512], s_o[512], s_red[16];
+    const uint32_t hv = blockIdx.x;
+    const uint32_t gph = p.num_v_heads / p.num_k_heads;
+    const uint32_t hk = hv / gph;
+    const uint32_t key_dim = p.key_dim, value_dim = p.value_dim, conv_dim = 2 * key_dim + value_dim;
+    const uint32_t Dv = p.head_v_dim, ks = p.kernel_size, tap_count = ks - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sl = lane & 31, half = lane >> 5;
+    const uint32_t rows_per_pass = 32; // 16 waves x 2
+
+    // state rows of the first passes are requested before anything else (they do not depend on the conv)
+    constexpr int MAXP = 4;
+    float4 pre[MAXP];
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps) {
+        const uint32_t i = ps * rows_per_pass + wave * 2 + half;
+        if (i < Dv) pre[ps] = *((const float4*)(p.state + ((size_t)hv * Dv + i) * DK) + sl);
+    }
+    // conv + SiLU for the channels this head consumes: q[hk], k[hk] (DK each), v[hv] (Dv)
+    for (uint32_t t = tid; t < 2 * DK + Dv; t += blockDim.x) {
+        uint32_t channel;
+        float* dst;
+        bool owner = true; // q/k channels are shared by the gph value heads of a key head: one writer
+        if (t < DK) channel = hk * DK + t, dst = &s_q[t], owner = (hv % gph) == 0;
+        else if (t < 2 * DK) channel = key_dim + hk * DK + (t - DK), dst = &s_k[t - DK], owner = (hv % gph) == 0;
+        else channel = 2 * key_dim + hv * Dv + (t - 2 * DK), dst = &s_v[t - 2 * DK];
+        float* st_row = p.conv_state + (size_t)channel * tap_count;
+        const float* w = p.conv_w + (size_t)channel * ks;
+        const float x = bf16_to_f32(p.in_proj[channel]);
+        float acc = p.conv_b ? p.conv_b[channel] : 0.0f;
+        float taps[8];
+#pragma unroll
+        for (uint32_t tap = 0; tap < 8; ++tap)
+            if (tap < tap_count) {
+                taps[tap] = st_row[tap];
+                acc += taps[tap] * w[tap];
+            }
+        acc += x * w[tap_count];
+        *dst = round_bf16(silu_f32(acc));
+        if (owner) {
+#pragma unroll
+            for (uint32_t tap = 1; tap < 8; ++tap)
+                if (tap < tap_count) st_row[tap - 1] = taps[tap];
+            st_row[tap_count - 1] = x;
+        }
+    }
+    __syncthreads();
+    float q[4], kk[4];
+    float q_sq = 0.f, k_sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        q[e] = s_q[sl * 4 + e];
+        kk[e] = s_k[sl * 4 + e];
+        q_sq += q[e] * q[e];
+        k_sq += kk[e] * kk[e];
+    }
+    q_sq = group_sum<32>(q_sq);
+    k_sq = group_sum<32>(k_sq);
+    const float q_inv_norm = 1.0f / sqrtf(q_sq + 1e-6f);
+    const float k_inv_norm = 1.0f / sqrtf(k_sq + 1e-6f);
+    const float q_scale = 1.0f / sqrtf((float)DK);
+    float kq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        q[e] = (q[e] * q_inv_norm) * q_scale;
+        kk[e] = kk[e] * k_inv_norm;
+        kq += kk[e] * q[e];
+    }
+    const float kq_dot = group_sum<32>(kq);
+    const float beta_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + hv]);
+    const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
+    const float a_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + p.num_v_heads + hv]);
+    const float sp_input = a_raw + p.dt_bias[hv];
+    const float sp = sp_input > 20.0f ? sp_input : logf_glibc(1.0f + expf_glibc(sp_input));
+    const float g = -expf_glibc(p.a_log[hv]) * sp;
+    const float decay = expf_glibc(g);
+
+    for (uint32_t ps = 0; ps * rows_per_pass < Dv; ++ps) {
+        const uint32_t i = ps * rows_per_pass + wave * 2 + half;
+        if (i < Dv) {
+            float4* srow = (float4*)(p.state + ((size_t)hv * Dv + i) * DK) + sl;
+            float4 sv;
+            if (ps < MAXP) {
+                // static selection keeps `pre` in registers
+                sv = ps == 0 ? pre[0] : ps == 1 ? pre[1] : ps == 2 ? pre[2] : pre[3];
+            } else {
+                sv = *srow;
+            }
+            const float v_i = s_v[i];
+            const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+            float sq = 0.f, sk = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sq = fmaf(s4[e], q[e], sq);
+                sk = fmaf(s4[e], kk[e], sk);
+            }
+            sq = group_sum<32>(sq);
+            sk = group_sum<32>(sk);
+            const float retrieved_i = decay * sk;
+            const float delta_i = beta * (v_i - retrieved_i);
+            const float o_i = decay * sq + delta_i * kq_dot;
+            float4 ns;
+            ns.x = decay * s4[0] + kk[0] * delta_i;
+            ns.y = decay * s4[1] + kk[1] * delta_i;
+            ns.z = decay * s4[2] + kk[2] * delta_i;
+            ns.w = decay * s4[3] + kk[3] * delta_i;
+            *srow = ns;
+            if (sl == 0) s_o[i] = o_i;
+        }
+    }
+    __syncthreads();
+    float o_sq = 0.f;
+    for (uint32_t i = tid; i < Dv; i += blockDim.x) o_sq += s_o[i] * s_o[i];
+    const float sumsq = block_sum(o_sq, s_red);
+    const float inv_rms = 1.0f / sqrtf(sumsq / (float)Dv + p.norm_epsilon);
+    for (uint32_t i = tid; i < Dv; i += blockDim.x) {
+        const float z_i = bf16_to_f32(p.in_proj[conv_dim + hv * Dv + i]);
+        p.out[hv * Dv + i] = f32_to_bf16(s_o[i] * inv_rms * p.norm_weight[i] * silu_f32(z_i));
+    }
+}
+uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p) {
+    if (p.head_v_dim > 512 || p.kernel_size > 9 || p.kernel_size < 2 || p.num_k_heads == 0 || p.num_v_heads % p.num_k_heads) {
+        set_error("delta_dec: unsupported configuration");
+        return UZU_ERR_UNSUPPORTED;
+    }
+    return launch_check([&] { hipLaunchKernelGGL(delta_dec_kernel, dim3(p.num_v_heads), dim3(1024), 0, s, p); }, "delta_dec");
+}
+
+// ---------------------------------------------------------------------------------------------- attn_dec
+// One decode token: QKVNorm (q, k) + AttentionPrepare (RoPE, KV append) + split-KV attention pass 1.
+// grid (kv_head * subs + sub, split); 256 threads.  Keys of split s: i = s, s + S, s + 2S, ...
+template <int HD, int GS>
+__global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
+    constexpr int LPK = HD / 8, KG = 64 / LPK, NGRP = 4 * KG;
+    __shared__ float s_q[GS][HD];
+    __shared__ float s_knew[HD], s_vnew[HD];
+    __shared__ float s_o[4][GS][HD];
+    __shared__ float s_m[4][GS], s_l[4][GS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t subs = p.gqa_factor / GS;
+    const uint32_t kvh = blockIdx.x / subs, sub = blockIdx.x % subs;
+    const uint32_t head0 = kvh * p.gqa_factor + sub * GS;
+    const uint32_t split = blockIdx.y, S = gridDim.y;
+    const uint32_t L = *p.ctx_len; // position of the new token = number of cached keys
+    const uint32_t nq = p.num_heads, nkv = p.num_heads / p.gqa_factor;
+    const uint32_t rope_dim = p.rope_dim, half_rope = rope_dim / 2;
+
+    // ---- prologue: normalised + roped q heads (one wave per head, elements lane + 64 j), new k and v rows ----
+    // (QKVNorm: qkv_norm.rs:45-76 ; AttentionPrepare: attention_prepare.rs:7-31,104-121)
+    for (int job = wave; job < GS + 2; job += 4) {
+        const bool is_q = job < GS, is_k = job == GS;
+        const uint32_t head_idx = is_q ? head0 + job : (is_k ? nq + kvh : nq + nkv + kvh);
+        const uint16_t* src = p.qkv + (size_t)head_idx * HD;
+        float vals[HD / 64];
+        float total = 0.f;
+#pragma unroll
+        for (int j = 0; j < HD / 64; ++j) {
+            vals[j] = bf16_to_f32(src[lane + 64 * j]);
+            total += vals[j] * vals[j];
+        }
+        const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
+        if (!(is_q || is_k) || !nm.present) {
+            // V rows (and un-normalised q/k) pass through
+        } else {
+            total = wave_sum(total);
+            const float rms_norm = 1.0f / sqrtf(total / (float)HD + nm.eps);
+#pragma unroll
+            for (int j = 0; j < HD / 64; ++j) {
+                const float normalized = vals[j] * rms_norm;
+                const uint32_t i = lane + 64 * j;
+                if (!nm.scales)
+                    vals[j] = round_bf16(normalized);
+                else if (nm.full_layer)
+                    vals[j] = round_bf16(normalized * (nm.scales[i] + nm.offset));
+                else
+                    vals[j] = round_bf16(round_bf16(normalized) * round_bf16(nm.scales[i] + nm.offset));
+            }
+        }
+        float* dst = is_q ? s_q[job] : (is_k ? s_knew : s_vnew);
+#pragma unroll
+        for (int j = 0; j < HD / 64; ++j) dst[lane + 64 * j] = vals[j];
+    }
+    __syncthreads();
+    if (rope_dim) { // half-rotation RoPE on q heads and the new key (table row = absolute position L); one thread per pair
+        const float* cosr = p.cosines + (size_t)L * rope_dim;
+        const float* sinr = p.sines + (size_t)L * rope_dim;
+        for (uint32_t t = tid; t < (GS + 1) * half_rope; t += 256) {
+            const uint32_t v = t / half_rope, d = t % half_rope;
+            float* vec = v < GS ? s_q[v] : s_knew;
+            const float a = vec[d], b = vec[d + half_rope];
+            const float lo = round_bf16(a * cosr[d] + (-b) * sinr[d]);
+            const float hi = round_bf16(b * cosr[d + half_rope] + a * sinr[d + half_rope]);
+            vec[d] = lo;
+            vec[d + half_rope] = hi;
+        }
+        __syncthreads();
+    }
+    if (split == 0 && sub == 0) { // append the new K / V rows to the cache (layout [tokens, kv_heads, hd])
+        for (uint32_t d = tid; d < HD; d += 256) {
+            p.keys[((size_t)L * nkv + kvh) * HD + d] = f32_to_bf16(s_knew[d]);
+            p.values[((size_t)L * nkv + kvh) * HD + d] = f32_to_bf16(s_vnew[d]);
+        }
+    }
+
+    // ---- split-KV online softmax over keys i = split + S * t, i <= L (causal, suffix length 1) ----
+    const int kgrp = lane / LPK, sl = lane % LPK;
+    const uint32_t my_group = wave * KG + kgrp;
+    float q[GS][8], o[GS][8], mx[GS], sm[GS];
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[g][e] = p.scale * s_q[g][sl * 8 + e], o[g][e] = 0.f;
+        mx[g] = -1e9f;
+        sm[g] = 0.f;
+    }
+    const uint16_t* kbase = p.keys + (size_t)kvh * HD + sl * 8;
+    const uint16_t* vbase = p.values + (size_t)kvh * HD + sl * 8;
+    const size_t seq_stride = (size_t)nkv * HD;
+    for (uint32_t i = split + S * my_group; i <= L; i += S * NGRP) {
+        float kf[8], vf[8];
+        if (i == L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kf[e] = s_knew[sl * 8 + e], vf[e] = s_vnew[sl * 8 + e];
+        } else {
+            const uint4 ku = *(const uint4*)(kbase + (size_t)i * seq_stride);
+            const uint4 vu = *(const uint4*)(vbase + (size_t)i * seq_stride);
+            const uint32_t kw[4] = {ku.x, ku.y, ku.z, ku.w}, vw[4] = {vu.x, vu.y, vu.z, vu.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bits_to_f32(kw[j] << 16), kf[2 * j + 1] = bits_to_f32(kw[j] & 0xFFFF0000u);
+                vf[2 * j] = bits_to_f32(vw[j] << 16), vf[2 * j + 1] = bits_to_f32(vw[j] & 0xFFFF0000u);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf(q[g][e], kf[e], part);
+            const float score = group_sum<LPK>(part);
+            const float new_max = fmaxf(mx[g], score);
+            const float factor = expf_glibc(mx[g] - new_max);
+            const float exp_score = expf_glibc(score - new_max);
+            mx[g] = new_max;
+            sm[g] = sm[g] * factor + exp_score;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * factor + exp_score * vf[e];
+        }
+    }
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            const float m2 = __shfl_xor(mx[g], off, 64), l2 = __shfl_xor(sm[g], off, 64);
+            const float nm = fmaxf(mx[g], m2);
+            const float f1 = expf_glibc(mx[g] - nm), f2 = expf_glibc(m2 - nm);
+            sm[g] = sm[g] * f1 + l2 * f2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * f1 + __shfl_xor(o[g][e], off, 64) * f2;
+            mx[g] = nm;
+        }
+    }
+    if (kgrp == 0) {
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_o[wave][g][sl * 8 + e] = o[g][e];
+            if (sl == 0) s_m[wave][g] = mx[g], s_l[wave][g] = sm[g];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < GS * HD; idx += 256) {
+        const int g = idx / HD, e = idx % HD;
+        float m = s_m[0][g];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = fmaxf(m, s_m[w][g]);
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = expf_glibc(s_m[w][g] - m);
+            l += s_l[w][g] * f;
+            acc += s_o[w][g][e] * f;
+        }
+        const size_t row = (size_t)(head0 + g) * S + split;
+        p.partials[row * HD + e] = acc;
+        if (e == 0) p.sums[row] = l, p.maxs[row] = m;
+    }
+}
+
+template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
+    const uint32_t kv_heads = p.num_heads / p.gqa_factor;
+    const uint32_t cap = HD >= 256 ? 4 : 8;
+    uint32_t gs = 1;
+    for (uint32_t c = cap; c >= 1; c >>= 1)
+        if (p.gqa_factor % c == 0) {
+            gs = c;
+            break;
+        }
+    const dim3 grid(kv_heads * (p.gqa_factor / gs), splits);
+#define UZU_LAUNCH(G) return launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G>), grid, dim3(256), 0, s, p); }, "attn_dec")
+    switch (gs) {
+    case 8: if constexpr (HD < 256) { UZU_LAUNCH(8); } [[fallthrough]];
+    case 4: UZU_LAUNCH(4);
+    case 2: UZU_LAUNCH(2);
+    default: UZU_LAUNCH(1);
+    }
+#undef UZU_LAUNCH
+}
+uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
+    if (p.rope_dim > p.head_dim || (p.rope_dim & 1)) {
+        set_error("attn_dec: bad rope_dim %u", p.rope_dim);
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    switch (p.head_dim) {
+    case 64: return launch_attn_dec<64>(s, p, splits);
+    case 128: return launch_attn_dec<128>(s, p, splits);
+    case 256: return launch_attn_dec<256>(s, p, splits);
+    default:
+        set_error("attn_dec: unsupported head_dim %u", p.head_dim);
+        return UZU_ERR_UNSUPPORTED;
+    }
+}
+
+// AttentionTwoPass2 over S splits + SigmoidGate: one workgroup per head, one thread per output element
+__global__ void __launch_bounds__(256) attn_merge_kernel(const float* partials, const float* sums, const float* maxs, const uint16_t* gate,
+                                                         uint16_t* out, uint32_t HD, uint32_t S) {
+    extern __shared__ float sw[]; // [S] weights
+    __shared__ float s_gsum;
+    const uint32_t head = blockIdx.x;
+    const float* mx = maxs + (size_t)head * S;
+    const float* sm = sums + (size_t)head * S;
+    float gmax = -INFINITY;
+    for (uint32_t b = 0; b < S; ++b) gmax = fmaxf(gmax, mx[b]);
+    for (uint32_t b = threadIdx.x; b < S; b += 256) sw[b] = expf_glibc(mx[b] - gmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gs = 0.f;
+        for (uint32_t b = 0; b < S; ++b) gs += sm[b] * sw[b];
+        s_gsum = gs;
+    }
+    __syncthreads();
+    const float gsum = s_gsum;
+    for (uint32_t j = threadIdx.x; j < HD; j += 256) {
+        float val = 0.f;
+        for (uint32_t b = 0; b < S; ++b) val += partials[((size_t)head * S + b) * HD + j] * sw[b];
+        float r = round_bf16(val / gsum);
+        if (gate) { // SigmoidGate (sigmoid_gate.rs:9-22)
+            const float g = bf16_to_f32(gate[(size_t)head * HD + j]);
+            r = round_bf16(r * (1.0f / (1.0f + expf_glibc(-g))));
+        }
+        out[(size_t)head * HD + j] = f32_to_bf16(r);
+    }
+}
+uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, const float* maxs, const uint16_t* gate, uint16_t* out,
+                      uint32_t num_heads, uint32_t head_dim, uint32_t splits) {
+    return launch_check([&] {
+        hipLaunchKernelGGL(attn_merge_kernel, dim3(num_heads), dim3(256), splits * sizeof(float), s, partials, sums, maxs, gate, out, head_dim, splits);
+    }, "attn_merge");
+}
+
+} // namespace k
+} // namespace uzu

@@ -4,25 +4,33 @@
 // rounding points exactly (compiled with -ffp-contract=off, glibc-exact expf), so they are BIT-EXACT
 // against the CPU path; kernels with a reduction (norms, argmax is exact) use fixed-order trees.
 #include "device_utils.h"
+#include "gemv_core.h"
 #include "kernels.h"
 
 namespace uzu {
 namespace k {
 
 // =============================================================== Normalization
-// BU/cpu/kernel/normalization/normalization.rs:56-125.  One workgroup per row; the (residual-added)
-// row is staged in LDS as f32 between the statistics pass and the scaling pass.
+// BU/cpu/kernel/normalization/normalization.rs:56-125.  One workgroup (256 threads) per row.  Reduction order
+// (shared with the fused decode prologue in k_decode.hip): thread t owns the E = ceil(n/256) consecutive
+// elements [t*E, t*E+E), accumulates them in order with one fma chain, then the wave butterfly 32..1, then the
+// four wave results are added in wave order.
+__device__ __forceinline__ float block_sum4(float v, float* red) { // 256 threads; red: 4 floats of LDS
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
 template <class T, class TA>
 __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* row = smem;                   // [element_count]
-    float* red = smem + p.element_count; // [16]
-    const uint32_t n = p.element_count;
+    __shared__ float red[8];
+    const uint32_t n = p.element_count, E = (n + 255) / 256;
     const size_t off = (size_t)blockIdx.x * n;
     const T* input = p.input ? (const T*)p.input : (const T*)p.output;
     T* shortcut = (T*)p.shortcut;
+    const uint32_t e0 = threadIdx.x * E, e1 = e0 + E < n ? e0 + E : n;
     float sum = 0.f, sum_sq = 0.f;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (uint32_t i = e0; i < e1; ++i) {
         float val = ld(input, off + i);
         if (p.copy_to_shortcut) {
             if (p.residual_add) {
@@ -31,20 +39,20 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
             }
             st(shortcut, off + i, val);
         }
-        row[i] = val;
         if (p.subtract_mean) sum += val;
-        sum_sq += val * val;
+        sum_sq = fmaf(val, val, sum_sq);
     }
     const float cnt = (float)n;
     float mean = 0.f;
-    if (p.subtract_mean) mean = block_sum(sum, red) / cnt;
-    const float variance = block_sum(sum_sq, red) / cnt - mean * mean;
+    if (p.subtract_mean) mean = block_sum4(sum, red) / cnt;
+    const float variance = block_sum4(sum_sq, red + 4) / cnt - mean * mean;
     const float rms_inv = 1.0f / sqrtf(variance + p.epsilon);
     T* out = (T*)p.output;
     const TA* scales = (const TA*)p.scales;
     const TA* biases = (const TA*)p.biases;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float normalized = (row[i] - mean) * rms_inv;
+    const T* src = p.residual_add ? (const T*)shortcut : input; // normalization.rs:95-99 (own elements: same thread wrote them)
+    for (uint32_t i = e0; i < e1; ++i) {
+        const float normalized = (ld(src, off + i) - mean) * rms_inv;
         float result;
         if (scales) {
             const float scale_val = ld(scales, i);
@@ -63,16 +71,11 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
 
 uzu_status normalization(hipStream_t s, const NormParams& p) {
     if (p.batch_size == 0) return UZU_OK;
-    const size_t lds = ((size_t)p.element_count + 16) * sizeof(float);
-    if (lds > 160 * 1024) {
-        set_error("normalization: element_count %u exceeds the LDS staging limit", p.element_count);
-        return UZU_ERR_UNSUPPORTED;
-    }
     return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
         if (p.affine_dt == UZU_F32)
-            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, float>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization");
+            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, float>), dim3(p.batch_size), dim3(256), 0, s, p); }, "normalization");
         if (p.affine_dt == UZU_BF16)
-            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, bf16_t>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization");
+            return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, bf16_t>), dim3(p.batch_size), dim3(256), 0, s, p); }, "normalization");
         set_error("normalization: unsupported affine dtype %u", p.affine_dt);
         return UZU_ERR_UNSUPPORTED;
     });

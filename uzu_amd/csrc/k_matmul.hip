@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "device_utils.h"
+#include "gemv_core.h"
 #include "kernels.h"
 
 namespace uzu {
@@ -101,107 +102,28 @@ __global__ void __launch_bounds__(256) matmul_ref_kernel(MatmulParams p, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast quantised GEMV.
-template <class T> struct Vec16;      // 16 bytes of activations
-template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
-template <> struct Vec16<float> { static constexpr int N = 4; };
-
-// load WPC activations starting at element e into f32 registers
-template <class TA, int WPC> __device__ __forceinline__ void load_x(const TA* a, size_t e, float (&xf)[WPC]);
-template <> __device__ __forceinline__ void load_x<bf16_t, 32>(const bf16_t* a, size_t e, float (&xf)[32]) {
-    const uint4* src = (const uint4*)(a + e);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const uint4 u = src[v];
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xf[v * 8 + 2 * j] = bits_to_f32(w[j] << 16);
-            xf[v * 8 + 2 * j + 1] = bits_to_f32(w[j] & 0xFFFF0000u);
-        }
-    }
-}
-template <> __device__ __forceinline__ void load_x<bf16_t, 16>(const bf16_t* a, size_t e, float (&xf)[16]) {
-    const uint4* src = (const uint4*)(a + e);
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        const uint4 u = src[v];
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xf[v * 8 + 2 * j] = bits_to_f32(w[j] << 16);
-            xf[v * 8 + 2 * j + 1] = bits_to_f32(w[j] & 0xFFFF0000u);
-        }
-    }
-}
-template <> __device__ __forceinline__ void load_x<float, 32>(const float* a, size_t e, float (&xf)[32]) {
-    const float4* src = (const float4*)(a + e);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const float4 u = src[v];
-        xf[v * 4] = u.x, xf[v * 4 + 1] = u.y, xf[v * 4 + 2] = u.z, xf[v * 4 + 3] = u.w;
-    }
-}
-template <> __device__ __forceinline__ void load_x<float, 16>(const float* a, size_t e, float (&xf)[16]) {
-    const float4* src = (const float4*)(a + e);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const float4 u = src[v];
-        xf[v * 4] = u.x, xf[v * 4 + 1] = u.y, xf[v * 4 + 2] = u.z, xf[v * 4 + 3] = u.w;
-    }
-}
-
-// sum_j code_j * x_j over one 16-byte chunk of codes
-template <int BITS> __device__ __forceinline__ float chunk_dot(const uint4& w, const float* xf);
-template <> __device__ __forceinline__ float chunk_dot<4>(const uint4& w, const float* xf) {
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t lo = ws[i] & 0x0F0F0F0Fu;        // codes 0,2,4,6 of this word
-        const uint32_t hi = (ws[i] >> 4) & 0x0F0F0F0Fu; // codes 1,3,5,7
-        const float* x = xf + i * 8;
-        d = fmaf((float)(lo & 0xFFu), x[0], d);
-        d = fmaf((float)(hi & 0xFFu), x[1], d);
-        d = fmaf((float)((lo >> 8) & 0xFFu), x[2], d);
-        d = fmaf((float)((hi >> 8) & 0xFFu), x[3], d);
-        d = fmaf((float)((lo >> 16) & 0xFFu), x[4], d);
-        d = fmaf((float)((hi >> 16) & 0xFFu), x[5], d);
-        d = fmaf((float)(lo >> 24), x[6], d);
-        d = fmaf((float)(hi >> 24), x[7], d);
-    }
-    return d;
-}
-template <> __device__ __forceinline__ float chunk_dot<8>(const uint4& w, const float* xf) {
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float* x = xf + i * 4;
-        d = fmaf((float)(ws[i] & 0xFFu), x[0], d);
-        d = fmaf((float)((ws[i] >> 8) & 0xFFu), x[1], d);
-        d = fmaf((float)((ws[i] >> 16) & 0xFFu), x[2], d);
-        d = fmaf((float)(ws[i] >> 24), x[3], d);
-    }
-    return d;
-}
+// Fast quantised GEMV (lane mapping and arithmetic: gemv_core.h).
+template <class TA> __device__ __forceinline__ void load_x32(const TA* a, size_t e, float (&xf)[32]);
+template <> __device__ __forceinline__ void load_x32<bf16_t>(const bf16_t* a, size_t e, float (&xf)[32]) { load32_bf16((const uint16_t*)a + e, xf); }
+template <> __device__ __forceinline__ void load_x32<float>(const float* a, size_t e, float (&xf)[32]) { load32_f32(a + e, xf); }
 
 template <class TW, class TA, int BITS, int MT, int R>
 __global__ void __launch_bounds__(256) gemv_q_kernel(MatmulParams p, int lpr_log2) {
-    constexpr int WPC = 128 / BITS; // weights per 16-byte chunk
+    using Codes = typename CodesT<BITS>::type;
+    constexpr int STEP_BYTES = 4 * BITS; // code bytes per 32-element step
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int sl = lane & (lpr - 1), rsub = lane >> lpr_log2;
     const uint32_t row_base = (blockIdx.x * 4 + wave) * (uint32_t)(R * rpw);
     const uint32_t m0 = blockIdx.y * MT;
-    const uint32_t C = p.k / WPC;
+    const uint32_t C = p.k / 32;
     const size_t row_bytes = (size_t)p.k * BITS / 8;
     const uint32_t G = (p.k + p.group_size - 1) / p.group_size;
     const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
     const uint32_t flip = p.signed_codes ? (BITS == 4 ? 0x88888888u : 0x80808080u) : 0u;
 
-    uint32_t rows[R];    // output column handled in slot r
-    size_t brow[R];      // B row (differs from rows[] only with gather; MT == 1 then)
+    uint32_t rows[R];
+    size_t brow[R];
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -222,12 +144,12 @@ __global__ void __launch_bounds__(256) gemv_q_kernel(MatmulParams p, int lpr_log
     const uint8_t* bcodes = (const uint8_t*)p.b;
 
     for (uint32_t c = sl; c < C; c += lpr) {
-        uint4 w[R];
+        Codes w[R];
         float sc[R], of[R];
-        const uint32_t grp = (c * WPC) / p.group_size;
+        const uint32_t grp = (c * 32) / p.group_size;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            w[r] = *(const uint4*)(bcodes + brow[r] * row_bytes + (size_t)c * 16);
+            load_codes(w[r], bcodes + brow[r] * row_bytes + (size_t)c * STEP_BYTES);
             sc[r] = ld(scales, brow[r] * G + grp);
         }
 #pragma unroll
@@ -246,19 +168,17 @@ __global__ void __launch_bounds__(256) gemv_q_kernel(MatmulParams p, int lpr_log
             } else {
                 of[r] = -sc[r] * (float)(1u << (BITS - 1));
             }
-            if (flip) w[r].x ^= flip, w[r].y ^= flip, w[r].z ^= flip, w[r].w ^= flip;
+            if (flip) flip_codes(w[r], flip);
         }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             if (m0 + mi < p.m) {
-                float xf[WPC];
-                load_x<TA, WPC>(a, (size_t)(m0 + mi) * p.k + (size_t)c * WPC, xf);
-                float xsum = 0.f;
-#pragma unroll
-                for (int j = 0; j < WPC; ++j) xsum += xf[j];
+                float xf[32];
+                load_x32<TA>(a, (size_t)(m0 + mi) * p.k + (size_t)c * 32, xf);
+                const float xsum = sum32(xf);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float dq = chunk_dot<BITS>(w[r], xf);
+                    const float dq = dot32(w[r], xf);
                     acc[mi][r] = fmaf(sc[r], dq, fmaf(of[r], xsum, acc[mi][r]));
                 }
             }
@@ -268,7 +188,7 @@ __global__ void __launch_bounds__(256) gemv_q_kernel(MatmulParams p, int lpr_log
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float v = group_sum_rt(acc[mi][r], lpr);
+            const float v = row_sum_rt(acc[mi][r], lpr);
             if (sl == 0 && valid[r] && m0 + mi < p.m) epilogue_store(p, m0 + mi, rows[r], v);
         }
 }
@@ -294,10 +214,7 @@ static const char* gemv_label(int bits, int mt, int R) {
 
 template <class TW, class TA, int BITS>
 static uzu_status launch_gemv(hipStream_t s, const MatmulParams& p, int num_cus, const char** variant) {
-    constexpr int WPC = 128 / BITS;
-    const uint32_t C = p.k / WPC;
-    int lpr_log2 = 0;
-    while ((1u << lpr_log2) < C && lpr_log2 < 6) ++lpr_log2;
+    const int lpr_log2 = gemv_lpr_log2(p.k);
     const int rpw = 64 >> lpr_log2;
     // rows per wave: enough waves to fill the chip (>= 8 waves per CU) before unrolling rows per lane
     const uint32_t target_waves = (uint32_t)num_cus * 8;
@@ -343,7 +260,7 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
         set_error("matmul: group size must be non-zero");
         return UZU_ERR_UNSUPPORTED;
     }
-    const uint32_t wpc = quant ? 128 / p.bits : 1;
+    const uint32_t wpc = quant ? 32 : 1; // a lane step covers 32 K elements (gemv_core.h)
     const bool aligned = ((uintptr_t)p.b % 16 == 0) && ((uintptr_t)p.a % 16 == 0);
     const bool fast = quant && !exact_mode() && aligned && p.k % wpc == 0 && p.group_size % wpc == 0 &&
                       (p.w_dt == p.a_dt) && (p.w_dt == UZU_BF16 || p.w_dt == UZU_F32);

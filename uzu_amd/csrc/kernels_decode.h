@@ -1,0 +1,83 @@
+// kernels_decode.h -- parameter blocks of the fused batch-1 decode kernels (k_decode.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uzu_hip.h"
+
+namespace uzu {
+namespace k {
+
+struct DecNorm {
+    uint32_t present;
+    uint32_t full_layer;
+    float eps, offset;
+    const float* scales;
+};
+
+struct DecGemvParams {
+    // one or two weight matrices with the same k / quantisation (e.g. qkv_projection || gate_projection)
+    const uint8_t* w[2];
+    const uint16_t* scales[2];
+    const uint16_t* biases[2];
+    const uint8_t* zp[2];
+    const uint16_t* out_bias[2];
+    uint16_t* out[2];
+    uint32_t n[2];
+    uint32_t k, bits, group_size, b_kind;
+    const uint16_t* x; // input row (bf16 [k])
+    // Normalization prologue (RMS; ShortcutMode Copy/Add)
+    uint32_t norm_plain;          // RMSNorm without scales
+    const float* norm_scales;     // non-null => normalise x first
+    float norm_eps, norm_offset;
+    uint32_t norm_full_layer, residual_add;
+    const uint16_t* shortcut_in;
+    uint16_t* shortcut_out;
+    uint16_t* normed_out;         // optional copy of the normalised row (debug / taps)
+    // epilogues
+    uint32_t act_mul, act_type;   // out[0][j] = up_j * act(gate_j), n[0] = 2h
+    float* part_val;              // arg-max partials, one per workgroup
+    uint32_t* part_idx;
+    uint32_t debug;               // microbenchmark ablations (tools/kbench): 1 = skip row loop, 2 = skip prologue
+};
+uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
+uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
+uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len, uint32_t* tokens,
+                         uint32_t* out_token, uint32_t* sampled);
+
+struct DeltaDecParams {
+    const uint16_t* in_proj;
+    const float* conv_w;
+    const float* conv_b;
+    float* conv_state;
+    const float* a_log;
+    const float* dt_bias;
+    const float* norm_weight;
+    float* state;
+    uint16_t* out;
+    uint32_t num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, kernel_size;
+    float norm_epsilon;
+};
+uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p);
+
+struct AttnDecParams {
+    const uint16_t* qkv;   // packed [q heads | k heads | v heads] x head_dim of the new token
+    uint16_t* keys;        // cache [tokens, kv_heads, hd]
+    uint16_t* values;
+    const float* cosines;  // [positions, rope_dim]
+    const float* sines;
+    const uint32_t* ctx_len;
+    DecNorm q_norm, k_norm;
+    uint32_t num_heads, gqa_factor, head_dim, rope_dim;
+    float scale;
+    float* partials;       // [heads, splits, hd]
+    float* sums;           // [heads, splits]
+    float* maxs;
+};
+uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits);
+uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, const float* maxs, const uint16_t* gate, uint16_t* out,
+                      uint32_t num_heads, uint32_t head_dim, uint32_t splits);
+
+} // namespace k
+} // namespace uzu
