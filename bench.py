@@ -132,7 +132,7 @@ def main():
         a[0] += 1
         a[1] += nbytes
         a[2] += ms
-    gemv = {k: v for k, v in agg.items() if k.startswith("gemv_q")}
+    gemv = {k: v for k, v in agg.items() if k.startswith(("gemv_q", "gemv_dec"))}
     dom_name = max(gemv, key=lambda k: gemv[k][2]) if gemv else max(agg, key=lambda k: agg[k][2])
     calls, dbytes, dms = agg[dom_name]
     achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0

@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
             p.num_v_heads = Hv, p.num_k_heads = 16, p.head_v_dim = Dv, p.key_dim = key_dim, p.value_dim = value_dim, p.kernel_size = 4, p.norm_epsilon = 1e-6f; return delta_dec(s, p); });
     }
     {   // attn_dec + merge, Qwen3.5-0.8B shape at ctx 2048
-        const uint32_t nq = 8, nkv = 2, hd = 256, ctx = 2048, splits = 64;
+        const uint32_t nq = 8, nkv = 2, hd = 256, ctx = 2048, splits = 128;
         uint16_t* qkv = dalloc<uint16_t>((nq + 2 * nkv) * hd, 0x3c); float* cosr = dalloc<float>((size_t)(ctx + 8) * 64, 0); float* sinr = dalloc<float>((size_t)(ctx + 8) * 64, 0);
         uint32_t* len = dalloc<uint32_t>(1, 0); uint32_t h = ctx; CK(hipMemcpy(len, &h, 4, hipMemcpyHostToDevice));
         float* qs = dalloc<float>(hd, 0); float* parts = dalloc<float>((size_t)nq * splits * hd); float* sums = dalloc<float>(nq * splits); float* maxs = dalloc<float>(nq * splits);
@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
             time_graph(sp == 32 ? "attn_dec ctx2048 S=32" : sp == 64 ? "attn_dec ctx2048 S=64" : "attn_dec ctx2048 S=128", (size_t)2 * ctx * nkv * hd * 2, reps, [&](int i) {
                 AttnDecParams p{}; p.qkv = qkv, p.keys = K[i % NBUF], p.values = V[i % NBUF], p.cosines = cosr, p.sines = sinr, p.ctx_len = len;
                 p.q_norm = {1, 1, 1e-6f, 1.f, qs}; p.k_norm = {1, 1, 1e-6f, 1.f, qs}; p.num_heads = nq, p.gqa_factor = 4, p.head_dim = hd, p.rope_dim = 64, p.scale = 0.0625f;
-                p.partials = parts, p.sums = sums, p.maxs = maxs; return attn_dec(s, p, sp > 64 ? 64 : sp); });
+                p.partials = parts, p.sums = sums, p.maxs = maxs; return attn_dec(s, p, sp); });
         time_graph("attn_merge S=64", (size_t)nq * 64 * hd * 4, reps, [&](int) { return attn_merge(s, parts, sums, maxs, gate, out, nq, hd, 64); });
     }
     return 0;

@@ -29,6 +29,11 @@ template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 
 constexpr int kWave = 64; // CDNA wavefront
 
+// exp for the softmax weights of the attention kernels: v_exp_f32 (2^x, <= 1 ulp) on x * log2(e).  The attention
+// kernels are tolerance-class (parallel reductions), so the glibc-exact expf (a dozen f64 ops + a table load per
+// call, hundreds of calls per lane) buys nothing there; the element-wise kernels keep expf_glibc.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // butterfly sum over the `width` (power of two <= 64) consecutive lanes that contain this lane
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) { return k::row_sum_rt(v, WIDTH); }
 __device__ __forceinline__ float wave_sum(float v) { return k::row_sum_rt(v, 64); }

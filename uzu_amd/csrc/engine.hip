@@ -716,7 +716,7 @@ uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc
         uint32_t wgs = 1; // kv_heads * head-subgroups of the widest attention layer
         for (auto& L : m->layers)
             if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
-                const uint32_t gqa = L.d.num_heads / L.d.num_groups, cap = L.d.head_dim >= 256 ? 4 : 8;
+                const uint32_t gqa = L.d.num_heads / L.d.num_groups, cap = 4;
                 uint32_t gs = 1;
                 for (uint32_t c = cap; c >= 1; c >>= 1)
                     if (gqa % c == 0) { gs = c; break; }

@@ -65,8 +65,8 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 // merge online-softmax state (m2,l2,o2) into (m,l,o)
 template <int N> __device__ __forceinline__ void merge_state(float& m, float& l, float (&o)[N], float m2, float l2, const float (&o2)[N]) {
     const float nm = fmaxf(m, m2);
-    const float f1 = (m == -INFINITY) ? 0.f : expf_glibc(m - nm);
-    const float f2 = (m2 == -INFINITY) ? 0.f : expf_glibc(m2 - nm);
+    const float f1 = (m == -INFINITY) ? 0.f : fast_exp(m - nm);
+    const float f2 = (m2 == -INFINITY) ? 0.f : fast_exp(m2 - nm);
     l = l * f1 + l2 * f2;
 #pragma unroll
     for (int e = 0; e < N; ++e) o[e] = o[e] * f1 + o2[e] * f2;
@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a,
             for (int e = 0; e < 8; ++e) part = fmaf(q[g][e], kf[e], part);
             const float score = group_sum<LPK>(part);
             const float new_max = fmaxf(mx[g], score);
-            const float factor = expf_glibc(mx[g] - new_max);
-            const float exp_score = expf_glibc(score - new_max);
+            const float factor = fast_exp(mx[g] - new_max);
+            const float exp_score = fast_exp(score - new_max);
             mx[g] = new_max;
             sm[g] = sm[g] * factor + exp_score;
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a,
         float l = 0.f, acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float f = (s_m[w][g] == -INFINITY) ? 0.f : expf_glibc(s_m[w][g] - m);
+            const float f = (s_m[w][g] == -INFINITY) ? 0.f : fast_exp(s_m[w][g] - m);
             l += s_l[w][g] * f;
             acc += s_o[w][g][e] * f;
         }

@@ -543,21 +543,43 @@ uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p) {
 // ---------------------------------------------------------------------------------------------- attn_dec
 // One decode token: QKVNorm (q, k) + AttentionPrepare (RoPE, KV append) + split-KV attention pass 1.
 // grid (kv_head * subs + sub, split); 256 threads.  Keys of split s: i = s, s + S, s + 2S, ...
+// Latency design: the context length is the only thing the kernel has to wait for before it can issue every
+// other load (qkv row, norm scales, RoPE row, and the first batch of K/V rows of each key group).
 template <int HD, int GS>
 __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     constexpr int LPK = HD / 8, KG = 64 / LPK, NGRP = 4 * KG;
+    constexpr int TB = 4; // keys per group per batch (all K/V loads of a batch are in flight together)
     __shared__ float s_q[GS][HD];
     __shared__ float s_knew[HD], s_vnew[HD];
-    __shared__ float s_o[4][GS][HD];
-    __shared__ float s_m[4][GS], s_l[4][GS];
+    __shared__ float s_o[NGRP][GS][HD];
+    __shared__ float s_m[NGRP][GS], s_l[NGRP][GS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t subs = p.gqa_factor / GS;
     const uint32_t kvh = blockIdx.x / subs, sub = blockIdx.x % subs;
     const uint32_t head0 = kvh * p.gqa_factor + sub * GS;
     const uint32_t split = blockIdx.y, S = gridDim.y;
-    const uint32_t L = *p.ctx_len; // position of the new token = number of cached keys
+    const uint32_t L = __builtin_amdgcn_readfirstlane(*p.ctx_len); // position of the new token = number of cached keys
     const uint32_t nq = p.num_heads, nkv = p.num_heads / p.gqa_factor;
     const uint32_t rope_dim = p.rope_dim, half_rope = rope_dim / 2;
+
+    const int kgrp = lane / LPK, sl = lane % LPK;
+    const uint32_t my_group = wave * KG + kgrp;
+    const uint16_t* kbase = p.keys + (size_t)kvh * HD + sl * 8;
+    const uint16_t* vbase = p.values + (size_t)kvh * HD + sl * 8;
+    const size_t seq_stride = (size_t)nkv * HD;
+    const uint32_t key0 = split + S * my_group, key_step = S * NGRP;
+    uint4 kq[TB], vq[TB];
+    auto fetch = [&](uint32_t first) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const uint32_t i = first + t * key_step;
+            if (i < L) {
+                kq[t] = *(const uint4*)(kbase + (size_t)i * seq_stride);
+                vq[t] = *(const uint4*)(vbase + (size_t)i * seq_stride);
+            }
+        }
+    };
+    fetch(key0);
 
     // ---- prologue: normalised + roped q heads (one wave per head, elements lane + 64 j), new k and v rows ----
     // (QKVNorm: qkv_norm.rs:45-76 ; AttentionPrepare: attention_prepare.rs:7-31,104-121)
@@ -573,9 +595,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
             total += vals[j] * vals[j];
         }
         const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
-        if (!(is_q || is_k) || !nm.present) {
-            // V rows (and un-normalised q/k) pass through
-        } else {
+        if ((is_q || is_k) && nm.present) {
             total = wave_sum(total);
             const float rms_norm = 1.0f / sqrtf(total / (float)HD + nm.eps);
 #pragma unroll
@@ -616,9 +636,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         }
     }
 
-    // ---- split-KV online softmax over keys i = split + S * t, i <= L (causal, suffix length 1) ----
-    const int kgrp = lane / LPK, sl = lane % LPK;
-    const uint32_t my_group = wave * KG + kgrp;
+    // ---- split-KV online softmax over keys i = key0 + key_step * t, i <= L (causal, suffix length 1) ----
     float q[GS][8], o[GS][8], mx[GS], sm[GS];
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
@@ -627,70 +645,60 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         mx[g] = -1e9f;
         sm[g] = 0.f;
     }
-    const uint16_t* kbase = p.keys + (size_t)kvh * HD + sl * 8;
-    const uint16_t* vbase = p.values + (size_t)kvh * HD + sl * 8;
-    const size_t seq_stride = (size_t)nkv * HD;
-    for (uint32_t i = split + S * my_group; i <= L; i += S * NGRP) {
-        float kf[8], vf[8];
-        if (i == L) {
+    for (uint32_t first = key0; first <= L; first += TB * key_step) {
+        uint4 kc[TB], vc[TB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) kf[e] = s_knew[sl * 8 + e], vf[e] = s_vnew[sl * 8 + e];
-        } else {
-            const uint4 ku = *(const uint4*)(kbase + (size_t)i * seq_stride);
-            const uint4 vu = *(const uint4*)(vbase + (size_t)i * seq_stride);
-            const uint32_t kw[4] = {ku.x, ku.y, ku.z, ku.w}, vw[4] = {vu.x, vu.y, vu.z, vu.w};
+        for (int t = 0; t < TB; ++t) kc[t] = kq[t], vc[t] = vq[t];
+        if (first + TB * key_step <= L) fetch(first + TB * key_step); // next batch in flight while this one is consumed
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bits_to_f32(kw[j] << 16), kf[2 * j + 1] = bits_to_f32(kw[j] & 0xFFFF0000u);
-                vf[2 * j] = bits_to_f32(vw[j] << 16), vf[2 * j + 1] = bits_to_f32(vw[j] & 0xFFFF0000u);
+        for (int t = 0; t < TB; ++t) {
+            const uint32_t i = first + t * key_step;
+            if (i > L) break;
+            float kf[8], vf[8];
+            if (i == L) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[e] = s_knew[sl * 8 + e], vf[e] = s_vnew[sl * 8 + e];
+            } else {
+                const uint32_t kw[4] = {kc[t].x, kc[t].y, kc[t].z, kc[t].w}, vw[4] = {vc[t].x, vc[t].y, vc[t].z, vc[t].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kf[2 * j] = bits_to_f32(kw[j] << 16), kf[2 * j + 1] = bits_to_f32(kw[j] & 0xFFFF0000u);
+                    vf[2 * j] = bits_to_f32(vw[j] << 16), vf[2 * j + 1] = bits_to_f32(vw[j] & 0xFFFF0000u);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < GS; ++g) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part = fmaf(q[g][e], kf[e], part);
+                const float score = group_sum<LPK>(part);
+                const float new_max = fmaxf(mx[g], score);
+                const float factor = fast_exp(mx[g] - new_max);
+                const float exp_score = fast_exp(score - new_max);
+                mx[g] = new_max;
+                sm[g] = sm[g] * factor + exp_score;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * factor + exp_score * vf[e];
             }
         }
-#pragma unroll
-        for (int g = 0; g < GS; ++g) {
-            float part = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) part = fmaf(q[g][e], kf[e], part);
-            const float score = group_sum<LPK>(part);
-            const float new_max = fmaxf(mx[g], score);
-            const float factor = expf_glibc(mx[g] - new_max);
-            const float exp_score = expf_glibc(score - new_max);
-            mx[g] = new_max;
-            sm[g] = sm[g] * factor + exp_score;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * factor + exp_score * vf[e];
-        }
     }
+    // every key group parks its state in LDS; the merge below runs over the NGRP groups in group order
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
+    for (int g = 0; g < GS; ++g) {
 #pragma unroll
-        for (int g = 0; g < GS; ++g) {
-            const float m2 = __shfl_xor(mx[g], off, 64), l2 = __shfl_xor(sm[g], off, 64);
-            const float nm = fmaxf(mx[g], m2);
-            const float f1 = expf_glibc(mx[g] - nm), f2 = expf_glibc(m2 - nm);
-            sm[g] = sm[g] * f1 + l2 * f2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] = o[g][e] * f1 + __shfl_xor(o[g][e], off, 64) * f2;
-            mx[g] = nm;
-        }
-    }
-    if (kgrp == 0) {
-#pragma unroll
-        for (int g = 0; g < GS; ++g) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_o[wave][g][sl * 8 + e] = o[g][e];
-            if (sl == 0) s_m[wave][g] = mx[g], s_l[wave][g] = sm[g];
-        }
+        for (int e = 0; e < 8; ++e) s_o[my_group][g][sl * 8 + e] = o[g][e];
+        if (sl == 0) s_m[my_group][g] = mx[g], s_l[my_group][g] = sm[g];
     }
     __syncthreads();
     for (int idx = tid; idx < GS * HD; idx += 256) {
         const int g = idx / HD, e = idx % HD;
         float m = s_m[0][g];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) m = fmaxf(m, s_m[w][g]);
+        for (int w = 1; w < NGRP; ++w) m = fmaxf(m, s_m[w][g]);
         float l = 0.f, acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = expf_glibc(s_m[w][g] - m);
+        for (int w = 0; w < NGRP; ++w) {
+            const float f = fast_exp(s_m[w][g] - m);
             l += s_l[w][g] * f;
             acc += s_o[w][g][e] * f;
         }
@@ -702,9 +710,8 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
 
 template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
     const uint32_t kv_heads = p.num_heads / p.gqa_factor;
-    const uint32_t cap = HD >= 256 ? 4 : 8;
     uint32_t gs = 1;
-    for (uint32_t c = cap; c >= 1; c >>= 1)
+    for (uint32_t c = 4; c >= 1; c >>= 1)
         if (p.gqa_factor % c == 0) {
             gs = c;
             break;
@@ -712,7 +719,6 @@ template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDec
     const dim3 grid(kv_heads * (p.gqa_factor / gs), splits);
 #define UZU_LAUNCH(G) return launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G>), grid, dim3(256), 0, s, p); }, "attn_dec")
     switch (gs) {
-    case 8: if constexpr (HD < 256) { UZU_LAUNCH(8); } [[fallthrough]];
     case 4: UZU_LAUNCH(4);
     case 2: UZU_LAUNCH(2);
     default: UZU_LAUNCH(1);
@@ -734,29 +740,40 @@ uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
     }
 }
 
-// AttentionTwoPass2 over S splits + SigmoidGate: one workgroup per head, one thread per output element
+// AttentionTwoPass2 over S splits + SigmoidGate.  grid (heads, hd / 64): wave 0 of the workgroup derives the S
+// merge weights (wave max / wave sum), then 64 threads x 4 key-slices accumulate the partials with independent loads.
 __global__ void __launch_bounds__(256) attn_merge_kernel(const float* partials, const float* sums, const float* maxs, const uint16_t* gate,
                                                          uint16_t* out, uint32_t HD, uint32_t S) {
-    extern __shared__ float sw[]; // [S] weights
+    __shared__ float sw[256];
+    __shared__ float s_acc[4][64];
     __shared__ float s_gsum;
-    const uint32_t head = blockIdx.x;
-    const float* mx = maxs + (size_t)head * S;
-    const float* sm = sums + (size_t)head * S;
-    float gmax = -INFINITY;
-    for (uint32_t b = 0; b < S; ++b) gmax = fmaxf(gmax, mx[b]);
-    for (uint32_t b = threadIdx.x; b < S; b += 256) sw[b] = expf_glibc(mx[b] - gmax);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float gs = 0.f;
-        for (uint32_t b = 0; b < S; ++b) gs += sm[b] * sw[b];
-        s_gsum = gs;
+    const uint32_t head = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    if (slice == 0) {
+        float m = -INFINITY;
+        for (uint32_t b = lane; b < S; b += 64) m = fmaxf(m, maxs[(size_t)head * S + b]);
+        const float gmax = wave_max(m);
+        float part = 0.f;
+        for (uint32_t b = lane; b < S; b += 64) {
+            const float w = expf_glibc(maxs[(size_t)head * S + b] - gmax);
+            sw[b] = w;
+            part += sums[(size_t)head * S + b] * w;
+        }
+        part = wave_sum(part);
+        if (lane == 0) s_gsum = part;
     }
     __syncthreads();
-    const float gsum = s_gsum;
-    for (uint32_t j = threadIdx.x; j < HD; j += 256) {
-        float val = 0.f;
-        for (uint32_t b = 0; b < S; ++b) val += partials[((size_t)head * S + b) * HD + j] * sw[b];
-        float r = round_bf16(val / gsum);
+    float val = 0.f;
+    if (j < HD) {
+        const float* pp = partials + (size_t)head * S * HD + j;
+#pragma unroll 4
+        for (uint32_t b = slice; b < S; b += 4) val = fmaf(pp[(size_t)b * HD], sw[b], val);
+    }
+    s_acc[slice][lane] = val;
+    __syncthreads();
+    if (slice == 0 && j < HD) {
+        const float total = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+        float r = round_bf16(total / s_gsum);
         if (gate) { // SigmoidGate (sigmoid_gate.rs:9-22)
             const float g = bf16_to_f32(gate[(size_t)head * HD + j]);
             r = round_bf16(r * (1.0f / (1.0f + expf_glibc(-g))));
@@ -766,8 +783,12 @@ __global__ void __launch_bounds__(256) attn_merge_kernel(const float* partials, 
 }
 uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, const float* maxs, const uint16_t* gate, uint16_t* out,
                       uint32_t num_heads, uint32_t head_dim, uint32_t splits) {
+    if (splits > 256) {
+        set_error("attn_merge: at most 256 splits");
+        return UZU_ERR_UNSUPPORTED;
+    }
     return launch_check([&] {
-        hipLaunchKernelGGL(attn_merge_kernel, dim3(num_heads), dim3(256), splits * sizeof(float), s, partials, sums, maxs, gate, out, head_dim, splits);
+        hipLaunchKernelGGL(attn_merge_kernel, dim3(num_heads, (head_dim + 63) / 64), dim3(256), 0, s, partials, sums, maxs, gate, out, head_dim, splits);
     }, "attn_merge");
 }
 
