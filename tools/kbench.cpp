@@ -30,9 +30,10 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const int reps = 64, NBUF = 8; // rotate weight buffers so weights come from HBM, not L2/MALL
+    const int NBUF0 = getenv("KB_NBUF") ? atoi(getenv("KB_NBUF")) : 8; const int reps = NBUF0 > 64 ? NBUF0 : 64; // rotate weight buffers so weights come from HBM, not L2/MALL
     auto bench_gemv = [&](const char* name, uint32_t n, uint32_t k, bool norm, bool act, bool amax, uint32_t n2 = 0, uint32_t debug = 0) {
         const uint32_t g = 128, groups = k / g;
+        const int NBUF = (size_t)n * k > (64u << 20) ? (NBUF0 < 3 ? NBUF0 : 3) : NBUF0;
         std::vector<uint8_t*> w(NBUF); std::vector<uint16_t*> sc(NBUF), bi(NBUF);
         const uint32_t nt = n + n2;
         for (int i = 0; i < NBUF; ++i) { w[i] = dalloc<uint8_t>((size_t)nt * k / 2, 0x53); sc[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); bi[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); }
@@ -74,6 +75,7 @@ int main(int argc, char** argv) {
             p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = 1, p.n = n, p.k = k; return matmul(s, p, cus); });
     }
     {   // delta_dec, Qwen3.5-0.8B shape
+        const int NBUF = NBUF0;
         const uint32_t Hv = 16, Dk = 128, Dv = 128, key_dim = 2048, value_dim = 2048, conv_dim = 6144, total = conv_dim + value_dim + 32;
         uint16_t* in_proj = dalloc<uint16_t>(total, 0x3c); float* cw = dalloc<float>(conv_dim * 4, 0); float* cs = dalloc<float>(conv_dim * 3, 0);
         float* al = dalloc<float>(Hv, 0); float* dt = dalloc<float>(Hv, 0); float* nw = dalloc<float>(Dv, 0); uint16_t* out = dalloc<uint16_t>(value_dim);
@@ -83,6 +85,7 @@ int main(int argc, char** argv) {
             p.num_v_heads = Hv, p.num_k_heads = 16, p.head_v_dim = Dv, p.key_dim = key_dim, p.value_dim = value_dim, p.kernel_size = 4, p.norm_epsilon = 1e-6f; return delta_dec(s, p); });
     }
     {   // attn_dec + merge, Qwen3.5-0.8B shape at ctx 2048
+        const int NBUF = NBUF0;
         const uint32_t nq = 8, nkv = 2, hd = 256, ctx = 2048, splits = 128;
         uint16_t* qkv = dalloc<uint16_t>((nq + 2 * nkv) * hd, 0x3c); float* cosr = dalloc<float>((size_t)(ctx + 8) * 64, 0); float* sinr = dalloc<float>((size_t)(ctx + 8) * 64, 0);
         uint32_t* len = dalloc<uint32_t>(1, 0); uint32_t h = ctx; CK(hipMemcpy(len, &h, 4, hipMemcpyHostToDevice));
