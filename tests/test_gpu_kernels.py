@@ -126,6 +126,50 @@ def test_gemv_epilogue_and_ragged(hip_ctx):
     assert ulp_diff_bf16(want, got).max() <= 1.0
 
 
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("group_size", [64, 128])
+@pytest.mark.parametrize("m", [16, 37, 128, 200])
+def test_gemm_mfma_variants(hip_ctx, bits, method, group_size, m):
+    """Prefill-sized M goes to the matrix-core kernel (k_gemm.hip): codes exact in bf16, f32 group scaling.
+    Ragged M and N (N = 200 is not a multiple of the 128 tile); same tolerance as the GEMV path."""
+    rng = np.random.default_rng(bits * 1000 + method * 100 + group_size + m)
+    n, k = 200, 512
+    q = quant_matrix(rng, n, k, bits, group_size, method)
+    a = activations(rng, m, k)
+    want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
+@pytest.mark.parametrize("n,k", QWEN_SHAPES)
+def test_gemm_mfma_qwen_shapes(hip_ctx, n, k):
+    """int4 ScaleBias g=128 at M = 64 on the reference's Qwen3.5-0.8B layer table (prefill GEMM)."""
+    rng = np.random.default_rng(n * 3 + k)
+    m = 64
+    q = quant_matrix(rng, n, k, 4, 128, 0)
+    a = activations(rng, m, k)
+    want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
+def test_gemm_mfma_epilogue(hip_ctx):
+    """ab_scale + accumulate + bias + soft-cap epilogue and signed codes on the matrix-core path."""
+    rng = np.random.default_rng(6)
+    n, k, m = 300, 256, 50
+    q = quant_matrix(rng, n, k, 4, 64, 2)
+    q["signed_codes"] = True
+    a = activations(rng, m, k)
+    bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
+    d0 = bf16(rng.uniform(-1, 1, size=(m, n)))
+    want = oracle_matmul(a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    got = hip_matmul(hip_ctx, a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+
+
 def test_matmul_reference_order_is_bit_exact(hip_ctx):
     """With the reference-order kernel the GPU reproduces the CPU path bit for bit (any shape, incl. K % 32 != 0)."""
     rng = np.random.default_rng(11)

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <array>
 #include <vector>
 #include "../uzu_amd/csrc/kernels.h"
 #include "../uzu_amd/csrc/kernels_decode.h"
@@ -52,6 +53,19 @@ int main(int argc, char** argv) {
             return gemv_dec(s, p, cus, nullptr);
         });
     };
+    if (getenv("KB_GEMM")) { // prefill GEMM on the matrix cores (k_gemm.hip)
+        for (auto sh : std::vector<std::array<uint32_t, 3>>{{1024, 8224, 1024}, {1024, 7168, 1024}, {1024, 1024, 3584}, {1024, 1024, 2048}, {1024, 3072, 1024}, {4096, 14336, 4096}}) {
+            const uint32_t m = sh[0], n = sh[1], k = sh[2], g = 128;
+            uint8_t* w = dalloc<uint8_t>((size_t)n * k / 2, 0x53); uint16_t* sc = dalloc<uint16_t>((size_t)n * k / g, 0x3c); uint16_t* bi = dalloc<uint16_t>((size_t)n * k / g, 0x3c);
+            uint16_t* x = dalloc<uint16_t>((size_t)m * k, 0x3f); uint16_t* out = dalloc<uint16_t>((size_t)m * n);
+            char name[64]; snprintf(name, sizeof name, "gemm_q_mfma %ux%ux%u", m, n, k);
+            const double us = time_graph(name, (size_t)n * k / 2 + (size_t)m * k * 2 + (size_t)m * n * 2, 8, [&](int) {
+                MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi, p.d = out; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
+                p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k; return matmul(s, p, cus); });
+            printf("    -> %.1f TFLOP/s\n", 2.0 * m * n * k / us / 1e6);
+        }
+        return 0;
+    }
     bench_gemv("gemv_dec in_proj 8224x1024 +norm", 8224, 1024, true, false, false);
     bench_gemv("gemv_dec in_proj 8224x1024", 8224, 1024, false, false, false);
     bench_gemv("  .. prologue only (no rows)", 8224, 1024, false, false, false, 0, 1);

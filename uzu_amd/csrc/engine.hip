@@ -723,7 +723,9 @@ uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc
                 const uint32_t w = L.d.num_groups * (gqa / gs);
                 wgs = wgs > w ? wgs : w;
             }
-        uint32_t splits = 128 / wgs;
+        // ~256 workgroups (one per CU); more splits shorten attn_dec but lengthen attn_merge (measured: 64 best at 2k context)
+        uint32_t splits = 256 / wgs;
+        if (const char* ev = getenv("UZU_DEC_SPLITS")) splits = (uint32_t)atoi(ev);
         m->dec_splits = splits < 8 ? 8 : (splits > 128 ? 128 : splits);
         ALLOC(dec_partials, float, (size_t)max_heads * m->dec_splits * max_hd);
         ALLOC(dec_sums, float, (size_t)max_heads * m->dec_splits);

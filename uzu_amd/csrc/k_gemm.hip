@@ -1,0 +1,291 @@
+// k_gemm.hip -- prefill MatmulKernel for gfx950: D[m,n] = ab_scale * sum_k A[m,k] * deq(B)[n,k] (+D)(+bias)(soft-cap)
+// for M >= 16 rows of bf16 activations against int4 / int8 block-quantised weights, on the bf16 matrix cores.
+//
+// Reference semantics: BU/cpu/kernel/matmul/kernel.rs:164-293 (same as k_matmul.hip).  The design is MI355X-first:
+//
+//   * The centred integer codes are EXACT in bf16 (int4: (q - 8) / 16 through v_cvt_off_f32_i4 with SDWA byte selects,
+//     int8: q - 128 through v_cvt_f32_i32 sext byte selects; 14 VALU ops per 8 codes), the activations are bf16
+//     already, so every MFMA product is exact in f32.  Centring matters: with unsigned (or offset) codes the group
+//     accumulator carries mean(code) * sum(a), which costs accuracy when it is cancelled against the bias term.  The quantisation scale never touches the
+//     MFMA operands: one group of `group_size` k's accumulates into a per-group accumulator tile, and at the group
+//     boundary   acc += scale[n,g] * acc_g + coef[n,g] * sum_k A[m,k in g]   runs on the VALU in f32 -- the same
+//     grouped form the decode GEMV uses (gemv_core.h), so prefill and decode see the same arithmetic up to summation
+//     order.  Nothing is ever rounded to a bf16 *weight*.
+//   * v_mfma_f32_32x32x16_bf16; workgroup tile 128 x 128 x 64, four waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA
+//     blocks.  The B operand of the instruction (a lane holds 8 consecutive k of ONE column n) is exactly one u32 of
+//     packed int4 codes, so the weights go global -> VGPR -> dequant -> MFMA with no LDS round trip;
+//     a lane fetches 16 bytes (32 codes) per 32-column block per k-step.  Only the activations are staged through
+//     LDS (double buffered, 144-byte row pitch => conflict-free ds_read_b128).
+//   * The k order inside an MFMA is irrelevant as long as A and B agree, so the kernel picks the order that makes
+//     the weight fetch one 16-byte vector per lane: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take
+//     k = 32+8s..32+8s+7 at step s of a 64-wide k-step.
+//   * Row sums of the activations per quant group come for free from the staging threads (each holds 32 consecutive
+//     k of one row).
+#include <stdlib.h>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int A_PITCH = 144; // bytes per staged activation row: 64 bf16 + 16 bytes of pad
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { // v_cvt_pk_bf16_f32
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// 8 packed int4 codes (already xor-ed so that the nibble is the two's complement of q - 8) -> 8 bf16 values
+// (q - 8) / 16, natural k order.  v_cvt_off_f32_i4 reads the low nibble of the byte SDWA selects: 1 shift + 8 cvt + 4 pack.
+__device__ __forceinline__ u32x4_t dequant4(uint32_t w) {
+    uint32_t h = w >> 4;
+    asm volatile("" : "+v"(h)); // keep `h` materialised so that its bytes are SDWA operands too
+    u32x4_t r;
+    r.x = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w & 0xFF), __builtin_amdgcn_cvt_off_f32_i4(h & 0xFF));
+    r.y = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 8) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 8) & 0xFF));
+    r.z = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 16) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 16) & 0xFF));
+    r.w = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w >> 24), __builtin_amdgcn_cvt_off_f32_i4(h >> 24));
+    return r;
+}
+// 8 int8 codes (xor-ed so that the byte is the two's complement of q - 128) -> 8 bf16 values q - 128 (exact: 8 bits)
+__device__ __forceinline__ float sbyte(uint32_t w, int i) { return (float)(int)(int8_t)((w >> (8 * i)) & 0xFFu); }
+__device__ __forceinline__ u32x4_t dequant8(uint32_t w0, uint32_t w1) {
+    u32x4_t r;
+    r.x = pack_bf16(sbyte(w0, 0), sbyte(w0, 1));
+    r.y = pack_bf16(sbyte(w0, 2), sbyte(w0, 3));
+    r.z = pack_bf16(sbyte(w1, 0), sbyte(w1, 1));
+    r.w = pack_bf16(sbyte(w1, 2), sbyte(w1, 3));
+    return r;
+}
+__device__ __forceinline__ float chunk_sum(uint4 v) { // sum of 8 bf16
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s0 += bits_to_f32(w[i] << 16), s1 += bits_to_f32(w[i] & 0xFFFF0000u);
+    return s0 + s1;
+}
+} // namespace
+
+template <int BITS>
+__global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
+    constexpr int WV = BITS / 4; // 16-byte vectors of codes per lane per 32-column block per k-step
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
+    __shared__ __attribute__((aligned(16))) float s_asum[2][BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
+    const uint32_t M = p.m, N = p.n, K = p.k;
+    const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const uint32_t G = (K + p.group_size - 1) / p.group_size;
+    const uint32_t gs = p.group_size / BK; // k-steps per quant group
+    const uint32_t KT = K / BK;
+    const uint32_t row_bytes = K * BITS / 8;
+    const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
+
+    // ---- staging role: thread -> (row, 32-k part)
+    const int ra = tid >> 1, part = tid & 1;
+    const bool a_valid = m0 + ra < M;
+    const uint16_t* a_src = (const uint16_t*)p.a + (size_t)(m0 + ra) * K + 32 * part;
+    uint8_t* a_dst0 = &s_a[0][ra * A_PITCH + part * 64];
+    uint8_t* a_dst1 = &s_a[1][ra * A_PITCH + part * 64];
+    uint4 a_st[4];
+    auto load_a = [&](uint32_t kt) {
+        if (a_valid) {
+            const uint4* src = (const uint4*)(a_src + (size_t)kt * BK);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_st[j] = src[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_st[j] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    float asum_run = 0.f;
+    auto stage_a = [&](uint32_t kt) { // a_st holds k-step kt
+        uint8_t* dst = (kt & 1) ? a_dst1 : a_dst0;
+        float part_sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            part_sum += chunk_sum(a_st[j]);
+            *(uint4*)(dst + 16 * j) = a_st[j];
+        }
+        asum_run += part_sum;
+        if ((kt + 1) % gs == 0) { // last k-step of its group: publish the row sum of the group
+            const float total = xadd1(asum_run);
+            if (!part) s_asum[(kt / gs) & 1][ra] = total;
+            asum_run = 0.f;
+        }
+    };
+
+    // ---- compute role
+    uint32_t ncol[2];
+    const uint8_t* w_src[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const uint32_t n = n0 + wn * 64 + nb * 32 + l32;
+        ncol[nb] = n < N ? n : N - 1;
+        w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)(32 * half) * BITS / 8;
+    }
+    uint4 w_cur[2][WV], w_nxt[2][WV];
+    auto load_w = [&](uint32_t kt, uint4 (&w)[2][WV]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint4* src = (const uint4*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
+#pragma unroll
+            for (int v = 0; v < WV; ++v) w[nb][v] = src[v];
+        }
+    };
+    // unsigned code q (after the optional `signed_codes` flip of the top bit, kernel.rs:268-275) -> two's complement of q - 2^(bits-1)
+    const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
+
+    f32x16_t acc_g[2][2], acc_t[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_g[mb][nb][r] = 0.f, acc_t[mb][nb][r] = 0.f;
+
+    uint16_t sc_raw[2] = {0, 0}, of_raw[2] = {0, 0};
+    auto load_group = [&](uint32_t g) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            sc_raw[nb] = ((const uint16_t*)p.scales)[(size_t)ncol[nb] * G + g];
+            if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) of_raw[nb] = ((const uint16_t*)p.biases)[(size_t)ncol[nb] * G + g];
+            else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                const uint8_t z = p.zero_points[(size_t)ncol[nb] * zp_stride + (BITS == 4 ? (g >> 1) : g)];
+                of_raw[nb] = BITS == 4 ? ((g & 1) ? (z >> 4) : (z & 0xF)) : z;
+            }
+        }
+    };
+
+    load_a(0);
+    load_w(0, w_cur);
+    load_group(0);
+    stage_a(0);
+    __syncthreads();
+
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const uint32_t cur = kt & 1;
+        if (kt + 1 < KT) {
+            load_a(kt + 1);
+            load_w(kt + 1, w_nxt);
+        }
+        const uint8_t* a_base = &s_a[cur][(wm * 64 + l32) * A_PITCH + half * 64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4_t bfrag[2], afrag[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (BITS == 4) {
+                    const uint32_t ws[4] = {w_cur[nb][0].x, w_cur[nb][0].y, w_cur[nb][0].z, w_cur[nb][0].w};
+                    bfrag[nb] = dequant4(ws[s] ^ flip);
+                } else {
+                    const uint4 v = w_cur[nb][s >> 1];
+                    bfrag[nb] = (s & 1) ? dequant8(v.z ^ flip, v.w ^ flip) : dequant8(v.x ^ flip, v.y ^ flip);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const uint4 t = *(const uint4*)(a_base + mb * 32 * A_PITCH + s * 16);
+                afrag[mb] = u32x4_t{t.x, t.y, t.z, t.w};
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, afrag[mb]), __builtin_bit_cast(bf16x8_t, bfrag[nb]),
+                                                                           acc_g[mb][nb], 0, 0, 0);
+        }
+        if ((kt + 1) % gs == 0) { // group boundary: fold the group accumulator into the total with the f32 scale
+            const uint32_t g = kt / gs;
+            const float* asum = s_asum[g & 1];
+            float sc[2], coef[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const float scale = bf16_to_f32(sc_raw[nb]);
+                const float mid = (float)(1u << (BITS - 1)); // the codes were fed centred: q - mid (int4: divided by 16)
+                if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) coef[nb] = fmaf(mid, scale, bf16_to_f32(of_raw[nb]));
+                else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) coef[nb] = scale * (mid - (float)of_raw[nb]);
+                else coef[nb] = 0.0f;
+                sc[nb] = BITS == 4 ? 16.0f * scale : scale;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float as[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = *(const float4*)(asum + wm * 64 + mb * 32 + 8 * j + 4 * half);
+                    as[4 * j] = t.x, as[4 * j + 1] = t.y, as[4 * j + 2] = t.z, as[4 * j + 3] = t.w;
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc_t[mb][nb][r] = fmaf(sc[nb], acc_g[mb][nb][r], fmaf(coef[nb], as[r], acc_t[mb][nb][r]));
+                        acc_g[mb][nb][r] = 0.f;
+                    }
+            }
+            if (g + 1 < G) load_group(g + 1);
+        }
+        if (kt + 1 < KT) {
+            stage_a(kt + 1);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int v = 0; v < WV; ++v) w_cur[nb][v] = w_nxt[nb][v];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue in the reference's order (kernel.rs:281-292): lane holds column n, rows (r&3) + 8*(r>>2) + 4*half
+    uint16_t* d = (uint16_t*)p.d;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const uint32_t n = n0 + wn * 64 + nb * 32 + l32;
+        if (n >= N) continue;
+        const float bias = p.bias ? bf16_to_f32(((const uint16_t*)p.bias)[n]) : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const size_t idx = (size_t)m * N + n;
+                float value = p.ab_scale * acc_t[mb][nb][r];
+                if (p.accumulate) value += bf16_to_f32(d[idx]);
+                if (p.bias) value += bias;
+                if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
+                d[idx] = f32_to_bf16(value);
+            }
+    }
+}
+
+// Shapes the matrix-core path covers; everything else stays on the GEMV-tiled / reference kernels of k_matmul.hip.
+bool gemm_q_mfma_supported(const MatmulParams& p) {
+    static const uint32_t min_m = [] {
+        const char* e = getenv("UZU_GEMM_MIN_M");
+        return e ? (uint32_t)atoi(e) : 16u;
+    }();
+    if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || (p.bits != 4 && p.bits != 8)) return false;
+    if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || p.d_dt != UZU_BF16) return false;
+    if (p.m < min_m || p.gather || p.act_mul) return false;
+    if (p.k % BK || p.group_size % BK || p.k % p.group_size) return false;
+    if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16 || ((size_t)p.k * p.bits / 8) % 16) return false;
+    return true;
+}
+
+uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p) {
+    const dim3 grid((p.n + BN - 1) / BN, (p.m + BM - 1) / BM);
+    if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL(gemm_q_mfma_kernel<4>, grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+    return launch_check([&] { hipLaunchKernelGGL(gemm_q_mfma_kernel<8>, grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+}
+
+} // namespace k
+} // namespace uzu

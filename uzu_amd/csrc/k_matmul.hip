@@ -270,6 +270,10 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
             hipLaunchKernelGGL(matmul_ref_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, p, 1u, p.k);
         }, "matmul_ref");
     }
+    if (gemm_q_mfma_supported(p)) { // prefill-sized M: bf16 matrix cores (k_gemm.hip)
+        if (variant) *variant = p.bits == 4 ? "gemm_q_mfma<4>" : "gemm_q_mfma<8>";
+        return gemm_q_mfma(s, p);
+    }
     if (p.w_dt == UZU_BF16) {
         if (p.bits == 4) return launch_gemv<bf16_t, bf16_t, 4>(s, p, num_cus, variant);
         return launch_gemv<bf16_t, bf16_t, 8>(s, p, num_cus, variant);

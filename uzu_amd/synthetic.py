@@ -167,6 +167,12 @@ def make_linear(cfg: ModelConfig, name: str, n: int, k: int, gain: float = 1.0,
     return D.LinearWeights(n, k, bits, g, method, codes, scales_b, biases_b, zero_points, ob)
 
 
+def readout_row_multipliers(cfg: ModelConfig) -> np.ndarray:
+    """The log-normal per-token multipliers applied to the read-out rows (logit i scales with multiplier i)."""
+    rng = _rng(cfg.seed, "row_mult")
+    return np.exp(rng.normal(0.0, cfg.logit_row_sigma, size=(cfg.vocab_size,)))
+
+
 def make_norm(cfg: ModelConfig, name: str, dim: int) -> D.NormWeights:
     rng = _rng(cfg.seed, name)
     centre = 0.0 if cfg.norm_scale_offset != 0.0 else 1.0
@@ -176,8 +182,7 @@ def make_norm(cfg: ModelConfig, name: str, dim: int) -> D.NormWeights:
 
 def build_model(cfg: ModelConfig) -> D.ModelBundle:
     d = cfg.model_dim
-    rng = _rng(cfg.seed, "row_mult")
-    row_mult = np.exp(rng.normal(0.0, cfg.logit_row_sigma, size=(cfg.vocab_size,)))
+    row_mult = readout_row_multipliers(cfg)
     embedding = make_linear(cfg, "embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
     output_embedding = None
     if not cfg.tied_embeddings:
