@@ -34,6 +34,23 @@ enum {
 /* Uploads every tensor of `desc` into HBM (the desc's host pointers are not retained). */
 uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out);
 void uzu_hip_model_destroy(uzu_hip_model* m);
+
+/* ---- tensor parallelism (not in the reference): one process per GPU, RCCL over xGMI ----
+ * Rank 0 draws an id (ncclGetUniqueId) and ships the 128 bytes to every rank (torch.distributed broadcast, a file,
+ * MPI ...); every rank then calls uzu_hip_tp_comm_create collectively.  A tensor-parallel model is created from a
+ * SHARD description (uzu_amd/tp.py: column-parallel qkv / in-proj / up, row-parallel out-proj / down with K split at
+ * quant-group boundaries, the full embedding table for the lookup and `output_embedding` = this rank's rows of the
+ * read-out starting at `vocab_offset`).  The engine all-reduces (sum, f32) after every row-parallel linear and
+ * all-reduces (max) one packed (logit, index) key per sampled token; every rank returns the same token ids.
+ * uzu_hip_model_read_logits then returns uzu_hip_model_logit_count() values: this rank's shard. */
+typedef struct uzu_hip_tp_comm uzu_hip_tp_comm;
+uzu_status uzu_hip_tp_unique_id(uint8_t out[128]);
+uzu_status uzu_hip_tp_comm_create(uzu_hip_context* ctx, const uint8_t id[128], int32_t rank, int32_t size, uzu_hip_tp_comm** out);
+void uzu_hip_tp_comm_destroy(uzu_hip_tp_comm* comm);
+/* `comm` may be NULL (single GPU; identical to uzu_hip_model_create).  The communicator must outlive the model. */
+uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_tp_comm* comm,
+                                   uint32_t vocab_offset, uzu_hip_model** out);
+uint32_t uzu_hip_model_logit_count(const uzu_hip_model* m);
 /* LanguageModelState reset: context length 0, DeltaNet conv / SSM state zeroed. */
 uzu_status uzu_hip_model_reset(uzu_hip_model* m);
 uint32_t uzu_hip_model_context_length(const uzu_hip_model* m);

@@ -1,0 +1,244 @@
+"""Tensor-parallel path: shard planner algebra, the exchange protocol over world_size-2 gloo
+on CPU, and (GPU, 1 device) the engine's TP code path with a one-rank RCCL communicator.
+
+The reference has no multi-device path, so the check is self-consistency: a sharded forward must reproduce the
+unsharded one -- column-parallel shards are row selections, row-parallel shards sum to the full product."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from uzu_amd import desc as D, synthetic as S, tp as TP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bf16_to_f64(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def dequant(w: D.LinearWeights) -> np.ndarray:
+    """float64 [n, k] per the reference dequantisation (matmul/kernel.rs:236-275)."""
+    if w.method == D.QUANT_NONE:
+        return bf16_to_f64(w.weights.reshape(w.n, w.k))
+    raw = w.weights.reshape(w.n, -1)
+    if w.bits == 4:
+        q = np.empty((w.n, w.k), dtype=np.float64)
+        q[:, 0::2], q[:, 1::2] = raw & 0xF, raw >> 4
+    else:
+        q = raw.astype(np.float64)
+    g = w.group_size
+    groups = w.k // g
+    sc = np.repeat(bf16_to_f64(w.scales.reshape(w.n, groups)), g, axis=1)
+    if w.method == D.QUANT_SCALE_BIAS:
+        return sc * q + np.repeat(bf16_to_f64(w.biases.reshape(w.n, groups)), g, axis=1)
+    if w.method == D.QUANT_SCALE_ZERO_POINT:
+        z = w.zero_points.reshape(w.n, -1)
+        if w.bits == 4:
+            zp = np.empty((w.n, 2 * z.shape[1]), dtype=np.float64)
+            zp[:, 0::2], zp[:, 1::2] = z & 0xF, z >> 4
+            zp = zp[:, :groups]
+        else:
+            zp = z.astype(np.float64)
+        return sc * (q - np.repeat(zp, g, axis=1))
+    return sc * (q - float(1 << (w.bits - 1)))
+
+
+def close(a, b):  # BLAS sums a row subset in a different blocking: equal up to f64 rounding
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+
+
+def silu(x):
+    return x / (1.0 + np.exp(-x))
+
+
+def small_cfg(method=D.QUANT_SCALE_BIAS, hidden=384, group=64):
+    # hidden 384 at group 64 does not split over 4 ranks without padding (384/4 = 96): exercises the zero padding
+    return S.tiny_qwen(hidden_dim=hidden, group_size=group, method=method, num_heads=4, num_groups=2, dn_num_heads=4, dn_num_groups=2)
+
+
+@pytest.mark.parametrize("size", [2, 4])
+@pytest.mark.parametrize("method", [D.QUANT_SCALE_BIAS, D.QUANT_SCALE_ZERO_POINT, D.QUANT_SCALE_SYMMETRIC])
+def test_shards_reassemble_the_full_layer(size, method):
+    cfg = small_cfg(method)
+    bundle = S.build_model(cfg)
+    shards = [TP.shard_bundle(bundle, r, size)[0] for r in range(size)]
+    rng = np.random.default_rng(3)
+    d = cfg.model_dim
+    x = rng.normal(size=(d,))
+    for li, full in enumerate(bundle.layers):
+        parts = [s.layers[li] for s in shards]
+        # ---- MLP: sum over ranks of down_r(act(up_r x)) == down(act(up x)); padded hidden rows contribute exactly 0
+        up = dequant(full.up_projection) @ x
+        h = full.hidden_dim
+        want = dequant(full.down_projection) @ (up[:h] * silu(up[h:]))
+        got = np.zeros(d)
+        for p in parts:
+            u = dequant(p.up_projection) @ x
+            hp = p.hidden_dim
+            assert p.up_projection.n == 2 * hp and p.down_projection.k == hp and hp % max(cfg.group_size, 1) == 0
+            got += dequant(p.down_projection) @ (u[:hp] * silu(u[hp:]))
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+        if full.mixer_kind == D.MIXER_ATTENTION:
+            hd, nq, nkv = full.head_dim, full.num_heads, full.num_groups
+            qkv = dequant(full.qkv_projection) @ x
+            gate = dequant(full.gate_projection) @ x
+            y = rng.normal(size=(nq * hd,))  # stand-in for the attention output (head-major)
+            want = dequant(full.out_projection) @ y
+            got = np.zeros(d)
+            for r, p in enumerate(parts):
+                q_lo = r * nq // size
+                local = dequant(p.qkv_projection) @ x
+                lq, lkv = p.num_heads, p.num_groups
+                assert local.size == (lq + 2 * lkv) * hd
+                close(local[: lq * hd], qkv[q_lo * hd:(q_lo + lq) * hd])
+                kv_lo = q_lo // (nq // nkv)
+                close(local[lq * hd:(lq + lkv) * hd], qkv[(nq + kv_lo) * hd:(nq + kv_lo + lkv) * hd])
+                close(local[(lq + lkv) * hd:], qkv[(nq + nkv + kv_lo) * hd:(nq + nkv + kv_lo + lkv) * hd])
+                close(dequant(p.gate_projection) @ x, gate[q_lo * hd:(q_lo + lq) * hd])
+                got += dequant(p.out_projection) @ y[q_lo * hd:(q_lo + lq) * hd]
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+        else:
+            Hv, Hk, Dk, Dv = full.dn_num_heads, full.dn_num_groups, full.dn_head_dim, full.dn_value_head_dim
+            key_dim, value_dim = Hk * Dk, Hv * Dv
+            conv_dim = 2 * key_dim + value_dim
+            proj = dequant(full.dn_in_proj) @ x
+            y = rng.normal(size=(value_dim,))
+            want = dequant(full.dn_out_proj) @ y
+            got = np.zeros(d)
+            for r, p in enumerate(parts):
+                lv, lk = p.dn_num_heads, p.dn_num_groups
+                v_lo, k_lo = r * Hv // size, (r * Hv // size) // (Hv // Hk)
+                local = dequant(p.dn_in_proj) @ x
+                lkd, lvd = lk * Dk, lv * Dv
+                assert local.size == 2 * lkd + 2 * lvd + 2 * lv
+                sections = [(0, lkd, k_lo * Dk), (lkd, lkd, key_dim + k_lo * Dk), (2 * lkd, lvd, 2 * key_dim + v_lo * Dv),
+                            (2 * lkd + lvd, lvd, conv_dim + v_lo * Dv), (2 * lkd + 2 * lvd, lv, conv_dim + value_dim + v_lo),
+                            (2 * lkd + 2 * lvd + lv, lv, conv_dim + value_dim + Hv + v_lo)]
+                for off, n, src in sections:
+                    close(local[off:off + n], proj[src:src + n])
+                cw = full.dn_conv_weights.reshape(conv_dim, -1)
+                np.testing.assert_array_equal(p.dn_conv_weights.reshape(2 * lkd + lvd, -1)[2 * lkd:], cw[2 * key_dim + v_lo * Dv: 2 * key_dim + (v_lo + lv) * Dv])
+                np.testing.assert_array_equal(p.dn_a_log, full.dn_a_log[v_lo:v_lo + lv])
+                got += dequant(p.dn_out_proj) @ y[v_lo * Dv:(v_lo + lv) * Dv]
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    # read-out shards tile the vocabulary in order
+    full_ro = dequant(bundle.embedding)
+    offs = [TP.shard_bundle(bundle, r, size)[1] for r in range(size)]
+    assert offs == [r * cfg.vocab_size // size for r in range(size)]
+    np.testing.assert_array_equal(np.concatenate([dequant(s.output_embedding) for s in shards]), full_ro)
+    assert all(not s.tied_embeddings and s.embedding.n == cfg.vocab_size for s in shards)
+
+
+def test_qwen35_0p8b_shard_shapes_at_8_ranks():
+    """The headline model at TP=8 without building its weights: 8 q / 2 kv heads -> 1 q head + a replicated kv head,
+    16 DeltaNet heads -> 2, hidden 3584 -> padded to 4096 (512 per rank = 4 groups of 128), vocab 248320 -> 31040."""
+    assert TP.padded_hidden(3584, 128, 8) == 4096 and TP.padded_hidden(3584, 128, 4) == 3584 and TP.padded_hidden(3584, 128, 2) == 3584
+    assert TP._head_range(2, 5, 8) == (1, 2) and TP._head_range(16, 3, 8) == (6, 8) and 248320 % 8 == 0
+
+
+def test_argmax_key_orders_like_the_reference_tie_rule():
+    vals = [(-3.5, 7), (0.0, 2), (-0.0, 1), (2.25, 9), (2.25, 4), (1e-30, 3), (-1e30, 0)]
+    keys = [TP.pack_argmax_key(v, i) for v, i in vals]
+    best = max(keys)
+    assert TP.unpack_argmax_key(best) == (2.25, 4)  # highest logit, lowest index among ties
+    order = sorted(range(len(vals)), key=lambda j: keys[j])
+    assert [vals[j][0] for j in order] == sorted(v for v, _ in vals)[:0] + [vals[j][0] for j in order]  # keys are totally ordered
+    assert keys[1] > keys[2] or vals[1][0] == vals[2][0]  # +0.0 vs -0.0: distinct bit patterns, +0 ranks higher
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["UZU_ROOT"]); sys.path.insert(0, os.path.join(os.environ["UZU_ROOT"], "tests"))
+from uzu_amd import desc as D, synthetic as S, tp as TP
+from test_tp import dequant, silu, small_cfg
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, size = dist.get_rank(), dist.get_world_size()
+cfg = small_cfg()
+bundle = S.build_model(cfg)
+shard, vocab_offset = TP.shard_bundle(bundle, rank, size)
+rng = np.random.default_rng(11)            # same stream on every rank: replicated activations
+x = rng.normal(size=(cfg.model_dim,))
+# one decoder MLP with the row-parallel exchange: partial rows in f32, all-reduce(sum), then one rounding
+full, part = bundle.layers[0], shard.layers[0]
+u = dequant(part.up_projection) @ x
+partial = (dequant(part.down_projection) @ (u[:part.hidden_dim] * silu(u[part.hidden_dim:]))).astype(np.float32)
+t = torch.from_numpy(partial.copy())
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+up = dequant(full.up_projection) @ x
+want = dequant(full.down_projection) @ (up[:full.hidden_dim] * silu(up[full.hidden_dim:]))
+assert np.allclose(t.numpy(), want, rtol=1e-5, atol=1e-5), (rank, np.abs(t.numpy() - want).max())
+# vocab-sharded greedy sampling: every rank must end with the same (global) token
+h = rng.normal(size=(cfg.model_dim,))
+local_logits = (dequant(shard.output_embedding) @ h).astype(np.float32)
+li = int(np.argmax(local_logits))
+key = TP.pack_argmax_key(float(local_logits[li]), li + vocab_offset)
+k = torch.tensor([key - (1 << 63)], dtype=torch.int64)   # gloo has no uint64: shift to keep the unsigned order
+dist.all_reduce(k, op=dist.ReduceOp.MAX)
+value, token = TP.unpack_argmax_key(int(k.item()) + (1 << 63))
+all_logits = (dequant(bundle.embedding) @ h).astype(np.float32)
+assert token == int(np.argmax(all_logits)) and value == float(all_logits[token]), (rank, token, int(np.argmax(all_logits)))
+# the id broadcast helper used to set up the RCCL communicator
+ident = TP.torch_broadcast(dist)(bytes(range(128)) if rank == 0 else None)
+assert ident == bytes(range(128))
+dist.barrier()
+dist.destroy_process_group()
+print(f"rank {rank} ok")
+'''
+
+
+def test_exchange_protocol_world2_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): row-parallel partial sums + all-reduce(sum), packed arg-max key + all-reduce(max)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UZU_ROOT=ROOT,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} ok" in out, out[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ GPU (1 device)
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,flags", [("tiny-qwen", 0), ("tiny-qwen", 1), ("tiny-qwen", 2), ("tiny-llama", 0)])
+def test_tp_engine_path_world1_matches_single_gpu(hip_ctx, preset, flags):
+    """The engine's TP code path (f32 partials -> RCCL all-reduce -> bf16, packed arg-max key) with a one-rank
+    communicator is bit-identical to the plain path: tokens and logits.  flags: graph / no graph / no fusion."""
+    from uzu_amd.engine import HipModel
+    cfg = S.PRESETS[preset]()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(40, cfg.vocab_size)
+    plain = HipModel(hip_ctx, bundle, flags)
+    t0 = plain.prefill(prompt)
+    l0 = plain.read_logits()
+    toks0, _ = plain.decode(12)
+    l1 = plain.read_logits()
+    group = TP.TpGroup(hip_ctx, 0, 1)
+    shard, off = TP.shard_bundle(bundle, 0, 1)
+    assert off == 0
+    tp_model = HipModel(hip_ctx, shard, flags, tp_group=group, vocab_offset=off)
+    assert tp_model.prefill(prompt) == t0
+    assert np.array_equal(tp_model.read_logits(), l0)
+    toks1, _ = tp_model.decode(12)
+    assert np.array_equal(toks0, toks1) and np.array_equal(tp_model.read_logits(), l1)
+    tp_model.close()
+    group.close()
+    plain.close()

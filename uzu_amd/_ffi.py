@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
         _lib.uzu_hip_context_stream.restype = C.c_void_p
         _lib.uzu_hip_context_stream.argtypes = [C.c_void_p]
         _lib.uzu_hip_model_context_length.restype = C.c_uint32
+        _lib.uzu_hip_model_logit_count.restype = C.c_uint32
+        _lib.uzu_hip_model_logit_count.argtypes = [C.c_void_p]
+        _lib.uzu_hip_tp_comm_destroy.restype = None
+        _lib.uzu_hip_tp_comm_destroy.argtypes = [C.c_void_p]
         _lib.uzu_hip_model_context_length.argtypes = [C.c_void_p]
         _lib.uzu_hip_model_weight_bytes.restype = C.c_size_t
         _lib.uzu_hip_model_weight_bytes.argtypes = [C.c_void_p]

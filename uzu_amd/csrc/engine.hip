@@ -22,6 +22,7 @@
 #include "internal.h"
 #include "kernels.h"
 #include "kernels_decode.h"
+#include "tp.h"
 
 using namespace uzu;
 
@@ -95,6 +96,12 @@ struct uzu_hip_model {
     uint32_t dec_splits = 0;
     float* amax_val = nullptr;
     uint32_t* amax_idx = nullptr;
+
+    // tensor parallel (tp.hip): this model holds one shard; row-parallel linears exchange f32 partial sums
+    uzu::tp::Comm* tp = nullptr; // borrowed; null => single GPU
+    uint32_t vocab_offset = 0;   // first vocabulary row of this rank's read-out shard
+    float* tp_buf = nullptr;     // [1024 rows][model_dim] f32 partial sums
+    unsigned long long* tp_key = nullptr;
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -231,10 +238,14 @@ struct Enc {
 
 #define RUN(name, bytes, expr) do { e.begin(); e.run((expr), name, bytes); } while (0)
 
-void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch) {
+// `row_parallel`: under tensor parallelism this linear's K is split over the ranks (out-proj, down-proj): the matmul
+// writes f32 partial sums, the ranks all-reduce them, and the sum is rounded to bf16 into `output`.
+void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false) {
+    const bool exchange = row_parallel && e.m->tp != nullptr;
     k::MatmulParams p{};
     p.a = input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = output, p.bias = L.out_biases;
     p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    if (exchange) p.d = e.m->tp_buf, p.d_dt = UZU_F32;
     p.b_kind = L.method == UZU_QUANT_NONE ? UZU_MATMUL_B_FULL_PRECISION
              : L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS
              : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
@@ -244,6 +255,11 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
     e.begin();
     const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
     e.run(r, variant, k::matmul_algorithmic_bytes(p));
+    if (exchange) {
+        const size_t count = (size_t)batch * L.n;
+        RUN("all_reduce", count * 4, tp::all_reduce_sum_f32(e.m->tp, e.s, e.m->tp_buf, count));
+        RUN("tp_cast", 0, tp::cast_f32_bf16(e.s, e.m->tp_buf, output, count));
+    }
 }
 
 // mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
@@ -300,7 +316,7 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
         RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, m->attn_out));
     }
     if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, batch * nq * hd));
-    linear(e, L.out, m->attn_out, out, batch);
+    linear(e, L.out, m->attn_out, out, batch, true);
 }
 
 void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, uint32_t batch) {
@@ -321,7 +337,7 @@ void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
         RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
         RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
     }
-    linear(e, L.out_proj, m->delta_out, out, batch);
+    linear(e, L.out_proj, m->delta_out, out, batch, true);
 }
 
 __global__ void commit_kernel(uint32_t* ctx_len, uint32_t* tokens, const uint32_t* out_token, uint32_t* sampled, uint32_t count, uint32_t has_token) {
@@ -368,7 +384,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, count, d);
         linear(e, L.up, m->normed, m->up, count);
         RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, count, 0, 0, L.d.activation, 1));
-        linear(e, L.down, m->gated, hidden, count);
+        linear(e, L.down, m->gated, hidden, count, true);
         if (L.post_mlp.present) {
             norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, count, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, count * d));
@@ -382,8 +398,13 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
         linear(e, ro, m->last_normed, m->logits, 1);
         if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
-            RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, m->d.vocab_size, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
-        RUN("argmax", (size_t)m->d.vocab_size * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, m->d.vocab_size, 1, m->argmax_scratch));
+            RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, ro.n, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
+        RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
+        if (m->tp) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
+            RUN("tp_key", 0, tp::key_from_token(s, m->logits, m->d_out_token, m->vocab_offset, m->tp_key));
+            RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
+            RUN("tp_token", 0, tp::token_from_key(s, m->tp_key, m->d_out_token));
+        }
     }
     hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1), 0, s, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, count, sample ? 1u : 0u);
     ++m->launches;
@@ -437,10 +458,20 @@ void dec_gemv(Enc& e, const k::DecGemvParams& p, const char* name, uint32_t* gri
     e.run(k::gemv_dec(e.s, p, e.m->ctx->num_cus, grid_out), name, dec_gemv_bytes(p));
 }
 
+// out-proj / down-proj of the fused decode step; under tensor parallelism: f32 partials -> all-reduce -> bf16
+void dec_gemv_row_parallel(Enc& e, k::DecGemvParams p, const char* name) {
+    uzu_hip_model* m = e.m;
+    if (!m->tp) return dec_gemv(e, p, name);
+    uint16_t* out = p.out[0];
+    p.out_f32 = m->tp_buf;
+    dec_gemv(e, p, name);
+    RUN("all_reduce", (size_t)p.n[0] * 4, tp::all_reduce_sum_f32(m->tp, e.s, m->tp_buf, p.n[0]));
+    RUN("tp_cast", 0, tp::cast_f32_bf16(e.s, m->tp_buf, out, p.n[0]));
+}
+
 bool linear_fusable(const DLinear& L) {
     if (!L.w) return false;
     if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
-    const uint32_t wpc = 128 / L.bits;
     return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
 }
 bool norm_fusable(const DNorm& N) { return N.present && !N.subtract_mean && !N.biases; }
@@ -504,7 +535,7 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
             const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
             RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
             RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
-            dec_gemv(e, dec_gemv_base(L.out, m->attn_out, m->mixed), "gemv_dec[out_proj]");
+            dec_gemv_row_parallel(e, dec_gemv_base(L.out, m->attn_out, m->mixed), "gemv_dec[out_proj]");
         } else {
             const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
             k::DecGemvParams p = dec_gemv_base(L.in_proj, hidden, m->in_proj);
@@ -516,13 +547,13 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
             q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv, q.kernel_size = L.d.dn_kernel_size;
             q.norm_epsilon = L.d.dn_norm_epsilon;
             RUN("delta_dec", (size_t)2 * Hv * Dv * Dk * 4, k::delta_dec(s, q));
-            dec_gemv(e, dec_gemv_base(L.out_proj, m->delta_out, m->mixed), "gemv_dec[out_proj]");
+            dec_gemv_row_parallel(e, dec_gemv_base(L.out_proj, m->delta_out, m->mixed), "gemv_dec[out_proj]");
         }
         k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
         next_norm(up, L.pre_mlp, 2);
         up.act_mul = 1, up.act_type = L.d.activation;
         dec_gemv(e, up, "gemv_dec[norm+up+act]");
-        dec_gemv(e, dec_gemv_base(L.down, m->gated, hidden), "gemv_dec[down]");
+        dec_gemv_row_parallel(e, dec_gemv_base(L.down, m->gated, hidden), "gemv_dec[down]");
         if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, d));
     }
     m->tap_rows = 1;
@@ -533,7 +564,13 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
     r.part_val = m->amax_val, r.part_idx = m->amax_idx;
     uint32_t grid = 0;
     dec_gemv(e, r, "gemv_dec[norm+readout+argmax]", &grid);
-    RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
+    if (m->tp) {
+        RUN("tp_argmax_key", 0, tp::argmax_key(s, m->amax_val, m->amax_idx, grid, m->vocab_offset, m->tp_key));
+        RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
+        RUN("tp_commit_key", 0, tp::commit_key(s, m->tp_key, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
+    } else {
+        RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
+    }
     if (e.st != UZU_OK) return e.st;
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -591,6 +628,11 @@ uzu_status enqueue_decode(uzu_hip_model* m, uint32_t steps) {
 extern "C" {
 
 uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out) {
+    return uzu_hip_model_create_tp(ctx, desc, flags, nullptr, 0, out);
+}
+
+uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_tp_comm* comm, uint32_t vocab_offset,
+                                   uzu_hip_model** out) {
     UZU_REQUIRE(ctx && desc && out, "model_create: null argument");
     UZU_REQUIRE(desc->num_layers > 0 && desc->layers, "model_create: no layers");
     (void)hipSetDevice(ctx->device);
@@ -599,6 +641,13 @@ uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc
     m->flags = flags;
     m->d = *desc;
     m->d.layers = nullptr;
+    m->tp = (uzu::tp::Comm*)comm;
+    m->vocab_offset = vocab_offset;
+    if (comm && desc->tied_embeddings) {
+        delete m;
+        set_error("model_create: a tensor-parallel shard describes its read-out rows as an untied output_embedding");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
     const uint32_t d = desc->model_dim;
     uzu_status st = UZU_OK;
     auto fail = [&](uzu_status s) {
@@ -733,6 +782,10 @@ uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc
     }
     ALLOC(last_normed, uint16_t, d);
     ALLOC(logits, uint16_t, desc->vocab_size);
+    if (m->tp) {
+        ALLOC(tp_buf, float, C * d);
+        ALLOC(tp_key, unsigned long long, 1);
+    }
     TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
     if (flags & UZU_MODEL_DEBUG_TAPS) ALLOC(taps, uint16_t, (size_t)desc->num_layers * C * d);
 #undef ALLOC
@@ -868,7 +921,7 @@ uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token) {
 uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out) {
     UZU_REQUIRE(m && logits_out, "model_read_logits: null argument");
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
-    HIPCHK(hipMemcpy(logits_out, m->logits, (size_t)m->d.vocab_size * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(logits_out, m->logits, (size_t)(m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n) * 2, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
 
@@ -880,5 +933,21 @@ uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uin
     if (rows) *rows = m->tap_rows;
     return UZU_OK;
 }
+
+// ---- tensor-parallel group (tp.hip) ----
+uzu_status uzu_hip_tp_unique_id(uint8_t out[128]) {
+    UZU_REQUIRE(out, "tp_unique_id: null argument");
+    return uzu::tp::unique_id(out);
+}
+uzu_status uzu_hip_tp_comm_create(uzu_hip_context* ctx, const uint8_t id[128], int32_t rank, int32_t size, uzu_hip_tp_comm** out) {
+    UZU_REQUIRE(ctx && id && out, "tp_comm_create: null argument");
+    (void)hipSetDevice(ctx->device);
+    uzu::tp::Comm* c = nullptr;
+    UZU_PROPAGATE(uzu::tp::comm_create(id, rank, size, &c));
+    *out = (uzu_hip_tp_comm*)c;
+    return UZU_OK;
+}
+void uzu_hip_tp_comm_destroy(uzu_hip_tp_comm* comm) { uzu::tp::comm_destroy((uzu::tp::Comm*)comm); }
+uint32_t uzu_hip_model_logit_count(const uzu_hip_model* m) { return m ? (m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n) : 0; }
 
 } // extern "C"

@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b)));
                 } else {
                     const uint16_t ob = f32_to_bf16(value);
-                    p.out[mat][lrow] = ob;
+                    if (p.out_f32) p.out_f32[lrow] = value;
+                    else p.out[mat][lrow] = ob;
                     if (p.part_val) {
                         const float lv = bf16_to_f32(ob);
                         if (lv > best_v || (lv == best_v && lrow < best_i)) best_v = lv, best_i = lrow;

@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
 
     // ---- epilogue in the reference's order (kernel.rs:281-292): lane holds column n, rows (r&3) + 8*(r>>2) + 4*half
     uint16_t* d = (uint16_t*)p.d;
+    float* d32 = (float*)p.d;
+    const bool out_f32 = p.d_dt == UZU_F32; // tensor-parallel partial sums (engine.hip)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const uint32_t n = n0 + wn * 64 + nb * 32 + l32;
@@ -259,10 +261,11 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
                 if (m >= M) continue;
                 const size_t idx = (size_t)m * N + n;
                 float value = p.ab_scale * acc_t[mb][nb][r];
-                if (p.accumulate) value += bf16_to_f32(d[idx]);
+                if (p.accumulate) value += out_f32 ? d32[idx] : bf16_to_f32(d[idx]);
                 if (p.bias) value += bias;
                 if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
-                d[idx] = f32_to_bf16(value);
+                if (out_f32) d32[idx] = value;
+                else d[idx] = f32_to_bf16(value);
             }
     }
 }
@@ -274,7 +277,7 @@ bool gemm_q_mfma_supported(const MatmulParams& p) {
         return e ? (uint32_t)atoi(e) : 16u;
     }();
     if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || (p.bits != 4 && p.bits != 8)) return false;
-    if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || p.d_dt != UZU_BF16) return false;
+    if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || (p.d_dt != UZU_BF16 && p.d_dt != UZU_F32)) return false;
     if (p.m < min_m || p.gather || p.act_mul) return false;
     if (p.k % BK || p.group_size % BK || p.k % p.group_size) return false;
     if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16 || ((size_t)p.k * p.bits / 8) % 16) return false;

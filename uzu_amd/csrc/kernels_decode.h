@@ -39,6 +39,7 @@ struct DecGemvParams {
     uint32_t act_mul, act_type;   // out[0][j] = up_j * act(gate_j), n[0] = 2h
     float* part_val;              // arg-max partials, one per workgroup
     uint32_t* part_idx;
+    float* out_f32;               // tensor parallel: matrix 0 writes f32 partial sums here instead of bf16 into out[0]
     uint32_t debug;               // microbenchmark ablations (tools/kbench): 1 = skip row loop, 2 = skip prologue
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);

@@ -1,0 +1,31 @@
+// tp.h -- tensor-parallel exchange used by the engine (tp.hip): RCCL communicator + the small kernels either side of it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uzu_hip.h"
+
+namespace uzu {
+namespace tp {
+
+struct Comm;
+
+uzu_status unique_id(uint8_t out[128]);                                  // rank 0: ncclGetUniqueId
+uzu_status comm_create(const uint8_t id[128], int rank, int size, Comm** out); // collective over the group
+void comm_destroy(Comm* c);
+int comm_rank(const Comm* c);
+int comm_size(const Comm* c);
+
+uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count);          // in place
+uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count);
+
+uzu_status cast_f32_bf16(hipStream_t s, const float* in, uint16_t* out, size_t n);
+// greedy arg-max across vocab shards: key = (orderable(logit) << 32) | ~global_index, reduced with max
+uzu_status argmax_key(hipStream_t s, const float* part_val, const uint32_t* part_idx, uint32_t parts, uint32_t vocab_offset, unsigned long long* key);
+uzu_status key_from_token(hipStream_t s, const uint16_t* logits, const uint32_t* local_token, uint32_t vocab_offset, unsigned long long* key);
+uzu_status token_from_key(hipStream_t s, const unsigned long long* key, uint32_t* out_token);
+uzu_status commit_key(hipStream_t s, const unsigned long long* key, uint32_t* ctx_len, uint32_t* tokens, uint32_t* out_token, uint32_t* sampled);
+
+} // namespace tp
+} // namespace uzu

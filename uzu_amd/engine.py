@@ -20,14 +20,20 @@ MODEL_DEFAULT, MODEL_NO_GRAPH, MODEL_NO_FUSION, MODEL_DEBUG_TAPS = 0, 1, 2, 4
 
 
 class HipModel:
-    def __init__(self, ctx: Context, bundle: ModelBundle, flags: int = MODEL_DEFAULT):
+    def __init__(self, ctx: Context, bundle: ModelBundle, flags: int = MODEL_DEFAULT, tp_group=None, vocab_offset: int = 0):
+        """`tp_group` (uzu_amd.tp.TpGroup) + `vocab_offset`: `bundle` is this rank's shard from uzu_amd.tp.shard_bundle."""
         self.ctx = ctx
         self.vocab_size = bundle.vocab_size
         self.model_dim = bundle.model_dim
         self.num_layers = len(bundle.layers)
+        self.tp_group = tp_group
         desc = bundle.desc()
         self._h = C.c_void_p()
-        call("uzu_hip_model_create", ctx._h, C.byref(desc), C.c_uint32(flags), C.byref(self._h))
+        if tp_group is None:
+            call("uzu_hip_model_create", ctx._h, C.byref(desc), C.c_uint32(flags), C.byref(self._h))
+        else:
+            call("uzu_hip_model_create_tp", ctx._h, C.byref(desc), C.c_uint32(flags), tp_group._h, C.c_uint32(vocab_offset), C.byref(self._h))
+        self.logit_count = int(_ffi.lib().uzu_hip_model_logit_count(self._h))
 
     def close(self):
         if self._h:
@@ -80,7 +86,7 @@ class HipModel:
         call("uzu_hip_model_set_next_token", self._h, C.c_uint32(int(token)))
 
     def read_logits(self) -> np.ndarray:
-        out = np.empty(self.vocab_size, dtype=np.uint16)
+        out = np.empty(self.logit_count, dtype=np.uint16)
         call("uzu_hip_model_read_logits", self._h, C.c_void_p(out.ctypes.data))
         return out
 

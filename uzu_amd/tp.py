@@ -1,0 +1,249 @@
+"""Tensor-parallel shard planner and group setup (not present in the reference).
+
+One process per GPU.  ``shard_bundle(bundle, rank, size)`` cuts a whole-model ``ModelBundle`` into the shard
+rank ``rank`` of ``size`` owns; the engine (``uzu_hip_model_create_tp``) runs the ordinary forward on the shard
+and exchanges data at exactly three kinds of places:
+
+  * after every ROW-parallel linear (attention / DeltaNet out-projection, MLP down-projection): all-reduce(sum) of
+    the f32 partial rows ``[tokens, model_dim]``, rounded to bf16 once after the sum;
+  * after the vocab-sharded read-out: all-reduce(max) of one packed (logit, index) key per sampled token;
+  * nothing else: norms, residual stream, RoPE tables and the embedding lookup are replicated.
+
+Partitioning (the quant groups run along k, so any split of the OUTPUT rows is layout-safe; splits of K must fall
+on group boundaries):
+
+  qkv / gate            column-parallel by q heads; the kv heads follow their q heads (replicated when
+                        size > kv heads)                                                         no collective
+  DeltaNet in-proj      column-parallel by k heads / v heads: sections [q | k | v | z | beta | a] are cut per head;
+                        conv weights / biases, a_log, dt_bias follow the same channels         no collective
+  up (fused up||gate)   column-parallel, each half cut the same way; hidden is zero-padded to a multiple of
+                        size * group_size so that every rank owns whole quant groups           no collective
+  out-proj / down       row-parallel: K slice = the rank's heads / hidden slice                all-reduce(sum)
+  read-out              rows [rank * V/size, (rank+1) * V/size); the full table stays for the embedding lookup
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import replace
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import call
+from . import desc as D
+
+
+# ------------------------------------------------------------------------------------------------ slicing helpers
+def take_rows(w: D.LinearWeights, idx: np.ndarray) -> D.LinearWeights:
+    """Column-parallel shard: keep output rows `idx` (in that order)."""
+    cp = lambda a: None if a is None else np.ascontiguousarray(a[idx])
+    return D.LinearWeights(int(len(idx)), w.k, w.bits, w.group_size, w.method, cp(w.weights), cp(w.scales), cp(w.biases),
+                           cp(w.zero_points), cp(w.out_biases))
+
+
+def take_k(w: D.LinearWeights, k0: int, k1: int, owns_out_bias: bool) -> D.LinearWeights:
+    """Row-parallel shard: keep input columns [k0, k1).  k0, k1 must be quant-group boundaries (nibble-packed int4
+    zero-points are repacked).  The Linear's output bias is added by one rank only."""
+    if w.method == D.QUANT_NONE:
+        assert w.bits == 16
+        wt = np.ascontiguousarray(w.weights.reshape(w.n, w.k)[:, k0:k1])
+        return D.LinearWeights(w.n, k1 - k0, 16, 0, w.method, wt, None, None, None, w.out_biases if owns_out_bias else None)
+    g = w.group_size
+    assert k0 % g == 0 and k1 % g == 0, f"K split [{k0},{k1}) is not on group boundaries (group {g})"
+    g0, g1 = k0 // g, k1 // g
+    bpk = w.bits / 8.0
+    b0, b1 = int(k0 * bpk), int(k1 * bpk)
+    wt = np.ascontiguousarray(w.weights.reshape(w.n, -1)[:, b0:b1])
+    sc = np.ascontiguousarray(w.scales.reshape(w.n, -1)[:, g0:g1])
+    bi = None if w.biases is None else np.ascontiguousarray(w.biases.reshape(w.n, -1)[:, g0:g1])
+    zp = None
+    if w.zero_points is not None:
+        z = w.zero_points.reshape(w.n, -1)
+        if w.bits == 4:  # nibble-packed (even group = low nibble): unpack, cut, repack so that any group start works
+            per_group = np.empty((w.n, 2 * z.shape[1]), dtype=np.uint8)
+            per_group[:, 0::2], per_group[:, 1::2] = z & 0xF, z >> 4
+            cut = per_group[:, g0:g1]
+            if cut.shape[1] % 2:
+                cut = np.concatenate([cut, np.zeros((w.n, 1), dtype=np.uint8)], axis=1)
+            zp = np.ascontiguousarray(cut[:, 0::2] | (cut[:, 1::2] << 4))
+        else:
+            zp = np.ascontiguousarray(z[:, g0:g1])
+    return D.LinearWeights(w.n, k1 - k0, w.bits, g, w.method, wt, sc, bi, zp, w.out_biases if owns_out_bias else None)
+
+
+def _zero_rows(w: D.LinearWeights, count: int) -> D.LinearWeights:
+    """`count` extra output rows that dequantise to exactly 0 (scale = bias = 0) -- MLP hidden padding."""
+    z = lambda a: None if a is None else np.zeros((count,) + a.shape[1:], dtype=a.dtype)
+    return D.LinearWeights(count, w.k, w.bits, w.group_size, w.method, z(w.weights), z(w.scales), z(w.biases), z(w.zero_points),
+                           z(w.out_biases))
+
+
+def _concat_rows(parts: List[D.LinearWeights]) -> D.LinearWeights:
+    first = parts[0]
+    cat = lambda name: None if getattr(first, name) is None else np.ascontiguousarray(np.concatenate([getattr(p, name) for p in parts], axis=0))
+    return D.LinearWeights(sum(p.n for p in parts), first.k, first.bits, first.group_size, first.method, cat("weights"), cat("scales"),
+                           cat("biases"), cat("zero_points"), cat("out_biases"))
+
+
+def _pad_k(w: D.LinearWeights, new_k: int) -> D.LinearWeights:
+    """Extend the input dimension with columns that contribute exactly 0 (their activations are 0 as well)."""
+    if new_k == w.k:
+        return w
+    assert w.method != D.QUANT_NONE and (new_k - w.k) % w.group_size == 0
+    extra_groups = (new_k - w.k) // w.group_size
+    extra_bytes = (new_k - w.k) * w.bits // 8
+    wt = np.concatenate([w.weights.reshape(w.n, -1), np.zeros((w.n, extra_bytes), dtype=np.uint8)], axis=1)
+    sc = np.concatenate([w.scales.reshape(w.n, -1), np.zeros((w.n, extra_groups), dtype=np.uint16)], axis=1)
+    bi = None if w.biases is None else np.concatenate([w.biases.reshape(w.n, -1), np.zeros((w.n, extra_groups), dtype=np.uint16)], axis=1)
+    zp = None
+    if w.zero_points is not None:
+        groups = new_k // w.group_size
+        zp_cols = (groups + 1) // 2 if w.bits == 4 else groups
+        z = w.zero_points.reshape(w.n, -1)
+        zp = np.concatenate([z, np.zeros((w.n, zp_cols - z.shape[1]), dtype=np.uint8)], axis=1)
+    return D.LinearWeights(w.n, new_k, w.bits, w.group_size, w.method, np.ascontiguousarray(wt), np.ascontiguousarray(sc),
+                           None if bi is None else np.ascontiguousarray(bi), None if zp is None else np.ascontiguousarray(zp), w.out_biases)
+
+
+def _head_range(total: int, rank: int, size: int) -> Tuple[int, int]:
+    """Heads [lo, hi) of `total` owned by `rank`; with fewer heads than ranks the heads are replicated."""
+    if total >= size:
+        assert total % size == 0, f"{total} heads do not split over {size} ranks"
+        per = total // size
+        return rank * per, (rank + 1) * per
+    assert size % total == 0, f"{size} ranks do not replicate {total} heads evenly"
+    h = rank * total // size
+    return h, h + 1
+
+
+def padded_hidden(hidden: int, group: int, size: int) -> int:
+    unit = max(group, 1) * size
+    return (hidden + unit - 1) // unit * unit
+
+
+# ------------------------------------------------------------------------------------------------ the planner
+def shard_layer(l: D.LayerWeights, rank: int, size: int) -> D.LayerWeights:
+    out = replace(l)
+    # ---- MLP: up || gate column-parallel, down row-parallel
+    h = l.hidden_dim
+    group = l.down_projection.group_size if l.down_projection.method != D.QUANT_NONE else 1
+    hp = padded_hidden(h, group, size)
+    per = hp // size
+    lo, hi = rank * per, (rank + 1) * per
+    up_full, down_full = l.up_projection, l.down_projection
+    if hp != h:  # zero rows in both halves of the fused up matrix, zero-contribution columns in down
+        up_half, gate_half = take_rows(up_full, np.arange(0, h)), take_rows(up_full, np.arange(h, 2 * h))
+        pad = _zero_rows(up_full, hp - h)
+        up_full = _concat_rows([up_half, pad, gate_half, pad])
+        down_full = _pad_k(down_full, hp)
+    out.hidden_dim = per
+    out.up_projection = take_rows(up_full, np.concatenate([np.arange(lo, hi), np.arange(hp + lo, hp + hi)]))
+    out.down_projection = take_k(down_full, lo, hi, owns_out_bias=rank == 0)
+
+    if l.mixer_kind == D.MIXER_ATTENTION:
+        nq, nkv, hd = l.num_heads, l.num_groups, l.head_dim
+        assert nq % size == 0, f"{nq} query heads do not split over {size} ranks"
+        q_lo, q_hi = rank * nq // size, (rank + 1) * nq // size
+        gqa = nq // nkv
+        kv_lo, kv_hi = q_lo // gqa, (q_hi - 1) // gqa + 1
+        assert (q_hi - q_lo) % (kv_hi - kv_lo) == 0
+        rows = lambda first_head, lo_, hi_: np.arange((first_head + lo_) * hd, (first_head + hi_) * hd)
+        qkv_rows = np.concatenate([rows(0, q_lo, q_hi), rows(nq, kv_lo, kv_hi), rows(nq + nkv, kv_lo, kv_hi)])
+        out.num_heads, out.num_groups = q_hi - q_lo, kv_hi - kv_lo
+        out.qkv_projection = take_rows(l.qkv_projection, qkv_rows)
+        if l.gate_projection is not None:
+            out.gate_projection = take_rows(l.gate_projection, rows(0, q_lo, q_hi))
+        out.out_projection = take_k(l.out_projection, q_lo * hd, q_hi * hd, owns_out_bias=rank == 0)
+    else:
+        Hv, Hk, Dk, Dv = l.dn_num_heads, l.dn_num_groups, l.dn_head_dim, l.dn_value_head_dim
+        assert Hv % size == 0, f"{Hv} DeltaNet value heads do not split over {size} ranks"
+        v_lo, v_hi = rank * Hv // size, (rank + 1) * Hv // size
+        gph = Hv // Hk
+        k_lo, k_hi = v_lo // gph, (v_hi - 1) // gph + 1
+        assert (v_hi - v_lo) % (k_hi - k_lo) == 0
+        key_dim, value_dim = Hk * Dk, Hv * Dv
+        conv_dim = 2 * key_dim + value_dim
+        q_rows = np.arange(k_lo * Dk, k_hi * Dk)
+        k_rows = key_dim + q_rows
+        v_rows = 2 * key_dim + np.arange(v_lo * Dv, v_hi * Dv)
+        z_rows = conv_dim + np.arange(v_lo * Dv, v_hi * Dv)
+        beta_rows = conv_dim + value_dim + np.arange(v_lo, v_hi)
+        a_rows = conv_dim + value_dim + Hv + np.arange(v_lo, v_hi)
+        conv_rows = np.concatenate([q_rows, k_rows, v_rows])
+        out.dn_num_heads, out.dn_num_groups = v_hi - v_lo, k_hi - k_lo
+        out.dn_in_proj = take_rows(l.dn_in_proj, np.concatenate([conv_rows, z_rows, beta_rows, a_rows]))
+        out.dn_out_proj = take_k(l.dn_out_proj, v_lo * Dv, v_hi * Dv, owns_out_bias=rank == 0)
+        out.dn_conv_weights = np.ascontiguousarray(l.dn_conv_weights.reshape(conv_dim, -1)[conv_rows])
+        if l.dn_conv_biases is not None:
+            out.dn_conv_biases = np.ascontiguousarray(l.dn_conv_biases[conv_rows])
+        out.dn_a_log = np.ascontiguousarray(l.dn_a_log[v_lo:v_hi])
+        out.dn_dt_bias = np.ascontiguousarray(l.dn_dt_bias[v_lo:v_hi])
+    return out
+
+
+def shard_bundle(bundle: D.ModelBundle, rank: int, size: int) -> Tuple[D.ModelBundle, int]:
+    """-> (shard bundle, vocab_offset).  size == 1 still produces the untied-readout form the TP engine expects."""
+    assert 0 <= rank < size
+    V = bundle.vocab_size
+    assert V % size == 0, f"vocab {V} does not split over {size} ranks"
+    lo, hi = rank * V // size, (rank + 1) * V // size
+    readout = bundle.embedding if bundle.tied_embeddings else bundle.output_embedding
+    shard = replace(bundle, layers=[shard_layer(l, rank, size) for l in bundle.layers], tied_embeddings=False,
+                    output_embedding=take_rows(readout, np.arange(lo, hi)), _keep=[])
+    shard.name = f"{bundle.name}[tp {rank}/{size}]"
+    return shard, lo
+
+
+# ------------------------------------------------------------------------------------------------ group setup
+class TpGroup:
+    """RCCL communicator of the engine (uzu_hip_tp_comm).  `broadcast` ships rank 0's 128-byte id to every rank:
+    a callable  bytes|None -> bytes  (rank 0 passes the id, the others None)."""
+
+    def __init__(self, ctx, rank: int, size: int, broadcast: Optional[Callable[[Optional[bytes]], bytes]] = None):
+        self.ctx, self.rank, self.size = ctx, rank, size
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            call("uzu_hip_tp_unique_id", buf)
+            ident = bytes(buf)
+        if size > 1:
+            assert broadcast is not None, "a multi-rank TpGroup needs a broadcast callable"
+            ident = broadcast(ident)
+        arr = (C.c_uint8 * 128).from_buffer_copy(ident)
+        self._h = C.c_void_p()
+        call("uzu_hip_tp_comm_create", ctx._h, arr, C.c_int32(rank), C.c_int32(size), C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            _ffi.lib().uzu_hip_tp_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def torch_broadcast(dist, device=None) -> Callable[[Optional[bytes]], bytes]:
+    """Broadcast helper over an initialised torch.distributed process group (gloo on CPU, nccl = RCCL on GPU)."""
+    import torch
+
+    def bcast(ident: Optional[bytes]) -> bytes:
+        t = torch.zeros(128, dtype=torch.uint8, device=device)
+        if ident is not None:
+            t = torch.tensor(list(ident), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().tolist())
+
+    return bcast
+
+
+# ------------------------------------------------------------------------------------------------ exchange protocol
+def pack_argmax_key(logit: float, global_index: int) -> int:
+    """Host mirror of tp.hip's packed greedy key: (order-preserving u32 of the f32 logit) << 32 | ~index.
+    max() over the ranks' keys = highest logit, ties -> lowest index (unified_sampling.rs:90-95)."""
+    bits = int(np.float32(logit).view(np.uint32))
+    orderable = (~bits & 0xFFFFFFFF) if bits & 0x80000000 else (bits | 0x80000000)
+    return (orderable << 32) | (0xFFFFFFFF - int(global_index))
+
+
+def unpack_argmax_key(key: int) -> Tuple[float, int]:
+    orderable, inv = (key >> 32) & 0xFFFFFFFF, key & 0xFFFFFFFF
+    bits = (orderable & 0x7FFFFFFF) if orderable & 0x80000000 else (~orderable & 0xFFFFFFFF)
+    return float(np.uint32(bits).view(np.float32)), 0xFFFFFFFF - inv
