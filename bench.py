@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--context", type=int, default=2048, help="context length at which the timed decode starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--parallelism", choices=["tp", "replicas"], default="tp", help="what N > 1 GPUs do (default: tensor parallel)")
+    ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path even with one rank (self-test on a 1-GPU box)")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
     return ap.parse_args()
 
@@ -90,39 +92,9 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     return (best[1], best[2]) if best else (None, None)
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from uzu_amd import synthetic as S
-    from uzu_amd.backend import Context
-    from uzu_amd.engine import MODEL_DEFAULT, MODEL_NO_GRAPH, HipModel
-
-    total_positions = args.context + args.warmup + args.steps + 8
-    cfg = S.PRESETS[args.model](max_context_length=total_positions)
-    bundle = S.build_model(cfg)
-    ctx = Context.new(local_rank)
-    model = HipModel(ctx, bundle, MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT)
-
-    # fill the context: prompt = context - warmup tokens, then `warmup` untimed decode steps reach `context`
-    prompt_len = max(args.context - args.warmup, 1)
-    prompt = S.synthetic_prompt(prompt_len, cfg.vocab_size)
-    t0 = time.perf_counter()
-    model.prefill(prompt)
-    ctx.synchronize()
-    prefill_s = time.perf_counter() - t0
-    if args.warmup:
-        model.decode(args.warmup)
-    start_ctx = model.context_length
-
+def timed_decode(model, ctx, args, dist, prompt):
+    """prefill -> `warmup` untimed steps -> EXACTLY `steps` timed greedy decode steps between barrier + device sync on
+    both sides; elapsed = max over ranks.  Returns (elapsed_s, gpu_ms, start_ctx, end_ctx, prefill_s)."""
     def sync():
         ctx.synchronize()
         if dist is not None:
@@ -132,20 +104,82 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    toks, gpu_ms = model.decode(args.steps)  # K graph replays, chained on the device; returns after the last one
+    model.prefill(prompt)
+    ctx.synchronize()
+    prefill_s = time.perf_counter() - t0
+    if args.warmup:
+        model.decode(args.warmup)
+    start_ctx = model.context_length
+    sync()
+    t0 = time.perf_counter()
+    _, gpu_ms = model.decode(args.steps)  # K graph replays, chained on the device; returns after the last one
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed, prefill_s], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    end_ctx = model.context_length
-    mean_ctx = (start_ctx + end_ctx - 1) / 2.0
+        elapsed, prefill_s = float(t[0].item()), float(t[1].item())
+    return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s
 
-    tokens_per_s = world * args.steps / elapsed
-    bytes_per_token = bundle.decode_bytes_per_token(int(round(mean_ctx)))
-    step_gbps = bytes_per_token * (args.steps / elapsed) / 1e9
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    multi = world > 1 or args.force_dist
+    if multi:
+        import datetime
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=300))
+
+    from uzu_amd import synthetic as S
+    from uzu_amd import tp as TP
+    from uzu_amd.backend import Context
+    from uzu_amd.engine import MODEL_DEFAULT, MODEL_NO_GRAPH, HipModel
+
+    total_positions = args.context + args.warmup + args.steps + 8
+    cfg = S.PRESETS[args.model](max_context_length=total_positions)
+    bundle = S.build_model(cfg)
+    ctx = Context.new(local_rank)
+    flags = MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT
+    # fill the context: prompt = context - warmup tokens, then `warmup` untimed decode steps reach `context`
+    prompt_len = max(args.context - args.warmup, 1)
+    prompt = S.synthetic_prompt(prompt_len, cfg.vocab_size)
+
+    # N > 1: tensor-parallel shards of ONE sequence (north_star; strong scaling).  `--parallelism replicas` (or a
+    # model whose heads do not split over N ranks) runs N independent sequences instead (weak scaling).
+    mode = args.parallelism if multi else "single"
+    group = None
+    note = None
+    local_bundle = bundle
+    if mode == "tp":
+        try:
+            local_bundle, vocab_offset = TP.shard_bundle(bundle, rank, world)
+        except AssertionError as exc:  # deterministic on every rank: the planner only looks at shapes
+            mode, note, local_bundle = "replicas", f"tp{world} not applicable: {exc}", bundle
+    if mode == "tp":
+        import torch
+        group = TP.TpGroup(ctx, rank, world, TP.torch_broadcast(dist, device=torch.device("cuda", local_rank)))
+        model = HipModel(ctx, local_bundle, flags, tp_group=group, vocab_offset=vocab_offset)
+    else:
+        model = HipModel(ctx, bundle, flags)
+
+    elapsed, gpu_ms, start_ctx, end_ctx, prefill_s = timed_decode(model, ctx, args, dist, prompt)
+    mean_ctx = (start_ctx + end_ctx - 1) / 2.0
+    sequences = world if mode == "replicas" else 1
+    tokens_per_s = sequences * args.steps / elapsed
+    # algorithmic bytes per token summed over the GPUs of the job (each rank streams its shard / its replica)
+    bytes_per_token = local_bundle.decode_bytes_per_token(int(round(mean_ctx)))
+    job_bytes_per_token = bytes_per_token * (world if mode != "single" else 1)
+    per_gpu_gbps = bytes_per_token * (args.steps / elapsed) / 1e9
 
     # per-kernel roofline of the dominant kernel: one extra decode step with HIP events around every launch
     prof = model.profile_decode_step()
@@ -168,35 +202,62 @@ def main():
         "launches_per_step": calls, "bytes_per_launch": int(dbytes / max(calls, 1)), "avg_launch_us": round(dms * 1e3 / max(calls, 1), 3),
         "all_gemv": {"launches_per_step": sum(v[0] for v in gemv.values()), "achieved": round(gemv_bytes / max(gemv_ms, 1e-9) / 1e6, 1),
                      "unit": "GB/s", "sum_us": round(gemv_ms * 1e3, 1)},
-        "decode_step": {"algorithmic_bytes_per_token": int(bytes_per_token), "achieved": round(step_gbps, 1), "unit": "GB/s",
-                        "frac": round(step_gbps / HBM_PEAK_GBPS, 4), "kernels_per_step": len(prof),
-                        "sum_kernel_us": round(sum(p[2] for p in prof) * 1e3, 1)},
-        "method": "HIP events on the context stream around every kernel of one decode step (uzu_hip_model_profile_decode_step)",
+        "decode_step": {"algorithmic_bytes_per_token_per_gpu": int(bytes_per_token), "algorithmic_bytes_per_token_job": int(job_bytes_per_token),
+                        "achieved_per_gpu": round(per_gpu_gbps, 1), "unit": "GB/s", "frac_per_gpu": round(per_gpu_gbps / HBM_PEAK_GBPS, 4),
+                        "kernels_per_step": len(prof), "sum_kernel_us": round(sum(p[2] for p in prof) * 1e3, 1)},
+        "method": "HIP events on the context stream around every kernel of one decode step of rank 0 (uzu_hip_model_profile_decode_step); "
+                  "event bracketing adds ~2 us per launch over the rocprofv3 begin->end duration (profiles/*_kernel_stats.csv)",
     }
     per_kernel = {k: {"calls": v[0], "us": round(v[2] * 1e3, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+    parallelism = {"single": "1 GPU", "tp": f"tp{world}: one sequence, column/row-parallel shards, RCCL all-reduce after out-proj and down-proj "
+                   f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]
 
     result = {
         "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)",
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-        "scaling": "weak" if world > 1 else "weak", "vs_baseline": None, "dtype": "int4 weights x bf16 activations, f32 accumulate",
+        "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int4 weights x bf16 activations, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int4 ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
-                   "prompt_tokens": prompt_len, "graph": not args.no_graph,
-                   "parallelism": "1 GPU" if world == 1 else f"{world} independent sequences (one per GPU)"},
+                   "prompt_tokens": prompt_len, "graph": not args.no_graph, "parallelism": parallelism},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
-        "prefill_tokens_per_s": round(prompt_len / prefill_s, 1),
+        "prefill_tokens_per_s": round(sequences * prompt_len / prefill_s, 1),
         "roofline": roofline,
         "kernel_us_per_step": per_kernel,
         "device": ctx.device_name(),
     }
+    if note:
+        result["config"]["note"] = note
+    if mode == "tp":
+        ar = agg.get("all_reduce", [0, 0, 0.0])
+        result["tp"] = {"all_reduces_per_token": ar[0], "all_reduce_us_per_token": round(ar[2] * 1e3, 1),
+                        "share_of_kernel_time": round(ar[2] / max(sum(p[2] for p in prof), 1e-9), 3)}
+        # the serving-throughput view of the same N GPUs: N independent sequences, one whole model per GPU
+        model.close()
+        try:
+            replica = HipModel(ctx, bundle, flags)
+            r_elapsed, _, _, _, r_prefill = timed_decode(replica, ctx, args, dist, prompt)
+            result["replicas"] = {"value": round(world * args.steps / r_elapsed, 2), "unit": "tokens/s", "scaling": "weak",
+                                  "prefill_tokens_per_s": round(world * prompt_len / r_prefill, 1),
+                                  "note": f"{world} independent sequences, one per GPU, no collective (not the headline value)"}
+            model = replica
+        except Exception as exc:  # noqa: BLE001 -- the secondary figure must never take the headline down
+            result["replicas"] = {"error": str(exc)[:200]}
+            model = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(bundle, cfg, args.cpu_baseline_tokens)
-    if rank == 0:
-        print(json.dumps(result))
-    model.close()
+    if model is not None:
+        model.close()
+    if group is not None:
+        group.close()
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio (block-buffered on a pipe): flush it BEFORE the JSON line so that
+    # the JSON is the last line of rank 0's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
