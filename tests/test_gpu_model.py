@@ -167,3 +167,14 @@ def test_qwen35_0p8b_full_size(hip_ctx):
     # (tools/fullsize_check.py); the 4-layer toy models stay below 0.1 sigma.  Tolerance here: 0.5 sigma.
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 128, 8, logit_tol=0.5)
     assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
+
+
+@pytest.mark.parametrize("bits,method", [(4, D.QUANT_SCALE_BIAS), (8, D.QUANT_SCALE_ZERO_POINT)])
+def test_llama3_8b_shapes_two_layers(hip_ctx, bits, method):
+    """BASELINE configs 3/4 at their real matrix shapes (d 4096, ffn 14336, 32 q / 8 kv heads, hd 128, vocab 128256,
+    untied read-out, Llama-3 RoPE scaling) but 2 of the 32 layers so that the CPU reference finishes in seconds:
+    int4 MLX ScaleBias and int8 asymmetric, 48-token prefill (matrix-core GEMM) + 6 greedy decode steps (fused GEMV)."""
+    cfg = S.llama3_8b(max_context_length=512, layer_kinds=[D.MIXER_ATTENTION] * 2, bits=bits, method=method, seed=7)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 48, 6)
+    assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
+

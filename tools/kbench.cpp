@@ -49,7 +49,6 @@ int main(int argc, char** argv) {
             if (norm) { p.norm_scales = ns, p.norm_eps = 1e-6f, p.norm_offset = 1.f, p.norm_full_layer = 1, p.residual_add = 1, p.shortcut_in = sh, p.shortcut_out = sho; }
             if (act) p.act_mul = 1;
             if (amax) p.part_val = pv, p.part_idx = pi;
-            p.debug = debug;
             return gemv_dec(s, p, cus, nullptr);
         });
     };
@@ -66,15 +65,17 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (getenv("KB_LLAMA")) { // Llama-3-8B decode shapes (bandwidth regime)
+        bench_gemv("L8 qkv 6144x4096 +norm", 6144, 4096, true, false, false);
+        bench_gemv("L8 out 4096x4096", 4096, 4096, false, false, false);
+        bench_gemv("L8 up+act 28672x4096 +norm", 28672, 4096, true, true, false);
+        bench_gemv("L8 down 4096x14336", 4096, 14336, false, false, false);
+        bench_gemv("L8 readout 128256x4096 +norm", 128256, 4096, true, false, true);
+        bench_gemv("Q readout 248320x1024 +norm", 248320, 1024, true, false, true);
+        return 0;
+    }
     bench_gemv("gemv_dec in_proj 8224x1024 +norm", 8224, 1024, true, false, false);
     bench_gemv("gemv_dec in_proj 8224x1024", 8224, 1024, false, false, false);
-    bench_gemv("  .. prologue only (no rows)", 8224, 1024, false, false, false, 0, 1);
-    bench_gemv("  .. rows only (no prologue)", 8224, 1024, false, false, false, 0, 2);
-    bench_gemv("  .. neither", 8224, 1024, false, false, false, 0, 3);
-    bench_gemv("  .. rows only, no store", 8224, 1024, false, false, false, 0, 2 | 4);
-    bench_gemv("  .. rows only, no weight loads", 8224, 1024, false, false, false, 0, 2 | 8);
-    bench_gemv("  .. rows only, no loads no store", 8224, 1024, false, false, false, 0, 2 | 4 | 8);
-    bench_gemv("  .. +norm prologue only", 8224, 1024, true, false, false, 0, 1);
     bench_gemv("gemv_dec out_proj 1024x2048", 1024, 2048, false, false, false);
     bench_gemv("gemv_dec up+act 7168x1024 +norm", 7168, 1024, true, true, false);
     bench_gemv("gemv_dec down 1024x3584", 1024, 3584, false, false, false);

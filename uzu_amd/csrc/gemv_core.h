@@ -42,8 +42,14 @@ __device__ __forceinline__ float dot32(const Codes4& c, const float (&x)[32]) {
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t lo = ws[i] & 0x0F0F0F0Fu;        // codes 0,2,4,6
-        const uint32_t hi = (ws[i] >> 4) & 0x0F0F0F0Fu; // codes 1,3,5,7
+        uint32_t lo = ws[i] & 0x0F0F0F0Fu;        // codes 0,2,4,6
+        uint32_t hi = (ws[i] >> 4) & 0x0F0F0F0Fu; // codes 1,3,5,7
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keep the masked words opaque: otherwise the byte extracts below are rewritten into v_bfe_u32 of the
+        // original word + v_cvt_f32_ubyte0 (2 instructions per code) instead of v_cvt_f32_ubyte0..3 (1 per code)
+        asm("" : "+v"(lo));
+        asm("" : "+v"(hi));
+#endif
         d0 = fmaf(ub0(lo), x[8 * i + 0], d0);
         d1 = fmaf(ub0(hi), x[8 * i + 1], d1);
         d2 = fmaf(ub1(lo), x[8 * i + 2], d2);

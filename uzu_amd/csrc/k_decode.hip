@@ -53,7 +53,7 @@ __device__ __forceinline__ float act_bf16(uint32_t act, float x) { // activation
 //     next batch is prefetched while the current one is computed (tools/microbench2: a kernel boundary costs
 //     1.6 us, a dependent HBM round trip 0.3-0.5 us: the kernel should pay exactly one of the latter);
 //   * epilogues: plain store | SiLU(gate)*up | arg-max partial per workgroup.
-template <int BITS, int CPLT, int R, bool ACT>
+template <int BITS, int CPLT, int R, bool ACT, int KIND>
 __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_log2) {
     using Codes = typename CodesT<BITS>::type;
     constexpr int STEP_BYTES = 4 * BITS;
@@ -80,10 +80,11 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         Codes w[R][NPHYS];
         uint16_t s[R][NPHYS], o[R][NPHYS];
     };
-    // wave-uniform matrix selection: batches [0, batches0) belong to matrix 0, the rest to matrix 1
+    // Loads of one (batch, step) item.  Batches [0, batches0) belong to matrix 0, the rest to matrix 1 (wave-uniform:
+    // the base pointers stay in SGPRs and the per-lane part of every address is a 32-bit byte offset -- host-checked).
     auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
         const uint32_t c = sl + lpr * j;
-        if (b >= num_batches || c >= C || (p.debug & 8)) return;
+        if (b >= num_batches || c >= C) return;
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
         const uint32_t nl = mat ? p.n[1] : n_log0;
@@ -99,22 +100,23 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
 #pragma unroll
             for (int h = 0; h < NPHYS; ++h) {
                 const uint32_t prow = ACT ? lr + (h ? p.n[0] / 2 : 0) : lr;
-                load_codes(it.w[r][h], wp + (size_t)prow * row_bytes + (size_t)c * STEP_BYTES);
-                it.s[r][h] = sp[(size_t)prow * G + grp];
-                if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) it.o[r][h] = bp[(size_t)prow * G + grp];
-                else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) it.o[r][h] = BITS == 4 ? zp[(size_t)prow * zp_stride + (grp >> 1)] : zp[(size_t)prow * zp_stride + grp];
+                load_codes(it.w[r][h], wp + (prow * row_bytes + c * STEP_BYTES));
+                const uint32_t gi = prow * G + grp;
+                it.s[r][h] = sp[gi];
+                if (KIND == UZU_MATMUL_B_SCALE_BIAS) it.o[r][h] = bp[gi];
+                else if (KIND == UZU_MATMUL_B_SCALE_ZERO_POINT) it.o[r][h] = BITS == 4 ? zp[prow * zp_stride + (grp >> 1)] : zp[prow * zp_stride + grp];
             }
         }
     };
 
     const uint32_t b0 = blockIdx.x * 4 + wave;
-    Item cur, nxt;
-    if (!(p.debug & 1)) load_item(b0, 0, cur); // in flight during the whole prologue
+    Item itA, itB;
+    load_item(b0, 0, itA); // in flight during the whole prologue
 
     // ---- prologue ---------------------------------------------------------------------------------------
     float xf[CPL][32];
     float xsm[CPL];
-    if (CPLT != 0 && !(p.debug & 2)) {
+    if (CPLT != 0) {
         const bool normed = p.norm_scales || p.norm_plain;
         if (!normed) { // plain activation row: every lane fetches its own steps
 #pragma unroll
@@ -207,54 +209,31 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     }
 
     // ---- row loop, software pipelined over (batch, step) items ---------------------------------------------
+    // Two item buffers alternate roles (no register copies): while one is consumed the loads of the next (batch,
+    // step) land in the other.
     float best_v = -INFINITY; // arg-max epilogue state (lane-local)
     uint32_t best_i = 0xFFFFFFFFu;
-    if (!(p.debug & 1))
-    for (uint32_t b = b0; b < num_batches; b += total_waves) {
-        float acc[R][NPHYS];
+    auto compute = [&](const Item& it, uint32_t c, const float (&x)[32], float xs, float (&acc)[R][NPHYS]) {
+        const uint32_t grp = (c * 32) >> gshift;
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int h = 0; h < NPHYS; ++h) acc[r][h] = 0.f;
-        auto compute = [&](const Item& it, uint32_t c, const float (&x)[32], float xs) {
-            const uint32_t grp = (c * 32) >> gshift;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int h = 0; h < NPHYS; ++h) {
-                    const float sc = bf16_to_f32(it.s[r][h]);
-                    float of;
-                    if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(it.o[r][h]);
-                    else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
-                        const uint32_t zpv = BITS == 4 ? ((grp & 1) ? (it.o[r][h] >> 4) : (it.o[r][h] & 0x0F)) : it.o[r][h];
-                        of = -sc * (float)zpv;
-                    } else of = -sc * (float)(1u << (BITS - 1));
-                    const float dq = dot32(it.w[r][h], x);
-                    acc[r][h] = fmaf(sc, dq, fmaf(of, xs, acc[r][h]));
-                }
-        };
-        if (CPLT != 0) {
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                const bool last = j + 1 == CPL;
-                load_item(last ? b + total_waves : b, last ? 0 : j + 1, nxt);
-                const uint32_t c = sl + lpr * j;
-                if (c < C) compute(cur, c, xf[j], xsm[j]);
-                cur = nxt;
+            for (int h = 0; h < NPHYS; ++h) {
+                const float sc = bf16_to_f32(it.s[r][h]);
+                float of;
+                if (KIND == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(it.o[r][h]);
+                else if (KIND == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                    const uint32_t zpv = BITS == 4 ? ((grp & 1) ? (it.o[r][h] >> 4) : (it.o[r][h] & 0x0F)) : it.o[r][h];
+                    of = -sc * (float)zpv;
+                } else of = -sc * (float)(1u << (BITS - 1));
+                const float dq = dot32(it.w[r][h], x);
+                acc[r][h] = fmaf(sc, dq, fmaf(of, xs, acc[r][h]));
+                // one row at a time: without the fence the scheduler interleaves the R dot products and keeps
+                // R x 32 converted codes live (350+ VGPRs at R = 4 => one wave per SIMD)
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            for (uint32_t j = 0; j < steps_per_lane; ++j) {
-                const bool last = j + 1 == steps_per_lane;
-                load_item(last ? b + total_waves : b, last ? 0 : j + 1, nxt);
-                const uint32_t c = sl + lpr * j;
-                if (c < C) {
-                    float x[32];
-                    load32_bf16(p.x + (size_t)c * 32, x);
-                    compute(cur, c, x, sum32(x));
-                }
-                cur = nxt;
-            }
-        }
+    };
+    auto finish = [&](uint32_t b, float (&acc)[R][NPHYS]) {
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
         const uint32_t nl = mat ? p.n[1] : n_log0;
@@ -263,7 +242,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             const float v0 = row_sum_rt(acc[r][0], lpr);
             const float v1 = ACT ? row_sum_rt(acc[r][NPHYS - 1], lpr) : 0.f;
             const uint32_t lrow = lb * rows_per_batch + r * rpw + rsub;
-            if (sl == 0 && lrow < nl && !((p.debug & 4) && v0 != 123.f)) {
+            if (sl == 0 && lrow < nl) {
                 // MatmulKernel epilogue with ab_scale = 1, no accumulate / soft-cap (kernel.rs:281-292)
                 float value = 1.0f * v0;
                 if (p.out_bias[mat]) value += bf16_to_f32(p.out_bias[mat][lrow]);
@@ -283,6 +262,62 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     }
                 }
             }
+        }
+    };
+    // one batch whose first item sits in `first`; on return the first item of batch b + total_waves sits in
+    // `first` (even number of steps) or in `second` (odd number of steps)
+    auto batch = [&](uint32_t b, Item& first, Item& second) {
+        float acc[R][NPHYS];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int h = 0; h < NPHYS; ++h) acc[r][h] = 0.f;
+        if (CPLT != 0) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                Item& cur = (j & 1) ? second : first;
+                Item& nxt = (j & 1) ? first : second;
+                if (j + 1 < CPL) load_item(b, j + 1, nxt);
+                else load_item(b + total_waves, 0, nxt);
+                const uint32_t c = sl + lpr * j;
+                if (c < C) compute(cur, c, xf[j], xsm[j], acc);
+            }
+        } else {
+            for (uint32_t j = 0; j < steps_per_lane; j += 2) {
+                {
+                    const bool last = j + 1 == steps_per_lane;
+                    load_item(last ? b + total_waves : b, last ? 0 : j + 1, second);
+                    const uint32_t c = sl + lpr * j;
+                    if (c < C) {
+                        float x[32];
+                        load32_bf16(p.x + (size_t)c * 32, x);
+                        compute(first, c, x, sum32(x), acc);
+                    }
+                    if (last) { // odd step count: hand the prefetched item over (one copy per batch)
+                        first = second;
+                        break;
+                    }
+                }
+                {
+                    const bool last = j + 2 == steps_per_lane;
+                    load_item(last ? b + total_waves : b, last ? 0 : j + 2, first);
+                    const uint32_t c = sl + lpr * (j + 1);
+                    if (c < C) {
+                        float x[32];
+                        load32_bf16(p.x + (size_t)c * 32, x);
+                        compute(second, c, x, sum32(x), acc);
+                    }
+                }
+            }
+        }
+        finish(b, acc);
+    };
+    if (CPLT == 0 || (CPL & 1) == 0) {
+        for (uint32_t b = b0; b < num_batches; b += total_waves) batch(b, itA, itB);
+    } else {
+        for (uint32_t b = b0; b < num_batches; b += 2 * total_waves) {
+            batch(b, itA, itB);
+            if (b + total_waves < num_batches) batch(b + total_waves, itB, itA);
         }
     }
     if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
@@ -304,56 +339,85 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     }
 }
 
-uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2_out, int* R_out) {
+// Launch geometry.  Two regimes (tools/kbench.cpp sweeps):
+//   * small matrices (a few MB, latency-bound): as many waves as there are row batches, R chosen so that every
+//     SIMD of the chip gets a wave;
+//   * big matrices (>= 16 MB, bandwidth-bound): a PERSISTENT grid of exactly the resident workgroups
+//     (occupancy x CUs, from the instance's register count) so that the prologue is paid once per resident
+//     workgroup, and R = 1 (R = 2 for the 2-step register path): more waves beat more rows per wave.
+static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2_out, int* R_out) {
     const int lpr_log2 = gemv_lpr_log2(p.k);
     const int rpw = 64 >> lpr_log2;
     const uint32_t n_log0 = p.act_mul ? p.n[0] / 2 : p.n[0];
-    static int force_r = -1, tw = -1, capw = -1;
+    static int force_r = -1, tw = -1;
     if (force_r < 0) {
         const char* e = getenv("UZU_DEC_R");
         force_r = e ? atoi(e) : 0;
         const char* t = getenv("UZU_DEC_TW");
         tw = t ? atoi(t) : 8;
-        const char* c = getenv("UZU_DEC_CAP");
-        capw = c ? atoi(c) : 6;
     }
-    int R = p.act_mul ? 2 : 4;
-    const uint32_t target_waves = (uint32_t)num_cus * tw;
+    const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
+    const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
+    int R;
     auto nb = [&](int rr) { return (n_log0 + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw) + (p.n[1] + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw); };
-    while (R > 1 && nb(R) < target_waves) R >>= 1;
-    if (force_r > 0) R = p.act_mul && force_r > 2 ? 2 : force_r;
-    {
-        const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
+    if (weight_bytes >= (16u << 20)) {
+        R = (cpl == 2 && !p.act_mul) ? 2 : 1;
+    } else {
+        R = p.act_mul ? 2 : 4;
+        const uint32_t target_waves = (uint32_t)num_cus * tw;
+        while (R > 1 && nb(R) < target_waves) R >>= 1;
         if (cpl > 2 && R > 2 && (p.norm_scales || p.norm_plain)) R = 2; // the 4-step register path is instantiated for R <= 2
     }
-    uint32_t grid = (nb(R) + 3) / 4;
-    const uint32_t cap = (uint32_t)num_cus * capw; // persistent beyond that many workgroups per CU
-    if (grid > cap) grid = cap;
+    if (force_r > 0) R = p.act_mul && force_r > 2 ? 2 : force_r;
     *lpr_log2_out = lpr_log2;
     *R_out = R;
-    return grid;
+    return (nb(R) + 3) / 4;
 }
 
-template <int BITS, int CPLT, bool ACT>
-static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t grid, int lpr_log2, int R) {
+template <int BITS, int CPLT, bool ACT, int KIND>
+static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
     const size_t lds = (p.norm_scales || p.norm_plain) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
-#define UZU_LAUNCH(RR) return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec")
+    static const int cap_override = [] {
+        const char* c = getenv("UZU_DEC_CAP");
+        return c ? atoi(c) : 0;
+    }();
+#define UZU_LAUNCH(RR)                                                                                                              \
+    do {                                                                                                                            \
+        static int occ = 0; /* resident workgroups per CU of this instance (LDS use only lowers it for K > 8192: ignored) */        \
+        if (!occ) {                                                                                                                 \
+            int n = 0;                                                                                                              \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND>, 256, lds) != hipSuccess || n < 1) n = 2; \
+            occ = n > 8 ? 8 : n;                                                                                                    \
+        }                                                                                                                           \
+        const uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                 \
+        const uint32_t grid = want > cap ? cap : want;                                                                              \
+        if (grid_out) *grid_out = grid;                                                                                             \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
+    } while (0)
     if (!ACT && R == 4) UZU_LAUNCH(ACT ? 2 : 4);
     if (R >= 2) UZU_LAUNCH(2);
     UZU_LAUNCH(1);
 #undef UZU_LAUNCH
 }
+template <int BITS, int CPLT, bool ACT>
+static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+    switch (p.b_kind) {
+    case UZU_MATMUL_B_SCALE_BIAS: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_BIAS>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    case UZU_MATMUL_B_SCALE_ZERO_POINT: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_ZERO_POINT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    default: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_SYMMETRIC>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    }
+}
 template <int BITS, bool ACT>
-static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uint32_t grid, int lpr_log2, int R) {
+static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
-    if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, grid, lpr_log2, R);
-    if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, grid, lpr_log2, R);
-    if (cpl <= 4 && (p.norm_scales || p.norm_plain)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, grid, lpr_log2, R);
+    if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if (cpl <= 4 && (p.norm_scales || p.norm_plain)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
     if (p.norm_scales || p.norm_plain) {
         set_error("gemv_dec: Normalization prologue supports K <= 8192, K %% 1024 == 0 (got %u)", p.k);
         return UZU_ERR_UNSUPPORTED;
     }
-    return launch_gemv_dec_r<BITS, 0, ACT>(s, p, grid, lpr_log2, R);
+    return launch_gemv_dec_r<BITS, 0, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
 }
 
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out) {
@@ -361,15 +425,19 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t
         set_error("gemv_dec: unsupported shape (bits %u, k %u, group %u)", p.bits, p.k, p.group_size);
         return UZU_ERR_UNSUPPORTED;
     }
+    for (int i = 0; i < 2; ++i)
+        if ((uint64_t)p.n[i] * p.k * p.bits / 8 >= (1ull << 32)) { // per-lane byte offsets are 32-bit
+            set_error("gemv_dec: weight matrix of %u x %u exceeds 4 GiB", p.n[i], p.k);
+            return UZU_ERR_UNSUPPORTED;
+        }
     int lpr_log2, R;
-    uint32_t grid = gemv_dec_grid(p, num_cus, &lpr_log2, &R);
-    if (grid_out) *grid_out = grid;
+    const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R);
     if (p.act_mul) {
-        if (p.bits == 4) return launch_gemv_dec_cpl<4, true>(s, p, grid, lpr_log2, R);
-        return launch_gemv_dec_cpl<8, true>(s, p, grid, lpr_log2, R);
+        if (p.bits == 4) return launch_gemv_dec_cpl<4, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+        return launch_gemv_dec_cpl<8, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
     }
-    if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, grid, lpr_log2, R);
-    return launch_gemv_dec_cpl<8, false>(s, p, grid, lpr_log2, R);
+    if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    return launch_gemv_dec_cpl<8, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
 }
 
 // ---------------------------------------------------------------------------------------------- argmax_commit

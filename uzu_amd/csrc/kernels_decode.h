@@ -40,7 +40,6 @@ struct DecGemvParams {
     float* part_val;              // arg-max partials, one per workgroup
     uint32_t* part_idx;
     float* out_f32;               // tensor parallel: matrix 0 writes f32 partial sums here instead of bf16 into out[0]
-    uint32_t debug;               // microbenchmark ablations (tools/kbench): 1 = skip row loop, 2 = skip prologue
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
