@@ -92,12 +92,25 @@ int main(int argc, char** argv) {
     {   // delta_dec, Qwen3.5-0.8B shape
         const int NBUF = NBUF0;
         const uint32_t Hv = 16, Dk = 128, Dv = 128, key_dim = 2048, value_dim = 2048, conv_dim = 6144, total = conv_dim + value_dim + 32;
-        uint16_t* in_proj = dalloc<uint16_t>(total, 0x3c); float* cw = dalloc<float>(conv_dim * 4, 0); float* cs = dalloc<float>(conv_dim * 3, 0);
-        float* al = dalloc<float>(Hv, 0); float* dt = dalloc<float>(Hv, 0); float* nw = dalloc<float>(Dv, 0); uint16_t* out = dalloc<uint16_t>(value_dim);
+        uint16_t* in_proj = dalloc<uint16_t>(total, 0x3c);
+        float* al = dalloc<float>(Hv, 0); float* dt = dalloc<float>(Hv, 0); float* o = dalloc<float>(value_dim); float* sz = dalloc<float>(value_dim);
         std::vector<float*> st(NBUF); for (auto& p : st) p = dalloc<float>((size_t)Hv * Dv * Dk, 0);
         time_graph("delta_dec 16x128x128", (size_t)2 * Hv * Dv * Dk * 4, reps, [&](int i) {
-            DeltaDecParams p{}; p.in_proj = in_proj, p.conv_w = cw, p.conv_state = cs, p.a_log = al, p.dt_bias = dt, p.norm_weight = nw, p.state = st[i % NBUF], p.out = out;
-            p.num_v_heads = Hv, p.num_k_heads = 16, p.head_v_dim = Dv, p.key_dim = key_dim, p.value_dim = value_dim, p.kernel_size = 4, p.norm_epsilon = 1e-6f; return delta_dec(s, p); });
+            DeltaDecParams p{}; p.in_proj = in_proj, p.a_log = al, p.dt_bias = dt, p.state = st[i % NBUF], p.o = o, p.sz = sz;
+            p.num_v_heads = Hv, p.num_k_heads = 16, p.head_v_dim = Dv, p.key_dim = key_dim, p.value_dim = value_dim; return delta_dec(s, p); });
+        // in-proj with the conv epilogue and out-proj with the norm-gate prologue
+        const uint32_t g = 128;
+        uint8_t* w = dalloc<uint8_t>((size_t)8224 * 1024 / 2, 0x53); uint16_t* sc = dalloc<uint16_t>((size_t)8224 * 8, 0x3c); uint16_t* bi = dalloc<uint16_t>((size_t)8224 * 8, 0x3c);
+        uint16_t* x = dalloc<uint16_t>(2048, 0x3f); uint16_t* sh = dalloc<uint16_t>(1024, 0x3f); uint16_t* sho = dalloc<uint16_t>(1024); float* ns = dalloc<float>(1024, 0);
+        float* cw = dalloc<float>(conv_dim * 4, 0); float* cs = dalloc<float>(conv_dim * 3, 0); uint16_t* out = dalloc<uint16_t>(8224);
+        time_graph("gemv_dec in_proj +norm +conv", (size_t)8224 * 1024 / 2, reps, [&](int) {
+            DecGemvParams p{}; p.w[0] = w, p.scales[0] = sc, p.biases[0] = bi, p.out[0] = out, p.n[0] = 8224; p.k = 1024, p.bits = 4, p.group_size = g, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.x = x;
+            p.norm_scales = ns, p.norm_eps = 1e-6f, p.norm_offset = 1.f, p.norm_full_layer = 1, p.residual_add = 1, p.shortcut_in = sh, p.shortcut_out = sho;
+            p.conv_w = cw, p.conv_state = cs, p.conv_dim = conv_dim, p.conv_ks = 4; return gemv_dec(s, p, cus, nullptr); });
+        float* nw = dalloc<float>(Dv, 0);
+        time_graph("gemv_dec out_proj +norm-gate", (size_t)1024 * 2048 / 2, reps, [&](int) {
+            DecGemvParams p{}; p.w[0] = w, p.scales[0] = sc, p.biases[0] = bi, p.out[0] = out, p.n[0] = 1024; p.k = 2048, p.bits = 4, p.group_size = g, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.x = x;
+            p.dg_o = o, p.dg_sz = sz, p.dg_w = nw, p.dg_dv = Dv, p.dg_eps = 1e-6f; return gemv_dec(s, p, cus, nullptr); });
     }
     {   // attn_dec + merge, Qwen3.5-0.8B shape at ctx 2048
         const int NBUF = NBUF0;

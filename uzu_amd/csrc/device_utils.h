@@ -44,6 +44,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float group_sum_rt(float v, int width) { return k::row_sum_rt(v, width); }
 
+// DeltaNet norm-gate, canonical sum of squares over a head's Dv outputs (shared by the stand-alone update kernel and
+// the fused out-proj prologue so that both give the same bits): chunk sums of 8 consecutive elements (sequential
+// fma), then the xor butterfly over the Dv / 8 chunks.
+__device__ __forceinline__ float chunk8_sumsq(const float* v) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
+    return s;
+}
+
 // workgroup sum (blockDim.x multiple of 64, <= 1024); `red` = 16 floats of LDS; result broadcast
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

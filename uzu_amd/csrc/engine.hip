@@ -93,6 +93,7 @@ struct uzu_hip_model {
     bool fusable = false;
     uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
     float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
+    float *dn_o = nullptr, *dn_sz = nullptr; // raw DeltaNet outputs and SiLU(z) of the decode token (f32 [value_dim])
     uint32_t dec_splits = 0;
     float* amax_val = nullptr;
     uint32_t* amax_idx = nullptr;
@@ -493,7 +494,11 @@ bool model_fusable(const uzu_hip_model* m) {
             if ((L.qn.present && (L.qn.subtract_mean || L.qn.biases)) || (L.kn.present && (L.kn.subtract_mean || L.kn.biases))) return false;
         } else {
             if (!linear_fusable(L.in_proj) || !linear_fusable(L.out_proj)) return false;
-            if (L.d.dn_head_dim != 128 || L.d.dn_value_head_dim > 512 || L.d.dn_kernel_size > 9) return false;
+            if (L.d.dn_head_dim != 128 || L.d.dn_value_head_dim > 512 || L.d.dn_kernel_size != 4) return false; // conv epilogue of the in-proj GEMV
+            {   // norm-gate prologue of the out-proj GEMV (k_decode.hip): chunks of 8 outputs, <= 4 chunks per thread
+                const uint32_t dv = L.d.dn_value_head_dim, kk = L.d.dn_num_heads * dv, nchunks = kk / 8, per = nchunks > 256 ? nchunks / 256 : 1;
+                if (dv < 8 || (dv & (dv - 1)) || kk > 8192 || (nchunks > 256 && (nchunks % 256 || per > 4)) || (dv / 8) % per) return false;
+            }
         }
     }
     return true;
@@ -540,14 +545,17 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
             const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
             k::DecGemvParams p = dec_gemv_base(L.in_proj, hidden, m->in_proj);
             next_norm(p, L.pre_mixer, l > 0 ? 2 : 1);
-            dec_gemv(e, p, "gemv_dec[norm+in_proj]");
+            // DeltaNetConvUpdate rides in the in-proj epilogue: the lane that finishes a conv channel's row convolves it
+            p.conv_w = L.conv_w, p.conv_b = L.conv_b, p.conv_state = L.conv_state, p.conv_dim = 2 * Hk * Dk + Hv * Dv, p.conv_ks = L.d.dn_kernel_size;
+            dec_gemv(e, p, "gemv_dec[norm+in_proj+conv]");
             k::DeltaDecParams q{};
-            q.in_proj = m->in_proj, q.conv_w = L.conv_w, q.conv_b = L.conv_b, q.conv_state = L.conv_state, q.a_log = L.a_log, q.dt_bias = L.dt_bias;
-            q.norm_weight = L.dn_norm, q.state = L.ssm_state, q.out = m->delta_out;
-            q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv, q.kernel_size = L.d.dn_kernel_size;
-            q.norm_epsilon = L.d.dn_norm_epsilon;
+            q.in_proj = m->in_proj, q.a_log = L.a_log, q.dt_bias = L.dt_bias, q.state = L.ssm_state, q.o = m->dn_o, q.sz = m->dn_sz;
+            q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv;
             RUN("delta_dec", (size_t)2 * Hv * Dv * Dk * 4, k::delta_dec(s, q));
-            dec_gemv_row_parallel(e, dec_gemv_base(L.out_proj, m->delta_out, m->mixed), "gemv_dec[out_proj]");
+            // ... and the RMSNorm * SiLU(z) gate in the out-proj prologue (it needs all Dv outputs of a head)
+            k::DecGemvParams op = dec_gemv_base(L.out_proj, m->delta_out, m->mixed);
+            op.dg_o = m->dn_o, op.dg_sz = m->dn_sz, op.dg_w = L.dn_norm, op.dg_dv = Dv, op.dg_eps = L.d.dn_norm_epsilon;
+            dec_gemv_row_parallel(e, op, "gemv_dec[gate+out_proj]");
         }
         k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
         next_norm(up, L.pre_mlp, 2);
@@ -752,6 +760,8 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     if (max_proj) {
         ALLOC(in_proj, uint16_t, C * max_proj);
         ALLOC(delta_out, uint16_t, C * max_value);
+        ALLOC(dn_o, float, max_value);
+        ALLOC(dn_sz, float, max_value);
         ALLOC(padded, float, (C + 8) * max_proj);
         ALLOC(qn, float, C * max_key);
         ALLOC(kn, float, C * max_key);

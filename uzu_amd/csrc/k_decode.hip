@@ -53,7 +53,7 @@ __device__ __forceinline__ float act_bf16(uint32_t act, float x) { // activation
 //     next batch is prefetched while the current one is computed (tools/microbench2: a kernel boundary costs
 //     1.6 us, a dependent HBM round trip 0.3-0.5 us: the kernel should pay exactly one of the latter);
 //   * epilogues: plain store | SiLU(gate)*up | arg-max partial per workgroup.
-template <int BITS, int CPLT, int R, bool ACT, int KIND>
+template <int BITS, int CPLT, int R, bool ACT, int KIND, bool CONV>
 __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_log2) {
     using Codes = typename CodesT<BITS>::type;
     constexpr int STEP_BYTES = 4 * BITS;
@@ -118,7 +118,64 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     float xsm[CPL];
     if (CPLT != 0) {
         const bool normed = p.norm_scales || p.norm_plain;
-        if (!normed) { // plain activation row: every lane fetches its own steps
+        if (p.dg_o) {
+            // DeltaNet norm-gate (tail of update.rs:30-143) as the out-proj prologue: thread t owns `per` chunks of 8
+            // consecutive outputs; sum of squares per head in chunk8_sumsq order; x = bf16(o * inv_rms * w * SiLU(z)).
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            float* xs = smem;
+            const uint32_t nchunks = K / 8, per = nchunks > 256 ? nchunks / 256 : 1;
+            const uint32_t dv = p.dg_dv, lanes_per_head = (dv / 8) / per;
+            float ov[4][8], zv[4][8];
+            float local = 0.f;
+            const bool active = (uint32_t)tid * per < nchunks;
+            if (active) {
+                float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (q >= per) break;
+                    const uint32_t e0 = ((uint32_t)tid * per + q) * 8;
+                    const float4 a0 = *(const float4*)(p.dg_o + e0), a1 = *(const float4*)(p.dg_o + e0 + 4);
+                    const float4 z0 = *(const float4*)(p.dg_sz + e0), z1 = *(const float4*)(p.dg_sz + e0 + 4);
+                    ov[q][0] = a0.x, ov[q][1] = a0.y, ov[q][2] = a0.z, ov[q][3] = a0.w, ov[q][4] = a1.x, ov[q][5] = a1.y, ov[q][6] = a1.z, ov[q][7] = a1.w;
+                    zv[q][0] = z0.x, zv[q][1] = z0.y, zv[q][2] = z0.z, zv[q][3] = z0.w, zv[q][4] = z1.x, zv[q][5] = z1.y, zv[q][6] = z1.z, zv[q][7] = z1.w;
+                    cs[q] = chunk8_sumsq(ov[q]);
+                }
+                local = per == 1 ? cs[0] : per == 2 ? cs[0] + cs[1] : (cs[0] + cs[1]) + (cs[2] + cs[3]);
+            }
+            const float sumsq = row_sum_rt(local, (int)lanes_per_head); // lanes of one head are consecutive and aligned
+            const float inv_rms = 1.0f / sqrtf(sumsq / (float)dv + p.dg_eps);
+            if (active) {
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (q >= per) break;
+                    const uint32_t e0 = ((uint32_t)tid * per + q) * 8;
+                    const float4 w0 = *(const float4*)(p.dg_w + e0 % dv), w1 = *(const float4*)(p.dg_w + e0 % dv + 4);
+                    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = round_bf16(ov[q][i] * inv_rms * wv[i] * zv[q][i]);
+                    float* slot = xs + (size_t)(e0 / 32) * 36 + e0 % 32;
+                    *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(slot + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const uint32_t c = sl + lpr * j;
+                if (c < C) {
+                    const float4* xv = (const float4*)(xs + (size_t)c * 36);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 t = xv[i];
+                        xf[j][4 * i] = t.x, xf[j][4 * i + 1] = t.y, xf[j][4 * i + 2] = t.z, xf[j][4 * i + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                }
+            }
+        } else if (!normed) { // plain activation row: every lane fetches its own steps
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
@@ -233,7 +290,27 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-    auto finish = [&](uint32_t b, float (&acc)[R][NPHYS]) {
+    struct ConvPre { // taps / weights of the conv channels this lane finishes (kernel size 4: the common case)
+        float tap[3];
+        float4 w;
+        float bias;
+    };
+    constexpr bool conv_fast = CONV; // launch selects CONV only for kernel size 4 (the prefetching form)
+    auto conv_prefetch = [&](uint32_t b, ConvPre (&cp)[CONV ? R : 1]) { // issued at batch start: lands while the rows are computed
+        if (sl != 0 || b >= batches0) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t lrow = b * rows_per_batch + r * rpw + rsub;
+            if (lrow < p.conv_dim && lrow < n_log0) {
+                ConvPre& c4 = cp[CONV ? r : 0];
+                const float* st_row = p.conv_state + (size_t)lrow * 3;
+                c4.tap[0] = st_row[0], c4.tap[1] = st_row[1], c4.tap[2] = st_row[2];
+                c4.w = *(const float4*)(p.conv_w + (size_t)lrow * 4);
+                c4.bias = p.conv_b ? p.conv_b[lrow] : 0.0f;
+            }
+        }
+    };
+    auto finish = [&](uint32_t b, float (&acc)[R][NPHYS], const ConvPre (&cp)[CONV ? R : 1]) {
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
         const uint32_t nl = mat ? p.n[1] : n_log0;
@@ -252,6 +329,18 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     const float up_b = round_bf16(value), gate_b = round_bf16(gate);
                     // GatedActMul (gated_act_mul/mod.rs:5-12): (up * act(gate)) in bf16
                     p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b)));
+                } else if (CONV && mat == 0 && lrow < p.conv_dim) {
+                    // DeltaNetConvUpdate (conv_update.rs:17-55), kernel size 4, operands prefetched at batch start
+                    float* st_row = p.conv_state + (size_t)lrow * 3;
+                    const float xin = round_bf16(value);
+                    const ConvPre& c4 = cp[CONV ? r : 0];
+                    float cacc = c4.bias;
+                    cacc += c4.tap[0] * c4.w.x;
+                    cacc += c4.tap[1] * c4.w.y;
+                    cacc += c4.tap[2] * c4.w.z;
+                    cacc += xin * c4.w.w;
+                    p.out[0][lrow] = f32_to_bf16(silu_f32(cacc));
+                    st_row[0] = c4.tap[1], st_row[1] = c4.tap[2], st_row[2] = xin;
                 } else {
                     const uint16_t ob = f32_to_bf16(value);
                     if (p.out_f32) p.out_f32[lrow] = value;
@@ -272,6 +361,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int h = 0; h < NPHYS; ++h) acc[r][h] = 0.f;
+        ConvPre cp[CONV ? R : 1];
+        if (CONV) conv_prefetch(b, cp);
         if (CPLT != 0) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -310,7 +401,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 }
             }
         }
-        finish(b, acc);
+        finish(b, acc, cp);
     };
     if (CPLT == 0 || (CPL & 1) == 0) {
         for (uint32_t b = b0; b < num_batches; b += total_waves) batch(b, itA, itB);
@@ -374,9 +465,9 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     return (nb(R) + 3) / 4;
 }
 
-template <int BITS, int CPLT, bool ACT, int KIND>
-static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
-    const size_t lds = (p.norm_scales || p.norm_plain) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
+template <int BITS, int CPLT, bool ACT, int KIND, bool CONV>
+static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+    const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
     static const int cap_override = [] {
         const char* c = getenv("UZU_DEC_CAP");
         return c ? atoi(c) : 0;
@@ -386,18 +477,29 @@ static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint3
         static int occ = 0; /* resident workgroups per CU of this instance (LDS use only lowers it for K > 8192: ignored) */        \
         if (!occ) {                                                                                                                 \
             int n = 0;                                                                                                              \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND>, 256, lds) != hipSuccess || n < 1) n = 2; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, CONV>, 256, lds) != hipSuccess || n < 1) n = 2; \
             occ = n > 8 ? 8 : n;                                                                                                    \
         }                                                                                                                           \
         const uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                 \
         const uint32_t grid = want > cap ? cap : want;                                                                              \
         if (grid_out) *grid_out = grid;                                                                                             \
-        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, CONV>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
     } while (0)
-    if (!ACT && R == 4) UZU_LAUNCH(ACT ? 2 : 4);
+    if (!ACT && !CONV && R == 4) UZU_LAUNCH((ACT || CONV) ? 2 : 4);
     if (R >= 2) UZU_LAUNCH(2);
     UZU_LAUNCH(1);
 #undef UZU_LAUNCH
+}
+template <int BITS, int CPLT, bool ACT, int KIND>
+static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+    if (!ACT && p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
+        if (R > 2) {
+            want *= (uint32_t)(R / 2);
+            R = 2;
+        }
+        return launch_gemv_dec_c<BITS, CPLT, false, KIND, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    }
+    return launch_gemv_dec_c<BITS, CPLT, ACT, KIND, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
 }
 template <int BITS, int CPLT, bool ACT>
 static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
@@ -412,9 +514,9 @@ static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uin
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
     if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
     if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    if (cpl <= 4 && (p.norm_scales || p.norm_plain)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    if (p.norm_scales || p.norm_plain) {
-        set_error("gemv_dec: Normalization prologue supports K <= 8192, K %% 1024 == 0 (got %u)", p.k);
+    if (cpl <= 4 && (p.norm_scales || p.norm_plain || p.dg_o)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if (p.norm_scales || p.norm_plain || p.dg_o) {
+        set_error("gemv_dec: Normalization / norm-gate prologue supports K <= 8192, K %% 1024 == 0 (got %u)", p.k);
         return UZU_ERR_UNSUPPORTED;
     }
     return launch_gemv_dec_r<BITS, 0, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
@@ -423,6 +525,19 @@ static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uin
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out) {
     if ((p.bits != 4 && p.bits != 8) || p.k % 32 || p.group_size % 32 || (p.group_size & (p.group_size - 1)) || ((p.norm_scales || p.norm_plain) && p.k % 1024)) {
         set_error("gemv_dec: unsupported shape (bits %u, k %u, group %u)", p.bits, p.k, p.group_size);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    if (p.dg_o) {
+        const uint32_t nchunks = p.k / 8, per = nchunks > 256 ? nchunks / 256 : 1, dv = p.dg_dv;
+        const bool ok = p.k % 8 == 0 && dv >= 8 && (dv & (dv - 1)) == 0 && dv <= 512 && p.k % dv == 0 && (nchunks <= 256 || (nchunks % 256 == 0 && per <= 4)) &&
+                        (dv / 8) % per == 0 && !p.norm_scales && !p.norm_plain && !p.act_mul;
+        if (!ok) {
+            set_error("gemv_dec: unsupported norm-gate prologue (k %u, dv %u)", p.k, dv);
+            return UZU_ERR_UNSUPPORTED;
+        }
+    }
+    if (p.conv_w && (p.conv_ks != 4 || p.act_mul || p.out_f32)) {
+        set_error("gemv_dec: the conv epilogue is instantiated for kernel size 4 (got %u)", p.conv_ks);
         return UZU_ERR_UNSUPPORTED;
     }
     for (int i = 0; i < 2; ++i)
@@ -478,62 +593,39 @@ uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uin
 }
 
 // ---------------------------------------------------------------------------------------------- delta_dec
-// DeltaNetConvUpdate (conv_update.rs:17-55) + DeltaNetUpdate (update.rs:30-143) for one token.
-// One workgroup (1024 threads) per value head; half a wave owns one state row per pass.
-__global__ void __launch_bounds__(1024) delta_dec_kernel(DeltaDecParams p) {
+// DeltaNetUpdate (update.rs:30-143) for one token, spread over the whole chip: grid (value head, Dv / 8), 256
+// threads, one state row (Dk = 128 f32) per half-wave.  The conv + SiLU already ran in the in-proj epilogue, the
+// RMSNorm * SiLU(z) gate runs in the out-proj prologue (it needs all Dv outputs of a head), so a workgroup only
+// streams its 8 state rows: one CU sustains ~25-50 GB/s, a 64 KB head on one CU was the bottleneck of the fused
+// single-workgroup version.  Every load is issued before the scalar math (sigmoid / softplus / exp, ~250
+// instructions) so that the math hides under the state-row latency.
+__global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
     constexpr int DK = 128;
-    __shared__ float s_q[DK], s_k[DK], s_v[512], s_o[512], s_red[16];
     const uint32_t hv = blockIdx.x;
     const uint32_t gph = p.num_v_heads / p.num_k_heads;
     const uint32_t hk = hv / gph;
     const uint32_t key_dim = p.key_dim, value_dim = p.value_dim, conv_dim = 2 * key_dim + value_dim;
-    const uint32_t Dv = p.head_v_dim, ks = p.kernel_size, tap_count = ks - 1;
+    const uint32_t Dv = p.head_v_dim;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sl = lane & 31, half = lane >> 5;
-    const uint32_t rows_per_pass = 32; // 16 waves x 2
+    const uint32_t i = blockIdx.y * 8 + wave * 2 + half; // state row = output index inside the head
+    const bool live = i < Dv;
+    const uint32_t row = live ? i : 0;
 
-    // state rows of the first passes are requested before anything else (they do not depend on the conv)
-    constexpr int MAXP = 4;
-    float4 pre[MAXP];
-#pragma unroll
-    for (int ps = 0; ps < MAXP; ++ps) {
-        const uint32_t i = ps * rows_per_pass + wave * 2 + half;
-        if (i < Dv) pre[ps] = *((const float4*)(p.state + ((size_t)hv * Dv + i) * DK) + sl);
-    }
-    // conv + SiLU for the channels this head consumes: q[hk], k[hk] (DK each), v[hv] (Dv)
-    for (uint32_t t = tid; t < 2 * DK + Dv; t += blockDim.x) {
-        uint32_t channel;
-        float* dst;
-        bool owner = true; // q/k channels are shared by the gph value heads of a key head: one writer
-        if (t < DK) channel = hk * DK + t, dst = &s_q[t], owner = (hv % gph) == 0;
-        else if (t < 2 * DK) channel = key_dim + hk * DK + (t - DK), dst = &s_k[t - DK], owner = (hv % gph) == 0;
-        else channel = 2 * key_dim + hv * Dv + (t - 2 * DK), dst = &s_v[t - 2 * DK];
-        float* st_row = p.conv_state + (size_t)channel * tap_count;
-        const float* w = p.conv_w + (size_t)channel * ks;
-        const float x = bf16_to_f32(p.in_proj[channel]);
-        float acc = p.conv_b ? p.conv_b[channel] : 0.0f;
-        float taps[8];
-#pragma unroll
-        for (uint32_t tap = 0; tap < 8; ++tap)
-            if (tap < tap_count) {
-                taps[tap] = st_row[tap];
-                acc += taps[tap] * w[tap];
-            }
-        acc += x * w[tap_count];
-        *dst = round_bf16(silu_f32(acc));
-        if (owner) {
-#pragma unroll
-            for (uint32_t tap = 1; tap < 8; ++tap)
-                if (tap < tap_count) st_row[tap - 1] = taps[tap];
-            st_row[tap_count - 1] = x;
-        }
-    }
-    __syncthreads();
-    float q[4], kk[4];
+    float4* srow = (float4*)(p.state + ((size_t)hv * Dv + row) * DK) + sl;
+    const float4 sv = *srow;
+    const uint2 qr = *(const uint2*)(p.in_proj + hk * DK + sl * 4);
+    const uint2 kr = *(const uint2*)(p.in_proj + key_dim + hk * DK + sl * 4);
+    const float v_i = bf16_to_f32(p.in_proj[2 * key_dim + hv * Dv + row]);
+    const float z_i = bf16_to_f32(p.in_proj[conv_dim + hv * Dv + row]);
+    const float beta_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + hv]);
+    const float a_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + p.num_v_heads + hv]);
+    const float dt_b = p.dt_bias[hv], a_l = p.a_log[hv];
+
+    float q[4] = {bits_to_f32(qr.x << 16), bits_to_f32(qr.x & 0xFFFF0000u), bits_to_f32(qr.y << 16), bits_to_f32(qr.y & 0xFFFF0000u)};
+    float kk[4] = {bits_to_f32(kr.x << 16), bits_to_f32(kr.x & 0xFFFF0000u), bits_to_f32(kr.y << 16), bits_to_f32(kr.y & 0xFFFF0000u)};
     float q_sq = 0.f, k_sq = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        q[e] = s_q[sl * 4 + e];
-        kk[e] = s_k[sl * 4 + e];
         q_sq += q[e] * q[e];
         k_sq += kk[e] * kk[e];
     }
@@ -550,63 +642,44 @@ __global__ void __launch_bounds__(1024) delta_dec_kernel(DeltaDecParams p) {
         kq += kk[e] * q[e];
     }
     const float kq_dot = group_sum<32>(kq);
-    const float beta_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + hv]);
     const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
-    const float a_raw = bf16_to_f32(p.in_proj[conv_dim + value_dim + p.num_v_heads + hv]);
-    const float sp_input = a_raw + p.dt_bias[hv];
+    const float sp_input = a_raw + dt_b;
     const float sp = sp_input > 20.0f ? sp_input : logf_glibc(1.0f + expf_glibc(sp_input));
-    const float g = -expf_glibc(p.a_log[hv]) * sp;
+    const float g = -expf_glibc(a_l) * sp;
     const float decay = expf_glibc(g);
+    const float sz_i = silu_f32(z_i);
 
-    for (uint32_t ps = 0; ps * rows_per_pass < Dv; ++ps) {
-        const uint32_t i = ps * rows_per_pass + wave * 2 + half;
-        if (i < Dv) {
-            float4* srow = (float4*)(p.state + ((size_t)hv * Dv + i) * DK) + sl;
-            float4 sv;
-            if (ps < MAXP) {
-                // static selection keeps `pre` in registers
-                sv = ps == 0 ? pre[0] : ps == 1 ? pre[1] : ps == 2 ? pre[2] : pre[3];
-            } else {
-                sv = *srow;
-            }
-            const float v_i = s_v[i];
-            const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
-            float sq = 0.f, sk = 0.f;
+    const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+    float sq = 0.f, sk = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sq = fmaf(s4[e], q[e], sq);
-                sk = fmaf(s4[e], kk[e], sk);
-            }
-            sq = group_sum<32>(sq);
-            sk = group_sum<32>(sk);
-            const float retrieved_i = decay * sk;
-            const float delta_i = beta * (v_i - retrieved_i);
-            const float o_i = decay * sq + delta_i * kq_dot;
-            float4 ns;
-            ns.x = decay * s4[0] + kk[0] * delta_i;
-            ns.y = decay * s4[1] + kk[1] * delta_i;
-            ns.z = decay * s4[2] + kk[2] * delta_i;
-            ns.w = decay * s4[3] + kk[3] * delta_i;
-            *srow = ns;
-            if (sl == 0) s_o[i] = o_i;
-        }
+    for (int e = 0; e < 4; ++e) {
+        sq = fmaf(s4[e], q[e], sq);
+        sk = fmaf(s4[e], kk[e], sk);
     }
-    __syncthreads();
-    float o_sq = 0.f;
-    for (uint32_t i = tid; i < Dv; i += blockDim.x) o_sq += s_o[i] * s_o[i];
-    const float sumsq = block_sum(o_sq, s_red);
-    const float inv_rms = 1.0f / sqrtf(sumsq / (float)Dv + p.norm_epsilon);
-    for (uint32_t i = tid; i < Dv; i += blockDim.x) {
-        const float z_i = bf16_to_f32(p.in_proj[conv_dim + hv * Dv + i]);
-        p.out[hv * Dv + i] = f32_to_bf16(s_o[i] * inv_rms * p.norm_weight[i] * silu_f32(z_i));
+    sq = group_sum<32>(sq);
+    sk = group_sum<32>(sk);
+    const float retrieved_i = decay * sk;
+    const float delta_i = beta * (v_i - retrieved_i);
+    const float o_i = decay * sq + delta_i * kq_dot;
+    if (live) {
+        float4 ns;
+        ns.x = decay * s4[0] + kk[0] * delta_i;
+        ns.y = decay * s4[1] + kk[1] * delta_i;
+        ns.z = decay * s4[2] + kk[2] * delta_i;
+        ns.w = decay * s4[3] + kk[3] * delta_i;
+        *srow = ns;
+        if (sl == 0) {
+            p.o[hv * Dv + i] = o_i;
+            p.sz[hv * Dv + i] = sz_i;
+        }
     }
 }
 uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p) {
-    if (p.head_v_dim > 512 || p.kernel_size > 9 || p.kernel_size < 2 || p.num_k_heads == 0 || p.num_v_heads % p.num_k_heads) {
+    if (p.head_v_dim > 512 || p.num_k_heads == 0 || p.num_v_heads % p.num_k_heads) {
         set_error("delta_dec: unsupported configuration");
         return UZU_ERR_UNSUPPORTED;
     }
-    return launch_check([&] { hipLaunchKernelGGL(delta_dec_kernel, dim3(p.num_v_heads), dim3(1024), 0, s, p); }, "delta_dec");
+    return launch_check([&] { hipLaunchKernelGGL(delta_dec_kernel, dim3(p.num_v_heads, (p.head_v_dim + 7) / 8), dim3(256), 0, s, p); }, "delta_dec");
 }
 
 // ---------------------------------------------------------------------------------------------- attn_dec
@@ -809,44 +882,63 @@ uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
     }
 }
 
-// AttentionTwoPass2 over S splits + SigmoidGate.  grid (heads, hd / 64): wave 0 of the workgroup derives the S
-// merge weights (wave max / wave sum), then 64 threads x 4 key-slices accumulate the partials with independent loads.
+// AttentionTwoPass2 over S splits + SigmoidGate.  grid (heads, hd / 16); thread = (element e of 16, key-slice of 16).
+// Every load (partials of the thread's splits, the S maxima / sums, the gate) is issued before anything is
+// consumed, so the kernel pays one memory round trip; wave 0 derives the S merge weights meanwhile.
 __global__ void __launch_bounds__(256) attn_merge_kernel(const float* partials, const float* sums, const float* maxs, const uint16_t* gate,
                                                          uint16_t* out, uint32_t HD, uint32_t S) {
     __shared__ float sw[256];
-    __shared__ float s_acc[4][64];
+    __shared__ float s_acc[16][16];
     __shared__ float s_gsum;
-    const uint32_t head = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    if (slice == 0) {
-        float m = -INFINITY;
-        for (uint32_t b = lane; b < S; b += 64) m = fmaxf(m, maxs[(size_t)head * S + b]);
-        const float gmax = wave_max(m);
+    const uint32_t head = blockIdx.x, e = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const uint32_t j = blockIdx.y * 16 + e;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = j < HD;
+    float pv[16];
+    const float* pp = partials + (size_t)head * S * HD + j;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t b = slice + 16 * t;
+        pv[t] = (live && b < S) ? pp[(size_t)b * HD] : 0.f;
+    }
+    const float g = (gate && live && slice == 0) ? bf16_to_f32(gate[(size_t)head * HD + j]) : 0.f;
+    if (wave == 0) {
+        float mv[4], sv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t b = lane + 64 * t;
+            mv[t] = b < S ? maxs[(size_t)head * S + b] : -INFINITY;
+            sv[t] = b < S ? sums[(size_t)head * S + b] : 0.f;
+        }
+        const float gmax = wave_max(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])));
         float part = 0.f;
-        for (uint32_t b = lane; b < S; b += 64) {
-            const float w = expf_glibc(maxs[(size_t)head * S + b] - gmax);
-            sw[b] = w;
-            part += sums[(size_t)head * S + b] * w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t b = lane + 64 * t;
+            if (b < S) {
+                const float w = fast_exp(mv[t] - gmax);
+                sw[b] = w;
+                part += sv[t] * w;
+            }
         }
         part = wave_sum(part);
         if (lane == 0) s_gsum = part;
     }
     __syncthreads();
     float val = 0.f;
-    if (j < HD) {
-        const float* pp = partials + (size_t)head * S * HD + j;
-#pragma unroll 4
-        for (uint32_t b = slice; b < S; b += 4) val = fmaf(pp[(size_t)b * HD], sw[b], val);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t b = slice + 16 * t;
+        if (b < S) val = fmaf(pv[t], sw[b], val);
     }
-    s_acc[slice][lane] = val;
+    s_acc[slice][e] = val;
     __syncthreads();
-    if (slice == 0 && j < HD) {
-        const float total = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    if (slice == 0 && live) {
+        float total = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) total += s_acc[q][e];
         float r = round_bf16(total / s_gsum);
-        if (gate) { // SigmoidGate (sigmoid_gate.rs:9-22)
-            const float g = bf16_to_f32(gate[(size_t)head * HD + j]);
-            r = round_bf16(r * (1.0f / (1.0f + expf_glibc(-g))));
-        }
+        if (gate) r = round_bf16(r * (1.0f / (1.0f + expf_glibc(-g)))); // SigmoidGate (sigmoid_gate.rs:9-22)
         out[(size_t)head * HD + j] = f32_to_bf16(r);
     }
 }
@@ -857,7 +949,7 @@ uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, c
         return UZU_ERR_UNSUPPORTED;
     }
     return launch_check([&] {
-        hipLaunchKernelGGL(attn_merge_kernel, dim3(num_heads, (head_dim + 63) / 64), dim3(256), 0, s, partials, sums, maxs, gate, out, head_dim, splits);
+        hipLaunchKernelGGL(attn_merge_kernel, dim3(num_heads, (head_dim + 15) / 16), dim3(256), 0, s, partials, sums, maxs, gate, out, head_dim, splits);
     }, "attn_merge");
 }
 

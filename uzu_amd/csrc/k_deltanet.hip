@@ -118,9 +118,14 @@ __global__ void __launch_bounds__(512) delta_net_update_kernel(const uint16_t* i
         }
     }
     __syncthreads();
-    float o_sq = 0.f;
-    for (uint32_t i = threadIdx.x; i < head_v_dim; i += blockDim.x) o_sq += s_o[i] * s_o[i];
-    const float sumsq = block_sum(o_sq, s_red);
+    if (wave == 0) { // chunk8_sumsq order (device_utils.h): lane t < Dv/8 owns chunk t, butterfly over the chunks
+        const uint32_t chunks = head_v_dim / 8;
+        const float c = (uint32_t)lane < chunks ? chunk8_sumsq(&s_o[8 * lane]) : 0.f;
+        const float total = group_sum_rt(c, (int)chunks);
+        if (lane == 0) s_red[0] = total;
+    }
+    __syncthreads();
+    const float sumsq = s_red[0];
     const float inv_rms = 1.0f / sqrtf(sumsq / (float)head_v_dim + norm_epsilon);
     for (uint32_t i = threadIdx.x; i < head_v_dim; i += blockDim.x) {
         const float z_i = bf16_to_f32(in_proj[conv_dim + hv * head_v_dim + i]);
@@ -132,8 +137,8 @@ uzu_status delta_net_update(hipStream_t s, const uint16_t* in_proj, const float*
                             const float* norm_weight, float* state, uint16_t* out, uint32_t num_v_heads,
                             uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
                             uint32_t value_dim, float norm_epsilon) {
-    if (head_k_dim != 128 || head_v_dim > 512 || num_k_heads == 0 || num_v_heads % num_k_heads) {
-        set_error("delta_net_update: needs head_k_dim == 128, head_v_dim <= 512, Hv %% Hk == 0");
+    if (head_k_dim != 128 || head_v_dim > 512 || head_v_dim < 8 || (head_v_dim & (head_v_dim - 1)) || num_k_heads == 0 || num_v_heads % num_k_heads) {
+        set_error("delta_net_update: needs head_k_dim == 128, head_v_dim a power of two in [8, 512], Hv %% Hk == 0");
         return UZU_ERR_UNSUPPORTED;
     }
     if (!num_v_heads) return UZU_OK;

@@ -40,6 +40,19 @@ struct DecGemvParams {
     float* part_val;              // arg-max partials, one per workgroup
     uint32_t* part_idx;
     float* out_f32;               // tensor parallel: matrix 0 writes f32 partial sums here instead of bf16 into out[0]
+    // DeltaNetConvUpdate epilogue (in-proj): rows < conv_dim of matrix 0 go through the causal conv + SiLU of their
+    // channel (one lane owns a channel: taps read, shifted and written by that lane only) -- conv_update.rs:17-55
+    const float* conv_w;          // [conv_dim, ks]
+    const float* conv_b;          // [conv_dim] or null
+    float* conv_state;            // [conv_dim, ks - 1]
+    uint32_t conv_dim, conv_ks;
+    // DeltaNet norm-gate prologue (out-proj): x[e] = bf16(o[e] * inv_rms(head) * w[e % dv] * sz[e]) from the f32
+    // outputs of delta_dec -- the tail of update.rs:30-143
+    const float* dg_o;            // [k] raw delta-rule outputs
+    const float* dg_sz;           // [k] SiLU(z)
+    const float* dg_w;            // [dv] norm weight
+    uint32_t dg_dv;
+    float dg_eps;
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
@@ -47,17 +60,13 @@ uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uin
                          uint32_t* out_token, uint32_t* sampled);
 
 struct DeltaDecParams {
-    const uint16_t* in_proj;
-    const float* conv_w;
-    const float* conv_b;
-    float* conv_state;
+    const uint16_t* in_proj;  // post-conv row: [q | k | v | z | beta | a] (the conv ran in the in-proj epilogue)
     const float* a_log;
     const float* dt_bias;
-    const float* norm_weight;
-    float* state;
-    uint16_t* out;
-    uint32_t num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, kernel_size;
-    float norm_epsilon;
+    float* state;             // [Hv, Dv, Dk] f32
+    float* o;                 // [Hv * Dv] f32 raw outputs (normalised + gated by the out-proj prologue)
+    float* sz;                // [Hv * Dv] f32 SiLU(z)
+    uint32_t num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim;
 };
 uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p);
 
