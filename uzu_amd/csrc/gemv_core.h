@@ -124,7 +124,7 @@ __device__ __forceinline__ void store32_bf16(uint16_t* p, const float (&x)[32]) 
     }
 }
 
-// v + v[lane ^ off] with compile-time patterns: DPP for 1/2/4/8, ds_swizzle for 16, DPP row_bcast + v_readlane for 32.
+// v + v[lane ^ off] with compile-time patterns: DPP for 1/2/4/8, DPP row_bcast + v_readlane for 16 and 32.
 // (hipcc lowers __shfl_xor to ds_bpermute_b32, ~100+ cycles of dependent latency per step.)  For a SUM the
 // mirror patterns are equivalent to the xor patterns once the lower levels have been reduced, and float
 // addition is commutative, so the result equals the plain xor butterfly bit for bit.
@@ -132,7 +132,16 @@ __device__ __forceinline__ float xadd1(float v) { return v + __builtin_bit_cast(
 __device__ __forceinline__ float xadd2(float v) { return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
 __device__ __forceinline__ float xadd4(float v) { return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); } // row_half_mirror
 __device__ __forceinline__ float xadd8(float v) { return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); } // row_mirror
-__device__ __forceinline__ float xadd16(float v) { return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)); }       // xor 16
+// level 16 (every row of 16 lanes already holds its row total): DPP row_bcast:15 hands a row's total to the next row,
+// so the odd rows hold row(2i) + row(2i+1); v_readlane of lanes 31 / 63 + a select by the wave half broadcast it
+// (same two operands as the xor-16 butterfly, no LDS round trip -- ds_swizzle costs ~100 cycles of dependent latency).
+__device__ __forceinline__ float xadd16(float v) {
+    const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    const float t = prev + v; // valid in rows 1 and 3
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+    return (__lane_id() & 32) ? hi : lo;
+}
 // level 32 (both halves already hold their 32-lane totals): DPP row_bcast:31 hands the lower total to the upper
 // half, v_readlane of lane 63 broadcasts lower + upper to the whole wave (same operands as the xor butterfly).
 __device__ __forceinline__ float xadd32(float v) {

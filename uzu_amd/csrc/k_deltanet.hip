@@ -268,7 +268,17 @@ uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const 
 }
 
 // ---------------------------------------------------------------- DeltaNetPrefill (prefill.rs:39-80)
-// Sequential scan over tokens with the state row held in registers: half a wave per (hv, dv) row.
+// Sequential scan over tokens with the state row held in registers: half a wave per (hv, dv) row, 8 rows of ONE value
+// head per workgroup (all 256 CUs busy at Hv * Dv = 2048 rows).  The recurrence makes every step depend on the
+// previous one, so the per-step cost must be the arithmetic chain (two 32-lane reductions), not memory latency:
+// the q / k rows, decay, beta and the 8 v values of TILE tokens are staged through double-buffered LDS, the loads
+// of tile n+1 are in flight while tile n is scanned, and the LDS reads of step t+1 are issued before step t's math.
+namespace {
+constexpr int DNP_TILE = 32;      // tokens per staged tile
+constexpr int DNP_ROWS = 8;       // state rows (one value head) per workgroup
+constexpr int DNP_QK = 2 * 128;   // floats of k and q per token
+constexpr int DNP_SLOT = DNP_QK + 2 + DNP_ROWS + 2; // + decay, beta, v[8], pad -> 268 floats (multiple of 4)
+}
 __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_norm, const float* k_norm,
                                                                 const float* beta_buf, const float* decay_buf,
                                                                 const uint16_t* in_proj, float* state, uint16_t* out,
@@ -276,37 +286,90 @@ __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_n
                                                                 uint32_t head_v_dim, uint32_t key_dim,
                                                                 uint32_t value_dim, uint32_t suffix_len) {
     constexpr int DK = 128;
-    const uint32_t row = ((blockIdx.x * blockDim.x + threadIdx.x) >> 5); // global (hv, dv) row index
-    const int sl = threadIdx.x & 31;
-    if (row >= num_v_heads * head_v_dim) return;
-    const uint32_t hv = row / head_v_dim, i = row % head_v_dim;
+    __shared__ __attribute__((aligned(16))) float s_tile[2][DNP_TILE * DNP_SLOT];
+    const int tid = threadIdx.x, sl = tid & 31, hw = tid >> 5; // hw = half-wave = row inside the workgroup
+    const uint32_t blocks_per_head = head_v_dim / DNP_ROWS;
+    const uint32_t hv = blockIdx.x / blocks_per_head, i = (blockIdx.x % blocks_per_head) * DNP_ROWS + hw;
     const uint32_t hk = hv / (num_v_heads / num_k_heads);
     const uint32_t conv_dim = 2 * key_dim + value_dim;
     const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    const uint32_t row = hv * head_v_dim + i;
     float4* srow = (float4*)(state + (size_t)row * DK) + sl;
     float4 sv = *srow;
     float s4[4] = {sv.x, sv.y, sv.z, sv.w};
-    for (uint32_t token = 0; token < suffix_len; ++token) {
-        const size_t qk_off = (size_t)token * key_dim + hk * DK + sl * 4;
-        const float4 k4 = *(const float4*)(k_norm + qk_off);
-        const float4 q4 = *(const float4*)(q_norm + qk_off);
-        const float kf[4] = {k4.x, k4.y, k4.z, k4.w}, qf[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float decay = decay_buf[(size_t)token * num_v_heads + hv];
-        const float beta = beta_buf[(size_t)token * num_v_heads + hv];
-        float kv_mem = 0.f;
+
+    // staging role: thread -> (token of the tile, 32-float slice of the k|q row); extras by the first threads
+    const int st_tok = tid >> 3, st_part = tid & 7; // 32 tokens x 8 slices of 32 floats (k: slices 0-3, q: 4-7)
+    float4 stage[8];
+    float stage_x = 0.f;
+    auto load_tile = [&](uint32_t t0) {
+        const uint32_t token = t0 + st_tok;
+        if (token < suffix_len) {
+            const float* src = (st_part < 4 ? k_norm : q_norm) + (size_t)token * key_dim + hk * DK + (st_part & 3) * 32;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) kv_mem = fmaf(decay * s4[e], kf[e], kv_mem);
-        kv_mem = group_sum<32>(kv_mem);
-        const float v_val = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + 2 * key_dim + hv * head_v_dim + i]);
-        const float delta = beta * (v_val - kv_mem);
-        float o_val = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s4[e] = decay * s4[e] + kf[e] * delta;
-            o_val = fmaf(s4[e], qf[e], o_val);
+            for (int v = 0; v < 8; ++v) stage[v] = ((const float4*)src)[v];
         }
-        o_val = group_sum<32>(o_val);
-        if (sl == 0) out[(size_t)token * value_dim + hv * head_v_dim + i] = f32_to_bf16(o_val);
+        // extras: thread e < 32*10 would be needed; 256 threads cover 32 tokens x 8 v values, decay / beta by slices 0 / 1
+        const uint32_t xt = t0 + (tid >> 3);
+        if (xt < suffix_len) stage_x = bf16_to_f32(in_proj[(size_t)xt * total_proj_dim + 2 * key_dim + hv * head_v_dim + (blockIdx.x % blocks_per_head) * DNP_ROWS + (tid & 7)]);
+    };
+    float stage_d = 0.f, stage_b = 0.f;
+    auto load_scalars = [&](uint32_t t0) {
+        if (tid < DNP_TILE && t0 + tid < suffix_len) {
+            stage_d = decay_buf[(size_t)(t0 + tid) * num_v_heads + hv];
+            stage_b = beta_buf[(size_t)(t0 + tid) * num_v_heads + hv];
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* slot = &s_tile[buf][st_tok * DNP_SLOT];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) *(float4*)(slot + st_part * 32 + v * 4) = stage[v];
+        slot[DNP_QK + 2 + (tid & 7)] = stage_x;
+        if (tid < DNP_TILE) {
+            float* sc = &s_tile[buf][tid * DNP_SLOT + DNP_QK];
+            sc[0] = stage_d, sc[1] = stage_b;
+        }
+    };
+
+    load_tile(0);
+    load_scalars(0);
+    store_tile(0);
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < suffix_len; t0 += DNP_TILE) {
+        const int buf = (t0 / DNP_TILE) & 1;
+        const bool more = t0 + DNP_TILE < suffix_len;
+        if (more) {
+            load_tile(t0 + DNP_TILE);
+            load_scalars(t0 + DNP_TILE);
+        }
+        const uint32_t steps = suffix_len - t0 < (uint32_t)DNP_TILE ? suffix_len - t0 : (uint32_t)DNP_TILE;
+        const float* base = s_tile[buf];
+        float4 k4 = *(const float4*)(base + sl * 4), q4 = *(const float4*)(base + 128 + sl * 4);
+        float decay = base[DNP_QK], beta = base[DNP_QK + 1], v_val = base[DNP_QK + 2 + hw];
+        for (uint32_t t = 0; t < steps; ++t) {
+            const float kf[4] = {k4.x, k4.y, k4.z, k4.w}, qf[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float decay_t = decay, beta_t = beta, v_t = v_val;
+            if (t + 1 < steps) { // operands of the next step: issued before this step's dependent chain
+                const float* nx = base + (size_t)(t + 1) * DNP_SLOT;
+                k4 = *(const float4*)(nx + sl * 4), q4 = *(const float4*)(nx + 128 + sl * 4);
+                decay = nx[DNP_QK], beta = nx[DNP_QK + 1], v_val = nx[DNP_QK + 2 + hw];
+            }
+            float kv_mem = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kv_mem = fmaf(decay_t * s4[e], kf[e], kv_mem);
+            kv_mem = group_sum<32>(kv_mem);
+            const float delta = beta_t * (v_t - kv_mem);
+            float o_val = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s4[e] = decay_t * s4[e] + kf[e] * delta;
+                o_val = fmaf(s4[e], qf[e], o_val);
+            }
+            o_val = group_sum<32>(o_val);
+            if (sl == 0) out[(size_t)(t0 + t) * value_dim + hv * head_v_dim + i] = f32_to_bf16(o_val);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
     }
     sv.x = s4[0], sv.y = s4[1], sv.z = s4[2], sv.w = s4[3];
     *srow = sv;
@@ -315,14 +378,14 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
                              const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
                              uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
                              uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
-    if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads) {
-        set_error("delta_net_prefill: needs head_k_dim == 128");
+    if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads || head_v_dim % DNP_ROWS) {
+        set_error("delta_net_prefill: needs head_k_dim == 128 and head_v_dim %% 8 == 0");
         return UZU_ERR_UNSUPPORTED;
     }
     const uint32_t rows = num_v_heads * head_v_dim;
     if (!rows || !suffix_len) return UZU_OK;
     return launch_check([&] {
-        hipLaunchKernelGGL(delta_net_prefill_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, q_norm, k_norm, beta, decay, in_proj,
+        hipLaunchKernelGGL(delta_net_prefill_kernel, dim3(rows / DNP_ROWS), dim3(256), 0, s, q_norm, k_norm, beta, decay, in_proj,
                            state, out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
     }, "delta_net_prefill");
 }
