@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int A_PITCH = 144; // bytes per staged activation row: 64 bf16 + 16 bytes of pad
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -73,8 +73,11 @@ __device__ __forceinline__ float chunk_sum(uint4 v) { // sum of 8 bf16
 }
 } // namespace
 
-template <int BITS>
+template <int BITS, int MB, int NB> // a wave owns MB x NB blocks of 32 x 32; four waves as 2 x 2 => workgroup tile (64 MB) x (64 NB)
 __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
+    constexpr int BM = 64 * MB, BN = 64 * NB;
+    constexpr int PARTS = 256 / BM;        // staging threads per activation row (2 or 4)
+    constexpr int CH = 8 / PARTS;          // 16-byte chunks (8 k) per staging thread per k-step
     constexpr int WV = BITS / 4; // 16-byte vectors of codes per lane per 32-column block per k-step
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
     __shared__ __attribute__((aligned(16))) float s_asum[2][BM];
@@ -89,21 +92,21 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
     const uint32_t row_bytes = K * BITS / 8;
     const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
 
-    // ---- staging role: thread -> (row, 32-k part)
-    const int ra = tid >> 1, part = tid & 1;
+    // ---- staging role: thread -> (row, CH chunks of 8 k)
+    const int ra = tid / PARTS, part = tid % PARTS;
     const bool a_valid = m0 + ra < M;
-    const uint16_t* a_src = (const uint16_t*)p.a + (size_t)(m0 + ra) * K + 32 * part;
-    uint8_t* a_dst0 = &s_a[0][ra * A_PITCH + part * 64];
-    uint8_t* a_dst1 = &s_a[1][ra * A_PITCH + part * 64];
-    uint4 a_st[4];
+    const uint16_t* a_src = (const uint16_t*)p.a + (size_t)(m0 + ra) * K + 8 * CH * part;
+    uint8_t* a_dst0 = &s_a[0][ra * A_PITCH + part * 16 * CH];
+    uint8_t* a_dst1 = &s_a[1][ra * A_PITCH + part * 16 * CH];
+    uint4 a_st[CH];
     auto load_a = [&](uint32_t kt) {
         if (a_valid) {
             const uint4* src = (const uint4*)(a_src + (size_t)kt * BK);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a_st[j] = src[j];
+            for (int j = 0; j < CH; ++j) a_st[j] = src[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a_st[j] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < CH; ++j) a_st[j] = make_uint4(0, 0, 0, 0);
         }
     };
     float asum_run = 0.f;
@@ -111,31 +114,32 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         uint8_t* dst = (kt & 1) ? a_dst1 : a_dst0;
         float part_sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
             part_sum += chunk_sum(a_st[j]);
             *(uint4*)(dst + 16 * j) = a_st[j];
         }
         asum_run += part_sum;
         if ((kt + 1) % gs == 0) { // last k-step of its group: publish the row sum of the group
-            const float total = xadd1(asum_run);
+            float total = xadd1(asum_run);
+            if (PARTS == 4) total = xadd2(total);
             if (!part) s_asum[(kt / gs) & 1][ra] = total;
             asum_run = 0.f;
         }
     };
 
     // ---- compute role
-    uint32_t ncol[2];
-    const uint8_t* w_src[2];
+    uint32_t ncol[NB];
+    const uint8_t* w_src[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const uint32_t n = n0 + wn * 64 + nb * 32 + l32;
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t n = n0 + wn * (32 * NB) + nb * 32 + l32;
         ncol[nb] = n < N ? n : N - 1;
         w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)(32 * half) * BITS / 8;
     }
-    uint4 w_cur[2][WV], w_nxt[2][WV];
-    auto load_w = [&](uint32_t kt, uint4 (&w)[2][WV]) {
+    uint4 w_cur[NB][WV], w_nxt[NB][WV];
+    auto load_w = [&](uint32_t kt, uint4 (&w)[NB][WV]) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const uint4* src = (const uint4*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
 #pragma unroll
             for (int v = 0; v < WV; ++v) w[nb][v] = src[v];
@@ -144,18 +148,18 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
     // unsigned code q (after the optional `signed_codes` flip of the top bit, kernel.rs:268-275) -> two's complement of q - 2^(bits-1)
     const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
 
-    f32x16_t acc_g[2][2], acc_t[2][2];
+    f32x16_t acc_g[MB][NB], acc_t[MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_g[mb][nb][r] = 0.f, acc_t[mb][nb][r] = 0.f;
 
-    uint16_t sc_raw[2] = {0, 0}, of_raw[2] = {0, 0};
+    uint16_t sc_raw[NB] = {}, of_raw[NB] = {};
     auto load_group = [&](uint32_t g) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             sc_raw[nb] = ((const uint16_t*)p.scales)[(size_t)ncol[nb] * G + g];
             if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) of_raw[nb] = ((const uint16_t*)p.biases)[(size_t)ncol[nb] * G + g];
             else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
@@ -177,12 +181,12 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
             load_a(kt + 1);
             load_w(kt + 1, w_nxt);
         }
-        const uint8_t* a_base = &s_a[cur][(wm * 64 + l32) * A_PITCH + half * 64];
+        const uint8_t* a_base = &s_a[cur][(wm * (32 * MB) + l32) * A_PITCH + half * 64];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32x4_t bfrag[2], afrag[2];
+            u32x4_t bfrag[NB], afrag[MB];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 if (BITS == 4) {
                     const uint32_t ws[4] = {w_cur[nb][0].x, w_cur[nb][0].y, w_cur[nb][0].z, w_cur[nb][0].w};
                     bfrag[nb] = dequant4(ws[s] ^ flip);
@@ -192,23 +196,23 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
                 }
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 const uint4 t = *(const uint4*)(a_base + mb * 32 * A_PITCH + s * 16);
                 afrag[mb] = u32x4_t{t.x, t.y, t.z, t.w};
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, afrag[mb]), __builtin_bit_cast(bf16x8_t, bfrag[nb]),
                                                                            acc_g[mb][nb], 0, 0, 0);
         }
         if ((kt + 1) % gs == 0) { // group boundary: fold the group accumulator into the total with the f32 scale
             const uint32_t g = kt / gs;
             const float* asum = s_asum[g & 1];
-            float sc[2], coef[2];
+            float sc[NB], coef[NB];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 const float scale = bf16_to_f32(sc_raw[nb]);
                 const float mid = (float)(1u << (BITS - 1)); // the codes were fed centred: q - mid (int4: divided by 16)
                 if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) coef[nb] = fmaf(mid, scale, bf16_to_f32(of_raw[nb]));
@@ -217,15 +221,15 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
                 sc[nb] = BITS == 4 ? 16.0f * scale : scale;
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 float as[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 t = *(const float4*)(asum + wm * 64 + mb * 32 + 8 * j + 4 * half);
+                    const float4 t = *(const float4*)(asum + wm * (32 * MB) + mb * 32 + 8 * j + 4 * half);
                     as[4 * j] = t.x, as[4 * j + 1] = t.y, as[4 * j + 2] = t.z, as[4 * j + 3] = t.w;
                 }
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         acc_t[mb][nb][r] = fmaf(sc[nb], acc_g[mb][nb][r], fmaf(coef[nb], as[r], acc_t[mb][nb][r]));
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         if (kt + 1 < KT) {
             stage_a(kt + 1);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int v = 0; v < WV; ++v) w_cur[nb][v] = w_nxt[nb][v];
         }
@@ -249,15 +253,15 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
     float* d32 = (float*)p.d;
     const bool out_f32 = p.d_dt == UZU_F32; // tensor-parallel partial sums (engine.hip)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const uint32_t n = n0 + wn * 64 + nb * 32 + l32;
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t n = n0 + wn * (32 * NB) + nb * 32 + l32;
         if (n >= N) continue;
         const float bias = p.bias ? bf16_to_f32(((const uint16_t*)p.bias)[n]) : 0.0f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const uint32_t m = m0 + wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 const size_t idx = (size_t)m * N + n;
                 float value = p.ab_scale * acc_t[mb][nb][r];
@@ -284,10 +288,23 @@ bool gemm_q_mfma_supported(const MatmulParams& p) {
     return true;
 }
 
-uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p) {
-    const dim3 grid((p.n + BN - 1) / BN, (p.m + BM - 1) / BM);
-    if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL(gemm_q_mfma_kernel<4>, grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
-    return launch_check([&] { hipLaunchKernelGGL(gemm_q_mfma_kernel<8>, grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+template <int MB, int NB> static uzu_status launch_gemm(hipStream_t s, const MatmulParams& p) {
+    const dim3 grid((p.n + 64 * NB - 1) / (64 * NB), (p.m + 64 * MB - 1) / (64 * MB));
+    if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<4, MB, NB>), grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+    return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<8, MB, NB>), grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+}
+// Tile choice: the 128 x 128 workgroup tile needs 304 VGPRs (one wave per SIMD: nothing hides the operand latency);
+// 64 x 64 runs four waves per SIMD and is 1.4-1.7x faster from 1024 x 1024 x 2048 up to 4096 x 14336 x 4096.
+uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus) {
+    static const int force = [] {
+        const char* e = getenv("UZU_GEMM_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    (void)num_cus;
+    switch (force) { // tools/kbench KB_GEMM sweep: 64 x 64 tiles (108 VGPRs, 4 waves / SIMD) win at every shape tried
+    case 128: return launch_gemm<2, 2>(s, p);
+    default: return launch_gemm<1, 1>(s, p);
+    }
 }
 
 } // namespace k

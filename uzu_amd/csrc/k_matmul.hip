@@ -272,7 +272,7 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
     }
     if (gemm_q_mfma_supported(p)) { // prefill-sized M: bf16 matrix cores (k_gemm.hip)
         if (variant) *variant = p.bits == 4 ? "gemm_q_mfma<4>" : "gemm_q_mfma<8>";
-        return gemm_q_mfma(s, p);
+        return gemm_q_mfma(s, p, num_cus);
     }
     if (p.w_dt == UZU_BF16) {
         if (p.bits == 4) return launch_gemv<bf16_t, bf16_t, 4>(s, p, num_cus, variant);

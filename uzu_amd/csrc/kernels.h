@@ -44,7 +44,7 @@ struct MatmulParams {
 // `variant` (optional) receives a short label of the kernel instance chosen (for per-kernel profiles)
 uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char** variant = nullptr);
 bool gemm_q_mfma_supported(const MatmulParams& p);   // k_gemm.hip: M >= 16, bf16 activations, int4/int8 codes, group % 64 == 0
-uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p);
+uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus);
 size_t matmul_algorithmic_bytes(const MatmulParams& p); // codes + scales + correction + A + D, SURVEY.md §8d
 
 // ---------------------------------------------------------------- normalization
