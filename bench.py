@@ -23,6 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -36,6 +37,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--parallelism", choices=["tp", "replicas"], default="tp", help="what N > 1 GPUs do (default: tensor parallel)")
+    ap.add_argument("--tp-graph", action="store_true", help="replay the TP decode step (RCCL all-reduces included) as a hipGraph; default: plain "
+                    "stream launches, the conservative form for a multi-rank collective that could not be exercised on the 1-GPU dev box")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path even with one rank (self-test on a 1-GPU box)")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
     return ap.parse_args()
@@ -168,7 +171,8 @@ def main():
     if mode == "tp":
         import torch
         group = TP.TpGroup(ctx, rank, world, TP.torch_broadcast(dist, device=torch.device("cuda", local_rank)))
-        model = HipModel(ctx, local_bundle, flags, tp_group=group, vocab_offset=vocab_offset)
+        tp_flags = flags if args.tp_graph else (flags | MODEL_NO_GRAPH)
+        model = HipModel(ctx, local_bundle, tp_flags, tp_group=group, vocab_offset=vocab_offset)
     else:
         model = HipModel(ctx, bundle, flags)
 
@@ -219,9 +223,13 @@ def main():
         "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int4 weights x bf16 activations, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int4 ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
-                   "prompt_tokens": prompt_len, "graph": not args.no_graph, "parallelism": parallelism},
+                   "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or args.tp_graph), "parallelism": parallelism},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
         "prefill_tokens_per_s": round(sequences * prompt_len / prefill_s, 1),
+        "prefill_roofline": {"bound": "mfma", "achieved": round(sequences * bundle.prefill_flops(prompt_len) / prefill_s / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(sequences * bundle.prefill_flops(prompt_len) / prefill_s / 1e12 / (MFMA_BF16_PEAK_TFLOPS * max(world, 1)), 5),
+                             "note": "whole prefill (GEMMs on the matrix cores + sequential DeltaNet scan + VALU attention) over its wall time; "
+                                     "the GEMM kernel alone: profiles/*_kernel_stats.csv, tools/kbench KB_GEMM"},
         "roofline": roofline,
         "kernel_us_per_step": per_kernel,
         "device": ctx.device_name(),

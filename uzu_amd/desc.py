@@ -262,6 +262,24 @@ class ModelBundle:
                 total += conv_dim * l.dn_kernel_size * 4                      # conv taps
         return total
 
+    def prefill_flops(self, tokens: int, context_before: int = 0) -> float:
+        """Algorithmic FLOPs of prefilling `tokens` tokens: 2*M*sum(N*K) over the linears (the
+        read-out runs for the last row only) + causal attention 4*heads*hd per (query, visible key) pair."""
+        macs = 0
+        for l in self.layers:
+            for _, w in l.linears():
+                macs += w.n * w.k
+        flops = 2.0 * tokens * macs
+        readout = self.embedding if self.tied_embeddings else self.output_embedding
+        flops += 2.0 * readout.n * readout.k
+        pairs = tokens * context_before + tokens * (tokens + 1) / 2.0
+        for l in self.layers:
+            if l.mixer_kind == MIXER_ATTENTION:
+                flops += 4.0 * pairs * l.num_heads * l.head_dim
+            else:  # delta rule: ~6 flops per state element per token (decay, S k, rank-1 update, S q)
+                flops += 6.0 * tokens * l.dn_num_heads * l.dn_value_head_dim * l.dn_head_dim
+        return flops
+
     def decode_bytes_per_token(self, context: int) -> int:
         emb_row = self.embedding.nbytes() // self.vocab_size
         return self.weight_stream_bytes() + self.state_bytes_per_token(context) + emb_row
