@@ -105,6 +105,8 @@ def timed_decode(model, ctx, args, dist, prompt):
             torch.cuda.synchronize()
             dist.barrier()
 
+    model.prefill(prompt)  # warm-up run, discarded (the reference's bench does the same: cli/src/bench/runner.rs:67-68);
+    model.reset()          # it also takes the one-time code-object loads out of the timed prefill
     sync()
     t0 = time.perf_counter()
     model.prefill(prompt)

@@ -98,25 +98,26 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
     const uint16_t* a_src = (const uint16_t*)p.a + (size_t)(m0 + ra) * K + 8 * CH * part;
     uint8_t* a_dst0 = &s_a[0][ra * A_PITCH + part * 16 * CH];
     uint8_t* a_dst1 = &s_a[1][ra * A_PITCH + part * 16 * CH];
-    uint4 a_st[CH];
-    auto load_a = [&](uint32_t kt) {
-        if (a_valid) {
+    constexpr int D = 4; // register stages: the operands of k-step kt + D - 1 are requested while k-step kt is computed
+    uint4 a_st[D][CH];
+    auto load_a = [&](uint32_t kt, uint4 (&st)[CH]) {
+        if (a_valid && kt < KT) {
             const uint4* src = (const uint4*)(a_src + (size_t)kt * BK);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) a_st[j] = src[j];
+            for (int j = 0; j < CH; ++j) st[j] = src[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) a_st[j] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < CH; ++j) st[j] = make_uint4(0, 0, 0, 0);
         }
     };
     float asum_run = 0.f;
-    auto stage_a = [&](uint32_t kt) { // a_st holds k-step kt
+    auto stage_a = [&](uint32_t kt, const uint4 (&st)[CH]) { // st holds k-step kt
         uint8_t* dst = (kt & 1) ? a_dst1 : a_dst0;
         float part_sum = 0.f;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            part_sum += chunk_sum(a_st[j]);
-            *(uint4*)(dst + 16 * j) = a_st[j];
+            part_sum += chunk_sum(st[j]);
+            *(uint4*)(dst + 16 * j) = st[j];
         }
         asum_run += part_sum;
         if ((kt + 1) % gs == 0) { // last k-step of its group: publish the row sum of the group
@@ -136,8 +137,9 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         ncol[nb] = n < N ? n : N - 1;
         w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)(32 * half) * BITS / 8;
     }
-    uint4 w_cur[NB][WV], w_nxt[NB][WV];
+    uint4 w_st[D][NB][WV];
     auto load_w = [&](uint32_t kt, uint4 (&w)[NB][WV]) {
+        if (kt >= KT) return;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const uint4* src = (const uint4*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
@@ -169,29 +171,19 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         }
     };
 
-    load_a(0);
-    load_w(0, w_cur);
-    load_group(0);
-    stage_a(0);
-    __syncthreads();
-
-    for (uint32_t kt = 0; kt < KT; ++kt) {
-        const uint32_t cur = kt & 1;
-        if (kt + 1 < KT) {
-            load_a(kt + 1);
-            load_w(kt + 1, w_nxt);
-        }
-        const uint8_t* a_base = &s_a[cur][(wm * (32 * MB) + l32) * A_PITCH + half * 64];
+    // one k-step: MFMAs from LDS buffer kt & 1 and the weight registers of stage `w`
+    auto compute = [&](uint32_t kt, const uint4 (&w)[NB][WV]) {
+        const uint8_t* a_base = &s_a[kt & 1][(wm * (32 * MB) + l32) * A_PITCH + half * 64];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4_t bfrag[NB], afrag[MB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if (BITS == 4) {
-                    const uint32_t ws[4] = {w_cur[nb][0].x, w_cur[nb][0].y, w_cur[nb][0].z, w_cur[nb][0].w};
+                    const uint32_t ws[4] = {w[nb][0].x, w[nb][0].y, w[nb][0].z, w[nb][0].w};
                     bfrag[nb] = dequant4(ws[s] ^ flip);
                 } else {
-                    const uint4 v = w_cur[nb][s >> 1];
+                    const uint4 v = w[nb][s >> 1];
                     bfrag[nb] = (s & 1) ? dequant8(v.z ^ flip, v.w ^ flip) : dequant8(v.x ^ flip, v.y ^ flip);
                 }
             }
@@ -238,14 +230,31 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
             }
             if (g + 1 < G) load_group(g + 1);
         }
-        if (kt + 1 < KT) {
-            stage_a(kt + 1);
+    };
+
+    // Software pipeline, D register stages deep (global/L2 latency is ~1 us, a k-step of MFMAs ~0.1 us): stage u holds
+    // k-step kt0 + u.  Iteration kt: MFMAs of kt; then the activations of kt + 1 (requested D - 1 iterations ago) move
+    // from registers to the other LDS buffer, and stage u is refilled with k-step kt + D.
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+    for (int u = 0; u < D; ++u) {
+        load_a(u, a_st[u]);
+        load_w(u, w_st[u]);
+    }
+    load_group(0);
+    stage_a(0, a_st[0]);
+    __syncthreads();
+    for (uint32_t kt0 = 0; kt0 < KT; kt0 += D) {
 #pragma unroll
-                for (int v = 0; v < WV; ++v) w_cur[nb][v] = w_nxt[nb][v];
+        for (int u = 0; u < D; ++u) {
+            const uint32_t kt = kt0 + u;
+            if (kt < KT) {
+                compute(kt, w_st[u]);
+                if (kt + 1 < KT) stage_a(kt + 1, a_st[(u + 1) % D]);
+                load_a(kt + D, a_st[u]); // a_st[u] went to LDS one iteration ago, w_st[u] was consumed just now
+                load_w(kt + D, w_st[u]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue in the reference's order (kernel.rs:281-292): lane holds column n, rows (r&3) + 8*(r>>2) + 4*half
