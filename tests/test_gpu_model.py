@@ -35,6 +35,13 @@ def logits_close(want_bits, got_bits, row_mult=None, tol=0.25):
     return np.abs(w - g) <= tol * w.std()
 
 
+def top2_gap(logit_bits):
+    """(top-1 - top-2) of a logit row in units of the row's standard deviation."""
+    w = f32(logit_bits).astype(np.float64)
+    top = np.partition(w, -2)[-2:]
+    return float((top[1] - top[0]) / w.std())
+
+
 def run_pair(hip_ctx, cfg, prompt_len, steps, flags=0, teacher_forced=False, logit_tol=0.25):
     bundle = S.build_model(cfg)
     row_mult = S.readout_row_multipliers(cfg)
@@ -44,6 +51,7 @@ def run_pair(hip_ctx, cfg, prompt_len, steps, flags=0, teacher_forced=False, log
     o_tok, o_logits = om.prefill(prompt, True)
     h_tok = hm.prefill(prompt)
     o_tokens, h_tokens, worst = [o_tok], [h_tok], 0.0
+    run_pair.gaps = [top2_gap(o_logits)]
     assert logits_close(o_logits, hm.read_logits(), row_mult, logit_tol).all(), "prefill logits out of tolerance"
     for _ in range(steps):
         if teacher_forced:
@@ -53,6 +61,7 @@ def run_pair(hip_ctx, cfg, prompt_len, steps, flags=0, teacher_forced=False, log
         ok = logits_close(o_logits, hm.read_logits(), row_mult, logit_tol)
         assert ok.all(), f"decode logits out of tolerance at ctx {om.context_length}"
         worst = max(worst, float(np.abs(f32(o_logits) - f32(hm.read_logits())).max()))
+        run_pair.gaps.append(top2_gap(o_logits))
         o_tokens.append(o_tok)
         h_tokens.append(int(toks[0]))
     return o_tokens, h_tokens, worst, om, hm
@@ -75,7 +84,10 @@ def test_tiny_model_teacher_forced_and_no_graph(hip_ctx, preset):
     wherever the oracle's top-2 gap exceeds the tolerance."""
     cfg = S.PRESETS[preset]()
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 17, 12, flags=MODEL_NO_GRAPH, teacher_forced=True)
-    assert h_tokens == o_tokens
+    # teacher forcing keeps the two runs on the same prefix, so every step is an independent comparison: the arg-max
+    # may only differ where the reference's own top-2 gap is inside the logit tolerance (a near-tie)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
 
 
 def test_tiny_qwen_layer_taps_and_exact_mode(hip_ctx):

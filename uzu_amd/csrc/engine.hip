@@ -310,7 +310,9 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
     a.dyn = m->d_ctx_len;
     const size_t kv_bytes = (size_t)2 * (m->context_length + batch) * nkv * hd * 2; // K and V rows read once
     const bool two_pass = m->regime_override >= 0 ? m->regime_override == 1 : m->context_length + batch > 1024;
-    if (two_pass) { // core/mod.rs:89-92
+    if (k::attention_prefill_mfma_supported(a)) { // prefill chunk: flash-attention tiles on the matrix cores, any context length
+        RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, m->attn_out));
+    } else if (two_pass) { // core/mod.rs:89-92
         RUN("attention_two_pass1", kv_bytes, k::attention_two_pass1(e.s, a, m->partials, m->sums, m->maxs));
         RUN("attention_two_pass2", 0, k::attention_two_pass2(e.s, m->partials, m->sums, m->maxs, m->attn_out, UZU_BF16, hd, nq, batch));
     } else {

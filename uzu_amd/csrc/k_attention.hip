@@ -248,6 +248,7 @@ static uzu_status check_attention(const AttentionParams& a) {
 uzu_status attention_single_pass(hipStream_t s, const AttentionParams& a, void* out) {
     if (!a.suffix_length || !a.num_heads) return UZU_OK;
     UZU_PROPAGATE(check_attention(a));
+    if (attention_prefill_mfma_supported(a)) return attention_prefill_mfma(s, a, out); // prefill-sized causal tiles
     return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status { return dispatch_hd<T>(s, a, 1, -INFINITY, out, nullptr, nullptr, nullptr); });
 }
 

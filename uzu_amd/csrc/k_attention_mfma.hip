@@ -1,0 +1,247 @@
+// k_attention_mfma.hip -- prefill attention on the bf16 matrix cores (flash-attention form) for gfx950.
+//
+// Reference semantics: AttentionSinglePass / TwoPass (BU/cpu/kernel/attention/attention_single_pass.rs:37-127,
+// mask.rs:3-61): per (head, query) softmax(scale * q.k) over the visible keys (all cached keys + the causal part of
+// the suffix), output [M, heads, hd] bf16.  The stand-alone VALU kernels (k_attention.hip) spend ~45 instructions per
+// (query, key, head); at a 1024-token chunk that is the third-largest item of the prefill.  Here:
+//
+//   * a workgroup = one kv head x a tile of queries; its four waves are the (up to) four q heads of the GQA group --
+//     they share every K / V tile, staged once in LDS -- or further 32-query tiles when the group is smaller;
+//   * everything is computed TRANSPOSED so that a lane owns one query: S^T = K Q^T (A = K rows from LDS, B = Q^T from
+//     registers), the C layout of v_mfma_f32_32x32x16_bf16 then gives a lane 16 key scores of ITS query (col = lane &
+//     31), so the online-softmax statistics are per-lane scalars (one exchange with lane ^ 32 per tile for the
+//     running maximum);  O^T = V^T P^T: the P^T operand is exactly those 16 registers (converted to bf16) -- no
+//     shuffle, no LDS round trip -- and the O^T accumulator columns are again "this lane's query", so the rescale by
+//     exp(m_old - m_new) and the final 1 / l are per-lane multiplies;
+//   * V is stored transposed in LDS ([hd][key]): the contraction runs over keys, so a lane needs 8 keys of one hd
+//     column; K stays [key][hd];
+//   * q, k, v are bf16 already => every q.k product is exact in f32.  The probabilities are NOT bf16: they are fed
+//     as hi + lo (two bf16 MFMAs, 16 significant bits), so the only arithmetic difference to the f32 reference is
+//     the summation order.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+namespace {
+constexpr int TK = 32; // keys per tile (one MFMA block)
+constexpr int TQ = 32; // queries per wave
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// value of lane ^ 32 (the other half of the wave): the one cross-half exchange per tile
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
+} // namespace
+
+// grid: (kv_head * groups_per_kv + sub, query tiles); 256 threads.
+//   WPH = waves that are distinct q heads (min(gqa, 4)); the remaining factor 4 / WPH are extra query tiles.
+template <int HD>
+__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t heads_per_wg) {
+    constexpr int KP = HD * 2 + 16;  // K tile row pitch in bytes (conflict-free ds_read_b128)
+    constexpr int VP = TK * 2 + 8;   // V^T tile row pitch in bytes: 32 keys + 8 bytes of pad (conflict-free ds_read_b64)
+    constexpr int NS = HD / 16;      // k16 steps of the QK^T contraction
+    constexpr int NB = HD / 32;      // 32-row blocks of O^T
+    __shared__ __attribute__((aligned(16))) uint8_t s_k[2][TK * KP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_vt[2][HD * VP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+    const uint32_t tiles_per_wg = 4 / heads_per_wg; // query tiles per workgroup
+    const uint32_t groups_per_kv = a.gqa_factor / heads_per_wg;
+    const uint32_t kv_head = blockIdx.x / groups_per_kv, sub = blockIdx.x % groups_per_kv;
+    const uint32_t head = kv_head * a.gqa_factor + sub * heads_per_wg + wave % heads_per_wg;
+    const uint32_t M = a.suffix_length;
+    const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
+    const uint32_t prefix = sequence_length - M;
+    const uint32_t q0_wg = blockIdx.y * (TQ * tiles_per_wg);
+    const uint32_t q0 = q0_wg + (wave / heads_per_wg) * TQ; // first query of this wave
+    const uint32_t qi = q0 + l32;                           // this lane's query (suffix index)
+    const bool q_live = qi < M;
+
+    // ---- Q^T operand: lane = (query l32, hd half): 8 consecutive hd elements per k16 step, kept in registers
+    u32x4_t qf[NS];
+    {
+        const uint16_t* qrow = (const uint16_t*)a.queries + ((size_t)head * M + (q_live ? qi : 0)) * HD + 8 * half;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 t = q_live ? *(const uint4*)(qrow + 16 * s) : make_uint4(0, 0, 0, 0);
+            qf[s] = u32x4_t{t.x, t.y, t.z, t.w};
+        }
+    }
+
+    // ---- staging role: thread -> (key of the tile, 64-byte slice of its hd row)
+    const uint16_t* kbase = (const uint16_t*)a.keys + (size_t)kv_head * a.k_head_stride;
+    const uint16_t* vbase = (const uint16_t*)a.values + (size_t)kv_head * a.v_head_stride;
+    constexpr int SLICES = HD / 32;               // 32 hd elements (64 bytes) per slice
+    constexpr int ROUNDS = (TK * SLICES + 255) / 256;
+    uint4 kst[ROUNDS][4], vst[ROUNDS][4];
+    // keys visible to ANY query of the workgroup: 0 .. prefix + last query of the workgroup
+    const uint32_t wg_last_q = (q0_wg + TQ * tiles_per_wg < M ? q0_wg + TQ * tiles_per_wg : M) - 1;
+    const uint32_t key_end = prefix + wg_last_q + 1;
+    const uint32_t n_tiles = (key_end + TK - 1) / TK;
+    auto load_tile = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t idx = tid + 256 * r, key = idx / SLICES, sl = idx % SLICES;
+            const uint32_t i = t * TK + key;
+            if (idx < TK * SLICES && i < key_end) {
+                const uint4* ks = (const uint4*)(kbase + (size_t)i * a.k_seq_stride + sl * 32);
+                const uint4* vs = (const uint4*)(vbase + (size_t)i * a.v_seq_stride + sl * 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kst[r][j] = ks[j], vst[r][j] = vs[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kst[r][j] = make_uint4(0, 0, 0, 0), vst[r][j] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t idx = tid + 256 * r, key = idx / SLICES, sl = idx % SLICES;
+            if (idx >= TK * SLICES) continue;
+            uint8_t* kd = &s_k[buf][key * KP + sl * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(uint4*)(kd + 16 * j) = kst[r][j];
+            // V transposed: element (key, hd) -> s_vt[hd][key]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w[4] = {vst[r][j].x, vst[r][j].y, vst[r][j].z, vst[r][j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t hd0 = sl * 32 + j * 8 + 2 * e;
+                    *(uint16_t*)&s_vt[buf][hd0 * VP + key * 2] = (uint16_t)(w[e] & 0xFFFFu);
+                    *(uint16_t*)&s_vt[buf][(hd0 + 1) * VP + key * 2] = (uint16_t)(w[e] >> 16);
+                }
+            }
+        }
+    };
+
+    f32x16_t o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f; // l_run: this lane's half of the keys only (merged at the end)
+    const uint32_t my_last_key = prefix + qi; // causal: keys 0 .. prefix + qi
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) load_tile(t + 1);
+        // a wave whose queries all end before this tile has nothing to add (causal), but must keep the barriers
+        const uint32_t wave_last_key = prefix + (q0 + TQ - 1 < M ? q0 + TQ - 1 : M - 1);
+        if (q0 < M && t * TK <= wave_last_key) {
+            // ---- S^T = K Q^T
+            f32x16_t sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const uint8_t* kt = &s_k[buf][l32 * KP + half * 16];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint4 kv = *(const uint4*)(kt + s * 32);
+                const u32x4_t kfrag = {kv.x, kv.y, kv.z, kv.w};
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kfrag), __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
+            }
+            // ---- scale, causal mask, online softmax (lane = one query; its 16 keys: (r & 3) + 8 (r >> 2) + 4 half)
+            float sc[16];
+            float m_loc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t key = t * TK + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool vis = q_live && key <= my_last_key;
+                sc[r] = vis ? a.scale * sacc[r] : -INFINITY;
+                m_loc = fmaxf(m_loc, sc[r]);
+            }
+            const float m_new = fmaxf(m_run, fmaxf(m_loc, other_half(m_loc)));
+            const float alpha = m_new == -INFINITY ? 1.0f : fast_exp(m_run - m_new); // m_run = -inf => exp(-inf) = 0
+            float psum = 0.f;
+            uint32_t p_hi[8], p_lo[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = m_new == -INFINITY ? 0.f : fast_exp(sc[r] - m_new), p1 = m_new == -INFINITY ? 0.f : fast_exp(sc[r + 1] - m_new);
+                psum += p0 + p1;
+                const float h0 = round_bf16(p0), h1 = round_bf16(p1);
+                p_hi[r / 2] = pack2(h0, h1);
+                p_lo[r / 2] = pack2(p0 - h0, p1 - h1);
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+            // ---- O^T += V^T P^T : two k16 steps (registers 0..7 and 8..15 of the score tile), P as hi + lo
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const u32x4_t ph = {p_hi[4 * st], p_hi[4 * st + 1], p_hi[4 * st + 2], p_hi[4 * st + 3]};
+                const u32x4_t pl = {p_lo[4 * st], p_lo[4 * st + 1], p_lo[4 * st + 2], p_lo[4 * st + 3]};
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    // A = V^T: lane = (hd row b*32 + l32, half): keys 16 st + 4 half + {0..3} and 16 st + 8 + 4 half + {0..3}
+                    const uint8_t* vr = &s_vt[buf][(b * 32 + l32) * VP + (16 * st + 4 * half) * 2];
+                    const uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 16);
+                    const u32x4_t vfrag = {v0.x, v0.y, v1.x, v1.y};
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, ph), o[b], 0, 0, 0);
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfrag), __builtin_bit_cast(bf16x8_t, pl), o[b], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < n_tiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- finish: l = both halves' sums (same maximum), out[q][head][hd] = O / l
+    const float l_tot = l_run + other_half(l_run);
+    if (q_live) {
+        const float inv = 1.0f / l_tot;
+        uint16_t* orow = out + ((size_t)qi * a.num_heads + head) * HD;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { // rows (hd) 8 j + 4 half + {0..3} of block b
+                uint2 w;
+                w.x = pack2(o[b][4 * j] * inv, o[b][4 * j + 1] * inv);
+                w.y = pack2(o[b][4 * j + 2] * inv, o[b][4 * j + 3] * inv);
+                *(uint2*)(orow + b * 32 + 8 * j + 4 * half) = w;
+            }
+    }
+}
+
+bool attention_prefill_mfma_supported(const AttentionParams& a) {
+    static const uint32_t min_m = [] {
+        const char* e = getenv("UZU_ATTN_MFMA_MIN_M");
+        return e ? (uint32_t)atoi(e) : 16u;
+    }();
+    if (a.dt != UZU_BF16 || !a.is_causal || a.sinks || a.is_sliding_window || a.is_kv_cache_ring) return false;
+    if (a.suffix_length < min_m || !(a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256)) return false;
+    if (a.gqa_factor == 0 || a.num_heads % a.gqa_factor) return false;
+    if (a.gqa_factor > 4 ? a.gqa_factor % 4 != 0 : (4 % a.gqa_factor) != 0) return false;
+    if (a.k_head_stride % 8 || a.k_seq_stride % 8 || a.v_head_stride % 8 || a.v_seq_stride % 8) return false;
+    return true;
+}
+
+uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out) {
+    const uint32_t heads_per_wg = a.gqa_factor >= 4 ? 4 : a.gqa_factor;
+    const uint32_t kv_heads = a.num_heads / a.gqa_factor;
+    const uint32_t q_per_wg = TQ * (4 / heads_per_wg);
+    const dim3 grid(kv_heads * (a.gqa_factor / heads_per_wg), (a.suffix_length + q_per_wg - 1) / q_per_wg);
+#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, heads_per_wg); }, "attention_prefill_mfma")
+    switch (a.head_dim) {
+    case 64: UZU_LAUNCH(64);
+    case 128: UZU_LAUNCH(128);
+    default: UZU_LAUNCH(256);
+    }
+#undef UZU_LAUNCH
+}
+
+} // namespace k
+} // namespace uzu

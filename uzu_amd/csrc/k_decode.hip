@@ -295,7 +295,6 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         float4 w;
         float bias;
     };
-    constexpr bool conv_fast = CONV; // launch selects CONV only for kernel size 4 (the prefetching form)
     auto conv_prefetch = [&](uint32_t b, ConvPre (&cp)[CONV ? R : 1]) { // issued at batch start: lands while the rows are computed
         if (sl != 0 || b >= batches0) return;
 #pragma unroll

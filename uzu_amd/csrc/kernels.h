@@ -86,6 +86,8 @@ struct AttentionParams {
     const uint32_t* dyn;
 };
 uzu_status attention_single_pass(hipStream_t s, const AttentionParams& p, void* out);
+bool attention_prefill_mfma_supported(const AttentionParams& p); // k_attention_mfma.hip: causal bf16 prefill tiles on the matrix cores
+uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& p, void* out);
 uzu_status attention_two_pass1(hipStream_t s, const AttentionParams& p, float* partials, float* sums, float* maxs);
 uzu_status attention_two_pass2(hipStream_t s, const float* partials, const float* sums, const float* maxs, void* out,
                                uint32_t dt, uint32_t head_dim, uint32_t num_heads, uint32_t suffix_length);
