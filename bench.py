@@ -33,6 +33,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="qwen3.5-0.8b")
+    ap.add_argument("--bits", type=int, default=0, help="override the preset's code width (4 or 8) -- side runs, not the headline config")
     ap.add_argument("--context", type=int, default=2048, help="context length at which the timed decode starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -151,7 +152,7 @@ def main():
     from uzu_amd.engine import MODEL_DEFAULT, MODEL_NO_GRAPH, HipModel
 
     total_positions = args.context + args.warmup + args.steps + 8
-    cfg = S.PRESETS[args.model](max_context_length=total_positions)
+    cfg = S.PRESETS[args.model](max_context_length=total_positions, **({"bits": args.bits} if args.bits else {}))
     bundle = S.build_model(cfg)
     ctx = Context.new(local_rank)
     flags = MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT
@@ -219,12 +220,12 @@ def main():
                    f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]
 
     result = {
-        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)",
+        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)" if (args.model, cfg.bits) == ("qwen3.5-0.8b", 4) else f"decode tokens/s ({cfg.name} int{cfg.bits}, batch 1, greedy)",
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-        "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int4 weights x bf16 activations, f32 accumulate",
+        "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": f"int{cfg.bits} weights x bf16 activations, f32 accumulate",
         "data": "synthetic",
-        "config": {"workload": f"{cfg.name} int4 ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
+        "config": {"workload": f"{cfg.name} int{cfg.bits} ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
                    "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or args.tp_graph), "parallelism": parallelism},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
         "prefill_tokens_per_s": round(sequences * prompt_len / prefill_s, 1),

@@ -34,18 +34,19 @@ int main(int argc, char** argv) {
     const int NBUF0 = getenv("KB_NBUF") ? atoi(getenv("KB_NBUF")) : 8; const int reps = NBUF0 > 64 ? NBUF0 : 64; // rotate weight buffers so weights come from HBM, not L2/MALL
     auto bench_gemv = [&](const char* name, uint32_t n, uint32_t k, bool norm, bool act, bool amax, uint32_t n2 = 0, uint32_t debug = 0) {
         const uint32_t g = 128, groups = k / g;
+        const uint32_t bits = getenv("KB_BITS") ? atoi(getenv("KB_BITS")) : 4;
         const int NBUF = (size_t)n * k > (64u << 20) ? (NBUF0 < 3 ? NBUF0 : 3) : NBUF0;
         std::vector<uint8_t*> w(NBUF); std::vector<uint16_t*> sc(NBUF), bi(NBUF);
         const uint32_t nt = n + n2;
-        for (int i = 0; i < NBUF; ++i) { w[i] = dalloc<uint8_t>((size_t)nt * k / 2, 0x53); sc[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); bi[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); }
+        for (int i = 0; i < NBUF; ++i) { w[i] = dalloc<uint8_t>((size_t)nt * k * bits / 8, 0x53); sc[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); bi[i] = dalloc<uint16_t>((size_t)nt * groups, 0x3c); }
         uint16_t* x = dalloc<uint16_t>(k, 0x3f); uint16_t* sh = dalloc<uint16_t>(k, 0x3f); uint16_t* sho = dalloc<uint16_t>(k);
         float* ns = dalloc<float>(k, 0); uint16_t* out = dalloc<uint16_t>(nt); float* pv = dalloc<float>(8192); uint32_t* pi = dalloc<uint32_t>(8192);
-        const size_t bytes = (size_t)nt * k / 2 + (size_t)nt * groups * 4 + nt * 2 + k * 2;
+        const size_t bytes = (size_t)nt * k * bits / 8 + (size_t)nt * groups * 4 + nt * 2 + k * 2;
         time_graph(name, bytes, reps, [&](int i) {
             DecGemvParams p{};
             p.w[0] = w[i % NBUF], p.scales[0] = sc[i % NBUF], p.biases[0] = bi[i % NBUF], p.out[0] = out, p.n[0] = n;
-            if (n2) { p.w[1] = w[i % NBUF] + (size_t)n * k / 2, p.scales[1] = sc[i % NBUF] + (size_t)n * groups, p.biases[1] = bi[i % NBUF] + (size_t)n * groups, p.out[1] = out + n, p.n[1] = n2; }
-            p.k = k, p.bits = 4, p.group_size = g, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.x = x;
+            if (n2) { p.w[1] = w[i % NBUF] + (size_t)n * k * bits / 8, p.scales[1] = sc[i % NBUF] + (size_t)n * groups, p.biases[1] = bi[i % NBUF] + (size_t)n * groups, p.out[1] = out + n, p.n[1] = n2; }
+            p.k = k, p.bits = bits, p.group_size = g, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.x = x;
             if (norm) { p.norm_scales = ns, p.norm_eps = 1e-6f, p.norm_offset = 1.f, p.norm_full_layer = 1, p.residual_add = 1, p.shortcut_in = sh, p.shortcut_out = sho; }
             if (act) p.act_mul = 1;
             if (amax) p.part_val = pv, p.part_idx = pi;

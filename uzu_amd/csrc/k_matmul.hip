@@ -23,6 +23,7 @@
 #include "device_utils.h"
 #include "gemv_core.h"
 #include "kernels.h"
+#include "kernels_decode.h"
 
 namespace uzu {
 namespace k {
@@ -269,6 +270,17 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
         return launch_check([&] {
             hipLaunchKernelGGL(matmul_ref_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, p, 1u, p.k);
         }, "matmul_ref");
+    }
+    // M == 1 with the plain epilogue: the decode GEMV of k_decode.hip (same lane mapping and arithmetic as gemv_q_kernel
+    // below, i.e. bit-identical results; ping-pong prefetch, persistent grid for big matrices)
+    if (p.m == 1 && p.w_dt == UZU_BF16 && p.d_dt == UZU_BF16 && !p.signed_codes && p.ab_scale == 1.0f && !p.accumulate && !p.has_soft_cap && !p.gather && !p.act_mul &&
+        (p.group_size & (p.group_size - 1)) == 0 && (uint64_t)p.n * p.k * p.bits / 8 < (1ull << 32)) {
+        DecGemvParams q{};
+        q.w[0] = (const uint8_t*)p.b, q.scales[0] = (const uint16_t*)p.scales, q.biases[0] = (const uint16_t*)p.biases, q.zp[0] = p.zero_points;
+        q.out_bias[0] = (const uint16_t*)p.bias, q.out[0] = (uint16_t*)p.d, q.n[0] = p.n;
+        q.k = p.k, q.bits = p.bits, q.group_size = p.group_size, q.b_kind = p.b_kind, q.x = (const uint16_t*)p.a;
+        if (variant) *variant = p.bits == 4 ? "gemv_dec<4>" : "gemv_dec<8>";
+        return gemv_dec(s, q, num_cus, nullptr);
     }
     if (gemm_q_mfma_supported(p)) { // prefill-sized M: bf16 matrix cores (k_gemm.hip)
         if (variant) *variant = p.bits == 4 ? "gemm_q_mfma<4>" : "gemm_q_mfma<8>";
