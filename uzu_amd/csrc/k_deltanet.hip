@@ -268,16 +268,24 @@ uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const 
 }
 
 // ---------------------------------------------------------------- DeltaNetPrefill (prefill.rs:39-80)
-// Sequential scan over tokens with the state row held in registers: half a wave per (hv, dv) row, 8 rows of ONE value
-// head per workgroup (all 256 CUs busy at Hv * Dv = 2048 rows).  The recurrence makes every step depend on the
-// previous one, so the per-step cost must be the arithmetic chain (two 32-lane reductions), not memory latency:
-// the q / k rows, decay, beta and the 8 v values of TILE tokens are staged through double-buffered LDS, the loads
-// of tile n+1 are in flight while tile n is scanned, and the LDS reads of step t+1 are issued before step t's math.
+// Scan over tokens with the state row held in registers: half a wave per (hv, dv) row, 8 rows of ONE value head per
+// workgroup (all 256 CUs busy at Hv * Dv = 2048 rows).  Every step depends on the previous one and there is exactly
+// one wave per SIMD, so the cost is the length of the dependent instruction chain -- not memory, not throughput:
+//   * TWO tokens per step.  With s the row before the pair, (a, b, v, k, q)_{1,2} the pair's operands:
+//         d1 = b1 (v1 - a1 s.k1)                          s1 = a1 s + d1 k1
+//         d2 = b2 (v2 - a2 (a1 s.k2 + d1 k1.k2))          s2 = a2 s1 + d2 k2
+//         o1 = a1 s.q1 + d1 k1.q1                         o2 = a2 (a1 s.q2 + d1 k1.q2) + d2 k2.q2
+//     the four row dots s.k1, s.k2, s.q1, s.q2 are independent (their reductions interleave), the four cross dots
+//     k1.k2, k1.q1, k1.q2, k2.q2 do not involve the state: they are computed once per staged tile.  Same algebra as
+//     the reference's one-token recurrence, different rounding order (tolerance-class like every reduction kernel);
+//   * the q / k rows, decay, beta and the 8 v values of TILE tokens are staged through double-buffered LDS, the loads
+//     of tile n+1 are in flight while tile n is scanned, the LDS reads of pair p+1 are issued before pair p's math.
 namespace {
 constexpr int DNP_TILE = 32;      // tokens per staged tile
 constexpr int DNP_ROWS = 8;       // state rows (one value head) per workgroup
 constexpr int DNP_QK = 2 * 128;   // floats of k and q per token
-constexpr int DNP_SLOT = DNP_QK + 2 + DNP_ROWS + 2; // + decay, beta, v[8], pad -> 268 floats (multiple of 4)
+constexpr int DNP_SLOT = DNP_QK + 16; // + decay, beta, v[8], cross dots[4] (even tokens), pad -> 272 floats
+constexpr int DNP_X = DNP_QK + 10;    // offset of the pair's cross dots inside the even token's slot
 }
 __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_norm, const float* k_norm,
                                                                 const float* beta_buf, const float* decay_buf,
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_n
     __shared__ __attribute__((aligned(16))) float s_tile[2][DNP_TILE * DNP_SLOT];
     const int tid = threadIdx.x, sl = tid & 31, hw = tid >> 5; // hw = half-wave = row inside the workgroup
     const uint32_t blocks_per_head = head_v_dim / DNP_ROWS;
-    const uint32_t hv = blockIdx.x / blocks_per_head, i = (blockIdx.x % blocks_per_head) * DNP_ROWS + hw;
+    const uint32_t hv = blockIdx.x / blocks_per_head, i0 = (blockIdx.x % blocks_per_head) * DNP_ROWS, i = i0 + hw;
     const uint32_t hk = hv / (num_v_heads / num_k_heads);
     const uint32_t conv_dim = 2 * key_dim + value_dim;
     const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
@@ -297,24 +305,20 @@ __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_n
     float4* srow = (float4*)(state + (size_t)row * DK) + sl;
     float4 sv = *srow;
     float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+    uint16_t* orow = out + (size_t)hv * head_v_dim + i;
 
-    // staging role: thread -> (token of the tile, 32-float slice of the k|q row); extras by the first threads
+    // staging role: thread -> (token of the tile, 32-float slice of the k|q row); v: one value per thread
     const int st_tok = tid >> 3, st_part = tid & 7; // 32 tokens x 8 slices of 32 floats (k: slices 0-3, q: 4-7)
     float4 stage[8];
-    float stage_x = 0.f;
+    float stage_x = 0.f, stage_d = 0.f, stage_b = 0.f;
     auto load_tile = [&](uint32_t t0) {
         const uint32_t token = t0 + st_tok;
         if (token < suffix_len) {
             const float* src = (st_part < 4 ? k_norm : q_norm) + (size_t)token * key_dim + hk * DK + (st_part & 3) * 32;
 #pragma unroll
             for (int v = 0; v < 8; ++v) stage[v] = ((const float4*)src)[v];
+            stage_x = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + 2 * key_dim + hv * head_v_dim + i0 + st_part]);
         }
-        // extras: thread e < 32*10 would be needed; 256 threads cover 32 tokens x 8 v values, decay / beta by slices 0 / 1
-        const uint32_t xt = t0 + (tid >> 3);
-        if (xt < suffix_len) stage_x = bf16_to_f32(in_proj[(size_t)xt * total_proj_dim + 2 * key_dim + hv * head_v_dim + (blockIdx.x % blocks_per_head) * DNP_ROWS + (tid & 7)]);
-    };
-    float stage_d = 0.f, stage_b = 0.f;
-    auto load_scalars = [&](uint32_t t0) {
         if (tid < DNP_TILE && t0 + tid < suffix_len) {
             stage_d = decay_buf[(size_t)(t0 + tid) * num_v_heads + hv];
             stage_b = beta_buf[(size_t)(t0 + tid) * num_v_heads + hv];
@@ -324,52 +328,97 @@ __global__ void __launch_bounds__(256) delta_net_prefill_kernel(const float* q_n
         float* slot = &s_tile[buf][st_tok * DNP_SLOT];
 #pragma unroll
         for (int v = 0; v < 8; ++v) *(float4*)(slot + st_part * 32 + v * 4) = stage[v];
-        slot[DNP_QK + 2 + (tid & 7)] = stage_x;
+        slot[DNP_QK + 2 + st_part] = stage_x;
         if (tid < DNP_TILE) {
             float* sc = &s_tile[buf][tid * DNP_SLOT + DNP_QK];
             sc[0] = stage_d, sc[1] = stage_b;
         }
     };
+    // cross dots of the 16 token pairs of a staged tile: 16 threads per pair = 4 dots x 4 partial threads
+    auto cross_dots = [&](int buf) {
+        const int pair = tid >> 4, dot = (tid >> 2) & 3, part = tid & 3;
+        const float* t1 = &s_tile[buf][(2 * pair) * DNP_SLOT];
+        const float* t2 = t1 + DNP_SLOT;
+        const float* x = dot == 3 ? t2 : t1;                                   // k2 | k1
+        const float* y = dot == 0 ? t2 : (dot == 1 ? t1 + 128 : t2 + 128);     // k2 | q1 | q2 | q2
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float4 xa = *(const float4*)(x + part * 32 + v * 4), ya = *(const float4*)(y + part * 32 + v * 4);
+            acc = fmaf(xa.x, ya.x, acc), acc = fmaf(xa.y, ya.y, acc), acc = fmaf(xa.z, ya.z, acc), acc = fmaf(xa.w, ya.w, acc);
+        }
+        acc = xadd2(xadd1(acc));
+        if (part == 0) s_tile[buf][(2 * pair) * DNP_SLOT + DNP_X + dot] = acc;
+    };
 
     load_tile(0);
-    load_scalars(0);
     store_tile(0);
+    __syncthreads();
+    cross_dots(0);
     __syncthreads();
     for (uint32_t t0 = 0; t0 < suffix_len; t0 += DNP_TILE) {
         const int buf = (t0 / DNP_TILE) & 1;
         const bool more = t0 + DNP_TILE < suffix_len;
-        if (more) {
-            load_tile(t0 + DNP_TILE);
-            load_scalars(t0 + DNP_TILE);
-        }
+        if (more) load_tile(t0 + DNP_TILE);
         const uint32_t steps = suffix_len - t0 < (uint32_t)DNP_TILE ? suffix_len - t0 : (uint32_t)DNP_TILE;
         const float* base = s_tile[buf];
-        float4 k4 = *(const float4*)(base + sl * 4), q4 = *(const float4*)(base + 128 + sl * 4);
-        float decay = base[DNP_QK], beta = base[DNP_QK + 1], v_val = base[DNP_QK + 2 + hw];
-        for (uint32_t t = 0; t < steps; ++t) {
-            const float kf[4] = {k4.x, k4.y, k4.z, k4.w}, qf[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float decay_t = decay, beta_t = beta, v_t = v_val;
-            if (t + 1 < steps) { // operands of the next step: issued before this step's dependent chain
-                const float* nx = base + (size_t)(t + 1) * DNP_SLOT;
-                k4 = *(const float4*)(nx + sl * 4), q4 = *(const float4*)(nx + 128 + sl * 4);
-                decay = nx[DNP_QK], beta = nx[DNP_QK + 1], v_val = nx[DNP_QK + 2 + hw];
-            }
-            float kv_mem = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) kv_mem = fmaf(decay_t * s4[e], kf[e], kv_mem);
-            kv_mem = group_sum<32>(kv_mem);
-            const float delta = beta_t * (v_t - kv_mem);
-            float o_val = 0.f;
+        uint32_t t = 0;
+        for (; t + 1 < steps; t += 2) { // ---- two tokens per step
+            const float* p1 = base + (size_t)t * DNP_SLOT;
+            const float* p2 = p1 + DNP_SLOT;
+            const float4 k1 = *(const float4*)(p1 + sl * 4), q1 = *(const float4*)(p1 + 128 + sl * 4);
+            const float4 k2 = *(const float4*)(p2 + sl * 4), q2 = *(const float4*)(p2 + 128 + sl * 4);
+            const float a1 = p1[DNP_QK], b1 = p1[DNP_QK + 1], v1 = p1[DNP_QK + 2 + hw];
+            const float a2 = p2[DNP_QK], b2 = p2[DNP_QK + 1], v2 = p2[DNP_QK + 2 + hw];
+            const float ckk = p1[DNP_X], ck1q1 = p1[DNP_X + 1], ck1q2 = p1[DNP_X + 2], ck2q2 = p1[DNP_X + 3];
+            const float k1f[4] = {k1.x, k1.y, k1.z, k1.w}, k2f[4] = {k2.x, k2.y, k2.z, k2.w};
+            const float q1f[4] = {q1.x, q1.y, q1.z, q1.w}, q2f[4] = {q2.x, q2.y, q2.z, q2.w};
+            float sk1 = 0.f, sk2 = 0.f, sq1 = 0.f, sq2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s4[e] = decay_t * s4[e] + kf[e] * delta;
-                o_val = fmaf(s4[e], qf[e], o_val);
+                sk1 = fmaf(s4[e], k1f[e], sk1);
+                sk2 = fmaf(s4[e], k2f[e], sk2);
+                sq1 = fmaf(s4[e], q1f[e], sq1);
+                sq2 = fmaf(s4[e], q2f[e], sq2);
             }
-            o_val = group_sum<32>(o_val);
-            if (sl == 0) out[(size_t)(t0 + t) * value_dim + hv * head_v_dim + i] = f32_to_bf16(o_val);
+            sk1 = group_sum<32>(sk1), sk2 = group_sum<32>(sk2), sq1 = group_sum<32>(sq1), sq2 = group_sum<32>(sq2);
+            const float d1 = b1 * (v1 - a1 * sk1);
+            const float d2 = b2 * (v2 - a2 * (a1 * sk2 + d1 * ckk));
+            const float o1 = a1 * sq1 + d1 * ck1q1;
+            const float o2 = a2 * (a1 * sq2 + d1 * ck1q2) + d2 * ck2q2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = a2 * (a1 * s4[e] + d1 * k1f[e]) + d2 * k2f[e];
+            if (sl == 0) {
+                orow[(size_t)(t0 + t) * value_dim] = f32_to_bf16(o1);
+                orow[(size_t)(t0 + t + 1) * value_dim] = f32_to_bf16(o2);
+            }
         }
-        if (more) store_tile(buf ^ 1);
+        if (t < steps) { // ---- odd tail of the tile: the one-token recurrence
+            const float* p1 = base + (size_t)t * DNP_SLOT;
+            const float4 k1 = *(const float4*)(p1 + sl * 4), q1 = *(const float4*)(p1 + 128 + sl * 4);
+            const float a1 = p1[DNP_QK], b1 = p1[DNP_QK + 1], v1 = p1[DNP_QK + 2 + hw];
+            const float k1f[4] = {k1.x, k1.y, k1.z, k1.w}, q1f[4] = {q1.x, q1.y, q1.z, q1.w};
+            float sk1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sk1 = fmaf(s4[e], k1f[e], sk1);
+            sk1 = group_sum<32>(sk1);
+            const float d1 = b1 * (v1 - a1 * sk1);
+            float o1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s4[e] = a1 * s4[e] + d1 * k1f[e];
+                o1 = fmaf(s4[e], q1f[e], o1);
+            }
+            o1 = group_sum<32>(o1);
+            if (sl == 0) orow[(size_t)(t0 + t) * value_dim] = f32_to_bf16(o1);
+        }
         __syncthreads();
+        if (more) {
+            store_tile(buf ^ 1);
+            __syncthreads();
+            cross_dots(buf ^ 1);
+            __syncthreads();
+        }
     }
     sv.x = s4[0], sv.y = s4[1], sv.z = s4[2], sv.w = s4[3];
     *srow = sv;
