@@ -19,8 +19,8 @@
 //   * The k order inside an MFMA is irrelevant as long as A and B agree, so the kernel picks the order that makes
 //     the weight fetch one 16-byte vector per lane: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take
 //     k = 32+8s..32+8s+7 at step s of a 64-wide k-step.
-//   * Row sums of the activations per quant group come for free from the staging threads (each holds 32 consecutive
-//     k of one row).
+//   * Row sums of the activations per quant group come from the matrix cores as well (one extra MFMA per k16 step with
+//     an all-ones B operand): the result lands in the accumulator layout the group fold needs.
 #include <stdlib.h>
 
 #include "device_utils.h"
@@ -74,13 +74,16 @@ __device__ __forceinline__ float chunk_sum(uint4 v) { // sum of 8 bf16
 } // namespace
 
 template <int BITS, int MB, int NB> // a wave owns MB x NB blocks of 32 x 32; four waves as 2 x 2 => workgroup tile (64 MB) x (64 NB)
-__global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
+__global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p, uint32_t lds_groups) {
     constexpr int BM = 64 * MB, BN = 64 * NB;
     constexpr int PARTS = 256 / BM;        // staging threads per activation row (2 or 4)
     constexpr int CH = 8 / PARTS;          // 16-byte chunks (8 k) per staging thread per k-step
     constexpr int WV = BITS / 4; // 16-byte vectors of codes per lane per 32-column block per k-step
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
-    __shared__ __attribute__((aligned(16))) float s_asum[2][BM];
+    // dequantised weight fragments in MFMA operand order, shared by the two waves that cover the same 32 columns:
+    // [buffer][column half wn][k16 step][lane] x 16 bytes.  Each of those two waves converts half of the steps.
+    __shared__ __attribute__((aligned(16))) uint4 s_b[2][2][4][64];
+    static_assert(MB == 1 && NB == 1, "the shared-fragment path assumes one 32 x 32 block per wave");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l32 = lane & 31;
@@ -110,22 +113,10 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
             for (int j = 0; j < CH; ++j) st[j] = make_uint4(0, 0, 0, 0);
         }
     };
-    float asum_run = 0.f;
     auto stage_a = [&](uint32_t kt, const uint4 (&st)[CH]) { // st holds k-step kt
         uint8_t* dst = (kt & 1) ? a_dst1 : a_dst0;
-        float part_sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            part_sum += chunk_sum(st[j]);
-            *(uint4*)(dst + 16 * j) = st[j];
-        }
-        asum_run += part_sum;
-        if ((kt + 1) % gs == 0) { // last k-step of its group: publish the row sum of the group
-            float total = xadd1(asum_run);
-            if (PARTS == 4) total = xadd2(total);
-            if (!part) s_asum[(kt / gs) & 1][ra] = total;
-            asum_run = 0.f;
-        }
+        for (int j = 0; j < CH; ++j) *(uint4*)(dst + 16 * j) = st[j];
     };
 
     // ---- compute role
@@ -137,29 +128,53 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         ncol[nb] = n < N ? n : N - 1;
         w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)(32 * half) * BITS / 8;
     }
-    uint4 w_st[D][NB][WV];
-    auto load_w = [&](uint32_t kt, uint4 (&w)[NB][WV]) {
+    // wave (wm, wn) converts k16 steps 2 wm and 2 wm + 1 of its 32 columns: 16 codes per lane per k-step
+    uint2 w_st[D][WV];
+    auto load_w = [&](uint32_t kt, uint2 (&w)[WV]) {
         if (kt >= KT) return;
+        const uint8_t* src = w_src[0] + (size_t)kt * BK * BITS / 8 + (size_t)wm * 2 * BITS; // 16 codes = 2 * BITS bytes
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const uint4* src = (const uint4*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
-#pragma unroll
-            for (int v = 0; v < WV; ++v) w[nb][v] = src[v];
-        }
+        for (int v = 0; v < WV; ++v) w[v] = ((const uint2*)src)[v];
     };
     // unsigned code q (after the optional `signed_codes` flip of the top bit, kernel.rs:268-275) -> two's complement of q - 2^(bits-1)
     const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
 
-    f32x16_t acc_g[MB][NB], acc_t[MB][NB];
+    // acc_s: the group's activation row sums, produced by the matrix cores too (B = all ones): it comes out in the
+    // accumulator layout the group fold needs (16 rows per lane) -- no VALU adds, no LDS exchange
+    f32x16_t acc_g[MB][NB], acc_t[MB][NB], acc_s[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_g[mb][nb][r] = 0.f, acc_t[mb][nb][r] = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_s[mb][r] = 0.f;
+    const u32x4_t ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; // eight bf16 1.0
 
+    // Group scales / offsets of the tile's BN columns: staged once in LDS ([group][column], scale | offset << 16) when
+    // they fit (`lds_groups` != 0) -- a per-group global load issued one group ahead is consumed two k-steps later,
+    // far inside the ~1 us load latency; otherwise (very long K) they are fetched per group as before.
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_sc[];
+    const bool sc_lds = lds_groups != 0;
+    if (sc_lds) {
+        for (uint32_t idx = tid; idx < G * BN; idx += 256) {
+            const uint32_t col = idx % BN, g = idx / BN;
+            const uint32_t n = n0 + col < N ? n0 + col : N - 1;
+            uint32_t v = ((const uint16_t*)p.scales)[(size_t)n * G + g];
+            if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) v |= (uint32_t)((const uint16_t*)p.biases)[(size_t)n * G + g] << 16;
+            else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                const uint8_t z = p.zero_points[(size_t)n * zp_stride + (BITS == 4 ? (g >> 1) : g)];
+                v |= (uint32_t)(BITS == 4 ? ((g & 1) ? (z >> 4) : (z & 0xF)) : z) << 16;
+            }
+            s_sc[g * BN + col] = v;
+        }
+    }
     uint16_t sc_raw[NB] = {}, of_raw[NB] = {};
     auto load_group = [&](uint32_t g) {
+        if (sc_lds) return;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             sc_raw[nb] = ((const uint16_t*)p.scales)[(size_t)ncol[nb] * G + g];
@@ -171,21 +186,25 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
         }
     };
 
-    // one k-step: MFMAs from LDS buffer kt & 1 and the weight registers of stage `w`
-    auto compute = [&](uint32_t kt, const uint4 (&w)[NB][WV]) {
+    // conversion of this wave's two k16 steps of k-step kt into the shared fragment buffer
+    auto stage_b = [&](uint32_t kt, const uint2 (&w)[WV]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4_t f;
+            if (BITS == 4) f = dequant4((j ? w[0].y : w[0].x) ^ flip);
+            else f = dequant8(w[j].x ^ flip, w[j].y ^ flip);
+            s_b[kt & 1][wn][2 * wm + j][lane] = make_uint4(f.x, f.y, f.z, f.w);
+        }
+    };
+    // one k-step: MFMAs from the LDS buffers kt & 1
+    auto compute = [&](uint32_t kt) {
         const uint8_t* a_base = &s_a[kt & 1][(wm * (32 * MB) + l32) * A_PITCH + half * 64];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4_t bfrag[NB], afrag[MB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (BITS == 4) {
-                    const uint32_t ws[4] = {w[nb][0].x, w[nb][0].y, w[nb][0].z, w[nb][0].w};
-                    bfrag[nb] = dequant4(ws[s] ^ flip);
-                } else {
-                    const uint4 v = w[nb][s >> 1];
-                    bfrag[nb] = (s & 1) ? dequant8(v.z ^ flip, v.w ^ flip) : dequant8(v.x ^ flip, v.y ^ flip);
-                }
+            {
+                const uint4 t = s_b[kt & 1][wn][s][lane];
+                bfrag[0] = u32x4_t{t.x, t.y, t.z, t.w};
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -193,40 +212,42 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
                 afrag[mb] = u32x4_t{t.x, t.y, t.z, t.w};
             }
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, afrag[mb]), __builtin_bit_cast(bf16x8_t, bfrag[nb]),
                                                                            acc_g[mb][nb], 0, 0, 0);
+                acc_s[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, afrag[mb]), __builtin_bit_cast(bf16x8_t, ones), acc_s[mb], 0, 0, 0);
+            }
         }
         if ((kt + 1) % gs == 0) { // group boundary: fold the group accumulator into the total with the f32 scale
             const uint32_t g = kt / gs;
-            const float* asum = s_asum[g & 1];
             float sc[NB], coef[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const float scale = bf16_to_f32(sc_raw[nb]);
+                uint16_t sr = sc_raw[nb], orw = of_raw[nb];
+                if (sc_lds) {
+                    const uint32_t v = s_sc[g * BN + wn * (32 * NB) + nb * 32 + l32];
+                    sr = (uint16_t)(v & 0xFFFFu), orw = (uint16_t)(v >> 16);
+                }
+                const float scale = bf16_to_f32(sr);
                 const float mid = (float)(1u << (BITS - 1)); // the codes were fed centred: q - mid (int4: divided by 16)
-                if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) coef[nb] = fmaf(mid, scale, bf16_to_f32(of_raw[nb]));
-                else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) coef[nb] = scale * (mid - (float)of_raw[nb]);
+                if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) coef[nb] = fmaf(mid, scale, bf16_to_f32(orw));
+                else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) coef[nb] = scale * (mid - (float)orw);
                 else coef[nb] = 0.0f;
                 sc[nb] = BITS == 4 ? 16.0f * scale : scale;
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                float as[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 t = *(const float4*)(asum + wm * (32 * MB) + mb * 32 + 8 * j + 4 * half);
-                    as[4 * j] = t.x, as[4 * j + 1] = t.y, as[4 * j + 2] = t.z, as[4 * j + 3] = t.w;
-                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        acc_t[mb][nb][r] = fmaf(sc[nb], acc_g[mb][nb][r], fmaf(coef[nb], as[r], acc_t[mb][nb][r]));
+                        acc_t[mb][nb][r] = fmaf(sc[nb], acc_g[mb][nb][r], fmaf(coef[nb], acc_s[mb][r], acc_t[mb][nb][r]));
                         acc_g[mb][nb][r] = 0.f;
                     }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_s[mb][r] = 0.f;
             }
             if (g + 1 < G) load_group(g + 1);
         }
@@ -242,16 +263,22 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p) {
     }
     load_group(0);
     stage_a(0, a_st[0]);
+    stage_b(0, w_st[0]);
+    load_a(D, a_st[0]);
+    load_w(D, w_st[0]);
     __syncthreads();
     for (uint32_t kt0 = 0; kt0 < KT; kt0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const uint32_t kt = kt0 + u;
             if (kt < KT) {
-                compute(kt, w_st[u]);
-                if (kt + 1 < KT) stage_a(kt + 1, a_st[(u + 1) % D]);
-                load_a(kt + D, a_st[u]); // a_st[u] went to LDS one iteration ago, w_st[u] was consumed just now
-                load_w(kt + D, w_st[u]);
+                compute(kt);
+                if (kt + 1 < KT) { // operands of k-step kt + 1 (requested D iterations ago): registers -> the other LDS buffers
+                    stage_a(kt + 1, a_st[(u + 1) % D]);
+                    stage_b(kt + 1, w_st[(u + 1) % D]);
+                }
+                load_a(kt + 1 + D, a_st[(u + 1) % D]);
+                load_w(kt + 1 + D, w_st[(u + 1) % D]);
             }
             __syncthreads();
         }
@@ -299,8 +326,12 @@ bool gemm_q_mfma_supported(const MatmulParams& p) {
 
 template <int MB, int NB> static uzu_status launch_gemm(hipStream_t s, const MatmulParams& p) {
     const dim3 grid((p.n + 64 * NB - 1) / (64 * NB), (p.m + 64 * MB - 1) / (64 * MB));
-    if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<4, MB, NB>), grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
-    return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<8, MB, NB>), grid, dim3(256), 0, s, p); }, "gemm_q_mfma");
+    const uint32_t groups = p.k / p.group_size;
+    const size_t sc_bytes = (size_t)groups * 64 * NB * 4;
+    const uint32_t lds_groups = sc_bytes <= 16 * 1024 ? groups : 0; // 18 KB + 16 KB static: three workgroups per CU stay resident
+    const size_t dyn = lds_groups ? sc_bytes : 0;
+    if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<4, MB, NB>), grid, dim3(256), dyn, s, p, lds_groups); }, "gemm_q_mfma");
+    return launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma_kernel<8, MB, NB>), grid, dim3(256), dyn, s, p, lds_groups); }, "gemm_q_mfma");
 }
 // Tile choice: the 128 x 128 workgroup tile needs 304 VGPRs (one wave per SIMD: nothing hides the operand latency);
 // 64 x 64 runs four waves per SIMD and is 1.4-1.7x faster from 1024 x 1024 x 2048 up to 4096 x 14336 x 4096.
@@ -311,7 +342,6 @@ uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus) {
     }();
     (void)num_cus;
     switch (force) { // tools/kbench KB_GEMM sweep: 64 x 64 tiles (108 VGPRs, 4 waves / SIMD) win at every shape tried
-    case 128: return launch_gemm<2, 2>(s, p);
     default: return launch_gemm<1, 1>(s, p);
     }
 }
