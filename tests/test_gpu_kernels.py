@@ -508,10 +508,12 @@ def test_delta_net_update(hip_ctx):
     assert ulp_diff_bf16(want, got).max() <= 2.0
 
 
-def test_delta_net_prefill_path(hip_ctx):
-    """conv_pack -> conv_scan -> prefill_prep -> prefill -> norm_gate against the oracle (GQA-style Hv = 2 Hk)."""
+@pytest.mark.parametrize("T", [37, 64, 200, 1000])
+def test_delta_net_prefill_path(hip_ctx, T):
+    """conv_pack -> conv_scan -> prefill_prep -> prefill -> norm_gate against the oracle (GQA-style Hv = 2 Hk).
+    T = 37 runs the one/two-token recurrence, T >= 64 the chunked form (32-token chunks, ragged last chunk)."""
     rng = np.random.default_rng(15)
-    Hv, Hk, Dk, Dv, ks, T = 4, 2, 128, 128, 4, 37
+    Hv, Hk, Dk, Dv, ks = 4, 2, 128, 128, 4
     key_dim, value_dim = Hk * Dk, Hv * Dv
     conv_dim = 2 * key_dim + value_dim
     total = conv_dim + value_dim + 2 * Hv

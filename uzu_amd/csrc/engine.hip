@@ -93,6 +93,7 @@ struct uzu_hip_model {
     bool fusable = false;
     uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
     float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
+    float* dn_ws = nullptr; // chunked DeltaNet prefill: T / P matrices of one 1024-token pass (k_deltanet_chunk.hip)
     float *dn_o = nullptr, *dn_sz = nullptr; // raw DeltaNet outputs and SiLU(z) of the decode token (f32 [value_dim])
     uint32_t dec_splits = 0;
     float* amax_val = nullptr;
@@ -337,7 +338,11 @@ void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
         RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, m->in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
                                      total_proj_dim));
         RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, m->in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
-        RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
+        if (m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch))
+            RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, m->dn_ws, Hv, Hk, Dv,
+                                                                          key_dim, value_dim, batch));
+        else
+            RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
         RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
     }
     linear(e, L.out_proj, m->delta_out, out, batch, true);
@@ -762,6 +767,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     if (max_proj) {
         ALLOC(in_proj, uint16_t, C * max_proj);
         ALLOC(delta_out, uint16_t, C * max_value);
+        ALLOC(dn_ws, float, k::delta_net_chunk_workspace_bytes(max_hv, (uint32_t)C) / sizeof(float));
         ALLOC(dn_o, float, max_value);
         ALLOC(dn_sz, float, max_value);
         ALLOC(padded, float, (C + 8) * max_proj);

@@ -138,6 +138,12 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
                              const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
                              uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
                              uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+// chunked form (k_deltanet_chunk.hip): 32-token chunks, T / P matrices built in parallel, four dense products per chunk
+bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len);
+size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t suffix_len);
+uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
+                                     float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                     uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
                                uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
                                uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
