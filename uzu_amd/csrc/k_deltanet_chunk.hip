@@ -26,7 +26,6 @@ constexpr int CC = 32;        // tokens per chunk
 constexpr int DKC = 128;      // head_k_dim
 constexpr int KP = DKC + 4;   // LDS row pitch of K / Q / S rows in floats (conflict-free b128 reads across rows)
 constexpr int TP = CC + 1;    // LDS row pitch of the 32 x 32 matrices
-constexpr int DVS = 16;       // value columns per scan workgroup
 constexpr int WS_FLOATS = 2 * CC * CC + 2 * CC; // per (chunk, value head): T, P, A, W
 } // namespace
 
@@ -72,6 +71,7 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
     {
         const int i = tid >> 3, j0 = (tid & 7) * 4;
         float kk[4] = {0.f, 0.f, 0.f, 0.f}, qk[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int d4 = 0; d4 < DKC; d4 += 4) {
             const float4 ki = *(const float4*)(sK + i * KP + d4), qi = *(const float4*)(sQ + i * KP + d4);
 #pragma unroll
@@ -112,13 +112,18 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
     }
 }
 
-// grid (Dv / DVS, Hv), 256 threads; walks the chunks sequentially
+// grid (Dv / DVS, Hv), 256 threads; walks the chunks sequentially.  The operands of chunk c + 1 are requested from
+// memory while chunk c is computed (registers), and moved to LDS between two barriers at the chunk boundary.
+template <int DVS>
 __global__ void __launch_bounds__(256) dn_chunk_scan_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
                                                             uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
                                                             uint32_t value_dim, uint32_t suffix_len) {
+    constexpr int NV = DVS / 8;          // value columns per thread in the token-major products (stages 1-3)
+    constexpr int SD = DVS * DKC / 256;  // state elements per thread (stage 4): 4 or 8 consecutive dk
+    constexpr int RP = DVS + 1;          // LDS pitch of R / D
     __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVS * KP];
     __shared__ float sT[CC * TP], sP[CC * TP];
-    __shared__ float sR[CC * (DVS + 1)], sD[CC * (DVS + 1)];
+    __shared__ float sR[CC * RP], sD[CC * RP];
     __shared__ float sA[CC], sW[CC];
     const int tid = threadIdx.x;
     const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVS, hk = hv / (num_v_heads / num_k_heads);
@@ -126,98 +131,134 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_kernel(const float* q_norm,
     const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
 
-    // state slice: thread -> (dv = tid / 16, 8 consecutive dk): registers for the whole scan, mirrored in LDS per chunk
-    const int s_dv = tid >> 4, s_dk = (tid & 15) * 8;
+    // state slice: thread -> (dv, SD consecutive dk): registers for the whole scan, mirrored in LDS per chunk
+    const int s_dv = tid / (DKC / SD), s_dk = (tid % (DKC / SD)) * SD;
     float* srow = state + ((size_t)hv * head_v_dim + dv_base + s_dv) * DKC + s_dk;
-    float sreg[8];
-    {
-        const float4 a = *(const float4*)srow, b = *(const float4*)(srow + 4);
-        sreg[0] = a.x, sreg[1] = a.y, sreg[2] = a.z, sreg[3] = a.w, sreg[4] = b.x, sreg[5] = b.y, sreg[6] = b.z, sreg[7] = b.w;
+    float sreg[SD];
+#pragma unroll
+    for (int e = 0; e < SD; e += 4) {
+        const float4 a = *(const float4*)(srow + e);
+        sreg[e] = a.x, sreg[e + 1] = a.y, sreg[e + 2] = a.z, sreg[e + 3] = a.w;
     }
-    // product mapping of stages 1-3: thread -> (token t = tid / 8, two value columns dvc, dvc + 1)
-    const int p_t = tid >> 3, p_dv = (tid & 7) * 2;
+    // product mapping of stages 1-3: thread -> (token t = tid / 8, NV value columns)
+    const int p_t = tid >> 3, p_dv = (tid & 7) * NV;
 
-    for (uint32_t c = 0; c < n_chunks; ++c) {
+    // ---- operand staging: registers <- memory (chunk c), LDS <- registers
+    float4 st_k[4], st_q[4];
+    float st_t[4], st_p[4], st_a = 0.f, st_w = 0.f, st_v[NV];
+    auto fetch = [&](uint32_t c) {
         const uint32_t t0 = c * CC;
         const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
-        // ---- stage 0: operands of the chunk into LDS
-        for (int idx = tid; idx < CC * (DKC / 4); idx += 256) {
-            const int t = idx / (DKC / 4), c4 = idx % (DKC / 4);
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), qv = kv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            st_k[r] = make_float4(0.f, 0.f, 0.f, 0.f), st_q[r] = st_k[r];
             if (t0 + t < suffix_len) {
-                kv = *(const float4*)(k_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
-                qv = *(const float4*)(q_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
+                st_k[r] = *(const float4*)(k_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
+                st_q[r] = *(const float4*)(q_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
             }
-            *(float4*)(sK + t * KP + c4 * 4) = kv;
-            *(float4*)(sQ + t * KP + c4 * 4) = qv;
+            st_t[r] = w_t[idx], st_p[r] = w_t[CC * CC + idx];
         }
-        for (int idx = tid; idx < CC * CC; idx += 256) {
-            sT[(idx / CC) * TP + idx % CC] = w_t[idx];
-            sP[(idx / CC) * TP + idx % CC] = w_t[CC * CC + idx];
-        }
-        if (tid < CC) sA[tid] = w_t[2 * CC * CC + tid], sW[tid] = w_t[2 * CC * CC + CC + tid];
-        *(float4*)(sS + s_dv * KP + s_dk) = make_float4(sreg[0], sreg[1], sreg[2], sreg[3]);
-        *(float4*)(sS + s_dv * KP + s_dk + 4) = make_float4(sreg[4], sreg[5], sreg[6], sreg[7]);
-        float v0 = 0.f, v1 = 0.f;
+        if (tid < CC) st_a = w_t[2 * CC * CC + tid], st_w = w_t[2 * CC * CC + CC + tid];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) st_v[j] = 0.f;
         if (t0 + p_t < suffix_len) {
             const uint16_t* vp = in_proj + (size_t)(t0 + p_t) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + p_dv;
-            v0 = bf16_to_f32(vp[0]), v1 = bf16_to_f32(vp[1]);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) st_v[j] = bf16_to_f32(vp[j]);
         }
-        __syncthreads();
-        // ---- stage 1: K S^T and Q S^T for (t, dv..dv+1); R = V - A K S^T
-        float ks0 = 0.f, ks1 = 0.f, qs0 = 0.f, qs1 = 0.f;
+    };
+    float vreg[NV];
+    auto publish = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            *(float4*)(sK + t * KP + c4 * 4) = st_k[r];
+            *(float4*)(sQ + t * KP + c4 * 4) = st_q[r];
+            sT[(idx / CC) * TP + idx % CC] = st_t[r];
+            sP[(idx / CC) * TP + idx % CC] = st_p[r];
+        }
+        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
+#pragma unroll
+        for (int e = 0; e < SD; e += 4) *(float4*)(sS + s_dv * KP + s_dk + e) = make_float4(sreg[e], sreg[e + 1], sreg[e + 2], sreg[e + 3]);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) vreg[j] = st_v[j];
+    };
+
+    fetch(0);
+    publish();
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t t0 = c * CC;
+        if (c + 1 < n_chunks) fetch(c + 1);
+        // ---- stage 1: K S^T and Q S^T for (t, NV value columns); R = V - A K S^T
+        float ks[NV], qs[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) ks[j] = 0.f, qs[j] = 0.f;
+#pragma unroll 8
         for (int d4 = 0; d4 < DKC; d4 += 4) {
             const float4 kt = *(const float4*)(sK + p_t * KP + d4), qt = *(const float4*)(sQ + p_t * KP + d4);
-            const float4 sa = *(const float4*)(sS + p_dv * KP + d4), sb = *(const float4*)(sS + (p_dv + 1) * KP + d4);
-            ks0 = fmaf(kt.x, sa.x, ks0), ks0 = fmaf(kt.y, sa.y, ks0), ks0 = fmaf(kt.z, sa.z, ks0), ks0 = fmaf(kt.w, sa.w, ks0);
-            ks1 = fmaf(kt.x, sb.x, ks1), ks1 = fmaf(kt.y, sb.y, ks1), ks1 = fmaf(kt.z, sb.z, ks1), ks1 = fmaf(kt.w, sb.w, ks1);
-            qs0 = fmaf(qt.x, sa.x, qs0), qs0 = fmaf(qt.y, sa.y, qs0), qs0 = fmaf(qt.z, sa.z, qs0), qs0 = fmaf(qt.w, sa.w, qs0);
-            qs1 = fmaf(qt.x, sb.x, qs1), qs1 = fmaf(qt.y, sb.y, qs1), qs1 = fmaf(qt.z, sb.z, qs1), qs1 = fmaf(qt.w, sb.w, qs1);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float4 sv = *(const float4*)(sS + (p_dv + j) * KP + d4);
+                ks[j] = fmaf(kt.x, sv.x, ks[j]), ks[j] = fmaf(kt.y, sv.y, ks[j]), ks[j] = fmaf(kt.z, sv.z, ks[j]), ks[j] = fmaf(kt.w, sv.w, ks[j]);
+                qs[j] = fmaf(qt.x, sv.x, qs[j]), qs[j] = fmaf(qt.y, sv.y, qs[j]), qs[j] = fmaf(qt.z, sv.z, qs[j]), qs[j] = fmaf(qt.w, sv.w, qs[j]);
+            }
         }
         const float a_t = sA[p_t];
-        sR[p_t * (DVS + 1) + p_dv] = v0 - a_t * ks0;
-        sR[p_t * (DVS + 1) + p_dv + 1] = v1 - a_t * ks1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sR[p_t * RP + p_dv + j] = vreg[j] - a_t * ks[j];
         __syncthreads();
         // ---- stage 2: D = T R (T is lower triangular; the stored zeros keep the trip count fixed)
-        float d0 = 0.f, d1 = 0.f;
+        float dd[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) dd[j] = 0.f;
 #pragma unroll 8
         for (int i = 0; i < CC; ++i) {
             const float tv = sT[p_t * TP + i];
-            d0 = fmaf(tv, sR[i * (DVS + 1) + p_dv], d0);
-            d1 = fmaf(tv, sR[i * (DVS + 1) + p_dv + 1], d1);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dd[j] = fmaf(tv, sR[i * RP + p_dv + j], dd[j]);
         }
-        sD[p_t * (DVS + 1) + p_dv] = d0;
-        sD[p_t * (DVS + 1) + p_dv + 1] = d1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sD[p_t * RP + p_dv + j] = dd[j];
         __syncthreads();
         // ---- stage 3: O = A Q S^T + P D
-        float o0 = a_t * qs0, o1 = a_t * qs1;
+        float oo[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) oo[j] = a_t * qs[j];
 #pragma unroll 8
         for (int i = 0; i < CC; ++i) {
             const float pv = sP[p_t * TP + i];
-            o0 = fmaf(pv, sD[i * (DVS + 1) + p_dv], o0);
-            o1 = fmaf(pv, sD[i * (DVS + 1) + p_dv + 1], o1);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) oo[j] = fmaf(pv, sD[i * RP + p_dv + j], oo[j]);
         }
         if (t0 + p_t < suffix_len) {
-            const uint32_t packed = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
-            *(uint32_t*)(out + (size_t)(t0 + p_t) * value_dim + hv * head_v_dim + dv_base + p_dv) = packed;
+            uint16_t* op = out + (size_t)(t0 + p_t) * value_dim + hv * head_v_dim + dv_base + p_dv;
+            if (NV == 2) *(uint32_t*)op = (uint32_t)f32_to_bf16(oo[0]) | ((uint32_t)f32_to_bf16(oo[NV - 1]) << 16);
+            else op[0] = f32_to_bf16(oo[0]);
         }
-        // ---- stage 4: S = A_C S + D^T diag(W) K for (dv, 8 dk)
+        // ---- stage 4: S = A_C S + D^T diag(W) K for (dv, SD dk)
         {
             const float a_c = sA[CC - 1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sreg[e] *= a_c;
-#pragma unroll 4
+            for (int e = 0; e < SD; ++e) sreg[e] *= a_c;
+#pragma unroll 8
             for (int i = 0; i < CC; ++i) {
-                const float dw = sD[i * (DVS + 1) + s_dv] * sW[i];
-                const float4 ka = *(const float4*)(sK + i * KP + s_dk), kb = *(const float4*)(sK + i * KP + s_dk + 4);
-                sreg[0] = fmaf(dw, ka.x, sreg[0]), sreg[1] = fmaf(dw, ka.y, sreg[1]), sreg[2] = fmaf(dw, ka.z, sreg[2]), sreg[3] = fmaf(dw, ka.w, sreg[3]);
-                sreg[4] = fmaf(dw, kb.x, sreg[4]), sreg[5] = fmaf(dw, kb.y, sreg[5]), sreg[6] = fmaf(dw, kb.z, sreg[6]), sreg[7] = fmaf(dw, kb.w, sreg[7]);
+                const float dw = sD[i * RP + s_dv] * sW[i];
+#pragma unroll
+                for (int e = 0; e < SD; e += 4) {
+                    const float4 kv = *(const float4*)(sK + i * KP + s_dk + e);
+                    sreg[e] = fmaf(dw, kv.x, sreg[e]), sreg[e + 1] = fmaf(dw, kv.y, sreg[e + 1]), sreg[e + 2] = fmaf(dw, kv.z, sreg[e + 2]),
+                    sreg[e + 3] = fmaf(dw, kv.w, sreg[e + 3]);
+                }
             }
         }
-        __syncthreads(); // every LDS array is rewritten by the next chunk's stage 0
+        __syncthreads(); // all reads of this chunk's LDS operands are done
+        if (c + 1 < n_chunks) publish();
+        __syncthreads();
     }
-    *(float4*)srow = make_float4(sreg[0], sreg[1], sreg[2], sreg[3]);
-    *(float4*)(srow + 4) = make_float4(sreg[4], sreg[5], sreg[6], sreg[7]);
+#pragma unroll
+    for (int e = 0; e < SD; e += 4) *(float4*)(srow + e) = make_float4(sreg[e], sreg[e + 1], sreg[e + 2], sreg[e + 3]);
 }
 
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
@@ -225,7 +266,7 @@ bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_he
         const char* e = getenv("UZU_DN_CHUNK_MIN_T");
         return e ? (uint32_t)atoi(e) : 64u;
     }();
-    return head_k_dim == DKC && num_k_heads && num_v_heads % num_k_heads == 0 && head_v_dim % DVS == 0 && suffix_len >= min_t;
+    return head_k_dim == DKC && num_k_heads && num_v_heads % num_k_heads == 0 && head_v_dim % 16 == 0 && suffix_len >= min_t;
 }
 
 uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
@@ -236,8 +277,19 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         hipLaunchKernelGGL(dn_chunk_prep_kernel, dim3(n_chunks, num_v_heads), dim3(256), 0, s, q_norm, k_norm, beta, decay, workspace, num_v_heads, num_k_heads,
                            key_dim, suffix_len);
     }, "delta_net_chunk_prep"));
+    // 8 value columns per workgroup when that is what it takes to give every CU a workgroup (Hv * Dv / 8 = 256 at 0.8B)
+    static const int force = [] {
+        const char* e = getenv("UZU_DN_CHUNK_DVS");
+        return e ? atoi(e) : 0;
+    }();
+    const bool narrow = force ? force == 8 : num_v_heads * (head_v_dim / 16) < 200;
+    if (narrow)
+        return launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_scan_kernel<8>, dim3(head_v_dim / 8, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
+                               num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+        }, "delta_net_chunk_scan");
     return launch_check([&] {
-        hipLaunchKernelGGL(dn_chunk_scan_kernel, dim3(head_v_dim / DVS, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
+        hipLaunchKernelGGL(dn_chunk_scan_kernel<16>, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
                            num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
     }, "delta_net_chunk_scan");
 }
