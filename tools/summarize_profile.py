@@ -38,7 +38,8 @@ def main():
     rnd, trace_dir, pmc_dir = sys.argv[1:4]
     mfma_dir = sys.argv[4] if len(sys.argv) > 4 else None
     os.makedirs("profiles", exist_ok=True)
-    stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)
+    newest = lambda pattern, d: sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True), key=os.path.getmtime)[-1:]  # gpurun merges, never deletes
+    stats = newest("*_kernel_stats.csv", trace_dir)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(f"profiles/{rnd}_kernel_stats.csv", "w", newline="") as f:
@@ -47,7 +48,7 @@ def main():
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], f"{int(r['TotalDurationNs']) / 1e3:.1f}", f"{float(r['AverageNs']) / 1e3:.3f}",
                             r["Percentage"], f"{int(r['MinNs']) / 1e3:.3f}", f"{int(r['MaxNs']) / 1e3:.3f}"])
-    pmc = glob.glob(os.path.join(pmc_dir, "**", "*_counter_collection.csv"), recursive=True)
+    pmc = newest("*_counter_collection.csv", pmc_dir)
     if pmc:
         agg = collections.defaultdict(lambda: [0, 0.0, 0])
         for r in csv.DictReader(open(pmc[0])):
@@ -66,7 +67,7 @@ def main():
                 w.writerow([k, grid, n, f"{total / n:.2f}", int(hbm), f"{dur / n / 1e3:.2f}"])
                 out[f"{k}|{grid}"] = int(hbm)
         json.dump(out, open(f"profiles/{rnd}_pmc_fetch.json", "w"), indent=1, sort_keys=True)
-    mf = glob.glob(os.path.join(mfma_dir, "**", "*_counter_collection.csv"), recursive=True) if mfma_dir else []
+    mf = newest("*_counter_collection.csv", mfma_dir) if mfma_dir else []
     if mf:
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(mf[0])):
