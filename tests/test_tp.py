@@ -242,3 +242,24 @@ def test_tp_engine_path_world1_matches_single_gpu(hip_ctx, preset, flags):
     tp_model.close()
     group.close()
     plain.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_full_size_shard_shapes_execute(hip_ctx, size):
+    """Every kernel of the engine at the SHARD shapes of Qwen3.5-0.8B (tp 2 / 4 / 8: 1-4 q heads, 2-8 DeltaNet heads,
+    hidden 1792 / 896 / 512 with padding, K slices 1024 / 512 / 256) -- on one GPU with a one-rank communicator, so the
+    partial sums are not completed and the tokens mean nothing; the point is that no launch is rejected or faults,
+    in prefill (matrix-core GEMM, chunked DeltaNet, flash attention) and in graph-replayed decode."""
+    from uzu_amd.engine import HipModel
+    cfg = S.qwen35_0p8b(max_context_length=512)
+    bundle = S.build_model(cfg)
+    shard, off = TP.shard_bundle(bundle, size - 1, size)
+    group = TP.TpGroup(hip_ctx, 0, 1)
+    model = HipModel(hip_ctx, shard, 0, tp_group=group, vocab_offset=off)
+    first = model.prefill(S.synthetic_prompt(130, cfg.vocab_size))
+    toks, _ = model.decode(6)
+    assert off <= first < cfg.vocab_size and all(off <= int(t) < off + shard.output_embedding.n for t in toks)
+    assert model.logit_count == cfg.vocab_size // size
+    model.close()
+    group.close()
