@@ -334,9 +334,13 @@ void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
         RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, m->in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
                                   L.d.dn_norm_epsilon));
     } else {
-        RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, m->in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
-        RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, m->in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
-                                     total_proj_dim));
+        if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(kSuffixCapacity + 8) * total_proj_dim) {
+            RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, m->in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
+        } else {
+            RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, m->in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
+            RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, m->in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
+                                         total_proj_dim));
+        }
         RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, m->in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
         if (m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch))
             RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, m->dn_ws, Hv, Hk, Dv,

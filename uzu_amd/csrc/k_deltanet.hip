@@ -204,6 +204,83 @@ uzu_status delta_net_conv_scan(hipStream_t s, const float* conv_padded, const fl
     }, "delta_net_conv_scan");
 }
 
+// ---------------------------------------------------------------- fused Conv1dPack + DeltaNetConvScan (engine prefill)
+// The reference packs [state | suffix] into an f32 buffer (conv1d.rs:10-40) and convolves out of it (conv_scan.rs:32-73)
+// because the scan writes its result over its own input.  At a 1024-token chunk that buffer is 34 MB written and read
+// four times.  Same arithmetic without it: `conv_halo_kernel` saves the (kernel_size - 1) pre-conv rows in front of
+// every block of TBLK tokens (block 0: the carried state; plus the rows that become the next state), then
+// `conv_apply_kernel` gives every (block, channel) one thread that slides a register window down its block and writes
+// in place -- no thread reads a row another thread rewrites.
+namespace {
+constexpr int CONV_TBLK = 16;
+constexpr int CONV_MAXK = 8;
+// X[i] of the virtual sequence [state | suffix]: i in [-(ks-1), T)
+__device__ __forceinline__ float conv_x(const uint16_t* in_proj, const float* state, int i, uint32_t c, uint32_t ks, uint32_t out_stride) {
+    return i < 0 ? state[(size_t)c * (ks - 1) + (ks - 1) + i] : bf16_to_f32(in_proj[(size_t)i * out_stride + c]);
+}
+}
+// halo[b][tap][c], b in [0, nblocks]: rows X[b*TBLK - (ks-1) + tap]; slot nblocks holds the next state X[T - (ks-1) + tap]
+__global__ void __launch_bounds__(256) conv_halo_kernel(const uint16_t* in_proj, const float* state, float* halo, uint32_t suffix_len, uint32_t ks,
+                                                        uint32_t conv_dim, uint32_t out_stride, uint32_t nblocks) {
+    const uint32_t taps = ks - 1;
+    const size_t total = (size_t)(nblocks + 1) * taps * conv_dim;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t c = idx % conv_dim, tap = (idx / conv_dim) % taps, b = idx / ((size_t)conv_dim * taps);
+        const int base = b < nblocks ? (int)(b * CONV_TBLK) : (int)suffix_len;
+        halo[idx] = conv_x(in_proj, state, base - (int)taps + (int)tap, c, ks, out_stride);
+    }
+}
+__global__ void __launch_bounds__(256) conv_apply_kernel(uint16_t* in_proj, const float* conv_weight, const float* bias, const float* halo, float* state,
+                                                         uint32_t suffix_len, uint32_t ks, uint32_t conv_dim, uint32_t out_stride, uint32_t nblocks) {
+    const uint32_t taps = ks - 1;
+    const size_t total = (size_t)nblocks * conv_dim;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t c = idx % conv_dim, b = idx / conv_dim;
+        float w[CONV_MAXK], win[CONV_MAXK];
+#pragma unroll
+        for (uint32_t tap = 0; tap < CONV_MAXK; ++tap) {
+            w[tap] = tap < ks ? conv_weight[(size_t)c * ks + tap] : 0.0f;
+            win[tap] = tap < taps ? halo[((size_t)b * taps + tap) * conv_dim + c] : 0.0f;
+        }
+        const float b0 = bias ? bias[c] : 0.0f;
+        const uint32_t t_end = (b + 1) * CONV_TBLK < suffix_len ? (b + 1) * CONV_TBLK : suffix_len;
+        for (uint32_t t = b * CONV_TBLK; t < t_end; ++t) {
+            uint16_t* px = in_proj + (size_t)t * out_stride + c;
+            const float x = bf16_to_f32(*px);
+            float acc = b0; // the reference's order: taps oldest first, the new token last (conv_scan.rs:44-52)
+#pragma unroll
+            for (uint32_t tap = 0; tap < CONV_MAXK; ++tap)
+                if (tap < taps) acc += w[tap] * win[tap];
+            acc += w[taps] * x;
+            *px = f32_to_bf16(silu_f32(acc));
+#pragma unroll
+            for (uint32_t tap = 0; tap + 1 < CONV_MAXK; ++tap)
+                if (tap + 1 < taps) win[tap] = win[tap + 1];
+            win[taps - 1] = x;
+        }
+        if (b + 1 == nblocks) // this channel's carried state for the next pass
+            for (uint32_t tap = 0; tap < taps; ++tap) state[(size_t)c * taps + tap] = halo[((size_t)nblocks * taps + tap) * conv_dim + c];
+    }
+}
+size_t delta_net_conv_fused_workspace_floats(uint32_t suffix_len, uint32_t kernel_size, uint32_t conv_dim) {
+    return (size_t)((suffix_len + CONV_TBLK - 1) / CONV_TBLK + 1) * (kernel_size - 1) * conv_dim;
+}
+uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* conv_weight, const float* bias, float* state, float* halo, uint32_t suffix_len,
+                                uint32_t kernel_size, uint32_t conv_dim, uint32_t out_stride) {
+    if (kernel_size < 2 || kernel_size > CONV_MAXK) {
+        set_error("delta_net_conv_fused: kernel size %u", kernel_size);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    if (!suffix_len || !conv_dim) return UZU_OK;
+    const uint32_t nblocks = (suffix_len + CONV_TBLK - 1) / CONV_TBLK;
+    const size_t h_total = (size_t)(nblocks + 1) * (kernel_size - 1) * conv_dim, a_total = (size_t)nblocks * conv_dim;
+    const uint32_t gh = (uint32_t)((h_total + 255) / 256 > 4096 ? 4096 : (h_total + 255) / 256), ga = (uint32_t)((a_total + 255) / 256 > 8192 ? 8192 : (a_total + 255) / 256);
+    UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(conv_halo_kernel, dim3(gh), dim3(256), 0, s, in_proj, state, halo, suffix_len, kernel_size, conv_dim, out_stride, nblocks); },
+                               "conv_halo"));
+    return launch_check([&] { hipLaunchKernelGGL(conv_apply_kernel, dim3(ga), dim3(256), 0, s, in_proj, conv_weight, bias, halo, state, suffix_len, kernel_size, conv_dim,
+                                                 out_stride, nblocks); }, "conv_apply");
+}
+
 // ---------------------------------------------------------------- DeltaNetPrefillPrep (prefill_prep.rs:30-113)
 // one wave per (token, k-head): 128 elements = 2 per lane
 __global__ void __launch_bounds__(256) delta_net_prefill_prep_kernel(const uint16_t* in_proj, const float* a_log,

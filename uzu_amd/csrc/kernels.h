@@ -138,6 +138,10 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
                              const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
                              uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
                              uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+// Conv1dPack + DeltaNetConvScan without the packed f32 buffer (engine prefill); `halo` holds delta_net_conv_fused_workspace_floats floats
+size_t delta_net_conv_fused_workspace_floats(uint32_t suffix_len, uint32_t kernel_size, uint32_t conv_dim);
+uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* conv_weight, const float* bias, float* state, float* halo, uint32_t suffix_len,
+                                uint32_t kernel_size, uint32_t conv_dim, uint32_t out_stride);
 // chunked form (k_deltanet_chunk.hip): 32-token chunks, T / P matrices built in parallel, four dense products per chunk
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len);
 size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t suffix_len);
