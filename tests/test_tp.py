@@ -140,13 +140,14 @@ def test_qwen35_0p8b_shard_shapes_at_8_ranks():
 
 
 def test_argmax_key_orders_like_the_reference_tie_rule():
-    vals = [(-3.5, 7), (0.0, 2), (-0.0, 1), (2.25, 9), (2.25, 4), (1e-30, 3), (-1e30, 0)]
+    """max() over packed keys = highest logit, ties -> lowest index; the key order is the float order."""
+    vals = [(-3.5, 7), (0.0, 2), (2.25, 9), (2.25, 4), (1e-30, 3), (-1e30, 0), (-1e-30, 5)]
     keys = [TP.pack_argmax_key(v, i) for v, i in vals]
-    best = max(keys)
-    assert TP.unpack_argmax_key(best) == (2.25, 4)  # highest logit, lowest index among ties
-    order = sorted(range(len(vals)), key=lambda j: keys[j])
-    assert [vals[j][0] for j in order] == sorted(v for v, _ in vals)[:0] + [vals[j][0] for j in order]  # keys are totally ordered
-    assert keys[1] > keys[2] or vals[1][0] == vals[2][0]  # +0.0 vs -0.0: distinct bit patterns, +0 ranks higher
+    assert TP.unpack_argmax_key(max(keys)) == (2.25, 4)
+    by_key = [vals[j][0] for j in sorted(range(len(vals)), key=lambda j: keys[j])]
+    assert by_key == sorted(by_key)
+    for v, i in vals:
+        assert TP.unpack_argmax_key(TP.pack_argmax_key(v, i)) == (float(np.float32(v)), i)
 
 
 WORKER = r'''
