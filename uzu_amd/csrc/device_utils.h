@@ -29,6 +29,13 @@ template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 
 constexpr int kWave = 64; // CDNA wavefront
 
+// Native vector types for values that are HELD IN REGISTERS across other code (software-pipeline stages): HIP's
+// uint4 / float4 are classes, an assignment from memory becomes llvm.memcpy into a private-memory temporary that SROA
+// does not always dissolve -- the "registers" then live in scratch and every prefetch is waited for immediately.
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_v __attribute__((ext_vector_type(2)));
+typedef float f32x4_v __attribute__((ext_vector_type(4)));
+
 // exp for the softmax weights of the attention kernels: v_exp_f32 (2^x, <= 1 ulp) on x * log2(e).  The attention
 // kernels are tolerance-class (parallel reductions), so the glibc-exact expf (a dozen f64 ops + a table load per
 // call, hundreds of calls per lane) buys nothing there; the element-wise kernels keep expf_glibc.
@@ -53,6 +60,13 @@ __device__ __forceinline__ float chunk8_sumsq(const float* v) {
     for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
     return s;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier, and the release fence makes
+// hipcc drain vmcnt(0) -- EVERY outstanding global load, including the ones a software pipeline issued precisely so
+// that they would still be in flight across the barrier (the counter is shared and in-order).  Kernels that exchange
+// data through LDS only and prefetch global operands across iterations use this instead: LDS writes are complete
+// (lgkmcnt(0)) before the barrier, the compiler still waits for a global load where its registers are consumed.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // workgroup sum (blockDim.x multiple of 64, <= 1024); `red` = 16 floats of LDS; result broadcast
 __device__ __forceinline__ float block_sum(float v, float* red) {

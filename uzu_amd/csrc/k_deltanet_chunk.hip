@@ -261,6 +261,135 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_kernel(const float* q_norm,
     for (int e = 0; e < SD; e += 4) *(float4*)(srow + e) = make_float4(sreg[e], sreg[e + 1], sreg[e + 2], sreg[e + 3]);
 }
 
+// Eight-wave variant for DVS = 8 (the 0.8B shape: 256 workgroups, one per CU).  With four waves every SIMD holds one
+// wave and the LDS latency of the short product loops is fully exposed; 512 threads halve each thread's share of the
+// two large products (stage 1: one 128-long dot per thread, stage 4: two state elements per thread) and give every
+// SIMD a second wave to switch to.  Stage 2 runs on the K-threads, stage 3 on the Q-threads (they hold Q S^T).
+__global__ void __launch_bounds__(512) dn_chunk_scan8w_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
+                                                              uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
+                                                              uint32_t value_dim, uint32_t suffix_len) {
+    constexpr int DVS = 8, RP = DVS + 1;
+    __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVS * KP];
+    __shared__ float sT[CC * TP], sP[CC * TP];
+    __shared__ float sR[CC * RP], sD[CC * RP];
+    __shared__ float sA[CC], sW[CC];
+    const int tid = threadIdx.x;
+    const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVS, hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
+
+    // state: thread -> (dv = tid / 64, two consecutive dk)
+    const int s_dv = tid >> 6, s_dk = (tid & 63) * 2;
+    float* srow = state + ((size_t)hv * head_v_dim + dv_base + s_dv) * DKC + s_dk;
+    float2 sreg = *(const float2*)srow;
+    // products: thread -> (token t = tid / 16, value column dv = tid % 8, operand: K (0) or Q (1))
+    const int p_t = tid >> 4, p_dv = tid & 7, p_q = (tid >> 3) & 1;
+
+    // staging registers: native vectors + UNCONDITIONAL loads (clamped token, zeroed by a select) so that the compiler can
+    // keep them in flight across the LDS-only barriers below
+    f32x4_v st_k[2], st_q[2];
+    float st_t[2], st_p[2], st_a = 0.f, st_w = 0.f, st_v = 0.f;
+    auto fetch = [&](uint32_t c) {
+        const uint32_t t0 = c * CC;
+        const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = tid + 512 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            const bool live = t0 + t < suffix_len;
+            const size_t tok = live ? t0 + t : suffix_len - 1;
+            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_v kv = *(const f32x4_v*)(k_norm + tok * key_dim + hk * DKC + c4 * 4);
+            const f32x4_v qv = *(const f32x4_v*)(q_norm + tok * key_dim + hk * DKC + c4 * 4);
+            st_k[r] = live ? kv : zero, st_q[r] = live ? qv : zero;
+            st_t[r] = w_t[idx], st_p[r] = w_t[CC * CC + idx];
+        }
+        st_a = w_t[2 * CC * CC + (tid & (CC - 1))], st_w = w_t[2 * CC * CC + CC + (tid & (CC - 1))];
+        {
+            const bool live = t0 + p_t < suffix_len;
+            const float vv = bf16_to_f32(in_proj[(size_t)(live ? t0 + p_t : suffix_len - 1) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + p_dv]);
+            st_v = live && !p_q ? vv : 0.f;
+        }
+    };
+    float vreg = 0.f;
+    auto publish = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = tid + 512 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            *(f32x4_v*)(sK + t * KP + c4 * 4) = st_k[r];
+            *(f32x4_v*)(sQ + t * KP + c4 * 4) = st_q[r];
+            sT[(idx / CC) * TP + idx % CC] = st_t[r];
+            sP[(idx / CC) * TP + idx % CC] = st_p[r];
+        }
+        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
+        *(float2*)(sS + s_dv * KP + s_dk) = sreg;
+        vreg = st_v;
+    };
+
+    fetch(0);
+    publish();
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t t0 = c * CC;
+        fetch(c + 1 < n_chunks ? c + 1 : c); // unconditional (the last chunk refetches itself): countable loads
+        // ---- stage 1: one dot per thread: (K | Q)[t] . S[dv]
+        float dot;
+        {   // four independent chains (a single accumulator makes the 128 FMAs one dependent chain)
+            const float* xr = (p_q ? sQ : sK) + p_t * KP;
+            const float* sr = sS + p_dv * KP;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 8
+            for (int d4 = 0; d4 < DKC; d4 += 4) {
+                const float4 xv = *(const float4*)(xr + d4), sv = *(const float4*)(sr + d4);
+                d0 = fmaf(xv.x, sv.x, d0), d1 = fmaf(xv.y, sv.y, d1), d2 = fmaf(xv.z, sv.z, d2), d3 = fmaf(xv.w, sv.w, d3);
+            }
+            dot = (d0 + d1) + (d2 + d3);
+        }
+        const float a_t = sA[p_t];
+        if (!p_q) sR[p_t * RP + p_dv] = vreg - a_t * dot;
+        lds_barrier();
+        // ---- stage 2 (K-threads): D = T R
+        if (!p_q) {
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CC; i += 4) {
+                e0 = fmaf(sT[p_t * TP + i], sR[i * RP + p_dv], e0), e1 = fmaf(sT[p_t * TP + i + 1], sR[(i + 1) * RP + p_dv], e1);
+                e2 = fmaf(sT[p_t * TP + i + 2], sR[(i + 2) * RP + p_dv], e2), e3 = fmaf(sT[p_t * TP + i + 3], sR[(i + 3) * RP + p_dv], e3);
+            }
+            sD[p_t * RP + p_dv] = (e0 + e1) + (e2 + e3);
+        }
+        lds_barrier();
+        // ---- stage 3 (Q-threads): O = A Q S^T + P D
+        if (p_q) {
+            float e0 = a_t * dot, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CC; i += 4) {
+                e0 = fmaf(sP[p_t * TP + i], sD[i * RP + p_dv], e0), e1 = fmaf(sP[p_t * TP + i + 1], sD[(i + 1) * RP + p_dv], e1);
+                e2 = fmaf(sP[p_t * TP + i + 2], sD[(i + 2) * RP + p_dv], e2), e3 = fmaf(sP[p_t * TP + i + 3], sD[(i + 3) * RP + p_dv], e3);
+            }
+            const float oo = (e0 + e1) + (e2 + e3);
+            if (t0 + p_t < suffix_len) out[(size_t)(t0 + p_t) * value_dim + hv * head_v_dim + dv_base + p_dv] = f32_to_bf16(oo);
+        }
+        // ---- stage 4: S = A_C S + D^T diag(W) K for (dv, two dk)
+        {
+            const float a_c = sA[CC - 1];
+            float2 u0 = make_float2(sreg.x * a_c, sreg.y * a_c), u1 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < CC; i += 2) {
+                const float dw0 = sD[i * RP + s_dv] * sW[i], dw1 = sD[(i + 1) * RP + s_dv] * sW[i + 1];
+                const float2 k0 = *(const float2*)(sK + i * KP + s_dk), k1 = *(const float2*)(sK + (i + 1) * KP + s_dk);
+                u0.x = fmaf(dw0, k0.x, u0.x), u0.y = fmaf(dw0, k0.y, u0.y);
+                u1.x = fmaf(dw1, k1.x, u1.x), u1.y = fmaf(dw1, k1.y, u1.y);
+            }
+            sreg = make_float2(u0.x + u1.x, u0.y + u1.y);
+        }
+        lds_barrier();
+        if (c + 1 < n_chunks) publish();
+        lds_barrier();
+    }
+    *(float2*)srow = sreg;
+}
+
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
     static const uint32_t min_t = [] {
         const char* e = getenv("UZU_DN_CHUNK_MIN_T");
@@ -283,6 +412,15 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         return e ? atoi(e) : 0;
     }();
     const bool narrow = force ? force == 8 : num_v_heads * (head_v_dim / 16) < 200;
+    static const int waves8 = [] {
+        const char* e = getenv("UZU_DN_CHUNK_8W");
+        return e ? atoi(e) : 1;
+    }();
+    if (narrow && waves8)
+        return launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_scan8w_kernel, dim3(head_v_dim / 8, num_v_heads), dim3(512), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
+                               num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+        }, "delta_net_chunk_scan");
     if (narrow)
         return launch_check([&] {
             hipLaunchKernelGGL(dn_chunk_scan_kernel<8>, dim3(head_v_dim / 8, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
