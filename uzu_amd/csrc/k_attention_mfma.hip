@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     const uint16_t* vbase = (const uint16_t*)a.values + (size_t)kv_head * a.v_head_stride;
     constexpr int SLICES = HD / 32;               // 32 hd elements (64 bytes) per slice
     constexpr int ROUNDS = (TK * SLICES + 255) / 256;
-    uint4 kst[ROUNDS][4], vst[ROUNDS][4];
+    u32x4_v kst[ROUNDS][4], vst[ROUNDS][4]; // native vectors + unconditional loads: stay in registers and in flight across lds_barrier()
     // keys visible to ANY query of the workgroup: 0 .. prefix + last query of the workgroup
     const uint32_t wg_last_q = (q0_wg + TQ * tiles_per_wg < M ? q0_wg + TQ * tiles_per_wg : M) - 1;
     const uint32_t key_end = prefix + wg_last_q + 1;
@@ -91,14 +91,15 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t idx = tid + 256 * r, key = idx / SLICES, sl = idx % SLICES;
             const uint32_t i = t * TK + key;
-            if (idx < TK * SLICES && i < key_end) {
-                const uint4* ks = (const uint4*)(kbase + (size_t)i * a.k_seq_stride + sl * 32);
-                const uint4* vs = (const uint4*)(vbase + (size_t)i * a.v_seq_stride + sl * 32);
+            const bool live = idx < TK * SLICES && i < key_end;
+            const uint32_t ic = i < key_end ? i : key_end - 1; // clamped row: masked keys get probability 0 anyway, zeroed for hygiene
+            const u32x4_v* ks = (const u32x4_v*)(kbase + (size_t)ic * a.k_seq_stride + (sl % SLICES) * 32);
+            const u32x4_v* vs = (const u32x4_v*)(vbase + (size_t)ic * a.v_seq_stride + (sl % SLICES) * 32);
+            const u32x4_v zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) kst[r][j] = ks[j], vst[r][j] = vs[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) kst[r][j] = make_uint4(0, 0, 0, 0), vst[r][j] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const u32x4_v kk = ks[j], vv = vs[j];
+                kst[r][j] = live ? kk : zero, vst[r][j] = live ? vv : zero;
             }
         }
     };
@@ -109,11 +110,11 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
             if (idx >= TK * SLICES) continue;
             uint8_t* kd = &s_k[buf][key * KP + sl * 64];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(uint4*)(kd + 16 * j) = kst[r][j];
+            for (int j = 0; j < 4; ++j) *(u32x4_v*)(kd + 16 * j) = kst[r][j];
             // V transposed: element (key, hd) -> s_vt[hd][key]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t w[4] = {vst[r][j].x, vst[r][j].y, vst[r][j].z, vst[r][j].w};
+                const uint32_t w[4] = {vst[r][j][0], vst[r][j][1], vst[r][j][2], vst[r][j][3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t hd0 = sl * 32 + j * 8 + 2 * e;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     __syncthreads();
     for (uint32_t t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < n_tiles) load_tile(t + 1);
+        load_tile(t + 1 < n_tiles ? t + 1 : t); // unconditional: the compiler can count the loads in flight
         // a wave whose queries all end before this tile has nothing to add (causal), but must keep the barriers
         const uint32_t wave_last_key = prefix + (q0 + TQ - 1 < M ? q0 + TQ - 1 : M - 1);
         if (q0 < M && t * TK <= wave_last_key) {
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
             }
         }
         if (t + 1 < n_tiles) store_tile(buf ^ 1);
-        __syncthreads();
+        lds_barrier();
     }
     // ---- finish: l = both halves' sums (same maximum), out[q][head][hd] = O / l
     const float l_tot = l_run + other_half(l_run);
