@@ -41,6 +41,17 @@ typedef float f32x4_v __attribute__((ext_vector_type(4)));
 // call, hundreds of calls per lane) buys nothing there; the element-wise kernels keep expf_glibc.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; } // v_log_f32 (log2) * ln 2
+// DeltaNet decode scalars (write strength, decay): tolerance-class inputs of the state update, evaluated with the
+// hardware exp2 / log2 (<= 1 ulp each) instead of the ~150 double-precision operations of the libm-exact forms --
+// a quarter of the 256-workgroup decode kernel's critical path.  Both decode kernels use these, so they agree bit for bit.
+__device__ __forceinline__ float delta_beta_fast(float beta_raw) { return 1.0f / (1.0f + fast_exp(-beta_raw)); }
+__device__ __forceinline__ float delta_decay_fast(float a_raw, float dt_bias, float a_log) {
+    const float sp_input = a_raw + dt_bias;
+    const float sp = sp_input > 20.0f ? sp_input : fast_log(1.0f + fast_exp(sp_input));
+    return fast_exp(-fast_exp(a_log) * sp);
+}
+
 // butterfly sum over the `width` (power of two <= 64) consecutive lanes that contain this lane
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) { return k::row_sum_rt(v, WIDTH); }
 __device__ __forceinline__ float wave_sum(float v) { return k::row_sum_rt(v, 64); }

@@ -641,11 +641,8 @@ __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
         kq += kk[e] * q[e];
     }
     const float kq_dot = group_sum<32>(kq);
-    const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
-    const float sp_input = a_raw + dt_b;
-    const float sp = sp_input > 20.0f ? sp_input : logf_glibc(1.0f + expf_glibc(sp_input));
-    const float g = -expf_glibc(a_l) * sp;
-    const float decay = expf_glibc(g);
+    const float beta = delta_beta_fast(beta_raw);
+    const float decay = delta_decay_fast(a_raw, dt_b, a_l);
     const float sz_i = silu_f32(z_i);
 
     const float s4[4] = {sv.x, sv.y, sv.z, sv.w};

@@ -82,12 +82,9 @@ __global__ void __launch_bounds__(512) delta_net_update_kernel(const uint16_t* i
     const float kq_dot = group_sum<32>(kq);
 
     const float beta_raw = bf16_to_f32(in_proj[conv_dim + value_dim + hv]);
-    const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
+    const float beta = delta_beta_fast(beta_raw);
     const float a_raw = bf16_to_f32(in_proj[conv_dim + value_dim + num_v_heads + hv]);
-    const float sp_input = a_raw + dt_bias[hv];
-    const float sp = sp_input > 20.0f ? sp_input : logf_glibc(1.0f + expf_glibc(sp_input));
-    const float g = -expf_glibc(a_log[hv]) * sp;
-    const float decay = expf_glibc(g);
+    const float decay = delta_decay_fast(a_raw, dt_bias[hv], a_log[hv]);
 
     const uint32_t rows_per_pass = (blockDim.x >> 6) * 2;
     for (uint32_t i0 = 0; i0 < head_v_dim; i0 += rows_per_pass) {
