@@ -259,7 +259,7 @@ uzu_status uzu_hip_unified_sampling_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb
                                            uzu_buf seeds, uzu_buf bitmask, float temperature, uint32_t top_k,
                                            float top_p, float min_p, uint32_t vocab_size, uint32_t batch_size);
 
-/* ---- Gated DeltaNet (cpu/kernel/gdn/*.rs with the Metal buffer types, metal/kernel/gdn/update.metal:19-31) */
+/* ---- Gated DeltaNet (cpu/kernel/gdn/ *.rs with the Metal buffer types, metal/kernel/gdn/update.metal:19-31) */
 uzu_status uzu_hip_delta_net_conv_update_create(uzu_hip_context* ctx, uint32_t t, uint32_t has_bias,
                                                 uzu_hip_kernel** out);
 uzu_status uzu_hip_delta_net_conv_update_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf conv_weight,

@@ -53,13 +53,15 @@ __device__ __forceinline__ float act_bf16(uint32_t act, float x) { // activation
 //     next batch is prefetched while the current one is computed (tools/microbench2: a kernel boundary costs
 //     1.6 us, a dependent HBM round trip 0.3-0.5 us: the kernel should pay exactly one of the latter);
 //   * epilogues: plain store | SiLU(gate)*up | arg-max partial per workgroup.
-template <int BITS, int CPLT, int R, bool ACT, int KIND, bool CONV>
+//   * PRO selects the prologue at compile time (0 plain row, 1 Normalization, 2 DeltaNet norm-gate): a run-time branch in
+//     front of the first weight loads -- even a wave-uniform one -- makes the compiler fall back to vmcnt(0) waits.
+template <int BITS, int CPLT, int R, bool ACT, int KIND, int PRO, bool CONV>
 __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_log2) {
     using Codes = typename CodesT<BITS>::type;
     constexpr int STEP_BYTES = 4 * BITS;
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t K = p.k;
     const int lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int sl = lane & (lpr - 1), rsub = lane >> lpr_log2;
@@ -82,9 +84,14 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     };
     // Loads of one (batch, step) item.  Batches [0, batches0) belong to matrix 0, the rest to matrix 1 (wave-uniform:
     // the base pointers stay in SGPRs and the per-lane part of every address is a 32-bit byte offset -- host-checked).
+    const uint32_t b_own = min((uint32_t)(blockIdx.x * 4 + wave), num_batches - 1);
     auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
-        const uint32_t c = sl + lpr * j;
-        if (b >= num_batches || c >= C) return;
+        // Unconditional: batch and step are clamped into range and a clamped reload is never consumed.  VMEM returns in
+        // issue order and the compiler only emits counted waits (vmcnt(N)) across loads that are always issued; even a
+        // wave-uniform branch around them costs the normed kernels 0.4 us and the readout 15 % (tools/kbench A/B).
+        const uint32_t c_raw = sl + lpr * j;
+        const uint32_t c = c_raw < C ? c_raw : C - 1;
+        b = b < num_batches ? b : b_own; // past the end: re-read the wave's first batch (cache hit, spread over channels)
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
         const uint32_t nl = mat ? p.n[1] : n_log0;
@@ -111,14 +118,41 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
 
     const uint32_t b0 = blockIdx.x * 4 + wave;
     Item itA, itB;
+    // VMEM loads return in issue order.  The activation row (written by the previous kernel: L2 / memory-side cache,
+    // ~0.8 us) is needed first and the weights (HBM, ~1.3 us) only after the prologue, so the activation loads are
+    // issued FIRST and the first weight item right behind them; with LDS-only barriers in the prologue nothing waits
+    // for the weights before the row loop.
+    constexpr int NPRE = CPL; // staged 4-element vectors per thread: K / 1024 <= CPL whenever lpr <= 32; the rest loads in place
+    u32x2_v x_pre[NPRE], s_pre[NPRE];
+    f32x4_v n_pre[NPRE];
+    if (PRO == 1) {
+        const uint32_t E = K / 256;
+#pragma unroll
+        for (int qi = 0; qi < NPRE; ++qi) {
+            const uint32_t q = (uint32_t)qi * 4 < E ? (uint32_t)qi * 4 : E - 4; // clamped: never consumed past E
+            const uint32_t e = tid * E + q;
+            x_pre[qi] = *(const u32x2_v*)(p.x + e);
+            s_pre[qi] = *(const u32x2_v*)((p.residual_add ? p.shortcut_in : p.x) + e);
+            n_pre[qi] = *(const f32x4_v*)(p.norm_scales ? p.norm_scales + e : (const float*)p.x);
+        }
+    }
+    f32x4_v dg_pre[6]; // norm-gate prologue: chunk 0 of this thread (o, z, w: two vectors each); further chunks load in place
+    if (PRO == 2) {
+        const uint32_t nchunks = K / 8, per = nchunks > 256 ? nchunks / 256 : 1;
+        const uint32_t chunk = min((uint32_t)tid * per, nchunks - 1), e0 = chunk * 8;
+        dg_pre[0] = *(const f32x4_v*)(p.dg_o + e0), dg_pre[1] = *(const f32x4_v*)(p.dg_o + e0 + 4);
+        dg_pre[2] = *(const f32x4_v*)(p.dg_sz + e0), dg_pre[3] = *(const f32x4_v*)(p.dg_sz + e0 + 4);
+        dg_pre[4] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv), dg_pre[5] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the issue order: the scheduler would hoist the weight loads above the staging
     load_item(b0, 0, itA); // in flight during the whole prologue
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- prologue ---------------------------------------------------------------------------------------
     float xf[CPL][32];
     float xsm[CPL];
     if (CPLT != 0) {
-        const bool normed = p.norm_scales || p.norm_plain;
-        if (p.dg_o) {
+        if (PRO == 2) {
             // DeltaNet norm-gate (tail of update.rs:30-143) as the out-proj prologue: thread t owns `per` chunks of 8
             // consecutive outputs; sum of squares per head in chunk8_sumsq order; x = bf16(o * inv_rms * w * SiLU(z)).
             extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -134,8 +168,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 for (uint32_t q = 0; q < 4; ++q) {
                     if (q >= per) break;
                     const uint32_t e0 = ((uint32_t)tid * per + q) * 8;
-                    const float4 a0 = *(const float4*)(p.dg_o + e0), a1 = *(const float4*)(p.dg_o + e0 + 4);
-                    const float4 z0 = *(const float4*)(p.dg_sz + e0), z1 = *(const float4*)(p.dg_sz + e0 + 4);
+                    const f32x4_v a0 = q == 0 ? dg_pre[0] : *(const f32x4_v*)(p.dg_o + e0), a1 = q == 0 ? dg_pre[1] : *(const f32x4_v*)(p.dg_o + e0 + 4);
+                    const f32x4_v z0 = q == 0 ? dg_pre[2] : *(const f32x4_v*)(p.dg_sz + e0), z1 = q == 0 ? dg_pre[3] : *(const f32x4_v*)(p.dg_sz + e0 + 4);
                     ov[q][0] = a0.x, ov[q][1] = a0.y, ov[q][2] = a0.z, ov[q][3] = a0.w, ov[q][4] = a1.x, ov[q][5] = a1.y, ov[q][6] = a1.z, ov[q][7] = a1.w;
                     zv[q][0] = z0.x, zv[q][1] = z0.y, zv[q][2] = z0.z, zv[q][3] = z0.w, zv[q][4] = z1.x, zv[q][5] = z1.y, zv[q][6] = z1.z, zv[q][7] = z1.w;
                     cs[q] = chunk8_sumsq(ov[q]);
@@ -149,7 +183,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 for (uint32_t q = 0; q < 4; ++q) {
                     if (q >= per) break;
                     const uint32_t e0 = ((uint32_t)tid * per + q) * 8;
-                    const float4 w0 = *(const float4*)(p.dg_w + e0 % dv), w1 = *(const float4*)(p.dg_w + e0 % dv + 4);
+                    const f32x4_v w0 = q == 0 ? dg_pre[4] : *(const f32x4_v*)(p.dg_w + e0 % dv), w1 = q == 0 ? dg_pre[5] : *(const f32x4_v*)(p.dg_w + e0 % dv + 4);
                     const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                     float v[8];
 #pragma unroll
@@ -159,7 +193,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     *(float4*)(slot + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
@@ -175,7 +209,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
                 }
             }
-        } else if (!normed) { // plain activation row: every lane fetches its own steps
+        } else if (PRO == 0) { // plain activation row: every lane fetches its own steps
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
@@ -193,12 +227,15 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             float* red = smem + (size_t)C * 36;     // [4]
             const uint32_t E = K / 256;
             float ss = 0.f;
-            for (uint32_t q = 0; q < E; q += 4) {
+#pragma unroll
+            for (int qi = 0; qi < 2 * CPL; ++qi) {
+                const uint32_t q = (uint32_t)qi * 4;
+                if (q >= E) break;
                 const uint32_t e = tid * E + q;
-                const uint2 xr = *(const uint2*)(p.x + e);
+                const u32x2_v xr = qi < NPRE ? x_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.x + e);
                 float v[4] = {bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u)};
                 if (p.residual_add) {
-                    const uint2 sr = *(const uint2*)(p.shortcut_in + e);
+                    const u32x2_v sr = qi < NPRE ? s_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.shortcut_in + e);
                     const float sc[4] = {bits_to_f32(sr.x << 16), bits_to_f32(sr.x & 0xFFFF0000u), bits_to_f32(sr.y << 16), bits_to_f32(sr.y & 0xFFFF0000u)};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = round_bf16(v[i] + sc[i]);
@@ -215,20 +252,20 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             }
             ss = wave_sum(ss);
             if (lane == 0) red[wave] = ss;
-            __syncthreads();
+            lds_barrier();
             const float total = ((red[0] + red[1]) + red[2]) + red[3];
             const float variance = total / (float)K - 0.0f * 0.0f;
             const float rms_inv = 1.0f / sqrtf(variance + p.norm_eps);
-            for (uint32_t q = 0; q < E; q += 4) {
+#pragma unroll
+            for (int qi = 0; qi < 2 * CPL; ++qi) {
+                const uint32_t q = (uint32_t)qi * 4;
+                if (q >= E) break;
                 const uint32_t e = tid * E + q;
                 float* slot = xs + (size_t)(e / 32) * 36 + e % 32;
                 const float4 vv = *(const float4*)slot; // own elements: no barrier needed
                 float v[4] = {vv.x, vv.y, vv.z, vv.w};
-                float scl[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.norm_scales) {
-                    const float4 t = *(const float4*)(p.norm_scales + e);
-                    scl[0] = t.x, scl[1] = t.y, scl[2] = t.z, scl[3] = t.w;
-                }
+                const f32x4_v t4 = qi < NPRE ? n_pre[qi < NPRE ? qi : 0] : *(const f32x4_v*)(p.norm_scales ? p.norm_scales + e : (const float*)p.x);
+                const float scl[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float normalized = (v[i] - 0.0f) * rms_inv;
@@ -244,7 +281,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     *(uint2*)(p.normed_out + e) = o;
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
@@ -292,21 +329,22 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     };
     struct ConvPre { // taps / weights of the conv channels this lane finishes (kernel size 4: the common case)
         float tap[3];
-        float4 w;
+        f32x4_v w;
         float bias;
     };
     auto conv_prefetch = [&](uint32_t b, ConvPre (&cp)[CONV ? R : 1]) { // issued at batch start: lands while the rows are computed
-        if (sl != 0 || b >= batches0) return;
+        // every lane of the row loads (same address: one request), rows outside the conv block read channel 0 and are
+        // not consumed -- unconditional for the same reason as load_item
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t lrow = b * rows_per_batch + r * rpw + rsub;
-            if (lrow < p.conv_dim && lrow < n_log0) {
-                ConvPre& c4 = cp[CONV ? r : 0];
-                const float* st_row = p.conv_state + (size_t)lrow * 3;
-                c4.tap[0] = st_row[0], c4.tap[1] = st_row[1], c4.tap[2] = st_row[2];
-                c4.w = *(const float4*)(p.conv_w + (size_t)lrow * 4);
-                c4.bias = p.conv_b ? p.conv_b[lrow] : 0.0f;
-            }
+            const uint32_t lrow_raw = b * rows_per_batch + r * rpw + rsub;
+            const uint32_t lrow = (b < batches0 && lrow_raw < p.conv_dim && lrow_raw < n_log0) ? lrow_raw : 0;
+            ConvPre& c4 = cp[CONV ? r : 0];
+            const float* st_row = p.conv_state + lrow * 3;
+            c4.tap[0] = st_row[0], c4.tap[1] = st_row[1], c4.tap[2] = st_row[2];
+            c4.w = *(const f32x4_v*)(p.conv_w + lrow * 4);
+            const float bias = (p.conv_b ? p.conv_b : p.conv_w)[lrow];
+            c4.bias = p.conv_b ? bias : 0.0f;
         }
     };
     auto finish = [&](uint32_t b, float (&acc)[R][NPHYS], const ConvPre (&cp)[CONV ? R : 1]) {
@@ -464,7 +502,7 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     return (nb(R) + 3) / 4;
 }
 
-template <int BITS, int CPLT, bool ACT, int KIND, bool CONV>
+template <int BITS, int CPLT, bool ACT, int KIND, int PRO, bool CONV>
 static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
     const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
     static const int cap_override = [] {
@@ -476,29 +514,46 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         static int occ = 0; /* resident workgroups per CU of this instance (LDS use only lowers it for K > 8192: ignored) */        \
         if (!occ) {                                                                                                                 \
             int n = 0;                                                                                                              \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, CONV>, 256, lds) != hipSuccess || n < 1) n = 2; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>, 256, lds) != hipSuccess || n < 1) n = 2; \
             occ = n > 8 ? 8 : n;                                                                                                    \
         }                                                                                                                           \
         const uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                 \
         const uint32_t grid = want > cap ? cap : want;                                                                              \
         if (grid_out) *grid_out = grid;                                                                                             \
-        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, CONV>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
     } while (0)
     if (!ACT && !CONV && R == 4) UZU_LAUNCH((ACT || CONV) ? 2 : 4);
     if (R >= 2) UZU_LAUNCH(2);
     UZU_LAUNCH(1);
 #undef UZU_LAUNCH
 }
+template <int BITS, int CPLT, bool ACT, int KIND, int PRO>
+static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+    if constexpr (!ACT && PRO != 2) {
+        if (p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
+            if (R > 2) {
+                want *= (uint32_t)(R / 2);
+                R = 2;
+            }
+            return launch_gemv_dec_c<BITS, CPLT, false, KIND, PRO, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+        }
+    }
+    return launch_gemv_dec_c<BITS, CPLT, ACT, KIND, PRO, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
+}
 template <int BITS, int CPLT, bool ACT, int KIND>
 static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
-    if (!ACT && p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
-        if (R > 2) {
-            want *= (uint32_t)(R / 2);
-            R = 2;
-        }
-        return launch_gemv_dec_c<BITS, CPLT, false, KIND, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    const bool normed = p.norm_scales || p.norm_plain;
+    if constexpr (CPLT != 0) { // prologues keep the row in registers (checked by the caller)
+        if constexpr (!ACT)
+            if (p.dg_o) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 2>(s, p, want, lpr_log2, R, num_cus, grid_out);
+        if (normed) return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 1>(s, p, want, lpr_log2, R, num_cus, grid_out);
     }
-    return launch_gemv_dec_c<BITS, CPLT, ACT, KIND, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if constexpr (CPLT == 4) {
+        set_error("gemv_dec: the 4-step register path is instantiated for the prologue variants only");
+        return UZU_ERR_UNSUPPORTED;
+    } else {
+        return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 0>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    }
 }
 template <int BITS, int CPLT, bool ACT>
 static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
