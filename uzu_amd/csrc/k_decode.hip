@@ -761,66 +761,94 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     const uint16_t* vbase = p.values + (size_t)kvh * HD + sl * 8;
     const size_t seq_stride = (size_t)nkv * HD;
     const uint32_t key0 = split + S * my_group, key_step = S * NGRP;
-    uint4 kq[TB], vq[TB];
-    auto fetch = [&](uint32_t first) {
+    // Load order (VMEM returns in issue order, a load the compiler cannot count forces vmcnt(0)): the new token's q/k/v
+    // rows and norm scales (L2) first, then the first K/V batch (HBM), then the RoPE row; everything unconditional with
+    // clamped addresses.  The prologue between the loads and the key loop only uses LDS barriers.
+    constexpr int NJ = (GS + 2 + 3) / 4;           // prologue jobs per wave
+    constexpr int NROPE = ((GS + 1) * (HD / 2) + 255) / 256;
+    float vals[NJ][HD / 64], nsc[NJ][HD / 64];
 #pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const uint32_t i = first + t * key_step;
-            if (i < L) {
-                kq[t] = *(const uint4*)(kbase + (size_t)i * seq_stride);
-                vq[t] = *(const uint4*)(vbase + (size_t)i * seq_stride);
-            }
-        }
-    };
-    fetch(key0);
-
-    // ---- prologue: normalised + roped q heads (one wave per head, elements lane + 64 j), new k and v rows ----
-    // (QKVNorm: qkv_norm.rs:45-76 ; AttentionPrepare: attention_prepare.rs:7-31,104-121)
-    for (int job = wave; job < GS + 2; job += 4) {
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int job = min(wave + 4 * jj, GS + 1);
         const bool is_q = job < GS, is_k = job == GS;
         const uint32_t head_idx = is_q ? head0 + job : (is_k ? nq + kvh : nq + nkv + kvh);
         const uint16_t* src = p.qkv + (size_t)head_idx * HD;
-        float vals[HD / 64];
-        float total = 0.f;
+        const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
+        const float* nsrc = nm.scales ? nm.scales : (const float*)p.qkv; // dummy source (>= 2 head rows long), never consumed
 #pragma unroll
         for (int j = 0; j < HD / 64; ++j) {
-            vals[j] = bf16_to_f32(src[lane + 64 * j]);
-            total += vals[j] * vals[j];
+            vals[jj][j] = bf16_to_f32(src[lane + 64 * j]);
+            nsc[jj][j] = nsrc[lane + 64 * j];
         }
+    }
+    u32x4_v kq[TB], vq[TB];
+    const uint32_t last_row = L ? L - 1 : 0;
+    auto fetch = [&](uint32_t first) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const uint32_t i = min(first + t * key_step, last_row); // clamped rows are loaded (cache hit) and never consumed
+            kq[t] = *(const u32x4_v*)(kbase + (size_t)i * seq_stride);
+            vq[t] = *(const u32x4_v*)(vbase + (size_t)i * seq_stride);
+        }
+    };
+    fetch(key0);
+    float rc[NROPE][4];
+    if (rope_dim) {
+        const float* cosr = p.cosines + (size_t)L * rope_dim;
+        const float* sinr = p.sines + (size_t)L * rope_dim;
+#pragma unroll
+        for (int r = 0; r < NROPE; ++r) {
+            const uint32_t t = min((uint32_t)tid + 256u * r, (GS + 1) * half_rope - 1), d = t % half_rope;
+            rc[r][0] = cosr[d], rc[r][1] = sinr[d], rc[r][2] = cosr[d + half_rope], rc[r][3] = sinr[d + half_rope];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: normalised + roped q heads (one wave per head, elements lane + 64 j), new k and v rows ----
+    // (QKVNorm: qkv_norm.rs:45-76 ; AttentionPrepare: attention_prepare.rs:7-31,104-121)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int job = wave + 4 * jj;
+        if (job >= GS + 2) break;
+        const bool is_q = job < GS, is_k = job == GS;
+        float total = 0.f;
+#pragma unroll
+        for (int j = 0; j < HD / 64; ++j) total += vals[jj][j] * vals[jj][j];
         const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
         if ((is_q || is_k) && nm.present) {
             total = wave_sum(total);
             const float rms_norm = 1.0f / sqrtf(total / (float)HD + nm.eps);
 #pragma unroll
             for (int j = 0; j < HD / 64; ++j) {
-                const float normalized = vals[j] * rms_norm;
-                const uint32_t i = lane + 64 * j;
+                const float normalized = vals[jj][j] * rms_norm;
                 if (!nm.scales)
-                    vals[j] = round_bf16(normalized);
+                    vals[jj][j] = round_bf16(normalized);
                 else if (nm.full_layer)
-                    vals[j] = round_bf16(normalized * (nm.scales[i] + nm.offset));
+                    vals[jj][j] = round_bf16(normalized * (nsc[jj][j] + nm.offset));
                 else
-                    vals[j] = round_bf16(round_bf16(normalized) * round_bf16(nm.scales[i] + nm.offset));
+                    vals[jj][j] = round_bf16(round_bf16(normalized) * round_bf16(nsc[jj][j] + nm.offset));
             }
         }
         float* dst = is_q ? s_q[job] : (is_k ? s_knew : s_vnew);
 #pragma unroll
-        for (int j = 0; j < HD / 64; ++j) dst[lane + 64 * j] = vals[j];
+        for (int j = 0; j < HD / 64; ++j) dst[lane + 64 * j] = vals[jj][j];
     }
-    __syncthreads();
+    lds_barrier();
     if (rope_dim) { // half-rotation RoPE on q heads and the new key (table row = absolute position L); one thread per pair
-        const float* cosr = p.cosines + (size_t)L * rope_dim;
-        const float* sinr = p.sines + (size_t)L * rope_dim;
-        for (uint32_t t = tid; t < (GS + 1) * half_rope; t += 256) {
-            const uint32_t v = t / half_rope, d = t % half_rope;
-            float* vec = v < GS ? s_q[v] : s_knew;
-            const float a = vec[d], b = vec[d + half_rope];
-            const float lo = round_bf16(a * cosr[d] + (-b) * sinr[d]);
-            const float hi = round_bf16(b * cosr[d + half_rope] + a * sinr[d + half_rope]);
-            vec[d] = lo;
-            vec[d + half_rope] = hi;
+#pragma unroll
+        for (int r = 0; r < NROPE; ++r) {
+            const uint32_t t = (uint32_t)tid + 256u * r;
+            if (t < (GS + 1) * half_rope) {
+                const uint32_t v = t / half_rope, d = t % half_rope;
+                float* vec = v < GS ? s_q[v] : s_knew;
+                const float a = vec[d], b = vec[d + half_rope];
+                const float lo = round_bf16(a * rc[r][0] + (-b) * rc[r][1]);
+                const float hi = round_bf16(b * rc[r][2] + a * rc[r][3]);
+                vec[d] = lo;
+                vec[d + half_rope] = hi;
+            }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (split == 0 && sub == 0) { // append the new K / V rows to the cache (layout [tokens, kv_heads, hd])
         for (uint32_t d = tid; d < HD; d += 256) {
@@ -838,11 +866,12 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         mx[g] = -1e9f;
         sm[g] = 0.f;
     }
-    for (uint32_t first = key0; first <= L; first += TB * key_step) {
-        uint4 kc[TB], vc[TB];
+    for (uint32_t base = split; base <= L; base += TB * key_step) { // wave-uniform trip count
+        const uint32_t first = base + S * my_group;
+        u32x4_v kc[TB], vc[TB];
 #pragma unroll
         for (int t = 0; t < TB; ++t) kc[t] = kq[t], vc[t] = vq[t];
-        if (first + TB * key_step <= L) fetch(first + TB * key_step); // next batch in flight while this one is consumed
+        fetch(first + TB * key_step); // next batch in flight while this one is consumed (clamped past the end)
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const uint32_t i = first + t * key_step;
@@ -882,7 +911,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         for (int e = 0; e < 8; ++e) s_o[my_group][g][sl * 8 + e] = o[g][e];
         if (sl == 0) s_m[my_group][g] = mx[g], s_l[my_group][g] = sm[g];
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < GS * HD; idx += 256) {
         const int g = idx / HD, e = idx % HD;
         float m = s_m[0][g];
