@@ -156,6 +156,25 @@ def test_gemm_mfma_qwen_shapes(hip_ctx, n, k):
     assert (want == got).mean() >= 0.97
 
 
+@pytest.mark.parametrize("bits,method,group_size", [(4, 0, 128), (4, 1, 256), (4, 2, 64), (8, 0, 64), (8, 1, 128), (8, 2, 256)])
+@pytest.mark.parametrize("splits", ["1", "2", ""])
+def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeypatch):
+    """M >= 128 takes the 128 x 128 tile kernel (k_gemm128.hip): weights straight from global memory into the MFMA
+    operand, the offset term as extra k-steps of bf16 pieces, optional split-K.  Ragged M (300) and N (520)."""
+    if splits:
+        monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
+    else:
+        monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+    rng = np.random.default_rng(bits * 1000 + method * 100 + group_size)
+    n, k, m = 520, 2048, 300
+    q = quant_matrix(rng, n, k, bits, group_size, method)
+    a = activations(rng, m, k)
+    want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
 def test_gemm_mfma_epilogue(hip_ctx):
     """ab_scale + accumulate + bias + soft-cap epilogue and signed codes on the matrix-core path."""
     rng = np.random.default_rng(6)
@@ -164,6 +183,12 @@ def test_gemm_mfma_epilogue(hip_ctx):
     q["signed_codes"] = True
     a = activations(rng, m, k)
     bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
+    d0 = bf16(rng.uniform(-1, 1, size=(m, n)))
+    want = oracle_matmul(a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    got = hip_matmul(hip_ctx, a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+    m = 160  # the 128 x 128 tile kernel, with and without split-K
+    a = activations(rng, m, k)
     d0 = bf16(rng.uniform(-1, 1, size=(m, n)))
     want = oracle_matmul(a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)
     got = hip_matmul(hip_ctx, a, q, m, bias=bias, ab_scale=0.5, accumulate_d=d0, soft_cap=2.0)

@@ -7,6 +7,7 @@
 #include <functional>
 #include <array>
 #include <vector>
+#include <algorithm>
 #include "../uzu_amd/csrc/kernels.h"
 #include "../uzu_amd/csrc/kernels_decode.h"
 using namespace uzu::k;
@@ -58,11 +59,31 @@ int main(int argc, char** argv) {
             const uint32_t m = sh[0], n = sh[1], k = sh[2], g = 128;
             uint8_t* w = dalloc<uint8_t>((size_t)n * k / 2, 0x53); uint16_t* sc = dalloc<uint16_t>((size_t)n * k / g, 0x3c); uint16_t* bi = dalloc<uint16_t>((size_t)n * k / g, 0x3c);
             uint16_t* x = dalloc<uint16_t>((size_t)m * k, 0x3f); uint16_t* out = dalloc<uint16_t>((size_t)m * n);
+            void* gemm_ws = dalloc<uint8_t>((size_t)m * 2048 * 2 + (size_t)n * (k / g) * 4 + (size_t)4 * m * n * 4 + 65536);
             char name[64]; snprintf(name, sizeof name, "gemm_q_mfma %ux%ux%u", m, n, k);
             const double us = time_graph(name, (size_t)n * k / 2 + (size_t)m * k * 2 + (size_t)m * n * 2, 8, [&](int) {
                 MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi, p.d = out; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
-                p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k; return matmul(s, p, cus); });
+                p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k;
+                if (!getenv("KB_GEMM64") && gemm_q_mfma128_supported(p, cus)) return gemm_q_mfma128(s, p, cus, gemm_ws); // preallocated: no pool allocation while capturing
+                return matmul(s, p, cus); });
             printf("    -> %.1f TFLOP/s\n", 2.0 * m * n * k / us / 1e6);
+            if (getenv("KB_GEMM_DBG")) { // one instrumented launch: phase durations per workgroup
+                const size_t slots = 65536;
+                unsigned long long* d = dalloc<unsigned long long>(slots * 8, 0);
+                uzu::k::g_gemm128_dbg = d;
+                MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi, p.d = out; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
+                p.bits = 4, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k;
+                gemm_q_mfma128(s, p, cus, gemm_ws); CK(hipStreamSynchronize(s));
+                uzu::k::g_gemm128_dbg = nullptr;
+                std::vector<unsigned long long> h(slots * 8); CK(hipMemcpy(h.data(), d, slots * 64, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t1 = 0; double ph[3] = {0, 0, 0}; int cnt = 0;
+                for (size_t i = 0; i < slots; ++i) { const unsigned long long* o = &h[i * 8]; if (!o[0]) continue; ++cnt; t0 = o[0] < t0 ? o[0] : t0; t1 = o[3] > t1 ? o[3] : t1; for (int q = 0; q < 3; ++q) ph[q] += (double)(o[q + 1] - o[q]); }
+                printf("    dbg: %d workgroups, span %.1f us; mean us: prologue %.2f  main loop %.2f  offset term + epilogue %.2f\n", cnt, (t1 - t0) * 0.01,
+                       ph[0] / cnt * 0.01, ph[1] / cnt * 0.01, ph[2] / cnt * 0.01);
+                // start-time histogram: how many rounds
+                std::vector<double> st; for (size_t i = 0; i < slots; ++i) if (h[i * 8]) st.push_back((h[i * 8] - t0) * 0.01);
+                std::sort(st.begin(), st.end()); printf("    dbg: start times us: p10 %.1f p50 %.1f p90 %.1f max %.1f\n", st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st.back());
+            }
         }
         return 0;
     }

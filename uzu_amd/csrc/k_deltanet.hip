@@ -508,18 +508,10 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
     const uint32_t rows = num_v_heads * head_v_dim;
     if (!rows || !suffix_len) return UZU_OK;
     if (delta_net_prefill_chunked_supported(num_v_heads, num_k_heads, head_k_dim, head_v_dim, suffix_len)) {
-        // long suffix: chunked form with a stream-ordered scratch allocation (not while the stream is being captured)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-            void* ws = nullptr;
-            if (hipMallocAsync(&ws, delta_net_chunk_workspace_bytes(num_v_heads, suffix_len), s) == hipSuccess) {
-                const uzu_status st = delta_net_prefill_chunked(s, q_norm, k_norm, beta, decay, in_proj, state, out, (float*)ws, num_v_heads, num_k_heads, head_v_dim,
-                                                                key_dim, value_dim, suffix_len);
-                (void)hipFreeAsync(ws, s);
-                return st;
-            }
-            (void)hipGetLastError();
-        }
+        // long suffix: chunked form; scratch = the stream's workspace block (not while the stream is being captured)
+        if (void* ws = stream_workspace(s, delta_net_chunk_workspace_bytes(num_v_heads, suffix_len)))
+            return delta_net_prefill_chunked(s, q_norm, k_norm, beta, decay, in_proj, state, out, (float*)ws, num_v_heads, num_k_heads, head_v_dim, key_dim,
+                                             value_dim, suffix_len);
     }
     return launch_check([&] {
         hipLaunchKernelGGL(delta_net_prefill_kernel, dim3(rows / DNP_ROWS), dim3(256), 0, s, q_norm, k_norm, beta, decay, in_proj,

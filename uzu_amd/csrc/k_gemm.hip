@@ -340,7 +340,11 @@ uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus) {
         const char* e = getenv("UZU_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
-    (void)num_cus;
+    // M >= 128: the 128 x 128 tile kernel (k_gemm128.hip).  Its scratch (row-sum pieces of A, split-K partials) is the
+    // stream's workspace block, which is not available while the stream is being captured into a graph.
+    if (force != 64 && gemm_q_mfma128_supported(p, num_cus)) {
+        if (void* ws = stream_workspace(s, gemm_q_mfma128_workspace_bytes(p, num_cus))) return gemm_q_mfma128(s, p, num_cus, ws);
+    }
     switch (force) { // tools/kbench KB_GEMM sweep: 64 x 64 tiles (108 VGPRs, 4 waves / SIMD) win at every shape tried
     default: return launch_gemm<1, 1>(s, p);
     }

@@ -1,0 +1,483 @@
+// k_gemm128.hip -- the large-tile prefill MatmulKernel for gfx950 (M >= 128 rows): 128 x 128 x 64 workgroup tile,
+// weights never touch LDS.  Same reference semantics as k_gemm.hip (BU/cpu/kernel/matmul/kernel.rs:164-293).
+//
+//   * Four waves as 2 x 2, each wave 64 x 64 = 2 x 2 blocks of v_mfma_f32_32x32x16_bf16.  The k order inside a k-step
+//     is free as long as A and B agree: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take k = 32+8s..32+8s+7 at MFMA
+//     s of a 64-wide k-step, so the B operand of a lane is one 16-byte vector of its column's packed codes: global ->
+//     VGPR -> exact centred bf16 codes (v_cvt_off_f32_i4 / sext byte converts, as in k_gemm.hip) -> MFMA.  Only the
+//     activations are staged through LDS (double buffered, 144-byte pitch), one LDS-only barrier per k-step.
+//   * A quant group accumulates into acc_g (first MFMA of the group takes C = 0); at the group boundary
+//     acc_t += scale[n,g] * acc_g on the VALU (packed f32 FMAs).
+//   * The offset term  sum_g coef[n,g] * rowsum_g(A)[m]  is added once, in the epilogue: a pre-pass writes the group
+//     row sums of A (f32, [group][row]), and every lane runs G packed FMAs per pair of its 64 outputs -- no row-sum
+//     MFMAs and no per-group offset work in the main loop.
+//   * Every global load is unconditional (rows / columns / steps clamped into range) and prefetched into a register
+//     ring; the loop is unrolled by the ring depth so that all indices are static (vmcnt waits stay counted).
+//   * Tiles are numbered in 8 x 8 super-tiles per XCD (tile_map) so that the ~64 workgroups an XCD runs at a time share
+//     their activation and weight panels in its L2; few-tile shapes split K over gridDim.y with f32 partial tiles and
+//     a fixed-order reduction.  bf16 results leave through LDS as 16-byte row segments.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+namespace {
+constexpr int BK = 64, BM = 128, BN = 128;
+constexpr int A_PITCH = 144;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { // v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ u32x4_t dequant4(uint32_t w) { // nibbles = two's complement of q - 8 -> bf16 (q - 8) / 16
+    uint32_t h = w >> 4;
+    asm volatile("" : "+v"(h));
+    u32x4_t r;
+    r.x = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w & 0xFF), __builtin_amdgcn_cvt_off_f32_i4(h & 0xFF));
+    r.y = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 8) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 8) & 0xFF));
+    r.z = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 16) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 16) & 0xFF));
+    r.w = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w >> 24), __builtin_amdgcn_cvt_off_f32_i4(h >> 24));
+    return r;
+}
+__device__ __forceinline__ float sbyte(uint32_t w, int i) { return (float)(int)(int8_t)((w >> (8 * i)) & 0xFFu); }
+__device__ __forceinline__ u32x4_t dequant8(uint32_t w0, uint32_t w1) { // bytes = two's complement of q - 128
+    u32x4_t r;
+    r.x = pack_bf16(sbyte(w0, 0), sbyte(w0, 1));
+    r.y = pack_bf16(sbyte(w0, 2), sbyte(w0, 3));
+    r.z = pack_bf16(sbyte(w1, 0), sbyte(w1, 1));
+    r.w = pack_bf16(sbyte(w1, 2), sbyte(w1, 3));
+    return r;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------------- pre-pass
+// Blocks [0, rowsum_blocks): rowsum[g][m] = sum of A[m, k in group g] (f32), row stride Mp = M rounded up to 4 (pad rows are
+// zero); the remaining blocks: coef[g][n].  Row sums: one wave per row; lane l owns the 8-element chunks l, l + 64, ...;
+// the lanes of a group (group_size / 8, a power of two <= 64) are reduced with xor shuffles in a fixed order.
+__global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float* rowsum, float* coef, uint32_t rowsum_blocks) {
+    const uint32_t M = p.m, K = p.k, N = p.n, group_size = p.group_size, G = K / group_size;
+    if (blockIdx.x >= rowsum_blocks) {
+        // coef[g][n] (f32, the layout the epilogue's f32 MFMA operand wants: lanes = consecutive columns):
+        // ScaleBias: bias + mid * scale, ZeroPoint: scale * (mid - zp)   (codes were fed centred on mid = 2^(bits-1))
+        const uint32_t idx = (blockIdx.x - rowsum_blocks) * 256 + threadIdx.x;
+        if (idx >= N * G) return;
+        const uint32_t n = idx / G, g = idx % G; // consecutive threads read consecutive scales
+        const float mid = (float)(1u << (p.bits - 1));
+        const float scale = bf16_to_f32(((const uint16_t*)p.scales)[(size_t)n * G + g]);
+        float c;
+        if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+            const uint32_t zp_stride = p.bits == 4 ? (G + 1) / 2 : G;
+            const uint32_t zb = p.zero_points[(size_t)n * zp_stride + (p.bits == 4 ? (g >> 1) : g)];
+            c = scale * (mid - (float)(p.bits == 4 ? ((g & 1) ? (zb >> 4) : (zb & 0xF)) : zb));
+        } else {
+            c = fmaf(mid, scale, bf16_to_f32(((const uint16_t*)p.biases)[(size_t)n * G + g]));
+        }
+        coef[(size_t)g * N + n] = c;
+        return;
+    }
+    const uint16_t* a = (const uint16_t*)p.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = blockIdx.x * 4 + wave, Mp = (M + 3) & ~3u;
+    if (m >= Mp) return;
+    const uint32_t lpg = group_size / 8;
+    if (m >= M) { // pad rows are read (never stored) by the edge tiles
+        for (uint32_t g = lane; g < G; g += 64) rowsum[(size_t)g * Mp + m] = 0.f;
+        return;
+    }
+    const uint16_t* row = a + (size_t)m * K;
+    for (uint32_t base = 0; base < K / 8; base += 64) {
+        const uint32_t chunk = base + lane;
+        float s = 0.f;
+        if (chunk < K / 8) {
+            const u32x4_v v = *(const u32x4_v*)(row + (size_t)chunk * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s0 += bits_to_f32(w[i] << 16), s1 += bits_to_f32(w[i] & 0xFFFF0000u);
+            s = s0 + s1;
+        }
+        for (uint32_t off = 1; off < lpg; off <<= 1) s += __shfl_xor(s, (int)off, 64);
+        if (chunk < K / 8 && lane % lpg == 0) rowsum[(size_t)(chunk / lpg) * Mp + m] = s;
+    }
+}
+
+struct TileMap {
+    uint32_t TM, TN, S, m_blocks, Q; // super-tile of TM x TN tiles (S = TM TN <= 64), Q super-tiles in all
+};
+__host__ __device__ inline TileMap tile_map(uint32_t m_tiles, uint32_t n_tiles) {
+    TileMap t;
+    uint32_t tm0 = 1;
+    while (tm0 * 2 <= m_tiles && tm0 < 8) tm0 *= 2;
+    uint32_t tn = n_tiles / 8 < 64 / tm0 ? n_tiles / 8 : 64 / tm0; // keep at least one super-column per XCD
+    t.TN = tn ? tn : 1;
+    t.TM = tm0;
+    t.S = t.TM * t.TN;
+    t.m_blocks = (m_tiles + t.TM - 1) / t.TM;
+    t.Q = t.m_blocks * ((n_tiles + t.TN - 1) / t.TN);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------- main kernel
+// grid (8 S ceil(Q / 8), splits), see tile_map().  GS = k-steps per quant group (1, 2, 4 <=> group 64, 128, 256).
+template <int BITS, int GS>
+__global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, const float* rowsum, const float* coef, float* partials, unsigned long long* dbg) {
+    constexpr int WV = BITS / 4;           // 16-byte code vectors per lane per 32-column block per k-step
+    constexpr int DB = BITS == 4 ? 4 : 2;  // weight ring depth (k-steps in flight + 1)
+    constexpr int DA = 2;                  // activation register stages
+    constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
+    const uint32_t M = p.m, N = p.n, K = p.k;
+    const uint32_t m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+    // Workgroups are dealt to the 8 XCDs round-robin and an XCD runs ~64 of them at a time, so tile numbering decides
+    // what each 4 MB L2 sees: XCD x works through super-tiles x, x + 8, ... of TM x TN tiles (8 x 8 when the matrix is
+    // large enough) -- the 64 resident workgroups then share 8 activation row blocks and 8 weight column blocks.
+    const TileMap tm = tile_map(m_tiles, n_tiles);
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t q = xcd + 8 * (slot / tm.S), in = slot % tm.S;
+    const uint32_t m_t = (q % tm.m_blocks) * tm.TM + in % tm.TM, n_t = (q / tm.m_blocks) * tm.TN + in / tm.TM;
+    if (m_t >= m_tiles || n_t >= n_tiles) return;
+    unsigned long long ts[4];
+    ts[0] = wall_clock64();
+    const uint32_t m0 = m_t * BM, n0 = n_t * BN;
+    const uint32_t G = K / p.group_size;
+    const uint32_t splits = gridDim.y, z = blockIdx.y;
+    const uint32_t Gz = G / splits, g_lo = z * Gz;
+    const uint32_t kt_lo = g_lo * GS, KTz = Gz * GS; // KTz % U == 0 (host-checked)
+    const uint32_t row_bytes = K * BITS / 8;
+    const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
+    const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
+    const float mid = (float)(1u << (BITS - 1));
+
+    // ---- activation staging role: 8 lanes fetch one row's 128 bytes (one cache line per row per instruction), four
+    // passes of 32 rows.  (One thread per (row, 64-byte half) costs 45 L1 accesses per wave instruction -- rocprofv3
+    // TCP_TOTAL_CACHE_ACCESSES / TA_FLAT_READ_WAVEFRONTS -- and saturates the texture addresser at 4096^2-sized shapes.)
+    const int chunk = tid & 7, rpass = tid >> 3;
+    uint32_t a_off[4]; // element offsets of the thread's four rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = min(m0 + 32 * j + (uint32_t)rpass, M - 1) * K + kt_lo * BK + 8 * chunk;
+    const uint16_t* a_base = (const uint16_t*)p.a;
+    u32x4_v a_st[DA][4];
+    auto load_a = [&](uint32_t kt, u32x4_v (&st)[4]) {
+        kt = min(kt, KTz - 1); // past the end: re-read the last tile (never staged into a buffer that is read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[j] = *(const u32x4_v*)(a_base + (size_t)a_off[j] + kt * BK);
+    };
+    auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[4]) {
+        uint8_t* dst = &s_a[kt & 1][rpass * A_PITCH + chunk * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4_v*)(dst + j * 32 * A_PITCH) = st[j];
+    };
+
+    // ---- weight role: lane -> column c of each of the wave's two 32-column blocks, k half h
+    uint32_t ncol[2];
+    const uint8_t* w_src[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        ncol[nb] = min(n0 + wn * 64 + nb * 32 + c, N - 1);
+        w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)kt_lo * BK * BITS / 8 + (size_t)(32 * h) * BITS / 8;
+    }
+    u32x4_v ring[DB][2][WV];
+    auto load_w = [&](uint32_t kt, u32x4_v (&r)[2][WV]) {
+        kt = min(kt, KTz - 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const u32x4_v* src = (const u32x4_v*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
+#pragma unroll
+            for (int v = 0; v < WV; ++v) r[nb][v] = src[v];
+        }
+    };
+    const uint16_t* scales = (const uint16_t*)p.scales;
+
+    f32x16_t acc_g[2][2], acc_t[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_g[mb][nb][r] = 0.f, acc_t[mb][nb][r] = 0.f;
+
+    // group scales: sc_cur = group being accumulated, sc_nxt = the next one (requested one group ahead)
+    uint16_t sc_cur[2], sc_nxt[2];
+    auto load_scale = [&](uint32_t g, uint16_t (&dst)[2]) {
+        g = min(g_lo + g, G - 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) dst[nb] = scales[(size_t)ncol[nb] * G + g];
+    };
+
+    const uint8_t* a_frag_base = &s_a[0][(wm * 64 + c) * A_PITCH + h * 64];
+    // one k-step of code MFMAs out of LDS buffer (kt & 1) and a ring slot; `first` = first k-step of a quant group
+    auto mfma_codes = [&](uint32_t kt, const u32x4_v (&raw)[2][WV], bool first) {
+        const uint8_t* ab = a_frag_base + (kt & 1) * (BM * A_PITCH);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4_t bf[2], af[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (BITS == 4) bf[nb] = dequant4(raw[nb][0][s] ^ flip);
+                else bf[nb] = dequant8(raw[nb][s >> 1][(s & 1) * 2] ^ flip, raw[nb][s >> 1][(s & 1) * 2 + 1] ^ flip);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const f32x16_t zero = {};
+                    acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[mb]), __builtin_bit_cast(bf16x8_t, bf[nb]),
+                                                                           (first && s == 0) ? zero : acc_g[mb][nb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0); // keep the conversions of MFMA s next to their use (register pressure)
+        }
+    };
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    auto fold = [&]() { // acc_t += scale * acc_g at a group boundary
+        f32x2_t sc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = (BITS == 4 ? 16.0f : 1.0f) * bf16_to_f32(sc_cur[nb]);
+        // In place on acc_t through inline asm: left to itself the register allocator writes the result over acc_g and
+        // permutes the 16-register accumulator tuples around the loop (60-180 VGPRs of spills at the 256 budget).  The
+        // hazard recogniser cannot see an MFMA -> VALU read through inline asm, so the wait for the last MFMA of the
+        // group (at most 16 passes: 18 wait states) is spelled out.
+        asm volatile("s_nop 15\n\ts_nop 3");
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t t = {acc_t[mb][nb][r], acc_t[mb][nb][r + 1]};
+                    const f32x2_t g = {acc_g[mb][nb][r], acc_g[mb][nb][r + 1]};
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(sc[nb]), "v"(g));
+                    acc_t[mb][nb][r] = t.x, acc_t[mb][nb][r + 1] = t.y;
+                }
+        __builtin_amdgcn_sched_barrier(0); // the next group's first MFMA must not be hoisted above the fold (it would need a second acc_g)
+    };
+
+    // ---- prologue: activation tile 0 -> LDS, tiles 1 .. DA -> registers, ring slots 0 .. DB-2, scales of groups 0 and 1
+    {
+        u32x4_v first[4];
+        load_a(0, first);
+#pragma unroll
+        for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
+#pragma unroll
+        for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
+        load_scale(0, sc_cur);
+        load_scale(1, sc_nxt);
+        stage_a(0, first);
+    }
+    lds_barrier();
+    ts[1] = wall_clock64();
+
+    for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t kt = kt0 + u;
+            load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
+            mfma_codes(kt, ring[u % DB], u % GS == 0);
+            stage_a(kt + 1, a_st[(u + 1) % DA]); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
+            load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
+            if ((u + 1) % GS == 0) {
+                fold();
+                sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
+                load_scale((kt + 1) / GS + 1, sc_nxt);
+            }
+            lds_barrier();
+        }
+    }
+    ts[2] = wall_clock64();
+
+    // ---- offset term: acc_t[m, n] += sum_g rowsum[g][m] * coef[g][n] over this split's groups, on the matrix cores in
+    // f32 (v_mfma_f32_32x32x2_f32: products and sums exact to f32): lane (c, h) supplies row / column c of group 2 i + h,
+    // every load is one coalesced dword per lane.
+    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC) {
+        const uint32_t Mp = (M + 3) & ~3u;
+        uint32_t arow[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) arow[mb] = min(m0 + wm * 64 + mb * 32 + c, Mp - 1);
+        const uint32_t g_end = g_lo + Gz;
+#pragma unroll 4
+        for (uint32_t g2 = g_lo; g2 < g_end; g2 += 2) {
+            const uint32_t g = min(g2 + h, g_end - 1);
+            const bool live = g2 + h < g_end;
+            float av[2], bv[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) av[mb] = rowsum[(size_t)g * Mp + arow[mb]];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bv[nb] = live ? coef[(size_t)g * N + ncol[nb]] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc_t[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc_t[mb][nb], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (kernel.rs:281-292): lane holds column n, rows (r & 3) + 8 (r >> 2) + 4 h of each block
+    uint16_t* d = (uint16_t*)p.d;
+    float* d32 = (float*)p.d;
+    const bool out_f32 = p.d_dt == UZU_F32;
+    const bool via_lds = !partials && !out_f32 && !p.accumulate && !p.has_soft_cap && N % 8 == 0 && (uintptr_t)p.d % 16 == 0;
+    if (via_lds) {
+        // Common case, branch-free: bf16(ab_scale * acc + bias) goes to a wave-private LDS tile (64 rows x 64 columns,
+        // 144-byte pitch; the activation buffers are free after the last barrier) and leaves as 16-byte row segments,
+        // 8 lanes per 128-byte row -- instead of 64 two-byte stores per lane.
+        uint16_t* s_d = (uint16_t*)&s_a[0][0] + wave * (64 * 72);
+        const float ab = p.ab_scale;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float bias = p.bias ? bf16_to_f32(((const uint16_t*)p.bias)[ncol[nb]]) : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) { // rows r and r + 1 are consecutive
+                    const uint32_t lr = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const uint32_t pk = pack_bf16(__fadd_rn(__fmul_rn(ab, acc_t[mb][nb][r]), bias), __fadd_rn(__fmul_rn(ab, acc_t[mb][nb][r + 1]), bias)); // two roundings, as the reference
+                    s_d[lr * 72 + nb * 32 + c] = (uint16_t)pk;
+                    s_d[(lr + 1) * 72 + nb * 32 + c] = (uint16_t)(pk >> 16);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no workgroup barrier needed
+        const int seg = lane & 7, rsub = lane >> 3;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const uint32_t lr = pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n0 + wn * 64 + seg * 8;
+            const u32x4_v v = *(const u32x4_v*)(s_d + lr * 72 + seg * 8);
+            if (m < M && n < N) *(u32x4_v*)(d + (size_t)m * N + n) = v;
+        }
+    } else if (partials) { // split-K: raw f32 partial tile (32 lanes = one 128-byte row segment per store)
+        float* pz = partials + (size_t)z * M * N;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint32_t n = n0 + wn * 64 + nb * 32 + c;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M && n < N) pz[(size_t)m * N + n] = acc_t[mb][nb][r];
+                }
+        }
+    } else {
+#pragma unroll 1
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint32_t n = n0 + wn * 64 + nb * 32 + c;
+            const float bias = (p.bias && n < N) ? bf16_to_f32(((const uint16_t*)p.bias)[n]) : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m >= M || n >= N) continue;
+                    const size_t idx = (size_t)m * N + n;
+                    const float acc = nb ? acc_t[mb][1][r] : acc_t[mb][0][r];
+                    float value = p.ab_scale * acc;
+                    if (p.accumulate) value += out_f32 ? d32[idx] : bf16_to_f32(d[idx]);
+                    if (p.bias) value += bias;
+                    if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
+                    if (out_f32) d32[idx] = value;
+                    else d[idx] = f32_to_bf16(value);
+                }
+        }
+    }
+    if (dbg && tid == 0) {
+        ts[3] = wall_clock64();
+        unsigned long long* o = dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 4; ++i) o[i] = ts[i];
+        o[6] = (unsigned long long)m_t << 32 | n_t;
+        o[7] = xcd;
+    }
+}
+
+// split-K reduction in split order + the epilogue
+__global__ void __launch_bounds__(256) gemm_split_reduce_kernel(MatmulParams p, const float* partials, uint32_t splits) {
+    const size_t total = (size_t)p.m * p.n;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    float acc = partials[idx];
+    for (uint32_t z = 1; z < splits; ++z) acc += partials[(size_t)z * total + idx];
+    const uint32_t n = (uint32_t)(idx % p.n);
+    const bool out_f32 = p.d_dt == UZU_F32;
+    float value = p.ab_scale * acc;
+    if (p.accumulate) value += out_f32 ? ((const float*)p.d)[idx] : bf16_to_f32(((const uint16_t*)p.d)[idx]);
+    if (p.bias) value += bf16_to_f32(((const uint16_t*)p.bias)[n]);
+    if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
+    if (out_f32) ((float*)p.d)[idx] = value;
+    else ((uint16_t*)p.d)[idx] = f32_to_bf16(value);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+unsigned long long* g_gemm128_dbg = nullptr; // tools/kbench KB_GEMM_DBG: per-workgroup phase timestamps (100 MHz wall clock)
+static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
+    const char* e = getenv("UZU_GEMM_SPLITS"); // read per call: tests/test_gpu_kernels.py pins it to cover both paths
+    const int force = e ? atoi(e) : 0;
+    const uint32_t G = p.k / p.group_size, gs = p.group_size / BK;
+    const uint32_t tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
+    auto ok = [&](uint32_t s) { return G % s == 0 && ((G / s) * gs) % 4 == 0; };
+    if (force > 0) return ok((uint32_t)force) ? (uint32_t)force : 0u;
+    if (!ok(1)) return 0;
+    uint32_t best = 1;
+    for (uint32_t s = 2; s <= 4; ++s) // each split adds an f32 tile round trip: stop once the chip has a workgroup per CU
+        if (ok(s) && tiles * best < (uint32_t)num_cus * 3 / 4 && tiles * s <= (uint32_t)num_cus * 2) best = s;
+    return best;
+}
+bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
+    if (p.m < 128 || p.n < 64) return false;
+    if (p.group_size != 64 && p.group_size != 128 && p.group_size != 256) return false;
+    if ((size_t)p.k * p.bits / 8 % 16 || p.k % BK) return false;
+    if ((uint64_t)p.m * p.k >= (1ull << 32) || (uint64_t)p.n * p.k * p.bits / 8 >= (1ull << 32)) return false; // 32-bit element offsets
+    return gemm128_splits(p, num_cus) != 0;
+}
+size_t gemm_q_mfma128_workspace_bytes(const MatmulParams& p, int num_cus) {
+    const uint32_t G = p.k / p.group_size;
+    const uint32_t splits = gemm128_splits(p, num_cus);
+    size_t bytes = ((size_t)((p.m + 3) & ~3u) * G * 4 + 255) / 256 * 256 + ((size_t)p.n * G * 4 + 255) / 256 * 256;
+    if (splits > 1) bytes += (size_t)splits * p.m * p.n * 4;
+    return bytes;
+}
+uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, void* workspace) {
+    const uint32_t G = p.k / p.group_size;
+    const uint32_t splits = gemm128_splits(p, num_cus);
+    const size_t rowsum_bytes = ((size_t)((p.m + 3) & ~3u) * G * 4 + 255) / 256 * 256, coef_bytes = ((size_t)p.n * G * 4 + 255) / 256 * 256;
+    float* rowsum = (float*)workspace;
+    float* coef = (float*)((uint8_t*)workspace + rowsum_bytes);
+    float* partials = splits > 1 ? (float*)((uint8_t*)workspace + rowsum_bytes + coef_bytes) : nullptr;
+    uzu_status st = UZU_OK;
+    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC) {
+        const uint32_t rowsum_blocks = (((p.m + 3) & ~3u) + 3) / 4, coef_blocks = (p.n * G + 255) / 256;
+        st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
+        if (st != UZU_OK) return st;
+    }
+    const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
+    const TileMap tm = tile_map(m_tiles, n_tiles);
+    const dim3 grid(8 * tm.S * ((tm.Q + 7) / 8), splits);
+#define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum, coef, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
+    const uint32_t gs = p.group_size / BK;
+    if (p.bits == 4) {
+        if (gs == 1) UZU_LAUNCH(4, 1);
+        else if (gs == 2) UZU_LAUNCH(4, 2);
+        else UZU_LAUNCH(4, 4);
+    } else {
+        if (gs == 1) UZU_LAUNCH(8, 1);
+        else if (gs == 2) UZU_LAUNCH(8, 2);
+        else UZU_LAUNCH(8, 4);
+    }
+#undef UZU_LAUNCH
+    if (st != UZU_OK || splits == 1) return st;
+    const size_t total = (size_t)p.m * p.n;
+    return launch_check([&] { hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, p, partials, splits); }, "gemm_split_reduce");
+}
+
+} // namespace k
+} // namespace uzu

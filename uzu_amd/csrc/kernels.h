@@ -41,10 +41,18 @@ struct MatmulParams {
     uint32_t act_mul;   // epilogue: rows [0,n/2) = up, [n/2,n) = gate; writes d[m, n/2] = up * act(gate)
     uint32_t act_type;
 };
+// runtime.hip: grow-only per-stream scratch block; nullptr while `s` is being captured (or when the allocation fails)
+void* stream_workspace(hipStream_t s, size_t bytes);
+void stream_workspace_release(hipStream_t s);
 // `variant` (optional) receives a short label of the kernel instance chosen (for per-kernel profiles)
 uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char** variant = nullptr);
 bool gemm_q_mfma_supported(const MatmulParams& p);   // k_gemm.hip: M >= 16, bf16 activations, int4/int8 codes, group % 64 == 0
 uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus);
+// k_gemm128.hip: 128 x 128 tiles, M >= 128, group 64 / 128 / 256; `workspace` holds the activation row-sum pieces (+ split-K partials)
+bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus);
+size_t gemm_q_mfma128_workspace_bytes(const MatmulParams& p, int num_cus);
+uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, void* workspace);
+extern unsigned long long* g_gemm128_dbg; // profiling aid (tools/kbench KB_GEMM_DBG)
 size_t matmul_algorithmic_bytes(const MatmulParams& p); // codes + scales + correction + A + D, SURVEY.md §8d
 
 // ---------------------------------------------------------------- normalization

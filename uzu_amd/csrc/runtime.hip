@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 
 #include "internal.h"
 
@@ -35,6 +36,50 @@ uzu_status cmdbuf_check_encoding(uzu_hip_cmdbuf* cb) {
     return UZU_OK;
 }
 
+} // namespace uzu
+
+namespace uzu {
+namespace k {
+// Per-stream scratch for kernels that need a transient device buffer (split-K partials, DeltaNet chunk tables, arg-max
+// partials).  One grow-only hipMalloc block per stream: consecutive users on a stream are ordered by the stream itself.
+// (The stream-ordered pool, hipMallocAsync / hipFreeAsync, handed out blocks that were overwritten while the kernels of
+// the call were still in flight on this ROCm build -- tools/dbg_gemm.py -- so it is not used.)
+namespace {
+struct WsEntry {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_ws_mutex;
+std::unordered_map<hipStream_t, WsEntry> g_ws;
+} // namespace
+void* stream_workspace(hipStream_t s, size_t bytes) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr; // a graph would pin a block that may be regrown
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    WsEntry& e = g_ws[s];
+    if (e.bytes >= bytes) return e.ptr;
+    if (e.ptr) { // earlier users may still be running: drain the stream before the block goes away
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(e.ptr);
+        e.ptr = nullptr, e.bytes = 0;
+    }
+    const size_t want = ((bytes > 2 * e.bytes ? bytes : 2 * e.bytes) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    e.ptr = p, e.bytes = want;
+    return p;
+}
+void stream_workspace_release(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws.find(s);
+    if (it == g_ws.end()) return;
+    if (it->second.ptr) (void)hipFree(it->second.ptr);
+    g_ws.erase(it);
+}
+} // namespace k
 } // namespace uzu
 
 using namespace uzu;
@@ -73,6 +118,7 @@ void uzu_hip_context_destroy(uzu_hip_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
+    k::stream_workspace_release(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
