@@ -16,3 +16,13 @@ def test_expf_logf_match_glibc_bitwise():
     lines = dict(l.split(":") for l in out.strip().splitlines() if ":" in l)
     assert lines["expf"].strip().endswith(" 0 mismatches") and lines["logf"].strip().endswith(" 0 mismatches"), out
     assert int(lines["expf"].split()[0]) > 3_000_000
+
+
+def test_gemm_tile_map_visits_every_tile_once():
+    """uzu_amd/csrc/gemm_tile_map.h (workgroup id -> output tile of the large-tile prefill GEMM, XCD super-tiles):
+    exhaustive host check over 48 x 160 tile counts."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "tile_map_check")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "tile_map_check.cpp")], check=True)
+        out = subprocess.check_output([exe]).decode()
+    assert out.strip().endswith(" 0 bad"), out

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "device_utils.h"
+#include "gemm_tile_map.h"
 #include "kernels.h"
 
 namespace uzu {
@@ -111,22 +112,6 @@ __global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float
     }
 }
 
-struct TileMap {
-    uint32_t TM, TN, S, m_blocks, Q; // super-tile of TM x TN tiles (S = TM TN <= 64), Q super-tiles in all
-};
-__host__ __device__ inline TileMap tile_map(uint32_t m_tiles, uint32_t n_tiles) {
-    TileMap t;
-    uint32_t tm0 = 1;
-    while (tm0 * 2 <= m_tiles && tm0 < 8) tm0 *= 2;
-    uint32_t tn = n_tiles / 8 < 64 / tm0 ? n_tiles / 8 : 64 / tm0; // keep at least one super-column per XCD
-    t.TN = tn ? tn : 1;
-    t.TM = tm0;
-    t.S = t.TM * t.TN;
-    t.m_blocks = (m_tiles + t.TM - 1) / t.TM;
-    t.Q = t.m_blocks * ((n_tiles + t.TN - 1) / t.TN);
-    return t;
-}
-
 // ---------------------------------------------------------------------------------------------- main kernel
 // grid (8 S ceil(Q / 8), splits), see tile_map().  GS = k-steps per quant group (1, 2, 4 <=> group 64, 128, 256).
 template <int BITS, int GS>
@@ -144,11 +129,9 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     // Workgroups are dealt to the 8 XCDs round-robin and an XCD runs ~64 of them at a time, so tile numbering decides
     // what each 4 MB L2 sees: XCD x works through super-tiles x, x + 8, ... of TM x TN tiles (8 x 8 when the matrix is
     // large enough) -- the 64 resident workgroups then share 8 activation row blocks and 8 weight column blocks.
-    const TileMap tm = tile_map(m_tiles, n_tiles);
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t q = xcd + 8 * (slot / tm.S), in = slot % tm.S;
-    const uint32_t m_t = (q % tm.m_blocks) * tm.TM + in % tm.TM, n_t = (q / tm.m_blocks) * tm.TN + in / tm.TM;
-    if (m_t >= m_tiles || n_t >= n_tiles) return;
+    uint32_t m_t, n_t;
+    if (!gemm_tile_of_block(blockIdx.x, m_tiles, n_tiles, &m_t, &n_t)) return;
+    const uint32_t xcd = blockIdx.x & 7;
     unsigned long long ts[4];
     ts[0] = wall_clock64();
     const uint32_t m0 = m_t * BM, n0 = n_t * BN;
@@ -460,8 +443,7 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
         if (st != UZU_OK) return st;
     }
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
-    const TileMap tm = tile_map(m_tiles, n_tiles);
-    const dim3 grid(8 * tm.S * ((tm.Q + 7) / 8), splits);
+    const dim3 grid(gemm_grid_x(m_tiles, n_tiles), splits);
 #define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum, coef, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
     const uint32_t gs = p.group_size / BK;
     if (p.bits == 4) {
