@@ -175,6 +175,31 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
     assert (want == got).mean() >= 0.97
 
 
+@pytest.mark.parametrize("splits", ["1", ""])
+def test_gemm_mfma_f32_output(hip_ctx, splits, monkeypatch):
+    """f32 result buffer (the tensor-parallel row-parallel linears hand f32 partial sums to the all-reduce): the
+    large-tile kernel's direct-store epilogue and the split-K reduction, against the oracle rounded to bf16."""
+    if splits:
+        monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
+    else:
+        monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+    rng = np.random.default_rng(77)
+    n, k, m = 520, 1024, 200
+    q = quant_matrix(rng, n, k, 4, 128, 0)
+    a = activations(rng, m, k)
+    want = oracle_matmul(a, q, m)
+    kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.F32)
+    ba, bw, bs, bb = hip_ctx.buffer_from(a), hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"]), hip_ctx.buffer_from(q["biases"])
+    bd = hip_ctx.buffer_from(np.zeros((m, n), dtype=np.float32))
+    run(hip_ctx, lambda cb: kern.encode(cb, a=ba, b=bw, d=bd, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bs, biases=bb, zero_points=None,
+                                         mode=B.QMODE_U4, group_size=128, signed_codes=False, ab_scale=1.0, accumulate=False, bias=None,
+                                         soft_cap=None, gather_indices=None))
+    got = bf16(bd.download(np.float32, m * n).reshape(m, n))
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
 def test_gemm_mfma_epilogue(hip_ctx):
     """ab_scale + accumulate + bias + soft-cap epilogue and signed codes on the matrix-core path."""
     rng = np.random.default_rng(6)
