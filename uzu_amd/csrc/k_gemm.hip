@@ -11,14 +11,14 @@
 //     boundary   acc += scale[n,g] * acc_g + coef[n,g] * sum_k A[m,k in g]   runs on the VALU in f32 -- the same
 //     grouped form the decode GEMV uses (gemv_core.h), so prefill and decode see the same arithmetic up to summation
 //     order.  Nothing is ever rounded to a bf16 *weight*.
-//   * v_mfma_f32_32x32x16_bf16; workgroup tile 128 x 128 x 64, four waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA
-//     blocks.  The B operand of the instruction (a lane holds 8 consecutive k of ONE column n) is exactly one u32 of
-//     packed int4 codes, so the weights go global -> VGPR -> dequant -> MFMA with no LDS round trip;
-//     a lane fetches 16 bytes (32 codes) per 32-column block per k-step.  Only the activations are staged through
-//     LDS (double buffered, 144-byte row pitch => conflict-free ds_read_b128).
-//   * The k order inside an MFMA is irrelevant as long as A and B agree, so the kernel picks the order that makes
-//     the weight fetch one 16-byte vector per lane: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take
-//     k = 32+8s..32+8s+7 at step s of a 64-wide k-step.
+//   * v_mfma_f32_32x32x16_bf16; workgroup tile 64 x 64 x 64, four waves as 2 x 2, each wave one 32 x 32 block (three
+//     workgroups per CU).  This is the kernel for 16 <= M < 128 and for shapes the large-tile kernel (k_gemm128.hip: 128 x 128
+//     tiles, weights straight from global memory into the MFMA operand) does not cover.
+//   * The k order inside an MFMA is irrelevant as long as A and B agree, so the kernel picks the order that makes the
+//     weight fetch one vector per lane: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take k = 32+8s..32+8s+7 at step s
+//     of a 64-wide k-step.  The two waves that cover the same 32 columns convert half of the k16 steps each and share the
+//     converted fragments through LDS in operand order; the activations are staged through LDS as well (double buffered,
+//     144-byte row pitch => conflict-free ds_read_b128).
 //   * Row sums of the activations per quant group come from the matrix cores as well (one extra MFMA per k16 step with
 //     an all-ones B operand): the result lands in the accumulator layout the group fold needs.
 #include <stdlib.h>

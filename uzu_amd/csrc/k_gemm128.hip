@@ -140,9 +140,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     const uint32_t Gz = G / splits, g_lo = z * Gz;
     const uint32_t kt_lo = g_lo * GS, KTz = Gz * GS; // KTz % U == 0 (host-checked)
     const uint32_t row_bytes = K * BITS / 8;
-    const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
     const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
-    const float mid = (float)(1u << (BITS - 1));
 
     // ---- activation staging role: 8 lanes fetch one row's 128 bytes (one cache line per row per instruction), four
     // passes of 32 rows.  (One thread per (row, 64-byte half) costs 45 L1 accesses per wave instruction -- rocprofv3
