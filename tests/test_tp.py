@@ -132,6 +132,45 @@ def test_shards_reassemble_the_full_layer(size, method):
     assert all(not s.tied_embeddings and s.embedding.n == cfg.vocab_size for s in shards)
 
 
+@pytest.mark.parametrize("heads,kv_heads,size,hidden", [(32, 8, 4, 448), (40, 8, 8, 544), (8, 2, 8, 224)])
+def test_attention_only_models_shard_like_baseline_configs(heads, kv_heads, size, hidden):
+    """BASELINE configs C4 (Llama-3-8B: 32 q / 8 kv heads, TP 4) and C5 (Qwen3-14B class: 40 / 8, TP 8) at toy widths, plus
+    kv heads replicated over more ranks than heads: untied read-out, no gate projection, ZeroPoint int4 groups of 32
+    (hidden sizes that need zero padding)."""
+    hd = 32  # = the quant group: a rank's slice of the out-projection's K (its heads) falls on group boundaries, as with hd 128 / group 128
+    cfg = S.tiny_llama(num_heads=heads, num_groups=kv_heads, head_dim=hd, model_dim=128, hidden_dim=hidden, vocab_size=64 * size,
+                       rope=D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=hd, max_sequence_length=256, base=10000.0), layer_kinds=[D.MIXER_ATTENTION] * 2)
+    bundle = S.build_model(cfg)
+    shards = [TP.shard_bundle(bundle, r, size) for r in range(size)]
+    rng = np.random.default_rng(9)
+    x, y = rng.normal(size=(cfg.model_dim,)), rng.normal(size=(heads * hd,))
+    for li, full in enumerate(bundle.layers):
+        qkv = dequant(full.qkv_projection) @ x
+        want_attn = dequant(full.out_projection) @ y
+        up = dequant(full.up_projection) @ x
+        want_mlp = dequant(full.down_projection) @ (up[:hidden] * silu(up[hidden:]))
+        got_attn, got_mlp = np.zeros(cfg.model_dim), np.zeros(cfg.model_dim)
+        for r, (shard, _) in enumerate(shards):
+            p = shard.layers[li]
+            lq, lkv = p.num_heads, p.num_groups
+            assert lq == heads // size and lkv == max(kv_heads // size, 1) and lq % lkv == 0
+            q_lo, kv_lo = r * lq, (r * lq) // (heads // kv_heads)
+            local = dequant(p.qkv_projection) @ x
+            close(local[: lq * hd], qkv[q_lo * hd:(q_lo + lq) * hd])
+            close(local[lq * hd:(lq + lkv) * hd], qkv[(heads + kv_lo) * hd:(heads + kv_lo + lkv) * hd])
+            close(local[(lq + lkv) * hd:], qkv[(heads + kv_heads + kv_lo) * hd:(heads + kv_heads + kv_lo + lkv) * hd])
+            got_attn += dequant(p.out_projection) @ y[q_lo * hd:(q_lo + lq) * hd]
+            u = dequant(p.up_projection) @ x
+            hp = p.hidden_dim
+            assert hp % cfg.group_size == 0 and hp * size >= hidden
+            got_mlp += dequant(p.down_projection) @ (u[:hp] * silu(u[hp:]))
+        np.testing.assert_allclose(got_attn, want_attn, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(got_mlp, want_mlp, rtol=1e-12, atol=1e-12)
+    assert [o for _, o in shards] == [r * cfg.vocab_size // size for r in range(size)]
+    np.testing.assert_array_equal(np.concatenate([dequant(s.output_embedding) for s, _ in shards]), dequant(bundle.output_embedding))
+    assert all(np.array_equal(dequant(s.embedding), dequant(bundle.embedding)) for s, _ in shards)  # input embedding replicated
+
+
 def test_qwen35_0p8b_shard_shapes_at_8_ranks():
     """The headline model at TP=8 without building its weights: 8 q / 2 kv heads -> 1 q head + a replicated kv head,
     16 DeltaNet heads -> 2, hidden 3584 -> padded to 4096 (512 per rank = 4 groups of 128), vocab 248320 -> 31040."""
