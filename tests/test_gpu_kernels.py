@@ -175,6 +175,21 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
     assert (want == got).mean() >= 0.97
 
 
+@pytest.mark.parametrize("m", [131, 203, 1023])
+def test_gemm_mfma_row_count_not_a_multiple_of_four(hip_ctx, m):
+    """The offset-term tables are padded to whole quads of rows (k_gemm128.hip pre-pass); 1023 is the second chunk of the
+    benchmark's 2047-token prefill."""
+    rng = np.random.default_rng(m)
+    n, k = 264, 512
+    for method in (0, 1):
+        q = quant_matrix(rng, n, k, 4, 128, method)
+        a = activations(rng, m, k)
+        want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+        ulps = ulp_diff_bf16(want, got)
+        assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+        assert (want == got).mean() >= 0.97
+
+
 @pytest.mark.parametrize("splits", ["1", ""])
 def test_gemm_mfma_f32_output(hip_ctx, splits, monkeypatch):
     """f32 result buffer (the tensor-parallel row-parallel linears hand f32 partial sums to the all-reduce): the
