@@ -9,10 +9,11 @@
  *
  * PARITY STATUS: the reference is Rust 1.94 (no toolchain in this environment, no network) and
  * ships no golden vectors for this path, so this oracle cannot be checked against outputs of the
- * reference itself: **parity unpinned** except for (a) the one literal known-answer test in the
- * reference tree (gated_act_mul_test.rs:139-160) and (b) independent float64 NumPy references of
- * the same math, mirroring the reference's own `reference_attention` style checks
- * (tests/test_oracle_*.py).
+ * reference itself: **parity unpinned** except for (a) the literal known answers the reference tree
+ * holds (gated_act_mul_test.rs:139-160; gumbel_test.rs: the uniform mapping of the sampler), (b) the
+ * published Random123 known-answer vectors of Philox4x32-10, the sampler's generator, and
+ * (c) independent float64 NumPy references of the same math, mirroring the reference's own
+ * `reference_attention` style checks (tests/test_oracle_*.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
  * The product (uzu_amd/) never does.
@@ -149,7 +150,16 @@ void orc_tensor_add_scale(const void* input, const void* bias, void* output, uin
 void orc_tensor_add_swap(void* skip, void* main_buf, uint32_t dtype, uint32_t length);
 void orc_tensor_copy(const void* src, void* dst, uint32_t dtype, uint32_t length);
 void orc_argmax(const void* logits, uint32_t dtype, uint32_t* output, uint32_t vocab_size,
-                uint32_t batch_size); /* unified_sampling.rs greedy: ties -> lowest index */
+                uint32_t batch_size);
+/* sampler RNG (gumbel.rs) and the full UnifiedSampling kernel (unified_sampling.rs:13-99); seeds / bitmask may be NULL */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float orc_unit_interval(uint32_t word);
+float orc_uniform_float(uint64_t key, uint32_t offset, uint32_t word);
+float orc_gumbel_float(uint64_t key, uint32_t offset, uint32_t word);
+void orc_revidx(uint32_t logit_idx, uint32_t vocab_size, uint32_t* offset, uint32_t* word);
+void orc_unified_sampling(const void* logits, uint32_t dtype, uint32_t* output, const uint64_t* seeds, const uint32_t* bitmask,
+                          uint32_t has_temperature, float temperature, uint32_t has_top_k, uint32_t top_k, uint32_t has_top_p,
+                          float top_p, uint32_t has_min_p, float min_p, uint32_t vocab_size, uint32_t batch_size); /* unified_sampling.rs greedy: ties -> lowest index */
 
 /* ---- Gated DeltaNet (cpu/kernel/gdn/{conv_update,update,conv_scan,prefill_prep,prefill,norm_gate}.rs,
  *      ssm/conv1d.rs Conv1dPack) with the Metal kernels' buffer types: T = bf16 activations,

@@ -608,6 +608,113 @@ void orc_argmax(const void* logits, uint32_t dt, uint32_t* output, uint32_t voca
     }
 }
 
+/* ------------------------------------------------------------------ stochastic sampling
+ * Counter-based RNG of the sampler: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+ * the reference's copy: BU/encodable_block/sampling/gumbel.rs:1-57).  Pinned in tests/test_oracle_sampling.py by the
+ * published Random123 known-answer vectors and by the reference's own unit test of unit_interval (gumbel_test.rs). */
+void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+    uint32_t ctr[4] = {ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3]};
+    uint32_t key[2] = {key_in[0], key_in[1]};
+    for (int round = 0; round < 10; ++round) {
+        if (round) { /* philox4x32_bumpkey */
+            key[0] += 0x9E3779B9u;
+            key[1] += 0xBB67AE85u;
+        }
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0], p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ ctr[1] ^ key[0], n2 = hi0 ^ ctr[3] ^ key[1];
+        ctr[0] = n0, ctr[1] = lo1, ctr[2] = n2, ctr[3] = lo0;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = ctr[i];
+}
+/* gumbel.rs:52-57: uniform in [2^-24, 1 - 2^-24] from the top 24 bits */
+float orc_unit_interval(uint32_t word) {
+    const uint32_t top = word >> 8;
+    return (float)(top > 1u ? top : 1u) * (1.0f / 16777216.0f);
+}
+/* gumbel.rs:34-50: counter (offset, 0, 0, 0), key = the 64-bit seed, word selects one of the four outputs */
+float orc_uniform_float(uint64_t key, uint32_t offset, uint32_t word) {
+    const uint32_t ctr[4] = {offset, 0u, 0u, 0u}, k[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+    uint32_t out[4];
+    orc_philox4x32_10(ctr, k, out);
+    return orc_unit_interval(out[word & 3u]);
+}
+float orc_gumbel_float(uint64_t key, uint32_t offset, uint32_t word) { /* gumbel.rs:59-64 */
+    return -logf(-logf(orc_uniform_float(key, offset, word)));
+}
+/* gumbel.rs:66-81: (counter offset, word) of logit `logit_idx` -- the numbering of the GPU kernel's 1024-thread groups */
+void orc_revidx(uint32_t logit_idx, uint32_t vocab_size, uint32_t* offset, uint32_t* word) {
+    const uint32_t tg = 1024u, words = 4u;
+    const uint32_t thread_idx = logit_idx % tg;
+    const uint32_t thread_offset = ((vocab_size + tg * words - 1u) / (tg * words)) * thread_idx;
+    const uint32_t block_idx = logit_idx / tg;
+    *offset = thread_offset + block_idx / words;
+    *word = block_idx % words;
+}
+
+typedef struct {
+    uint32_t index;
+    float logit;
+} orc_indexed_logit;
+static int orc_sort_desc(const void* pa, const void* pb) { /* b.1.partial_cmp(&a.1).unwrap_or(Equal).then(a.0.cmp(&b.0)) */
+    const orc_indexed_logit *a = (const orc_indexed_logit*)pa, *b = (const orc_indexed_logit*)pb;
+    if (b->logit < a->logit) return -1;
+    if (b->logit > a->logit) return 1;
+    return a->index < b->index ? -1 : (a->index > b->index ? 1 : 0);
+}
+/* BU/cpu/kernel/sampling/unified_sampling.rs:13-99, every specialisation: grammar bitmask, temperature, top-k / top-p /
+ * min-p (the three cuts act on ONE descending pass, "parallel", as the reference notes), Gumbel-max noise, arg-max with
+ * ties -> lowest index.  seeds == NULL <=> !is_stochastic, bitmask == NULL <=> !has_bitmask; has_* select the filters. */
+void orc_unified_sampling(const void* logits_in, uint32_t dt, uint32_t* output, const uint64_t* seeds, const uint32_t* bitmask,
+                          uint32_t has_temperature, float temperature, uint32_t has_top_k, uint32_t top_k, uint32_t has_top_p,
+                          float top_p, uint32_t has_min_p, float min_p, uint32_t vocab_size, uint32_t batch_size) {
+    float* logits = (float*)malloc((size_t)vocab_size * sizeof(float));
+    orc_indexed_logit* sorted = (orc_indexed_logit*)malloc((size_t)vocab_size * sizeof(orc_indexed_logit));
+    const uint32_t mask_words = (vocab_size + 31u) / 32u;
+    for (size_t b = 0; b < batch_size; ++b) {
+        for (size_t i = 0; i < vocab_size; ++i) logits[i] = rd(logits_in, dt, b * vocab_size + i);
+        if (bitmask) {
+            const uint32_t* bm = bitmask + b * mask_words;
+            for (size_t i = 0; i < vocab_size; ++i)
+                if ((bm[i / 32] & (1u << (i % 32))) == 0) logits[i] = -INFINITY;
+        }
+        if (has_temperature) {
+            const float recip_temperature = 1.0f / temperature;
+            for (size_t i = 0; i < vocab_size; ++i) logits[i] *= recip_temperature;
+        }
+        if (has_top_k || has_top_p || has_min_p) {
+            for (size_t i = 0; i < vocab_size; ++i) sorted[i].index = (uint32_t)i, sorted[i].logit = logits[i];
+            qsort(sorted, vocab_size, sizeof(orc_indexed_logit), orc_sort_desc); /* total order (index tie-break): any sort gives the same result */
+            const float logits_max = sorted[0].logit;
+            float logits_norm = 0.0f;
+            for (size_t i = 0; i < vocab_size; ++i) logits_norm += expf(sorted[i].logit - logits_max);
+            for (size_t i = 0; i < vocab_size; ++i) logits[i] = -INFINITY;
+            float top_p_mass = 0.0f;
+            const float min_p_ln = has_min_p ? logf(min_p) : 0.0f;
+            for (size_t rank = 0; rank < vocab_size; ++rank) {
+                const float logit = sorted[rank].logit;
+                if ((has_top_k && (uint32_t)rank >= top_k) || (has_top_p && top_p_mass >= top_p) || (has_min_p && logit < logits_max + min_p_ln)) break;
+                logits[sorted[rank].index] = logit;
+                top_p_mass += expf(logit - logits_max) / logits_norm;
+            }
+        }
+        if (seeds) {
+            const uint64_t seed = seeds[b];
+            for (size_t i = 0; i < vocab_size; ++i) {
+                uint32_t offset, word;
+                orc_revidx((uint32_t)i, vocab_size, &offset, &word);
+                logits[i] += orc_gumbel_float(seed, offset, word);
+            }
+        }
+        size_t best = 0;
+        for (size_t i = 1; i < vocab_size; ++i)
+            if (logits[i] > logits[best]) best = i; /* max_by(partial_cmp .then(b.0.cmp(&a.0))): ties and NaN -> lowest index */
+        output[b] = (uint32_t)best;
+    }
+    free(sorted);
+    free(logits);
+}
+
 /* ------------------------------------------------------------------ Gated DeltaNet, decode
  * BU/cpu/kernel/gdn/conv_update.rs:17-55 */
 void orc_delta_net_conv_update(const float* conv_weight, const float* bias, uint16_t* in_out, float* state,
