@@ -148,3 +148,20 @@ def test_gumbel_noise_has_the_right_moments():
     lib.orc_gumbel_float.restype = C.c_float
     g = np.array([lib.orc_gumbel_float(C.c_uint64(12345), C.c_uint32(o), C.c_uint32(w)) for o in range(5000) for w in range(4)], np.float64)
     assert abs(g.mean() - 0.5772156649) < 0.03 and abs(g.var() - np.pi ** 2 / 6) < 0.08 and np.isfinite(g).all()
+
+
+def test_sampling_matches_committed_golden():
+    """tests/golden/sampling.json (make_sampling_golden.py): tokens for fixed logits / seeds / filter settings."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_sampling_golden as G
+    gold = json.load(open(os.path.join(here, "golden", "sampling.json")))
+    assert (gold["vocab"], gold["batch"]) == (G.VOCAB, G.BATCH)
+    logits, seeds, mask = G.inputs()
+    for case in gold["cases"]:
+        assert G.draw(case, logits, seeds, mask) == case["tokens"], case["name"]
+    drawn = {c["name"]: c["tokens"] for c in gold["cases"]}
+    assert drawn["stochastic"] != drawn["temperature"] and len(set(drawn["stochastic"])) > 6  # the cases really differ
