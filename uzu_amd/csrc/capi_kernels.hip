@@ -456,10 +456,15 @@ uzu_status uzu_hip_unified_sampling_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb
     UZU_PROPAGATE(check(k, KK_UNIFIED_SAMPLING, cb));
     UZU_REQUIRE(logits.buffer && output.buffer && !seeds.buffer && !bitmask.buffer, "unified_sampling: greedy kernel takes logits and output only");
     (void)temperature, (void)top_k, (void)top_p, (void)min_p;
-    // scratch for the two-level reduction: the stream's workspace block
-    void* scratch = k::stream_workspace(cb_stream(cb), k::argmax_scratch_bytes(batch_size));
-    UZU_REQUIRE(scratch, "unified_sampling: no scratch memory (stream being captured, or out of device memory)");
-    return k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    // scratch for the two-level reduction: the stream's workspace block; inside a graph-captured command buffer
+    // (UZU_CMDBUF_GRAPH) the allocation becomes a pair of graph memory nodes instead
+    if (void* scratch = k::stream_workspace(cb_stream(cb), k::argmax_scratch_bytes(batch_size)))
+        return k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    void* scratch = nullptr;
+    UZU_HIP_TRY(hipMallocAsync(&scratch, k::argmax_scratch_bytes(batch_size), cb_stream(cb)));
+    uzu_status st = k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    UZU_HIP_TRY(hipFreeAsync(scratch, cb_stream(cb)));
+    return st;
 }
 
 // ------------------------------------------------------------------------------------- Gated DeltaNet
