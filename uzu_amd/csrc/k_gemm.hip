@@ -24,46 +24,17 @@
 #include <stdlib.h>
 
 #include "device_utils.h"
+#include "gemm_convert.h"
 #include "kernels.h"
 
 namespace uzu {
 namespace k {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 namespace {
 constexpr int BK = 64;
 constexpr int A_PITCH = 144; // bytes per staged activation row: 64 bf16 + 16 bytes of pad
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { // v_cvt_pk_bf16_f32
-    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, v);
-}
-// 8 packed int4 codes (already xor-ed so that the nibble is the two's complement of q - 8) -> 8 bf16 values
-// (q - 8) / 16, natural k order.  v_cvt_off_f32_i4 reads the low nibble of the byte SDWA selects: 1 shift + 8 cvt + 4 pack.
-__device__ __forceinline__ u32x4_t dequant4(uint32_t w) {
-    uint32_t h = w >> 4;
-    asm volatile("" : "+v"(h)); // keep `h` materialised so that its bytes are SDWA operands too
-    u32x4_t r;
-    r.x = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w & 0xFF), __builtin_amdgcn_cvt_off_f32_i4(h & 0xFF));
-    r.y = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 8) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 8) & 0xFF));
-    r.z = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4((w >> 16) & 0xFF), __builtin_amdgcn_cvt_off_f32_i4((h >> 16) & 0xFF));
-    r.w = pack_bf16(__builtin_amdgcn_cvt_off_f32_i4(w >> 24), __builtin_amdgcn_cvt_off_f32_i4(h >> 24));
-    return r;
-}
-// 8 int8 codes (xor-ed so that the byte is the two's complement of q - 128) -> 8 bf16 values q - 128 (exact: 8 bits)
-__device__ __forceinline__ float sbyte(uint32_t w, int i) { return (float)(int)(int8_t)((w >> (8 * i)) & 0xFFu); }
-__device__ __forceinline__ u32x4_t dequant8(uint32_t w0, uint32_t w1) {
-    u32x4_t r;
-    r.x = pack_bf16(sbyte(w0, 0), sbyte(w0, 1));
-    r.y = pack_bf16(sbyte(w0, 2), sbyte(w0, 3));
-    r.z = pack_bf16(sbyte(w1, 0), sbyte(w1, 1));
-    r.w = pack_bf16(sbyte(w1, 2), sbyte(w1, 3));
-    return r;
-}
 __device__ __forceinline__ float chunk_sum(uint4 v) { // sum of 8 bf16
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     float s0 = 0.f, s1 = 0.f;
