@@ -79,3 +79,89 @@ def dequantize(q):
     else:
         b = -s * (1 << (bits - 1))
     return s * codes + b
+
+
+def ref_attention_inputs(heads, kv_heads, seq, suffix, hd):
+    """The reference test's own procedural inputs and layout (attention_single_pass_test.rs:34-79): queries
+    [heads * suffix, hd] = sin(0.13 i + 0.5) / 2, keys / values HEAD-major [kv_heads, seq, hd] = cos(0.07 i + 1) / 2 and
+    sin(0.11 i + 2) / 2, evaluated in f32 and rounded to bf16; k_head_stride = seq * hd, k_seq_stride = hd."""
+    def gen(n, a, b, fn):
+        i = np.arange(n, dtype=np.float32)
+        return bf16(fn(i * np.float32(a) + np.float32(b)).astype(np.float32) * np.float32(0.5))
+    q = gen(heads * suffix * hd, 0.13, 0.5, np.sin)
+    k = gen(kv_heads * seq * hd, 0.07, 1.0, np.cos)
+    v = gen(kv_heads * seq * hd, 0.11, 2.0, np.sin)
+    return q, k, v
+
+
+MASK_VARIANTS = {
+    # name: (is_causal, sliding window or None, (ring_offset, ring_length) or None, sinks)
+    "non_causal": (0, None, None, False),
+    "causal": (1, None, None, False),
+    "sliding_causal": (1, 9, None, False),
+    "sliding_non_causal": (0, 10, None, False),
+    "ring_full": (1, None, (5, None), False),        # ring_length = prefix length (every slot holds a token)
+    "ring_partial": (1, None, (0, 0.6), False),      # 60 % of the slots filled
+    "ring_sliding": (1, 12, (7, None), False),
+    "sinks": (1, None, None, True),
+    "sinks_sliding": (1, 9, None, True),
+}
+
+
+def mask_case(variant, seq, suffix, heads, window_scale=1, ring_scale=1):
+    """(is_causal, window, ring_params, sinks_bits) of a MASK_VARIANTS entry for a concrete shape."""
+    is_causal, window, ring, has_sinks = MASK_VARIANTS[variant]
+    prefix = seq - suffix
+    ring_params = None
+    if ring is not None and prefix > 0:
+        length = prefix if ring[1] is None else max(1, int(prefix * ring[1]))
+        ring_params = ((ring[0] * ring_scale) % prefix, length)
+    sinks = bf16(np.linspace(-1.0, 2.0, heads)) if has_sinks else None
+    return is_causal, (window * window_scale if window else None), ring_params, sinks
+
+
+def attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, k_head_stride, k_seq_stride, scale, is_causal, window, ring_params, sinks):
+    """Independent float64 statement of attention_single_pass.rs:37-127 + mask.rs:3-61 (non-trie): returns [suffix, heads, hd]."""
+    qf, kf, vf = f32(q).astype(np.float64), f32(k).astype(np.float64), f32(v).astype(np.float64)
+    prefix = seq - suffix
+    suffix_position = ring_params[1] if ring_params else prefix
+    out = np.zeros((suffix, heads, hd))
+    gqa = heads // kv_heads
+    for h in range(heads):
+        kvh = h // gqa
+        for qi in range(suffix):
+            qv = qf.reshape(-1)[(h * suffix + qi) * hd:(h * suffix + qi + 1) * hd] * scale
+            query_position = suffix_position + qi
+            scores, vals = [], []
+            for i in range(seq):
+                use = True
+                if i >= prefix:
+                    key_position = suffix_position + (i - prefix)
+                    if is_causal:
+                        use &= (i - prefix) <= qi
+                else:
+                    if ring_params:
+                        key_position = (prefix + i - ring_params[0]) % prefix
+                        use &= key_position < ring_params[1]
+                    else:
+                        key_position = i
+                if window:
+                    if is_causal:
+                        use &= key_position <= query_position and (query_position - key_position) < window
+                    elif key_position <= query_position:
+                        use &= (query_position - key_position) <= window // 2
+                    else:
+                        use &= (key_position - query_position) <= window // 2
+                if not use:
+                    continue
+                base = kvh * k_head_stride + i * k_seq_stride
+                scores.append(float(qv @ kf.reshape(-1)[base:base + hd]))
+                vals.append(vf.reshape(-1)[base:base + hd])
+            sink = float(f32(sinks)[h]) if sinks is not None else None
+            if not scores and sink is None:
+                continue
+            m = max(scores + ([sink] if sink is not None else []))
+            p = np.exp(np.array(scores) - m) if scores else np.zeros(0)
+            denom = p.sum() + (np.exp(sink - m) if sink is not None else 0.0)
+            out[qi, h] = (p @ np.array(vals)) / denom if scores else 0.0
+    return out

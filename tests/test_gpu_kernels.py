@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import bf16, f32, quant_matrix, ulp_diff_bf16
+from helpers import MASK_VARIANTS, bf16, f32, mask_case, quant_matrix, ref_attention_inputs, ulp_diff_bf16
 from oracle import oracle as O
 from uzu_amd import _ffi
 from uzu_amd import backend as B
@@ -532,6 +532,71 @@ def test_attention_two_pass(hip_ctx, heads, kv_heads, hd, seq, suffix):
     bp2, bs2, bm2 = hip_ctx.buffer_from(wp), hip_ctx.buffer_from(ws), hip_ctx.buffer_from(wm)
     run(hip_ctx, lambda cb: k2.encode(bp2, bs2, bm2, bo, heads, suffix, cb))
     assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("variant", sorted(MASK_VARIANTS))
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(4, 4, 64, 16, 1), (4, 4, 64, 8, 4), (8, 2, 128, 70, 3), (8, 2, 256, 45, 1)])
+def test_attention_single_pass_mask_variants(hip_ctx, variant, heads, kv_heads, hd, seq, suffix):
+    """mask.rs:3-61 beyond the plain causal mask -- non-causal, sliding window (causal and centred), ring-buffer KV
+    positions (full and partially filled), attention sinks -- on the reference test's own inputs and head-major K/V
+    strides (attention_single_pass_test.rs:34-131).  Reference tolerance 1e-2; ours <= 2 bf16 ulps or 2e-3."""
+    is_causal, window, ring_params, sinks = mask_case(variant, seq, suffix, heads)
+    has_sinks = sinks is not None
+    q, k, v = ref_attention_inputs(heads, kv_heads, seq, suffix, hd)
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, seq * hd, hd, seq * hd, hd,
+                        1 if ring_params else 0, ring_params[0] if ring_params else 0, ring_params[1] if ring_params else 0, 1.0 / np.sqrt(hd),
+                        1 if window else 0, window or 0, sinks.ctypes.data if has_sinks else None, heads, suffix, is_causal)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    kern = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, int(has_sinks), int(ring_params is not None), is_causal, 0, int(window is not None))
+    bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
+    bs = hip_ctx.buffer_from(sinks) if has_sinks else None
+    run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, seq * hd, hd, seq * hd, hd, ring_params, 1.0 / np.sqrt(hd),
+                                        None, window, bs, heads, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+
+
+@pytest.mark.parametrize("variant", sorted(MASK_VARIANTS))
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(8, 2, 256, 1300, 1), (8, 2, 128, 1100, 3), (4, 4, 64, 40, 2)])
+def test_attention_two_pass_mask_variants(hip_ctx, variant, heads, kv_heads, hd, seq, suffix):
+    """The same mask variants through the split-KV kernels (attention_two_pass.rs:41-190): pass-1 maxima / sums per
+    block agree with the reference's blocks (sinks enter block 0 only), merged output <= 2 bf16 ulps or 2e-3."""
+    is_causal, window, ring_params, sinks = mask_case(variant, seq, suffix, heads, window_scale=40 if seq > 400 else 1, ring_scale=37)
+    has_sinks = sinks is not None
+    rng = np.random.default_rng(seq + hd + len(variant))
+    q, k, v, _ = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd,
+                        1 if ring_params else 0, ring_params[0] if ring_params else 0, ring_params[1] if ring_params else 0, 1.0 / np.sqrt(hd),
+                        1 if window else 0, window or 0, sinks.ctypes.data if has_sinks else None, heads, suffix, is_causal)
+    rows = suffix * heads
+    wp, ws, wm = np.zeros((rows, 32, hd), np.float32), np.zeros((rows, 32), np.float32), np.zeros((rows, 32), np.float32)
+    O.lib().orc_attention_two_pass1(C.byref(a), O.p(wp), O.p(ws), O.p(wm))
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.call("orc_attention_two_pass2", wp, ws, wm, want, O.BF16, hd, heads, suffix)
+    # the single-pass restatement must agree with the two-pass one on the same mask (cross-check of the oracle itself)
+    want1 = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want1))
+    assert np.abs(f32(want) - f32(want1)).max() <= 1e-2
+    k1 = B.AttentionTwoPass1Kernel.new(hip_ctx, B.BF16, hd, int(has_sinks), int(ring_params is not None), is_causal, 0, int(window is not None))
+    k2 = B.AttentionTwoPass2Kernel.new(hip_ctx, B.BF16, hd)
+    bq, bk, bv = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v)
+    bp, bsum, bm, bo = hip_ctx.create_buffer(wp.nbytes), hip_ctx.create_buffer(ws.nbytes), hip_ctx.create_buffer(wm.nbytes), hip_ctx.create_buffer(want.nbytes)
+    bs = hip_ctx.buffer_from(sinks) if has_sinks else None
+
+    def enc(cb):
+        k1.encode(bq, bk, bv, bp, bsum, bm, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, ring_params, 1.0 / np.sqrt(hd), heads, suffix,
+                  None, window, bs, cb)
+        k2.encode(bp, bsum, bm, bo, heads, suffix, cb)
+    run(hip_ctx, enc)
+    np.testing.assert_allclose(bm.download(np.float32, wm.size).reshape(wm.shape), wm, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(bsum.download(np.float32, ws.size).reshape(ws.shape), ws, rtol=1e-4, atol=1e-6)
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
 
 
 # ------------------------------------------------------------------------------------------ gated delta net

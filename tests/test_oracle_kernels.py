@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import bf16, dequantize, f32, quant_matrix
+from helpers import MASK_VARIANTS, attention_float64, bf16, dequantize, f32, mask_case, quant_matrix, ref_attention_inputs
 from oracle import oracle as O
 from uzu_amd import synthetic as S
 
@@ -172,6 +172,30 @@ def test_attention_sliding_window_and_sinks_masks():
         p = np.exp(sc - m)
         want = (p @ vf[keys]) / (p.sum() + np.exp(float(f32(sinks)[h]) - m))
         assert np.abs(f32(out)[0, h] - want).max() <= 1e-2
+
+
+@pytest.mark.parametrize("variant", sorted(MASK_VARIANTS))
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(4, 4, 64, 16, 1), (4, 4, 64, 8, 4), (4, 2, 64, 45, 3)])
+def test_attention_mask_variants_against_float64(variant, heads, kv_heads, hd, seq, suffix):
+    """Pins the restatement of mask.rs:3-61 (non-causal, sliding window causal / centred, ring positions full and
+    partially filled, sinks) with an independent float64 statement, on the reference test's procedural inputs and
+    head-major strides (attention_single_pass_test.rs:34-131); single-pass and two-pass restatements agree."""
+    is_causal, window, ring_params, sinks = mask_case(variant, seq, suffix, heads)
+    q, k, v = ref_attention_inputs(heads, kv_heads, seq, suffix, hd)
+    scale = 1.0 / np.sqrt(hd)
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, seq * hd, hd, seq * hd, hd,
+                        1 if ring_params else 0, ring_params[0] if ring_params else 0, ring_params[1] if ring_params else 0, scale,
+                        1 if window else 0, window or 0, sinks.ctypes.data if sinks is not None else None, heads, suffix, is_causal)
+    got = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(got))
+    want = attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, seq * hd, hd, np.float32(scale), is_causal, window, ring_params, sinks)
+    assert np.abs(f32(got) - want).max() <= 4e-3  # bf16 output rounding of values <= 0.5
+    rows = suffix * heads
+    wp, ws, wm = np.zeros((rows, 32, hd), np.float32), np.zeros((rows, 32), np.float32), np.zeros((rows, 32), np.float32)
+    O.lib().orc_attention_two_pass1(C.byref(a), O.p(wp), O.p(ws), O.p(wm))
+    got2 = np.zeros((suffix, heads, hd), np.uint16)
+    O.call("orc_attention_two_pass2", wp, ws, wm, got2, O.BF16, hd, heads, suffix)
+    assert np.abs(f32(got2) - want).max() <= 4e-3
 
 
 def test_rope_table_and_attention_prepare():

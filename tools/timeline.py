@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Where does a decode step's time go?  Runs the bench configuration (Qwen3.5-0.8B int4, context 2048, graph
+replay) on the UZU_TIMELINE build of the library, which stamps the 100 MHz wall clock per workgroup at kernel entry /
+after the prologue / after the row loop / at exit, and prints per launch:
+  gap    first entry of this launch - last exit of the previous launch   (the kernel boundary)
+  ramp   last entry - first entry                                        (dispatch of the grid)
+  pro    median (after prologue - entry)
+  body   median (after row loop - after prologue)
+  tail   median (exit - after row loop)
+  span   last exit - first entry
+GPU box only:  UZU_HIP_LIB=uzu_amd/lib_tl/libuzu_hip.so python tools/timeline.py [--context 2048] > gpurun_out/timeline.txt
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--context", type=int, default=2048)
+    ap.add_argument("--model", default="qwen3.5-0.8b")
+    args = ap.parse_args()
+    from uzu_amd import _ffi
+    from uzu_amd import synthetic as S
+    from uzu_amd.backend import Context
+    from uzu_amd.engine import HipModel
+    lib = _ffi.lib()
+    assert hasattr(lib, "uzu_hip_debug_set_timeline"), "not the UZU_TIMELINE build (set UZU_HIP_LIB)"
+    cfg = S.PRESETS[args.model](max_context_length=args.context + 64)
+    bundle = S.build_model(cfg)
+    ctx = Context.new(0)
+    hm = HipModel(ctx, bundle)
+    hm.prefill(S.synthetic_prompt(args.context - 8, cfg.vocab_size))
+    max_launches = 256
+    buf = ctx.create_buffer(max_launches * 4096 * 8)
+    buf.upload(np.zeros(max_launches * 4096, dtype=np.uint64))
+    lib.uzu_hip_debug_set_timeline.argtypes = [C.c_void_p, C.c_uint32]
+    lib.uzu_hip_debug_set_timeline.restype = None
+    lib.uzu_hip_debug_set_timeline(C.c_void_p(buf.gpu_ptr()), C.c_uint32(max_launches))
+    hm.decode(8)  # first call captures the graph (the stamp slots are baked into it); the last replay's stamps remain
+    ctx.synchronize()
+    t = buf.download(np.uint64).reshape(max_launches, 1024, 4).astype(np.int64)
+    labels = hm.profile_labels() if hasattr(hm, "profile_labels") else None
+    prev_end = None
+    print(f"# {cfg.name} ctx {hm.context_length}; times in us (10 ns clock); only gemv_dec / delta_dec / attn_dec launches are stamped")
+    print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'pro':>6} {'body':>6} {'tail':>6} {'span':>6}  p90(exit-entry)")
+    tot = dict(gap=0.0, span=0.0)
+    first = None
+    for i in range(max_launches):
+        live = t[i][:, 0] > 0
+        if not live.any():
+            continue
+        e = t[i][live]
+        t0, t3 = e[:, 0], e[:, 3]
+        has12 = (e[:, 1] > 0).all() and (e[:, 2] > 0).all()
+        if first is None:
+            first = t0.min()
+        gap = (t0.min() - prev_end) * 0.01 if prev_end is not None else float("nan")
+        ramp = (t0.max() - t0.min()) * 0.01
+        pro = np.median(e[:, 1] - t0) * 0.01 if has12 else float("nan")
+        body = np.median(e[:, 2] - e[:, 1]) * 0.01 if has12 else float("nan")
+        tail = np.median(t3 - e[:, 2]) * 0.01 if has12 else float("nan")
+        span = (t3.max() - t0.min()) * 0.01
+        p90 = np.percentile(t3 - t0, 90) * 0.01
+        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {pro:6.2f} {body:6.2f} {tail:6.2f} {span:6.2f}  {p90:6.2f}")
+        if gap == gap:
+            tot["gap"] += gap
+        tot["span"] += span
+        prev_end = t3.max()
+    print(f"# stamped launches: sum of spans {tot['span']:.1f} us, sum of gaps {tot['gap']:.1f} us (gaps include the un-stamped kernels: attn_merge, commit, embedding), "
+          f"first entry -> last exit {(prev_end - first) * 0.01:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

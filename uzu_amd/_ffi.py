@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libuzu_hip.so")
+# UZU_HIP_LIB: development switch for A/B runs against another in-tree build of the same sources (tools/ab_*.sh)
+LIB_PATH = os.environ.get("UZU_HIP_LIB") or os.path.join(_HERE, "lib", "libuzu_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 

@@ -29,6 +29,7 @@ using namespace uzu;
 namespace {
 
 constexpr uint32_t kSuffixCapacity = 1024; // ATTENTION_SUFFIX_CAPACITY, mixer/attention/state.rs:14
+constexpr uint32_t kArgmaxPartials = 4096; // capacity of the read-out GEMV's per-workgroup arg-max partials (DecGemvParams::part_capacity)
 
 struct DLinear {
     uint32_t n = 0, k = 0, bits = 0, group = 0, method = UZU_QUANT_NONE;
@@ -65,6 +66,7 @@ struct uzu_hip_model {
     DLinear embedding, output_embedding;
     DNorm output_norm;
     std::vector<void*> allocations;
+    std::vector<size_t> allocation_bytes; // parallel to `allocations` (context memory accounting)
     size_t weight_bytes = 0;
 
     float *rope_cos = nullptr, *rope_sin = nullptr;
@@ -107,6 +109,7 @@ struct uzu_hip_model {
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool hidden_ready = false; // row 0 of `hidden` already holds the embedding of the next input token (written by the fused commit)
     uint32_t launches = 0; // kernel launches of the last encoded forward
     void* prof_sink = nullptr; // std::vector<ProfEntry>* while profiling one step
     int regime_override = -1; // graph capture: 0 = single-pass attention, 1 = two-pass (else decided by context_length)
@@ -125,11 +128,23 @@ uzu_status dev_alloc(uzu_hip_model* m, size_t bytes, void** out, bool zero = fal
         return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
     }
     m->allocations.push_back(p);
+    m->allocation_bytes.push_back(alloc);
     m->ctx->current_bytes += alloc;
     if (m->ctx->current_bytes > m->ctx->peak_bytes) m->ctx->peak_bytes = m->ctx->current_bytes;
     if (zero) HIPCHK(hipMemset(p, 0, alloc));
     *out = p;
     return UZU_OK;
+}
+
+void dev_free(uzu_hip_model* m, void* p) {
+    for (size_t i = 0; i < m->allocations.size(); ++i)
+        if (m->allocations[i] == p) {
+            (void)hipFree(p);
+            m->ctx->current_bytes -= m->allocation_bytes[i] < m->ctx->current_bytes ? m->allocation_bytes[i] : m->ctx->current_bytes;
+            m->allocations.erase(m->allocations.begin() + i);
+            m->allocation_bytes.erase(m->allocation_bytes.begin() + i);
+            return;
+        }
 }
 
 template <class T> uzu_status upload(uzu_hip_model* m, const void* host, size_t bytes, T** out) {
@@ -278,6 +293,11 @@ void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint1
 
 uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
     if (rows <= m->partial_rows) return UZU_OK;
+    if (m->partials) { // regrow: earlier passes may still read the old blocks
+        HIPCHK(hipStreamSynchronize(m->ctx->stream));
+        for (void* old : {(void*)m->partials, (void*)m->sums, (void*)m->maxs}) dev_free(m, old);
+        m->partials = m->sums = m->maxs = nullptr, m->partial_rows = 0;
+    }
     void* p;
     UZU_PROPAGATE(dev_alloc(m, (size_t)rows * 32 * head_dim * 4, &p));
     m->partials = (float*)p;
@@ -418,9 +438,11 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             RUN("tp_token", 0, tp::token_from_key(s, m->tp_key, m->d_out_token));
         }
     }
+    // an earlier launch failed: leave the device-side context length / next token untouched so that they keep agreeing
+    // with the host mirror (m->context_length is only advanced by the callers on success)
+    if (e.st != UZU_OK) return e.st;
     hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1), 0, s, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, count, sample ? 1u : 0u);
     ++m->launches;
-    if (e.st != UZU_OK) return e.st;
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("engine: forward launch failed: %s", hipGetErrorString(err));
@@ -515,18 +537,28 @@ bool model_fusable(const uzu_hip_model* m) {
     return true;
 }
 
-// One decode step (count == 1, sampling) with the fused kernels of k_decode.hip.
-uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
+// The commit kernel of a single-GPU fused step also writes the sampled token's embedding row (the next step's input).
+bool commit_embeds(const uzu_hip_model* m) { return m->tp == nullptr; }
+
+void encode_embed_row0(Enc& e) {
+    uzu_hip_model* m = e.m;
+    const uint32_t d = m->d.model_dim;
+    if (m->embedding.method == UZU_QUANT_NONE)
+        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(e.s, m->d_tokens, m->embedding.w, m->hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale));
+    else
+        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(e.s, m->d_tokens, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
+                                            m->hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits, m->embedding.method));
+}
+
+// One decode step (count == 1, sampling) with the fused kernels of k_decode.hip.  `with_embed`: look the input token's
+// embedding row up first (the first step after a prefill / set_next_token; later steps find it written by the commit).
+uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed) {
     Enc e{m, s};
     e.prof = (std::vector<ProfEntry>*)m->prof_sink;
     m->launches = 0;
     const uint32_t d = m->d.model_dim;
     uint16_t* hidden = m->hidden;
-    if (m->embedding.method == UZU_QUANT_NONE)
-        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, m->d_tokens, m->embedding.w, hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale));
-    else
-        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, m->d_tokens, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
-                                            hidden, UZU_BF16, 1, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits, m->embedding.method));
+    if (with_embed) encode_embed_row0(e);
     uint16_t* sc[2] = {m->shortcut, m->shortcut_b};
     int cur = 1; // the first norm (copy mode) writes sc[0]
     auto next_norm = [&](k::DecGemvParams& p, const DNorm& N, int mode) {
@@ -580,7 +612,7 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
     k::DecGemvParams r = dec_gemv_base(ro, hidden, m->logits);
     next_norm(r, m->output_norm, 2);
     r.normed_out = m->last_normed;
-    r.part_val = m->amax_val, r.part_idx = m->amax_idx;
+    r.part_val = m->amax_val, r.part_idx = m->amax_idx, r.part_capacity = kArgmaxPartials;
     uint32_t grid = 0;
     dec_gemv(e, r, "gemv_dec[norm+readout+argmax]", &grid);
     if (m->tp) {
@@ -588,7 +620,12 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
         RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
         RUN("tp_commit_key", 0, tp::commit_key(s, m->tp_key, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
     } else {
-        RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
+        k::CommitEmbed eb{};
+        eb.weights = (const uint8_t*)m->embedding.w, eb.scales = (const uint16_t*)m->embedding.scales, eb.zero_points = m->embedding.zp;
+        eb.biases = (const uint16_t*)m->embedding.biases, eb.output = hidden;
+        eb.vocab_size = m->d.vocab_size, eb.model_dim = d, eb.group_size = m->embedding.group, eb.bits = m->embedding.bits, eb.method = m->embedding.method;
+        eb.input_scale = m->d.input_scale;
+        RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, &eb));
     }
     if (e.st != UZU_OK) return e.st;
     hipError_t err = hipGetLastError();
@@ -599,8 +636,16 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s) {
     return UZU_OK;
 }
 
+bool decode_is_fused(const uzu_hip_model* m) { return m->fusable && !(m->flags & UZU_MODEL_NO_FUSION); }
+
+// eager decode step; keeps `hidden_ready` in step with what the step left behind
 uzu_status encode_decode(uzu_hip_model* m, hipStream_t s) {
-    if (m->fusable && !(m->flags & UZU_MODEL_NO_FUSION)) return encode_decode_fused(m, s);
+    if (decode_is_fused(m)) {
+        const uzu_status st = encode_decode_fused(m, s, !m->hidden_ready);
+        m->hidden_ready = st == UZU_OK && commit_embeds(m);
+        return st;
+    }
+    m->hidden_ready = false;
     return encode_forward(m, s, 1, true);
 }
 
@@ -608,7 +653,9 @@ uzu_status build_decode_graph(uzu_hip_model* m, hipGraphExec_t* out, bool two_pa
     hipStream_t s = m->ctx->stream;
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     m->regime_override = two_pass ? 1 : 0;
-    uzu_status st = encode_decode(m, s);
+    // the captured step starts at layer 0 when its own commit leaves the next embedding row behind (enqueue_decode looks
+    // the first one up eagerly); otherwise the lookup is part of the graph
+    uzu_status st = decode_is_fused(m) ? encode_decode_fused(m, s, !commit_embeds(m)) : encode_forward(m, s, 1, true);
     m->regime_override = -1;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(s, &g);
@@ -635,7 +682,13 @@ uzu_status enqueue_decode(uzu_hip_model* m, uint32_t steps) {
             const bool two = m->context_length + 1 > 1024;
             hipGraphExec_t* g = two ? &m->graph_two : &m->graph_single;
             if (!*g) UZU_PROPAGATE(build_decode_graph(m, g, two));
+            if (decode_is_fused(m) && commit_embeds(m) && !m->hidden_ready) { // first step after a prefill / set_next_token
+                Enc e{m, m->ctx->stream};
+                encode_embed_row0(e);
+                UZU_PROPAGATE(e.st);
+            }
             HIPCHK(hipGraphLaunch(*g, m->ctx->stream));
+            m->hidden_ready = decode_is_fused(m) && commit_embeds(m);
         }
         m->context_length += 1;
     }
@@ -781,8 +834,8 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         ALLOC(decay, float, C * max_hv);
     }
     ALLOC(shortcut_b, uint16_t, C * d);
-    ALLOC(amax_val, float, 4096);
-    ALLOC(amax_idx, uint32_t, 4096);
+    ALLOC(amax_val, float, kArgmaxPartials);
+    ALLOC(amax_idx, uint32_t, kArgmaxPartials);
     if (max_qkv) {
         uint32_t wgs = 1; // kv_heads * head-subgroups of the widest attention layer
         for (auto& L : m->layers)
@@ -830,6 +883,7 @@ void uzu_hip_model_destroy(uzu_hip_model* m) {
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (void* p : m->allocations) (void)hipFree(p);
+    for (size_t b : m->allocation_bytes) m->ctx->current_bytes -= b < m->ctx->current_bytes ? b : m->ctx->current_bytes;
     delete m;
 }
 
@@ -843,6 +897,7 @@ uzu_status uzu_hip_model_reset(uzu_hip_model* m) {
     }
     HIPCHK(hipStreamSynchronize(s));
     m->context_length = 0;
+    m->hidden_ready = false;
     return UZU_OK;
 }
 
@@ -855,6 +910,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
     UZU_REQUIRE(m->context_length + count <= m->d.max_context_length, "model_prefill: %u + %u tokens exceed max_context_length %u",
                 m->context_length, count, m->d.max_context_length);
     hipStream_t s = m->ctx->stream;
+    m->hidden_ready = false; // the prefill pass uses `hidden` for its own rows
     for (uint32_t start = 0; start < count; start += kSuffixCapacity) {
         const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
         const bool last = start + n == count;
@@ -937,6 +993,7 @@ uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token) {
     UZU_REQUIRE(m, "model_set_next_token: null model");
     HIPCHK(hipMemcpyAsync(m->d_tokens, &token, 4, hipMemcpyHostToDevice, m->ctx->stream));
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    m->hidden_ready = false;
     return UZU_OK;
 }
 

@@ -27,6 +27,22 @@ template <> struct CodesT<8> { using type = Codes8; };
 
 __device__ __forceinline__ void load_codes(Codes4& c, const uint8_t* p) { c.a = *(const uint4*)p; }
 __device__ __forceinline__ void load_codes(Codes8& c, const uint8_t* p) { c.a = ((const uint4*)p)[0], c.b = ((const uint4*)p)[1]; }
+// streamed weights (each byte is read once per token by one CU): non-temporal loads keep them from displacing the
+// activations / KV / state lines in L2 and the memory-side cache (MI355X_MICROARCH.md, row nt-weights)
+#ifndef UZU_GEMV_NT
+#define UZU_GEMV_NT 1
+#endif
+typedef uint32_t gc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load16_stream(const uint8_t* p) {
+#if UZU_GEMV_NT
+    const gc_u32x4 v = __builtin_nontemporal_load((const gc_u32x4*)p);
+#else
+    const gc_u32x4 v = *(const gc_u32x4*)p;
+#endif
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void load_codes_stream(Codes4& c, const uint8_t* p) { c.a = load16_stream(p); }
+__device__ __forceinline__ void load_codes_stream(Codes8& c, const uint8_t* p) { c.a = load16_stream(p), c.b = load16_stream(p + 16); }
 __device__ __forceinline__ void flip_codes(Codes4& c, uint32_t m) { c.a.x ^= m, c.a.y ^= m, c.a.z ^= m, c.a.w ^= m; }
 __device__ __forceinline__ void flip_codes(Codes8& c, uint32_t m) { c.a.x ^= m, c.a.y ^= m, c.a.z ^= m, c.a.w ^= m, c.b.x ^= m, c.b.y ^= m, c.b.z ^= m, c.b.w ^= m; }
 
@@ -73,6 +89,79 @@ __device__ __forceinline__ float dot32(const Codes8& c, const float (&x)[32]) {
     }
     return (d0 + d1) + (d2 + d3);
 }
+// ---- int4 x bf16 on the packed-dot unit -------------------------------------------------------------------------
+// A nibble q placed in mantissa bits 6..3 of a bf16 whose exponent field says 2^4 reads as the value 16 + q:
+//   0x4180 | (q << 3)  ==  bf16(16 + q)   (exact: 16 * (1 + 8q / 128)).
+// One shift + one v_and_or_b32 therefore turns a code word into a PAIR of bf16 codes (nibble s of the low half-word
+// and nibble s of the high half-word, i.e. elements 8w + s and 8w + 4 + s), which v_dot2c_f32_bf16 multiplies with
+// the matching pair of bf16 activations and accumulates in f32: 1.5 VALU instructions per weight instead of 2.25
+// (v_cvt_f32_ubyteN + v_fma_f32 + the nibble masks), and the activation step lives in 16 registers instead of 32.
+// Every product (16 + q) * x is exact (5 x 8 significant bits); the surplus 16 * sum(x) leaves through the group
+// offset: acc += scale * D + (offset - 16 * scale) * sum(x).  Offset 16 rather than 128 (mantissa bits 3..0, no
+// shift for one nibble in four): the accumulated value is then at most ~2x the wanted one instead of ~17x, so the
+// f32 rounding noise stays at the level of the plain q * x chain (tools/sim_offset_trick.py).
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+constexpr float kQ4Offset = 16.0f;
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, a), __builtin_bit_cast(bf16x2_v, b), c, false);
+#else
+    return c;
+#endif
+}
+// activation step for the packed dot: word 4w + s = (x[8w + s], x[8w + 4 + s]) as a bf16 pair (low half = first)
+struct XPack { uint32_t v[16]; };
+__device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi) { // both bf16-representable
+    return __builtin_amdgcn_perm(f32_to_bits(hi), f32_to_bits(lo), 0x07060302u);
+}
+__device__ __forceinline__ void xpack_from_f32(XPack& o, const float (&x)[32]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o.v[4 * w + s] = pack_bf16_pair(x[8 * w + s], x[8 * w + 4 + s]);
+}
+// 32 consecutive bf16 activations from memory; also returns their sum (f32, through the same unit: x * 1.0 pairs)
+__device__ __forceinline__ float xpack_load(XPack& o, const uint16_t* p) {
+    const uint4* src = (const uint4*)p;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t ones = 0x3F803F80u;
+    asm("" : "+v"(ones));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint4 u = src[w]; // (x0,x1) (x2,x3) (x4,x5) (x6,x7)
+        o.v[4 * w + 0] = __builtin_amdgcn_perm(u.z, u.x, 0x05040100u);
+        o.v[4 * w + 1] = __builtin_amdgcn_perm(u.z, u.x, 0x07060302u);
+        o.v[4 * w + 2] = __builtin_amdgcn_perm(u.w, u.y, 0x05040100u);
+        o.v[4 * w + 3] = __builtin_amdgcn_perm(u.w, u.y, 0x07060302u);
+        s0 = dot2_bf16(o.v[4 * w + 0], ones, s0);
+        s1 = dot2_bf16(o.v[4 * w + 1], ones, s1);
+        s2 = dot2_bf16(o.v[4 * w + 2], ones, s2);
+        s3 = dot2_bf16(o.v[4 * w + 3], ones, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+// sum_{i<32} (16 + code_i) * x_i
+__device__ __forceinline__ float dot32p(const Codes4& c, const XPack& x) {
+    const uint32_t ws[4] = {c.a.x, c.a.y, c.a.z, c.a.w};
+    uint32_t mask = 0x00780078u, magic = 0x41804180u;
+    // opaque register constants: with literals the compiler emits v_and_b32 + v_or_b32 (a VOP3 cannot carry a literal)
+    asm("" : "+s"(mask));
+    asm("" : "+v"(magic));
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t q0 = ((ws[w] << 3) & mask) | magic; // nibbles 0 and 4
+        const uint32_t q1 = ((ws[w] >> 1) & mask) | magic; // nibbles 1 and 5
+        const uint32_t q2 = ((ws[w] >> 5) & mask) | magic; // nibbles 2 and 6
+        const uint32_t q3 = ((ws[w] >> 9) & mask) | magic; // nibbles 3 and 7
+        d0 = dot2_bf16(q0, x.v[4 * w + 0], d0);
+        d1 = dot2_bf16(q1, x.v[4 * w + 1], d1);
+        d2 = dot2_bf16(q2, x.v[4 * w + 2], d2);
+        d3 = dot2_bf16(q3, x.v[4 * w + 3], d3);
+    }
+    return (d0 + d1) + (d2 + d3);
+}
+
 __device__ __forceinline__ float sum32(const float (&x)[32]) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll

@@ -31,13 +31,13 @@ namespace uzu {
 namespace k {
 
 // ---------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ float act_bf16(uint32_t act, float x) { // activation_type.rs, T = bf16
+__device__ __forceinline__ float act_bf16(uint32_t act, float x, const uint64_t* exp_tab) { // activation_type.rs, T = bf16
     switch (act) {
-    case 0: return round_bf16(x / (1.0f + expf_glibc(-1.0f * x)));
+    case 0: return round_bf16(x / (1.0f + expf_glibc_tab(-1.0f * x, exp_tab)));
     case 1: return round_bf16(0.5f * x * (1.0f + tanhf(0.7978846f * (x + 0.044715f * x * x * x))));
     case 2: return round_bf16(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
     case 3: return x;
-    default: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc(x)));
+    default: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc_tab(x, exp_tab)));
     }
 }
 
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    UZU_TL_STAMP(p, 0);
     const uint32_t K = p.k;
     const int lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int sl = lane & (lpr - 1), rsub = lane >> lpr_log2;
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
 #pragma unroll
             for (int h = 0; h < NPHYS; ++h) {
                 const uint32_t prow = ACT ? lr + (h ? p.n[0] / 2 : 0) : lr;
-                load_codes(it.w[r][h], wp + (prow * row_bytes + c * STEP_BYTES));
+                load_codes_stream(it.w[r][h], wp + (prow * row_bytes + c * STEP_BYTES));
                 const uint32_t gi = prow * G + grp;
                 it.s[r][h] = sp[gi];
                 if (KIND == UZU_MATMUL_B_SCALE_BIAS) it.o[r][h] = bp[gi];
@@ -116,6 +117,26 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         }
     };
 
+    struct ConvPre { // taps / weights of the conv channels this lane finishes (kernel size 4: the common case)
+        float tap[3];
+        f32x4_v w;
+        float bias;
+    };
+    auto conv_prefetch = [&](uint32_t b, ConvPre (&cp)[CONV ? R : 1]) { // issued one batch ahead: lands while the rows are computed
+        // every lane of the row loads (same address: one request), rows outside the conv block read channel 0 and are
+        // not consumed -- unconditional for the same reason as load_item
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t lrow_raw = b * rows_per_batch + r * rpw + rsub;
+            const uint32_t lrow = (b < batches0 && lrow_raw < p.conv_dim && lrow_raw < n_log0) ? lrow_raw : 0;
+            ConvPre& c4 = cp[CONV ? r : 0];
+            const float* st_row = p.conv_state + lrow * 3;
+            c4.tap[0] = st_row[0], c4.tap[1] = st_row[1], c4.tap[2] = st_row[2];
+            c4.w = *(const f32x4_v*)(p.conv_w + lrow * 4);
+            const float bias = (p.conv_b ? p.conv_b : p.conv_w)[lrow];
+            c4.bias = p.conv_b ? bias : 0.0f;
+        }
+    };
     const uint32_t b0 = blockIdx.x * 4 + wave;
     Item itA, itB;
     // VMEM loads return in issue order.  The activation row (written by the previous kernel: L2 / memory-side cache,
@@ -144,9 +165,21 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         dg_pre[2] = *(const f32x4_v*)(p.dg_sz + e0), dg_pre[3] = *(const f32x4_v*)(p.dg_sz + e0 + 4);
         dg_pre[4] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv), dg_pre[5] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv + 4);
     }
+    // exp() table of the SiLU / softplus epilogues (uzu_math.h): fetched with the first loads, parked in LDS before the
+    // first barrier -- the epilogue's table read is then an LDS access instead of a dependent global-memory round trip
+    __shared__ uint64_t s_exp_tab[(ACT || CONV) ? 32 : 1];
+    uint64_t exp_entry = 0;
+    if (ACT || CONV) exp_entry = kExp2fTab[tid & 31];
     __builtin_amdgcn_sched_barrier(0); // keep the issue order: the scheduler would hoist the weight loads above the staging
     load_item(b0, 0, itA); // in flight during the whole prologue
     __builtin_amdgcn_sched_barrier(0);
+    ConvPre cp_cur[CONV ? R : 1]; // conv operands of the wave's first batch: in flight during the prologue as well
+    if (CONV) conv_prefetch(b0, cp_cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ACT || CONV) {
+        if (tid < 32) s_exp_tab[tid] = exp_entry;
+        if (PRO == 0 || CPLT == 0) lds_barrier(); // the prologue variants pass a barrier of their own before any epilogue runs
+    }
 
     // ---- prologue ---------------------------------------------------------------------------------------
     float xf[CPL][32];
@@ -301,13 +334,21 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
 #pragma unroll
         for (int j = 0; j < CPL; ++j) xsm[j] = sum32(xf[j]);
     }
+    // int4: the row goes through the packed-dot unit (gemv_core.h: dot32p) -- bf16 pairs, 16 registers per step; the
+    // f32 copy is dead from here on
+    XPack xq[BITS == 4 ? CPL : 1];
+    if (BITS == 4 && CPLT != 0) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) xpack_from_f32(xq[BITS == 4 ? j : 0], xf[j]);
+    }
 
+    UZU_TL_STAMP(p, 1);
     // ---- row loop, software pipelined over (batch, step) items ---------------------------------------------
     // Two item buffers alternate roles (no register copies): while one is consumed the loads of the next (batch,
     // step) land in the other.
     float best_v = -INFINITY; // arg-max epilogue state (lane-local)
     uint32_t best_i = 0xFFFFFFFFu;
-    auto compute = [&](const Item& it, uint32_t c, const float (&x)[32], float xs, float (&acc)[R][NPHYS]) {
+    auto compute = [&](const Item& it, uint32_t c, const auto& x, float xs, float (&acc)[R][NPHYS]) {
         const uint32_t grp = (c * 32) >> gshift;
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -320,31 +361,28 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     const uint32_t zpv = BITS == 4 ? ((grp & 1) ? (it.o[r][h] >> 4) : (it.o[r][h] & 0x0F)) : it.o[r][h];
                     of = -sc * (float)zpv;
                 } else of = -sc * (float)(1u << (BITS - 1));
-                const float dq = dot32(it.w[r][h], x);
+                float dq;
+                if constexpr (BITS == 4) {
+                    dq = dot32p(it.w[r][h], x);       // sum (16 + q) x
+                    of = fmaf(-kQ4Offset, sc, of);     // exact: both bf16-derived, exponents a few bits apart
+                } else {
+                    dq = dot32(it.w[r][h], x);
+                }
                 acc[r][h] = fmaf(sc, dq, fmaf(of, xs, acc[r][h]));
                 // one row at a time: without the fence the scheduler interleaves the R dot products and keeps
                 // R x 32 converted codes live (350+ VGPRs at R = 4 => one wave per SIMD)
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-    struct ConvPre { // taps / weights of the conv channels this lane finishes (kernel size 4: the common case)
-        float tap[3];
-        f32x4_v w;
-        float bias;
-    };
-    auto conv_prefetch = [&](uint32_t b, ConvPre (&cp)[CONV ? R : 1]) { // issued at batch start: lands while the rows are computed
-        // every lane of the row loads (same address: one request), rows outside the conv block read channel 0 and are
-        // not consumed -- unconditional for the same reason as load_item
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t lrow_raw = b * rows_per_batch + r * rpw + rsub;
-            const uint32_t lrow = (b < batches0 && lrow_raw < p.conv_dim && lrow_raw < n_log0) ? lrow_raw : 0;
-            ConvPre& c4 = cp[CONV ? r : 0];
-            const float* st_row = p.conv_state + lrow * 3;
-            c4.tap[0] = st_row[0], c4.tap[1] = st_row[1], c4.tap[2] = st_row[2];
-            c4.w = *(const f32x4_v*)(p.conv_w + lrow * 4);
-            const float bias = (p.conv_b ? p.conv_b : p.conv_w)[lrow];
-            c4.bias = p.conv_b ? bias : 0.0f;
+    auto stream_step = [&](const Item& it, uint32_t c, float (&acc)[R][NPHYS]) { // K > 8192: the row is re-read per step (L1 / L2)
+        if constexpr (BITS == 4) {
+            XPack x;
+            const float xs = xpack_load(x, p.x + (size_t)c * 32);
+            compute(it, c, x, xs, acc);
+        } else {
+            float x[32];
+            load32_bf16(p.x + (size_t)c * 32, x);
+            compute(it, c, x, sum32(x), acc);
         }
     };
     auto finish = [&](uint32_t b, float (&acc)[R][NPHYS], const ConvPre (&cp)[CONV ? R : 1]) {
@@ -365,7 +403,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     if (p.out_bias[0]) gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
                     const float up_b = round_bf16(value), gate_b = round_bf16(gate);
                     // GatedActMul (gated_act_mul/mod.rs:5-12): (up * act(gate)) in bf16
-                    p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b)));
+                    p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b, s_exp_tab)));
                 } else if (CONV && mat == 0 && lrow < p.conv_dim) {
                     // DeltaNetConvUpdate (conv_update.rs:17-55), kernel size 4, operands prefetched at batch start
                     float* st_row = p.conv_state + (size_t)lrow * 3;
@@ -376,7 +414,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     cacc += c4.tap[1] * c4.w.y;
                     cacc += c4.tap[2] * c4.w.z;
                     cacc += xin * c4.w.w;
-                    p.out[0][lrow] = f32_to_bf16(silu_f32(cacc));
+                    p.out[0][lrow] = f32_to_bf16(silu_f32_tab(cacc, s_exp_tab));
                     st_row[0] = c4.tap[1], st_row[1] = c4.tap[2], st_row[2] = xin;
                 } else {
                     const uint16_t ob = f32_to_bf16(value);
@@ -398,8 +436,6 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int h = 0; h < NPHYS; ++h) acc[r][h] = 0.f;
-        ConvPre cp[CONV ? R : 1];
-        if (CONV) conv_prefetch(b, cp);
         if (CPLT != 0) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -408,7 +444,10 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 if (j + 1 < CPL) load_item(b, j + 1, nxt);
                 else load_item(b + total_waves, 0, nxt);
                 const uint32_t c = sl + lpr * j;
-                if (c < C) compute(cur, c, xf[j], xsm[j], acc);
+                if (c < C) {
+                    if constexpr (BITS == 4) compute(cur, c, xq[j], xsm[j], acc);
+                    else compute(cur, c, xf[j], xsm[j], acc);
+                }
             }
         } else {
             for (uint32_t j = 0; j < steps_per_lane; j += 2) {
@@ -416,11 +455,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     const bool last = j + 1 == steps_per_lane;
                     load_item(last ? b + total_waves : b, last ? 0 : j + 1, second);
                     const uint32_t c = sl + lpr * j;
-                    if (c < C) {
-                        float x[32];
-                        load32_bf16(p.x + (size_t)c * 32, x);
-                        compute(first, c, x, sum32(x), acc);
-                    }
+                    if (c < C) stream_step(first, c, acc);
                     if (last) { // odd step count: hand the prefetched item over (one copy per batch)
                         first = second;
                         break;
@@ -430,15 +465,12 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     const bool last = j + 2 == steps_per_lane;
                     load_item(last ? b + total_waves : b, last ? 0 : j + 2, first);
                     const uint32_t c = sl + lpr * (j + 1);
-                    if (c < C) {
-                        float x[32];
-                        load32_bf16(p.x + (size_t)c * 32, x);
-                        compute(second, c, x, sum32(x), acc);
-                    }
+                    if (c < C) stream_step(second, c, acc);
                 }
             }
         }
-        finish(b, acc, cp);
+        finish(b, acc, cp_cur);
+        if (CONV) conv_prefetch(b + total_waves, cp_cur); // operands of this wave's next batch
     };
     if (CPLT == 0 || (CPL & 1) == 0) {
         for (uint32_t b = b0; b < num_batches; b += total_waves) batch(b, itA, itB);
@@ -448,6 +480,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             if (b + total_waves < num_batches) batch(b + total_waves, itB, itA);
         }
     }
+    UZU_TL_STAMP(p, 2);
     if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
         __shared__ float sv[4];
         __shared__ uint32_t si[4];
@@ -465,6 +498,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             p.part_idx[blockIdx.x] = best_i;
         }
     }
+    UZU_TL_STAMP(p, 3);
 }
 
 // Launch geometry.  Two regimes (tools/kbench.cpp sweeps):
@@ -517,7 +551,8 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>, 256, lds) != hipSuccess || n < 1) n = 2; \
             occ = n > 8 ? 8 : n;                                                                                                    \
         }                                                                                                                           \
-        const uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                 \
+        uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                       \
+        if (p.part_val && p.part_capacity && cap > p.part_capacity) cap = p.part_capacity; /* one arg-max partial per workgroup */  \
         const uint32_t grid = want > cap ? cap : want;                                                                              \
         if (grid_out) *grid_out = grid;                                                                                             \
         return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
@@ -576,7 +611,21 @@ static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uin
     return launch_gemv_dec_r<BITS, 0, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
 }
 
-uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out) {
+#ifdef UZU_TIMELINE
+static unsigned long long* g_tl_base = nullptr;
+static uint32_t g_tl_max = 0, g_tl_next = 0;
+unsigned long long* timeline_next_slot() {
+    if (!g_tl_base || g_tl_next >= g_tl_max) return nullptr;
+    return g_tl_base + (size_t)(g_tl_next++) * 4096;
+}
+extern "C" void uzu_hip_debug_set_timeline(unsigned long long* base, uint32_t max_launches) { g_tl_base = base, g_tl_max = max_launches, g_tl_next = 0; }
+#endif
+
+uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint32_t* grid_out) {
+    DecGemvParams p = p_in;
+#ifdef UZU_TIMELINE
+    p.tl = timeline_next_slot();
+#endif
     if ((p.bits != 4 && p.bits != 8) || p.k % 32 || p.group_size % 32 || (p.group_size & (p.group_size - 1)) || ((p.norm_scales || p.norm_plain) && p.k % 1024)) {
         set_error("gemv_dec: unsupported shape (bits %u, k %u, group %u)", p.bits, p.k, p.group_size);
         return UZU_ERR_UNSUPPORTED;
@@ -611,9 +660,10 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t
 
 // ---------------------------------------------------------------------------------------------- argmax_commit
 __global__ void __launch_bounds__(256) argmax_commit_kernel(const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len,
-                                                            uint32_t* tokens, uint32_t* out_token, uint32_t* sampled) {
+                                                            uint32_t* tokens, uint32_t* out_token, uint32_t* sampled, CommitEmbed eb) {
     __shared__ float sv[4];
     __shared__ uint32_t si[4];
+    __shared__ uint32_t s_token;
     float bv = -INFINITY;
     uint32_t bi = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < parts; i += 256) {
@@ -638,11 +688,58 @@ __global__ void __launch_bounds__(256) argmax_commit_kernel(const float* pv, con
         sampled[len] = t;
         tokens[0] = t;
         *ctx_len = len + 1;
+        s_token = t;
+    }
+    if (!eb.output) return;
+    __syncthreads();
+    // the sampled token's embedding row = input of the next decode step (same arithmetic as k_elementwise.hip's lookups)
+    const uint32_t token_id = s_token;
+    for (uint32_t dim_idx = threadIdx.x; dim_idx < eb.model_dim; dim_idx += 256) {
+        float out_f;
+        if (token_id >= eb.vocab_size) {
+            out_f = 0.0f;
+        } else if (eb.method == UZU_QUANT_NONE) {
+            out_f = bf16_to_f32(((const uint16_t*)eb.weights)[(size_t)token_id * eb.model_dim + dim_idx]) * round_bf16(eb.input_scale);
+        } else {
+            const uint32_t packing_divisor = 8 / eb.bits;
+            const size_t weights_stride = eb.model_dim / packing_divisor;
+            const size_t num_groups = (eb.model_dim + eb.group_size - 1) / eb.group_size;
+            const size_t zero_points_stride = eb.bits == 4 ? (num_groups + 1) / 2 : num_groups;
+            const size_t group_idx = dim_idx / eb.group_size;
+            const float scale = bf16_to_f32(eb.scales[(size_t)token_id * num_groups + group_idx]);
+            int quantized_value;
+            if (eb.bits == 4) {
+                const uint8_t packed = eb.weights[(size_t)token_id * weights_stride + dim_idx / 2];
+                quantized_value = (dim_idx & 1) == 0 ? (packed & 0x0F) : ((packed >> 4) & 0x0F);
+            } else {
+                quantized_value = eb.weights[(size_t)token_id * weights_stride + dim_idx];
+            }
+            float bias;
+            if (eb.method == UZU_QUANT_SCALE_BIAS) {
+                bias = bf16_to_f32(eb.biases[(size_t)token_id * num_groups + group_idx]);
+            } else if (eb.method == UZU_QUANT_SCALE_ZERO_POINT) {
+                uint8_t zero_point;
+                if (eb.bits == 4) {
+                    const uint8_t packed = eb.zero_points[(size_t)token_id * zero_points_stride + group_idx / 2];
+                    zero_point = (group_idx & 1) == 0 ? (packed & 0x0F) : ((packed >> 4) & 0x0F);
+                } else {
+                    zero_point = eb.zero_points[(size_t)token_id * zero_points_stride + group_idx];
+                }
+                bias = -scale * (float)zero_point;
+            } else {
+                bias = -scale * (float)(1 << (eb.bits - 1));
+            }
+            out_f = scale * (float)quantized_value + bias;
+            out_f = out_f * eb.input_scale;
+        }
+        eb.output[dim_idx] = f32_to_bf16(out_f);
     }
 }
 uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len, uint32_t* tokens,
-                         uint32_t* out_token, uint32_t* sampled) {
-    return launch_check([&] { hipLaunchKernelGGL(argmax_commit_kernel, dim3(1), dim3(256), 0, s, pv, pi, parts, ctx_len, tokens, out_token, sampled); },
+                         uint32_t* out_token, uint32_t* sampled, const CommitEmbed* embed) {
+    CommitEmbed eb{};
+    if (embed) eb = *embed;
+    return launch_check([&] { hipLaunchKernelGGL(argmax_commit_kernel, dim3(1), dim3(256), 0, s, pv, pi, parts, ctx_len, tokens, out_token, sampled, eb); },
                         "argmax_commit");
 }
 
@@ -655,6 +752,7 @@ uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uin
 // instructions) so that the math hides under the state-row latency.
 __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
     constexpr int DK = 128;
+    UZU_TL_STAMP(p, 0);
     const uint32_t hv = blockIdx.x;
     const uint32_t gph = p.num_v_heads / p.num_k_heads;
     const uint32_t hk = hv / gph;
@@ -724,8 +822,13 @@ __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
             p.sz[hv * Dv + i] = sz_i;
         }
     }
+    UZU_TL_STAMP(p, 3);
 }
-uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p) {
+uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p_in) {
+    DeltaDecParams p = p_in;
+#ifdef UZU_TIMELINE
+    p.tl = timeline_next_slot();
+#endif
     if (p.head_v_dim > 512 || p.num_k_heads == 0 || p.num_v_heads % p.num_k_heads) {
         set_error("delta_dec: unsupported configuration");
         return UZU_ERR_UNSUPPORTED;
@@ -747,6 +850,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     __shared__ float s_o[NGRP][GS][HD];
     __shared__ float s_m[NGRP][GS], s_l[NGRP][GS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    UZU_TL_STAMP(p, 0);
     const uint32_t subs = p.gqa_factor / GS;
     const uint32_t kvh = blockIdx.x / subs, sub = blockIdx.x % subs;
     const uint32_t head0 = kvh * p.gqa_factor + sub * GS;
@@ -857,6 +961,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         }
     }
 
+    UZU_TL_STAMP(p, 1);
     // ---- split-KV online softmax over keys i = key0 + key_step * t, i <= L (causal, suffix length 1) ----
     float q[GS][8], o[GS][8], mx[GS], sm[GS];
 #pragma unroll
@@ -904,6 +1009,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
             }
         }
     }
+    UZU_TL_STAMP(p, 2);
     // every key group parks its state in LDS; the merge below runs over the NGRP groups in group order
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
@@ -928,6 +1034,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         p.partials[row * HD + e] = acc;
         if (e == 0) p.sums[row] = l, p.maxs[row] = m;
     }
+    UZU_TL_STAMP(p, 3);
 }
 
 template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
@@ -947,7 +1054,11 @@ template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDec
     }
 #undef UZU_LAUNCH
 }
-uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
+uzu_status attn_dec(hipStream_t s, const AttnDecParams& p_in, uint32_t splits) {
+    AttnDecParams p = p_in;
+#ifdef UZU_TIMELINE
+    p.tl = timeline_next_slot();
+#endif
     if (p.rope_dim > p.head_dim || (p.rope_dim & 1)) {
         set_error("attn_dec: bad rope_dim %u", p.rope_dim);
         return UZU_ERR_INVALID_ARGUMENT;

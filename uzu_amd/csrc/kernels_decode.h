@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/uzu_hip.h"
+#include "../../include/uzu_model_desc.h"
 
 namespace uzu {
 namespace k {
@@ -16,7 +17,26 @@ struct DecNorm {
     const float* scales;
 };
 
+// Per-workgroup phase timestamps (100 MHz wall clock, s_memrealtime) for tools/timeline.py.  Compiled in only with
+// -DUZU_TIMELINE (a separate library variant: the production kernels carry no trace of it).
+#ifdef UZU_TIMELINE
+#define UZU_TL_FIELD unsigned long long* tl;
+#define UZU_TL_STAMP(p, slot)                                                                   \
+    do {                                                                                        \
+        if ((p).tl && threadIdx.x == 0) {                                                        \
+            const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;                             \
+            if (wg < 1024) (p).tl[wg * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();            \
+        }                                                                                       \
+    } while (0)
+unsigned long long* timeline_next_slot(); // next per-launch block of 1024 x 4 stamps, or null
+extern "C" void uzu_hip_debug_set_timeline(unsigned long long* base, uint32_t max_launches);
+#else
+#define UZU_TL_FIELD
+#define UZU_TL_STAMP(p, slot) do { } while (0)
+#endif
+
 struct DecGemvParams {
+    UZU_TL_FIELD
     // one or two weight matrices with the same k / quantisation (e.g. qkv_projection || gate_projection)
     const uint8_t* w[2];
     const uint16_t* scales[2];
@@ -39,6 +59,7 @@ struct DecGemvParams {
     uint32_t act_mul, act_type;   // out[0][j] = up_j * act(gate_j), n[0] = 2h
     float* part_val;              // arg-max partials, one per workgroup
     uint32_t* part_idx;
+    uint32_t part_capacity;       // entries in part_val / part_idx: the grid is clamped to it (0 = unchecked, 8192 in tools)
     float* out_f32;               // tensor parallel: matrix 0 writes f32 partial sums here instead of bf16 into out[0]
     // DeltaNetConvUpdate epilogue (in-proj): rows < conv_dim of matrix 0 go through the causal conv + SiLU of their
     // channel (one lane owns a channel: taps read, shifted and written by that lane only) -- conv_update.rs:17-55
@@ -56,10 +77,23 @@ struct DecGemvParams {
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
+// Embedding row of the token the commit kernel has just sampled (the next decode step's input row): the lookup of
+// quant_embedding.rs:36-116 / full_precision_embedding.rs:17-31 for one token, done by the committing workgroup instead
+// of a launch of its own at the head of the next step.  `output` null => plain commit.
+struct CommitEmbed {
+    const uint8_t* weights;      // packed codes [vocab, dim / pack], or bf16 [vocab, dim] when method == UZU_QUANT_NONE
+    const uint16_t* scales;      // bf16 [vocab, groups]
+    const uint8_t* zero_points;
+    const uint16_t* biases;
+    uint16_t* output;            // bf16 [dim]
+    uint32_t vocab_size, model_dim, group_size, bits, method;
+    float input_scale;
+};
 uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len, uint32_t* tokens,
-                         uint32_t* out_token, uint32_t* sampled);
+                         uint32_t* out_token, uint32_t* sampled, const CommitEmbed* embed = nullptr);
 
 struct DeltaDecParams {
+    UZU_TL_FIELD
     const uint16_t* in_proj;  // post-conv row: [q | k | v | z | beta | a] (the conv ran in the in-proj epilogue)
     const float* a_log;
     const float* dt_bias;
@@ -71,6 +105,7 @@ struct DeltaDecParams {
 uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p);
 
 struct AttnDecParams {
+    UZU_TL_FIELD
     const uint16_t* qkv;   // packed [q heads | k heads | v heads] x head_dim of the new token
     uint16_t* keys;        // cache [tokens, kv_heads, hd]
     uint16_t* values;

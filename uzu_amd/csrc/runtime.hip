@@ -246,8 +246,12 @@ uzu_status uzu_hip_cmdbuf_create(uzu_hip_context* ctx, const char* name, uint32_
     cb->ctx = ctx;
     cb->name = name ? name : "";
     cb->flags = flags;
-    UZU_HIP_TRY(hipEventCreate(&cb->ev_start));
-    UZU_HIP_TRY(hipEventCreate(&cb->ev_end));
+    if (hipEventCreate(&cb->ev_start) != hipSuccess || hipEventCreate(&cb->ev_end) != hipSuccess) {
+        if (cb->ev_start) (void)hipEventDestroy(cb->ev_start);
+        delete cb;
+        set_error("cmdbuf_create: hipEventCreate failed");
+        return UZU_ERR_HIP;
+    }
     *out = cb;
     return UZU_OK;
 }

@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* in, uin
 
 // order-preserving map f32 -> u32 (larger float <=> larger unsigned); NaN never wins a greedy arg-max upstream
 __device__ __forceinline__ uint32_t orderable(float v) {
-    const uint32_t b = f32_to_bits(v);
+    // -0.0 and +0.0 compare equal in every per-rank reduction (ties -> lowest index, unified_sampling.rs:90-95), so they
+    // must map to the same key: otherwise the winner between ranks would depend on how the vocabulary is sharded
+    const uint32_t raw = f32_to_bits(v);
+    const uint32_t b = (raw << 1) == 0u ? 0u : raw;
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __device__ __forceinline__ float from_orderable(uint32_t u) { return bits_to_f32((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }

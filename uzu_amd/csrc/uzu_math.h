@@ -78,7 +78,9 @@ static const uint64_t kExp2fTab[32] = {
     0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL,
 };
 
-UZU_HD float expf_glibc(float x) {
+// `tab`: the 32-entry table -- kExp2fTab, or a copy of it in LDS (decode epilogues: a table read from global memory is
+// a dependent memory round trip on the critical path of a 4 us kernel)
+UZU_HD float expf_glibc_tab(float x, const uint64_t* tab) {
     const uint32_t ix = f32_to_bits(x);
     const uint32_t abstop = (ix >> 20) & 0x7ff;
     if (abstop >= 0x42b) { // |x| >= 88 or NaN/Inf
@@ -98,7 +100,7 @@ UZU_HD float expf_glibc(float x) {
     const uint64_t ki = f64_to_bits(kd);
     kd -= Shift;
     const double r = z - kd;
-    uint64_t t = kExp2fTab[ki & 31];
+    uint64_t t = tab[ki & 31];
     t += ki << (52 - 5);
     const double s = bits_to_f64(t);
     z = __builtin_fma(C0, r, C1);
@@ -108,6 +110,8 @@ UZU_HD float expf_glibc(float x) {
     y = y * s;
     return (float)y;
 }
+
+UZU_HD float expf_glibc(float x) { return expf_glibc_tab(x, kExp2fTab); }
 
 // logf: glibc sysdeps/ieee754/flt-32/e_logf.c (same family: 16-entry table, degree-3 polynomial in
 // double).  T[i] = {invc, logc} with c near the centre of the i-th subinterval of [0x3f330000 .. *2).
@@ -156,5 +160,6 @@ UZU_HD float logf_glibc(float x) {
 
 // activation_type.rs:44-65: x / (1 + exp(-alpha*x)) with alpha = 1, evaluated in f32
 UZU_HD float silu_f32(float x) { return x / (1.0f + expf_glibc(-1.0f * x)); }
+UZU_HD float silu_f32_tab(float x, const uint64_t* tab) { return x / (1.0f + expf_glibc_tab(-1.0f * x, tab)); }
 
 } // namespace uzu

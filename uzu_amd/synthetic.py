@@ -81,7 +81,10 @@ def qwen35_0p8b(max_context_length: int = 4096, **kw) -> ModelConfig:
         dn_num_heads=16, dn_num_groups=16, dn_head_dim=128, dn_value_head_dim=128, dn_kernel_size=4,
         norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
         bits=4, group_size=128, method=D.QUANT_SCALE_BIAS, tied_embeddings=True,
-        max_context_length=max_context_length)
+        max_context_length=max_context_length,
+        # seed 45: the greedy stream of the 2040-token synthetic prompt keeps moving (13 distinct tokens in 25, every top-2
+        # gap >= 0.33 sigma) instead of falling into a fixed point after a few steps as most seeds do (tools/seed_search.py)
+        seed=45)
     return replace(cfg, **kw)
 
 

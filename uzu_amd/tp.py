@@ -239,6 +239,8 @@ def pack_argmax_key(logit: float, global_index: int) -> int:
     """Host mirror of tp.hip's packed greedy key: (order-preserving u32 of the f32 logit) << 32 | ~index.
     max() over the ranks' keys = highest logit, ties -> lowest index (unified_sampling.rs:90-95)."""
     bits = int(np.float32(logit).view(np.uint32))
+    if bits & 0x7FFFFFFF == 0:
+        bits = 0  # -0.0 == +0.0: same key, the index decides
     orderable = (~bits & 0xFFFFFFFF) if bits & 0x80000000 else (bits | 0x80000000)
     return (orderable << 32) | (0xFFFFFFFF - int(global_index))
 
