@@ -45,15 +45,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(bundle, cfg, decode_tokens):
+def cpu_baseline(bundle, cfg, decode_tokens, context):
     """Time the CPU oracle (oracle/ = port of the reference's CPU backend, which is single-threaded by
-    construction: backends/cpu/context.rs:20-33) on a bounded sample of the same workload."""
+    construction: backends/cpu/context.rs:20-33) on a bounded sample of the same workload: `decode_tokens` greedy
+    decode steps AT THE BENCH CONTEXT.  The context is reached without a CPU prefill (which would take ~25 minutes):
+    orc_model_fill_synthetic_context puts `context` synthetic KV rows in place -- the cost of a decode step depends on the
+    context length, not on the values."""
     from oracle import oracle as O
     om = O.OracleModel(bundle)
     O.set_threads(1)
     from uzu_amd import synthetic as S
     prompt = S.synthetic_prompt(2, cfg.vocab_size)
     tok = om.prefill(prompt)
+    om.fill_synthetic_context(context)
     t0 = time.perf_counter()
     for _ in range(decode_tokens):
         tok = om.forward([tok])
@@ -68,8 +72,8 @@ def cpu_baseline(bundle, cfg, decode_tokens):
     allc = decode_tokens / (time.perf_counter() - t0)
     om.close()
     return {"value": round(one, 4), "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": f"{decode_tokens} greedy decode tokens at context 2..{2 + decode_tokens} after a 2-token prompt, same weights, "
-                      f"1 thread (the reference CPU backend is single-threaded); weights dominate cost at this context",
+            "sample": f"{decode_tokens} greedy decode tokens at context {context}..{context + decode_tokens} (synthetic KV rows instead of a CPU prefill), same "
+                      f"weights, 1 thread (the reference CPU backend is single-threaded)",
             "all_cores_value": round(allc, 4), "all_cores": cores}
 
 
@@ -129,11 +133,36 @@ def timed_decode(model, ctx, args, dist, prompt):
     return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run
+    on 127.0.0.1) and pass rank 0's JSON line through.  Never falls back to fewer GPUs silently."""
+    import socket
+    import subprocess
+    try:
+        import torch
+        visible = torch.cuda.device_count()
+    except Exception as exc:  # noqa: BLE001
+        sys.exit(f"bench.py --gpus {n}: cannot count GPUs ({exc})")
+    if visible < n:
+        sys.exit(f"bench.py --gpus {n}: only {visible} GPU(s) visible -- refusing to report a {n}-GPU line from fewer devices")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.force_dist:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     dist = None
     multi = world > 1 or args.force_dist
     if multi:
@@ -256,7 +285,7 @@ def main():
             result["replicas"] = {"error": str(exc)[:200]}
             model = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(bundle, cfg, args.cpu_baseline_tokens)
+        result["cpu_baseline"] = cpu_baseline(bundle, cfg, args.cpu_baseline_tokens, start_ctx)
     if model is not None:
         model.close()
     if group is not None:

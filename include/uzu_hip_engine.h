@@ -30,6 +30,8 @@ enum {
     UZU_MODEL_NO_FUSION = 2,  /* one kernel per reference kernel (no fused prologues / epilogues) */
     UZU_MODEL_DEBUG_TAPS = 4  /* keep every layer's output of the last forward pass for inspection */
 };
+/* bits 8..15 of `flags`: sequences one batched prefill pass may carry (scratch is sized for it); 0 = 1 */
+#define UZU_MODEL_BATCH(n) (((uint32_t)(n) & 0xFFu) << 8)
 
 /* Uploads every tensor of `desc` into HBM (the desc's host pointers are not retained). */
 uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out);
@@ -51,6 +53,25 @@ void uzu_hip_tp_comm_destroy(uzu_hip_tp_comm* comm);
 uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_tp_comm* comm,
                                    uint32_t vocab_offset, uzu_hip_model** out);
 uint32_t uzu_hip_model_logit_count(const uzu_hip_model* m);
+/* ---- sequence state (LanguageModelState, engine/language_model/state.rs:9-16) ----
+ * The reference keeps everything that belongs to one sequence (KV caches, DeltaNet conv / SSM states, token history)
+ * apart from the model, so that several sequences share one set of weights (BASELINE configs 3 and 5).  A model is
+ * created with a state of its own; further ones come from uzu_hip_state_create.  prefill / decode / reset / read_* act on
+ * the state BOUND to the model (uzu_hip_model_bind_state; NULL re-binds the model's own).  Each state owns its captured
+ * decode graphs.  States must be destroyed before their model. */
+typedef struct uzu_hip_state uzu_hip_state;
+uzu_status uzu_hip_state_create(uzu_hip_model* m, uzu_hip_state** out);
+void uzu_hip_state_destroy(uzu_hip_state* st);
+uzu_status uzu_hip_state_reset(uzu_hip_state* st);
+uint32_t uzu_hip_state_context_length(const uzu_hip_state* st);
+uzu_status uzu_hip_model_bind_state(uzu_hip_model* m, uzu_hip_state* st);
+/* Prefill `nseq` (<= UZU_MODEL_BATCH at creation) independent sequences with `count` prompt tokens each (token_ids is
+ * row-major [nseq, count]): the linear layers see one matrix of nseq * chunk rows -- weights are streamed once for all
+ * sequences -- while attention and DeltaNet run per sequence on its own state.  Per sequence the results are those of
+ * uzu_hip_model_prefill on that state (the reference has no cross-sequence batching: SURVEY.md F10).  first_tokens[i]
+ * receives the token sampled from sequence i's last row.  The binding in force before the call is restored. */
+uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states, uint32_t nseq, const uint32_t* token_ids, uint32_t count,
+                                       uint32_t* first_tokens);
 /* LanguageModelState reset: context length 0, DeltaNet conv / SSM state zeroed. */
 uzu_status uzu_hip_model_reset(uzu_hip_model* m);
 uint32_t uzu_hip_model_context_length(const uzu_hip_model* m);

@@ -160,6 +160,11 @@ class OracleModel:
     def context_length(self) -> int:
         return lib().orc_model_context_length(self._h)
 
+    def fill_synthetic_context(self, n: int):
+        """Timing aid: jump to context length n with synthetic KV rows (no prefill); see uzu_oracle_model.c."""
+        lib().orc_model_fill_synthetic_context.argtypes = [C.c_void_p, C.c_uint32]
+        lib().orc_model_fill_synthetic_context(self._h, C.c_uint32(n))
+
     def forward(self, tokens, want_logits: bool = False):
         tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
         logits = np.empty(self.vocab_size, dtype=np.uint16) if want_logits else None

@@ -195,6 +195,7 @@ typedef struct orc_model orc_model;
 orc_model* orc_model_create(const uzu_model_desc* desc); /* keeps the desc's pointers: caller keeps them alive */
 void orc_model_destroy(orc_model* m);
 void orc_model_reset(orc_model* m);
+void orc_model_fill_synthetic_context(orc_model* m, uint32_t n); /* timing aid (bench.py cpu_baseline): see the .c file */
 uint32_t orc_model_context_length(const orc_model* m);
 /* One forward pass over `count` tokens of one sequence (count <= 1024) appended at the current context
  * length; writes logits (bf16 [vocab]) of the LAST row if logits_out != NULL, returns greedy token of the

@@ -110,6 +110,25 @@ void orc_model_destroy(orc_model* m) {
     free(m);
 }
 
+/* Timing aid for bench.py's cpu_baseline leg: puts the model at context length `n` WITHOUT running a prefill -- the KV
+ * rows get small deterministic values, the DeltaNet states stay as they are.  The cost of a decode step does not depend
+ * on the data, only on the context length (KV rows scanned); results after this call are not reference results. */
+void orc_model_fill_synthetic_context(orc_model* m, uint32_t n) {
+    if (n > m->desc.max_context_length) n = m->desc.max_context_length;
+    for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        if (L->mixer_kind != UZU_MIXER_ATTENTION) continue;
+        const size_t element_size = (size_t)L->num_groups * L->head_dim;
+        for (size_t i = 0; i < (size_t)n * element_size; ++i) {
+            const uint32_t h = (uint32_t)(i * 2654435761u + l * 40503u);
+            m->states[l].keys[i] = (uint16_t)(0x3C00u + (h >> 26));           /* bf16 in [0.0078, 0.0156) */
+            m->states[l].values[i] = (uint16_t)(0xBC00u + ((h >> 20) & 63u)); /* small negative values */
+        }
+        m->states[l].length = n;
+    }
+    m->context_length = n;
+}
+
 uint32_t orc_model_context_length(const orc_model* m) { return m->context_length; }
 const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint32_t* rows) {
     if (rows) *rows = m->last_rows;

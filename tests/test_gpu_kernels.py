@@ -11,6 +11,8 @@ procedural inputs -> CPU kernel as oracle -> compare.  Bars:
   * matmul in reference-order mode (uzu_hip_set_exact_matmul): BIT-EXACT.
 """
 import ctypes as C
+import json
+import os
 
 import numpy as np
 import pytest
@@ -434,6 +436,83 @@ def test_argmax_exact_with_ties(hip_ctx):
     assert bo.download(np.uint32, batch).tolist() == want.tolist()
     with pytest.raises(B.UzuHipError):
         B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 1, 0, 0, 0, 0, 0)  # stochastic: unsupported, loudly
+
+
+
+# ------------------------------------------------------------------------------------------ UnifiedSampling, every specialisation
+def hip_sample(hip_ctx, logits, seeds=None, bitmask=None, temperature=None, top_k=None, top_p=None, min_p=None, graph=False, kern=None):
+    batch, vocab = logits.shape
+    kern = kern or B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, int(seeds is not None), int(bitmask is not None), int(temperature is not None),
+                                               int(top_k is not None), int(top_p is not None), int(min_p is not None))
+    bl, bo = hip_ctx.buffer_from(logits), hip_ctx.create_buffer(batch * 4)
+    bs = hip_ctx.buffer_from(np.ascontiguousarray(seeds, dtype=np.uint64)) if seeds is not None else None
+    bm = hip_ctx.buffer_from(np.ascontiguousarray(bitmask, dtype=np.uint32)) if bitmask is not None else None
+    if graph:
+        cb = hip_ctx.create_command_buffer("sampling", graph=True).start_encoding()
+        try:
+            kern.encode(bl, bo, bs, bm, temperature, top_k, top_p, min_p, vocab, batch, cb)
+        except B.UzuHipError:
+            _ffi.lib().uzu_hip_cmdbuf_destroy(cb._h)  # ends the stream capture the failed encode left open
+            cb._h = C.c_void_p()
+            raise
+        cb.end_encoding().submit().wait_until_completed()
+    else:
+        run(hip_ctx, lambda cb: kern.encode(bl, bo, bs, bm, temperature, top_k, top_p, min_p, vocab, batch, cb))
+    return bo.download(np.uint32, batch)
+
+
+def test_unified_sampling_committed_fixture(hip_ctx):
+    """tests/golden/sampling.json: tokens of every specialisation (stochastic, temperature, top-k, top-p, min-p, all filters +
+    grammar bitmask, greedy + bitmask) for fixed logits / seeds, generated by the CPU restatement of unified_sampling.rs:33-98."""
+    from golden.make_sampling_golden import CASES, inputs
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sampling.json")))
+    logits, seeds, mask = inputs()
+    assert gold["vocab"] == logits.shape[1] and gold["batch"] == logits.shape[0]
+    for case, want in zip(CASES, gold["cases"]):
+        assert case["name"] == want["name"]
+        got = hip_sample(hip_ctx, logits, seeds=seeds if case["stochastic"] else None, bitmask=mask if case["mask"] else None,
+                         temperature=case["temperature"], top_k=case["top_k"], top_p=case["top_p"], min_p=case["min_p"])
+        assert got.tolist() == want["tokens"], f"{case['name']}: hip {got.tolist()} != fixture {want['tokens']}"
+
+
+@pytest.mark.parametrize("vocab,spread", [(248320, 2.5), (128256, 0.6), (50000, 6.0), (4097, 0.05)])
+@pytest.mark.parametrize("setting", [
+    dict(), dict(stochastic=True), dict(stochastic=True, temperature=0.8), dict(stochastic=True, top_k=50), dict(stochastic=True, top_k=1),
+    dict(stochastic=True, top_p=0.9), dict(stochastic=True, top_p=0.999), dict(stochastic=True, temperature=1.3, min_p=0.02),
+    dict(stochastic=True, temperature=0.7, top_k=200, top_p=0.95, min_p=0.001, mask=True), dict(top_k=5, mask=True),
+])
+def test_unified_sampling_matches_cpu_restatement(hip_ctx, vocab, spread, setting):
+    """Real vocabulary sizes (Qwen3.5 248 320, Llama-3 128 256), peaked and nearly flat bf16 logit rows (flat rows have
+    thousands of exactly tied logits: the cut of top-k / top-p then falls inside a tie group, which the reference's sort orders by
+    index), every filter combination: identical tokens."""
+    rng = np.random.default_rng(vocab + len(setting))
+    batch = 3
+    logits = bf16(rng.normal(0.0, spread, (batch, vocab)))
+    seeds = rng.integers(0, 2 ** 63, batch, dtype=np.uint64) if setting.get("stochastic") else None
+    mask = rng.integers(0, 2 ** 32, (batch, (vocab + 31) // 32), dtype=np.uint64).astype(np.uint32) if setting.get("mask") else None
+    from test_oracle_sampling import sample
+    kw = dict(temperature=setting.get("temperature"), top_k=setting.get("top_k"), top_p=setting.get("top_p"), min_p=setting.get("min_p"))
+    want = sample(logits, seeds=seeds, bitmask=mask, **kw)
+    got = hip_sample(hip_ctx, logits, seeds=seeds, bitmask=mask, **kw)
+    assert got.tolist() == want.tolist()
+
+
+def test_unified_sampling_in_a_graph_captured_command_buffer(hip_ctx):
+    """A UZU_CMDBUF_GRAPH command buffer replays the sampling kernels with the kernel-owned scratch block (no stream-ordered
+    allocation inside the capture): same tokens as the eager encode; a batch that would need a larger block than the kernel
+    owns is refused inside a capture and accepted after one eager encode."""
+    rng = np.random.default_rng(5)
+    logits = bf16(rng.normal(0.0, 2.0, (4, 30000)))
+    seeds = rng.integers(0, 2 ** 63, 4, dtype=np.uint64)
+    for kw in (dict(), dict(seeds=seeds, temperature=0.9), dict(seeds=seeds, top_k=20, top_p=0.9)):
+        assert hip_sample(hip_ctx, logits, graph=True, **kw).tolist() == hip_sample(hip_ctx, logits, **kw).tolist()
+    big = bf16(rng.normal(0.0, 2.0, (80, 2000)))  # 80 rows > the 64 the kernel object is created for
+    kern = B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 0, 0, 1, 0, 0, 0)
+    with pytest.raises(B.UzuHipError):
+        hip_sample(hip_ctx, big, temperature=0.5, graph=True, kern=kern)
+    eager = hip_sample(hip_ctx, big, temperature=0.5, kern=kern)
+    assert hip_sample(hip_ctx, big, temperature=0.5, graph=True, kern=kern).tolist() == eager.tolist()
+    assert eager.tolist() == [int(np.argmax(f32(r))) for r in big]
 
 
 def test_kv_cache_update(hip_ctx):

@@ -19,7 +19,7 @@ from oracle import oracle as O
 from uzu_amd import _ffi
 from uzu_amd import synthetic as S
 from uzu_amd import desc as D
-from uzu_amd.engine import MODEL_DEBUG_TAPS, MODEL_NO_FUSION, MODEL_NO_GRAPH, HipModel
+from uzu_amd.engine import MODEL_BATCH, MODEL_DEBUG_TAPS, MODEL_NO_FUSION, MODEL_NO_GRAPH, HipModel
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -173,11 +173,15 @@ def test_reset_and_determinism(hip_ctx):
 def test_qwen35_0p8b_full_size(hip_ctx):
     """BASELINE config 1/2 at full size: Qwen3.5-0.8B int4 g128, 128-token prompt + greedy decode,
     oracle (OpenMP over output rows; bit-identical to 1 thread) vs HIP."""
-    cfg = S.qwen35_0p8b(max_context_length=1024)
+    # seed 42: every top-2 gap of this 128-token stream is >= 0.5 sigma in the oracle (asserted below), so the chained greedy
+    # comparison is not decided by a near-tie; the preset's default seed is tuned for the 2040-token bench prompt instead
+    # (tests/golden/fullsize_qwen_bench.json, test_qwen_bench_config_matches_oracle_fixture)
+    cfg = S.qwen35_0p8b(max_context_length=1024, seed=42)
     # 24 layers of bf16 residual-stream arithmetic: 1-ulp differences per kernel (summation order) grow to a few
     # percent of the final hidden state, measured max 0.35 sigma / mean 0.05 sigma on the row-normalised logits
     # (tools/fullsize_check.py); the 4-layer toy models stay below 0.1 sigma.  Tolerance here: 0.5 sigma.
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 128, 8, logit_tol=0.5)
+    assert min(run_pair.gaps) >= 0.5, f"test premise: oracle top-2 gaps {run_pair.gaps}"
     assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
 
 
@@ -190,3 +194,132 @@ def test_llama3_8b_shapes_two_layers(hip_ctx, bits, method):
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 48, 6)
     assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
 
+
+
+# ------------------------------------------------------------------------------------------ committed full-size fixtures
+NEAR_TIE_SIGMA = 0.3  # a top-2 gap below this many logit standard deviations is inside the bf16 pipeline's noise (measured max
+#                       full-size logit error: 0.35 sigma over 248k logits, typically 0.05 at a given logit)
+
+
+def check_against_fixture(hip_ctx, name, flags=0, logit_tol=0.5):
+    """HIP engine vs a committed oracle fixture (tests/golden/make_fullsize.py), in two passes over the same weights:
+    (1) chained greedy decode exactly as bench.py runs it (hipGraph replay, fused kernels, the sampled token fed back on the
+        device): the token stream must equal the oracle's up to -- and not necessarily including -- the first step whose
+        oracle top-2 gap is a near-tie (< NEAR_TIE_SIGMA); after such a step the two streams may legitimately part;
+    (2) teacher-forced over ALL steps (the oracle's token is fed in, so every step is an independent comparison): the top-8
+        logits of the oracle are matched within `logit_tol` sigma and the arg-max is identical wherever the gap is not a
+        near-tie."""
+    fx = json.load(open(os.path.join(GOLDEN, f"fullsize_{name}.json")))
+    kw = dict(fx["config"])
+    cfg = S.PRESETS[fx["preset"]](**kw)
+    assert cfg.seed == fx["seed"] and cfg.bits == fx["bits"] and abs(cfg.logit_row_sigma - fx["logit_row_sigma"]) < 1e-12
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg)
+    prompt = S.synthetic_prompt(fx["prompt_len"], cfg.vocab_size)
+    rows = fx["rows"]
+    hm = HipModel(hip_ctx, bundle, flags)
+    # pass 1: chained
+    first = hm.prefill(prompt)
+    toks, _ = hm.decode(fx["steps"])
+    got = [first] + [int(t) for t in toks]
+    safe = 0
+    while safe < len(rows) and rows[safe]["gap_sigma"] >= NEAR_TIE_SIGMA:
+        safe += 1
+    safe = min(safe + 1, len(rows))  # the near-tie step's own INPUT is still the common prefix; its output may differ
+    want = [r["token"] for r in rows]
+    assert got[:safe - 1] == want[:safe - 1], f"chained greedy stream differs before the first near-tie (step {safe - 1})\noracle {want}\nhip    {got}"
+    assert hm.context_length == fx["prompt_len"] + fx["steps"]
+    # pass 2: teacher-forced, logits of the oracle's top-8
+    hm.reset()
+    hm.prefill(prompt)
+    worst = 0.0
+    exact_argmax = 0
+    for step, r in enumerate(rows):
+        if step > 0:
+            hm.set_next_token(rows[step - 1]["token"])
+            hm.decode(1)
+        lg = f32(hm.read_logits()).astype(np.float64)
+        sigma = (lg / row_mult).std()  # row-normalised, as in logits_close(): logit i and its error scale with multiplier i
+        for tok, bits in r["top8"]:
+            err = abs(lg[tok] - float(f32(np.array([bits], np.uint16))[0])) / row_mult[tok] / sigma
+            worst = max(worst, err)
+            assert err <= logit_tol, f"{name} step {step}: logit of token {tok} off by {err:.3f} sigma"
+        amax = int(np.argmax(lg))
+        if r["gap_sigma"] >= NEAR_TIE_SIGMA:
+            assert amax == r["token"], f"{name} step {step}: arg-max {amax} != oracle {r['token']} at gap {r['gap_sigma']} sigma"
+        exact_argmax += amax == r["token"]
+    hm.close()
+    print(f"fixture {name}: chained prefix {safe - 1} tokens identical, teacher-forced arg-max identical in {exact_argmax}/{len(rows)} steps, "
+          f"worst top-8 logit error {worst:.3f} sigma")
+    return got, want, worst
+
+
+def test_qwen_bench_config_matches_oracle_fixture(hip_ctx):
+    """BASELINE configs[1] in EXACTLY bench.py's mode: full-size Qwen3.5-0.8B int4 g128, synthetic 2040-token prompt (two
+    prefill chunks), then chained greedy decode at context 2040+ through the captured two-pass graph with the fused decode
+    kernels (attn_dec<256, 4> with 64 KV splits, gemv_dec, delta_dec).  Oracle side: tests/golden/fullsize_qwen_bench.json
+    (28 CPU-minutes, committed).  The synthetic stream visits >= 12 distinct tokens."""
+    got, want, worst = check_against_fixture(hip_ctx, "qwen_bench")
+    assert len(set(want)) >= 12
+    assert worst <= 0.5
+
+
+@pytest.mark.parametrize("name", ["llama_int4", "llama_int8"])
+def test_llama3_8b_full_depth_matches_oracle_fixture(hip_ctx, name):
+    """BASELINE configs[2] / [3] weights at full depth: all 32 layers of Llama-3-8B (int4 MLX ScaleBias; int8 asymmetric),
+    48-token prefill on the matrix cores + 8 chained greedy decode steps, against the committed oracle fixtures."""
+    if not os.path.exists(os.path.join(GOLDEN, f"fullsize_{name}.json")):
+        pytest.fail(f"tests/golden/fullsize_{name}.json is missing: run python tests/golden/make_fullsize.py {name}")
+    check_against_fixture(hip_ctx, name)
+
+
+# ------------------------------------------------------------------------------------------ sequence states
+@pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
+def test_sequence_states_are_independent_and_batched_prefill_matches_single(hip_ctx, preset):
+    """LanguageModelState split from the model (state.rs:9-16): three sequences with different prompts share one set of
+    weights.  (1) interleaved prefill / decode on separately created states gives exactly the tokens each sequence gets
+    alone; (2) one batched prefill pass over all three (linear layers on 3 x count rows, attention / DeltaNet per state)
+    followed by per-state decode gives the same tokens again; every sequence equals the single-sequence oracle."""
+    cfg = S.PRESETS[preset]()
+    bundle = S.build_model(cfg)
+    count, steps, nseq = 37, 6, 3
+    prompts = np.stack([(S.synthetic_prompt(count, cfg.vocab_size).astype(np.int64) * (3 + 2 * i) + 11 * i) % cfg.vocab_size for i in range(nseq)]).astype(np.uint32)
+    want = []
+    om = O.OracleModel(bundle)
+    for i in range(nseq):
+        om.reset()
+        tok = om.prefill(prompts[i])
+        seq = [tok]
+        for _ in range(steps):
+            tok = om.forward([tok])
+            seq.append(tok)
+        want.append(seq)
+    hm = HipModel(hip_ctx, bundle, MODEL_BATCH(nseq))
+    # (1) interleaved use of three states
+    states = [hm.new_state() for _ in range(nseq)]
+    got = [[] for _ in range(nseq)]
+    for i in (2, 0, 1):
+        hm.bind(states[i])
+        got[i].append(hm.prefill(prompts[i]))
+    for _ in range(steps):
+        for i in (1, 2, 0):
+            hm.bind(states[i])
+            got[i].append(int(hm.decode(1)[0][0]))
+    assert got == want, f"interleaved states\noracle {want}\nhip    {got}"
+    assert [st.context_length for st in states] == [count + steps] * nseq
+    # (2) batched prefill into fresh states, then chained decode per state (each state owns its graphs)
+    for st in states:
+        st.reset()
+    first = hm.prefill_batch(states, prompts)
+    got2 = [[int(first[i])] for i in range(nseq)]
+    for i in range(nseq):
+        hm.bind(states[i])
+        got2[i] += [int(t) for t in hm.decode(steps)[0]]
+    assert got2 == want, f"batched prefill\noracle {want}\nhip    {got2}"
+    # the model's own state is untouched by all of this
+    hm.bind(None)
+    assert hm.context_length == 0
+    assert hm.prefill(prompts[0]) == want[0][0]
+    for st in states:
+        st.close()
+    hm.close()

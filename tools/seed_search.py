@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--sigma", type=float, nargs="+", default=[0.6])
     ap.add_argument("--seeds", type=int, nargs="+", default=[42])
     ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--quiet", action="store_true", help="print only seeds with >= --min-distinct tokens and every top-2 gap >= --min-gap")
+    ap.add_argument("--min-distinct", type=int, default=12)
+    ap.add_argument("--min-gap", type=float, default=0.4)
     args = ap.parse_args()
     from helpers import f32
     from uzu_amd import synthetic as S
@@ -53,8 +56,10 @@ def main():
                 toks.append(int(t[0]))
                 gaps.append(gap())
             hm.close()
-            print(f"{args.model} sigma {sigma} seed {seed}: distinct {len(set(toks))}/{len(toks)} min gap {min(gaps):.3f} median gap {np.median(gaps):.3f} "
-                  f"({time.time() - t0:.0f} s)\n   tokens {toks}\n   gaps {[round(g, 3) for g in gaps]}", flush=True)
+            good = len(set(toks)) >= args.min_distinct and min(gaps) >= args.min_gap
+            if good or not args.quiet:
+                print(f"{args.model} sigma {sigma} seed {seed}: distinct {len(set(toks))}/{len(toks)} min gap {min(gaps):.3f} median gap {np.median(gaps):.3f} "
+                      f"({time.time() - t0:.0f} s)" + (f"\n   tokens {toks}\n   gaps {[round(g, 3) for g in gaps]}" if good or not args.quiet else ""), flush=True)
     ctx.close()
 
 

@@ -17,6 +17,7 @@ import sys
 
 import numpy as np
 
+SLOTS = 8  # UZU_TL_SLOTS (kernels_decode.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -38,41 +39,48 @@ def main():
     hm = HipModel(ctx, bundle)
     hm.prefill(S.synthetic_prompt(args.context - 8, cfg.vocab_size))
     max_launches = 256
-    buf = ctx.create_buffer(max_launches * 4096 * 8)
-    buf.upload(np.zeros(max_launches * 4096, dtype=np.uint64))
+    buf = ctx.create_buffer(max_launches * 1024 * SLOTS * 8)
+    buf.upload(np.zeros(max_launches * 1024 * SLOTS, dtype=np.uint64))
     lib.uzu_hip_debug_set_timeline.argtypes = [C.c_void_p, C.c_uint32]
     lib.uzu_hip_debug_set_timeline.restype = None
     lib.uzu_hip_debug_set_timeline(C.c_void_p(buf.gpu_ptr()), C.c_uint32(max_launches))
     hm.decode(8)  # first call captures the graph (the stamp slots are baked into it); the last replay's stamps remain
     ctx.synchronize()
-    t = buf.download(np.uint64).reshape(max_launches, 1024, 4).astype(np.int64)
-    labels = hm.profile_labels() if hasattr(hm, "profile_labels") else None
+    t = buf.download(np.uint64).reshape(max_launches, 1024, SLOTS).astype(np.int64)
     prev_end = None
     print(f"# {cfg.name} ctx {hm.context_length}; times in us (10 ns clock); only gemv_dec / delta_dec / attn_dec launches are stamped")
-    print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'pro':>6} {'body':>6} {'tail':>6} {'span':>6}  p90(exit-entry)")
+    print("# gap = first entry - previous launch's last exit; ramp = last entry - first entry; the other columns are medians over the workgroups:")
+    print("# x = entry -> activation vector consumed; pro = entry -> prologue done; dots = prologue done -> last batch's dot products done;")
+    print("# fin = reduction + epilogue of the last batch; span = first entry -> last exit")
+    print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'x':>6} {'pro':>6} {'dots':>6} {'fin':>6} {'exit':>6} {'span':>6}")
     tot = dict(gap=0.0, span=0.0)
     first = None
+
+    def med(a):
+        return float(np.median(a)) * 0.01
+
     for i in range(max_launches):
         live = t[i][:, 0] > 0
         if not live.any():
             continue
         e = t[i][live]
-        t0, t3 = e[:, 0], e[:, 3]
-        has12 = (e[:, 1] > 0).all() and (e[:, 2] > 0).all()
+        t0, t_end = e[:, 0], e[:, 4]
         if first is None:
             first = t0.min()
         gap = (t0.min() - prev_end) * 0.01 if prev_end is not None else float("nan")
         ramp = (t0.max() - t0.min()) * 0.01
-        pro = np.median(e[:, 1] - t0) * 0.01 if has12 else float("nan")
-        body = np.median(e[:, 2] - e[:, 1]) * 0.01 if has12 else float("nan")
-        tail = np.median(t3 - e[:, 2]) * 0.01 if has12 else float("nan")
-        span = (t3.max() - t0.min()) * 0.01
-        p90 = np.percentile(t3 - t0, 90) * 0.01
-        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {pro:6.2f} {body:6.2f} {tail:6.2f} {span:6.2f}  {p90:6.2f}")
+        nan = float("nan")
+        x = med(e[:, 1] - t0) if (e[:, 1] > 0).all() else nan
+        pro = med(e[:, 2] - t0) if (e[:, 2] > 0).all() else nan
+        dots = med(e[:, 5] - e[:, 2]) if (e[:, 5] > 0).all() and (e[:, 2] > 0).all() else nan
+        fin = med(e[:, 6] - e[:, 5]) if (e[:, 6] > 0).all() and (e[:, 5] > 0).all() else nan
+        ex = med(t_end - t0)
+        span = (t_end.max() - t0.min()) * 0.01
+        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f}")
         if gap == gap:
             tot["gap"] += gap
         tot["span"] += span
-        prev_end = t3.max()
+        prev_end = t_end.max()
     print(f"# stamped launches: sum of spans {tot['span']:.1f} us, sum of gaps {tot['gap']:.1f} us (gaps include the un-stamped kernels: attn_merge, commit, embedding), "
           f"first entry -> last exit {(prev_end - first) * 0.01:.1f} us")
 

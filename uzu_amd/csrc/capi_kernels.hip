@@ -440,31 +440,65 @@ uzu_status uzu_hip_tensor_copy_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu
     return k::tensor_copy(cb_stream(cb), bptr(src), bptr(dst), k->t[0], length);
 }
 
-// ------------------------------------------------------------------------------------- UnifiedSampling (greedy)
+// ------------------------------------------------------------------------------------- UnifiedSampling
+// unified_sampling.rs:13-32: every specialisation.  Transient arg-max partials live in a kernel-owned grow-only block that is
+// allocated at creation (64 rows) and regrown at encode time OUTSIDE stream capture only: the stream-ordered pool is not
+// trusted on this ROCm build (runtime.hip) and a captured graph must not reference a block that may be regrown.
+static uzu_status sampling_scratch(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uint32_t batch_size, void** out) {
+    const size_t need = k::unified_sampling_scratch_bytes(batch_size) > k::argmax_scratch_bytes(batch_size) ? k::unified_sampling_scratch_bytes(batch_size)
+                                                                                                         : k::argmax_scratch_bytes(batch_size);
+    if (need > k->scratch_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(cb_stream(cb), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            set_error("unified_sampling: batch_size %u needs a larger scratch block than the kernel owns; encode once outside a graph-captured "
+                      "command buffer first (the block cannot grow during capture)", batch_size);
+            return UZU_ERR_UNSUPPORTED;
+        }
+        UZU_HIP_TRY(hipStreamSynchronize(cb_stream(cb))); // earlier encodes on this stream may still use the old block
+        if (k->scratch) (void)hipFree(k->scratch);
+        k->scratch = nullptr, k->scratch_bytes = 0;
+        UZU_HIP_TRY(hipMalloc(&k->scratch, need));
+        k->scratch_bytes = need;
+    }
+    *out = k->scratch;
+    return UZU_OK;
+}
 uzu_status uzu_hip_unified_sampling_create(uzu_hip_context* ctx, uint32_t t, uint32_t is_stochastic, uint32_t has_bitmask, uint32_t has_temperature,
                                            uint32_t has_top_k, uint32_t has_top_p, uint32_t has_min_p, uzu_hip_kernel** out) {
     REQ_DT(t, "unified_sampling");
-    UZU_UNSUPPORTED(is_stochastic || has_bitmask || has_temperature || has_top_k || has_top_p || has_min_p,
-                    "unified_sampling: only greedy (argmax) sampling is implemented on the hip path");
     uzu_hip_kernel* k;
     UZU_PROPAGATE(make_kernel(ctx, KK_UNIFIED_SAMPLING, out, &k));
     k->t[0] = t;
+    k->f[0] = is_stochastic, k->f[1] = has_bitmask, k->f[2] = has_temperature, k->f[3] = has_top_k, k->f[4] = has_top_p, k->f[5] = has_min_p;
+    const size_t bytes = k::unified_sampling_scratch_bytes(64);
+    if (hipMalloc(&k->scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        uzu_hip_kernel_destroy(k);
+        *out = nullptr;
+        set_error("unified_sampling: cannot allocate %zu bytes of scratch", bytes);
+        return UZU_ERR_OUT_OF_MEMORY;
+    }
+    k->scratch_bytes = bytes;
     return UZU_OK;
 }
 uzu_status uzu_hip_unified_sampling_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf logits, uzu_buf output, uzu_buf seeds, uzu_buf bitmask,
                                            float temperature, uint32_t top_k, float top_p, float min_p, uint32_t vocab_size, uint32_t batch_size) {
     UZU_PROPAGATE(check(k, KK_UNIFIED_SAMPLING, cb));
-    UZU_REQUIRE(logits.buffer && output.buffer && !seeds.buffer && !bitmask.buffer, "unified_sampling: greedy kernel takes logits and output only");
-    (void)temperature, (void)top_k, (void)top_p, (void)min_p;
-    // scratch for the two-level reduction: the stream's workspace block; inside a graph-captured command buffer
-    // (UZU_CMDBUF_GRAPH) the allocation becomes a pair of graph memory nodes instead
-    if (void* scratch = k::stream_workspace(cb_stream(cb), k::argmax_scratch_bytes(batch_size)))
-        return k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    UZU_REQUIRE(logits.buffer && output.buffer, "unified_sampling: null logits / output");
+    UZU_REQUIRE((seeds.buffer != nullptr) == (k->f[0] != 0), "unified_sampling: seeds presence must equal is_stochastic");
+    UZU_REQUIRE((bitmask.buffer != nullptr) == (k->f[1] != 0), "unified_sampling: bitmask presence must equal has_bitmask");
+    UZU_REQUIRE(!k->f[2] || temperature > 0.0f, "unified_sampling: temperature must be positive");
     void* scratch = nullptr;
-    UZU_HIP_TRY(hipMallocAsync(&scratch, k::argmax_scratch_bytes(batch_size), cb_stream(cb)));
-    uzu_status st = k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
-    UZU_HIP_TRY(hipFreeAsync(scratch, cb_stream(cb)));
-    return st;
+    UZU_PROPAGATE(sampling_scratch(k, cb, batch_size, &scratch));
+    const bool plain_greedy = !k->f[0] && !k->f[1] && !k->f[2] && !k->f[3] && !k->f[4] && !k->f[5];
+    if (plain_greedy) return k::argmax(cb_stream(cb), bptr(logits), k->t[0], (uint32_t*)bptr(output), vocab_size, batch_size, scratch);
+    k::UnifiedSamplingParams p{};
+    p.logits = bptr(logits), p.dt = k->t[0], p.output = (uint32_t*)bptr(output);
+    p.seeds = (const uint64_t*)bptr(seeds), p.bitmask = (const uint32_t*)bptr(bitmask);
+    p.has_temperature = k->f[2], p.has_top_k = k->f[3], p.has_top_p = k->f[4], p.has_min_p = k->f[5];
+    p.temperature = temperature, p.top_k = top_k, p.top_p = top_p, p.min_p = min_p;
+    p.vocab_size = vocab_size, p.batch_size = batch_size;
+    return k::unified_sampling(cb_stream(cb), p, scratch);
 }
 
 // ------------------------------------------------------------------------------------- Gated DeltaNet

@@ -58,8 +58,28 @@ struct DLayer {
 
 } // namespace
 
+// LanguageModelState (engine/language_model/state.rs:9-16): everything that belongs to ONE sequence -- KV caches,
+// DeltaNet conv / SSM states, the device-resident decode control block and the captured decode graphs (their nodes
+// carry this state's pointers).  Weights and scratch stay in the model; a model works on its currently BOUND state,
+// whose pointers are mirrored in the DLayer / model fields the encoders read (bind_state).
+struct uzu_hip_state {
+    uzu_hip_model* m = nullptr;
+    struct Layer {
+        uint16_t *keys = nullptr, *values = nullptr;
+        float *conv_state = nullptr, *ssm_state = nullptr;
+    };
+    std::vector<Layer> layers;
+    uint32_t *d_ctx_len = nullptr, *d_tokens = nullptr, *d_out_token = nullptr, *d_sampled = nullptr;
+    uint32_t context_length = 0;
+    hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
+    std::vector<void*> allocations;
+    size_t bytes = 0;
+};
+
 struct uzu_hip_model {
     uzu_hip_context* ctx = nullptr;
+    uzu_hip_state* state0 = nullptr; // the model's own sequence state (uzu_hip_model_create); owned
+    uzu_hip_state* bound = nullptr;  // state whose pointers the fields below currently mirror
     uint32_t flags = 0;
     uzu_model_desc d; // scalars only
     std::vector<DLayer> layers;
@@ -77,6 +97,8 @@ struct uzu_hip_model {
     uint32_t* d_sampled = nullptr;  // [max positions] token sampled from the row at absolute position p
     uint32_t context_length = 0;    // host mirror of *d_ctx_len
     uint32_t max_positions = 0;
+    uint32_t max_seqs = 1;          // sequences one batched prefill pass may carry (UZU_MODEL_BATCH(n) at creation)
+    uint32_t* batch_tokens = nullptr; // [max_seqs * 1024] token ids of a batched pass
 
     // scratch (sized for one 1024-token chunk)
     uint16_t *hidden = nullptr, *normed = nullptr, *mixed = nullptr, *shortcut = nullptr;
@@ -145,6 +167,87 @@ void dev_free(uzu_hip_model* m, void* p) {
             m->allocation_bytes.erase(m->allocation_bytes.begin() + i);
             return;
         }
+}
+
+uzu_status state_alloc(uzu_hip_state* st, size_t bytes, void** out) {
+    void* p = nullptr;
+    const size_t alloc = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+    hipError_t e = hipMalloc(&p, alloc);
+    if (e != hipSuccess) {
+        set_error("state: hipMalloc(%zu) failed: %s", alloc, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
+    }
+    st->allocations.push_back(p);
+    st->bytes += alloc;
+    uzu_hip_context* ctx = st->m->ctx;
+    ctx->current_bytes += alloc;
+    if (ctx->current_bytes > ctx->peak_bytes) ctx->peak_bytes = ctx->current_bytes;
+    HIPCHK(hipMemset(p, 0, alloc));
+    *out = p;
+    return UZU_OK;
+}
+
+void state_free(uzu_hip_state* st) {
+    if (!st) return;
+    if (st->graph_single) (void)hipGraphExecDestroy(st->graph_single);
+    if (st->graph_two) (void)hipGraphExecDestroy(st->graph_two);
+    for (void* p : st->allocations) (void)hipFree(p);
+    uzu_hip_context* ctx = st->m->ctx;
+    ctx->current_bytes -= st->bytes < ctx->current_bytes ? st->bytes : ctx->current_bytes;
+    delete st;
+}
+
+// KV caches for max_context_length + 1024 rows (mixer/attention/state.rs:14), DeltaNet conv / SSM states, control block
+uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
+    auto* st = new uzu_hip_state();
+    st->m = m;
+    st->layers.resize(m->layers.size());
+    uzu_status r = UZU_OK;
+    auto need = [&](size_t bytes, void** p) {
+        if (r == UZU_OK) r = state_alloc(st, bytes, p);
+    };
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+        const uzu_layer_desc& h = m->layers[l].d;
+        void* p = nullptr;
+        if (h.mixer_kind == UZU_MIXER_ATTENTION) {
+            const size_t kv_bytes = (size_t)m->max_positions * h.num_groups * h.head_dim * 2;
+            need(kv_bytes, &p), st->layers[l].keys = (uint16_t*)p;
+            need(kv_bytes, &p), st->layers[l].values = (uint16_t*)p;
+        } else {
+            need(m->layers[l].conv_state_bytes, &p), st->layers[l].conv_state = (float*)p;
+            need(m->layers[l].ssm_state_bytes, &p), st->layers[l].ssm_state = (float*)p;
+        }
+    }
+    void* p = nullptr;
+    need(4, &p), st->d_ctx_len = (uint32_t*)p;
+    need((size_t)kSuffixCapacity * 4, &p), st->d_tokens = (uint32_t*)p;
+    need(4, &p), st->d_out_token = (uint32_t*)p;
+    need((size_t)m->max_positions * 4, &p), st->d_sampled = (uint32_t*)p;
+    if (r != UZU_OK) {
+        state_free(st);
+        return r;
+    }
+    *out = st;
+    return UZU_OK;
+}
+
+// Make `st` the state the encoders work on: its pointers go into the DLayer / model fields, the host-side mirrors
+// (context length, graphs) of the previously bound state are written back first.
+void bind_state(uzu_hip_model* m, uzu_hip_state* st) {
+    if (m->bound == st) return;
+    if (m->bound) {
+        m->bound->context_length = m->context_length;
+        m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two;
+    }
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+        m->layers[l].keys = st->layers[l].keys, m->layers[l].values = st->layers[l].values;
+        m->layers[l].conv_state = st->layers[l].conv_state, m->layers[l].ssm_state = st->layers[l].ssm_state;
+    }
+    m->d_ctx_len = st->d_ctx_len, m->d_tokens = st->d_tokens, m->d_out_token = st->d_out_token, m->d_sampled = st->d_sampled;
+    m->context_length = st->context_length;
+    m->graph_single = st->graph_single, m->graph_two = st->graph_two;
+    m->hidden_ready = false; // row 0 of the scratch `hidden` belongs to whoever ran last
+    m->bound = st;
 }
 
 template <class T> uzu_status upload(uzu_hip_model* m, const void* host, size_t bytes, T** out) {
@@ -309,20 +412,54 @@ uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
     return UZU_OK;
 }
 
-void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, uint32_t batch) {
+// The sequences of one forward pass.  n == 0: the bound state, `count` rows (the plain single-sequence pass).  n >= 1:
+// `count` rows per sequence, sequence q in rows [q * count, (q + 1) * count) of every activation buffer: the linear
+// layers, norms and element-wise kernels run once over all n * count rows (one GEMM with M = n * count: the weights are
+// streamed once for all sequences), attention / KV append / DeltaNet run per sequence on its own state.  The reference
+// has no cross-sequence batching: per sequence the arithmetic is that of the single-sequence pass.
+struct Seqs {
+    uzu_hip_state** st = nullptr;
+    uint32_t n = 0;
+    uint32_t count = 0;
+    uint32_t rows() const { return (n ? n : 1) * count; }
+};
+
+void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
+
+void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q) {
     uzu_hip_model* m = e.m;
     const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
-    if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, batch);
-    linear(e, L.qkv, hidden, m->qkv, batch);
+    const uint32_t rows = q.rows();
+    if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, rows);
+    linear(e, L.qkv, hidden, m->qkv, rows);
     if (L.qn.present)
-        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, batch, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
+        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, rows, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
     if (L.kn.present)
-        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.kn.scales, batch, total_heads, hd, L.kn.eps, L.kn.offset, nq, nkv, L.kn.full_layer));
+        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.kn.scales, rows, total_heads, hd, L.kn.eps, L.kn.offset, nq, nkv, L.kn.full_layer));
+    if (q.n == 0) {
+        attention_core(e, L, q.count, 0);
+    } else {
+        for (uint32_t i = 0; i < q.n; ++i) {
+            bind_state(m, q.st[i]);
+            attention_core(e, L, q.count, (size_t)i * q.count);
+        }
+    }
+    if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, rows * nq * hd));
+    linear(e, L.out, m->attn_out, out, rows, true);
+}
+
+// AttentionPrepare + attention of `batch` rows of the bound sequence, which start at row `row0` of qkv / queries / attn_out
+void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
+    uzu_hip_model* m = e.m;
+    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
+    const uint16_t* qkv = m->qkv + row0 * total_heads * hd;
+    uint16_t* queries = m->queries + row0 * nq * hd;
+    uint16_t* attn_out = m->attn_out + row0 * nq * hd;
     const uint32_t rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
-    RUN("attention_prepare", 0, k::attention_prepare(e.s, m->qkv, m->queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, 0, batch, 1,
+    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, 0, batch, 1,
                                m->d_ctx_len));
     k::AttentionParams a{};
-    a.queries = m->queries, a.keys = L.keys, a.values = L.values;
+    a.queries = queries, a.keys = L.keys, a.values = L.values;
     a.dt = UZU_BF16, a.head_dim = hd, a.gqa_factor = nq / nkv;
     a.sequence_length = batch; // + *d_ctx_len on the device
     a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;
@@ -332,44 +469,60 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, u
     const size_t kv_bytes = (size_t)2 * (m->context_length + batch) * nkv * hd * 2; // K and V rows read once
     const bool two_pass = m->regime_override >= 0 ? m->regime_override == 1 : m->context_length + batch > 1024;
     if (k::attention_prefill_mfma_supported(a)) { // prefill chunk: flash-attention tiles on the matrix cores, any context length
-        RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, m->attn_out));
+        RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, attn_out));
     } else if (two_pass) { // core/mod.rs:89-92
         RUN("attention_two_pass1", kv_bytes, k::attention_two_pass1(e.s, a, m->partials, m->sums, m->maxs));
-        RUN("attention_two_pass2", 0, k::attention_two_pass2(e.s, m->partials, m->sums, m->maxs, m->attn_out, UZU_BF16, hd, nq, batch));
+        RUN("attention_two_pass2", 0, k::attention_two_pass2(e.s, m->partials, m->sums, m->maxs, attn_out, UZU_BF16, hd, nq, batch));
     } else {
-        RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, m->attn_out));
+        RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, attn_out));
     }
-    if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, batch * nq * hd));
-    linear(e, L.out, m->attn_out, out, batch, true);
 }
 
-void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, uint32_t batch) {
+void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
+
+void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q) {
+    uzu_hip_model* m = e.m;
+    const uint32_t rows = q.rows();
+    linear(e, L.in_proj, hidden, m->in_proj, rows);
+    if (q.n == 0) {
+        delta_net_core(e, L, q.count, 0);
+    } else {
+        for (uint32_t i = 0; i < q.n; ++i) {
+            bind_state(m, q.st[i]);
+            delta_net_core(e, L, q.count, (size_t)i * q.count);
+        }
+    }
+    linear(e, L.out_proj, m->delta_out, out, rows, true);
+}
+
+// conv + delta rule + norm-gate over `batch` rows of the bound sequence, starting at row `row0` of in_proj / delta_out
+void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     uzu_hip_model* m = e.m;
     const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
     const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
     const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv, ks = L.d.dn_kernel_size;
-    linear(e, L.in_proj, hidden, m->in_proj, batch);
+    uint16_t* in_proj = m->in_proj + row0 * total_proj_dim;
+    uint16_t* delta_out = m->delta_out + row0 * value_dim;
     if (batch == 1) {
-        RUN("delta_net_conv_update", 0, k::delta_net_conv_update(e.s, L.conv_w, L.conv_b, m->in_proj, L.conv_state, ks, conv_dim, ks - 1));
-        RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, m->in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
+        RUN("delta_net_conv_update", 0, k::delta_net_conv_update(e.s, L.conv_w, L.conv_b, in_proj, L.conv_state, ks, conv_dim, ks - 1));
+        RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
                                   L.d.dn_norm_epsilon));
     } else {
         if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(kSuffixCapacity + 8) * total_proj_dim) {
-            RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, m->in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
+            RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
         } else {
-            RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, m->in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
-            RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, m->in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
+            RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
+            RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
                                          total_proj_dim));
         }
-        RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, m->in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
+        RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
         if (m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch))
-            RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, m->dn_ws, Hv, Hk, Dv,
+            RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, in_proj, L.ssm_state, delta_out, m->dn_ws, Hv, Hk, Dv,
                                                                           key_dim, value_dim, batch));
         else
-            RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, m->in_proj, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
-        RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
+            RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, in_proj, L.ssm_state, delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
+        RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, delta_out, in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
     }
-    linear(e, L.out_proj, m->delta_out, out, batch, true);
 }
 
 __global__ void commit_kernel(uint32_t* ctx_len, uint32_t* tokens, const uint32_t* out_token, uint32_t* sampled, uint32_t count, uint32_t has_token) {
@@ -382,67 +535,76 @@ __global__ void commit_kernel(uint32_t* ctx_len, uint32_t* tokens, const uint32_
     *ctx_len = len + count;
 }
 
-// One forward pass over `count` tokens already in m->d_tokens; `sample` => output norm + readout + argmax.
-uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool sample) {
+// One forward pass.  `seqs` null: `count` tokens of the bound state, already in m->d_tokens.  `seqs` non-null: `count`
+// tokens for each of the `nseq` states, token ids already in m->batch_tokens (row q * count + i); see struct Seqs.
+// `sample` => output norm + readout + argmax on the last row (of every sequence).
+uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool sample, uzu_hip_state** seqs = nullptr, uint32_t nseq = 0) {
     Enc e{m, s};
     e.prof = (std::vector<ProfEntry>*)m->prof_sink;
     m->launches = 0;
     const uint32_t d = m->d.model_dim;
+    Seqs q;
+    q.st = seqs, q.n = seqs ? nseq : 0, q.count = count;
+    const uint32_t rows = q.rows();
+    const uint32_t* token_ids = seqs ? m->batch_tokens : m->d_tokens;
     uint16_t* hidden = m->hidden;
     if (m->embedding.method == UZU_QUANT_NONE)
-        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, m->d_tokens, m->embedding.w, hidden, UZU_BF16, count, m->d.vocab_size, d, m->d.input_scale));
+        RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, token_ids, m->embedding.w, hidden, UZU_BF16, rows, m->d.vocab_size, d, m->d.input_scale));
     else
-        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, m->d_tokens, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
-                                            hidden, UZU_BF16, count, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits,
+        RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, token_ids, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
+                                            hidden, UZU_BF16, rows, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits,
                                             m->embedding.method));
     for (uint32_t l = 0; l < m->d.num_layers; ++l) {
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
         if (L.pre_mixer.present) {
-            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, count, d);
+            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d);
             h = m->normed;
         } else {
-            RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, count * d));
+            RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, rows * d));
         }
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
-            attention_mixer(e, L, h, m->mixed, count);
+            attention_mixer(e, L, h, m->mixed, q);
         else
-            delta_net_mixer(e, L, h, m->mixed, count);
+            delta_net_mixer(e, L, h, m->mixed, q);
         const uint16_t* mixed = m->mixed;
         if (L.post_mixer.present) {
-            norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, count, d);
-            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, count * d));
+            norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, rows, d);
+            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, rows * d));
         }
-        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, count, d);
-        linear(e, L.up, m->normed, m->up, count);
-        RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, count, 0, 0, L.d.activation, 1));
-        linear(e, L.down, m->gated, hidden, count, true);
+        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d);
+        linear(e, L.up, m->normed, m->up, rows);
+        RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
+        linear(e, L.down, m->gated, hidden, rows, true);
         if (L.post_mlp.present) {
-            norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, count, d);
-            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, count * d));
+            norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, rows, d);
+            RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, rows * d));
         }
-        if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, count * d));
+        if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, count * d));
     }
     m->tap_rows = count;
-    if (sample) {
-        const size_t last = (size_t)(count - 1) * d;
-        norm(e, m->output_norm, hidden + last, m->last_normed, m->shortcut + last, 2, 1, d);
-        const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
-        linear(e, ro, m->last_normed, m->logits, 1);
-        if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
-            RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, ro.n, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
-        RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
-        if (m->tp) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
-            RUN("tp_key", 0, tp::key_from_token(s, m->logits, m->d_out_token, m->vocab_offset, m->tp_key));
-            RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
-            RUN("tp_token", 0, tp::token_from_key(s, m->tp_key, m->d_out_token));
+    for (uint32_t i = 0; i < (seqs ? nseq : 1u); ++i) { // per sequence: sample from its last row, then commit
+        if (seqs) bind_state(m, seqs[i]);
+        if (sample) {
+            const size_t last = ((size_t)i * count + count - 1) * d;
+            norm(e, m->output_norm, hidden + last, m->last_normed, m->shortcut + last, 2, 1, d);
+            const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+            linear(e, ro, m->last_normed, m->logits, 1);
+            if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
+                RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, ro.n, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
+            RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
+            if (m->tp) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
+                RUN("tp_key", 0, tp::key_from_token(s, m->logits, m->d_out_token, m->vocab_offset, m->tp_key));
+                RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
+                RUN("tp_token", 0, tp::token_from_key(s, m->tp_key, m->d_out_token));
+            }
         }
+        // an earlier launch failed: leave the device-side context length / next token untouched so that they keep agreeing
+        // with the host mirror (m->context_length is only advanced by the callers on success)
+        if (e.st != UZU_OK) return e.st;
+        hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1), 0, s, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, count, sample ? 1u : 0u);
+        ++m->launches;
     }
-    // an earlier launch failed: leave the device-side context length / next token untouched so that they keep agreeing
-    // with the host mirror (m->context_length is only advanced by the callers on success)
-    if (e.st != UZU_OK) return e.st;
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1), 0, s, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, count, sample ? 1u : 0u);
-    ++m->launches;
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("engine: forward launch failed: %s", hipGetErrorString(err));
@@ -758,12 +920,6 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             TRY(upload_linear(m, h.out_projection, &L.out));
             TRY(upload_norm(m, h.query_norm, h.head_dim, &L.qn));
             TRY(upload_norm(m, h.key_norm, h.head_dim, &L.kn));
-            const size_t kv_bytes = (size_t)m->max_positions * h.num_groups * h.head_dim * 2;
-            void* p;
-            TRY(dev_alloc(m, kv_bytes, &p, true));
-            L.keys = (uint16_t*)p;
-            TRY(dev_alloc(m, kv_bytes, &p, true));
-            L.values = (uint16_t*)p;
             const uint32_t qdim = h.num_heads * h.head_dim;
             max_qkv = max_qkv > h.qkv_projection.n ? max_qkv : h.qkv_projection.n;
             max_qdim = max_qdim > qdim ? max_qdim : qdim;
@@ -781,11 +937,6 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             TRY(upload(m, h.dn_norm_scales, (size_t)h.dn_value_head_dim * 4, &L.dn_norm));
             L.conv_state_bytes = (size_t)conv_dim * (h.dn_kernel_size - 1) * 4;
             L.ssm_state_bytes = (size_t)h.dn_num_heads * h.dn_value_head_dim * h.dn_head_dim * 4;
-            void* p;
-            TRY(dev_alloc(m, L.conv_state_bytes, &p, true));
-            L.conv_state = (float*)p;
-            TRY(dev_alloc(m, L.ssm_state_bytes, &p, true));
-            L.ssm_state = (float*)p;
             const uint32_t proj = conv_dim + value_dim + 2 * h.dn_num_heads;
             max_proj = max_proj > proj ? max_proj : proj;
             max_value = max_value > value_dim ? max_value : value_dim;
@@ -804,26 +955,27 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     void* p;
     const size_t C = kSuffixCapacity;
 #define ALLOC(field, type, elems) do { TRY(dev_alloc(m, (size_t)(elems) * sizeof(type), &p, true)); m->field = (type*)p; } while (0)
-    ALLOC(d_ctx_len, uint32_t, 1);
-    ALLOC(d_tokens, uint32_t, C);
-    ALLOC(d_out_token, uint32_t, 1);
-    ALLOC(d_sampled, uint32_t, m->max_positions);
-    ALLOC(hidden, uint16_t, C * d);
-    ALLOC(normed, uint16_t, C * d);
-    ALLOC(mixed, uint16_t, C * d);
-    ALLOC(shortcut, uint16_t, C * d);
+    TRY(state_build(m, &m->state0));
+    bind_state(m, m->state0);
+    m->max_seqs = (flags >> 8) & 0xFFu ? (flags >> 8) & 0xFFu : 1u;
+    const size_t CB = C * m->max_seqs; // rows of a batched pass: row-major activation buffers are sized for it
+    ALLOC(batch_tokens, uint32_t, CB);
+    ALLOC(hidden, uint16_t, CB * d);
+    ALLOC(normed, uint16_t, CB * d);
+    ALLOC(mixed, uint16_t, CB * d);
+    ALLOC(shortcut, uint16_t, CB * d);
     if (max_qkv) {
-        ALLOC(qkv, uint16_t, C * max_qkv);
-        ALLOC(gate, uint16_t, C * max_qdim);
-        ALLOC(queries, uint16_t, C * max_qdim);
-        ALLOC(attn_out, uint16_t, C * max_qdim);
+        ALLOC(qkv, uint16_t, CB * max_qkv);
+        ALLOC(gate, uint16_t, CB * max_qdim);
+        ALLOC(queries, uint16_t, CB * max_qdim);
+        ALLOC(attn_out, uint16_t, CB * max_qdim);
         TRY(ensure_partials(m, max_heads, max_hd)); // decode rows; prefill grows it on demand
     }
-    ALLOC(up, uint16_t, C * 2 * max_hidden);
-    ALLOC(gated, uint16_t, C * max_hidden);
+    ALLOC(up, uint16_t, CB * 2 * max_hidden);
+    ALLOC(gated, uint16_t, CB * max_hidden);
     if (max_proj) {
-        ALLOC(in_proj, uint16_t, C * max_proj);
-        ALLOC(delta_out, uint16_t, C * max_value);
+        ALLOC(in_proj, uint16_t, CB * max_proj);
+        ALLOC(delta_out, uint16_t, CB * max_value);
         ALLOC(dn_ws, float, k::delta_net_chunk_workspace_bytes(max_hv, (uint32_t)C) / sizeof(float));
         ALLOC(dn_o, float, max_value);
         ALLOC(dn_sz, float, max_value);
@@ -858,7 +1010,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     ALLOC(last_normed, uint16_t, d);
     ALLOC(logits, uint16_t, desc->vocab_size);
     if (m->tp) {
-        ALLOC(tp_buf, float, C * d);
+        ALLOC(tp_buf, float, CB * d);
         ALLOC(tp_key, unsigned long long, 1);
     }
     TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
@@ -878,8 +1030,8 @@ void uzu_hip_model_destroy(uzu_hip_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    if (m->graph_single) (void)hipGraphExecDestroy(m->graph_single);
-    if (m->graph_two) (void)hipGraphExecDestroy(m->graph_two);
+    if (m->bound) m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two;
+    state_free(m->state0); // (states created with uzu_hip_state_create belong to the caller and must be destroyed first)
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (void* p : m->allocations) (void)hipFree(p);
@@ -898,6 +1050,84 @@ uzu_status uzu_hip_model_reset(uzu_hip_model* m) {
     HIPCHK(hipStreamSynchronize(s));
     m->context_length = 0;
     m->hidden_ready = false;
+    return UZU_OK;
+}
+
+// ---- sequence states (LanguageModelState, engine/language_model/state.rs:9-16) ----
+uzu_status uzu_hip_state_create(uzu_hip_model* m, uzu_hip_state** out) {
+    UZU_REQUIRE(m && out, "state_create: null argument");
+    (void)hipSetDevice(m->ctx->device);
+    return state_build(m, out);
+}
+void uzu_hip_state_destroy(uzu_hip_state* st) {
+    if (!st) return;
+    uzu_hip_model* m = st->m;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->bound == st) { // hand the model back to its own state first
+        st->graph_single = m->graph_single, st->graph_two = m->graph_two;
+        m->bound = nullptr;
+        bind_state(m, m->state0);
+    }
+    if (st != m->state0) state_free(st);
+}
+uzu_status uzu_hip_model_bind_state(uzu_hip_model* m, uzu_hip_state* st) {
+    UZU_REQUIRE(m, "model_bind_state: null model");
+    UZU_REQUIRE(!st || st->m == m, "model_bind_state: the state belongs to another model");
+    bind_state(m, st ? st : m->state0);
+    return UZU_OK;
+}
+uzu_status uzu_hip_state_reset(uzu_hip_state* st) {
+    UZU_REQUIRE(st, "state_reset: null state");
+    uzu_hip_model* m = st->m;
+    uzu_hip_state* prev = m->bound;
+    bind_state(m, st);
+    const uzu_status r = uzu_hip_model_reset(m);
+    bind_state(m, prev);
+    return r;
+}
+uint32_t uzu_hip_state_context_length(const uzu_hip_state* st) {
+    if (!st) return 0;
+    return st->m->bound == st ? st->m->context_length : st->context_length;
+}
+
+// LanguageModelStream::new for `nseq` independent sequences at once: `count` prompt tokens each (token_ids row-major
+// [nseq, count]), chunks of <= 1024 tokens per sequence, every chunk pass carrying all sequences (struct Seqs).
+uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states, uint32_t nseq, const uint32_t* token_ids, uint32_t count,
+                                       uint32_t* first_tokens) {
+    UZU_REQUIRE(m && states && token_ids && nseq > 0 && count > 0, "model_prefill_batch: null / empty input");
+    UZU_REQUIRE(nseq <= m->max_seqs, "model_prefill_batch: %u sequences, model created for at most %u (UZU_MODEL_BATCH)", nseq, m->max_seqs);
+    for (uint32_t i = 0; i < nseq; ++i) {
+        UZU_REQUIRE(states[i] && states[i]->m == m, "model_prefill_batch: state %u is null or belongs to another model", i);
+        for (uint32_t j = 0; j < i; ++j) UZU_REQUIRE(states[i] != states[j], "model_prefill_batch: state %u listed twice", i);
+        UZU_REQUIRE(uzu_hip_state_context_length(states[i]) + count <= m->d.max_context_length, "model_prefill_batch: sequence %u exceeds max_context_length", i);
+    }
+    hipStream_t s = m->ctx->stream;
+    uzu_hip_state* prev = m->bound;
+    m->hidden_ready = false;
+    uint32_t max_heads = 0, max_hd = 0;
+    for (auto& L : m->layers)
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+            max_heads = max_heads > L.d.num_heads ? max_heads : L.d.num_heads;
+            max_hd = max_hd > L.d.head_dim ? max_hd : L.d.head_dim;
+        }
+    std::vector<uint32_t> staging((size_t)nseq * kSuffixCapacity);
+    for (uint32_t start = 0; start < count; start += kSuffixCapacity) {
+        const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
+        const bool last = start + n == count;
+        for (uint32_t i = 0; i < nseq; ++i) memcpy(&staging[(size_t)i * n], token_ids + (size_t)i * count + start, (size_t)n * 4);
+        HIPCHK(hipMemcpyAsync(m->batch_tokens, staging.data(), (size_t)nseq * n * 4, hipMemcpyHostToDevice, s));
+        if (max_heads) UZU_PROPAGATE(ensure_partials(m, n * max_heads, max_hd)); // any sequence may be past 1024 keys
+        UZU_PROPAGATE(encode_forward(m, s, n, last, states, nseq));
+        HIPCHK(hipStreamSynchronize(s)); // the staging buffer is reused; also surfaces kernel faults per chunk
+        for (uint32_t i = 0; i < nseq; ++i) {
+            bind_state(m, states[i]);
+            m->context_length += n;
+        }
+    }
+    if (first_tokens)
+        for (uint32_t i = 0; i < nseq; ++i) HIPCHK(hipMemcpy(first_tokens + i, states[i]->d_out_token, 4, hipMemcpyDeviceToHost));
+    bind_state(m, prev);
     return UZU_OK;
 }
 

@@ -120,7 +120,27 @@ __device__ __forceinline__ void xpack_from_f32(XPack& o, const float (&x)[32]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) o.v[4 * w + s] = pack_bf16_pair(x[8 * w + s], x[8 * w + 4 + s]);
 }
-// 32 consecutive bf16 activations from memory; also returns their sum (f32, through the same unit: x * 1.0 pairs)
+// 32 consecutive bf16 activations (four 16-byte words as loaded) -> packed-dot order; also returns their sum (f32,
+// through the same unit: x * 1.0 pairs)
+typedef uint32_t gc_raw4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float xpack_from_raw(XPack& o, const gc_raw4 (&raw)[4]) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t ones = 0x3F803F80u;
+    asm("" : "+v"(ones));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const gc_raw4 u = raw[w]; // (x0,x1) (x2,x3) (x4,x5) (x6,x7)
+        o.v[4 * w + 0] = __builtin_amdgcn_perm(u.z, u.x, 0x05040100u);
+        o.v[4 * w + 1] = __builtin_amdgcn_perm(u.z, u.x, 0x07060302u);
+        o.v[4 * w + 2] = __builtin_amdgcn_perm(u.w, u.y, 0x05040100u);
+        o.v[4 * w + 3] = __builtin_amdgcn_perm(u.w, u.y, 0x07060302u);
+        s0 = dot2_bf16(o.v[4 * w + 0], ones, s0);
+        s1 = dot2_bf16(o.v[4 * w + 1], ones, s1);
+        s2 = dot2_bf16(o.v[4 * w + 2], ones, s2);
+        s3 = dot2_bf16(o.v[4 * w + 3], ones, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
 __device__ __forceinline__ float xpack_load(XPack& o, const uint16_t* p) {
     const uint4* src = (const uint4*)p;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;

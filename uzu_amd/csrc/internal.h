@@ -85,6 +85,9 @@ struct uzu_hip_kernel {
     uint32_t kind = 0;   // KernelKind
     uint32_t t[4] = {0}; // data types
     uint32_t f[12] = {0}; // specialization flags / consts
+    // kernel-owned device scratch (UnifiedSampling's arg-max partials): hipMalloc'd outside any stream capture, grow-only
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
 };
 
 namespace uzu {

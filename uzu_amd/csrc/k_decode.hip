@@ -56,13 +56,28 @@ __device__ __forceinline__ float act_bf16(uint32_t act, float x, const uint64_t*
 //   * PRO selects the prologue at compile time (0 plain row, 1 Normalization, 2 DeltaNet norm-gate): a run-time branch in
 //     front of the first weight loads -- even a wave-uniform one -- makes the compiler fall back to vmcnt(0) waits.
 template <int BITS, int CPLT, int R, bool ACT, int KIND, int PRO, bool CONV>
-__global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_log2) {
+__global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const void* a1, const void* a2, uint32_t k_arg, int lpr_log2, const uint8_t* w0,
+                                                       const uint16_t* s0, const uint16_t* o0, DecGemvParams p) {
+    // The six pointers every address computation of the first loads starts from are separate leading kernel arguments:
+    // with -mllvm -amdgpu-kernarg-preload-count=12 (csrc/Makefile, this file only) the command processor places them in
+    // SGPRs at wave launch, so the first loads do not wait for a scalar load of the 300-byte parameter block
+    // (tools/lat_lab: -0.1..0.3 us per launch).  They duplicate p.x / p.shortcut_in / p.norm_scales (or p.dg_o / p.dg_sz /
+    // p.dg_w for the norm-gate prologue), p.k (the activation loads' addresses depend on it) and p.w[0] / p.scales[0] /
+    // p.biases[0]: 14 dwords, the most the user-SGPR budget admits.
+    p.k = k_arg;
+    if (PRO == 2) {
+        p.dg_o = (const float*)a0, p.dg_sz = (const float*)a1, p.dg_w = (const float*)a2;
+    } else {
+        p.x = (const uint16_t*)a0, p.shortcut_in = (const uint16_t*)a1, p.norm_scales = (const float*)a2;
+    }
+    p.w[0] = w0, p.scales[0] = s0, p.biases[0] = o0;
     using Codes = typename CodesT<BITS>::type;
     constexpr int STEP_BYTES = 4 * BITS;
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    UZU_TL_STAMP(p, 0);
+    UZU_TL_DECL;
+    UZU_TL_STAMP(0);
     const uint32_t K = p.k;
     const int lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int sl = lane & (lpr - 1), rsub = lane >> lpr_log2;
@@ -143,7 +158,10 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     // ~0.8 us) is needed first and the weights (HBM, ~1.3 us) only after the prologue, so the activation loads are
     // issued FIRST and the first weight item right behind them; with LDS-only barriers in the prologue nothing waits
     // for the weights before the row loop.
-    constexpr int NPRE = CPL; // staged 4-element vectors per thread: K / 1024 <= CPL whenever lpr <= 32; the rest loads in place
+    // staged 4-element vectors per thread: K / 1024 <= 2 CPL always (K = 32 lpr CPL, lpr <= 64).  ALL of them are requested
+    // ahead of the weights: a vector fetched in place inside the prologue queues behind the first weight batch of every
+    // resident workgroup (VMEM returns in order) -- 5-7 us of prologue at K = 4096 (tools/timeline.py, round 2)
+    constexpr int NPRE = 2 * CPL;
     u32x2_v x_pre[NPRE], s_pre[NPRE];
     f32x4_v n_pre[NPRE];
     if (PRO == 1) {
@@ -165,6 +183,17 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         dg_pre[2] = *(const f32x4_v*)(p.dg_sz + e0), dg_pre[3] = *(const f32x4_v*)(p.dg_sz + e0 + 4);
         dg_pre[4] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv), dg_pre[5] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv + 4);
     }
+    constexpr int XST = (BITS == 4 && CPLT == 0) ? 4 : 1; // steps of the LDS-resident row staged per thread (K <= 32768)
+    gc_raw4 xrow_raw[XST][4];
+    if (BITS == 4 && CPLT == 0) {
+#pragma unroll
+        for (int q = 0; q < XST; ++q) {
+            const uint32_t c = min((uint32_t)tid + 256u * q, C - 1); // clamped: a re-read, never stored
+            const gc_raw4* src = (const gc_raw4*)(p.x + (size_t)c * 32);
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) xrow_raw[q][w4] = src[w4];
+        }
+    }
     // exp() table of the SiLU / softplus epilogues (uzu_math.h): fetched with the first loads, parked in LDS before the
     // first barrier -- the epilogue's table read is then an LDS access instead of a dependent global-memory round trip
     __shared__ uint64_t s_exp_tab[(ACT || CONV) ? 32 : 1];
@@ -176,10 +205,6 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     ConvPre cp_cur[CONV ? R : 1]; // conv operands of the wave's first batch: in flight during the prologue as well
     if (CONV) conv_prefetch(b0, cp_cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (ACT || CONV) {
-        if (tid < 32) s_exp_tab[tid] = exp_entry;
-        if (PRO == 0 || CPLT == 0) lds_barrier(); // the prologue variants pass a barrier of their own before any epilogue runs
-    }
 
     // ---- prologue ---------------------------------------------------------------------------------------
     float xf[CPL][32];
@@ -226,6 +251,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     *(float4*)(slot + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
+            if ((ACT || CONV) && tid < 32) s_exp_tab[tid] = exp_entry; // rides on the barrier below
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -283,6 +309,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 for (int i = 0; i < 4; ++i) ss = fmaf(v[i], v[i], ss);
                 *(float4*)(xs + (size_t)(e / 32) * 36 + e % 32) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            UZU_TL_STAMP(1); // the activation vector has arrived and gone through the residual add / sum of squares
             ss = wave_sum(ss);
             if (lane == 0) red[wave] = ss;
             lds_barrier();
@@ -314,6 +341,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                     *(uint2*)(p.normed_out + e) = o;
                 }
             }
+            if ((ACT || CONV) && tid < 32) s_exp_tab[tid] = exp_entry; // rides on the barrier below (requested with the first loads)
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -334,6 +362,32 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
 #pragma unroll
         for (int j = 0; j < CPL; ++j) xsm[j] = sum32(xf[j]);
     }
+    // K > 8192 (CPLT == 0), int4: the whole activation row is parked once per workgroup in LDS, already in packed-dot order
+    // (step c = 16 words at a stride of 20 words: conflict-free ds_read_b128 for 16 consecutive steps) together with the
+    // per-step sums.  The per-step re-read from global memory it replaces cost four more VMEM instructions, 16 v_perm and 16
+    // dot2 per 16-byte weight load (Llama-3-8B down-projection: 2.9 TB/s).  Its loads were issued ahead of the weights.
+    if (BITS == 4 && CPLT == 0) {
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        uint32_t* xw = (uint32_t*)smem;
+        float* xsum = smem + (size_t)C * 20;
+#pragma unroll
+        for (int q = 0; q < XST; ++q) {
+            const uint32_t c = (uint32_t)tid + 256u * q;
+            if (c < C) {
+                XPack xp;
+                const float sx = xpack_from_raw(xp, xrow_raw[q]);
+                u32x4_v* dst = (u32x4_v*)(xw + (size_t)c * 20);
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    u32x4_v v;
+                    v.x = xp.v[4 * w4], v.y = xp.v[4 * w4 + 1], v.z = xp.v[4 * w4 + 2], v.w = xp.v[4 * w4 + 3];
+                    dst[w4] = v;
+                }
+                xsum[c] = sx;
+            }
+        }
+        lds_barrier();
+    }
     // int4: the row goes through the packed-dot unit (gemv_core.h: dot32p) -- bf16 pairs, 16 registers per step; the
     // f32 copy is dead from here on
     XPack xq[BITS == 4 ? CPL : 1];
@@ -342,7 +396,11 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
         for (int j = 0; j < CPL; ++j) xpack_from_f32(xq[BITS == 4 ? j : 0], xf[j]);
     }
 
-    UZU_TL_STAMP(p, 1);
+    if ((ACT || CONV) && (PRO == 0 || CPLT == 0)) { // no prologue barrier to ride on
+        if (tid < 32) s_exp_tab[tid] = exp_entry;
+        lds_barrier();
+    }
+    UZU_TL_STAMP(2);
     // ---- row loop, software pipelined over (batch, step) items ---------------------------------------------
     // Two item buffers alternate roles (no register copies): while one is consumed the loads of the next (batch,
     // step) land in the other.
@@ -376,9 +434,15 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
     };
     auto stream_step = [&](const Item& it, uint32_t c, float (&acc)[R][NPHYS]) { // K > 8192: the row is re-read per step (L1 / L2)
         if constexpr (BITS == 4) {
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            const u32x4_v* src = (const u32x4_v*)((const uint32_t*)smem + (size_t)c * 20);
             XPack x;
-            const float xs = xpack_load(x, p.x + (size_t)c * 32);
-            compute(it, c, x, xs, acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4_v v = src[q];
+                x.v[4 * q] = v.x, x.v[4 * q + 1] = v.y, x.v[4 * q + 2] = v.z, x.v[4 * q + 3] = v.w;
+            }
+            compute(it, c, x, (smem + (size_t)C * 20)[c], acc);
         } else {
             float x[32];
             load32_bf16(p.x + (size_t)c * 32, x);
@@ -469,7 +533,9 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
                 }
             }
         }
+        UZU_TL_STAMP(5); // dot products of the (last) batch done
         finish(b, acc, cp_cur);
+        UZU_TL_STAMP(6);
         if (CONV) conv_prefetch(b + total_waves, cp_cur); // operands of this wave's next batch
     };
     if (CPLT == 0 || (CPL & 1) == 0) {
@@ -480,7 +546,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             if (b + total_waves < num_batches) batch(b + total_waves, itB, itA);
         }
     }
-    UZU_TL_STAMP(p, 2);
+    UZU_TL_STAMP(3);
     if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
         __shared__ float sv[4];
         __shared__ uint32_t si[4];
@@ -498,7 +564,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(DecGemvParams p, int lpr_
             p.part_idx[blockIdx.x] = best_i;
         }
     }
-    UZU_TL_STAMP(p, 3);
+    UZU_TL_STAMP(4);
+    UZU_TL_FLUSH(p);
 }
 
 // Launch geometry.  Two regimes (tools/kbench.cpp sweeps):
@@ -538,7 +605,9 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
 
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO, bool CONV>
 static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
-    const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
+    const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float)
+                       : (CPLT == 0 && BITS == 4)                  ? ((size_t)(p.k / 32) * 21 + 16) * sizeof(float) // packed row + per-step sums
+                                                                   : 0;
     static const int cap_override = [] {
         const char* c = getenv("UZU_DEC_CAP");
         return c ? atoi(c) : 0;
@@ -554,8 +623,15 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                       \
         if (p.part_val && p.part_capacity && cap > p.part_capacity) cap = p.part_capacity; /* one arg-max partial per workgroup */  \
         const uint32_t grid = want > cap ? cap : want;                                                                              \
+        if (lds > 65536) { /* K > ~24k on the LDS-resident-row path */                                                              \
+            static bool raised = false;                                                                                             \
+            if (!raised) raised = hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; \
+        }                                                                                                                           \
         if (grid_out) *grid_out = grid;                                                                                             \
-        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>), dim3(grid), dim3(256), lds, s, p, lpr_log2); }, "gemv_dec"); \
+        const void* a0 = PRO == 2 ? (const void*)p.dg_o : (const void*)p.x;                                                         \
+        const void* a1 = PRO == 2 ? (const void*)p.dg_sz : (const void*)p.shortcut_in;                                              \
+        const void* a2 = PRO == 2 ? (const void*)p.dg_w : (const void*)p.norm_scales;                                               \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>), dim3(grid), dim3(256), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], p); }, "gemv_dec"); \
     } while (0)
     if (!ACT && !CONV && R == 4) UZU_LAUNCH((ACT || CONV) ? 2 : 4);
     if (R >= 2) UZU_LAUNCH(2);
@@ -616,7 +692,7 @@ static unsigned long long* g_tl_base = nullptr;
 static uint32_t g_tl_max = 0, g_tl_next = 0;
 unsigned long long* timeline_next_slot() {
     if (!g_tl_base || g_tl_next >= g_tl_max) return nullptr;
-    return g_tl_base + (size_t)(g_tl_next++) * 4096;
+    return g_tl_base + (size_t)(g_tl_next++) * 1024 * UZU_TL_SLOTS;
 }
 extern "C" void uzu_hip_debug_set_timeline(unsigned long long* base, uint32_t max_launches) { g_tl_base = base, g_tl_max = max_launches, g_tl_next = 0; }
 #endif
@@ -752,7 +828,8 @@ uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uin
 // instructions) so that the math hides under the state-row latency.
 __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
     constexpr int DK = 128;
-    UZU_TL_STAMP(p, 0);
+    UZU_TL_DECL;
+    UZU_TL_STAMP(0);
     const uint32_t hv = blockIdx.x;
     const uint32_t gph = p.num_v_heads / p.num_k_heads;
     const uint32_t hk = hv / gph;
@@ -798,6 +875,7 @@ __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
     const float decay = delta_decay_fast(a_raw, dt_b, a_l);
     const float sz_i = silu_f32(z_i);
 
+    UZU_TL_STAMP(2); // scalar math done (state row may still be in flight)
     const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
     float sq = 0.f, sk = 0.f;
 #pragma unroll
@@ -822,7 +900,8 @@ __global__ void __launch_bounds__(256) delta_dec_kernel(DeltaDecParams p) {
             p.sz[hv * Dv + i] = sz_i;
         }
     }
-    UZU_TL_STAMP(p, 3);
+    UZU_TL_STAMP(4);
+    UZU_TL_FLUSH(p);
 }
 uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p_in) {
     DeltaDecParams p = p_in;
@@ -850,7 +929,8 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     __shared__ float s_o[NGRP][GS][HD];
     __shared__ float s_m[NGRP][GS], s_l[NGRP][GS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    UZU_TL_STAMP(p, 0);
+    UZU_TL_DECL;
+    UZU_TL_STAMP(0);
     const uint32_t subs = p.gqa_factor / GS;
     const uint32_t kvh = blockIdx.x / subs, sub = blockIdx.x % subs;
     const uint32_t head0 = kvh * p.gqa_factor + sub * GS;
@@ -961,7 +1041,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         }
     }
 
-    UZU_TL_STAMP(p, 1);
+    UZU_TL_STAMP(2);
     // ---- split-KV online softmax over keys i = key0 + key_step * t, i <= L (causal, suffix length 1) ----
     float q[GS][8], o[GS][8], mx[GS], sm[GS];
 #pragma unroll
@@ -1009,7 +1089,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
             }
         }
     }
-    UZU_TL_STAMP(p, 2);
+    UZU_TL_STAMP(3);
     // every key group parks its state in LDS; the merge below runs over the NGRP groups in group order
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
@@ -1034,7 +1114,8 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         p.partials[row * HD + e] = acc;
         if (e == 0) p.sums[row] = l, p.maxs[row] = m;
     }
-    UZU_TL_STAMP(p, 3);
+    UZU_TL_STAMP(4);
+    UZU_TL_FLUSH(p);
 }
 
 template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {

@@ -125,6 +125,22 @@ uzu_status tensor_copy(hipStream_t s, const void* src, void* dst, uint32_t dt, u
 uzu_status argmax(hipStream_t s, const void* logits, uint32_t dt, uint32_t* output, uint32_t vocab_size,
                   uint32_t batch_size, void* scratch);
 size_t argmax_scratch_bytes(uint32_t batch_size);
+// UnifiedSampling with any of: grammar bitmask, temperature, top-k / top-p / min-p, Gumbel-max noise (k_sampling.hip).
+// `scratch` (unified_sampling_scratch_bytes) is only used when no filter is set (two-level arg-max over 256 workgroups).
+struct UnifiedSamplingParams {
+    const void* logits;      // [batch, vocab] of dt
+    uint32_t dt;
+    uint32_t* output;        // [batch]
+    const uint64_t* seeds;   // [batch] or null (greedy)
+    const uint32_t* bitmask; // [batch, ceil(vocab / 32)] or null
+    uint32_t has_temperature, has_top_k, has_top_p, has_min_p;
+    float temperature;
+    uint32_t top_k;
+    float top_p, min_p;
+    uint32_t vocab_size, batch_size;
+};
+uzu_status unified_sampling(hipStream_t s, const UnifiedSamplingParams& p, void* scratch);
+size_t unified_sampling_scratch_bytes(uint32_t batch_size);
 
 // ---------------------------------------------------------------- gated delta net
 uzu_status delta_net_conv_update(hipStream_t s, const float* conv_weight, const float* bias, uint16_t* in_out,

@@ -18,21 +18,29 @@ struct DecNorm {
 };
 
 // Per-workgroup phase timestamps (100 MHz wall clock, s_memrealtime) for tools/timeline.py.  Compiled in only with
-// -DUZU_TIMELINE (a separate library variant: the production kernels carry no trace of it).
+// -DUZU_TIMELINE (a separate library variant: the production kernels carry no trace of it).  The stamps live in
+// registers and are stored by thread 0 at the very end of the kernel (a store in front of the first loads would sit in
+// the same in-order VMEM queue and delay what it is meant to measure).
 #ifdef UZU_TIMELINE
 #define UZU_TL_FIELD unsigned long long* tl;
-#define UZU_TL_STAMP(p, slot)                                                                   \
-    do {                                                                                        \
-        if ((p).tl && threadIdx.x == 0) {                                                        \
-            const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;                             \
-            if (wg < 1024) (p).tl[wg * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();            \
-        }                                                                                       \
+#define UZU_TL_SLOTS 8
+#define UZU_TL_DECL unsigned long long tl_t[UZU_TL_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define UZU_TL_STAMP(slot) (tl_t[slot] = __builtin_amdgcn_s_memrealtime())
+#define UZU_TL_FLUSH(p)                                                                              \
+    do {                                                                                             \
+        if ((p).tl && threadIdx.x == 0) {                                                            \
+            const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                \
+            if (wg_ < 1024)                                                                          \
+                for (int i_ = 0; i_ < UZU_TL_SLOTS; ++i_) (p).tl[wg_ * UZU_TL_SLOTS + i_] = tl_t[i_]; \
+        }                                                                                            \
     } while (0)
-unsigned long long* timeline_next_slot(); // next per-launch block of 1024 x 4 stamps, or null
+unsigned long long* timeline_next_slot(); // next per-launch block of 1024 x UZU_TL_SLOTS stamps, or null
 extern "C" void uzu_hip_debug_set_timeline(unsigned long long* base, uint32_t max_launches);
 #else
 #define UZU_TL_FIELD
-#define UZU_TL_STAMP(p, slot) do { } while (0)
+#define UZU_TL_DECL do { } while (0)
+#define UZU_TL_STAMP(slot) do { } while (0)
+#define UZU_TL_FLUSH(p) do { } while (0)
 #endif
 
 struct DecGemvParams {

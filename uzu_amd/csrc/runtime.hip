@@ -369,6 +369,13 @@ void uzu_hip_cmdbuf_destroy(uzu_hip_cmdbuf* cb) {
     delete cb;
 }
 
-void uzu_hip_kernel_destroy(uzu_hip_kernel* k) { delete k; }
+void uzu_hip_kernel_destroy(uzu_hip_kernel* k) {
+    if (!k) return;
+    if (k->scratch) { // encodes that reference the block may still be in flight
+        (void)hipStreamSynchronize(k->ctx->stream);
+        (void)hipFree(k->scratch);
+    }
+    delete k;
+}
 
 } // extern "C"

@@ -19,6 +19,43 @@ from .desc import ModelBundle
 MODEL_DEFAULT, MODEL_NO_GRAPH, MODEL_NO_FUSION, MODEL_DEBUG_TAPS = 0, 1, 2, 4
 
 
+def MODEL_BATCH(n: int) -> int:
+    """flags bits 8..15: sequences one batched prefill pass may carry (UZU_MODEL_BATCH)."""
+    return (int(n) & 0xFF) << 8
+
+
+class HipState:
+    """One sequence's state (LanguageModelState, engine/language_model/state.rs:9-16): KV caches, DeltaNet conv / SSM
+    states, token history, decode graphs.  HipModel.bind(state) makes the model work on it."""
+
+    def __init__(self, model: "HipModel"):
+        self.model = model
+        self._h = C.c_void_p()
+        call("uzu_hip_state_create", model._h, C.byref(self._h))
+
+    def close(self):
+        if self._h and self.model._h:
+            fn = _ffi.lib().uzu_hip_state_destroy
+            fn.restype, fn.argtypes = None, [C.c_void_p]
+            fn(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        call("uzu_hip_state_reset", self._h)
+
+    @property
+    def context_length(self) -> int:
+        fn = _ffi.lib().uzu_hip_state_context_length
+        fn.restype, fn.argtypes = C.c_uint32, [C.c_void_p]
+        return fn(self._h)
+
+
 class HipModel:
     def __init__(self, ctx: Context, bundle: ModelBundle, flags: int = MODEL_DEFAULT, tp_group=None, vocab_offset: int = 0):
         """`tp_group` (uzu_amd.tp.TpGroup) + `vocab_offset`: `bundle` is this rank's shard from uzu_amd.tp.shard_bundle."""
@@ -49,6 +86,25 @@ class HipModel:
 
     def reset(self):
         call("uzu_hip_model_reset", self._h)
+
+    # ---- sequence states ----
+    def new_state(self) -> HipState:
+        return HipState(self)
+
+    def bind(self, state: Optional[HipState]):
+        """Work on `state` from now on (None: the model's own state)."""
+        call("uzu_hip_model_bind_state", self._h, state._h if state is not None else None)
+
+    def prefill_batch(self, states, tokens) -> np.ndarray:
+        """`tokens` [len(states), count]: prefill every state with its row in one batched pass per chunk; returns the first
+        sampled token of every sequence."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        assert tokens.ndim == 2 and tokens.shape[0] == len(states)
+        handles = (C.c_void_p * len(states))(*[st._h for st in states])
+        first = np.zeros(len(states), dtype=np.uint32)
+        call("uzu_hip_model_prefill_batch", self._h, handles, C.c_uint32(len(states)), C.c_void_p(tokens.ctypes.data), C.c_uint32(tokens.shape[1]),
+             C.c_void_p(first.ctypes.data))
+        return first
 
     @property
     def context_length(self) -> int:
