@@ -71,7 +71,30 @@ void* uzu_hip_context_stream(uzu_hip_context* ctx); /* hipStream_t, for interop 
  * Device memory is hipMalloc'ed (never host-mapped: SURVEY.md H3).  `cpu_ptr` semantics are provided
  * by a lazily allocated pinned host mirror plus explicit upload/download (what `Allocation::copyin /
  * as_slice` and `ParameterLeaf::read_allocation` need, BU/allocator/allocator.rs:29-56). */
+/* Context::device_capabilities (BU/backends/common/device_capabilities.rs:6-8) */
+enum { UZU_DEVICE_CAP_SPARSE_BUFFERS = 1u << 0 };
+uzu_status uzu_hip_context_device_capabilities(uzu_hip_context* ctx, uint32_t* out);
+/* Context::{enable_capture, start_capture, stop_capture} (context.rs:38-45; used by engine/capture.rs:33,71 and the matmul
+ * benches).  Metal writes a .gputrace; here a capture (a) brackets the interval with roctx ranges and resumes / pauses an
+ * attached profiler (rocprofv3 --marker-trace; librocprofiler-sdk-roctx is loaded with dlopen, absent library = no-op),
+ * (b) turns every push_debug_group into a roctx range, and (c) writes to `trace_path`, at stop, one JSON record per command
+ * buffer completed in between: name, debug groups, GPU time.  Calling stop without start, or start twice: UZU_ERR_STATE. */
+void uzu_hip_context_enable_capture(void);
+uzu_status uzu_hip_context_start_capture(uzu_hip_context* ctx, const char* trace_path);
+uzu_status uzu_hip_context_stop_capture(uzu_hip_context* ctx);
+
 uzu_status uzu_hip_buffer_create(uzu_hip_context* ctx, size_t size, uzu_hip_buffer** out); /* Context::create_buffer */
+/* Context::create_sparse_buffer + SparseBuffer::{map, unmap, page_size_bytes} (context.rs:31-34, buffer/sparse.rs:5-19):
+ * `capacity` bytes of reserved virtual address space (rounded up to whole pages; uzu_hip_buffer_size returns the rounded
+ * size, total_pages = size / page_size), physical pages attached on demand with the HIP virtual-memory API.  gpu_ptr is
+ * stable, so kernels encoded against the buffer see whatever is mapped when they run -- the reference grows its KV caches
+ * this way (mixer/attention/state.rs:144-170).  The handle is an ordinary uzu_hip_buffer for uzu_buf / destroy / upload /
+ * download (mapped ranges only); cpu_ptr is UZU_ERR_UNSUPPORTED.  Pages are [first_page, end_page); mapping a mapped page or
+ * unmapping an unmapped one is a no-op.  UZU_ERR_UNSUPPORTED when device_capabilities lacks UZU_DEVICE_CAP_SPARSE_BUFFERS. */
+uzu_status uzu_hip_sparse_buffer_create(uzu_hip_context* ctx, size_t capacity, uzu_hip_buffer** out);
+uzu_status uzu_hip_sparse_buffer_map(uzu_hip_buffer* buf, size_t first_page, size_t end_page);
+uzu_status uzu_hip_sparse_buffer_unmap(uzu_hip_buffer* buf, size_t first_page, size_t end_page);
+size_t uzu_hip_sparse_buffer_page_size(const uzu_hip_buffer* buf);
 void uzu_hip_buffer_destroy(uzu_hip_buffer* buf);
 uint64_t uzu_hip_buffer_gpu_ptr(const uzu_hip_buffer* buf);   /* Buffer::gpu_ptr */
 size_t uzu_hip_buffer_size(const uzu_hip_buffer* buf);        /* Buffer::size */
@@ -193,6 +216,26 @@ uzu_status uzu_hip_attention_two_pass2_create(uzu_hip_context* ctx, uint32_t t, 
                                               uzu_hip_kernel** out);
 uzu_status uzu_hip_attention_two_pass2_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf partials, uzu_buf sums,
                                               uzu_buf maxs, uzu_buf out, uint32_t num_heads, uint32_t suffix_length);
+
+/* ---- AttentionGemmCore, a manual trait (BU/backends/common/kernel/attention_gemm/kernel.rs:8-24): the prefill attention
+ * core on the matrix cores.  `uzu_attention_core_arguments` = AttentionCoreNewArguments (encodable_block/mixer/attention/
+ * core/mod.rs:17-28; Option<T> as has_* + value).  is_supported is the trait's static query (causal bf16, head_dim 64 / 128 /
+ * 256, no sinks / ring / trie / sliding window, GQA factor 1, 2, 4 or a multiple of 4).  encode = AttentionCoreEncodeArguments
+ * (core/mod.rs:30-38) for AttentionStateType::Full { length = prefix_length }: queries [q_heads, suffix, hd] as written by
+ * AttentionPrepare, keys / values = the KV cache [tokens, kv_heads, hd] already holding the suffix rows, out [suffix, q_heads,
+ * hd] (the Rust trait returns a fresh Allocation; in C the caller passes it). */
+typedef struct {
+    uint32_t head_dim, num_groups, num_q_heads;
+    uint32_t has_sinks, is_kv_cache_ring, is_causal, is_trie;
+    uint32_t has_sliding_window, sliding_window_size;
+    uint32_t has_scale;
+    float scale;
+    uint32_t data_type;
+} uzu_attention_core_arguments;
+uzu_status uzu_hip_attention_gemm_is_supported(uzu_hip_context* ctx, const uzu_attention_core_arguments* arguments, uint32_t* out);
+uzu_status uzu_hip_attention_gemm_create(uzu_hip_context* ctx, const uzu_attention_core_arguments* arguments, uzu_hip_kernel** out);
+uzu_status uzu_hip_attention_gemm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out,
+                                         uint32_t prefix_length, uint32_t suffix_length);
 
 /* ---- KVCacheUpdate (cpu/kernel/attention/kv_cache_update.rs:7-15); copies are inline constants */
 typedef struct { uint32_t source, destination; } uzu_kv_copy; /* BU/gpu_types/kv_cache_update.rs */

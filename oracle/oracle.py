@@ -41,6 +41,7 @@ class MatmulArgs(C.Structure):
         ("d", C.c_void_p), ("d_dtype", C.c_uint32), ("ab_scale", C.c_float), ("accumulate", C.c_uint32),
         ("bias", C.c_void_p), ("has_soft_cap", C.c_uint32), ("soft_cap", C.c_float),
         ("gather_indices", C.c_void_p), ("m", C.c_uint32), ("n", C.c_uint32), ("k", C.c_uint32),
+        ("a_q", C.c_void_p), ("a_scales", C.c_void_p), ("a_group_size", C.c_uint32), ("rht_factors", C.c_void_p),
     ]
 
 

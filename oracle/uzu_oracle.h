@@ -72,8 +72,23 @@ typedef struct {
     float soft_cap;
     const uint32_t* gather_indices; /* [m,n] or NULL */
     uint32_t m, n, k;
+    /* A: MatmulA::Int8Symmetric { values, scales, group_sums, group_size } (matmul_a.rs:9-14) when a == NULL */
+    const int8_t* a_q;      /* [m, k] */
+    const float* a_scales;  /* [m, ceil(k / a_group_size)] */
+    uint32_t a_group_size;  /* 32 / 64 / 128 */
+    /* MatmulDOps::rht_factors (d_ops.rs:3-9): output RHT in place on D after the store, THEN the bias (kernel.rs:296-303) */
+    const int32_t* rht_factors; /* [n] or NULL */
 } orc_matmul_args;
 void orc_matmul(const orc_matmul_args* args);
+
+/* ---- ActivationTransform (cpu/kernel/activation_transform/activation_transform.rs:43-136, mod.rs:9-47) ----
+ * Randomised Hadamard transform over stripes of 32 elements (+-1 factors before the butterfly for InputRht / Quantize*, after it
+ * for OutputRht), optionally followed by symmetric int8 quantisation per `activation_scale_group_size` elements with i32 code
+ * sums per `sum_group_size`.  op: 0 InputRht, 1 OutputRht, 2 Quantize, 3 QuantizeWithGroupSums (gpu_types/activation_transform.rs).
+ * input == NULL <=> in place on fp_out. */
+void orc_activation_transform(const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
+                              const int32_t* rht_factors, uint32_t dtype, uint32_t batch_size, uint32_t element_count, uint32_t op,
+                              uint32_t activation_scale_group_size, uint32_t sum_group_size);
 
 /* ---- Normalization (cpu/kernel/normalization/normalization.rs:7-126) ---- */
 typedef struct {

@@ -86,7 +86,13 @@ void orc_matmul(const orc_matmul_args* g) {
             const size_t b_col = g->gather_indices ? g->gather_indices[row * n + col] : col;
             float accumulator = 0.0f;
             for (size_t inner = 0; inner < k; ++inner) {
-                const float a_value = rd(g->a, g->a_dtype, row * k + inner);
+                float a_value;
+                if (g->a) {
+                    a_value = rd(g->a, g->a_dtype, row * k + inner);
+                } else { /* AData::Int8 (kernel.rs:190-200): q * scale of the activation group */
+                    const size_t groups = (k + g->a_group_size - 1) / g->a_group_size;
+                    a_value = (float)g->a_q[row * k + inner] * g->a_scales[row * groups + inner / g->a_group_size];
+                }
                 float b_value;
                 if (!quant) {
                     const size_t index = g->b_transpose ? b_col * ld + inner : inner * ld + b_col;
@@ -126,11 +132,92 @@ void orc_matmul(const orc_matmul_args* g) {
             const size_t output_index = row * n + col;
             float value = g->ab_scale * accumulator;
             if (g->accumulate) value += rd(g->d, g->d_dtype, output_index);
-            if (g->bias) value += rd(g->bias, g->w_dtype, col);
+            if (g->bias && !g->rht_factors) value += rd(g->bias, g->w_dtype, col); /* bias_after_rht */
             if (g->has_soft_cap) value = g->soft_cap * tanhf(value / g->soft_cap);
             wr(g->d, g->d_dtype, output_index, value);
         }
     }
+    if (g->rht_factors) { /* kernel.rs:296-303: OutputRht in place on D, then TensorAddBias */
+        orc_activation_transform(NULL, g->d, NULL, NULL, NULL, g->rht_factors, g->d_dtype, g->m, g->n, 1u, 0u, 0u);
+        if (g->bias)
+            for (size_t i = 0; i < m * n; ++i) wr(g->d, g->d_dtype, i, rd(g->d, g->d_dtype, i) + rd(g->bias, g->w_dtype, i % n)); /* tensor_add_bias.rs */
+    }
+}
+
+/* ------------------------------------------------------------------ ActivationTransform
+ * BU/cpu/kernel/activation_transform/mod.rs:9-47 */
+static float orc_min_max_symmetric_divisor(const float* values, size_t n) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        mn = fminf(mn, values[i]); /* f32::min / max: the non-NaN operand wins, as fminf / fmaxf */
+        mx = fmaxf(mx, values[i]);
+    }
+    const float magnitude = fmaxf(fabsf(mn), fabsf(mx));
+    return (isfinite(magnitude) && magnitude > 0.0f) ? magnitude / 127.0f : 1.0f;
+}
+static int8_t orc_quantize_symmetric_i8(float value, float divisor) {
+    float r = roundf(value / divisor); /* f32::round: half away from zero */
+    if (r < -127.0f) r = -127.0f;
+    if (r > 127.0f) r = 127.0f;
+    return (int8_t)r;
+}
+static void orc_hadamard32(float* values) {
+    for (size_t stride = 1; stride < 32; stride <<= 1)
+        for (size_t lane = 0; lane < 32; ++lane)
+            if ((lane & stride) == 0) {
+                const float a = values[lane], b = values[lane | stride];
+                values[lane] = a + b;
+                values[lane | stride] = a - b;
+            }
+    const float scale = 1.0f / sqrtf(32.0f);
+    for (size_t i = 0; i < 32; ++i) values[i] *= scale;
+}
+/* activation_transform.rs:43-136 */
+void orc_activation_transform(const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
+                              const int32_t* rht_factors, uint32_t dtype, uint32_t batch_size, uint32_t element_count, uint32_t op,
+                              uint32_t activation_scale_group_size, uint32_t sum_group_size) {
+    const void* in = input ? input : fp_out;
+    const size_t rows = batch_size, columns = element_count;
+    const int input_rht = op != 1u;
+    const int quantize = op == 2u || op == 3u;
+    float* transformed = (float*)malloc(columns * sizeof(float));
+    for (size_t row = 0; row < rows; ++row) {
+        const size_t row_offset = row * columns;
+        for (size_t stripe_start = 0; stripe_start < columns; stripe_start += 32) {
+            float stripe[32];
+            for (size_t lane = 0; lane < 32; ++lane) {
+                const size_t index = stripe_start + lane;
+                const float value = rd(in, dtype, row_offset + index);
+                const float factor = (float)rht_factors[index];
+                stripe[lane] = input_rht ? value * factor : value;
+            }
+            orc_hadamard32(stripe);
+            for (size_t lane = 0; lane < 32; ++lane) {
+                const size_t index = stripe_start + lane;
+                const float factor = (float)rht_factors[index];
+                transformed[index] = input_rht ? stripe[lane] : stripe[lane] * factor;
+            }
+        }
+        if (quantize) { /* quantize_transformed_row (activation_transform.rs:11-41) */
+            const size_t scales_per_row = columns / activation_scale_group_size;
+            const size_t sums_per_row = op == 3u ? columns / sum_group_size : 0;
+            if (op == 3u) memset(group_sums_out + row * sums_per_row, 0, sums_per_row * sizeof(int32_t));
+            for (size_t gidx = 0; gidx < scales_per_row; ++gidx) {
+                const float* source = transformed + gidx * activation_scale_group_size;
+                const float scale = orc_min_max_symmetric_divisor(source, activation_scale_group_size);
+                scales_out[row * scales_per_row + gidx] = scale;
+                for (size_t i = 0; i < activation_scale_group_size; ++i) {
+                    const int8_t code = orc_quantize_symmetric_i8(source[i], scale);
+                    const size_t absolute_index = gidx * activation_scale_group_size + i;
+                    q_out[row_offset + absolute_index] = code;
+                    if (op == 3u) group_sums_out[row * sums_per_row + absolute_index / sum_group_size] += (int32_t)code;
+                }
+            }
+        } else {
+            for (size_t index = 0; index < columns; ++index) wr(fp_out, dtype, row_offset + index, transformed[index]);
+        }
+    }
+    free(transformed);
 }
 
 /* ------------------------------------------------------------------ Normalization

@@ -434,8 +434,9 @@ def test_argmax_exact_with_ties(hip_ctx):
     bl, bo = hip_ctx.buffer_from(logits), hip_ctx.create_buffer(batch * 4)
     run(hip_ctx, lambda cb: kern.encode(bl, bo, None, None, None, None, None, None, vocab, batch, cb))
     assert bo.download(np.uint32, batch).tolist() == want.tolist()
-    with pytest.raises(B.UzuHipError):
-        B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 1, 0, 0, 0, 0, 0)  # stochastic: unsupported, loudly
+    with pytest.raises(B.UzuHipError):  # a stochastic kernel needs its seeds
+        stoch = B.UnifiedSamplingKernel.new(hip_ctx, B.BF16, 1, 0, 0, 0, 0, 0)
+        run(hip_ctx, lambda cb: stoch.encode(bl, bo, None, None, None, None, None, None, vocab, batch, cb))
 
 
 
@@ -802,3 +803,95 @@ def test_command_buffer_typestate_copy_fill_graph(hip_ctx):
         g.submit().wait_until_completed()
     assert counter.download(np.float32, 4).tolist() == [3.0] * 4
     assert hip_ctx.peak_memory_usage() > 0 and "gfx950" in hip_ctx.device_name()
+
+
+# ------------------------------------------------------------------------------------------ boundary: sparse buffers, capture, capabilities
+def test_sparse_buffer_map_unmap_and_kernels_on_mapped_pages(hip_ctx):
+    """Context::create_sparse_buffer + SparseBuffer::{map, unmap, page_size_bytes} (context.rs:31-34, buffer/sparse.rs:5-19) the
+    way the reference's KV cache uses them (mixer/attention/state.rs:144-170): address space first, pages as the context grows;
+    a kernel (KVCacheUpdate row copy) runs on the mapped part; data survives mapping further pages; unmapped ranges are refused."""
+    assert hip_ctx.device_capabilities() & B.DEVICE_CAP_SPARSE_BUFFERS, "MI355X exposes the HIP virtual-memory API"
+    sb = hip_ctx.create_sparse_buffer(10 * (1 << 20) + 5)
+    page = sb.page_size_bytes()
+    assert page >= 4096 and (page & (page - 1)) == 0 and sb.size() % page == 0 and sb.size() >= 10 * (1 << 20) + 5
+    assert sb.total_pages() == sb.size() // page
+    gpu_ptr = sb.gpu_ptr()
+    before = hip_ctx.peak_memory_usage()
+    sb.map(0, 1)
+    sb.map(0, 1)  # idempotent
+    rows = np.arange(4 * 64, dtype=np.uint16).reshape(4, 64)
+    sb.upload(rows)
+    other = hip_ctx.buffer_from(rows)
+    kern = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16)
+    run(hip_ctx, lambda cb: kern.encode(sb, other, [(0, 3), (1, 2)], 2, 64, cb))
+    got = sb.download(np.uint16, rows.size).reshape(rows.shape)
+    assert np.array_equal(got[3], rows[0]) and np.array_equal(got[2], rows[1]) and np.array_equal(got[:2], rows[:2])
+    if sb.total_pages() > 1:
+        with pytest.raises(B.UzuHipError):
+            sb.download(np.uint16, 16, offset=page)  # second page not mapped yet
+        sb.map(1, sb.total_pages())
+        sb.upload(rows, offset=page)
+        assert np.array_equal(sb.download(np.uint16, rows.size, offset=page).reshape(rows.shape), rows)
+        assert np.array_equal(sb.download(np.uint16, rows.size).reshape(rows.shape), got)  # first page untouched
+        assert hip_ctx.peak_memory_usage() >= before  # mapped pages are accounted like any allocation
+        sb.unmap(1, sb.total_pages())
+        with pytest.raises(B.UzuHipError):
+            sb.upload(rows, offset=page)
+    assert sb.gpu_ptr() == gpu_ptr
+    with pytest.raises(B.UzuHipError):
+        sb.map(0, sb.total_pages() + 1)
+    with pytest.raises(B.UzuHipError):
+        call_cpu_ptr = C.c_void_p()
+        B.call("uzu_hip_buffer_cpu_ptr", sb._h, C.byref(call_cpu_ptr))
+
+
+def test_capture_writes_command_buffer_records(hip_ctx, tmp_path):
+    """Context::{enable_capture, start_capture, stop_capture} (context.rs:38-45): the trace file lists every command buffer
+    completed in between with its debug groups and GPU time; misuse is UZU_ERR_STATE."""
+    B.Context.enable_capture()
+    with pytest.raises(B.UzuHipError):
+        hip_ctx.stop_capture()
+    path = tmp_path / "trace.json"
+    hip_ctx.start_capture(str(path))
+    with pytest.raises(B.UzuHipError):
+        hip_ctx.start_capture(str(path))
+    a, b = hip_ctx.buffer_from(np.arange(1 << 16, dtype=np.uint8)), hip_ctx.create_buffer(1 << 16)
+    for name in ("first", "second"):
+        cb = hip_ctx.create_command_buffer(name).start_encoding()
+        cb.push_debug_group("copies")
+        cb.encode_copy(a, b, 1 << 16)
+        cb.pop_debug_group()
+        cb.end_encoding().submit().wait_until_completed()
+    hip_ctx.stop_capture()
+    trace = json.load(open(path))
+    assert [r["name"] for r in trace["command_buffers"]] == ["first", "second"]
+    assert all(r["debug_groups"] == ["copies"] and r["gpu_time_ns"] > 0 for r in trace["command_buffers"])
+    assert "gfx950" in trace["device"]
+
+
+@pytest.mark.parametrize("heads,kv_heads,hd,prefix,suffix", [(8, 2, 256, 700, 300), (32, 8, 128, 0, 128), (4, 4, 64, 33, 5)])
+def test_attention_gemm_core(hip_ctx, heads, kv_heads, hd, prefix, suffix):
+    """AttentionGemmCore (attention_gemm/kernel.rs:8-24): is_supported answers the static question AttentionCores::new asks
+    (core/mod.rs:53-61); encode on a Full KV cache equals the CPU single-pass kernel with suffix_length = M (the
+    CPU backend has no GEMM core, its prefill IS the single-pass kernel)."""
+    args = B.AttentionCoreArguments(hd, kv_heads, heads, 0, 0, 1, 0, 0, 0, 0, 0.0, B.BF16)
+    assert B.AttentionGemmCore.is_supported(hip_ctx, args)
+    for bad in (dict(is_causal=0), dict(has_sinks=1), dict(is_trie=1), dict(has_sliding_window=1, sliding_window_size=64), dict(head_dim=96)):
+        a2 = B.AttentionCoreArguments(hd, kv_heads, heads, 0, 0, 1, 0, 0, 0, 0, 0.0, B.BF16)
+        for k_, v_ in bad.items():
+            setattr(a2, k_, v_)
+        assert not B.AttentionGemmCore.is_supported(hip_ctx, a2)
+        with pytest.raises(B.UzuHipError):
+            B.AttentionGemmCore.new(hip_ctx, a2)
+    rng = np.random.default_rng(hd + suffix)
+    seq = prefix + suffix
+    q, k, v, a = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    core = B.AttentionGemmCore.new(hip_ctx, args)
+    bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
+    run(hip_ctx, lambda cb: core.encode(bq, bk, bv, bo, prefix, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3

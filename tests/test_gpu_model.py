@@ -274,27 +274,47 @@ def test_llama3_8b_full_depth_matches_oracle_fixture(hip_ctx, name):
 
 
 # ------------------------------------------------------------------------------------------ sequence states
+# prompt multipliers whose 7-token greedy streams have every oracle top-2 gap >= 0.4 sigma (the tiny bf16 models tie often:
+# 12 of 200 candidate prompts qualify for tiny-llama); the test asserts this premise
+ROBUST_PROMPT_MULTIPLIERS = {"tiny-qwen": (21, 13, 37), "tiny-llama": (149, 373, 223)}
+
+
 @pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
 def test_sequence_states_are_independent_and_batched_prefill_matches_single(hip_ctx, preset):
     """LanguageModelState split from the model (state.rs:9-16): three sequences with different prompts share one set of
-    weights.  (1) interleaved prefill / decode on separately created states gives exactly the tokens each sequence gets
-    alone; (2) one batched prefill pass over all three (linear layers on 3 x count rows, attention / DeltaNet per state)
-    followed by per-state decode gives the same tokens again; every sequence equals the single-sequence oracle."""
+    weights.  (1) interleaved prefill / decode on separately created states gives BIT-IDENTICAL tokens and logits to running
+    each sequence alone on the model's own state (same kernels, same shapes), and the oracle's tokens; (2) one batched prefill
+    pass over all three (linear layers on 3 x count rows, attention / DeltaNet per state) followed by per-state chained decode
+    gives the oracle's tokens again (the GEMM of a batched pass may split K differently: tolerance-class logits)."""
     cfg = S.PRESETS[preset]()
     bundle = S.build_model(cfg)
     count, steps, nseq = 37, 6, 3
-    prompts = np.stack([(S.synthetic_prompt(count, cfg.vocab_size).astype(np.int64) * (3 + 2 * i) + 11 * i) % cfg.vocab_size for i in range(nseq)]).astype(np.uint32)
+    base = S.synthetic_prompt(count, cfg.vocab_size).astype(np.int64)
+    prompts = np.stack([(base * a + 11 * a) % cfg.vocab_size for a in ROBUST_PROMPT_MULTIPLIERS[preset]]).astype(np.uint32)
     want = []
     om = O.OracleModel(bundle)
     for i in range(nseq):
         om.reset()
-        tok = om.prefill(prompts[i])
-        seq = [tok]
+        tok, lg = om.prefill(prompts[i], True)
+        seq, gaps = [tok], [top2_gap(lg)]
         for _ in range(steps):
-            tok = om.forward([tok])
+            tok, lg = om.forward([tok], True)
             seq.append(tok)
+            gaps.append(top2_gap(lg))
+        assert min(gaps) >= 0.4, f"test premise: sequence {i} has a near-tie (gaps {gaps})"
         want.append(seq)
     hm = HipModel(hip_ctx, bundle, MODEL_BATCH(nseq))
+    # every sequence alone on the model's own state
+    alone, alone_logits = [], []
+    for i in range(nseq):
+        hm.reset()
+        seq = [hm.prefill(prompts[i])]
+        for _ in range(steps):
+            seq.append(int(hm.decode(1)[0][0]))
+        alone.append(seq)
+        alone_logits.append(hm.read_logits())
+    assert alone == want, f"single sequence\noracle {want}\nhip    {alone}"
+    hm.reset()
     # (1) interleaved use of three states
     states = [hm.new_state() for _ in range(nseq)]
     got = [[] for _ in range(nseq)]
@@ -305,7 +325,7 @@ def test_sequence_states_are_independent_and_batched_prefill_matches_single(hip_
         for i in (1, 2, 0):
             hm.bind(states[i])
             got[i].append(int(hm.decode(1)[0][0]))
-    assert got == want, f"interleaved states\noracle {want}\nhip    {got}"
+    assert got == alone, f"interleaved states\nalone  {alone}\nstates {got}"
     assert [st.context_length for st in states] == [count + steps] * nseq
     # (2) batched prefill into fresh states, then chained decode per state (each state owns its graphs)
     for st in states:
@@ -315,6 +335,7 @@ def test_sequence_states_are_independent_and_batched_prefill_matches_single(hip_
     for i in range(nseq):
         hm.bind(states[i])
         got2[i] += [int(t) for t in hm.decode(steps)[0]]
+        assert logits_close(alone_logits[i], hm.read_logits()).all()
     assert got2 == want, f"batched prefill\noracle {want}\nhip    {got2}"
     # the model's own state is untouched by all of this
     hm.bind(None)

@@ -65,6 +65,26 @@ class Context:
     def synchronize(self):
         call("uzu_hip_context_synchronize", self._h)
 
+    def device_capabilities(self) -> int:
+        out = C.c_uint32()
+        call("uzu_hip_context_device_capabilities", self._h, C.byref(out))
+        return out.value
+
+    def create_sparse_buffer(self, capacity: int) -> "SparseBuffer":
+        return SparseBuffer(self, capacity)
+
+    @staticmethod
+    def enable_capture():
+        fn = _ffi.lib().uzu_hip_context_enable_capture
+        fn.restype, fn.argtypes = None, []
+        fn()
+
+    def start_capture(self, trace_path: str):
+        call("uzu_hip_context_start_capture", self._h, str(trace_path).encode())
+
+    def stop_capture(self):
+        call("uzu_hip_context_stop_capture", self._h)
+
     @property
     def stream(self) -> int:
         return _ffi.lib().uzu_hip_context_stream(self._h) or 0
@@ -76,6 +96,16 @@ class Context:
         if array.nbytes:
             b.upload(array)
         return b
+
+
+DEVICE_CAP_SPARSE_BUFFERS = 1
+
+
+class AttentionCoreArguments(C.Structure):
+    """AttentionCoreNewArguments (encodable_block/mixer/attention/core/mod.rs:17-28)"""
+    _fields_ = [("head_dim", C.c_uint32), ("num_groups", C.c_uint32), ("num_q_heads", C.c_uint32), ("has_sinks", C.c_uint32),
+                ("is_kv_cache_ring", C.c_uint32), ("is_causal", C.c_uint32), ("is_trie", C.c_uint32), ("has_sliding_window", C.c_uint32),
+                ("sliding_window_size", C.c_uint32), ("has_scale", C.c_uint32), ("scale", C.c_float), ("data_type", C.c_uint32)]
 
 
 class Buffer:
@@ -111,6 +141,30 @@ class Buffer:
         out = np.empty(count, dtype=dtype)
         call("uzu_hip_buffer_download", self._h, C.c_size_t(offset), C.c_void_p(out.ctypes.data), C.c_size_t(out.nbytes))
         return out
+
+
+class SparseBuffer(Buffer):
+    """buffer/sparse.rs:5-19: reserved address space, pages mapped on demand."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        call("uzu_hip_sparse_buffer_create", ctx._h, C.c_size_t(capacity), C.byref(self._h))
+        self._size = _ffi.lib().uzu_hip_buffer_size(self._h)
+
+    def page_size_bytes(self) -> int:
+        fn = _ffi.lib().uzu_hip_sparse_buffer_page_size
+        fn.restype, fn.argtypes = C.c_size_t, [C.c_void_p]
+        return fn(self._h)
+
+    def total_pages(self) -> int:
+        return self._size // self.page_size_bytes()
+
+    def map(self, first_page: int, end_page: int):
+        call("uzu_hip_sparse_buffer_map", self._h, C.c_size_t(first_page), C.c_size_t(end_page))
+
+    def unmap(self, first_page: int, end_page: int):
+        call("uzu_hip_sparse_buffer_unmap", self._h, C.c_size_t(first_page), C.c_size_t(end_page))
 
 
 BufArg = Union[None, Buffer, Tuple[Buffer, int]]
@@ -202,7 +256,7 @@ class _Kernel:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and self.ctx._h:  # a kernel dies before its context (it may own device scratch on the context's stream)
                 _ffi.lib().uzu_hip_kernel_destroy(self._h)
         except Exception:
             pass
@@ -277,6 +331,33 @@ class AttentionTwoPass1Kernel(_Kernel):
         self._enc(encoder, _buf(queries), _buf(keys), _buf(values), _buf(out), _buf(sums), _buf(maxs), _u(gqa_factor),
                   _u(sequence_length), _u(k_head_stride), _u(k_seq_stride), _u(v_head_stride), _u(v_seq_stride), rp, _f(scale),
                   _u(num_heads), _u(suffix_length), _buf(trie), _u(sliding_window_size or 0), _buf(sinks))
+
+
+class AttentionGemmCore:
+    """AttentionGemmCore (attention_gemm/kernel.rs:8-24): is_supported / new / encode"""
+
+    @staticmethod
+    def is_supported(ctx: Context, arguments: AttentionCoreArguments) -> bool:
+        out = C.c_uint32()
+        call("uzu_hip_attention_gemm_is_supported", ctx._h, C.byref(arguments), C.byref(out))
+        return bool(out.value)
+
+    def __init__(self, ctx: Context, arguments: AttentionCoreArguments):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        call("uzu_hip_attention_gemm_create", ctx._h, C.byref(arguments), C.byref(self._h))
+
+    new = classmethod(lambda cls, ctx, arguments: cls(ctx, arguments))
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                _ffi.lib().uzu_hip_kernel_destroy(self._h)
+        except Exception:
+            pass
+
+    def encode(self, queries, keys, values, out, prefix_length, suffix_length, encoder):
+        call("uzu_hip_attention_gemm_encode", self._h, encoder._h, _buf(queries), _buf(keys), _buf(values), _buf(out), _u(prefix_length), _u(suffix_length))
 
 
 class AttentionTwoPass2Kernel(_Kernel):

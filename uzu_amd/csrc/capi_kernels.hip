@@ -5,6 +5,7 @@
 // command buffer's stream.
 #include "internal.h"
 #include "kernels.h"
+#include "uzu_math.h"
 
 using namespace uzu;
 
@@ -12,7 +13,7 @@ namespace {
 
 enum KernelKind : uint32_t {
     KK_MATMUL = 1, KK_NORMALIZATION, KK_QKV_NORM, KK_ATTENTION_PREPARE, KK_ATTENTION_SINGLE_PASS, KK_ATTENTION_TWO_PASS1,
-    KK_ATTENTION_TWO_PASS2, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
+    KK_ATTENTION_TWO_PASS2, KK_ATTENTION_GEMM, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
     KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
     KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
 };
@@ -263,6 +264,50 @@ uzu_status uzu_hip_attention_two_pass1_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
     const k::AttentionParams a = attention_params(k, queries, keys, values, gqa_factor, sequence_length, k_head_stride, k_seq_stride, v_head_stride,
                                                   v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length);
     return k::attention_two_pass1(cb_stream(cb), a, (float*)bptr(out_partials), (float*)bptr(sums), (float*)bptr(maxs));
+}
+
+// AttentionGemmCore (BU/backends/common/kernel/attention_gemm/kernel.rs:8-24; arguments: encodable_block/mixer/attention/
+// core/mod.rs:17-38): the prefill attention on the matrix cores (k_attention_mfma.hip).  is_supported mirrors the trait's
+// static query; a backend that answers false is never constructed by AttentionCores::new (core/mod.rs:53-61).
+static bool attention_gemm_args_supported(const uzu_attention_core_arguments* a) {
+    if (a->data_type != UZU_BF16 || !a->is_causal || a->has_sinks || a->is_kv_cache_ring || a->is_trie || a->has_sliding_window) return false;
+    if (!(a->head_dim == 64 || a->head_dim == 128 || a->head_dim == 256)) return false;
+    if (a->num_groups == 0 || a->num_q_heads % a->num_groups) return false;
+    const uint32_t gqa = a->num_q_heads / a->num_groups;
+    return gqa > 4 ? gqa % 4 == 0 : 4 % gqa == 0;
+}
+uzu_status uzu_hip_attention_gemm_is_supported(uzu_hip_context* ctx, const uzu_attention_core_arguments* arguments, uint32_t* out) {
+    UZU_REQUIRE(ctx && arguments && out, "attention_gemm_is_supported: null argument");
+    *out = attention_gemm_args_supported(arguments) ? 1u : 0u;
+    return UZU_OK;
+}
+uzu_status uzu_hip_attention_gemm_create(uzu_hip_context* ctx, const uzu_attention_core_arguments* arguments, uzu_hip_kernel** out) {
+    UZU_REQUIRE(ctx && arguments && out, "attention_gemm_create: null argument");
+    UZU_UNSUPPORTED(!attention_gemm_args_supported(arguments), "attention_gemm: unsupported configuration (query uzu_hip_attention_gemm_is_supported first)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_ATTENTION_GEMM, out, &k));
+    k->t[0] = arguments->data_type;
+    k->f[0] = arguments->head_dim, k->f[1] = arguments->num_groups, k->f[2] = arguments->num_q_heads, k->f[3] = arguments->has_scale;
+    k->f[4] = uzu::f32_to_bits(arguments->scale);
+    return UZU_OK;
+}
+uzu_status uzu_hip_attention_gemm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out,
+                                         uint32_t prefix_length, uint32_t suffix_length) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_GEMM, cb));
+    UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out.buffer, "attention_gemm: queries/keys/values/out are required");
+    UZU_REQUIRE(suffix_length > 0, "attention_gemm: empty suffix");
+    const uint32_t hd = k->f[0], nkv = k->f[1], nq = k->f[2];
+    k::AttentionParams a{};
+    a.queries = bptr(queries), a.keys = bptr(keys), a.values = bptr(values);
+    a.dt = k->t[0], a.head_dim = hd, a.gqa_factor = nq / nkv;
+    a.sequence_length = prefix_length + suffix_length; // AttentionStateType::Full { length } + the suffix being attended
+    // strides of the KV cache layout [tokens, kv_heads, head_dim] (core/single_pass.rs:44-73)
+    a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;
+    if (k->f[3]) a.scale = uzu::bits_to_f32(k->f[4]);
+    else a.scale = 1.0f / sqrtf((float)hd);
+    a.num_heads = nq, a.suffix_length = suffix_length, a.is_causal = 1;
+    if (!k::attention_prefill_mfma_supported(a)) return k::attention_single_pass(cb_stream(cb), a, bptr(out)); // suffixes too short for a tile
+    return k::attention_prefill_mfma(cb_stream(cb), a, bptr(out));
 }
 
 uzu_status uzu_hip_attention_two_pass2_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim, uzu_hip_kernel** out) {

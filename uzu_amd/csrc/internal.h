@@ -57,6 +57,17 @@ struct uzu_hip_context {
     size_t staging_size = 0;
     int num_cus = 0;
     char name[128] = {0};
+    // Context::start_capture / stop_capture: while active, every completed command buffer leaves a record (name, debug
+    // groups, GPU time) that stop_capture writes to the trace file
+    bool capture_active = false;
+    std::string capture_path;
+    struct CaptureRecord {
+        std::string name;
+        std::vector<std::string> groups;
+        double gpu_ms;
+    };
+    std::vector<CaptureRecord> capture_records;
+    bool vmm_supported = false; // hipMem* virtual memory management => DeviceCapabilities::SPARSE_BUFFERS
 };
 
 struct uzu_hip_buffer {
@@ -64,6 +75,10 @@ struct uzu_hip_buffer {
     void* dptr = nullptr;
     size_t size = 0;
     void* mirror = nullptr; // pinned host mirror (cpu_ptr)
+    // SparseBuffer (buffer/sparse.rs:5-19): `size` bytes of reserved virtual address space, physical pages mapped on demand
+    bool sparse = false;
+    size_t page_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> pages; // one handle per mapped page (null = unmapped)
 };
 
 enum class CmdbufState { Initial, Encoding, Executable, Pending, Completed };
@@ -77,6 +92,7 @@ struct uzu_hip_cmdbuf {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<std::string> debug_groups;
+    std::vector<std::string> all_groups; // every group pushed while encoding (capture record)
     float last_ms = 0.f;
 };
 

@@ -6,6 +6,7 @@
 //   * one in-order HIP stream per context = the reference's "command buffers execute in submission order";
 //   * a command buffer is either eager (kernels are enqueued as they are encoded) or a captured hipGraph
 //     that submit() launches -- the launch-latency answer for decode loops.
+#include <dlfcn.h>
 #include <string.h>
 
 #include <mutex>
@@ -84,6 +85,44 @@ void stream_workspace_release(hipStream_t s) {
 
 using namespace uzu;
 
+// ---- roctx (optional): debug groups and capture brackets become marker ranges for an attached rocprofv3 --marker-trace.
+// Loaded on demand with dlopen (Context::enable_capture or the first range); absent library => silent no-ops.
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+typedef int (*roctx_ctl_fn)(uint64_t);
+struct Roctx {
+    bool tried = false;
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    roctx_ctl_fn pause = nullptr, resume = nullptr;
+} g_roctx;
+void roctx_load() {
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    g_roctx.push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+    g_roctx.pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+    g_roctx.pause = (roctx_ctl_fn)dlsym(h, "roctxProfilerPause");
+    g_roctx.resume = (roctx_ctl_fn)dlsym(h, "roctxProfilerResume");
+}
+void roctx_push(const char* name) {
+    if (g_roctx.tried && g_roctx.push) (void)g_roctx.push(name);
+}
+void roctx_pop() {
+    if (g_roctx.tried && g_roctx.pop) (void)g_roctx.pop();
+}
+void roctx_pause() {
+    if (g_roctx.tried && g_roctx.pause) (void)g_roctx.pause(0);
+}
+void roctx_resume() {
+    if (g_roctx.tried && g_roctx.resume) (void)g_roctx.resume(0);
+}
+} // namespace
+
 extern "C" {
 
 const char* uzu_hip_last_error(void) { return g_error; }
@@ -106,6 +145,12 @@ uzu_status uzu_hip_context_create(int32_t device_ordinal, uzu_hip_context** out)
     UZU_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     ctx->num_cus = prop.multiProcessorCount;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, device_ordinal) != hipSuccess) {
+        (void)hipGetLastError();
+        vmm = 0;
+    }
+    ctx->vmm_supported = vmm != 0;
     UZU_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->staging_size = 64u << 20;
     UZU_HIP_TRY(hipHostMalloc(&ctx->staging, ctx->staging_size, hipHostMallocDefault));
@@ -168,10 +213,163 @@ void uzu_hip_buffer_destroy(uzu_hip_buffer* b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream); // work encoded against this buffer may still be in flight
     if (b->mirror) (void)hipHostFree(b->mirror);
+    if (b->sparse) {
+        for (size_t i = 0; i < b->pages.size(); ++i)
+            if (b->pages[i]) {
+                (void)hipMemUnmap((char*)b->dptr + i * b->page_bytes, b->page_bytes);
+                (void)hipMemRelease(b->pages[i]);
+                b->ctx->current_bytes -= b->page_bytes;
+            }
+        if (b->dptr) (void)hipMemAddressFree(b->dptr, b->size);
+        delete b;
+        return;
+    }
     if (b->dptr) (void)hipFree(b->dptr);
     const size_t alloc = b->size ? (b->size + 255) & ~(size_t)255 : 256;
     b->ctx->current_bytes -= alloc;
     delete b;
+}
+
+// ---------------------------------------------------------------------------------- SparseBuffer (buffer/sparse.rs:5-19)
+// Context::create_sparse_buffer: `capacity` bytes of virtual address space (rounded up to whole pages), no memory behind
+// it.  map / unmap attach and detach physical pages (hipMemCreate + hipMemMap at the allocation granularity, 2 MiB on
+// MI355X): the reference grows its KV caches this way (mixer/attention/state.rs:144-170).  gpu_ptr() is stable for the
+// lifetime of the buffer, so kernels encoded against it see the pages mapped by the time they run.
+static hipMemAllocationProp sparse_prop(int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    return prop;
+}
+uzu_status uzu_hip_sparse_buffer_create(uzu_hip_context* ctx, size_t capacity, uzu_hip_buffer** out) {
+    UZU_REQUIRE(ctx && out, "sparse_buffer_create: null argument");
+    (void)hipSetDevice(ctx->device);
+    UZU_UNSUPPORTED(!ctx->vmm_supported, "sparse_buffer_create: this device / driver has no virtual memory management (device_capabilities lacks SPARSE_BUFFERS)");
+    const hipMemAllocationProp prop = sparse_prop(ctx->device);
+    size_t gran = 0;
+    UZU_HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    UZU_REQUIRE(gran > 0, "sparse_buffer_create: zero allocation granularity");
+    auto* b = new uzu_hip_buffer();
+    b->ctx = ctx, b->sparse = true, b->page_bytes = gran;
+    b->size = ((capacity ? capacity : 1) + gran - 1) / gran * gran;
+    hipError_t e = hipMemAddressReserve(&b->dptr, b->size, gran, nullptr, 0);
+    if (e != hipSuccess) {
+        delete b;
+        set_error("sparse_buffer_create: hipMemAddressReserve(%zu) failed: %s", b->size, hipGetErrorString(e));
+        return UZU_ERR_HIP;
+    }
+    b->pages.assign(b->size / gran, (hipMemGenericAllocationHandle_t) nullptr);
+    *out = b;
+    return UZU_OK;
+}
+size_t uzu_hip_sparse_buffer_page_size(const uzu_hip_buffer* b) { return b && b->sparse ? b->page_bytes : 0; }
+uzu_status uzu_hip_sparse_buffer_map(uzu_hip_buffer* b, size_t first_page, size_t end_page) {
+    UZU_REQUIRE(b && b->sparse, "sparse_buffer_map: not a sparse buffer");
+    UZU_REQUIRE(first_page <= end_page && end_page <= b->pages.size(), "sparse_buffer_map: pages %zu..%zu out of range (%zu pages)", first_page, end_page, b->pages.size());
+    (void)hipSetDevice(b->ctx->device);
+    const hipMemAllocationProp prop = sparse_prop(b->ctx->device);
+    hipMemAccessDesc access = {};
+    access.location.type = hipMemLocationTypeDevice, access.location.id = b->ctx->device, access.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t i = first_page; i < end_page; ++i) {
+        if (b->pages[i]) continue; // already mapped: Metal's updateTextureMappings is idempotent as well
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, b->page_bytes, &prop, 0);
+        if (e != hipSuccess) {
+            set_error("sparse_buffer_map: hipMemCreate(%zu) failed: %s", b->page_bytes, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
+        }
+        void* va = (char*)b->dptr + i * b->page_bytes;
+        if ((e = hipMemMap(va, b->page_bytes, 0, h, 0)) != hipSuccess || (e = hipMemSetAccess(va, b->page_bytes, &access, 1)) != hipSuccess) {
+            (void)hipMemRelease(h);
+            set_error("sparse_buffer_map: mapping page %zu failed: %s", i, hipGetErrorString(e));
+            return UZU_ERR_HIP;
+        }
+        b->pages[i] = h;
+        b->ctx->current_bytes += b->page_bytes;
+        if (b->ctx->current_bytes > b->ctx->peak_bytes) b->ctx->peak_bytes = b->ctx->current_bytes;
+    }
+    return UZU_OK;
+}
+uzu_status uzu_hip_sparse_buffer_unmap(uzu_hip_buffer* b, size_t first_page, size_t end_page) {
+    UZU_REQUIRE(b && b->sparse, "sparse_buffer_unmap: not a sparse buffer");
+    UZU_REQUIRE(first_page <= end_page && end_page <= b->pages.size(), "sparse_buffer_unmap: pages %zu..%zu out of range (%zu pages)", first_page, end_page, b->pages.size());
+    (void)hipSetDevice(b->ctx->device);
+    UZU_HIP_TRY(hipStreamSynchronize(b->ctx->stream)); // kernels encoded against these pages may still be running
+    for (size_t i = first_page; i < end_page; ++i) {
+        if (!b->pages[i]) continue;
+        UZU_HIP_TRY(hipMemUnmap((char*)b->dptr + i * b->page_bytes, b->page_bytes));
+        UZU_HIP_TRY(hipMemRelease(b->pages[i]));
+        b->pages[i] = nullptr;
+        b->ctx->current_bytes -= b->page_bytes;
+    }
+    return UZU_OK;
+}
+// transfers touch mapped pages only
+static uzu_status sparse_range_mapped(const uzu_hip_buffer* b, size_t offset, size_t size, const char* what) {
+    if (!b->sparse || !size) return UZU_OK;
+    for (size_t i = offset / b->page_bytes; i <= (offset + size - 1) / b->page_bytes; ++i)
+        if (!b->pages[i]) {
+            set_error("%s: page %zu of the sparse buffer is not mapped", what, i);
+            return UZU_ERR_INVALID_ARGUMENT;
+        }
+    return UZU_OK;
+}
+
+// ---------------------------------------------------------------------------------- capture, capabilities (context.rs:36-47)
+uzu_status uzu_hip_context_device_capabilities(uzu_hip_context* ctx, uint32_t* out) {
+    UZU_REQUIRE(ctx && out, "device_capabilities: null argument");
+    *out = ctx->vmm_supported ? UZU_DEVICE_CAP_SPARSE_BUFFERS : 0u;
+    return UZU_OK;
+}
+void uzu_hip_context_enable_capture(void) { roctx_load(); }
+uzu_status uzu_hip_context_start_capture(uzu_hip_context* ctx, const char* trace_path) {
+    UZU_REQUIRE(ctx && trace_path && trace_path[0], "start_capture: null / empty trace path");
+    if (ctx->capture_active) {
+        set_error("start_capture: a capture is already running (%s)", ctx->capture_path.c_str());
+        return UZU_ERR_STATE;
+    }
+    ctx->capture_active = true, ctx->capture_path = trace_path;
+    ctx->capture_records.clear();
+    roctx_resume(); // a profiler attached with its collection paused (rocprofv3 --collection-period / roctx control) starts here
+    roctx_push(trace_path);
+    return UZU_OK;
+}
+uzu_status uzu_hip_context_stop_capture(uzu_hip_context* ctx) {
+    UZU_REQUIRE(ctx, "stop_capture: null context");
+    if (!ctx->capture_active) {
+        set_error("stop_capture: no capture is running");
+        return UZU_ERR_STATE;
+    }
+    (void)hipSetDevice(ctx->device);
+    UZU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    roctx_pop();
+    roctx_pause();
+    ctx->capture_active = false;
+    FILE* f = fopen(ctx->capture_path.c_str(), "w");
+    if (!f) {
+        set_error("stop_capture: cannot write %s", ctx->capture_path.c_str());
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    auto esc = [](const std::string& in) {
+        std::string o;
+        for (char c : in) {
+            if (c == '"' || c == '\\') o += '\\';
+            o += (unsigned char)c < 0x20 ? ' ' : c;
+        }
+        return o;
+    };
+    fprintf(f, "{\"device\": \"%s\", \"command_buffers\": [", esc(ctx->name).c_str());
+    for (size_t i = 0; i < ctx->capture_records.size(); ++i) {
+        const auto& r = ctx->capture_records[i];
+        fprintf(f, "%s\n  {\"name\": \"%s\", \"gpu_time_ns\": %.0f, \"debug_groups\": [", i ? "," : "", esc(r.name).c_str(), r.gpu_ms * 1e6);
+        for (size_t g = 0; g < r.groups.size(); ++g) fprintf(f, "%s\"%s\"", g ? ", " : "", esc(r.groups[g]).c_str());
+        fprintf(f, "]}");
+    }
+    fprintf(f, "\n]}\n");
+    fclose(f);
+    ctx->capture_records.clear();
+    return UZU_OK;
 }
 
 uint64_t uzu_hip_buffer_gpu_ptr(const uzu_hip_buffer* b) { return b ? (uint64_t)(uintptr_t)b->dptr : 0; }
@@ -179,6 +377,7 @@ size_t uzu_hip_buffer_size(const uzu_hip_buffer* b) { return b ? b->size : 0; }
 
 uzu_status uzu_hip_buffer_cpu_ptr(uzu_hip_buffer* b, void** out) {
     UZU_REQUIRE(b && out, "buffer_cpu_ptr: null argument");
+    UZU_UNSUPPORTED(b->sparse, "buffer_cpu_ptr: a sparse buffer has no host view (the reference's SparseBuffer is a Buffer, not a DenseBuffer)");
     if (!b->mirror) {
         UZU_HIP_TRY(hipHostMalloc(&b->mirror, b->size ? b->size : 1, hipHostMallocDefault));
         memset(b->mirror, 0, b->size);
@@ -207,6 +406,7 @@ uzu_status uzu_hip_buffer_fetch_from_device(uzu_hip_buffer* b, size_t offset, si
 uzu_status uzu_hip_buffer_upload(uzu_hip_buffer* b, size_t offset, const void* src, size_t size) {
     UZU_REQUIRE(b && (src || !size), "buffer_upload: null argument");
     UZU_REQUIRE(offset + size <= b->size, "buffer_upload: range [%zu,+%zu) exceeds buffer size %zu", offset, size, b->size);
+    UZU_PROPAGATE(sparse_range_mapped(b, offset, size, "buffer_upload"));
     uzu_hip_context* ctx = b->ctx;
     (void)hipSetDevice(ctx->device);
     // pageable source: bounce through the pinned staging buffer in stream order
@@ -225,6 +425,7 @@ uzu_status uzu_hip_buffer_upload(uzu_hip_buffer* b, size_t offset, const void* s
 uzu_status uzu_hip_buffer_download(uzu_hip_buffer* b, size_t offset, void* dst, size_t size) {
     UZU_REQUIRE(b && (dst || !size), "buffer_download: null argument");
     UZU_REQUIRE(offset + size <= b->size, "buffer_download: range [%zu,+%zu) exceeds buffer size %zu", offset, size, b->size);
+    UZU_PROPAGATE(sparse_range_mapped(b, offset, size, "buffer_download"));
     uzu_hip_context* ctx = b->ctx;
     (void)hipSetDevice(ctx->device);
     size_t done = 0;
@@ -294,6 +495,8 @@ uzu_status uzu_hip_cmdbuf_encode_barrier(uzu_hip_cmdbuf* cb) { return cmdbuf_che
 uzu_status uzu_hip_cmdbuf_push_debug_group(uzu_hip_cmdbuf* cb, const char* name) {
     UZU_PROPAGATE(cmdbuf_check_encoding(cb));
     cb->debug_groups.push_back(name ? name : "");
+    cb->all_groups.push_back(name ? name : "");
+    roctx_push(name ? name : "");
     return UZU_OK;
 }
 
@@ -301,6 +504,7 @@ uzu_status uzu_hip_cmdbuf_pop_debug_group(uzu_hip_cmdbuf* cb) {
     UZU_PROPAGATE(cmdbuf_check_encoding(cb));
     UZU_REQUIRE(!cb->debug_groups.empty(), "pop_debug_group: no open group");
     cb->debug_groups.pop_back();
+    roctx_pop();
     return UZU_OK;
 }
 
@@ -340,6 +544,7 @@ uzu_status uzu_hip_cmdbuf_wait_until_completed(uzu_hip_cmdbuf* cb) {
     UZU_HIP_TRY(hipEventSynchronize(cb->ev_end));
     UZU_HIP_TRY(hipEventElapsedTime(&cb->last_ms, cb->ev_start, cb->ev_end));
     cb->state = CmdbufState::Completed;
+    if (cb->ctx->capture_active) cb->ctx->capture_records.push_back({cb->name, cb->all_groups, (double)cb->last_ms});
     return UZU_OK;
 }
 
