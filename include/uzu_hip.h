@@ -133,7 +133,7 @@ void uzu_hip_kernel_destroy(uzu_hip_kernel* k);
 typedef enum { UZU_MATMUL_B_FULL_PRECISION = 0, UZU_MATMUL_B_SCALE_BIAS = 1, UZU_MATMUL_B_SCALE_ZERO_POINT = 2,
                UZU_MATMUL_B_SCALE_SYMMETRIC = 3 } uzu_matmul_b_kind;
 typedef struct {
-    /* MatmulA::FullPrecision { values, offset(elements) }  (Int8Symmetric: UZU_ERR_UNSUPPORTED, "next") */
+    /* MatmulA::FullPrecision { values, offset(elements) }; for MatmulA::Int8Symmetric see a_kind at the end of the struct */
     uzu_buf a;
     size_t a_offset_elements;
     /* MatmulB */
@@ -152,15 +152,36 @@ typedef struct {
     float ab_scale;
     uint32_t accumulate;
     uzu_buf bias;             /* weights dtype [n] */
-    uzu_buf rht_factors;      /* UZU_ERR_UNSUPPORTED if present ("next") */
+    uzu_buf rht_factors;      /* i32 [n] sign factors: output RHT in place on D after the store, THEN the bias (kernel.rs:296-303) */
     uint32_t has_soft_cap;
     float soft_cap;
     uzu_buf gather_indices;   /* u32 [m,n] */
     uint32_t m, n, k;
+    /* MatmulA (matmul_a.rs:3-14): a_kind 0 = FullPrecision (a, a_offset_elements above); 1 = Int8Symmetric { values = a (i8
+     * [m,k]), scales = a_scales (f32 [m, k / a_group_size]), group_sums = a_group_sums (i32, optional: accepted, the kernel sums on
+     * the fly), group_size = a_group_size (32 / 64 / 128; weight groups 32 / 64 / 128) } -- else MatmulError::IncompatibleA. */
+    uint32_t a_kind;
+    uzu_buf a_scales;
+    uzu_buf a_group_sums;
+    uint32_t a_group_size;
 } uzu_matmul_arguments;
 uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint32_t input_dt, uint32_t output_dt,
                                  uzu_hip_kernel** out);
 uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* args);
+
+/* ---- ActivationTransform (cpu/kernel/activation_transform/activation_transform.rs:43-60): randomised Hadamard transform over
+ * stripes of 32 elements with +-1 factors (i32 [element_count]), optionally followed by symmetric int8 quantisation.
+ * new(context, T, ops, in_place, activation_scale_group_size, sum_group_size); encode(input?, fp_out?, q_out?, scales_out?,
+ * group_sums_out?, rht_factors, batch_size, element_count).  Optional buffers follow the #[optional] conditions of the
+ * reference: input iff !in_place; fp_out iff ops is an RHT op; q_out / scales_out iff a Quantize op; group_sums_out iff
+ * QuantizeWithGroupSums. */
+typedef enum { UZU_ACTIVATION_TRANSFORM_INPUT_RHT = 0, UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT = 1, UZU_ACTIVATION_TRANSFORM_QUANTIZE = 2,
+               UZU_ACTIVATION_TRANSFORM_QUANTIZE_WITH_GROUP_SUMS = 3 } uzu_activation_transform_op; /* gpu_types/activation_transform.rs */
+uzu_status uzu_hip_activation_transform_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t in_place,
+                                               uint32_t activation_scale_group_size, uint32_t sum_group_size, uzu_hip_kernel** out);
+uzu_status uzu_hip_activation_transform_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf fp_out, uzu_buf q_out,
+                                               uzu_buf scales_out, uzu_buf group_sums_out, uzu_buf rht_factors, uint32_t batch_size,
+                                               uint32_t element_count);
 
 /* ---- Normalization (BU/../cpu/kernel/normalization/normalization.rs:7-39) */
 uzu_status uzu_hip_normalization_create(uzu_hip_context* ctx, uint32_t input_t, uint32_t affine_t, uint32_t output_t,

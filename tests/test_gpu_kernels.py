@@ -895,3 +895,149 @@ def test_attention_gemm_core(hip_ctx, heads, kv_heads, hd, prefix, suffix):
     err = np.abs(f32(want) - f32(got))
     assert err.max() <= 1e-2
     assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------ RHT / A8
+@pytest.mark.parametrize("op", [B.ATX_INPUT_RHT, B.ATX_OUTPUT_RHT])
+@pytest.mark.parametrize("rows,cols,in_place", [(1, 1024, True), (37, 3584, False), (5, 96, True)])
+def test_activation_transform_rht_bit_exact(hip_ctx, op, rows, cols, in_place):
+    """ActivationTransform InputRht / OutputRht (activation_transform.rs:43-136): every addition of the 32-point butterfly is the
+    reference's own, so the result is bit-identical to the CPU kernel; in place and out of place."""
+    rng = np.random.default_rng(rows + cols + op)
+    x = bf16(rng.normal(0, 1.5, (rows, cols)))
+    factors = rng.choice(np.array([-1, 1], np.int32), cols)
+    want = x.copy() if in_place else np.zeros_like(x)
+    O.lib().orc_activation_transform(None if in_place else O.p(x), O.p(want), None, None, None, O.p(factors), O.BF16, rows, cols, op, 0, 0)
+    kern = B.ActivationTransformKernel.new(hip_ctx, B.BF16, op, int(in_place), 0, 0)
+    bx, bf_ = hip_ctx.buffer_from(x), hip_ctx.buffer_from(factors)
+    bo = bx if in_place else hip_ctx.create_buffer(x.nbytes)
+    run(hip_ctx, lambda cb: kern.encode(None if in_place else bx, bo, None, None, None, bf_, rows, cols, cb))
+    assert np.array_equal(bo.download(np.uint16, x.size).reshape(x.shape), want)
+
+
+@pytest.mark.parametrize("scale_group,sum_group", [(32, 32), (64, 128), (128, 64), (128, 128)])
+def test_activation_transform_quantize_bit_exact(hip_ctx, scale_group, sum_group):
+    """Quantize / QuantizeWithGroupSums: int8 codes, f32 divisors and i32 group sums identical to the CPU kernel (the divisor is one
+    IEEE division of the exact group maximum; codes are round-half-away of one IEEE division)."""
+    rng = np.random.default_rng(scale_group * 7 + sum_group)
+    rows, cols = 19, 2048
+    x = bf16(rng.normal(0, 2.0, (rows, cols)))
+    x[3, :256] = 0
+    factors = rng.choice(np.array([-1, 1], np.int32), cols)
+    for op in (B.ATX_QUANTIZE, B.ATX_QUANTIZE_WITH_GROUP_SUMS):
+        wq, wsc, wgs = np.zeros((rows, cols), np.int8), np.zeros((rows, cols // scale_group), np.float32), np.zeros((rows, cols // sum_group), np.int32)
+        O.lib().orc_activation_transform(O.p(x), None, O.p(wq), O.p(wsc), O.p(wgs), O.p(factors), O.BF16, rows, cols, op, scale_group, sum_group)
+        kern = B.ActivationTransformKernel.new(hip_ctx, B.BF16, op, 0, scale_group, sum_group)
+        bx, bf_ = hip_ctx.buffer_from(x), hip_ctx.buffer_from(factors)
+        bq, bs, bg = hip_ctx.create_buffer(wq.nbytes), hip_ctx.create_buffer(wsc.nbytes), hip_ctx.create_buffer(wgs.nbytes)
+        sums = bg if op == B.ATX_QUANTIZE_WITH_GROUP_SUMS else None
+        run(hip_ctx, lambda cb: kern.encode(bx, None, bq, bs, sums, bf_, rows, cols, cb))
+        assert np.array_equal(bs.download(np.float32, wsc.size).reshape(wsc.shape), wsc)
+        assert np.array_equal(bq.download(np.int8, wq.size).reshape(wq.shape), wq)
+        if sums is not None:
+            assert np.array_equal(bg.download(np.int32, wgs.size).reshape(wgs.shape), wgs)
+
+
+@pytest.mark.parametrize("bits,method,group_size,a_group", [(4, 0, 128, 128), (4, 1, 64, 32), (4, 2, 32, 64), (8, 0, 128, 64), (8, 1, 64, 128)])
+@pytest.mark.parametrize("m,n,k", [(1, 1024, 1024), (70, 200, 512), (256, 3072, 1024)])
+def test_matmul_int8_symmetric_activations(hip_ctx, bits, method, group_size, a_group, m, n, k):
+    """MatmulA::Int8Symmetric (matmul_a.rs:9-14; CPU semantics kernel.rs:190-200) against the CPU restatement: the integer part of
+    every 32-element step is exact, the f32 scaling is summation-order class: <= 1 bf16 ulp (the reference's own CPU-vs-GPU bar for
+    quantised matmuls is rel 0.05 / abs 0.4, quant_dispatch_test.rs:124)."""
+    rng = np.random.default_rng(bits * 100 + method * 10 + m)
+    q = quant_matrix(rng, n, k, bits, group_size, method)
+    x = bf16(rng.normal(0, 1.0, (m, k)))
+    factors = rng.choice(np.array([-1, 1], np.int32), k)
+    a_q, a_s = np.zeros((m, k), np.int8), np.zeros((m, k // a_group), np.float32)
+    O.lib().orc_activation_transform(O.p(x), None, O.p(a_q), O.p(a_s), None, O.p(factors), O.BF16, m, k, 2, a_group, 0)
+    bias = bf16(rng.normal(0, 0.2, n))
+    want = np.zeros((m, n), np.uint16)
+    args = O.MatmulArgs()
+    args.a, args.a_dtype = None, O.BF16
+    args.a_q, args.a_scales, args.a_group_size = a_q.ctypes.data, a_s.ctypes.data, a_group
+    args.b, args.scales = q["weights"].ctypes.data, q["scales"].ctypes.data
+    args.biases = q["biases"].ctypes.data if q["biases"] is not None else None
+    args.zero_points = q["zero_points"].ctypes.data if q["zero_points"] is not None else None
+    args.w_dtype, args.method, args.bits, args.group_size = O.BF16, method, bits, group_size
+    args.d, args.d_dtype, args.ab_scale, args.bias = want.ctypes.data, O.BF16, 1.0, bias.ctypes.data
+    args.m, args.n, args.k = m, n, k
+    O.lib().orc_matmul(C.byref(args))
+    kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
+    ba, bs_, bw, bsc, bd, bb = (hip_ctx.buffer_from(a_q), hip_ctx.buffer_from(a_s), hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"]),
+                                hip_ctx.create_buffer(want.nbytes), hip_ctx.buffer_from(bias))
+    bbi = hip_ctx.buffer_from(q["biases"]) if q["biases"] is not None else None
+    bzp = hip_ctx.buffer_from(q["zero_points"]) if q["zero_points"] is not None else None
+    run(hip_ctx, lambda cb: kern.encode(cb, a=ba, b=bw, d=bd, m=m, n=n, k=k, b_kind=method + 1, scales=bsc, biases=bbi, zero_points=bzp,
+                                        mode=B.QMODE_U4 if bits == 4 else B.QMODE_U8, group_size=group_size, bias=bb, a_int8_scales=bs_, a_group_size=a_group))
+    got = bd.download(np.uint16, want.size).reshape(want.shape)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (ulps == 0).mean() >= 0.97
+
+
+def test_matmul_output_rht_then_bias_and_the_rht_linear_chain(hip_ctx):
+    """MatmulDOps::rht_factors (d_ops.rs:3-9; kernel.rs:296-303): the output RHT runs in place on D after the store and the bias is
+    added after it.  Then the whole RHTLinearWrapper chain of the reference (linear/rht_wrapper.rs:215-298) through the C ABI:
+    InputRht in place on the activations -> quantised matmul -> OutputRht -> bias, against the same chain of CPU kernels;
+    and the A8 form of it (Quantize -> Int8Symmetric matmul -> OutputRht -> bias)."""
+    rng = np.random.default_rng(3)
+    m, n, k, g = 9, 1024, 2048, 128
+    q = quant_matrix(rng, n, k, 4, g, 0)
+    x = bf16(rng.normal(0, 1.0, (m, k)))
+    fin, fout = rng.choice(np.array([-1, 1], np.int32), k), rng.choice(np.array([-1, 1], np.int32), n)
+    bias = bf16(rng.normal(0, 0.2, n))
+
+    def oracle_chain(a8):
+        args = O.MatmulArgs()
+        xr = x.copy()
+        if a8:
+            a_q, a_s = np.zeros((m, k), np.int8), np.zeros((m, k // g), np.float32)
+            O.lib().orc_activation_transform(O.p(x), None, O.p(a_q), O.p(a_s), None, O.p(fin), O.BF16, m, k, 2, g, 0)
+            args.a, args.a_q, args.a_scales, args.a_group_size = None, a_q.ctypes.data, a_s.ctypes.data, g
+            keep = (a_q, a_s)
+        else:
+            O.lib().orc_activation_transform(None, O.p(xr), None, None, None, O.p(fin), O.BF16, m, k, 0, 0, 0)
+            args.a = xr.ctypes.data
+            keep = (xr,)
+        want = np.zeros((m, n), np.uint16)
+        args.a_dtype = O.BF16
+        args.b, args.scales, args.biases = q["weights"].ctypes.data, q["scales"].ctypes.data, q["biases"].ctypes.data
+        args.w_dtype, args.method, args.bits, args.group_size = O.BF16, 0, 4, g
+        args.d, args.d_dtype, args.ab_scale, args.bias, args.rht_factors = want.ctypes.data, O.BF16, 1.0, bias.ctypes.data, fout.ctypes.data
+        args.m, args.n, args.k = m, n, k
+        O.lib().orc_matmul(C.byref(args))
+        del keep
+        return want
+
+    mat = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
+    bw, bsc, bbi, bb = hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"]), hip_ctx.buffer_from(q["biases"]), hip_ctx.buffer_from(bias)
+    bfin, bfout = hip_ctx.buffer_from(fin), hip_ctx.buffer_from(fout)
+    # full-precision chain
+    bx, bd = hip_ctx.buffer_from(x), hip_ctx.create_buffer(m * n * 2)
+    rht = B.ActivationTransformKernel.new(hip_ctx, B.BF16, B.ATX_INPUT_RHT, 1, 0, 0)
+
+    def enc(cb):
+        rht.encode(None, bx, None, None, None, bfin, m, k, cb)
+        mat.encode(cb, a=bx, b=bw, d=bd, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, mode=B.QMODE_U4, group_size=g, bias=bb, rht_factors=bfout)
+    run(hip_ctx, enc)
+    want = oracle_chain(False)
+    got = bd.download(np.uint16, m * n).reshape(m, n)
+    # the transform adds 32 matmul outputs (each within 1 bf16 ulp of ITS magnitude) with signs: where they cancel, the sum's own
+    # ulp is smaller than the carried error -- a few ulps at worst, the bulk stays within one
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 4.0 and (ulps <= 1.0).mean() >= 0.98
+    # A8 chain
+    bx2, bq, bs_ = hip_ctx.buffer_from(x), hip_ctx.create_buffer(m * k), hip_ctx.create_buffer(m * (k // g) * 4)
+    quant = B.ActivationTransformKernel.new(hip_ctx, B.BF16, B.ATX_QUANTIZE, 0, g, 0)
+
+    def enc8(cb):
+        quant.encode(bx2, None, bq, bs_, None, bfin, m, k, cb)
+        mat.encode(cb, a=bq, b=bw, d=bd, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, mode=B.QMODE_U4, group_size=g, bias=bb, rht_factors=bfout,
+                   a_int8_scales=bs_, a_group_size=g)
+    run(hip_ctx, enc8)
+    want8 = oracle_chain(True)
+    got8 = bd.download(np.uint16, m * n).reshape(m, n)
+    ulps8 = ulp_diff_bf16(want8, got8)
+    assert ulps8.max() <= 4.0 and (ulps8 <= 1.0).mean() >= 0.98
+    # the two chains agree with each other within the int8 quantisation noise of the activations (~1 %)
+    assert np.abs(f32(want8) - f32(want)).max() <= 0.05 * np.abs(f32(want)).max()

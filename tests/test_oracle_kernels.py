@@ -367,3 +367,111 @@ def test_byte_accounting_matches_survey():
     dn = (8224 + 2048) * 1024
     weights = (6 * (attn + mlp) + 18 * (dn + mlp) + v * d) * per_w
     assert abs(weights - 399.4e6) / 399.4e6 < 0.01
+
+
+# ------------------------------------------------------------------------------------------ RHT / A8 (row f1)
+def hadamard32_np(v):
+    """Sylvester-ordered Walsh-Hadamard transform of 32 values / sqrt(32) -- the closed form of mod.rs:27-47's butterfly."""
+    h = np.array([[1.0]])
+    while h.shape[0] < 32:
+        h = np.block([[h, h], [h, -h]])
+    return h @ v / np.sqrt(32.0)
+
+
+def activation_transform_oracle(x_bits, factors, op, scale_group=0, sum_group=0, in_place=False):
+    rows, cols = x_bits.shape
+    fp = x_bits.copy() if in_place else np.zeros_like(x_bits)
+    q = np.zeros((rows, cols), np.int8)
+    sc = np.zeros((rows, max(cols // scale_group, 1) if scale_group else 1), np.float32)
+    gs = np.zeros((rows, max(cols // sum_group, 1) if sum_group else 1), np.int32)
+    O.lib().orc_activation_transform(None if in_place else O.p(x_bits), O.p(fp), O.p(q), O.p(sc), O.p(gs), O.p(factors), O.BF16, rows, cols, op,
+                                     scale_group, sum_group)
+    return fp, q, sc, gs
+
+
+@pytest.mark.parametrize("op", [0, 1])
+def test_activation_transform_rht_against_float64(op):
+    """InputRht: H (x * s); OutputRht: (H x) * s with the 32-point Sylvester Hadamard matrix / sqrt(32) (activation_transform.rs:
+    80-104).  The butterfly's f32 sums against the float64 closed form: <= 1 bf16 ulp after the final rounding; the transform is its
+    own inverse up to the sign placement (InputRht then OutputRht with the same factors is NOT the identity; H is)."""
+    rng = np.random.default_rng(op)
+    rows, cols = 5, 96
+    x = bf16(rng.normal(0, 1, (rows, cols)))
+    factors = rng.choice(np.array([-1, 1], np.int32), cols)
+    fp, _, _, _ = activation_transform_oracle(x, factors, op)
+    xf = f32(x).astype(np.float64)
+    for r in range(rows):
+        for s0 in range(0, cols, 32):
+            blk, sg = xf[r, s0:s0 + 32], factors[s0:s0 + 32].astype(np.float64)
+            want = hadamard32_np(blk * sg) if op == 0 else hadamard32_np(blk) * sg
+            assert np.abs(f32(fp[r, s0:s0 + 32]) - want).max() <= np.abs(want).max() * 2.0 ** -7
+    # in place == out of place
+    fp2, _, _, _ = activation_transform_oracle(x, factors, op, in_place=True)
+    assert np.array_equal(fp, fp2)
+
+
+@pytest.mark.parametrize("scale_group,sum_group", [(32, 32), (64, 128), (128, 64)])
+def test_activation_transform_quantize_against_numpy(scale_group, sum_group):
+    """Quantize / QuantizeWithGroupSums (activation_transform.rs:11-41, mod.rs:9-25): divisor = max |v| / 127 per activation group (1.0
+    for an all-zero group), codes = round-half-away(v / divisor) clamped to +-127, i32 code sums per sum group."""
+    rng = np.random.default_rng(scale_group)
+    rows, cols = 4, 256
+    x = bf16(rng.normal(0, 2, (rows, cols)))
+    x[1, :128] = 0  # an all-zero activation group keeps divisor 1.0
+    factors = rng.choice(np.array([-1, 1], np.int32), cols)
+    _, q, sc, gs = activation_transform_oracle(x, factors, 3, scale_group, sum_group)
+    _, q2, sc2, _ = activation_transform_oracle(x, factors, 2, scale_group, sum_group)
+    assert np.array_equal(q, q2) and np.array_equal(sc, sc2)
+    xf = f32(x).astype(np.float64)
+    t = np.zeros((rows, cols))
+    for r in range(rows):
+        for s0 in range(0, cols, 32):
+            t[r, s0:s0 + 32] = hadamard32_np(xf[r, s0:s0 + 32] * factors[s0:s0 + 32])
+    for r in range(rows):
+        for g in range(cols // scale_group):
+            blk = t[r, g * scale_group:(g + 1) * scale_group]
+            mag = np.abs(blk).max()
+            div = mag / 127.0 if mag > 0 else 1.0
+            assert abs(sc[r, g] - div) <= 1e-6 * max(div, 1e-30) + (0 if mag > 0 else 0)
+            codes = q[r, g * scale_group:(g + 1) * scale_group].astype(np.int64)
+            assert np.abs(codes).max() <= 127
+            # the f32 butterfly can sit one f32 ulp off the float64 value: allow a code to differ by 1 only on an exact .5 boundary
+            ideal = blk / float(sc[r, g])
+            assert np.abs(codes - ideal).max() <= 0.5 + 1e-3
+    for r in range(rows):
+        assert np.array_equal(gs[r], q[r].astype(np.int32).reshape(-1, sum_group).sum(axis=1))
+    assert sc[1, 0] == 1.0 and not q[1, :scale_group].any()
+
+
+@pytest.mark.parametrize("bits,method", [(4, 0), (4, 1), (8, 2)])
+def test_matmul_int8_activations_and_output_rht_against_float64(bits, method):
+    """MatmulA::Int8Symmetric (kernel.rs:190-200): A = q * scale per activation group; MatmulDOps::rht_factors (kernel.rs:296-303):
+    OutputRht on D, then the bias.  Against float64 over the dequantised operands."""
+    rng = np.random.default_rng(bits + method)
+    m, n, k, ag = 3, 64, 256, 64
+    qm = quant_matrix(rng, n, k, bits, 128, method)
+    a_q = rng.integers(-127, 128, (m, k), dtype=np.int8)
+    a_s = rng.uniform(0.001, 0.02, (m, k // ag)).astype(np.float32)
+    bias = bf16(rng.normal(0, 0.1, n))
+    factors = rng.choice(np.array([-1, 1], np.int32), n)
+    d = np.zeros((m, n), np.uint16)
+    args = O.MatmulArgs()
+    args.a, args.a_dtype = None, O.BF16
+    args.a_q, args.a_scales, args.a_group_size = a_q.ctypes.data, a_s.ctypes.data, ag
+    args.b, args.scales = qm["weights"].ctypes.data, qm["scales"].ctypes.data
+    args.biases = qm["biases"].ctypes.data if qm["biases"] is not None else None
+    args.zero_points = qm["zero_points"].ctypes.data if qm["zero_points"] is not None else None
+    args.w_dtype, args.method, args.bits, args.group_size = O.BF16, method, bits, 128
+    args.d, args.d_dtype, args.ab_scale = d.ctypes.data, O.BF16, 1.0
+    args.bias, args.rht_factors = bias.ctypes.data, factors.ctypes.data
+    args.m, args.n, args.k = m, n, k
+    O.lib().orc_matmul(C.byref(args))
+    A = a_q.astype(np.float64) * np.repeat(a_s.astype(np.float64), ag, axis=1)
+    plain = A @ dequantize(qm).T
+    plain = f32(bf16(plain.astype(np.float32))).astype(np.float64)  # the matmul stores D before the transform
+    want = np.zeros((m, n))
+    for r in range(m):
+        for s0 in range(0, n, 32):
+            want[r, s0:s0 + 32] = hadamard32_np(plain[r, s0:s0 + 32]) * factors[s0:s0 + 32]
+    want = f32(bf16(want.astype(np.float32))).astype(np.float64) + f32(bias).astype(np.float64)
+    assert np.abs(f32(d) - want).max() <= 0.03 * np.abs(want).max()

@@ -56,6 +56,7 @@ class MatmulArguments(C.Structure):
         ("ab_scale", C.c_float), ("accumulate", C.c_uint32), ("bias", Buf), ("rht_factors", Buf),
         ("has_soft_cap", C.c_uint32), ("soft_cap", C.c_float), ("gather_indices", Buf),
         ("m", C.c_uint32), ("n", C.c_uint32), ("k", C.c_uint32),
+        ("a_kind", C.c_uint32), ("a_scales", Buf), ("a_group_sums", Buf), ("a_group_size", C.c_uint32),
     ]
 
 

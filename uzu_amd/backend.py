@@ -273,12 +273,27 @@ class MatmulKernel(_Kernel):
                b_kind: int = B_FULL_PRECISION, scales: BufArg = None, biases: BufArg = None, zero_points: BufArg = None,
                mode: int = QMODE_U4, group_size: int = 0, signed_codes: bool = False, b_leading_dimension: Optional[int] = None,
                b_transpose: bool = True, ab_scale: float = 1.0, accumulate: bool = False, bias: BufArg = None,
-               rht_factors: BufArg = None, soft_cap: Optional[float] = None, gather_indices: BufArg = None):
+               rht_factors: BufArg = None, soft_cap: Optional[float] = None, gather_indices: BufArg = None,
+               a_int8_scales: BufArg = None, a_group_sums: BufArg = None, a_group_size: int = 0):
+        """`a_int8_scales` given => MatmulA::Int8Symmetric { values = a, scales, group_sums, group_size } (matmul_a.rs:9-14)."""
         args = MatmulArguments(
             _buf(a), a_offset, b_kind, _buf(b), _buf(scales), _buf(biases), _buf(zero_points), mode, group_size, int(signed_codes),
             int(b_leading_dimension is not None), b_leading_dimension or 0, int(b_transpose), _buf(d), ab_scale, int(accumulate),
-            _buf(bias), _buf(rht_factors), int(soft_cap is not None), soft_cap or 0.0, _buf(gather_indices), m, n, k)
+            _buf(bias), _buf(rht_factors), int(soft_cap is not None), soft_cap or 0.0, _buf(gather_indices), m, n, k,
+            int(a_int8_scales is not None), _buf(a_int8_scales), _buf(a_group_sums), a_group_size)
         self._enc(encoder, C.byref(args))
+
+
+ATX_INPUT_RHT, ATX_OUTPUT_RHT, ATX_QUANTIZE, ATX_QUANTIZE_WITH_GROUP_SUMS = 0, 1, 2, 3
+
+
+class ActivationTransformKernel(_Kernel):
+    """new(ctx, T, ops, in_place, activation_scale_group_size, sum_group_size) (activation_transform.rs:43-60)"""
+    _create, _encode = "uzu_hip_activation_transform_create", "uzu_hip_activation_transform_encode"
+
+    def encode(self, input, fp_out, q_out, scales_out, group_sums_out, rht_factors, batch_size, element_count, encoder):
+        self._enc(encoder, _buf(input), _buf(fp_out), _buf(q_out), _buf(scales_out), _buf(group_sums_out), _buf(rht_factors), _u(batch_size),
+                  _u(element_count))
 
 
 class NormalizationKernel(_Kernel):

@@ -13,7 +13,7 @@ namespace {
 
 enum KernelKind : uint32_t {
     KK_MATMUL = 1, KK_NORMALIZATION, KK_QKV_NORM, KK_ATTENTION_PREPARE, KK_ATTENTION_SINGLE_PASS, KK_ATTENTION_TWO_PASS1,
-    KK_ATTENTION_TWO_PASS2, KK_ATTENTION_GEMM, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
+    KK_ATTENTION_TWO_PASS2, KK_ATTENTION_GEMM, KK_ACTIVATION_TRANSFORM, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
     KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
     KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
 };
@@ -66,7 +66,9 @@ uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint
 uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* a) {
     UZU_PROPAGATE(check(k, KK_MATMUL, cb));
     UZU_REQUIRE(a && a->a.buffer && a->b.buffer && a->d.buffer, "matmul: a, b and d are required");
-    UZU_UNSUPPORTED(a->rht_factors.buffer != nullptr, "matmul: output-RHT epilogue (UnsupportedDOp RHT) is not implemented on the hip path yet");
+    UZU_REQUIRE(a->a_kind <= 1u, "matmul: unknown MatmulA kind %u", a->a_kind);
+    const bool post_rht = a->rht_factors.buffer != nullptr;
+    UZU_REQUIRE(!post_rht || a->n % 32u == 0, "matmul: output RHT needs n %% 32 == 0 (Hadamard block), got %u", a->n);
     k::MatmulParams p{};
     const size_t in_sz = k->t[1] == UZU_F32 ? 4 : 2;
     p.a = (const char*)bptr(a->a) + a->a_offset_elements * in_sz;
@@ -75,7 +77,7 @@ uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uz
     p.biases = bptr(a->biases);
     p.zero_points = (const uint8_t*)bptr(a->zero_points);
     p.d = bptr(a->d);
-    p.bias = bptr(a->bias);
+    p.bias = post_rht ? nullptr : bptr(a->bias); // bias_after_rht (kernel.rs:167)
     p.gather = (const uint32_t*)bptr(a->gather_indices);
     p.w_dt = k->t[0], p.a_dt = k->t[1], p.d_dt = k->t[2];
     p.b_kind = a->b_kind;
@@ -97,7 +99,44 @@ uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uz
     UZU_UNSUPPORTED(a->mode == UZU_QMODE_I8, "matmul: I8 quantization mode is not a weight-matrix mode (weight_matrix.rs:60-68)");
     p.bits = a->mode == UZU_QMODE_U4 ? 4 : 8;
     UZU_UNSUPPORTED(a->group_size == 0, "matmul: group size must be non-zero (MatmulError::UnsupportedGroupSize)");
-    return k::matmul(cb_stream(cb), p, cb->ctx->num_cus);
+    if (a->a_kind == 1u) { // MatmulA::Int8Symmetric
+        UZU_REQUIRE(a->a_scales.buffer, "matmul: Int8Symmetric activations need their scales");
+        UZU_REQUIRE(a->a_offset_elements == 0, "matmul: Int8Symmetric activations carry no element offset");
+        UZU_PROPAGATE(k::matmul_a8(cb_stream(cb), p, (const int8_t*)bptr(a->a), (const float*)bptr(a->a_scales), a->a_group_size));
+    } else {
+        UZU_PROPAGATE(k::matmul(cb_stream(cb), p, cb->ctx->num_cus));
+    }
+    if (post_rht) { // kernel.rs:296-303: OutputRht in place on D, then TensorAddBias
+        UZU_PROPAGATE(k::activation_transform(cb_stream(cb), nullptr, p.d, nullptr, nullptr, nullptr, (const int32_t*)bptr(a->rht_factors), k->t[2], a->m, a->n, 1u, 0u, 0u));
+        if (a->bias.buffer) UZU_PROPAGATE(k::tensor_add_bias(cb_stream(cb), p.d, bptr(a->bias), p.d, k->t[2], k->t[0], a->n, a->m * a->n));
+    }
+    return UZU_OK;
+}
+
+// ------------------------------------------------------------------------------------- ActivationTransform
+uzu_status uzu_hip_activation_transform_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t in_place, uint32_t activation_scale_group_size,
+                                               uint32_t sum_group_size, uzu_hip_kernel** out) {
+    REQ_DT(t, "activation_transform");
+    UZU_REQUIRE(ops <= UZU_ACTIVATION_TRANSFORM_QUANTIZE_WITH_GROUP_SUMS, "activation_transform: unknown op %u", ops);
+    UZU_REQUIRE(!in_place || ops <= UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, "activation_transform: a Quantize op cannot be in place (it has no fp_out)");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_ACTIVATION_TRANSFORM, out, &k));
+    k->t[0] = t;
+    k->f[0] = ops, k->f[1] = in_place, k->f[2] = activation_scale_group_size, k->f[3] = sum_group_size;
+    return UZU_OK;
+}
+uzu_status uzu_hip_activation_transform_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf fp_out, uzu_buf q_out, uzu_buf scales_out,
+                                               uzu_buf group_sums_out, uzu_buf rht_factors, uint32_t batch_size, uint32_t element_count) {
+    UZU_PROPAGATE(check(k, KK_ACTIVATION_TRANSFORM, cb));
+    const uint32_t ops = k->f[0];
+    const bool in_place = k->f[1] != 0, rht = ops <= UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, sums = ops == UZU_ACTIVATION_TRANSFORM_QUANTIZE_WITH_GROUP_SUMS;
+    UZU_REQUIRE(rht_factors.buffer, "activation_transform: rht_factors are required");
+    UZU_REQUIRE((input.buffer == nullptr) == in_place, "activation_transform: input presence must equal !in_place");
+    UZU_REQUIRE((fp_out.buffer != nullptr) == rht, "activation_transform: fp_out presence must equal (ops is an RHT op)");
+    UZU_REQUIRE((q_out.buffer != nullptr) == !rht && (scales_out.buffer != nullptr) == !rht, "activation_transform: q_out / scales_out presence must equal (ops is a Quantize op)");
+    UZU_REQUIRE((group_sums_out.buffer != nullptr) == sums, "activation_transform: group_sums_out presence must equal QuantizeWithGroupSums");
+    return k::activation_transform(cb_stream(cb), bptr(input), bptr(fp_out), (int8_t*)bptr(q_out), (float*)bptr(scales_out), (int32_t*)bptr(group_sums_out),
+                                   (const int32_t*)bptr(rht_factors), k->t[0], batch_size, element_count, ops, k->f[2], k->f[3]);
 }
 
 // ------------------------------------------------------------------------------------- Normalization

@@ -27,6 +27,17 @@ template <class T> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return round_bf16(v); }
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 
+// run-time typed element access (bf16 / f32 selected by a DataType value)
+__device__ __forceinline__ float ldt(const void* p, uint32_t dt, size_t i) {
+    return dt == UZU_F32 ? ((const float*)p)[i] : bf16_to_f32(((const uint16_t*)p)[i]);
+}
+__device__ __forceinline__ void stt(void* p, uint32_t dt, size_t i, float v) {
+    if (dt == UZU_F32)
+        ((float*)p)[i] = v;
+    else
+        ((uint16_t*)p)[i] = f32_to_bf16(v);
+}
+
 constexpr int kWave = 64; // CDNA wavefront
 
 // Native vector types for values that are HELD IN REGISTERS across other code (software-pipeline stages): HIP's

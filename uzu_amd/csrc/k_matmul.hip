@@ -28,16 +28,6 @@
 namespace uzu {
 namespace k {
 
-__device__ __forceinline__ float ldt(const void* p, uint32_t dt, size_t i) {
-    return dt == UZU_F32 ? ((const float*)p)[i] : bf16_to_f32(((const uint16_t*)p)[i]);
-}
-__device__ __forceinline__ void stt(void* p, uint32_t dt, size_t i, float v) {
-    if (dt == UZU_F32)
-        ((float*)p)[i] = v;
-    else
-        ((uint16_t*)p)[i] = f32_to_bf16(v);
-}
-
 // epilogue in the reference's order (kernel.rs:281-292)
 __device__ __forceinline__ void epilogue_store(const MatmulParams& p, uint32_t row, uint32_t col, float accumulator) {
     const size_t output_index = (size_t)row * p.n + col;

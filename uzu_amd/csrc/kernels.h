@@ -125,6 +125,12 @@ uzu_status tensor_copy(hipStream_t s, const void* src, void* dst, uint32_t dt, u
 uzu_status argmax(hipStream_t s, const void* logits, uint32_t dt, uint32_t* output, uint32_t vocab_size,
                   uint32_t batch_size, void* scratch);
 size_t argmax_scratch_bytes(uint32_t batch_size);
+// ActivationTransform (k_activation_transform.hip): op 0 InputRht, 1 OutputRht, 2 Quantize, 3 QuantizeWithGroupSums; input null = in place
+uzu_status activation_transform(hipStream_t s, const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
+                                const int32_t* rht_factors, uint32_t dt, uint32_t batch_size, uint32_t element_count, uint32_t op,
+                                uint32_t activation_scale_group_size, uint32_t sum_group_size);
+// MatmulA::Int8Symmetric: p.a is ignored, the activations are a_q [m,k] int8 with a_scales [m, k / a_group_size]
+uzu_status matmul_a8(hipStream_t s, const MatmulParams& p, const int8_t* a_q, const float* a_scales, uint32_t a_group_size);
 // UnifiedSampling with any of: grammar bitmask, temperature, top-k / top-p / min-p, Gumbel-max noise (k_sampling.hip).
 // `scratch` (unified_sampling_scratch_bytes) is only used when no filter is set (two-level arg-max over 256 workgroups).
 struct UnifiedSamplingParams {
