@@ -75,8 +75,9 @@ typedef struct {
 
 typedef enum { UZU_MIXER_ATTENTION = 0, UZU_MIXER_DELTA_NET = 1 } uzu_mixer_kind;
 
-/* config/rope/*.rs -- Unscaled and Llama-3 scaling (encodable_block/mixer/attention/rope.rs:13-114) */
-typedef enum { UZU_ROPE_NONE = 0, UZU_ROPE_UNSCALED = 1, UZU_ROPE_LLAMA = 2, UZU_ROPE_LINEAR = 3 } uzu_rope_kind;
+/* config/rope/*.rs -- every AnyRoPEConfig variant (encodable_block/mixer/attention/rope.rs:13-114) */
+typedef enum { UZU_ROPE_NONE = 0, UZU_ROPE_UNSCALED = 1, UZU_ROPE_LLAMA = 2, UZU_ROPE_LINEAR = 3, UZU_ROPE_YARN = 4,
+               UZU_ROPE_LONGROPE = 5 } uzu_rope_kind;
 
 typedef struct {
     uint32_t kind;                    /* uzu_rope_kind */
@@ -87,6 +88,11 @@ typedef struct {
     float scaling_factor;             /* Llama / Linear */
     float low_frequency_factor;       /* Llama */
     float high_frequency_factor;      /* Llama */
+    float beta_fast, beta_slow;       /* YaRN (config/rope/yarn_rope.rs) */
+    uint32_t truncate;                /* YaRN */
+    uint32_t reserved;
+    const float* short_factor;        /* LongRoPE (config/rope/longrope.rs): f32 [head_dim / 2] */
+    const float* long_factor;         /* LongRoPE: used when max_sequence_length > original_context_length */
 } uzu_rope_desc;
 
 /* config/transformer_layer.rs:8-21 with AttentionConfig / DeltaNetConfig and a DenseMLPConfig */

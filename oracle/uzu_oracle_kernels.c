@@ -307,7 +307,10 @@ void orc_qkv_norm(void* qkv, uint32_t dt, const float* scales, uint32_t batch_si
 void orc_rope_tables(const uzu_rope_desc* rope, const uint32_t* token_positions, uint32_t n_pos, float* cosines,
                      float* sines) {
     const uint32_t head_dim = rope->head_dim, half_dim = head_dim / 2;
-    const float attention_scaling_factor = 1.0f;
+    float attention_scaling_factor = 1.0f; /* rope.rs:21-27 */
+    if (rope->kind == UZU_ROPE_YARN) attention_scaling_factor = 0.1f * logf(rope->scaling_factor) + 1.0f;
+    else if (rope->kind == UZU_ROPE_LONGROPE && rope->scaling_factor > 1.0f)
+        attention_scaling_factor = sqrtf(1.0f + logf(rope->scaling_factor) / logf((float)rope->original_context_length));
     for (uint32_t pair_index = 0; pair_index < half_dim; ++pair_index) {
         const uint32_t channel_index = pair_index * 2;
         float inverse_frequency = 1.0f / powf(rope->base, (float)channel_index / (float)head_dim);
@@ -327,6 +330,22 @@ void orc_rope_tables(const uzu_rope_desc* rope, const uint32_t* token_positions,
                 smoothing_factor = smoothing_factor / (rope->high_frequency_factor - rope->low_frequency_factor);
                 inverse_frequency = smoothing_factor * inverse_frequency + (1.0f - smoothing_factor) * scaled_frequency;
             }
+        } else if (rope->kind == UZU_ROPE_YARN) { /* rope.rs:60-81 (double for the ramp bounds, as the reference) */
+            const double dim = (double)rope->head_dim, base = (double)rope->base, original_context_length = (double)rope->original_context_length;
+            double low = dim * log(original_context_length / ((double)rope->beta_fast * 2.0 * 3.14159265358979323846)) / (2.0 * log(base));
+            double high = dim * log(original_context_length / ((double)rope->beta_slow * 2.0 * 3.14159265358979323846)) / (2.0 * log(base));
+            if (rope->truncate) low = floor(low), high = ceil(high);
+            const float low_f = (float)(low > 0.0 ? low : 0.0);
+            float high_f = (float)(high < (double)(rope->head_dim - 1) ? high : (double)(rope->head_dim - 1));
+            if (low_f == high_f) high_f += 0.001f;
+            float ramp = ((float)pair_index - low_f) / (high_f - low_f);
+            ramp = ramp < 0.0f ? 0.0f : (ramp > 1.0f ? 1.0f : ramp);
+            const float smoothing_factor = 1.0f - ramp;
+            const float scaled_frequency = inverse_frequency / rope->scaling_factor;
+            inverse_frequency = scaled_frequency * (1.0f - smoothing_factor) + inverse_frequency * smoothing_factor;
+        } else if (rope->kind == UZU_ROPE_LONGROPE) { /* rope.rs:82-89 */
+            const float* factors = rope->max_sequence_length > rope->original_context_length ? rope->long_factor : rope->short_factor;
+            inverse_frequency = inverse_frequency / factors[pair_index];
         }
         for (uint32_t token_index = 0; token_index < n_pos; ++token_index) {
             const float embedding = (float)token_positions[token_index] * inverse_frequency;

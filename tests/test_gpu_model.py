@@ -179,8 +179,9 @@ def test_qwen35_0p8b_full_size(hip_ctx):
     cfg = S.qwen35_0p8b(max_context_length=1024, seed=42)
     # 24 layers of bf16 residual-stream arithmetic: 1-ulp differences per kernel (summation order) grow to a few
     # percent of the final hidden state, measured max 0.35 sigma / mean 0.05 sigma on the row-normalised logits
-    # (tools/fullsize_check.py); the 4-layer toy models stay below 0.1 sigma.  Tolerance here: 0.5 sigma.
-    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 128, 8, logit_tol=0.5)
+    # (tools/fullsize_check.py, round 1; the committed bench-config fixture measures 0.154 sigma over its top-8 logits in round 2);
+    # the 4-layer toy models stay below 0.1 sigma.  Tolerance here: 0.3 sigma.
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 128, 8, logit_tol=0.3)
     assert min(run_pair.gaps) >= 0.5, f"test premise: oracle top-2 gaps {run_pair.gaps}"
     assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
 
@@ -196,19 +197,40 @@ def test_llama3_8b_shapes_two_layers(hip_ctx, bits, method):
 
 
 
+@pytest.mark.parametrize("variant", ["yarn", "longrope"])
+def test_rope_variants_yarn_and_longrope(hip_ctx, variant):
+    """The engine's host RoPE tables for the YaRN and LongRoPE configurations (rope.rs:21-27,60-89): same tokens and logits
+    (tolerance) as the oracle on an attention-only model; the tables themselves are the same C arithmetic on both sides."""
+    hd = 64
+    if variant == "yarn":
+        rope = D.RopeConfig(kind=D.ROPE_YARN, head_dim=hd, max_sequence_length=8192, base=10000.0, scaling_factor=4.0,
+                            original_context_length=1024, beta_fast=32.0, beta_slow=1.0, truncate=True)
+    else:
+        rng = np.random.default_rng(1)
+        rope = D.RopeConfig(kind=D.ROPE_LONGROPE, head_dim=hd, max_sequence_length=8192, base=10000.0, scaling_factor=8.0,
+                            original_context_length=1024, short_factor=rng.uniform(1.0, 1.2, hd // 2).astype(np.float32),
+                            long_factor=rng.uniform(1.0, 6.0, hd // 2).astype(np.float32))
+    cfg = S.tiny_llama(rope=rope, seed=46)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 29, 6, teacher_forced=True)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+
+
 # ------------------------------------------------------------------------------------------ committed full-size fixtures
-NEAR_TIE_SIGMA = 0.3  # a top-2 gap below this many logit standard deviations is inside the bf16 pipeline's noise (measured max
-#                       full-size logit error: 0.35 sigma over 248k logits, typically 0.05 at a given logit)
+def check_against_fixture(hip_ctx, name, flags=0, logit_tol=0.25):
+    """HIP engine vs a committed oracle fixture (tests/golden/make_fullsize.py).  All comparisons are in ROW-NORMALISED units:
+    the synthetic read-out rows carry log-normal multipliers m_i (peaked logits), logit i and its error both scale with m_i, and
+    the tokens that compete for the arg-max are exactly the rows with the largest multipliers -- so a raw top-2 gap says little
+    about how decidable a step is.  `logit_tol` = allowed |logit_hip - logit_oracle| / m_i in units of the normalised row's standard
+    deviation (measured worst case over the fixtures: printed by the test).
 
-
-def check_against_fixture(hip_ctx, name, flags=0, logit_tol=0.5):
-    """HIP engine vs a committed oracle fixture (tests/golden/make_fullsize.py), in two passes over the same weights:
-    (1) chained greedy decode exactly as bench.py runs it (hipGraph replay, fused kernels, the sampled token fed back on the
-        device): the token stream must equal the oracle's up to -- and not necessarily including -- the first step whose
-        oracle top-2 gap is a near-tie (< NEAR_TIE_SIGMA); after such a step the two streams may legitimately part;
-    (2) teacher-forced over ALL steps (the oracle's token is fed in, so every step is an independent comparison): the top-8
-        logits of the oracle are matched within `logit_tol` sigma and the arg-max is identical wherever the gap is not a
-        near-tie."""
+    (1) teacher-forced over ALL steps (the oracle's token is fed in, every step is an independent comparison): the oracle's
+        top-8 logits are matched within `logit_tol`; the HIP arg-max is the oracle's token, or a token of the oracle's top-8 whose
+        ORACLE logit lies within the tolerance band of the oracle's top (a step the reference itself decides by less than the
+        numerical noise of a bf16 pipeline);
+    (2) chained greedy decode exactly as bench.py runs it (hipGraph replay, fused kernels, the sampled token fed back on the
+        device): the token stream equals the oracle's up to the first step of kind "decided by less than the tolerance";
+        from there on the two streams may legitimately part."""
     fx = json.load(open(os.path.join(GOLDEN, f"fullsize_{name}.json")))
     kw = dict(fx["config"])
     cfg = S.PRESETS[fx["preset"]](**kw)
@@ -217,41 +239,53 @@ def check_against_fixture(hip_ctx, name, flags=0, logit_tol=0.5):
     row_mult = S.readout_row_multipliers(cfg)
     prompt = S.synthetic_prompt(fx["prompt_len"], cfg.vocab_size)
     rows = fx["rows"]
-    hm = HipModel(hip_ctx, bundle, flags)
-    # pass 1: chained
-    first = hm.prefill(prompt)
-    toks, _ = hm.decode(fx["steps"])
-    got = [first] + [int(t) for t in toks]
-    safe = 0
-    while safe < len(rows) and rows[safe]["gap_sigma"] >= NEAR_TIE_SIGMA:
-        safe += 1
-    safe = min(safe + 1, len(rows))  # the near-tie step's own INPUT is still the common prefix; its output may differ
     want = [r["token"] for r in rows]
-    assert got[:safe - 1] == want[:safe - 1], f"chained greedy stream differs before the first near-tie (step {safe - 1})\noracle {want}\nhip    {got}"
-    assert hm.context_length == fx["prompt_len"] + fx["steps"]
-    # pass 2: teacher-forced, logits of the oracle's top-8
-    hm.reset()
+    hm = HipModel(hip_ctx, bundle, flags)
+
+    def within_band(r, tok, sigma):
+        """is `tok` one of the oracle's top-8 whose oracle logit is within the tolerance band of the oracle's top logit?"""
+        top = {t: float(f32(np.array([b], np.uint16))[0]) for t, b in r["top8"]}
+        if tok not in top:
+            return False
+        best = r["top8"][0][0]
+        band = logit_tol * sigma * (row_mult[best] + row_mult[tok])
+        return top[best] - top[tok] <= band
+
+    # pass 1: teacher-forced
     hm.prefill(prompt)
-    worst = 0.0
-    exact_argmax = 0
+    worst, exact_argmax, undecided = 0.0, 0, []
     for step, r in enumerate(rows):
         if step > 0:
             hm.set_next_token(rows[step - 1]["token"])
             hm.decode(1)
         lg = f32(hm.read_logits()).astype(np.float64)
-        sigma = (lg / row_mult).std()  # row-normalised, as in logits_close(): logit i and its error scale with multiplier i
+        sigma = (lg / row_mult).std()
         for tok, bits in r["top8"]:
             err = abs(lg[tok] - float(f32(np.array([bits], np.uint16))[0])) / row_mult[tok] / sigma
             worst = max(worst, err)
-            assert err <= logit_tol, f"{name} step {step}: logit of token {tok} off by {err:.3f} sigma"
+            assert err <= logit_tol, f"{name} step {step}: logit of token {tok} off by {err:.3f} sigma (row-normalised)"
         amax = int(np.argmax(lg))
-        if r["gap_sigma"] >= NEAR_TIE_SIGMA:
-            assert amax == r["token"], f"{name} step {step}: arg-max {amax} != oracle {r['token']} at gap {r['gap_sigma']} sigma"
-        exact_argmax += amax == r["token"]
+        if amax == r["token"]:
+            exact_argmax += 1
+        else:
+            assert within_band(r, amax, sigma), f"{name} step {step}: arg-max {amax} != oracle {r['token']} and outside the {logit_tol} sigma band"
+            undecided.append(step)
+    # pass 2: chained, bench mode
+    hm.reset()
+    first = hm.prefill(prompt)
+    toks, _ = hm.decode(fx["steps"])
+    got = [first] + [int(t) for t in toks]
+    assert hm.context_length == fx["prompt_len"] + fx["steps"]
+    common = 0
+    while common < len(want) and got[common] == want[common]:
+        common += 1
+    if common < len(want):
+        assert common in undecided, (f"{name}: chained greedy stream leaves the oracle's at step {common}, which the teacher-forced pass decided "
+                                     f"clearly (undecided steps: {undecided})\noracle {want}\nhip    {got}")
     hm.close()
-    print(f"fixture {name}: chained prefix {safe - 1} tokens identical, teacher-forced arg-max identical in {exact_argmax}/{len(rows)} steps, "
-          f"worst top-8 logit error {worst:.3f} sigma")
-    return got, want, worst
+    print(f"fixture {name}: teacher-forced arg-max identical in {exact_argmax}/{len(rows)} steps (within-band: {undecided}), worst top-8 logit error "
+          f"{worst:.3f} sigma (row-normalised), chained stream identical for the first {common} of {len(want)} tokens")
+    return got, want, worst, common
 
 
 def test_qwen_bench_config_matches_oracle_fixture(hip_ctx):
@@ -259,9 +293,9 @@ def test_qwen_bench_config_matches_oracle_fixture(hip_ctx):
     prefill chunks), then chained greedy decode at context 2040+ through the captured two-pass graph with the fused decode
     kernels (attn_dec<256, 4> with 64 KV splits, gemv_dec, delta_dec).  Oracle side: tests/golden/fullsize_qwen_bench.json
     (28 CPU-minutes, committed).  The synthetic stream visits >= 12 distinct tokens."""
-    got, want, worst = check_against_fixture(hip_ctx, "qwen_bench")
+    got, want, worst, common = check_against_fixture(hip_ctx, "qwen_bench")
     assert len(set(want)) >= 12
-    assert worst <= 0.5
+    assert common >= 8
 
 
 @pytest.mark.parametrize("name", ["llama_int4", "llama_int8"])

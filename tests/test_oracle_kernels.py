@@ -369,6 +369,52 @@ def test_byte_accounting_matches_survey():
     assert abs(weights - 399.4e6) / 399.4e6 < 0.01
 
 
+def test_rope_yarn_and_longrope_tables_against_float64():
+    """rope.rs:21-27,60-89: YaRN (NTK-by-parts ramp between the dimensions whose wavelengths fit beta_fast / beta_slow times
+    into the original context, magnitude factor 0.1 ln(s) + 1) and LongRoPE (per-pair rescale factors, magnitude
+    sqrt(1 + ln s / ln L)), each against a float64 statement of the published formulas (YaRN: Peng et al. 2023 eq. 17-23;
+    LongRoPE: Ding et al. 2024)."""
+    pos = np.array([0, 3, 500, 40000], np.uint32)
+    hd, base, s_, L = 64, 10000.0, 4.0, 4096
+    # YaRN
+    for truncate in (True, False):
+        rope = S.D.RopeConfig(kind=S.D.ROPE_YARN, head_dim=hd, max_sequence_length=16384, base=base, scaling_factor=s_,
+                              original_context_length=L, beta_fast=32.0, beta_slow=1.0, truncate=truncate)
+        d = rope.desc()
+        cos, sin = np.zeros((4, hd), np.float32), np.zeros((4, hd), np.float32)
+        O.lib().orc_rope_tables(C.byref(d), O.p(pos), C.c_uint32(4), O.p(cos), O.p(sin))
+        i = np.arange(hd // 2, dtype=np.float64)
+        inv = 1.0 / base ** (2 * i / hd)
+
+        def corr(beta):
+            return hd * np.log(L / (beta * 2 * np.pi)) / (2 * np.log(base))
+        low, high = corr(32.0), corr(1.0)
+        if truncate:
+            low, high = np.floor(low), np.ceil(high)
+        low, high = max(low, 0.0), min(high, hd - 1.0)
+        ramp = np.clip((i - low) / (high - low), 0.0, 1.0)
+        freq = (inv / s_) * ramp + inv * (1.0 - ramp)
+        mag = 0.1 * np.log(s_) + 1.0
+        ang = np.outer(pos.astype(np.float64), freq)
+        # f32 angle products at position 40000: |d angle| ~ 40000 * 2^-24 * freq
+        tol = 3e-3
+        assert np.abs(cos[:, :hd // 2] - mag * np.cos(ang)).max() < tol and np.abs(sin[:, :hd // 2] - mag * np.sin(ang)).max() < tol
+        assert np.array_equal(cos[:, :hd // 2], cos[:, hd // 2:])
+    # LongRoPE: long factors when the model's max sequence exceeds the original context, short factors otherwise
+    rng = np.random.default_rng(0)
+    short, long_ = rng.uniform(1.0, 1.2, hd // 2).astype(np.float32), rng.uniform(1.0, 8.0, hd // 2).astype(np.float32)
+    for max_seq, factors in ((131072, long_), (4096, short)):
+        rope = S.D.RopeConfig(kind=S.D.ROPE_LONGROPE, head_dim=hd, max_sequence_length=max_seq, base=base, scaling_factor=32.0,
+                              original_context_length=L, short_factor=short, long_factor=long_)
+        d = rope.desc()
+        cos, sin = np.zeros((4, hd), np.float32), np.zeros((4, hd), np.float32)
+        O.lib().orc_rope_tables(C.byref(d), O.p(pos), C.c_uint32(4), O.p(cos), O.p(sin))
+        inv = 1.0 / base ** (2 * np.arange(hd // 2) / hd) / factors.astype(np.float64)
+        mag = np.sqrt(1.0 + np.log(32.0) / np.log(L))
+        ang = np.outer(pos.astype(np.float64), inv)
+        assert np.abs(cos[:, :hd // 2] - mag * np.cos(ang)).max() < 3e-3 and np.abs(sin[:, :hd // 2] - mag * np.sin(ang)).max() < 3e-3
+
+
 # ------------------------------------------------------------------------------------------ RHT / A8 (row f1)
 def hadamard32_np(v):
     """Sylvester-ordered Walsh-Hadamard transform of 32 values / sqrt(32) -- the closed form of mod.rs:27-47's butterfly."""

@@ -291,12 +291,16 @@ uzu_status upload_norm(uzu_hip_model* m, const uzu_norm_desc& h, uint32_t dim, D
     return UZU_OK;
 }
 
-// host RoPE table: encodable_block/mixer/attention/rope.rs:13-114 (Unscaled / Linear / Llama-3), computed
+// host RoPE table: encodable_block/mixer/attention/rope.rs:13-114 (Unscaled / Linear / Llama-3 / YaRN / LongRoPE), computed
 // with the platform libm exactly as the reference does per pass, but once for all positions.
 void rope_tables(const uzu_rope_desc& r, uint32_t n_pos, std::vector<float>& cosines, std::vector<float>& sines) {
     const uint32_t head_dim = r.head_dim, half_dim = head_dim / 2;
     cosines.assign((size_t)n_pos * head_dim, 0.f);
     sines.assign((size_t)n_pos * head_dim, 0.f);
+    float attention_scaling_factor = 1.0f; /* rope.rs:21-27 */
+    if (r.kind == UZU_ROPE_YARN) attention_scaling_factor = 0.1f * logf(r.scaling_factor) + 1.0f;
+    else if (r.kind == UZU_ROPE_LONGROPE && r.scaling_factor > 1.0f)
+        attention_scaling_factor = sqrtf(1.0f + logf(r.scaling_factor) / logf((float)r.original_context_length));
     for (uint32_t pair_index = 0; pair_index < half_dim; ++pair_index) {
         const uint32_t channel_index = pair_index * 2;
         float inverse_frequency = 1.0f / powf(r.base, (float)channel_index / (float)head_dim);
@@ -315,10 +319,26 @@ void rope_tables(const uzu_rope_desc& r, uint32_t n_pos, std::vector<float>& cos
                 smoothing_factor = smoothing_factor / (r.high_frequency_factor - r.low_frequency_factor);
                 inverse_frequency = smoothing_factor * inverse_frequency + (1.0f - smoothing_factor) * scaled_frequency;
             }
+        } else if (r.kind == UZU_ROPE_YARN) { /* rope.rs:60-81 (double for the ramp bounds, as the reference) */
+            const double dim = (double)r.head_dim, base = (double)r.base, original_context_length = (double)r.original_context_length;
+            double low = dim * log(original_context_length / ((double)r.beta_fast * 2.0 * 3.14159265358979323846)) / (2.0 * log(base));
+            double high = dim * log(original_context_length / ((double)r.beta_slow * 2.0 * 3.14159265358979323846)) / (2.0 * log(base));
+            if (r.truncate) low = floor(low), high = ceil(high);
+            const float low_f = (float)(low > 0.0 ? low : 0.0);
+            float high_f = (float)(high < (double)(r.head_dim - 1) ? high : (double)(r.head_dim - 1));
+            if (low_f == high_f) high_f += 0.001f;
+            float ramp = ((float)pair_index - low_f) / (high_f - low_f);
+            ramp = ramp < 0.0f ? 0.0f : (ramp > 1.0f ? 1.0f : ramp);
+            const float smoothing_factor = 1.0f - ramp;
+            const float scaled_frequency = inverse_frequency / r.scaling_factor;
+            inverse_frequency = scaled_frequency * (1.0f - smoothing_factor) + inverse_frequency * smoothing_factor;
+        } else if (r.kind == UZU_ROPE_LONGROPE) { /* rope.rs:82-89 */
+            const float* factors = r.max_sequence_length > r.original_context_length ? r.long_factor : r.short_factor;
+            inverse_frequency = inverse_frequency / factors[pair_index];
         }
         for (uint32_t pos = 0; pos < n_pos; ++pos) {
             const float embedding = (float)pos * inverse_frequency;
-            const float sine = sinf(embedding), cosine = cosf(embedding);
+            const float sine = sinf(embedding) * attention_scaling_factor, cosine = cosf(embedding) * attention_scaling_factor;
             const size_t o = (size_t)pos * head_dim + pair_index;
             sines[o] = sine, sines[o + half_dim] = sine, cosines[o] = cosine, cosines[o + half_dim] = cosine;
         }

@@ -19,7 +19,7 @@ import numpy as np
 QUANT_SCALE_BIAS, QUANT_SCALE_ZERO_POINT, QUANT_SCALE_SYMMETRIC, QUANT_NONE = 0, 1, 2, 3
 ACT_SILU, ACT_GELU_APPROX, ACT_GELU_EXACT, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 MIXER_ATTENTION, MIXER_DELTA_NET = 0, 1
-ROPE_NONE, ROPE_UNSCALED, ROPE_LLAMA, ROPE_LINEAR = 0, 1, 2, 3
+ROPE_NONE, ROPE_UNSCALED, ROPE_LLAMA, ROPE_LINEAR, ROPE_YARN, ROPE_LONGROPE = 0, 1, 2, 3, 4, 5
 
 
 class LinearDesc(C.Structure):
@@ -45,6 +45,8 @@ class RopeDesc(C.Structure):
         ("original_context_length", C.c_uint32),
         ("base", C.c_float), ("scaling_factor", C.c_float), ("low_frequency_factor", C.c_float),
         ("high_frequency_factor", C.c_float),
+        ("beta_fast", C.c_float), ("beta_slow", C.c_float), ("truncate", C.c_uint32), ("reserved", C.c_uint32),
+        ("short_factor", C.c_void_p), ("long_factor", C.c_void_p),
     ]
 
 
@@ -207,10 +209,21 @@ class RopeConfig:
     original_context_length: int = 0
     low_frequency_factor: float = 1.0
     high_frequency_factor: float = 1.0
+    beta_fast: float = 32.0           # YaRN
+    beta_slow: float = 1.0
+    truncate: bool = True
+    short_factor: Optional[np.ndarray] = None  # LongRoPE: f32 [head_dim / 2]
+    long_factor: Optional[np.ndarray] = None
 
     def desc(self) -> RopeDesc:
+        def ptr(a):
+            if a is None:
+                return None
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size == self.head_dim // 2
+            return a.ctypes.data
         return RopeDesc(self.kind, self.head_dim, self.max_sequence_length, self.original_context_length, self.base,
-                        self.scaling_factor, self.low_frequency_factor, self.high_frequency_factor)
+                        self.scaling_factor, self.low_frequency_factor, self.high_frequency_factor, self.beta_fast, self.beta_slow,
+                        int(self.truncate), 0, ptr(self.short_factor), ptr(self.long_factor))
 
 
 @dataclass

@@ -82,9 +82,9 @@ def qwen35_0p8b(max_context_length: int = 4096, **kw) -> ModelConfig:
         norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
         bits=4, group_size=128, method=D.QUANT_SCALE_BIAS, tied_embeddings=True,
         max_context_length=max_context_length,
-        # seed 568: the greedy stream of the 2040-token synthetic prompt keeps moving (19 distinct tokens in 25, every top-2
-        # gap >= 0.5 sigma) instead of falling into a fixed point after a few steps as most seeds do (tools/seed_search.py: 9 of 500)
-        seed=568)
+        # seed 45: the greedy stream of the 2040-token synthetic prompt keeps moving (12 distinct tokens in 25 in the CPU
+        # restatement) instead of falling into a fixed point after a few steps as most seeds do (tools/seed_search.py)
+        seed=45)
     return replace(cfg, **kw)
 
 
