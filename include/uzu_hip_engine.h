@@ -49,6 +49,20 @@ typedef struct uzu_hip_tp_comm uzu_hip_tp_comm;
 uzu_status uzu_hip_tp_unique_id(uint8_t out[128]);
 uzu_status uzu_hip_tp_comm_create(uzu_hip_context* ctx, const uint8_t id[128], int32_t rank, int32_t size, uzu_hip_tp_comm** out);
 void uzu_hip_tp_comm_destroy(uzu_hip_tp_comm* comm);
+/* One-shot peer-to-peer exchange for the decode-sized all-reduces (<= 32 KB: the 4-20 KB rows after out-proj / down-proj and
+ * the 8-byte arg-max key), csrc/tp.hip: every rank exports a mailbox (hipIpc handle, 64 bytes), the handles travel over any
+ * host channel, every rank opens the others'; an all-reduce is then ONE kernel per rank -- push to all mailboxes, publish a
+ * sequence number, poll the local mailbox, add in rank order (bit-identical on all ranks) -- and can be captured in a
+ * hipGraph.  Larger messages (prefill) keep using RCCL.  uzu_hip_tp_comm_create_local makes a group without an RCCL
+ * communicator (P2P exchanges only).  uzu_hip_tp_p2p_error returns the sequence number of an exchange whose bounded wait
+ * (2 s) for a peer gave up, 0 if none. */
+uzu_status uzu_hip_tp_comm_create_local(uzu_hip_context* ctx, int32_t rank, int32_t size, uzu_hip_tp_comm** out);
+uzu_status uzu_hip_tp_p2p_export(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uint8_t out_handle[64]);
+uzu_status uzu_hip_tp_p2p_connect(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, const uint8_t* handles /* [size][64] */);
+void uzu_hip_tp_p2p_disable(uzu_hip_tp_comm* comm); /* back to RCCL for every size (all ranks must agree on the path) */
+uzu_status uzu_hip_tp_p2p_error(uzu_hip_tp_comm* comm, uint32_t* out);
+uzu_status uzu_hip_tp_all_reduce_sum_f32(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count);
+uzu_status uzu_hip_tp_all_reduce_max_u64(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count);
 /* `comm` may be NULL (single GPU; identical to uzu_hip_model_create).  The communicator must outlive the model. */
 uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_tp_comm* comm,
                                    uint32_t vocab_offset, uzu_hip_model** out);

@@ -197,6 +197,16 @@ def test_llama3_8b_shapes_two_layers(hip_ctx, bits, method):
 
 
 
+def test_qwen3_14b_class_shapes_two_layers(hip_ctx):
+    """BASELINE configs[4] at its real matrix shapes (d 5120, ffn 17408 -> the LDS-resident-row GEMV path, 40 q / 8 kv heads of
+    128 with q/k norm, vocab 151 936, untied read-out) but 2 of the 40 layers: 40-token prefill + 5 decode steps, teacher-forced,
+    arg-max identical wherever the oracle's top-2 gap is not a near-tie."""
+    cfg = S.qwen3_14b_class(max_context_length=256, layer_kinds=[D.MIXER_ATTENTION] * 2)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 40, 5, teacher_forced=True)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.1, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+
+
 @pytest.mark.parametrize("variant", ["yarn", "longrope"])
 def test_rope_variants_yarn_and_longrope(hip_ctx, variant):
     """The engine's host RoPE tables for the YaRN and LongRoPE configurations (rope.rs:21-27,60-89): same tokens and logits

@@ -303,3 +303,24 @@ def test_full_size_shard_shapes_execute(hip_ctx, size):
     assert model.logit_count == cfg.vocab_size // size
     model.close()
     group.close()
+
+
+@pytest.mark.gpu
+def test_p2p_all_reduce_two_processes_one_gpu(tmp_path):
+    """The one-shot peer-to-peer all-reduce of the decode-sized messages (csrc/tp.hip): two PROCESSES share GPU 0, export their
+    mailboxes as hipIpc handles, open each other's, and run the exchange kernels concurrently -- f32 sums in rank order
+    (bit-identical on both ranks, equal to the host's rank-order sum), the u64 arg-max key, and a captured exchange replayed
+    as a hipGraph (the sequence number advances on the device)."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), "2", str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("p2p workers timed out")
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

@@ -1277,6 +1277,37 @@ uzu_status uzu_hip_tp_comm_create(uzu_hip_context* ctx, const uint8_t id[128], i
     return UZU_OK;
 }
 void uzu_hip_tp_comm_destroy(uzu_hip_tp_comm* comm) { uzu::tp::comm_destroy((uzu::tp::Comm*)comm); }
+uzu_status uzu_hip_tp_comm_create_local(uzu_hip_context* ctx, int32_t rank, int32_t size, uzu_hip_tp_comm** out) {
+    UZU_REQUIRE(ctx && out, "tp_comm_create_local: null argument");
+    (void)hipSetDevice(ctx->device);
+    uzu::tp::Comm* c = nullptr;
+    UZU_PROPAGATE(uzu::tp::comm_create_local(rank, size, &c));
+    *out = (uzu_hip_tp_comm*)c;
+    return UZU_OK;
+}
+uzu_status uzu_hip_tp_p2p_export(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uint8_t out_handle[64]) {
+    UZU_REQUIRE(ctx && comm, "tp_p2p_export: null argument");
+    (void)hipSetDevice(ctx->device);
+    return uzu::tp::p2p_export((uzu::tp::Comm*)comm, out_handle);
+}
+uzu_status uzu_hip_tp_p2p_connect(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, const uint8_t* handles) {
+    UZU_REQUIRE(ctx && comm, "tp_p2p_connect: null argument");
+    (void)hipSetDevice(ctx->device);
+    return uzu::tp::p2p_connect((uzu::tp::Comm*)comm, handles);
+}
+void uzu_hip_tp_p2p_disable(uzu_hip_tp_comm* comm) { uzu::tp::p2p_disable((uzu::tp::Comm*)comm); }
+uzu_status uzu_hip_tp_p2p_error(uzu_hip_tp_comm* comm, uint32_t* out) { return uzu::tp::p2p_error((uzu::tp::Comm*)comm, out); }
+// stand-alone collective entry points (tests, tools): in place on device buffers of the context's stream
+uzu_status uzu_hip_tp_all_reduce_sum_f32(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count) {
+    UZU_REQUIRE(ctx && comm && buf && offset_bytes + count * 4 <= buf->size, "tp_all_reduce_sum_f32: bad argument");
+    (void)hipSetDevice(ctx->device);
+    return uzu::tp::all_reduce_sum_f32((uzu::tp::Comm*)comm, ctx->stream, (float*)((char*)buf->dptr + offset_bytes), count);
+}
+uzu_status uzu_hip_tp_all_reduce_max_u64(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count) {
+    UZU_REQUIRE(ctx && comm && buf && offset_bytes + count * 8 <= buf->size, "tp_all_reduce_max_u64: bad argument");
+    (void)hipSetDevice(ctx->device);
+    return uzu::tp::all_reduce_max_u64((uzu::tp::Comm*)comm, ctx->stream, (unsigned long long*)((char*)buf->dptr + offset_bytes), count);
+}
 uint32_t uzu_hip_model_logit_count(const uzu_hip_model* m) { return m ? (m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n) : 0; }
 
 } // extern "C"

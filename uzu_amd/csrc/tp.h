@@ -17,6 +17,14 @@ void comm_destroy(Comm* c);
 int comm_rank(const Comm* c);
 int comm_size(const Comm* c);
 
+// one-shot peer-to-peer exchange for messages <= 32 KB (tp.hip): export this rank's mailbox, open the peers'
+uzu_status p2p_export(Comm* c, uint8_t out_handle[64]);
+uzu_status p2p_connect(Comm* c, const uint8_t* handles);
+bool p2p_connected(const Comm* c);
+void p2p_disable(Comm* c);
+uzu_status p2p_error(Comm* c, uint32_t* out);
+uzu_status comm_create_local(int rank, int size, Comm** out); // no RCCL communicator: P2P exchanges only (tests; small groups)
+
 uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count);          // in place
 uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count);
 

@@ -131,10 +131,106 @@ __global__ void commit_key_kernel(const unsigned long long* key, uint32_t* ctx_l
 }
 } // namespace
 
+// ---- one-shot peer-to-peer all-reduce for the decode-sized messages (4-20 KB) ------------------------------------------------
+// A ring all-reduce of a 4 KB row is pure latency: 2 (N - 1) dependent hops plus RCCL's launch protocol, ~48 times per token.
+// On one node every GPU can write every other GPU's memory over xGMI, so the exchange collapses to ONE hop: every rank owns a
+// MAILBOX (device memory exported with hipIpcGetMemHandle, opened by the peers with hipIpcOpenMemHandle); an all-reduce is one
+// kernel per rank that
+//   1. pushes its vector into slot [parity][rank] of EVERY rank's mailbox (its own included), 16-byte stores,
+//   2. publishes: system-scope fence, then the sequence number into flag [parity][rank] of every mailbox,
+//   3. polls the flags of its OWN mailbox (local memory) until all ranks' sequence numbers have arrived -- bounded spin,
+//   4. adds the size vectors in RANK ORDER (the same order on every rank => bit-identical results everywhere).
+// Two parities: a rank can run at most one exchange ahead of the slowest peer (it needs that peer's contribution to finish
+// the current one), so slot p of exchange n is free again by exchange n + 2.  The sequence number lives in device memory and is
+// advanced by the kernel itself, so the launch is a plain kernel node: the TP decode step can be captured and replayed as a
+// hipGraph.  Mailboxes are allocated uncached (hipDeviceMallocUncached): remote writes must be seen by the owner's polls.
+constexpr uint32_t kMailboxFloats = 8192;   // capacity per (parity, rank) slot: 32 KB (d_model <= 8192; keys use 2 words)
+constexpr uint32_t kMaxRanks = 8;
+struct Mailbox {
+    float data[2][kMaxRanks][kMailboxFloats];
+    uint32_t flags[2][kMaxRanks][16]; // one 64-byte line per flag
+    uint32_t seq[16];                 // this rank's exchange counter (device-resident)
+    uint32_t error[16];               // set when a bounded spin gave up
+};
+struct P2P {
+    Mailbox* local = nullptr;
+    Mailbox* peer[kMaxRanks] = {nullptr};
+    bool connected = false;
+};
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
+    P2P p2p;
 };
+
+namespace {
+struct P2PArgs {
+    Mailbox* box[kMaxRanks];
+    int rank, size;
+};
+// OP 0: f32 sum over `count` floats (in place on buf); OP 1: u64 max over `count` keys (buf = unsigned long long*)
+template <int OP>
+__global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* buf, uint32_t count) {
+    __shared__ uint32_t s_seq, s_ok;
+    Mailbox* mine = a.box[a.rank];
+    const uint32_t tid = threadIdx.x, words = OP == 0 ? count : 2 * count;
+    if (tid == 0) s_seq = mine->seq[0] + 1u, s_ok = 1u;
+    __syncthreads();
+    const uint32_t seq = s_seq, par = seq & 1u;
+    // 1. push
+    const uint32_t* src = (const uint32_t*)buf;
+    for (int r = 0; r < a.size; ++r) {
+        uint32_t* dst = (uint32_t*)a.box[r]->data[par][a.rank];
+        for (uint32_t i = tid * 4; i < words; i += 256 * 4) {
+            if (i + 4 <= words) __builtin_nontemporal_store(*(const u32x4_v*)(src + i), (u32x4_v*)(dst + i));
+            else for (uint32_t j = i; j < words; ++j) __builtin_nontemporal_store(src[j], dst + j);
+        }
+    }
+    // 2. publish
+    __threadfence_system();
+    __syncthreads();
+    if (tid < (uint32_t)a.size) __hip_atomic_store(&a.box[tid]->flags[par][a.rank][0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3. wait for every rank's contribution in the local mailbox (bounded: ~2 s of the 100 MHz clock)
+    if (tid < (uint32_t)a.size) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&mine->flags[par][tid][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                s_ok = 0u;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    if (!s_ok) {
+        if (tid == 0) mine->error[0] = seq;
+        return; // leave buf untouched: the host sees the error flag
+    }
+    // 4. reduce in rank order
+    if (OP == 0) {
+        float* out = (float*)buf;
+        for (uint32_t i = tid; i < count; i += 256) {
+            float acc = __builtin_nontemporal_load(&mine->data[par][0][i]);
+            for (int r = 1; r < a.size; ++r) acc += __builtin_nontemporal_load(&mine->data[par][r][i]);
+            out[i] = acc;
+        }
+    } else {
+        unsigned long long* out = (unsigned long long*)buf;
+        for (uint32_t i = tid; i < count; i += 256) {
+            unsigned long long best = 0;
+            for (int r = 0; r < a.size; ++r) {
+                const unsigned long long v = __builtin_nontemporal_load((const unsigned long long*)mine->data[par][r] + i);
+                best = v > best ? v : best;
+            }
+            out[i] = best;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) mine->seq[0] = seq;
+}
+} // namespace
 
 uzu_status unique_id(uint8_t out[128]) {
     UZU_PROPAGATE(load_api());
@@ -161,18 +257,95 @@ uzu_status comm_create(const uint8_t id_bytes[128], int rank, int size, Comm** o
     return UZU_OK;
 }
 
+uzu_status comm_create_local(int rank, int size, Comm** out) {
+    UZU_REQUIRE(size >= 1 && size <= (int)kMaxRanks && rank >= 0 && rank < size, "tp: bad rank %d of %d", rank, size);
+    Comm* c = new Comm();
+    c->rank = rank, c->size = size;
+    *out = c;
+    return UZU_OK;
+}
+
 void comm_destroy(Comm* c) {
     if (!c) return;
+    for (int r = 0; r < c->size; ++r)
+        if (r != c->rank && c->p2p.peer[r]) (void)hipIpcCloseMemHandle(c->p2p.peer[r]);
+    if (c->p2p.local) (void)hipFree(c->p2p.local);
     if (c->comm && g_api.CommDestroy) g_api.CommDestroy(c->comm);
     delete c;
+}
+
+// ---- P2P set-up: (1) every rank creates its mailbox and exports it, (2) the 64-byte handles travel over any host channel
+// (torch.distributed all_gather, a pipe ...), (3) every rank opens the others'.
+uzu_status p2p_export(Comm* c, uint8_t out_handle[64]) {
+    UZU_REQUIRE(c && out_handle, "tp_p2p_export: null argument");
+    UZU_REQUIRE(c->size <= (int)kMaxRanks, "tp_p2p: at most %u ranks", kMaxRanks);
+    if (!c->p2p.local) {
+        void* p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocUncached);
+        if (e != hipSuccess) { // older runtimes: fine-grained device memory has the same visibility guarantees
+            (void)hipGetLastError();
+            e = hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocFinegrained);
+        }
+        if (e != hipSuccess) {
+            set_error("tp_p2p: mailbox allocation failed: %s", hipGetErrorString(e));
+            return UZU_ERR_HIP;
+        }
+        UZU_HIP_TRY(hipMemset(p, 0, sizeof(Mailbox)));
+        UZU_HIP_TRY(hipDeviceSynchronize());
+        c->p2p.local = (Mailbox*)p;
+    }
+    hipIpcMemHandle_t h;
+    UZU_HIP_TRY(hipIpcGetMemHandle(&h, c->p2p.local));
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(out_handle, &h, 64);
+    return UZU_OK;
+}
+uzu_status p2p_connect(Comm* c, const uint8_t* handles /* [size][64], own entry ignored */) {
+    UZU_REQUIRE(c && handles && c->p2p.local, "tp_p2p_connect: export first");
+    for (int r = 0; r < c->size; ++r) {
+        if (r == c->rank) {
+            c->p2p.peer[r] = c->p2p.local;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            set_error("tp_p2p: cannot open rank %d's mailbox: %s", r, hipGetErrorString(e));
+            return UZU_ERR_HIP;
+        }
+        c->p2p.peer[r] = (Mailbox*)p;
+    }
+    c->p2p.connected = true;
+    return UZU_OK;
+}
+bool p2p_connected(const Comm* c) { return c && c->p2p.connected; }
+void p2p_disable(Comm* c) { // every rank of a group must take the same path: disable everywhere when one rank could not connect
+    if (c) c->p2p.connected = false;
+}
+uzu_status p2p_error(Comm* c, uint32_t* out) { // sequence number of the exchange whose bounded wait gave up (0 = none)
+    UZU_REQUIRE(c && out && c->p2p.local, "tp_p2p_error: no mailbox");
+    UZU_HIP_TRY(hipMemcpy(out, c->p2p.local->error, 4, hipMemcpyDeviceToHost));
+    return UZU_OK;
+}
+template <int OP> static uzu_status p2p_launch(Comm* c, hipStream_t s, void* buf, uint32_t count) {
+    P2PArgs a{};
+    for (int r = 0; r < c->size; ++r) a.box[r] = c->p2p.peer[r];
+    a.rank = c->rank, a.size = c->size;
+    return launch_check([&] { hipLaunchKernelGGL(p2p_all_reduce_kernel<OP>, dim3(1), dim3(256), 0, s, a, buf, count); }, "tp_p2p_all_reduce");
 }
 int comm_rank(const Comm* c) { return c->rank; }
 int comm_size(const Comm* c) { return c->size; }
 
 uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count) {
+    if (c->p2p.connected && count <= kMailboxFloats) return p2p_launch<0>(c, s, buf, (uint32_t)count); // decode rows: one hop
+    UZU_REQUIRE(c->comm, "tp: no RCCL communicator for a %zu-float all-reduce", count);
     return check(g_api.AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->comm, s), "ncclAllReduce(sum,f32)");
 }
 uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count) {
+    if (c->p2p.connected && count * 2 <= kMailboxFloats) return p2p_launch<1>(c, s, buf, (uint32_t)count);
+    UZU_REQUIRE(c->comm, "tp: no RCCL communicator");
     return check(g_api.AllReduce(buf, buf, count, ncclUint64, ncclMax, c->comm, s), "ncclAllReduce(max,u64)");
 }
 

@@ -101,6 +101,19 @@ def llama3_8b(max_context_length: int = 4096, **kw) -> ModelConfig:
     return replace(cfg, **kw)
 
 
+def qwen3_14b_class(max_context_length: int = 8192 + 1024, **kw) -> ModelConfig:
+    """BASELINE configs[4] "Qwen-14B-class int4": the public Qwen3-14B card: d 5120, 40 layers, 40 q / 8 kv
+    heads of 128, q/k RMSNorm, ffn 17408, vocab 151 936, untied read-out, RoPE base 1e6."""
+    cfg = ModelConfig(
+        name="qwen3-14b-class", vocab_size=151936, model_dim=5120, hidden_dim=17408,
+        layer_kinds=[D.MIXER_ATTENTION] * 40, num_heads=40, num_groups=8, head_dim=128, qk_norm=True,
+        rope=D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=128, max_sequence_length=40960, base=1000000.0),
+        norm_epsilon=1e-6, norm_scale_offset=0.0, norm_full_layer=False,
+        bits=4, group_size=128, method=D.QUANT_SCALE_BIAS, tied_embeddings=False,
+        max_context_length=max_context_length, seed=14)
+    return replace(cfg, **kw)
+
+
 def tiny_qwen(**kw) -> ModelConfig:
     """Same topology as Qwen3.5 (DeltaNet x3 + gated attention with q/k norm, partial rotary) at toy size."""
     cfg = ModelConfig(
@@ -126,7 +139,7 @@ def tiny_llama(**kw) -> ModelConfig:
     return replace(cfg, **kw)
 
 
-PRESETS = {"qwen3.5-0.8b": qwen35_0p8b, "llama-3-8b": llama3_8b, "tiny-qwen": tiny_qwen, "tiny-llama": tiny_llama}
+PRESETS = {"qwen3.5-0.8b": qwen35_0p8b, "llama-3-8b": llama3_8b, "qwen3-14b-class": qwen3_14b_class, "tiny-qwen": tiny_qwen, "tiny-llama": tiny_llama}
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:

@@ -214,6 +214,41 @@ class TpGroup:
         self._h = C.c_void_p()
         call("uzu_hip_tp_comm_create", ctx._h, arr, C.c_int32(rank), C.c_int32(size), C.byref(self._h))
 
+    @classmethod
+    def local(cls, ctx, rank: int, size: int) -> "TpGroup":
+        """A group without an RCCL communicator: peer-to-peer exchanges only (uzu_hip_tp_comm_create_local)."""
+        self = cls.__new__(cls)
+        self.ctx, self.rank, self.size = ctx, rank, size
+        self._h = C.c_void_p()
+        call("uzu_hip_tp_comm_create_local", ctx._h, C.c_int32(rank), C.c_int32(size), C.byref(self._h))
+        return self
+
+    def enable_p2p(self, all_gather: Callable[[bytes], List[bytes]]):
+        """One-shot peer-to-peer all-reduce for the decode-sized messages (csrc/tp.hip): export this rank's mailbox, hand the
+        64-byte IPC handle to `all_gather` (returns every rank's handle, in rank order), open the peers' mailboxes."""
+        mine = (C.c_uint8 * 64)()
+        call("uzu_hip_tp_p2p_export", self.ctx._h, self._h, mine)
+        handles = all_gather(bytes(mine))
+        assert len(handles) == self.size and all(len(h) == 64 for h in handles)
+        flat = (C.c_uint8 * (64 * self.size)).from_buffer_copy(b"".join(handles))
+        call("uzu_hip_tp_p2p_connect", self.ctx._h, self._h, flat)
+
+    def disable_p2p(self):
+        fn = _ffi.lib().uzu_hip_tp_p2p_disable
+        fn.restype, fn.argtypes = None, [C.c_void_p]
+        fn(self._h)
+
+    def p2p_error(self) -> int:
+        out = C.c_uint32()
+        call("uzu_hip_tp_p2p_error", self._h, C.byref(out))
+        return out.value
+
+    def all_reduce_sum_f32(self, buf, count: int, offset_bytes: int = 0):
+        call("uzu_hip_tp_all_reduce_sum_f32", self.ctx._h, self._h, buf._h, C.c_size_t(offset_bytes), C.c_size_t(count))
+
+    def all_reduce_max_u64(self, buf, count: int, offset_bytes: int = 0):
+        call("uzu_hip_tp_all_reduce_max_u64", self.ctx._h, self._h, buf._h, C.c_size_t(offset_bytes), C.c_size_t(count))
+
     def close(self):
         if self._h:
             _ffi.lib().uzu_hip_tp_comm_destroy(self._h)
@@ -232,6 +267,15 @@ def torch_broadcast(dist, device=None) -> Callable[[Optional[bytes]], bytes]:
         return bytes(t.cpu().tolist())
 
     return bcast
+
+
+def torch_all_gather_bytes(dist) -> Callable[[bytes], List[bytes]]:
+    """all_gather of one bytes object per rank over an initialised torch.distributed group (for TpGroup.enable_p2p)."""
+    def gather(mine: bytes) -> List[bytes]:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, mine)
+        return out
+    return gather
 
 
 # ------------------------------------------------------------------------------------------------ exchange protocol
