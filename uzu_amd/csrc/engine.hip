@@ -1012,15 +1012,14 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         uint32_t wgs = 1; // kv_heads * head-subgroups of the widest attention layer
         for (auto& L : m->layers)
             if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
-                const uint32_t gqa = L.d.num_heads / L.d.num_groups, cap = 4;
-                uint32_t gs = 1;
-                for (uint32_t c = cap; c >= 1; c >>= 1)
-                    if (gqa % c == 0) { gs = c; break; }
-                const uint32_t w = L.d.num_groups * (gqa / gs);
+                const uint32_t gqa = L.d.num_heads / L.d.num_groups;
+                const uint32_t w = L.d.num_groups * (gqa / k::attn_dec_group_size(gqa));
                 wgs = wgs > w ? wgs : w;
             }
-        // ~256 workgroups (one per CU); more splits shorten attn_dec but lengthen attn_merge (measured: 64 best at 2k context)
-        uint32_t splits = 256 / wgs;
+        // ~256 workgroups (one per CU); more splits shorten attn_dec but lengthen attn_merge (measured: 64 best at 2k context).
+        // Long contexts are latency bound on the chain of K / V batches a key group walks (4 keys each, ~1 us per batch):
+        // twice the workgroups halve it (Qwen3-14B-class at 8k: 37 us per layer with 320 workgroups of 16 batches)
+        uint32_t splits = (desc->max_context_length >= 4096 ? 512 : 256) / wgs;
         if (const char* ev = getenv("UZU_DEC_SPLITS")) splits = (uint32_t)atoi(ev);
         m->dec_splits = splits < 8 ? 8 : (splits > 128 ? 128 : splits);
         ALLOC(dec_partials, float, (size_t)max_heads * m->dec_splits * max_hd);

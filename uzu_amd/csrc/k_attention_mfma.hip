@@ -5,8 +5,10 @@
 // the suffix), output [M, heads, hd] bf16.  The stand-alone VALU kernels (k_attention.hip) spend ~45 instructions per
 // (query, key, head); at a 1024-token chunk that is the third-largest item of the prefill.  Here:
 //
-//   * a workgroup = one kv head x a tile of queries; its four waves are the (up to) four q heads of the GQA group --
-//     they share every K / V tile, staged once in LDS -- or further 32-query tiles when the group is smaller;
+//   * a workgroup = one kv head x four wave tasks; a task is (32-query tile, q head of the kv head's GQA group), tasks are
+//     numbered tile-major, so the four waves of a workgroup are four heads of one tile (GQA factor 4, 8, ...), two heads of two
+//     tiles (factor 2), four tiles (factor 1) or whatever four consecutive tasks are (factor 3, 5, 6, 7: Qwen3-14B has 40 q /
+//     8 kv heads) -- they share every K / V tile, staged once in LDS, and a wave skips the tiles past its own causal range;
 //   * everything is computed TRANSPOSED so that a lane owns one query: S^T = K Q^T (A = K rows from LDS, B = Q^T from
 //     registers), the C layout of v_mfma_f32_32x32x16_bf16 then gives a lane 16 key scores of ITS query (col = lane &
 //     31), so the online-softmax statistics are per-lane scalars (one exchange with lane ^ 32 per tile for the
@@ -41,10 +43,9 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
 } // namespace
 
-// grid: (kv_head * groups_per_kv + sub, query tiles); 256 threads.
-//   WPH = waves that are distinct q heads (min(gqa, 4)); the remaining factor 4 / WPH are extra query tiles.
+// grid: (kv heads, ceil(gqa * query tiles / 4)); 256 threads.  Workgroups with the longest key ranges are numbered first.
 template <int HD>
-__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t heads_per_wg) {
+__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out) {
     constexpr int KP = HD * 2 + 16;  // K tile row pitch in bytes (conflict-free ds_read_b128)
     constexpr int VP = TK * 2 + 8;   // V^T tile row pitch in bytes: 32 keys + 8 bytes of pad (conflict-free ds_read_b64)
     constexpr int NS = HD / 16;      // k16 steps of the QK^T contraction
@@ -53,17 +54,19 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     __shared__ __attribute__((aligned(16))) uint8_t s_vt[2][HD * VP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
-    const uint32_t tiles_per_wg = 4 / heads_per_wg; // query tiles per workgroup
-    const uint32_t groups_per_kv = a.gqa_factor / heads_per_wg;
-    const uint32_t kv_head = blockIdx.x / groups_per_kv, sub = blockIdx.x % groups_per_kv;
-    const uint32_t head = kv_head * a.gqa_factor + sub * heads_per_wg + wave % heads_per_wg;
     const uint32_t M = a.suffix_length;
+    const uint32_t kv_head = blockIdx.x;
+    const uint32_t n_tasks = a.gqa_factor * ((M + TQ - 1) / TQ);
+    const uint32_t task0 = (gridDim.y - 1 - blockIdx.y) * 4; // heaviest (last query tiles) first
+    const uint32_t task = task0 + wave;
+    const bool wave_live = task < n_tasks;
+    const uint32_t task_c = wave_live ? task : n_tasks - 1;
+    const uint32_t head = kv_head * a.gqa_factor + task_c % a.gqa_factor;
     const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
     const uint32_t prefix = sequence_length - M;
-    const uint32_t q0_wg = blockIdx.y * (TQ * tiles_per_wg);
-    const uint32_t q0 = q0_wg + (wave / heads_per_wg) * TQ; // first query of this wave
+    const uint32_t q0 = (task_c / a.gqa_factor) * TQ; // first query of this wave
     const uint32_t qi = q0 + l32;                           // this lane's query (suffix index)
-    const bool q_live = qi < M;
+    const bool q_live = wave_live && qi < M;
 
     // ---- Q^T operand: lane = (query l32, hd half): 8 consecutive hd elements per k16 step, kept in registers
     u32x4_t qf[NS];
@@ -82,8 +85,9 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     constexpr int SLICES = HD / 32;               // 32 hd elements (64 bytes) per slice
     constexpr int ROUNDS = (TK * SLICES + 255) / 256;
     u32x4_v kst[ROUNDS][4], vst[ROUNDS][4]; // native vectors + unconditional loads: stay in registers and in flight across lds_barrier()
-    // keys visible to ANY query of the workgroup: 0 .. prefix + last query of the workgroup
-    const uint32_t wg_last_q = (q0_wg + TQ * tiles_per_wg < M ? q0_wg + TQ * tiles_per_wg : M) - 1;
+    // keys visible to ANY query of the workgroup: 0 .. prefix + last query of its last live task (tasks are tile-major)
+    const uint32_t last_tile = ((task0 + 3 < n_tasks ? task0 + 3 : n_tasks - 1) / a.gqa_factor + 1) * TQ;
+    const uint32_t wg_last_q = (last_tile < M ? last_tile : M) - 1;
     const uint32_t key_end = prefix + wg_last_q + 1;
     const uint32_t n_tiles = (key_end + TK - 1) / TK;
     auto load_tile = [&](uint32_t t) {
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
         load_tile(t + 1 < n_tiles ? t + 1 : t); // unconditional: the compiler can count the loads in flight
         // a wave whose queries all end before this tile has nothing to add (causal), but must keep the barriers
         const uint32_t wave_last_key = prefix + (q0 + TQ - 1 < M ? q0 + TQ - 1 : M - 1);
-        if (q0 < M && t * TK <= wave_last_key) {
+        if (wave_live && t * TK <= wave_last_key) {
             // ---- S^T = K Q^T
             f32x16_t sacc;
 #pragma unroll
@@ -225,17 +229,15 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
     if (a.dt != UZU_BF16 || !a.is_causal || a.sinks || a.is_sliding_window || a.is_kv_cache_ring) return false;
     if (a.suffix_length < min_m || !(a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256)) return false;
     if (a.gqa_factor == 0 || a.num_heads % a.gqa_factor) return false;
-    if (a.gqa_factor > 4 ? a.gqa_factor % 4 != 0 : (4 % a.gqa_factor) != 0) return false;
     if (a.k_head_stride % 8 || a.k_seq_stride % 8 || a.v_head_stride % 8 || a.v_seq_stride % 8) return false;
     return true;
 }
 
 uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out) {
-    const uint32_t heads_per_wg = a.gqa_factor >= 4 ? 4 : a.gqa_factor;
     const uint32_t kv_heads = a.num_heads / a.gqa_factor;
-    const uint32_t q_per_wg = TQ * (4 / heads_per_wg);
-    const dim3 grid(kv_heads * (a.gqa_factor / heads_per_wg), (a.suffix_length + q_per_wg - 1) / q_per_wg);
-#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, heads_per_wg); }, "attention_prefill_mfma")
+    const uint32_t n_tasks = a.gqa_factor * ((a.suffix_length + TQ - 1) / TQ);
+    const dim3 grid(kv_heads, (n_tasks + 3) / 4);
+#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out); }, "attention_prefill_mfma")
     switch (a.head_dim) {
     case 64: UZU_LAUNCH(64);
     case 128: UZU_LAUNCH(128);

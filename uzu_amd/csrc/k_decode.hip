@@ -55,8 +55,14 @@ __device__ __forceinline__ float act_bf16(uint32_t act, float x, const uint64_t*
 //   * epilogues: plain store | SiLU(gate)*up | arg-max partial per workgroup.
 //   * PRO selects the prologue at compile time (0 plain row, 1 Normalization, 2 DeltaNet norm-gate): a run-time branch in
 //     front of the first weight loads -- even a wave-uniform one -- makes the compiler fall back to vmcnt(0) waits.
-template <int BITS, int CPLT, int R, bool ACT, int KIND, int PRO, bool CONV>
-__global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const void* a1, const void* a2, uint32_t k_arg, int lpr_log2, const uint8_t* w0,
+//   * NW = waves per workgroup.  4 everywhere except the bandwidth regime's prologue kernels (K >= 4096, >= 16 MB of weights,
+//     persistent grid): there every resident workgroup pulls the same 32 KB (x, shortcut, f32 norm scales at K = 4096) through
+//     its CU's L1 and out of the same few L2 lines -- 1280 workgroups x 32 KB: the activation vector arrives after 3-4 us and
+//     the prologue ends after 6-8 us of a 19 us kernel (Llama-3-8B up-projection, tools/timeline.py).  With 12-16 waves per
+//     workgroup (one workgroup per CU) waves 0-3 run the same 256-thread prologue (same element mapping, same reduction
+//     order: bit-identical) and the other waves only keep their weight loads in flight: a quarter of the traffic.
+template <int BITS, int CPLT, int R, bool ACT, int KIND, int PRO, bool CONV, int NW>
+__global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const void* a1, const void* a2, uint32_t k_arg, int lpr_log2, const uint8_t* w0,
                                                        const uint16_t* s0, const uint16_t* o0, DecGemvParams p) {
     // The six pointers every address computation of the first loads starts from are separate leading kernel arguments:
     // with -mllvm -amdgpu-kernarg-preload-count=12 (csrc/Makefile, this file only) the command processor places them in
@@ -75,6 +81,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
     constexpr int STEP_BYTES = 4 * BITS;
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
+    constexpr int NT = 64 * NW;
+    static_assert(NW == 4 || (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))), "wide workgroups: prologue kernels of the bandwidth regime only");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     UZU_TL_DECL;
     UZU_TL_STAMP(0);
@@ -90,7 +98,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
     const uint32_t batches0 = (n_log0 + rows_per_batch - 1) / rows_per_batch;
     const uint32_t batches1 = ACT ? 0 : (p.n[1] + rows_per_batch - 1) / rows_per_batch;
     const uint32_t num_batches = batches0 + batches1;
-    const uint32_t total_waves = gridDim.x * 4;
+    const uint32_t total_waves = gridDim.x * NW;
     const uint32_t steps_per_lane = CPLT == 0 ? (C + lpr - 1) / lpr : CPL;
     const uint32_t gshift = 31 - __builtin_clz(p.group_size); // group_size is a power of two (checked at launch)
 
@@ -100,7 +108,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
     };
     // Loads of one (batch, step) item.  Batches [0, batches0) belong to matrix 0, the rest to matrix 1 (wave-uniform:
     // the base pointers stay in SGPRs and the per-lane part of every address is a 32-bit byte offset -- host-checked).
-    const uint32_t b_own = min((uint32_t)(blockIdx.x * 4 + wave), num_batches - 1);
+    const uint32_t b_own = min((uint32_t)(blockIdx.x * NW + wave), num_batches - 1);
     auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
         // Unconditional: batch and step are clamped into range and a clamped reload is never consumed.  VMEM returns in
         // issue order and the compiler only emits counted waits (vmcnt(N)) across loads that are always issued; even a
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
             c4.bias = p.conv_b ? bias : 0.0f;
         }
     };
-    const uint32_t b0 = blockIdx.x * 4 + wave;
+    const uint32_t b0 = blockIdx.x * NW + wave;
     Item itA, itB;
     // VMEM loads return in issue order.  The activation row (written by the previous kernel: L2 / memory-side cache,
     // ~0.8 us) is needed first and the weights (HBM, ~1.3 us) only after the prologue, so the activation loads are
@@ -164,7 +172,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
     constexpr int NPRE = 2 * CPL;
     u32x2_v x_pre[NPRE], s_pre[NPRE];
     f32x4_v n_pre[NPRE];
-    if (PRO == 1) {
+    const bool pro_wave = NW == 4 || wave < 4; // the prologue is a 256-thread affair (wave-uniform)
+    if (PRO == 1 && pro_wave) {
         const uint32_t E = K / 256;
 #pragma unroll
         for (int qi = 0; qi < NPRE; ++qi) {
@@ -183,12 +192,12 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
         dg_pre[2] = *(const f32x4_v*)(p.dg_sz + e0), dg_pre[3] = *(const f32x4_v*)(p.dg_sz + e0 + 4);
         dg_pre[4] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv), dg_pre[5] = *(const f32x4_v*)(p.dg_w + e0 % p.dg_dv + 4);
     }
-    constexpr int XST = (BITS == 4 && CPLT == 0) ? 4 : 1; // steps of the LDS-resident row staged per thread (K <= 32768)
+    constexpr int XST = (BITS == 4 && CPLT == 0) ? (NT >= 1024 ? 1 : 1024 / NT) : 1; // steps of the LDS-resident row staged per thread (K <= 32768)
     gc_raw4 xrow_raw[XST][4];
     if (BITS == 4 && CPLT == 0) {
 #pragma unroll
         for (int q = 0; q < XST; ++q) {
-            const uint32_t c = min((uint32_t)tid + 256u * q, C - 1); // clamped: a re-read, never stored
+            const uint32_t c = min((uint32_t)tid + (uint32_t)NT * q, C - 1); // clamped: a re-read, never stored
             const gc_raw4* src = (const gc_raw4*)(p.x + (size_t)c * 32);
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) xrow_raw[q][w4] = src[w4];
@@ -286,6 +295,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
             float* red = smem + (size_t)C * 36;     // [4]
             const uint32_t E = K / 256;
             float ss = 0.f;
+            if (pro_wave) {
 #pragma unroll
             for (int qi = 0; qi < 2 * CPL; ++qi) {
                 const uint32_t q = (uint32_t)qi * 4;
@@ -312,10 +322,12 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
             UZU_TL_STAMP(1); // the activation vector has arrived and gone through the residual add / sum of squares
             ss = wave_sum(ss);
             if (lane == 0) red[wave] = ss;
+            }
             lds_barrier();
             const float total = ((red[0] + red[1]) + red[2]) + red[3];
             const float variance = total / (float)K - 0.0f * 0.0f;
             const float rms_inv = 1.0f / sqrtf(variance + p.norm_eps);
+            if (pro_wave) {
 #pragma unroll
             for (int qi = 0; qi < 2 * CPL; ++qi) {
                 const uint32_t q = (uint32_t)qi * 4;
@@ -340,6 +352,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
                     o.y = (f32_to_bits(v[2]) >> 16) | (f32_to_bits(v[3]) & 0xFFFF0000u);
                     *(uint2*)(p.normed_out + e) = o;
                 }
+            }
             }
             if ((ACT || CONV) && tid < 32) s_exp_tab[tid] = exp_entry; // rides on the barrier below (requested with the first loads)
             lds_barrier();
@@ -372,7 +385,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
         float* xsum = smem + (size_t)C * 20;
 #pragma unroll
         for (int q = 0; q < XST; ++q) {
-            const uint32_t c = (uint32_t)tid + 256u * q;
+            const uint32_t c = (uint32_t)tid + (uint32_t)NT * q;
             if (c < C) {
                 XPack xp;
                 const float sx = xpack_from_raw(xp, xrow_raw[q]);
@@ -548,8 +561,8 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
     }
     UZU_TL_STAMP(3);
     if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
-        __shared__ float sv[4];
-        __shared__ uint32_t si[4];
+        __shared__ float sv[NW];
+        __shared__ uint32_t si[NW];
         for (int off = 32; off > 0; off >>= 1) {
             const float ov = __shfl_xor(best_v, off, 64);
             const uint32_t oi = __shfl_xor(best_i, off, 64);
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
         if (lane == 0) sv[wave] = best_v, si[wave] = best_i;
         __syncthreads();
         if (tid == 0) {
-            for (int w2 = 1; w2 < 4; ++w2)
+            for (int w2 = 1; w2 < NW; ++w2)
                 if (sv[w2] > best_v || (sv[w2] == best_v && si[w2] < best_i)) best_v = sv[w2], best_i = si[w2];
             p.part_val[blockIdx.x] = best_v;
             p.part_idx[blockIdx.x] = best_i;
@@ -574,7 +587,7 @@ __global__ void __launch_bounds__(256) gemv_dec_kernel(const void* a0, const voi
 //   * big matrices (>= 16 MB, bandwidth-bound): a PERSISTENT grid of exactly the resident workgroups
 //     (occupancy x CUs, from the instance's register count) so that the prologue is paid once per resident
 //     workgroup, and R = 1 (R = 2 for the 2-step register path): more waves beat more rows per wave.
-static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2_out, int* R_out) {
+static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2_out, int* R_out, bool* wide_out) {
     const int lpr_log2 = gemv_lpr_log2(p.k);
     const int rpw = 64 >> lpr_log2;
     const uint32_t n_log0 = p.act_mul ? p.n[0] / 2 : p.n[0];
@@ -589,8 +602,16 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
     int R;
     auto nb = [&](int rr) { return (n_log0 + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw) + (p.n[1] + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw); };
+    static const bool wide_on = [] { // UZU_DEC_WIDE=0: 4-wave workgroups everywhere (A/B runs)
+        const char* e = getenv("UZU_DEC_WIDE");
+        return !e || atoi(e) != 0;
+    }();
+    *wide_out = false;
     if (weight_bytes >= (16u << 20)) {
         R = (cpl == 2 && !p.act_mul) ? 2 : 1;
+        // measured (Llama-3-8B, Qwen3-14B-class, same box A/B): int4 up / down / qkv 5-25 % faster; the read-out (dozens of batches
+        // per wave: the prologue is not its problem, 16 instead of 20 waves per CU is) and the int8 kernels (128-register cap) slower
+        *wide_out = wide_on && force_r <= 0 && p.bits == 4 && !p.part_val && cpl >= 2;
     } else {
         R = p.act_mul ? 2 : 4;
         const uint32_t target_waves = (uint32_t)num_cus * tw;
@@ -604,7 +625,7 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
 }
 
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO, bool CONV>
-static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float)
                        : (CPLT == 0 && BITS == 4)                  ? ((size_t)(p.k / 32) * 21 + 16) * sizeof(float) // packed row + per-step sums
                                                                    : 0;
@@ -612,79 +633,89 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         const char* c = getenv("UZU_DEC_CAP");
         return c ? atoi(c) : 0;
     }();
-#define UZU_LAUNCH(RR)                                                                                                              \
+#define UZU_LAUNCH(RR) UZU_LAUNCH_N(RR, 4)
+#define UZU_LAUNCH_N(RR, NWV)                                                                                                       \
     do {                                                                                                                            \
         static int occ = 0; /* resident workgroups per CU of this instance (LDS use only lowers it for K > 8192: ignored) */        \
         if (!occ) {                                                                                                                 \
             int n = 0;                                                                                                              \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>, 256, lds) != hipSuccess || n < 1) n = 2; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, 64 * NWV, lds) != hipSuccess || n < 1) n = 2; \
             occ = n > 8 ? 8 : n;                                                                                                    \
         }                                                                                                                           \
         uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                       \
         if (p.part_val && p.part_capacity && cap > p.part_capacity) cap = p.part_capacity; /* one arg-max partial per workgroup */  \
-        const uint32_t grid = want > cap ? cap : want;                                                                              \
+        const uint32_t want_n = (want * 4 + NWV - 1) / NWV;                                                                         \
+        const uint32_t grid = want_n > cap ? cap : want_n;                                                                          \
         if (lds > 65536) { /* K > ~24k on the LDS-resident-row path */                                                              \
             static bool raised = false;                                                                                             \
-            if (!raised) raised = hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; \
+            if (!raised) raised = hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; \
         }                                                                                                                           \
         if (grid_out) *grid_out = grid;                                                                                             \
         const void* a0 = PRO == 2 ? (const void*)p.dg_o : (const void*)p.x;                                                         \
         const void* a1 = PRO == 2 ? (const void*)p.dg_sz : (const void*)p.shortcut_in;                                              \
         const void* a2 = PRO == 2 ? (const void*)p.dg_w : (const void*)p.norm_scales;                                               \
-        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV>), dim3(grid), dim3(256), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], p); }, "gemv_dec"); \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], p); }, "gemv_dec"); \
     } while (0)
+    if constexpr (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))) {
+        if (wide) { // bandwidth regime (gemv_dec_plan: R <= 2): one wide workgroup per CU shares the prologue
+            constexpr int NWV = CPLT == 4 ? (BITS == 8 ? 8 : 12) : 16; // 150-190 registers on the 4-step path: 3 (int8: 2) waves per SIMD
+            if (R >= 2) UZU_LAUNCH_N(2, NWV);
+            UZU_LAUNCH_N(1, NWV);
+        }
+    }
     if (!ACT && !CONV && R == 4) UZU_LAUNCH((ACT || CONV) ? 2 : 4);
     if (R >= 2) UZU_LAUNCH(2);
     UZU_LAUNCH(1);
 #undef UZU_LAUNCH
+#undef UZU_LAUNCH_N
 }
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO>
-static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     if constexpr (!ACT && PRO != 2) {
         if (p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
             if (R > 2) {
                 want *= (uint32_t)(R / 2);
                 R = 2;
             }
-            return launch_gemv_dec_c<BITS, CPLT, false, KIND, PRO, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+            return launch_gemv_dec_c<BITS, CPLT, false, KIND, PRO, true>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
         }
     }
-    return launch_gemv_dec_c<BITS, CPLT, ACT, KIND, PRO, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    return launch_gemv_dec_c<BITS, CPLT, ACT, KIND, PRO, false>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
 }
 template <int BITS, int CPLT, bool ACT, int KIND>
-static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     const bool normed = p.norm_scales || p.norm_plain;
     if constexpr (CPLT != 0) { // prologues keep the row in registers (checked by the caller)
         if constexpr (!ACT)
-            if (p.dg_o) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 2>(s, p, want, lpr_log2, R, num_cus, grid_out);
-        if (normed) return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 1>(s, p, want, lpr_log2, R, num_cus, grid_out);
+            if (p.dg_o) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 2>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+        if (normed) return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 1>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     }
     if constexpr (CPLT == 4) {
         set_error("gemv_dec: the 4-step register path is instantiated for the prologue variants only");
         return UZU_ERR_UNSUPPORTED;
     } else {
-        return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 0>(s, p, want, lpr_log2, R, num_cus, grid_out);
+        return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 0>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     }
 }
 template <int BITS, int CPLT, bool ACT>
-static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+static uzu_status launch_gemv_dec_r(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     switch (p.b_kind) {
-    case UZU_MATMUL_B_SCALE_BIAS: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_BIAS>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    case UZU_MATMUL_B_SCALE_ZERO_POINT: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_ZERO_POINT>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    default: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_SYMMETRIC>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    case UZU_MATMUL_B_SCALE_BIAS: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_BIAS>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+    case UZU_MATMUL_B_SCALE_ZERO_POINT: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_ZERO_POINT>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+    default: return launch_gemv_dec_k<BITS, CPLT, ACT, UZU_MATMUL_B_SCALE_SYMMETRIC>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     }
 }
 template <int BITS, bool ACT>
-static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out) {
+static uzu_status launch_gemv_dec_cpl(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
-    if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    if (cpl <= 4 && (p.norm_scales || p.norm_plain || p.dg_o)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if (cpl == 1) return launch_gemv_dec_r<BITS, 1, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+    if (cpl == 2) return launch_gemv_dec_r<BITS, 2, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+    if (cpl <= 4 && (p.norm_scales || p.norm_plain || p.dg_o)) return launch_gemv_dec_r<BITS, 4, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     if (p.norm_scales || p.norm_plain || p.dg_o) {
         set_error("gemv_dec: Normalization / norm-gate prologue supports K <= 8192, K %% 1024 == 0 (got %u)", p.k);
         return UZU_ERR_UNSUPPORTED;
     }
-    return launch_gemv_dec_r<BITS, 0, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    return launch_gemv_dec_r<BITS, 0, ACT>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
 }
 
 #ifdef UZU_TIMELINE
@@ -725,13 +756,14 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint3
             return UZU_ERR_UNSUPPORTED;
         }
     int lpr_log2, R;
-    const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R);
+    bool wide = false;
+    const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R, &wide);
     if (p.act_mul) {
-        if (p.bits == 4) return launch_gemv_dec_cpl<4, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
-        return launch_gemv_dec_cpl<8, true>(s, p, want, lpr_log2, R, num_cus, grid_out);
+        if (p.bits == 4) return launch_gemv_dec_cpl<4, true>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+        return launch_gemv_dec_cpl<8, true>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     }
-    if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
-    return launch_gemv_dec_cpl<8, false>(s, p, want, lpr_log2, R, num_cus, grid_out);
+    if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+    return launch_gemv_dec_cpl<8, false>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
 }
 
 // ---------------------------------------------------------------------------------------------- argmax_commit
@@ -1120,16 +1152,14 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
 
 template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits) {
     const uint32_t kv_heads = p.num_heads / p.gqa_factor;
-    uint32_t gs = 1;
-    for (uint32_t c = 4; c >= 1; c >>= 1)
-        if (p.gqa_factor % c == 0) {
-            gs = c;
-            break;
-        }
+    const uint32_t gs = attn_dec_group_size(p.gqa_factor);
     const dim3 grid(kv_heads * (p.gqa_factor / gs), splits);
 #define UZU_LAUNCH(G) return launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G>), grid, dim3(256), 0, s, p); }, "attn_dec")
     switch (gs) {
+    case 6: UZU_LAUNCH(6);
+    case 5: UZU_LAUNCH(5);
     case 4: UZU_LAUNCH(4);
+    case 3: UZU_LAUNCH(3);
     case 2: UZU_LAUNCH(2);
     default: UZU_LAUNCH(1);
     }

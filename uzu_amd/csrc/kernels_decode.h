@@ -128,6 +128,13 @@ struct AttnDecParams {
     float* maxs;
 };
 uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits);
+// query heads of one KV head a workgroup of attn_dec serves together (the K / V rows are read once for all of them):
+// the largest divisor of the GQA factor <= 6 (LDS: 8 KB of merge state per head)
+inline uint32_t attn_dec_group_size(uint32_t gqa_factor) {
+    for (uint32_t c = 6; c > 1; --c)
+        if (gqa_factor % c == 0) return c;
+    return 1;
+}
 uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, const float* maxs, const uint16_t* gate, uint16_t* out,
                       uint32_t num_heads, uint32_t head_dim, uint32_t splits);
 
