@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   cpu_baseline -- the CPU oracle (port of the reference's single-threaded CPU backend) timed on this host
 """
 import argparse
+import dataclasses
 import json
 import os
 import sys
@@ -33,6 +34,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="qwen3.5-0.8b")
+    ap.add_argument("--model-dir", default="", help="config.json + model.safetensors in the reference's layout (uzu_amd/loader.py); side runs, not the headline config")
     ap.add_argument("--bits", type=int, default=0, help="override the preset's code width (4 or 8) -- side runs, not the headline config")
     ap.add_argument("--context", type=int, default=2048, help="context length at which the timed decode starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,7 +284,12 @@ def main():
 
     total_positions = args.context + args.warmup + args.steps + 8 + (64 if args.config == "c5" else 0)  # c5: + the mixed leg's decode steps
     cfg = S.PRESETS[args.model](max_context_length=total_positions, **({"bits": args.bits} if args.bits else {}))
-    bundle = S.build_model(cfg)
+    if args.model_dir:  # a checkpoint in the reference's on-disk layout instead of the synthetic weights (same synthetic token ids)
+        from uzu_amd import loader
+        bundle = loader.load_model_dir(args.model_dir, max_context_length=total_positions)
+        cfg = dataclasses.replace(cfg, name=bundle.name, vocab_size=bundle.vocab_size)
+    else:
+        bundle = S.build_model(cfg)
     ctx = Context.new(local_rank)
     flags = MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT
     # fill the context: prompt = context - warmup tokens, then `warmup` untimed decode steps reach `context`
@@ -365,7 +372,7 @@ def main():
                    f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]
 
     result = {
-        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)" if (args.model, cfg.bits) == ("qwen3.5-0.8b", 4) else f"decode tokens/s ({cfg.name} int{cfg.bits}, batch 1, greedy)",
+        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)" if (args.model, cfg.bits) == ("qwen3.5-0.8b", 4) and not args.model_dir else f"decode tokens/s ({cfg.name} int{cfg.bits}, batch 1, greedy)",
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": f"int{cfg.bits} weights x bf16 activations, f32 accumulate",

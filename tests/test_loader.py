@@ -1,0 +1,175 @@
+"""Model-directory loader (uzu_amd/loader.py) against the reference's on-disk rules (SURVEY.md Appendix B;
+engine/language_model/mod.rs:57-130, parameters/safetensors_metadata.rs:40-127, parameters/loader.rs:162-250,
+encodable_block/weight_matrix.rs:101-162, the #[uzu_config] strictness of crates/backend-uzu-macros/src/uzu_config.rs)."""
+import dataclasses
+import json
+import os
+
+import numpy as np
+import pytest
+
+from uzu_amd import desc as D
+from uzu_amd import loader as L
+from uzu_amd import synthetic as S
+
+import oracle.oracle as O
+
+
+def bundles_equal(a, b, path="bundle"):
+    """Deep comparison of two ModelBundles (arrays bit-exact, scalars equal)."""
+    if dataclasses.is_dataclass(a):
+        assert type(a) is type(b), path
+        for f in dataclasses.fields(a):
+            if f.name in ("_keep", "name", "max_context_length"):
+                continue
+            bundles_equal(getattr(a, f.name), getattr(b, f.name), f"{path}.{f.name}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            bundles_equal(x, y, f"{path}[{i}]")
+    elif isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        assert a is not None and b is not None, path
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), path
+    elif isinstance(a, float):
+        assert np.float32(a) == np.float32(b), f"{path}: {a} != {b}"
+    else:
+        assert a == b, f"{path}: {a!r} != {b!r}"
+
+
+def variants():
+    rng = np.random.default_rng(3)
+    yield "tiny-qwen", S.tiny_qwen()
+    yield "tiny-llama-zp", S.tiny_llama()
+    yield "int8-symmetric-yarn", S.tiny_llama(bits=8, method=D.QUANT_SCALE_SYMMETRIC, tied_embeddings=True,
+                                              rope=D.RopeConfig(kind=D.ROPE_YARN, head_dim=64, max_sequence_length=8192, base=10000.0, scaling_factor=4.0,
+                                                                original_context_length=1024, beta_fast=32.0, beta_slow=1.0, truncate=False))
+    yield "longrope", S.tiny_llama(rope=D.RopeConfig(kind=D.ROPE_LONGROPE, head_dim=64, max_sequence_length=8192, base=10000.0, scaling_factor=8.0,
+                                                     original_context_length=1024, short_factor=rng.uniform(1.0, 1.2, 32).astype(np.float32),
+                                                     long_factor=rng.uniform(1.0, 6.0, 32).astype(np.float32)))
+
+
+@pytest.mark.parametrize("name,cfg", list(variants()), ids=[n for n, _ in variants()])
+def test_round_trip_is_lossless_and_the_oracle_agrees(tmp_path, name, cfg):
+    bundle = S.build_model(cfg)
+    if name == "tiny-llama-zp":  # Linear biases (has_qkv_biases / has_out_biases / has_up_biases): bf16 [n] next to the weights tree
+        lw = bundle.layers[0]
+        for lin in (lw.qkv_projection, lw.out_projection, lw.up_projection, lw.down_projection):
+            lin.out_biases = S.f32_to_bf16_bits(np.linspace(-0.1, 0.1, lin.n).astype(np.float32))
+        for l in bundle.layers[1:]:  # the config flags are per layer
+            for lin in (l.qkv_projection, l.out_projection, l.up_projection, l.down_projection):
+                lin.out_biases = S.f32_to_bf16_bits(np.zeros(lin.n, np.float32))
+    L.save_model_dir(bundle, str(tmp_path))
+    loaded = L.load_model_dir(str(tmp_path), max_context_length=bundle.max_context_length)
+    bundles_equal(bundle, loaded)
+    prompt = S.synthetic_prompt(12, cfg.vocab_size)
+    t0, l0 = O.OracleModel(bundle).prefill(prompt, True)
+    t1, l1 = O.OracleModel(loaded).prefill(prompt, True)
+    assert t0 == t1 and np.array_equal(l0, l1)
+
+
+def test_written_file_is_a_valid_safetensors_file_for_an_independent_reader(tmp_path):
+    """The `safetensors` package (the format's own implementation) reads what write_safetensors wrote, and SafeTensors reads
+    what the package wrote: header length, JSON header, __metadata__, dtypes, offsets."""
+    st_np = pytest.importorskip("safetensors.numpy")
+    from safetensors import safe_open
+    bundle = S.build_model(S.tiny_llama())
+    L.save_model_dir(bundle, str(tmp_path))
+    path = os.path.join(str(tmp_path), "model.safetensors")
+    ours = L.SafeTensors(path)
+    with safe_open(path, framework="np") as f:
+        assert set(f.keys()) == set(ours.index)
+        assert f.metadata() == ours.metadata
+        key = "decoder.transformer.layers.0.pre_mixer_norm.scales"
+        assert np.array_equal(f.get_tensor(key), ours.tensor(key, (256,), "F32"))
+        key = "decoder.transformer.layers.0.mixer.qkv_projection.weights.weights"
+        want = f.get_tensor(key)
+        assert np.array_equal(want, ours.tensor(key, want.shape, "U8"))
+    other = os.path.join(str(tmp_path), "theirs.safetensors")
+    a, b = np.arange(12, dtype=np.float32).reshape(3, 4), np.arange(6, dtype=np.uint8)
+    st_np.save_file({"x.y": a, "z": b}, other, metadata={"x.spec": '{"type":"MLXSpec"}'})
+    theirs = L.SafeTensors(other)
+    assert np.array_equal(theirs.tensor("x.y", (3, 4), "F32"), a) and np.array_equal(theirs.tensor("z", (6,), "U8"), b)
+    assert theirs.spec("x.spec") == {"type": "MLXSpec"}
+    theirs.assert_all_consumed()
+
+
+def edit_config(dirpath, fn):
+    p = os.path.join(dirpath, "config.json")
+    with open(p) as f:
+        cfg = json.load(f)
+    fn(cfg)
+    with open(p, "w") as f:
+        json.dump(cfg, f)
+
+
+def test_strictness_matches_the_reference(tmp_path):
+    bundle = S.build_model(S.tiny_qwen())
+    d = str(tmp_path)
+    layer0 = lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][0]
+
+    def fresh():
+        L.save_model_dir(bundle, d)
+
+    fresh()  # every field is required: an Option may be null but not absent (strict_serde::required)
+    edit_config(d, lambda c: layer0(c).pop("kv_source_layer_index"))
+    with pytest.raises(L.ModelFormatError, match="kv_source_layer_index is missing"):
+        L.load_model_dir(d)
+    fresh()  # deny_unknown_fields
+    edit_config(d, lambda c: layer0(c)["mixer_config"].update(window=7))
+    with pytest.raises(L.ModelFormatError, match="unknown field"):
+        L.load_model_dir(d)
+    fresh()  # tagged families: "type" must name a member
+    edit_config(d, lambda c: layer0(c)["mlp_config"]["activation"].update(type="Swish"))
+    with pytest.raises(L.ModelFormatError, match="type is 'Swish'"):
+        L.load_model_dir(d)
+    fresh()  # well-formed but outside the hot path: loud, not silent
+    edit_config(d, lambda c: layer0(c)["mlp_config"].update(type="MixtureOfExpertsConfig"))
+    with pytest.raises(L.UnsupportedModelError, match="mixture-of-experts"):
+        L.load_model_dir(d)
+    fresh()
+    edit_config(d, lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][3]["mixer_config"].update(sliding_window_size=128))
+    with pytest.raises(L.UnsupportedModelError, match="sliding-window"):
+        L.load_model_dir(d)
+
+
+def test_tensor_validation_matches_the_reference(tmp_path):
+    """validate(shape, dtype) per leaf (loader.rs:162-178), spec from __metadata__, every tensor consumed (loader.rs:230-250)."""
+    cfg = S.tiny_llama()
+    bundle = S.build_model(cfg)
+    d = str(tmp_path)
+    L.save_model_dir(bundle, d)
+    path = os.path.join(d, "model.safetensors")
+    st = L.SafeTensors(path)
+    tensors = {k: (st.index[k][0], st.tensor(k, st.index[k][1], st.index[k][0])) for k in st.index}
+    meta = dict(st.metadata)
+
+    extra = dict(tensors)
+    extra["decoder.transformer.layers.0.mixer.unused"] = ("F32", np.zeros(4, np.float32))
+    L.write_safetensors(path, extra, meta)
+    with pytest.raises(L.ModelFormatError, match="never read"):
+        L.load_model_dir(d)
+
+    wrong = dict(tensors)
+    key = "decoder.transformer.layers.1.mlp.down_projection.weights.scales"
+    wrong[key] = ("BF16", np.ascontiguousarray(tensors[key][1][:, :-1]))
+    L.write_safetensors(path, wrong, meta)
+    with pytest.raises(L.ModelFormatError, match="expected BF16"):
+        L.load_model_dir(d)
+
+    nospec = dict(meta)
+    del nospec["decoder.transformer.layers.2.mixer.out_projection.weights.spec"]
+    L.write_safetensors(path, tensors, nospec)
+    with pytest.raises(L.ModelFormatError, match="metadata entry"):
+        L.load_model_dir(d)
+
+    layout = dict(meta)  # a linear must be OutputInput (weight_matrix.rs:113-117)
+    k2 = "decoder.transformer.layers.0.mlp.up_projection.weights.spec"
+    layout[k2] = json.dumps({**json.loads(meta[k2]), "layout": "input_output"})
+    L.write_safetensors(path, tensors, layout)
+    with pytest.raises(L.ModelFormatError, match="expected output_input layout"):
+        L.load_model_dir(d)
+
+    with open(path, "r+b") as f:  # truncated header
+        f.write((10 ** 12).to_bytes(8, "little"))
+    with pytest.raises(L.ModelFormatError, match="header length"):
+        L.load_model_dir(d)
