@@ -5,7 +5,7 @@
 R=${1:-r1}
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 64 --warmup 8"
+CMD="python $ROOT/bench.py --steps 64 --warmup 8 --no-cpu-baseline"
 rm -rf $ROOT/gpurun_out/${R}_trace $ROOT/gpurun_out/${R}_pmc $ROOT/gpurun_out/${R}_mfma
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_trace -- $CMD > $ROOT/gpurun_out/${R}_trace.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/${R}_pmc -- $CMD > $ROOT/gpurun_out/${R}_pmc.log 2>&1

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--context", type=int, default=2048)
     ap.add_argument("--model", default="qwen3.5-0.8b")
+    ap.add_argument("--detail", type=float, default=0.0, help="for launches whose span is at least this many us: exit-time distribution by XCD / grid position")
     args = ap.parse_args()
     from uzu_amd import _ffi
     from uzu_amd import synthetic as S
@@ -77,6 +78,22 @@ def main():
         ex = med(t_end - t0)
         span = (t_end.max() - t0.min()) * 0.01
         print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f}")
+        if args.detail and span >= args.detail:
+            # who finishes late?  exit times (relative to the first entry) by XCD (workgroup id % 8: dispatch is round-robin over the
+            # XCDs) and by position in the grid (quarters of the workgroup-id range: the first workgroups own one batch more)
+            wg = np.nonzero(live)[0]
+            rel = (t_end - t0.min()) * 0.01
+            q = np.percentile(rel, [0, 10, 50, 90, 100])
+            print(f"      exit min/p10/p50/p90/max {q[0]:.2f} {q[1]:.2f} {q[2]:.2f} {q[3]:.2f} {q[4]:.2f}")
+            print("      per XCD  p50: " + " ".join(f"{np.median(rel[wg % 8 == xc]):6.2f}" for xc in range(8)) +
+                  "   max: " + " ".join(f"{rel[wg % 8 == xc].max():6.2f}" for xc in range(8)))
+            quarters = np.array_split(np.argsort(wg), 4)
+            print("      per quarter of the grid  p50: " + " ".join(f"{np.median(rel[ix]):6.2f}" for ix in quarters) +
+                  "   max: " + " ".join(f"{rel[ix].max():6.2f}" for ix in quarters))
+            cu = wg // 8 % 32  # consecutive workgroups of one XCD land on consecutive CUs (first wave of the grid)
+            late = rel > q[3]
+            print(f"      the slowest 10 %: XCD histogram {np.bincount(wg[late] % 8, minlength=8).tolist()}, first-wave CU-slot histogram "
+                  f"{np.bincount(cu[late], minlength=32).tolist()}")
         if gap == gap:
             tot["gap"] += gap
         tot["span"] += span

@@ -161,6 +161,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         }
     };
     const uint32_t b0 = blockIdx.x * NW + wave;
+    // Wide workgroups hand their batches out dynamically.  On a CU the oldest waves win the issue arbitration: with a static
+    // assignment the first-dispatched quarter of a 1024-workgroup grid finishes after 10.4 us, the last after 17.2 us
+    // (Llama-3-8B up-projection, tools/timeline.py --detail; no difference between XCDs), and the CU idles towards the end with
+    // ever fewer waves.  The workgroup's batches -- slot s of round r is batch blockIdx * NW + s + r * total_waves, so that its
+    // waves keep streaming neighbouring rows -- are drawn from an LDS counter (round 0 is the static b0): every wave stays busy
+    // until the workgroup's share is done.  Which wave computes a row does not change the row's arithmetic.
+    __shared__ uint32_t s_next_slot;
+    if (NW > 4 && tid == 0) s_next_slot = NW; // published by the prologue's barrier, first drawn after it
+    auto next_batch = [&](uint32_t b) -> uint32_t {
+        if constexpr (NW > 4) {
+            uint32_t n = 0;
+            if (lane == 0) n = atomicAdd(&s_next_slot, 1u);
+            n = __builtin_amdgcn_readfirstlane(n);
+            return blockIdx.x * NW + n % NW + (n / NW) * total_waves;
+        } else {
+            return b + total_waves;
+        }
+    };
     Item itA, itB;
     // VMEM loads return in issue order.  The activation row (written by the previous kernel: L2 / memory-side cache,
     // ~0.8 us) is needed first and the weights (HBM, ~1.3 us) only after the prologue, so the activation loads are
@@ -505,9 +523,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             }
         }
     };
-    // one batch whose first item sits in `first`; on return the first item of batch b + total_waves sits in
-    // `first` (even number of steps) or in `second` (odd number of steps)
-    auto batch = [&](uint32_t b, Item& first, Item& second) {
+    // one batch whose first item sits in `first`; returns the wave's next batch, whose first item then sits in `first` (even
+    // number of steps) or in `second` (odd number of steps)
+    auto batch = [&](uint32_t b, Item& first, Item& second) -> uint32_t {
+        const uint32_t bn = next_batch(b);
         float acc[R][NPHYS];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -519,7 +538,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                 Item& cur = (j & 1) ? second : first;
                 Item& nxt = (j & 1) ? first : second;
                 if (j + 1 < CPL) load_item(b, j + 1, nxt);
-                else load_item(b + total_waves, 0, nxt);
+                else load_item(bn, 0, nxt);
                 const uint32_t c = sl + lpr * j;
                 if (c < C) {
                     if constexpr (BITS == 4) compute(cur, c, xq[j], xsm[j], acc);
@@ -530,7 +549,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             for (uint32_t j = 0; j < steps_per_lane; j += 2) {
                 {
                     const bool last = j + 1 == steps_per_lane;
-                    load_item(last ? b + total_waves : b, last ? 0 : j + 1, second);
+                    load_item(last ? bn : b, last ? 0 : j + 1, second);
                     const uint32_t c = sl + lpr * j;
                     if (c < C) stream_step(first, c, acc);
                     if (last) { // odd step count: hand the prefetched item over (one copy per batch)
@@ -540,7 +559,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                 }
                 {
                     const bool last = j + 2 == steps_per_lane;
-                    load_item(last ? b + total_waves : b, last ? 0 : j + 2, first);
+                    load_item(last ? bn : b, last ? 0 : j + 2, first);
                     const uint32_t c = sl + lpr * (j + 1);
                     if (c < C) stream_step(second, c, acc);
                 }
@@ -549,14 +568,15 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         UZU_TL_STAMP(5); // dot products of the (last) batch done
         finish(b, acc, cp_cur);
         UZU_TL_STAMP(6);
-        if (CONV) conv_prefetch(b + total_waves, cp_cur); // operands of this wave's next batch
+        if (CONV) conv_prefetch(bn, cp_cur); // operands of this wave's next batch
+        return bn;
     };
     if (CPLT == 0 || (CPL & 1) == 0) {
-        for (uint32_t b = b0; b < num_batches; b += total_waves) batch(b, itA, itB);
+        for (uint32_t b = b0; b < num_batches;) b = batch(b, itA, itB);
     } else {
-        for (uint32_t b = b0; b < num_batches; b += 2 * total_waves) {
-            batch(b, itA, itB);
-            if (b + total_waves < num_batches) batch(b + total_waves, itB, itA);
+        for (uint32_t b = b0; b < num_batches;) {
+            b = batch(b, itA, itB);
+            if (b < num_batches) b = batch(b, itB, itA);
         }
     }
     UZU_TL_STAMP(3);
@@ -602,16 +622,17 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
     int R;
     auto nb = [&](int rr) { return (n_log0 + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw) + (p.n[1] + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw); };
-    static const bool wide_on = [] { // UZU_DEC_WIDE=0: 4-wave workgroups everywhere (A/B runs)
+    static const int wide_on = [] { // UZU_DEC_WIDE=0: 4-wave workgroups everywhere; 2: every bandwidth-regime kernel (A/B runs)
         const char* e = getenv("UZU_DEC_WIDE");
-        return !e || atoi(e) != 0;
+        return e ? atoi(e) : 1;
     }();
     *wide_out = false;
     if (weight_bytes >= (16u << 20)) {
         R = (cpl == 2 && !p.act_mul) ? 2 : 1;
-        // measured (Llama-3-8B, Qwen3-14B-class, same box A/B): int4 up / down / qkv 5-25 % faster; the read-out (dozens of batches
-        // per wave: the prologue is not its problem, 16 instead of 20 waves per CU is) and the int8 kernels (128-register cap) slower
-        *wide_out = wide_on && force_r <= 0 && p.bits == 4 && !p.part_val && cpl >= 2;
+        // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/gpu_call14/17.sh): int4 kernels with K >= 4096 5-25 % faster
+        // (up 22.3 -> 20.2 us, down 13.1 -> 11.1, read-out 62 -> 55, 14B read-out 113 -> 100); K = 1024 (Qwen3.5 read-out: dozens of
+        // batches per wave, a 2 KB activation row) 5 % slower and the int8 kernels (128-register cap at 16 waves) 10 % slower
+        *wide_out = wide_on && force_r <= 0 && (wide_on == 2 || (p.bits == 4 && cpl >= 2));
     } else {
         R = p.act_mul ? 2 : 4;
         const uint32_t target_waves = (uint32_t)num_cus * tw;
