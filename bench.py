@@ -100,19 +100,22 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     with one grid per matrix shape).  None when no pass is committed or nothing is within 25 %."""
     import glob
     family = kernel_name.split("[")[0]
-    best = None
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_fetch.json"))):
+    # newest round first: an older pass is only consulted when the newer ones hold nothing for this kernel family / size
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_fetch.json")), reverse=True):
         try:
             table = json.load(open(path))
         except (OSError, ValueError):
             continue
+        best = None
         for key, nbytes in table.items():
             if not key.startswith(family):
                 continue
             err = abs(nbytes - algorithmic_bytes) / max(algorithmic_bytes, 1)
             if err < 0.25 and (best is None or err < best[0]):
                 best = (err, nbytes, f"{os.path.basename(path)}:{key}")
-    return (best[1], best[2]) if best else (None, None)
+        if best:
+            return best[1], best[2]
+    return None, None
 
 
 def timed_decode(model, ctx, args, dist, prompt):

@@ -20,6 +20,8 @@
 //   * q, k, v are bf16 already => every q.k product is exact in f32.  The probabilities are NOT bf16: they are fed
 //     as hi + lo (two bf16 MFMAs, 16 significant bits), so the only arithmetic difference to the f32 reference is
 //     the summation order.
+#include <stdlib.h>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -43,9 +45,11 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
 } // namespace
 
-// grid: (kv heads, ceil(gqa * query tiles / 4)); 256 threads.  Workgroups with the longest key ranges are numbered first.
+// grid: (kv heads, ceil(gqa * query tiles / tpw)); 256 threads.  Workgroups with the longest key ranges are numbered first.
+// tpw = wave tasks per workgroup (4, 2 or 1): models with few heads (Qwen3.5-0.8B: 8 q heads -> 256 tasks per 1024-token chunk)
+// would fill 64 CUs at four tasks per workgroup; with fewer tasks the idle waves still help staging the K / V tiles.
 template <int HD>
-__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out) {
+__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t tpw) {
     constexpr int KP = HD * 2 + 16;  // K tile row pitch in bytes (conflict-free ds_read_b128)
     constexpr int VP = TK * 2 + 8;   // V^T tile row pitch in bytes: 32 keys + 8 bytes of pad (conflict-free ds_read_b64)
     constexpr int NS = HD / 16;      // k16 steps of the QK^T contraction
@@ -57,9 +61,9 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     const uint32_t M = a.suffix_length;
     const uint32_t kv_head = blockIdx.x;
     const uint32_t n_tasks = a.gqa_factor * ((M + TQ - 1) / TQ);
-    const uint32_t task0 = (gridDim.y - 1 - blockIdx.y) * 4; // heaviest (last query tiles) first
+    const uint32_t task0 = (gridDim.y - 1 - blockIdx.y) * tpw; // heaviest (last query tiles) first
     const uint32_t task = task0 + wave;
-    const bool wave_live = task < n_tasks;
+    const bool wave_live = (uint32_t)wave < tpw && task < n_tasks;
     const uint32_t task_c = wave_live ? task : n_tasks - 1;
     const uint32_t head = kv_head * a.gqa_factor + task_c % a.gqa_factor;
     const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
@@ -86,7 +90,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     constexpr int ROUNDS = (TK * SLICES + 255) / 256;
     u32x4_v kst[ROUNDS][4], vst[ROUNDS][4]; // native vectors + unconditional loads: stay in registers and in flight across lds_barrier()
     // keys visible to ANY query of the workgroup: 0 .. prefix + last query of its last live task (tasks are tile-major)
-    const uint32_t last_tile = ((task0 + 3 < n_tasks ? task0 + 3 : n_tasks - 1) / a.gqa_factor + 1) * TQ;
+    const uint32_t last_tile = ((task0 + tpw - 1 < n_tasks ? task0 + tpw - 1 : n_tasks - 1) / a.gqa_factor + 1) * TQ;
     const uint32_t wg_last_q = (last_tile < M ? last_tile : M) - 1;
     const uint32_t key_end = prefix + wg_last_q + 1;
     const uint32_t n_tiles = (key_end + TK - 1) / TK;
@@ -236,8 +240,15 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
 uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out) {
     const uint32_t kv_heads = a.num_heads / a.gqa_factor;
     const uint32_t n_tasks = a.gqa_factor * ((a.suffix_length + TQ - 1) / TQ);
-    const dim3 grid(kv_heads, (n_tasks + 3) / 4);
-#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out); }, "attention_prefill_mfma")
+    static const uint32_t force_tpw = [] {
+        const char* e = getenv("UZU_ATTN_TPW");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    uint32_t tpw = 4; // fewer tasks per workgroup until the grid covers most of the chip
+    while (tpw > 1 && kv_heads * ((n_tasks + tpw - 1) / tpw) < 192) tpw >>= 1;
+    if (force_tpw == 1 || force_tpw == 2 || force_tpw == 4) tpw = force_tpw;
+    const dim3 grid(kv_heads, (n_tasks + tpw - 1) / tpw);
+#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, tpw); }, "attention_prefill_mfma")
     switch (a.head_dim) {
     case 64: UZU_LAUNCH(64);
     case 128: UZU_LAUNCH(128);
