@@ -146,6 +146,10 @@ void orc_kv_cache_update(void* keys, void* values, uint32_t dtype, const orc_cop
                          uint32_t element_dim);                                             /* kv_cache_update.rs */
 void orc_sigmoid_gate(const void* gate, void* output, uint32_t dtype, uint32_t total);     /* sigmoid_gate.rs */
 float orc_activate(uint32_t act_type, float x, uint32_t dtype);                             /* activation_type.rs */
+void orc_gated_act_mul_rht(const void* act_operand, const void* value_operand, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
+                           const int32_t* hadamard_factors, uint32_t dtype, uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset,
+                           uint32_t value_row_stride, uint32_t act_type, uint32_t interleaved, uint32_t ops, uint32_t activation_scale_group_size,
+                           uint32_t sum_group_size);                                                 /* gated_act_mul.rs:47-118 (use_hadamard) */
 void orc_gated_act_mul(const void* act_operand, const void* value_operand, void* fp_out, uint32_t dtype,
                        uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
                        uint32_t act_type, uint32_t interleaved);                            /* gated_act_mul.rs */

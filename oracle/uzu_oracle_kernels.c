@@ -172,6 +172,23 @@ static void orc_hadamard32(float* values) {
     const float scale = 1.0f / sqrtf(32.0f);
     for (size_t i = 0; i < 32; ++i) values[i] *= scale;
 }
+/* quantize_transformed_row (activation_transform.rs:11-41): symmetric int8 per scale group, optional i32 code sums per sum group */
+static void orc_quantize_transformed_row(const float* transformed, size_t columns, size_t activation_scale_group_size, size_t sum_group_size,
+                                         int8_t* values, float* scales, int32_t* group_sums) {
+    const size_t scales_per_row = columns / activation_scale_group_size;
+    if (group_sums) memset(group_sums, 0, columns / sum_group_size * sizeof(int32_t));
+    for (size_t gidx = 0; gidx < scales_per_row; ++gidx) {
+        const float* source = transformed + gidx * activation_scale_group_size;
+        const float scale = orc_min_max_symmetric_divisor(source, activation_scale_group_size);
+        scales[gidx] = scale;
+        for (size_t i = 0; i < activation_scale_group_size; ++i) {
+            const int8_t code = orc_quantize_symmetric_i8(source[i], scale);
+            const size_t absolute_index = gidx * activation_scale_group_size + i;
+            values[absolute_index] = code;
+            if (group_sums) group_sums[absolute_index / sum_group_size] += (int32_t)code;
+        }
+    }
+}
 /* activation_transform.rs:43-136 */
 void orc_activation_transform(const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
                               const int32_t* rht_factors, uint32_t dtype, uint32_t batch_size, uint32_t element_count, uint32_t op,
@@ -198,21 +215,10 @@ void orc_activation_transform(const void* input, void* fp_out, int8_t* q_out, fl
                 transformed[index] = input_rht ? stripe[lane] : stripe[lane] * factor;
             }
         }
-        if (quantize) { /* quantize_transformed_row (activation_transform.rs:11-41) */
-            const size_t scales_per_row = columns / activation_scale_group_size;
-            const size_t sums_per_row = op == 3u ? columns / sum_group_size : 0;
-            if (op == 3u) memset(group_sums_out + row * sums_per_row, 0, sums_per_row * sizeof(int32_t));
-            for (size_t gidx = 0; gidx < scales_per_row; ++gidx) {
-                const float* source = transformed + gidx * activation_scale_group_size;
-                const float scale = orc_min_max_symmetric_divisor(source, activation_scale_group_size);
-                scales_out[row * scales_per_row + gidx] = scale;
-                for (size_t i = 0; i < activation_scale_group_size; ++i) {
-                    const int8_t code = orc_quantize_symmetric_i8(source[i], scale);
-                    const size_t absolute_index = gidx * activation_scale_group_size + i;
-                    q_out[row_offset + absolute_index] = code;
-                    if (op == 3u) group_sums_out[row * sums_per_row + absolute_index / sum_group_size] += (int32_t)code;
-                }
-            }
+        if (quantize) {
+            orc_quantize_transformed_row(transformed, columns, activation_scale_group_size, op == 3u ? sum_group_size : 0, q_out + row_offset,
+                                         scales_out + row * (columns / activation_scale_group_size),
+                                         op == 3u ? group_sums_out + row * (columns / sum_group_size) : NULL);
         } else {
             for (size_t index = 0; index < columns; ++index) wr(fp_out, dtype, row_offset + index, transformed[index]);
         }
@@ -601,6 +607,45 @@ void orc_gated_act_mul(const void* act_operand, const void* value_operand, void*
             const float result = rnd(dt, value * orc_activate(act_type, gate, dt));
             wr(fp_out, dt, batch * gated_dim + gated, result);
         }
+}
+/* BU/cpu/kernel/gated_act_mul/gated_act_mul.rs:47-118 with use_hadamard: the gated products of a row (rounded to T, mod.rs:5-12)
+ * times the sign factors, 32-point butterflies, then either stored as T (ops 0 FullPrecision) or quantised (1 Quantize,
+ * 2 QuantizeWithGroupSums: gpu_types/gated_act_mul.rs:3-7). */
+void orc_gated_act_mul_rht(const void* act_operand, const void* value_operand, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
+                           const int32_t* hadamard_factors, uint32_t dt, uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset,
+                           uint32_t value_row_stride, uint32_t act_type, uint32_t interleaved, uint32_t ops, uint32_t activation_scale_group_size,
+                           uint32_t sum_group_size) {
+    float* transformed = (float*)malloc((size_t)gated_dim * sizeof(float));
+    for (size_t batch = 0; batch < batch_dim; ++batch) {
+        for (size_t gated = 0; gated < gated_dim; ++gated) {
+            size_t act_index;
+            float value;
+            if (interleaved) {
+                const size_t base = batch * 2 * gated_dim;
+                act_index = base + gated_dim + gated;
+                value = rd(act_operand, dt, base + gated);
+            } else {
+                act_index = batch * gated_dim + gated;
+                value = rd(value_operand, dt, batch * value_row_stride + value_offset + gated);
+            }
+            const float gate = rd(act_operand, dt, act_index);
+            transformed[gated] = rnd(dt, value * orc_activate(act_type, gate, dt));
+        }
+        for (size_t stripe_start = 0; stripe_start < gated_dim; stripe_start += 32) {
+            float stripe[32];
+            for (size_t lane = 0; lane < 32; ++lane) stripe[lane] = transformed[stripe_start + lane] * (float)hadamard_factors[stripe_start + lane];
+            orc_hadamard32(stripe);
+            memcpy(transformed + stripe_start, stripe, sizeof stripe);
+        }
+        if (ops != 0u) {
+            orc_quantize_transformed_row(transformed, gated_dim, activation_scale_group_size, ops == 2u ? sum_group_size : 0, q_out + batch * gated_dim,
+                                         scales_out + batch * (gated_dim / activation_scale_group_size),
+                                         ops == 2u ? group_sums_out + batch * (gated_dim / sum_group_size) : NULL);
+        } else {
+            for (size_t gated = 0; gated < gated_dim; ++gated) wr(fp_out, dt, batch * gated_dim + gated, transformed[gated]);
+        }
+    }
+    free(transformed);
 }
 /* BU/cpu/kernel/embedding/quant_embedding.rs:36-116 (U4 / U8 codes) */
 void orc_quantized_embedding_lookup(const uint32_t* token_ids, const uint8_t* weights, const void* scales,

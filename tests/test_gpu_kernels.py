@@ -940,6 +940,42 @@ def test_activation_transform_quantize_bit_exact(hip_ctx, scale_group, sum_group
             assert np.array_equal(bg.download(np.int32, wgs.size).reshape(wgs.shape), wgs)
 
 
+@pytest.mark.parametrize("ops,scale_group,sum_group", [(0, 0, 0), (1, 64, 0), (2, 128, 32), (2, 32, 256)])
+@pytest.mark.parametrize("interleaved", [0, 1])
+def test_gated_act_mul_rht_variants_bit_exact(hip_ctx, ops, scale_group, sum_group, interleaved):
+    """GatedActMul with use_hadamard (gated_act_mul.rs:47-118): gated products rounded to bf16, sign factors, 32-point butterflies, then
+    bf16 (FullPrecision) or int8 codes + f32 divisors (+ i32 group sums): identical to the CPU restatement, SiLU and GELU."""
+    rng = np.random.default_rng(ops * 10 + scale_group + interleaved)
+    rows, dim = 7, 1536
+    for act in (0, 1):
+        if interleaved:
+            act_op, val_op, voff, vstride = bf16(rng.normal(0, 1.5, (rows, 2 * dim))), None, 0, 0
+        else:
+            act_op, val_op, voff, vstride = bf16(rng.normal(0, 1.5, (rows, dim))), bf16(rng.normal(0, 1.5, (rows, dim + 64))), 64, dim + 64
+        factors = rng.choice(np.array([-1, 1], np.int32), dim)
+        wf = np.zeros((rows, dim), np.uint16)
+        wq, wsc = np.zeros((rows, dim), np.int8), np.zeros((rows, dim // max(scale_group, 1)), np.float32)
+        wgs = np.zeros((rows, dim // max(sum_group, 1)), np.int32)
+        O.lib().orc_gated_act_mul_rht(O.p(act_op), O.p(val_op) if val_op is not None else None, O.p(wf) if ops == 0 else None, O.p(wq) if ops else None,
+                                      O.p(wsc) if ops else None, O.p(wgs) if ops == 2 else None, O.p(factors), O.BF16, dim, rows, voff, vstride, act,
+                                      interleaved, ops, scale_group, sum_group)
+        kern = B.GatedActMulKernel.new(hip_ctx, B.BF16, ops, interleaved, 1, scale_group, sum_group)
+        ba, bv, bfac = hip_ctx.buffer_from(act_op), hip_ctx.buffer_from(val_op) if val_op is not None else None, hip_ctx.buffer_from(factors)
+        bo = hip_ctx.create_buffer(wf.nbytes) if ops == 0 else None
+        bq, bs = (hip_ctx.create_buffer(wq.nbytes), hip_ctx.create_buffer(wsc.nbytes)) if ops else (None, None)
+        bg = hip_ctx.create_buffer(wgs.nbytes) if ops == 2 else None
+        run(hip_ctx, lambda cb: kern.encode(ba, bv, bo, bq, bs, bg, bfac, dim, rows, voff, vstride, act, cb))
+        if ops == 0:
+            assert np.array_equal(bo.download(np.uint16, wf.size).reshape(wf.shape), wf)
+        else:
+            assert np.array_equal(bs.download(np.float32, wsc.size).reshape(wsc.shape), wsc)
+            assert np.array_equal(bq.download(np.int8, wq.size).reshape(wq.shape), wq)
+        if ops == 2:
+            assert np.array_equal(bg.download(np.int32, wgs.size).reshape(wgs.shape), wgs)
+    with pytest.raises(B.UzuHipError):  # gated_act_mul.rs:39: quantized gate activation requires RHT
+        B.GatedActMulKernel.new(hip_ctx, B.BF16, 1, 0, 0, 64, 0)
+
+
 @pytest.mark.parametrize("bits,method,group_size,a_group", [(4, 0, 128, 128), (4, 1, 64, 32), (4, 2, 32, 64), (8, 0, 128, 64), (8, 1, 64, 128)])
 @pytest.mark.parametrize("m,n,k", [(1, 1024, 1024), (70, 200, 512), (256, 3072, 1024)])
 def test_matmul_int8_symmetric_activations(hip_ctx, bits, method, group_size, a_group, m, n, k):

@@ -489,6 +489,40 @@ def test_activation_transform_quantize_against_numpy(scale_group, sum_group):
     assert sc[1, 0] == 1.0 and not q[1, :scale_group].any()
 
 
+@pytest.mark.parametrize("ops", [0, 1, 2])
+@pytest.mark.parametrize("interleaved", [0, 1])
+def test_gated_act_mul_rht_is_gated_product_then_activation_transform(ops, interleaved):
+    """gated_act_mul.rs:47-118 (use_hadamard): the restatement of that function equals GatedActMul (FullPrecision) followed by
+    ActivationTransform {InputRht, Quantize, QuantizeWithGroupSums} on the bf16 products -- the identity the HIP boundary relies on
+    (capi_kernels.hip runs exactly these two kernels) -- and the gated products themselves match float64 to bf16 rounding."""
+    rng = np.random.default_rng(ops + 3 * interleaved)
+    rows, dim, sg, gg = 5, 256, 64, 128
+    if interleaved:
+        act_op, val_op, voff, vstride = bf16(rng.normal(0, 1.5, (rows, 2 * dim))), None, 0, 0
+        value, gate = act_op[:, :dim], act_op[:, dim:]
+    else:
+        act_op, val_op, voff, vstride = bf16(rng.normal(0, 1.5, (rows, dim))), bf16(rng.normal(0, 1.5, (rows, dim + 32))), 32, dim + 32
+        value, gate = val_op[:, 32:], act_op
+    factors = rng.choice(np.array([-1, 1], np.int32), dim)
+    wf, wq = np.zeros((rows, dim), np.uint16), np.zeros((rows, dim), np.int8)
+    wsc, wgs = np.zeros((rows, dim // sg), np.float32), np.zeros((rows, dim // gg), np.int32)
+    O.lib().orc_gated_act_mul_rht(O.p(act_op), O.p(val_op) if val_op is not None else None, O.p(wf) if ops == 0 else None, O.p(wq) if ops else None,
+                                  O.p(wsc) if ops else None, O.p(wgs) if ops == 2 else None, O.p(factors), O.BF16, dim, rows, voff, vstride, 0, interleaved,
+                                  ops, sg, gg)
+    prod = np.zeros((rows, dim), np.uint16)
+    O.lib().orc_gated_act_mul(O.p(act_op), O.p(val_op) if val_op is not None else None, O.p(prod), O.BF16, dim, rows, voff, vstride, 0, interleaved)
+    g64, v64 = f32(gate).astype(np.float64), f32(value).astype(np.float64)
+    ideal = v64 * (g64 / (1.0 + np.exp(-g64)))
+    assert np.abs(f32(prod) - ideal).max() <= 2.0 ** -7 * np.abs(ideal).max()  # two bf16 roundings (SiLU, product)
+    fp, q, sc, gs = activation_transform_oracle(prod, factors, {0: 0, 1: 2, 2: 3}[ops], sg, gg)
+    if ops == 0:
+        assert np.array_equal(wf, fp)
+    else:
+        assert np.array_equal(wq, q) and np.array_equal(wsc, sc)
+    if ops == 2:
+        assert np.array_equal(wgs, gs)
+
+
 @pytest.mark.parametrize("bits,method", [(4, 0), (4, 1), (8, 2)])
 def test_matmul_int8_activations_and_output_rht_against_float64(bits, method):
     """MatmulA::Int8Symmetric (kernel.rs:190-200): A = q * scale per activation group; MatmulDOps::rht_factors (kernel.rs:296-303):

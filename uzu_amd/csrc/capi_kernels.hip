@@ -394,29 +394,74 @@ uzu_status uzu_hip_sigmoid_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uz
     return k::sigmoid_gate(cb_stream(cb), bptr(gate), bptr(output), k->t[0], total_elements);
 }
 
+// Kernel-owned scratch (grow-only).  Regrown at encode time OUTSIDE stream capture only: the stream-ordered pool is not trusted
+// on this ROCm build (runtime.hip) and a captured graph must not reference a block that may be regrown.
+static uzu_status kernel_scratch(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, size_t need, const char* what, void** out) {
+    if (need > k->scratch_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(cb_stream(cb), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            set_error("%s: this call needs %zu bytes of scratch, more than the kernel owns; encode once outside a graph-captured command buffer "
+                      "first (the block cannot grow during capture)", what, need);
+            return UZU_ERR_UNSUPPORTED;
+        }
+        UZU_HIP_TRY(hipStreamSynchronize(cb_stream(cb))); // earlier encodes on this stream may still use the old block
+        if (k->scratch) (void)hipFree(k->scratch);
+        k->scratch = nullptr, k->scratch_bytes = 0;
+        UZU_HIP_TRY(hipMalloc(&k->scratch, need));
+        k->scratch_bytes = need;
+    }
+    *out = k->scratch;
+    return UZU_OK;
+}
+
 uzu_status uzu_hip_gated_act_mul_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t interleaved, uint32_t use_hadamard,
                                         uint32_t activation_scale_group_size, uint32_t sum_group_size, uzu_hip_kernel** out) {
     REQ_DT(t, "gated_act_mul");
-    UZU_UNSUPPORTED(ops != 0 || use_hadamard, "gated_act_mul: quantizing / RHT variants (A8 path) are not implemented on the hip path yet");
+    // gated_act_mul.rs:36-42
+    UZU_REQUIRE(ops <= 2u, "gated_act_mul: unknown op %u", ops);
+    UZU_REQUIRE(ops == 0u || use_hadamard, "quantized gate activation requires RHT");
+    if (ops != 0u) {
+        UZU_REQUIRE(activation_scale_group_size && activation_scale_group_size % 32u == 0 && activation_scale_group_size <= 256u &&
+                        (activation_scale_group_size & (activation_scale_group_size - 1)) == 0,
+                    "gated_act_mul: activation_scale_group_size must be 32, 64, 128 or 256 (got %u)", activation_scale_group_size);
+        UZU_REQUIRE(ops != 2u || (sum_group_size && sum_group_size % 32u == 0 && sum_group_size <= 256u && (sum_group_size & (sum_group_size - 1)) == 0),
+                    "gated_act_mul: sum_group_size must be 32, 64, 128 or 256 (got %u)", sum_group_size);
+    }
     uzu_hip_kernel* k;
     UZU_PROPAGATE(make_kernel(ctx, KK_GATED_ACT_MUL, out, &k));
     k->t[0] = t;
-    k->f[0] = interleaved;
-    (void)activation_scale_group_size;
-    (void)sum_group_size;
+    k->f[0] = interleaved, k->f[1] = ops, k->f[2] = use_hadamard, k->f[3] = activation_scale_group_size, k->f[4] = sum_group_size;
     return UZU_OK;
 }
+// RHT variants (gated_act_mul.rs:47-118): the gated product is rounded to T first (mod.rs:5-12), then sign factors, the 32-point
+// butterfly and, for the Quantize ops, quantize_transformed_row -- i.e. GatedActMul followed by ActivationTransform{InputRht |
+// Quantize | QuantizeWithGroupSums} on the rounded products; run as those two kernels (in place on fp_out, or through
+// kernel-owned scratch when there is no fp_out), bit-exact like each of them.
 uzu_status uzu_hip_gated_act_mul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf act_operand, uzu_buf value_operand, uzu_buf fp_out, uzu_buf q_out,
                                         uzu_buf scales_out, uzu_buf group_sums_out, uzu_buf hadamard_factors, uint32_t gated_dim, uint32_t batch_dim,
                                         uint32_t value_offset, uint32_t value_row_stride, uint32_t act_type) {
     UZU_PROPAGATE(check(k, KK_GATED_ACT_MUL, cb));
-    const bool interleaved = k->f[0];
-    UZU_REQUIRE(act_operand.buffer && fp_out.buffer, "FP gate activation requires fp_out");
+    const bool interleaved = k->f[0], use_hadamard = k->f[2];
+    const uint32_t ops = k->f[1];
+    const bool quantize = ops != 0u, sums = ops == 2u;
+    UZU_REQUIRE(act_operand.buffer, "gated_act_mul: act_operand is required");
+    UZU_REQUIRE((fp_out.buffer != nullptr) == !quantize, quantize ? "gated_act_mul: fp_out given to a Quantize kernel" : "FP gate activation requires fp_out");
     UZU_REQUIRE((value_operand.buffer == nullptr) == interleaved, "gated_act_mul: value_operand presence must equal !interleaved");
-    UZU_REQUIRE(!q_out.buffer && !scales_out.buffer && !group_sums_out.buffer && !hadamard_factors.buffer, "gated_act_mul: quantized outputs given to the FullPrecision kernel");
+    UZU_REQUIRE((q_out.buffer != nullptr) == quantize && (scales_out.buffer != nullptr) == quantize, "gated_act_mul: q_out / scales_out presence must equal (ops is a Quantize op)");
+    UZU_REQUIRE((group_sums_out.buffer != nullptr) == sums, "gated_act_mul: group_sums_out presence must equal QuantizeWithGroupSums");
+    UZU_REQUIRE((hadamard_factors.buffer != nullptr) == use_hadamard, "gated_act_mul: hadamard_factors presence must equal use_hadamard");
     UZU_REQUIRE(act_type <= 4, "gated_act_mul: unknown activation type %u", act_type);
-    return k::gated_act_mul(cb_stream(cb), bptr(act_operand), bptr(value_operand), bptr(fp_out), k->t[0], gated_dim, batch_dim, value_offset,
-                            value_row_stride, act_type, interleaved);
+    UZU_REQUIRE(!use_hadamard || gated_dim % 32u == 0, "gated_act_mul: RHT needs gated_dim %% 32 == 0 (got %u)", gated_dim);
+    UZU_REQUIRE(!quantize || gated_dim % k->f[3] == 0, "gated_act_mul: gated_dim %u is not a multiple of the scale group %u", gated_dim, k->f[3]);
+    UZU_REQUIRE(!sums || gated_dim % k->f[4] == 0, "gated_act_mul: gated_dim %u is not a multiple of the sum group %u", gated_dim, k->f[4]);
+    void* product = bptr(fp_out);
+    if (quantize) UZU_PROPAGATE(kernel_scratch(k, cb, (size_t)batch_dim * gated_dim * (k->t[0] == UZU_F32 ? 4 : 2), "gated_act_mul", &product));
+    UZU_PROPAGATE(k::gated_act_mul(cb_stream(cb), bptr(act_operand), bptr(value_operand), product, k->t[0], gated_dim, batch_dim, value_offset,
+                                   value_row_stride, act_type, interleaved));
+    if (!use_hadamard) return UZU_OK;
+    const uint32_t at_op = ops == 0u ? UZU_ACTIVATION_TRANSFORM_INPUT_RHT : ops == 1u ? UZU_ACTIVATION_TRANSFORM_QUANTIZE : UZU_ACTIVATION_TRANSFORM_QUANTIZE_WITH_GROUP_SUMS;
+    return k::activation_transform(cb_stream(cb), quantize ? product : nullptr, quantize ? nullptr : product, (int8_t*)bptr(q_out), (float*)bptr(scales_out),
+                                   (int32_t*)bptr(group_sums_out), (const int32_t*)bptr(hadamard_factors), k->t[0], batch_dim, gated_dim, at_op, k->f[3], k->f[4]);
 }
 
 // ------------------------------------------------------------------------------------- Embeddings
@@ -531,21 +576,7 @@ uzu_status uzu_hip_tensor_copy_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu
 static uzu_status sampling_scratch(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uint32_t batch_size, void** out) {
     const size_t need = k::unified_sampling_scratch_bytes(batch_size) > k::argmax_scratch_bytes(batch_size) ? k::unified_sampling_scratch_bytes(batch_size)
                                                                                                          : k::argmax_scratch_bytes(batch_size);
-    if (need > k->scratch_bytes) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(cb_stream(cb), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-            set_error("unified_sampling: batch_size %u needs a larger scratch block than the kernel owns; encode once outside a graph-captured "
-                      "command buffer first (the block cannot grow during capture)", batch_size);
-            return UZU_ERR_UNSUPPORTED;
-        }
-        UZU_HIP_TRY(hipStreamSynchronize(cb_stream(cb))); // earlier encodes on this stream may still use the old block
-        if (k->scratch) (void)hipFree(k->scratch);
-        k->scratch = nullptr, k->scratch_bytes = 0;
-        UZU_HIP_TRY(hipMalloc(&k->scratch, need));
-        k->scratch_bytes = need;
-    }
-    *out = k->scratch;
-    return UZU_OK;
+    return kernel_scratch(k, cb, need, "unified_sampling", out);
 }
 uzu_status uzu_hip_unified_sampling_create(uzu_hip_context* ctx, uint32_t t, uint32_t is_stochastic, uint32_t has_bitmask, uint32_t has_temperature,
                                            uint32_t has_top_k, uint32_t has_top_p, uint32_t has_min_p, uzu_hip_kernel** out) {
