@@ -241,7 +241,7 @@ uzu_status uzu_hip_attention_two_pass2_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
 /* ---- AttentionGemmCore, a manual trait (BU/backends/common/kernel/attention_gemm/kernel.rs:8-24): the prefill attention
  * core on the matrix cores.  `uzu_attention_core_arguments` = AttentionCoreNewArguments (encodable_block/mixer/attention/
  * core/mod.rs:17-28; Option<T> as has_* + value).  is_supported is the trait's static query (causal bf16, head_dim 64 / 128 /
- * 256, no sinks / ring / trie / sliding window, GQA factor 1, 2, 4 or a multiple of 4).  encode = AttentionCoreEncodeArguments
+ * 256, no sinks / ring / trie / sliding window, any GQA factor).  encode = AttentionCoreEncodeArguments
  * (core/mod.rs:30-38) for AttentionStateType::Full { length = prefix_length }: queries [q_heads, suffix, hd] as written by
  * AttentionPrepare, keys / values = the KV cache [tokens, kv_heads, hd] already holding the suffix rows, out [suffix, q_heads,
  * hd] (the Rust trait returns a fresh Allocation; in C the caller passes it). */
