@@ -29,9 +29,16 @@ namespace uzu {
 namespace k {
 
 
+#ifndef UZU_GEMM_PAIR_DEQUANT
+#define UZU_GEMM_PAIR_DEQUANT 1 // int4: bf16(16 + u) pairs (gemm_convert.h::dequant4_pairs); 0 = centred (u - 8) / 16 per code (A/B builds)
+#endif
 namespace {
 constexpr int BK = 64, BM = 128, BN = 128;
 constexpr int A_PITCH = 144;
+constexpr bool kPairs = UZU_GEMM_PAIR_DEQUANT != 0;
+#ifndef UZU_GEMM_PIPE
+#define UZU_GEMM_PIPE 1 // software-pipelined k16 steps (operands one step ahead of the MFMAs); 0 = operands right in front of them
+#endif
 
 } // namespace
 
@@ -47,13 +54,16 @@ __global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float
         const uint32_t idx = (blockIdx.x - rowsum_blocks) * 256 + threadIdx.x;
         if (idx >= N * G) return;
         const uint32_t n = idx / G, g = idx % G; // consecutive threads read consecutive scales
-        const float mid = (float)(1u << (p.bits - 1));
+        // `mid` = what the main loop subtracted from the unsigned code: 2^(bits-1) (centred codes) or -16 (int4 pair form: 16 + u)
+        const float mid = (kPairs && p.bits == 4) ? -16.0f : (float)(1u << (p.bits - 1));
         const float scale = bf16_to_f32(((const uint16_t*)p.scales)[(size_t)n * G + g]);
         float c;
         if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
             const uint32_t zp_stride = p.bits == 4 ? (G + 1) / 2 : G;
             const uint32_t zb = p.zero_points[(size_t)n * zp_stride + (p.bits == 4 ? (g >> 1) : g)];
             c = scale * (mid - (float)(p.bits == 4 ? ((g & 1) ? (zb >> 4) : (zb & 0xF)) : zb));
+        } else if (p.b_kind == UZU_MATMUL_B_SCALE_SYMMETRIC) {
+            c = scale * (mid - (float)(1u << (p.bits - 1))); // w = scale * (u - 2^(bits-1)); zero for centred codes
         } else {
             c = fmaf(mid, scale, bf16_to_f32(((const uint16_t*)p.biases)[(size_t)n * G + g]));
         }
@@ -114,7 +124,8 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     const uint32_t Gz = G / splits, g_lo = z * Gz;
     const uint32_t kt_lo = g_lo * GS, KTz = Gz * GS; // KTz % U == 0 (host-checked)
     const uint32_t row_bytes = K * BITS / 8;
-    const uint32_t flip = p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
+    // codes as the conversion wants them: two's complement of u - mid (centred form) or the unsigned u (int4 pair form)
+    const uint32_t flip = (kPairs && BITS == 4) ? (p.signed_codes ? 0x88888888u : 0u) : p.signed_codes ? 0u : (BITS == 4 ? 0x88888888u : 0x80808080u);
 
     // ---- activation staging role: 8 lanes fetch one row's 128 bytes (one cache line per row per instruction), four
     // passes of 32 rows.  (One thread per (row, 64-byte half) costs 45 L1 accesses per wave instruction -- rocprofv3
@@ -133,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[4]) {
         uint8_t* dst = &s_a[kt & 1][rpass * A_PITCH + chunk * 16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(u32x4_v*)(dst + j * 32 * A_PITCH) = st[j];
+        for (int j = 0; j < 4; ++j) *(u32x4_v*)(dst + j * 32 * A_PITCH) = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
     };
 
     // ---- weight role: lane -> column c of each of the wave's two 32-column blocks, k half h
@@ -176,16 +187,38 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     // one k-step of code MFMAs out of LDS buffer (kt & 1) and a ring slot; `first` = first k-step of a quant group
     auto mfma_codes = [&](uint32_t kt, const u32x4_v (&raw)[2][WV], bool first) {
         const uint8_t* ab = a_frag_base + (kt & 1) * (BM * A_PITCH);
+        auto operands = [&](int s, u32x4_t (&bf)[2], u32x4_t (&af)[2]) { // B fragments converted from the ring slot, A fragments from LDS
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (BITS == 4) bf[nb] = kPairs ? dequant4_pairs(raw[nb][0][s] ^ flip) : dequant4(raw[nb][0][s] ^ flip);
+                else bf[nb] = dequant8(raw[nb][s >> 1][(s & 1) * 2] ^ flip, raw[nb][s >> 1][(s & 1) * 2 + 1] ^ flip);
+            }
+        };
+#if UZU_GEMM_PIPE
+        // operands of k16 step s + 1 are requested / converted before the MFMAs of step s are issued: the LDS latency and the
+        // conversion VALU run under the 4 x 32 cycles of the matrix pipe instead of in front of it
+        u32x4_t bf[2][2], af[2][2];
+        operands(0, bf[0], af[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) operands(s + 1, bf[(s + 1) & 1], af[(s + 1) & 1]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const f32x16_t zero = {};
+                    acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s & 1][mb]), __builtin_bit_cast(bf16x8_t, bf[s & 1][nb]),
+                                                                           (first && s == 0) ? zero : acc_g[mb][nb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4_t bf[2], af[2];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                if (BITS == 4) bf[nb] = dequant4(raw[nb][0][s] ^ flip);
-                else bf[nb] = dequant8(raw[nb][s >> 1][(s & 1) * 2] ^ flip, raw[nb][s >> 1][(s & 1) * 2 + 1] ^ flip);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) af[mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+            operands(s, bf, af);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -196,12 +229,13 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
                 }
             __builtin_amdgcn_sched_barrier(0); // keep the conversions of MFMA s next to their use (register pressure)
         }
+#endif
     };
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
     auto fold = [&]() { // acc_t += scale * acc_g at a group boundary
         f32x2_t sc[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = (BITS == 4 ? 16.0f : 1.0f) * bf16_to_f32(sc_cur[nb]);
+        for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = ((BITS == 4 && !kPairs) ? 16.0f : 1.0f) * bf16_to_f32(sc_cur[nb]);
         // In place on acc_t through inline asm: left to itself the register allocator writes the result over acc_g and
         // permutes the 16-register accumulator tuples around the loop (60-180 VGPRs of spills at the 256 budget).  The
         // hazard recogniser cannot see an MFMA -> VALU read through inline asm, so the wait for the last MFMA of the
@@ -257,7 +291,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     // ---- offset term: acc_t[m, n] += sum_g rowsum[g][m] * coef[g][n] over this split's groups, on the matrix cores in
     // f32 (v_mfma_f32_32x32x2_f32: products and sums exact to f32): lane (c, h) supplies row / column c of group 2 i + h,
     // every load is one coalesced dword per lane.
-    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC) {
+    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && BITS == 4)) {
         const uint32_t Mp = (M + 3) & ~3u;
         uint32_t arow[2];
 #pragma unroll
@@ -409,7 +443,7 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     float* coef = (float*)((uint8_t*)workspace + rowsum_bytes);
     float* partials = splits > 1 ? (float*)((uint8_t*)workspace + rowsum_bytes + coef_bytes) : nullptr;
     uzu_status st = UZU_OK;
-    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC) {
+    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && p.bits == 4)) {
         const uint32_t rowsum_blocks = (((p.m + 3) & ~3u) + 3) / 4, coef_blocks = (p.n * G + 255) / 256;
         st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
         if (st != UZU_OK) return st;
