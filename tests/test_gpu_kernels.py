@@ -771,7 +771,10 @@ def test_delta_net_prefill_path(hip_ctx, T):
     np.testing.assert_array_equal(b_de.download(np.float32, decay.size).reshape(decay.shape), decay)
     np.testing.assert_allclose(b_st.download(np.float32, state.size).reshape(state.shape), w_st, rtol=1e-4, atol=1e-4)
     got = b_out.download(np.uint16, w_out.size).reshape(w_out.shape)
-    assert np.abs(f32(got) - f32(w_out)).max() <= 2e-2 and (ulp_diff_bf16(w_out, got) <= 2).mean() > 0.99
+    # the chunked form sums in another order than the one-token recurrence (f32, ~1e-6 relative): after the bf16 rounding of the
+    # output every element is within 2e-2 absolute or 1 bf16 ulp (|x| >= 4 has an ulp of 0.031), 99 % within 2 ulps
+    err, ulps = np.abs(f32(got) - f32(w_out)), ulp_diff_bf16(w_out, got)
+    assert ((err <= 2e-2) | (ulps <= 1)).all() and (ulps <= 2).mean() > 0.99
 
 
 # ------------------------------------------------------------------------------------------ command buffer

@@ -15,6 +15,8 @@
 // Same algebra, different rounding order: results agree with the one-token recurrence to ~1e-6 relative in f32
 // (tools/ prototype in the commit message), far below the bf16 output rounding.  Decays are carried in log space
 // (log a clamped at -80) so that products over a chunk cannot underflow into 0 / 0.
+#include <stdlib.h>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -390,6 +392,165 @@ __global__ void __launch_bounds__(512) dn_chunk_scan8w_kernel(const float* q_nor
     *(float2*)srow = sreg;
 }
 
+// Matrix-core scan (the shipping one).  The VALU scans above read two LDS operands per four FMAs: 780 KB of LDS reads per chunk and
+// workgroup, 158 us per 1024 tokens at the 0.8B shape.  Here the four products of a chunk run on v_mfma_f32_16x16x4_f32 -- f32
+// operands, exact f32 products, f32 accumulation: the arithmetic of the VALU scan in another summation order -- with operands
+// fetched once per chunk into registers.  A workgroup owns 16 value columns of a head (grid (Dv / 16, Hv), 4 waves):
+//   stage 1  [K; Q] S^T     wave w = one 16-token tile of K (w = 0, 1) or Q (w = 2, 3): 16 x 16 x 128, 32 MFMAs
+//   stage 2  D = T R        waves 0, 1: one 16-token tile each, 8 MFMAs; D and D diag(W) parked in LDS
+//   stage 3  O = A Q S^T + P D   waves 2, 3: their stage-1 accumulator is the C operand, 8 MFMAs
+//   stage 4  S = A_C S + (D W)^T K   every wave owns two 16-wide dk tiles of the state in its accumulators, 2 x 8 MFMAs
+// MFMA operand layout (16x16x4): A lane l = row l % 16, k-quarter l / 16; B lane l = column l % 16, k-quarter l / 16; C / D four
+// registers = rows 4 (l / 16) + r of column l % 16.  The contraction index of step s in quarter q is (K / 4) q + s for both
+// operands, so a lane's operand values are consecutive in memory.
+__global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
+                                                                 uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
+                                                                 uint32_t value_dim, uint32_t suffix_len) {
+    constexpr int DVT = 16, TPP = 36, RPP = 18; // value columns per workgroup; LDS pitches of T / P (16-byte rows) and R / D (conflict-free column walks)
+    __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVT * KP];
+    __shared__ __attribute__((aligned(16))) float sT[CC * TPP], sP[CC * TPP];
+    __shared__ float sR[CC * RPP], sD[CC * RPP], sDw[CC * RPP];
+    __shared__ float sA[CC], sW[CC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kq = lane >> 4;
+    const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVT, hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
+
+    // state: wave w owns dk tiles 2 w, 2 w + 1 in accumulator layout: creg[tile][r] = S[dv = 4 kq + r][dk = 16 (2 w + tile) + i16]
+    f32x4_v creg[2];
+    float* sbase = state + ((size_t)hv * head_v_dim + dv_base + 4 * kq) * DKC + 32 * wave + i16;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) creg[t][r] = sbase[(size_t)r * DKC + 16 * t];
+
+    // ---- operand staging: registers <- memory (chunk c + 1) while chunk c is computed, LDS <- registers at the chunk boundary
+    f32x4_v st_k[4], st_q[4];
+    float st_t[4], st_p[4], st_a = 0.f, st_w = 0.f, st_v[4];
+    const int v_row = 16 * (wave & 1) + 4 * kq; // stage-1 accumulator rows of waves 0, 1 (tokens of the chunk)
+    auto fetch = [&](uint32_t c) {
+        const uint32_t t0 = c * CC;
+        const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            const bool live = t0 + t < suffix_len;
+            const size_t tok = live ? t0 + t : suffix_len - 1; // clamped + zeroed: unconditional loads stay countable
+            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_v kv = *(const f32x4_v*)(k_norm + tok * key_dim + hk * DKC + c4 * 4);
+            const f32x4_v qv = *(const f32x4_v*)(q_norm + tok * key_dim + hk * DKC + c4 * 4);
+            st_k[r] = live ? kv : zero, st_q[r] = live ? qv : zero;
+            st_t[r] = w_t[idx], st_p[r] = w_t[CC * CC + idx];
+        }
+        st_a = w_t[2 * CC * CC + (tid & (CC - 1))], st_w = w_t[2 * CC * CC + CC + (tid & (CC - 1))];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = t0 + v_row + r < suffix_len;
+            const float vv = bf16_to_f32(in_proj[(size_t)(live ? t0 + v_row + r : suffix_len - 1) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + i16]);
+            st_v[r] = live ? vv : 0.f;
+        }
+    };
+    float vreg[4] = {0.f, 0.f, 0.f, 0.f};
+    auto publish = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            *(f32x4_v*)(sK + t * KP + c4 * 4) = st_k[r];
+            *(f32x4_v*)(sQ + t * KP + c4 * 4) = st_q[r];
+            sT[(idx / CC) * TPP + idx % CC] = st_t[r];
+            sP[(idx / CC) * TPP + idx % CC] = st_p[r];
+        }
+        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sS[(4 * kq + r) * KP + 32 * wave + 16 * t + i16] = creg[t][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vreg[r] = st_v[r];
+    };
+    auto mfma4 = [](float a, float b, f32x4_v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
+
+    fetch(0);
+    publish();
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t t0 = c * CC;
+        fetch(c + 1 < n_chunks ? c + 1 : c); // unconditional (the last chunk refetches itself)
+        // ---- stage 1: rows 16 (wave & 1) .. + 16 of K (waves 0, 1) or Q (waves 2, 3) against S^T, contraction over dk = 32 kq + s
+        f32x4_v acc1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float* xr = (wave < 2 ? sK : sQ) + (16 * (wave & 1) + i16) * KP + 32 * kq;
+            const float* sr = sS + i16 * KP + 32 * kq;
+            f32x4_v xa[8], sb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xa[q] = *(const f32x4_v*)(xr + 4 * q), sb[q] = *(const f32x4_v*)(sr + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1 = mfma4(xa[q][e], sb[q][e], acc1);
+        }
+        if (wave < 2) { // R = V - A (K S^T) for tokens v_row + r, value column i16
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sR[(v_row + r) * RPP + i16] = vreg[r] - sA[v_row + r] * acc1[r];
+        }
+        lds_barrier();
+        // ---- stage 2 (waves 0, 1): D = T R for tokens 16 wave + 4 kq + r; contraction over i = 8 kq + s
+        if (wave < 2) {
+            const float* tr = sT + (16 * wave + i16) * TPP + 8 * kq;
+            const f32x4_v ta0 = *(const f32x4_v*)tr, ta1 = *(const f32x4_v*)(tr + 4);
+            f32x4_v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) d = mfma4(s2 < 4 ? ta0[s2 & 3] : ta1[s2 & 3], sR[(8 * kq + s2) * RPP + i16], d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * wave + 4 * kq + r;
+                sD[t * RPP + i16] = d[r];
+                sDw[t * RPP + i16] = d[r] * sW[t];
+            }
+        }
+        lds_barrier();
+        // ---- stage 3 (waves 2, 3): O = A (Q S^T) + P D for tokens 16 (wave - 2) + 4 kq + r
+        if (wave >= 2) {
+            const int tb = 16 * (wave - 2);
+            const float* pr = sP + (tb + i16) * TPP + 8 * kq;
+            const f32x4_v pa0 = *(const f32x4_v*)pr, pa1 = *(const f32x4_v*)(pr + 4);
+            f32x4_v o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = sA[tb + 4 * kq + r] * acc1[r];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) o = mfma4(s2 < 4 ? pa0[s2 & 3] : pa1[s2 & 3], sD[(8 * kq + s2) * RPP + i16], o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t t = t0 + tb + 4 * kq + r;
+                if (t < suffix_len) out[(size_t)t * value_dim + hv * head_v_dim + dv_base + i16] = f32_to_bf16(o[r]);
+            }
+        }
+        // ---- stage 4 (all waves): S = A_C S + (D W)^T K for dk tiles 2 wave, 2 wave + 1; contraction over tokens 8 kq + s
+        {
+            const float a_c = sA[CC - 1];
+            float dw[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) dw[s2] = sDw[(8 * kq + s2) * RPP + i16]; // A operand: row = value column i16
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) creg[t][r] *= a_c;
+                const float* kc = sK + (8 * kq) * KP + 32 * wave + 16 * t + i16;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) creg[t] = mfma4(dw[s2], kc[s2 * KP], creg[t]);
+            }
+        }
+        lds_barrier(); // all reads of this chunk's LDS operands are done
+        if (c + 1 < n_chunks) publish();
+        lds_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sbase[(size_t)r * DKC + 16 * t] = creg[t][r];
+}
+
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
     static const uint32_t min_t = [] {
         const char* e = getenv("UZU_DN_CHUNK_MIN_T");
@@ -411,6 +572,15 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         const char* e = getenv("UZU_DN_CHUNK_DVS");
         return e ? atoi(e) : 0;
     }();
+    static const int use_mfma = [] {
+        const char* e = getenv("UZU_DN_CHUNK_MFMA");
+        return e ? atoi(e) : 1;
+    }();
+    if (use_mfma && !force)
+        return launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
+                               num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+        }, "delta_net_chunk_scan");
     const bool narrow = force ? force == 8 : num_v_heads * (head_v_dim / 16) < 200;
     static const int waves8 = [] {
         const char* e = getenv("UZU_DN_CHUNK_8W");
