@@ -46,6 +46,8 @@ typedef enum {
  *   zero_points  u8  [n, ceil(groups/pack)]               (ScaleZeroPoint only; 4 bit: nibble packed)
  *   out_biases   bf16 [n]                                 (Linear `biases`, optional)
  * method == UZU_QUANT_NONE: weights is bf16 [n,k], bits == 16, everything else NULL.
+ * HybridSpec { incoherence_processing_mode: InputOutput, block 32, no adapter } (RHTLinearWrapper, linear/rht_wrapper.rs:140-298):
+ *   input_signs  i32 [k], output_signs i32 [n] (+-1): y = OutputRht(W InputRht(x)) + out_biases; NULL = a plain linear.
  */
 typedef struct {
     uint32_t n;          /* output_dim */
@@ -59,6 +61,8 @@ typedef struct {
     const uint16_t* biases;
     const uint8_t* zero_points;
     const uint16_t* out_biases;
+    const int32_t* input_signs;
+    const int32_t* output_signs;
 } uzu_linear_desc;
 
 /* config/normalization.rs:10-18 + tensor `scales` f32 [dim] (encodable_block/normalization.rs:67-74) */

@@ -139,8 +139,17 @@ const uint16_t* orc_model_final_hidden(const orc_model* m) { return m->final_hid
 /* Linear::encode -> MatmulKernel::encode with b_transpose = true (linear/matmul.rs:122-148) */
 static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) {
     uint16_t* out = (uint16_t*)xcalloc((size_t)batch * lin->n, 2);
+    /* RHTLinearWrapper::encode_input (linear/rht_wrapper.rs:215-298), full-precision activation format: InputRht of the rows
+     * (encode_fp_in_place on the wrapper's own allocation), the inner LinearMatmul with MatmulDOps::rht_factors = output signs */
+    uint16_t* transformed = NULL;
+    if (lin->input_signs) {
+        transformed = (uint16_t*)xcalloc((size_t)batch * lin->k, 2);
+        orc_activation_transform(input, transformed, NULL, NULL, NULL, lin->input_signs, ORC_BF16, batch, lin->k, 0, 0, 0);
+        input = transformed;
+    }
     orc_matmul_args g;
     memset(&g, 0, sizeof(g));
+    g.rht_factors = lin->output_signs;
     g.a = input;
     g.a_dtype = ORC_BF16;
     g.b = lin->weights;
@@ -160,6 +169,7 @@ static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint3
     g.n = lin->n;
     g.k = lin->k;
     orc_matmul(&g);
+    free(transformed);
     return out;
 }
 

@@ -136,6 +136,17 @@ def test_model_directory_round_trip_runs_identically(hip_ctx, tmp_path):
         assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
+def test_rht_linears_end_to_end(hip_ctx, preset):
+    """HybridSpec InputOutput linears (RHTLinearWrapper, linear/rht_wrapper.rs:215-298) in every layer: InputRht on a copy of the
+    rows, the inner quantised matmul, OutputRht, then the bias -- prefill (matrix-core GEMM) and decode (transform + GEMV +
+    transform, graph replay) against the oracle, teacher-forced, arg-max identical outside near-ties."""
+    cfg = S.PRESETS[preset](rht=True)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 33, 8, teacher_forced=True)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+
+
 def test_fused_decode_matches_unfused(hip_ctx):
     """The fused decode kernels (norm prologue + GEMV + activation / arg-max epilogues, conv + delta update) use the
     same arithmetic as the one-kernel-per-reference-kernel path: on a DeltaNet-only model tokens AND logits are

@@ -43,6 +43,8 @@ def variants():
     yield "int8-symmetric-yarn", S.tiny_llama(bits=8, method=D.QUANT_SCALE_SYMMETRIC, tied_embeddings=True,
                                               rope=D.RopeConfig(kind=D.ROPE_YARN, head_dim=64, max_sequence_length=8192, base=10000.0, scaling_factor=4.0,
                                                                 original_context_length=1024, beta_fast=32.0, beta_slow=1.0, truncate=False))
+    yield "rht-qwen", S.tiny_qwen(rht=True)   # HybridSpec InputOutput linears: weights.quantized.* + weights.incoherence_signs.*
+    yield "rht-llama-int8", S.tiny_llama(rht=True, bits=8, method=D.QUANT_SCALE_BIAS)
     yield "longrope", S.tiny_llama(rope=D.RopeConfig(kind=D.ROPE_LONGROPE, head_dim=64, max_sequence_length=8192, base=10000.0, scaling_factor=8.0,
                                                      original_context_length=1024, short_factor=rng.uniform(1.0, 1.2, 32).astype(np.float32),
                                                      long_factor=rng.uniform(1.0, 6.0, 32).astype(np.float32)))
@@ -65,6 +67,33 @@ def test_round_trip_is_lossless_and_the_oracle_agrees(tmp_path, name, cfg):
     t0, l0 = O.OracleModel(bundle).prefill(prompt, True)
     t1, l1 = O.OracleModel(loaded).prefill(prompt, True)
     assert t0 == t1 and np.array_equal(l0, l1)
+
+
+def test_rht_linears_change_the_forward_and_are_refused_where_unsupported(tmp_path):
+    """HybridSpec (config/weight_matrix/hybrid_spec.rs): only {no adapter, block 32, input_output} maps onto RHTLinearWrapper
+    (linear/mod.rs:118-136); the sign vectors are part of the forward (another model without them)."""
+    cfg = S.tiny_llama(rht=True)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(9, cfg.vocab_size)
+    _, with_rht = O.OracleModel(bundle).prefill(prompt, True)
+    plain = S.build_model(S.tiny_llama())
+    _, without = O.OracleModel(plain).prefill(prompt, True)
+    assert not np.array_equal(with_rht, without)
+    d = str(tmp_path)
+    L.save_model_dir(bundle, d)
+    path = os.path.join(d, "model.safetensors")
+    st = L.SafeTensors(path)
+    tensors = {k: (st.index[k][0], st.tensor(k, st.index[k][1], st.index[k][0])) for k in st.index}
+    key = "decoder.transformer.layers.0.mlp.down_projection.weights.spec"
+    for field, value, what in (("incoherence_processing_mode", "input", "incoherence processing"), ("incoherence_block_size", 64, "incoherence processing"),
+                               ("adapter_spec", {"type": "LowRankSpec", "rank": 8}, "QLoRA")):
+        meta = dict(st.metadata)
+        meta[key] = json.dumps({**json.loads(meta[key]), field: value})
+        L.write_safetensors(path, tensors, meta)
+        with pytest.raises(L.UnsupportedModelError, match=what):
+            L.load_model_dir(d)
+    with pytest.raises(NotImplementedError):  # tensor-parallel shards of RHT linears are not planned yet
+        bundle.layers[0].up_projection.rows(0, 64)
 
 
 def test_written_file_is_a_valid_safetensors_file_for_an_independent_reader(tmp_path):

@@ -38,6 +38,8 @@ struct DLinear {
     void* biases = nullptr;
     uint8_t* zp = nullptr;
     void* out_biases = nullptr;
+    int32_t* in_signs = nullptr;  // HybridSpec InputOutput (RHTLinearWrapper): sign factors of the input / output Hadamard transforms
+    int32_t* out_signs = nullptr;
 };
 struct DNorm {
     bool present = false;
@@ -116,6 +118,8 @@ struct uzu_hip_model {
     // fused decode path
     bool fusable = false;
     uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
+    uint16_t* rht_scratch = nullptr; // [rows][widest RHT input]: InputRht works on a copy of the rows
+    uint32_t rht_max_k = 0;
     float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
     float* dn_ws = nullptr; // chunked DeltaNet prefill: T / P matrices of one 1024-token pass (k_deltanet_chunk.hip)
     float *dn_o = nullptr, *dn_sz = nullptr; // raw DeltaNet outputs and SiLU(z) of the decode token (f32 [value_dim])
@@ -279,6 +283,13 @@ uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o)
             UZU_PROPAGATE(upload(m, h.zero_points, (size_t)h.n * (h.bits == 4 ? (groups + 1) / 2 : groups), &o->zp));
     }
     UZU_PROPAGATE(upload(m, h.out_biases, (size_t)h.n * 2, &o->out_biases));
+    if (h.input_signs || h.output_signs) {
+        UZU_REQUIRE(h.input_signs && h.output_signs, "engine: an RHT linear needs both input_signs and output_signs (HybridSpec InputOutput)");
+        UZU_REQUIRE(h.n % 32 == 0 && h.k % 32 == 0, "engine: RHT linear %u x %u is not a whole number of 32-wide Hadamard blocks", h.n, h.k);
+        UZU_PROPAGATE(upload(m, h.input_signs, (size_t)h.k * 4, &o->in_signs));
+        UZU_PROPAGATE(upload(m, h.output_signs, (size_t)h.n * 4, &o->out_signs));
+        m->rht_max_k = m->rht_max_k > h.k ? m->rht_max_k : h.k;
+    }
     return UZU_OK;
 }
 
@@ -380,11 +391,21 @@ struct Enc {
 
 // `row_parallel`: under tensor parallelism this linear's K is split over the ranks (out-proj, down-proj): the matmul
 // writes f32 partial sums, the ranks all-reduce them, and the sum is rounded to bf16 into `output`.
+//
+// RHT linears (RHTLinearWrapper::encode_input, linear/rht_wrapper.rs:215-298, full-precision activation format): InputRht on a
+// copy of the rows (the reference transforms its own allocation in place), the inner matmul without its bias, OutputRht in place
+// on the result, then the bias (MatmulDOps::rht_factors, kernel.rs:296-303).
 void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false) {
     const bool exchange = row_parallel && e.m->tp != nullptr;
+    if (L.in_signs) {
+        RUN("activation_transform", 0, k::activation_transform(e.s, input, e.m->rht_scratch, nullptr, nullptr, nullptr, L.in_signs, UZU_BF16, batch, L.k,
+                                                                UZU_ACTIVATION_TRANSFORM_INPUT_RHT, 0, 0));
+        input = e.m->rht_scratch;
+    }
     k::MatmulParams p{};
     p.a = input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = output, p.bias = L.out_biases;
     p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    if (L.out_signs) p.bias = nullptr; // bias_after_rht
     if (exchange) p.d = e.m->tp_buf, p.d_dt = UZU_F32;
     p.b_kind = L.method == UZU_QUANT_NONE ? UZU_MATMUL_B_FULL_PRECISION
              : L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS
@@ -399,6 +420,11 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
         const size_t count = (size_t)batch * L.n;
         RUN("all_reduce", count * 4, tp::all_reduce_sum_f32(e.m->tp, e.s, e.m->tp_buf, count));
         RUN("tp_cast", 0, tp::cast_f32_bf16(e.s, e.m->tp_buf, output, count));
+    }
+    if (L.out_signs) {
+        RUN("activation_transform", 0, k::activation_transform(e.s, nullptr, output, nullptr, nullptr, nullptr, L.out_signs, UZU_BF16, batch, L.n,
+                                                                UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
+        if (L.out_biases) RUN("tensor_add_bias", 0, k::tensor_add_bias(e.s, output, L.out_biases, output, UZU_BF16, UZU_BF16, L.n, (size_t)batch * L.n));
     }
 }
 
@@ -686,7 +712,7 @@ void dec_gemv_row_parallel(Enc& e, k::DecGemvParams p, const char* name) {
 }
 
 bool linear_fusable(const DLinear& L) {
-    if (!L.w) return false;
+    if (!L.w || L.in_signs || L.out_signs) return false; // RHT linears run as transform + matmul + transform (unfused decode)
     if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
     return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
 }
@@ -1006,6 +1032,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         ALLOC(decay, float, C * max_hv);
     }
     ALLOC(shortcut_b, uint16_t, C * d);
+    if (m->rht_max_k) ALLOC(rht_scratch, uint16_t, CB * m->rht_max_k);
     ALLOC(amax_val, float, kArgmaxPartials);
     ALLOC(amax_idx, uint32_t, kArgmaxPartials);
     if (max_qkv) {

@@ -28,6 +28,7 @@ class LinearDesc(C.Structure):
         ("method", C.c_uint32), ("reserved", C.c_uint32),
         ("weights", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p),
         ("zero_points", C.c_void_p), ("out_biases", C.c_void_p),
+        ("input_signs", C.c_void_p), ("output_signs", C.c_void_p),
     ]
 
 
@@ -101,17 +102,22 @@ class LinearWeights:
     biases: Optional[np.ndarray] = None       # uint16 [n, groups]
     zero_points: Optional[np.ndarray] = None  # u8
     out_biases: Optional[np.ndarray] = None   # uint16 [n]
+    input_signs: Optional[np.ndarray] = None  # int32 [k]  (HybridSpec InputOutput: RHTLinearWrapper, rht_wrapper.rs:140-298)
+    output_signs: Optional[np.ndarray] = None  # int32 [n]
 
     def desc(self) -> LinearDesc:
         return LinearDesc(self.n, self.k, self.bits, self.group_size, self.method, 0, _ptr(self.weights),
-                          _ptr(self.scales), _ptr(self.biases), _ptr(self.zero_points), _ptr(self.out_biases))
+                          _ptr(self.scales), _ptr(self.biases), _ptr(self.zero_points), _ptr(self.out_biases),
+                          _ptr(self.input_signs), _ptr(self.output_signs))
 
     def nbytes(self) -> int:
-        return sum(a.nbytes for a in (self.weights, self.scales, self.biases, self.zero_points, self.out_biases)
-                   if a is not None)
+        return sum(a.nbytes for a in (self.weights, self.scales, self.biases, self.zero_points, self.out_biases, self.input_signs,
+                                      self.output_signs) if a is not None)
 
     def rows(self, lo: int, hi: int) -> "LinearWeights":
         """Column-parallel shard: output rows [lo, hi) (any split is layout-safe, groups run along k)."""
+        if self.input_signs is not None or self.output_signs is not None:
+            raise NotImplementedError("tensor-parallel shards of RHT (HybridSpec) linears")
         sl = slice(lo, hi)
         cp = lambda a: None if a is None else np.ascontiguousarray(a[sl])
         return LinearWeights(hi - lo, self.k, self.bits, self.group_size, self.method, cp(self.weights),

@@ -65,6 +65,7 @@ class ModelConfig:
     max_context_length: int = 4096
     seed: int = 42
     logit_row_sigma: float = 0.6   # log-normal spread of per-token readout row norms (peaked logits)
+    rht: bool = False              # every layer linear is a HybridSpec InputOutput linear (random +-1 sign vectors; not the embeddings)
 
     @property
     def num_layers(self) -> int:
@@ -180,7 +181,11 @@ def make_linear(cfg: ModelConfig, name: str, n: int, k: int, gain: float = 1.0,
     ob = None
     if out_bias:
         ob = f32_to_bf16_bits(rng.uniform(-0.1, 0.1, size=(n,)).astype(np.float32))
-    return D.LinearWeights(n, k, bits, g, method, codes, scales_b, biases_b, zero_points, ob)
+    lw = D.LinearWeights(n, k, bits, g, method, codes, scales_b, biases_b, zero_points, ob)
+    if cfg.rht and name.startswith("layers.") and n % 32 == 0 and k % 32 == 0:  # whole 32-wide Hadamard blocks on both sides
+        signs = np.array([-1, 1], np.int32)
+        lw.input_signs, lw.output_signs = np.ascontiguousarray(rng.choice(signs, k)), np.ascontiguousarray(rng.choice(signs, n))
+    return lw
 
 
 def readout_row_multipliers(cfg: ModelConfig) -> np.ndarray:
