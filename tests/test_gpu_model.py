@@ -147,6 +147,21 @@ def test_rht_linears_end_to_end(hip_ctx, preset):
         assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
 
 
+def test_gated_act_mul_in_the_gemm_epilogue_is_bit_identical(hip_ctx):
+    """Prefill-sized rows: the up projection's matrix-core GEMM pairs the up and gate columns of an output in one workgroup and
+    applies GatedActMul in its epilogue (k_gemm128.hip); with UZU_MODEL_NO_FUSION the engine runs the GEMM and gated_act_mul.rs's
+    kernel separately.  Same rounding points, so logits and tokens are bit-identical (160-token prompt, group 64)."""
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(160, cfg.vocab_size)
+    outs = []
+    for flags in (0, MODEL_NO_FUSION):
+        hm = HipModel(hip_ctx, bundle, flags)
+        outs.append((hm.prefill(prompt), hm.read_logits()))
+        hm.close()
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_fused_decode_matches_unfused(hip_ctx):
     """The fused decode kernels (norm prologue + GEMV + activation / arg-max epilogues, conv + delta update) use the
     same arithmetic as the one-kernel-per-reference-kernel path: on a DeltaNet-only model tokens AND logits are

@@ -428,6 +428,29 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
     }
 }
 
+// up projection + GatedActMul in one kernel (the matrix-core GEMM's epilogue pairs the up and gate columns of an output);
+// false = not available for this shape / mode: the caller runs the two kernels
+bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gated_out, uint32_t batch, uint32_t act_type) {
+    static const bool enabled = [] {
+        const char* v = getenv("UZU_GEMM_ACT");
+        return !v || atoi(v) != 0;
+    }();
+    if (!enabled || L.in_signs || L.out_signs || L.out_biases || L.method == UZU_QUANT_NONE || (e.m->flags & UZU_MODEL_NO_FUSION)) return false;
+    k::MatmulParams p{};
+    p.a = input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = gated_out;
+    p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    p.b_kind = L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+    p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f;
+    p.m = batch, p.n = L.n, p.k = L.k;
+    if (!k::matmul_act_mul_supported(e.s, p, e.m->ctx->num_cus)) return false;
+    p.act_mul = 1, p.act_type = act_type;
+    const char* variant = "matmul";
+    e.begin();
+    const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
+    e.run(r, "gemm_q_mfma+act", k::matmul_algorithmic_bytes(p));
+    return true;
+}
+
 // mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
 void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim) {
     k::NormParams p{};
@@ -619,8 +642,10 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, rows * d));
         }
         norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d);
-        linear(e, L.up, m->normed, m->up, rows);
-        RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
+        if (!linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
+            linear(e, L.up, m->normed, m->up, rows);
+            RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
+        }
         linear(e, L.down, m->gated, hidden, rows, true);
         if (L.post_mlp.present) {
             norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, rows, d);

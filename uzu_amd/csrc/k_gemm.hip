@@ -289,7 +289,7 @@ bool gemm_q_mfma_supported(const MatmulParams& p) {
     }();
     if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || (p.bits != 4 && p.bits != 8)) return false;
     if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || (p.d_dt != UZU_BF16 && p.d_dt != UZU_F32)) return false;
-    if (p.m < min_m || p.gather || p.act_mul) return false;
+    if (p.m < min_m || p.gather) return false; // act_mul: only the 128-tile kernel has the fused epilogue (checked in gemm_q_mfma)
     if (p.k % BK || p.group_size % BK || p.k % p.group_size) return false;
     if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16 || ((size_t)p.k * p.bits / 8) % 16) return false;
     return true;
@@ -313,8 +313,12 @@ uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus) {
     }();
     // M >= 128: the 128 x 128 tile kernel (k_gemm128.hip).  Its scratch (row-sum pieces of A, split-K partials) is the
     // stream's workspace block, which is not available while the stream is being captured into a graph.
-    if (force != 64 && gemm_q_mfma128_supported(p, num_cus)) {
+    if ((force != 64 || p.act_mul) && gemm_q_mfma128_supported(p, num_cus)) {
         if (void* ws = stream_workspace(s, gemm_q_mfma128_workspace_bytes(p, num_cus))) return gemm_q_mfma128(s, p, num_cus, ws);
+    }
+    if (p.act_mul) {
+        set_error("matmul: the fused GatedActMul epilogue is not available for this shape (callers ask matmul_act_mul_supported first)");
+        return UZU_ERR_UNSUPPORTED;
     }
     switch (force) { // tools/kbench KB_GEMM sweep: 64 x 64 tiles (108 VGPRs, 4 waves / SIMD) win at every shape tried
     default: return launch_gemm<1, 1>(s, p);

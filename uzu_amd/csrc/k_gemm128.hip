@@ -24,6 +24,7 @@
 #include "gemm_convert.h"
 #include "gemm_tile_map.h"
 #include "kernels.h"
+#include "uzu_math.h"
 
 namespace uzu {
 namespace k {
@@ -105,11 +106,17 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     constexpr int DA = 2;                  // activation register stages
     constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
+    __shared__ uint64_t s_exp_tab[32]; // gated epilogue only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
     const uint32_t M = p.m, N = p.n, K = p.k;
-    const uint32_t m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+    // GatedActMul fused into the epilogue (p.act_mul; the up projection's rows [0, N/2) = up, [N/2, N) = gate, gated_act_mul.rs:52-58):
+    // a workgroup takes 64 up columns (its wn = 0 waves) and the 64 gate columns of the same outputs (wn = 1), so the two operands
+    // of an output sit in the two wave tiles of one workgroup and D is [M, N/2].
+    const bool gated = p.act_mul != 0;
+    const uint32_t H = N / 2;
+    const uint32_t m_tiles = (M + BM - 1) / BM, n_tiles = gated ? (H + 63) / 64 : (N + BN - 1) / BN;
     // Workgroups are dealt to the 8 XCDs round-robin and an XCD runs ~64 of them at a time, so tile numbering decides
     // what each 4 MB L2 sees: XCD x works through super-tiles x, x + 8, ... of TM x TN tiles (8 x 8 when the matrix is
     // large enough) -- the 64 resident workgroups then share 8 activation row blocks and 8 weight column blocks.
@@ -152,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     const uint8_t* w_src[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        ncol[nb] = min(n0 + wn * 64 + nb * 32 + c, N - 1);
+        ncol[nb] = gated ? (wn ? H : 0u) + min(n_t * 64 + nb * 32 + c, H - 1) : min(n0 + wn * 64 + nb * 32 + c, N - 1);
         w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)kt_lo * BK * BITS / 8 + (size_t)(32 * h) * BITS / 8;
     }
     u32x4_v ring[DB][2][WV];
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     uint16_t* d = (uint16_t*)p.d;
     float* d32 = (float*)p.d;
     const bool out_f32 = p.d_dt == UZU_F32;
-    const bool via_lds = !partials && !out_f32 && !p.accumulate && !p.has_soft_cap && N % 8 == 0 && (uintptr_t)p.d % 16 == 0;
+    const bool via_lds = !partials && !out_f32 && !p.accumulate && !p.has_soft_cap && (gated ? H : N) % 8 == 0 && (uintptr_t)p.d % 16 == 0; // gated: host-checked
     if (via_lds) {
         // Common case, branch-free: bf16(ab_scale * acc + bias) goes to a wave-private LDS tile (64 rows x 64 columns,
         // 144-byte pitch; the activation buffers are free after the last barrier) and leaves as 16-byte row segments,
@@ -337,13 +344,37 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
                     s_d[(lr + 1) * 72 + nb * 32 + c] = (uint16_t)(pk >> 16);
                 }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no workgroup barrier needed
         const int seg = lane & 7, rsub = lane >> 3;
+        if (gated) {
+            // the up tile (wave wm * 2) and the gate tile (wave wm * 2 + 1) hold the same (row, column) positions:
+            // out = bf16(up * act(gate)), both operands already rounded to bf16 as the separate kernels would see them; each of the
+            // pair's waves combines 32 of the 64 rows; the exp table of SiLU / softplus sits in LDS (a table read from memory per
+            // element is a dependent round trip with two waves to hide it)
+            if (tid < 32) s_exp_tab[tid] = kExp2fTab[tid];
+            __syncthreads();
+            const uint16_t* s_u = (const uint16_t*)&s_a[0][0] + (wm * 2) * (64 * 72);
+            const uint16_t* s_g = s_u + 64 * 72;
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const uint32_t lr = pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n0 + wn * 64 + seg * 8;
-            const u32x4_v v = *(const u32x4_v*)(s_d + lr * 72 + seg * 8);
-            if (m < M && n < N) *(u32x4_v*)(d + (size_t)m * N + n) = v;
+            for (int pass = 0; pass < 4; ++pass) {
+                const uint32_t lr = wn * 32 + pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n_t * 64 + seg * 8;
+                const u32x4_v uv = *(const u32x4_v*)(s_u + lr * 72 + seg * 8), gv = *(const u32x4_v*)(s_g + lr * 72 + seg * 8);
+                u32x4_v ov;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float u0 = bits_to_f32(uv[w] << 16), u1 = bits_to_f32(uv[w] & 0xFFFF0000u);
+                    const float g0 = bits_to_f32(gv[w] << 16), g1 = bits_to_f32(gv[w] & 0xFFFF0000u);
+                    ov[w] = pack_bf16(u0 * activate_bf16_tab(p.act_type, g0, s_exp_tab), u1 * activate_bf16_tab(p.act_type, g1, s_exp_tab));
+                }
+                if (m < M && n < H) *(u32x4_v*)(d + (size_t)m * H + n) = ov;
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no workgroup barrier needed
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const uint32_t lr = pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n0 + wn * 64 + seg * 8;
+                const u32x4_v v = *(const u32x4_v*)(s_d + lr * 72 + seg * 8);
+                if (m < M && n < N) *(u32x4_v*)(d + (size_t)m * N + n) = v;
+            }
         }
     } else if (partials) { // split-K: raw f32 partial tile (32 lanes = one 128-byte row segment per store)
         float* pz = partials + (size_t)z * M * N;
@@ -414,8 +445,9 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
     const uint32_t G = p.k / p.group_size, gs = p.group_size / BK;
     const uint32_t tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
     auto ok = [&](uint32_t s) { return G % s == 0 && ((G / s) * gs) % 4 == 0; };
-    if (force > 0) return ok((uint32_t)force) ? (uint32_t)force : 0u;
+    if (force > 0 && !p.act_mul) return ok((uint32_t)force) ? (uint32_t)force : 0u;
     if (!ok(1)) return 0;
+    if (p.act_mul) return 1; // the gated epilogue pairs the two wave tiles of one workgroup: no partial tiles
     uint32_t best = 1;
     for (uint32_t s = 2; s <= 4; ++s) // each split adds an f32 tile round trip: stop once the chip has a workgroup per CU
         if (ok(s) && tiles * best < (uint32_t)num_cus * 3 / 4 && tiles * s <= (uint32_t)num_cus * 2) best = s;
@@ -423,6 +455,7 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;
+    if (p.act_mul && (p.n % 16 || p.d_dt != UZU_BF16 || p.accumulate || p.has_soft_cap || (uintptr_t)p.d % 16 || gemm128_splits(p, num_cus) != 1)) return false;
     if (p.group_size != 64 && p.group_size != 128 && p.group_size != 256) return false;
     if ((size_t)p.k * p.bits / 8 % 16 || p.k % BK) return false;
     if ((uint64_t)p.m * p.k >= (1ull << 32) || (uint64_t)p.n * p.k * p.bits / 8 >= (1ull << 32)) return false; // 32-bit element offsets
@@ -448,7 +481,7 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
         st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
         if (st != UZU_OK) return st;
     }
-    const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
+    const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
     const dim3 grid(gemm_grid_x(m_tiles, n_tiles), splits);
 #define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum, coef, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
     const uint32_t gs = p.group_size / BK;

@@ -284,6 +284,15 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
     return launch_gemv<float, float, 8>(s, p, num_cus, variant);
 }
 
+bool matmul_act_mul_supported(hipStream_t s, const MatmulParams& p, int num_cus) {
+    MatmulParams q = p;
+    q.act_mul = 1;
+    if (exact_mode() || q.b_kind == UZU_MATMUL_B_FULL_PRECISION || (uintptr_t)q.b % 16 || (uintptr_t)q.a % 16) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false; // no workspace during capture
+    return gemm_q_mfma_supported(q) && gemm_q_mfma128_supported(q, num_cus);
+}
+
 // full-precision B with explicit layout (b_transpose / leading dimension) -- reference-order kernel
 uzu_status matmul_full_precision(hipStream_t s, const MatmulParams& p, uint32_t b_transpose, uint32_t ld) {
     const size_t total = (size_t)p.m * p.n;

@@ -162,4 +162,24 @@ UZU_HD float logf_glibc(float x) {
 UZU_HD float silu_f32(float x) { return x / (1.0f + expf_glibc(-1.0f * x)); }
 UZU_HD float silu_f32_tab(float x, const uint64_t* tab) { return x / (1.0f + expf_glibc_tab(-1.0f * x, tab)); }
 
+// ActivationType::activate with T = bf16 (gpu_types/activation_type.rs:16-65): the arithmetic of k_elementwise.hip::activate<bf16_t>,
+// shared with the GEMM's fused GatedActMul epilogue (k_gemm128.hip)
+UZU_HD float activate_bf16(uint32_t act, float x) {
+    switch (act) {
+    case 0: return round_bf16(x / (1.0f + expf_glibc(-1.0f * x)));
+    case 1: return round_bf16(0.5f * x * (1.0f + tanhf(0.7978846f * (x + 0.044715f * x * x * x))));
+    case 2: return round_bf16(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
+    case 3: return x;
+    case 4: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc(x)));
+    default: return x;
+    }
+}
+// same, with the exp table parked in LDS by the caller (kExp2fTab, 32 entries): no dependent global-memory load per element
+__device__ __forceinline__ float activate_bf16_tab(uint32_t act, float x, const uint64_t* tab) {
+    switch (act) {
+    case 0: return round_bf16(x / (1.0f + expf_glibc_tab(-1.0f * x, tab)));
+    case 4: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc_tab(x, tab)));
+    default: return activate_bf16(act, x);
+    }
+}
 } // namespace uzu
