@@ -629,7 +629,7 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     *wide_out = false;
     if (weight_bytes >= (16u << 20)) {
         R = (cpl == 2 && !p.act_mul) ? 2 : 1;
-        // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/gpu_call14/17.sh): int4 kernels with K >= 4096 5-25 % faster
+        // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/ab_decode_env.sh): int4 kernels with K >= 4096 5-25 % faster
         // (up 22.3 -> 20.2 us, down 13.1 -> 11.1, read-out 62 -> 55, 14B read-out 113 -> 100); K = 1024 (Qwen3.5 read-out: dozens of
         // batches per wave, a 2 KB activation row) 5 % slower and the int8 kernels (128-register cap at 16 waves) 10 % slower
         *wide_out = wide_on && force_r <= 0 && (wide_on == 2 || (p.bits == 4 && cpl >= 2));
