@@ -418,8 +418,7 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
     e.run(r, variant, k::matmul_algorithmic_bytes(p));
     if (exchange) {
         const size_t count = (size_t)batch * L.n;
-        RUN("all_reduce", count * 4, tp::all_reduce_sum_f32(e.m->tp, e.s, e.m->tp_buf, count));
-        RUN("tp_cast", 0, tp::cast_f32_bf16(e.s, e.m->tp_buf, output, count));
+        RUN("all_reduce", count * 4, tp::all_reduce_sum_f32(e.m->tp, e.s, e.m->tp_buf, count, output)); // sums rounded to bf16 into `output`
     }
     if (L.out_signs) {
         RUN("activation_transform", 0, k::activation_transform(e.s, nullptr, output, nullptr, nullptr, nullptr, L.out_signs, UZU_BF16, batch, L.n,
@@ -732,8 +731,7 @@ void dec_gemv_row_parallel(Enc& e, k::DecGemvParams p, const char* name) {
     uint16_t* out = p.out[0];
     p.out_f32 = m->tp_buf;
     dec_gemv(e, p, name);
-    RUN("all_reduce", (size_t)p.n[0] * 4, tp::all_reduce_sum_f32(m->tp, e.s, m->tp_buf, p.n[0]));
-    RUN("tp_cast", 0, tp::cast_f32_bf16(e.s, m->tp_buf, out, p.n[0]));
+    RUN("all_reduce", (size_t)p.n[0] * 4, tp::all_reduce_sum_f32(m->tp, e.s, m->tp_buf, p.n[0], out));
 }
 
 bool linear_fusable(const DLinear& L) {

@@ -25,7 +25,7 @@ void p2p_disable(Comm* c);
 uzu_status p2p_error(Comm* c, uint32_t* out);
 uzu_status comm_create_local(int rank, int size, Comm** out); // no RCCL communicator: P2P exchanges only (tests; small groups)
 
-uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count);          // in place
+uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count, uint16_t* bf16_out = nullptr); // in place; optional bf16 copy of the sums
 uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count);
 
 uzu_status cast_f32_bf16(hipStream_t s, const float* in, uint16_t* out, size_t n);

@@ -169,33 +169,40 @@ struct P2PArgs {
     Mailbox* box[kMaxRanks];
     int rank, size;
 };
-// OP 0: f32 sum over `count` floats (in place on buf); OP 1: u64 max over `count` keys (buf = unsigned long long*)
+// OP 0: f32 sum over `count` floats (in place on buf; `bf16_out` (optional) also receives the sums rounded to bf16: the cast the
+// engine would otherwise launch as its own kernel); OP 1: u64 max over `count` keys (buf = unsigned long long*).
+//
+// Mailbox traffic uses relaxed system-scope 8-byte atomics (sc0 sc1 accesses: they bypass the caches on both sides whatever
+// memory type the peer mapping got) and explicit ordering instead of release / acquire fences -- a system-scope fence writes back
+// or invalidates the whole L2 (1.7 us each on a clean cache): payload stores -> every wave s_waitcnt vmcnt(0) (a write-through
+// store is acknowledged by the destination) -> workgroup barrier -> flag stores; on the other side the payload loads are issued
+// after the polling loop has seen the flag and the barrier has released the workgroup (no speculation across it).
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 ld_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 template <int OP>
-__global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* buf, uint32_t count) {
+__global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* buf, uint32_t count, uint16_t* bf16_out) {
     __shared__ uint32_t s_seq, s_ok;
     Mailbox* mine = a.box[a.rank];
-    const uint32_t tid = threadIdx.x, words = OP == 0 ? count : 2 * count;
+    const uint32_t tid = threadIdx.x, words = OP == 0 ? count : 2 * count, pairs = (words + 1) / 2;
     if (tid == 0) s_seq = mine->seq[0] + 1u, s_ok = 1u;
     __syncthreads();
     const uint32_t seq = s_seq, par = seq & 1u;
-    // 1. push
+    // 1. push: this rank's row into slot [parity][rank] of every mailbox (an odd tail word travels with a zero partner)
     const uint32_t* src = (const uint32_t*)buf;
-    for (int r = 0; r < a.size; ++r) {
-        uint32_t* dst = (uint32_t*)a.box[r]->data[par][a.rank];
-        for (uint32_t i = tid * 4; i < words; i += 256 * 4) {
-            if (i + 4 <= words) __builtin_nontemporal_store(*(const u32x4_v*)(src + i), (u32x4_v*)(dst + i));
-            else for (uint32_t j = i; j < words; ++j) __builtin_nontemporal_store(src[j], dst + j);
-        }
+    for (uint32_t i = tid; i < pairs; i += 256) {
+        const u64 v = (u64)src[2 * i] | (2 * i + 1 < words ? (u64)src[2 * i + 1] << 32 : 0ull);
+        for (int r = 0; r < a.size; ++r) st_sys((u64*)a.box[r]->data[par][a.rank] + i, v);
     }
-    // 2. publish
-    __threadfence_system();
+    // 2. publish once every payload store of the workgroup has been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < (uint32_t)a.size) __hip_atomic_store(&a.box[tid]->flags[par][a.rank][0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < (uint32_t)a.size) __hip_atomic_store(&a.box[tid]->flags[par][a.rank][0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // 3. wait for every rank's contribution in the local mailbox (bounded: ~2 s of the 100 MHz clock)
     if (tid < (uint32_t)a.size) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(&mine->flags[par][tid][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&mine->flags[par][tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
                 s_ok = 0u;
                 break;
@@ -203,28 +210,32 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
         }
     }
     __syncthreads();
-    __threadfence_system();
     if (!s_ok) {
         if (tid == 0) mine->error[0] = seq;
         return; // leave buf untouched: the host sees the error flag
     }
-    // 4. reduce in rank order
-    if (OP == 0) {
-        float* out = (float*)buf;
-        for (uint32_t i = tid; i < count; i += 256) {
-            float acc = __builtin_nontemporal_load(&mine->data[par][0][i]);
-            for (int r = 1; r < a.size; ++r) acc += __builtin_nontemporal_load(&mine->data[par][r][i]);
-            out[i] = acc;
-        }
-    } else {
-        unsigned long long* out = (unsigned long long*)buf;
-        for (uint32_t i = tid; i < count; i += 256) {
-            unsigned long long best = 0;
-            for (int r = 0; r < a.size; ++r) {
-                const unsigned long long v = __builtin_nontemporal_load((const unsigned long long*)mine->data[par][r] + i);
-                best = v > best ? v : best;
+    // 4. reduce in rank order (the same order on every rank: bit-identical results)
+    for (uint32_t i = tid; i < pairs; i += 256) {
+        u64 v = ld_sys((const u64*)mine->data[par][0] + i);
+        if (OP == 0) {
+            float lo = bits_to_f32((uint32_t)v), hi = bits_to_f32((uint32_t)(v >> 32));
+            for (int r = 1; r < a.size; ++r) {
+                const u64 w = ld_sys((const u64*)mine->data[par][r] + i);
+                lo += bits_to_f32((uint32_t)w), hi += bits_to_f32((uint32_t)(w >> 32));
             }
-            out[i] = best;
+            float* out = (float*)buf;
+            out[2 * i] = lo;
+            if (bf16_out) bf16_out[2 * i] = f32_to_bf16(lo);
+            if (2 * i + 1 < words) {
+                out[2 * i + 1] = hi;
+                if (bf16_out) bf16_out[2 * i + 1] = f32_to_bf16(hi);
+            }
+        } else {
+            for (int r = 1; r < a.size; ++r) {
+                const u64 w = ld_sys((const u64*)mine->data[par][r] + i);
+                v = w > v ? w : v;
+            }
+            ((u64*)buf)[i] = v;
         }
     }
     __syncthreads();
@@ -329,19 +340,20 @@ uzu_status p2p_error(Comm* c, uint32_t* out) { // sequence number of the exchang
     UZU_HIP_TRY(hipMemcpy(out, c->p2p.local->error, 4, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
-template <int OP> static uzu_status p2p_launch(Comm* c, hipStream_t s, void* buf, uint32_t count) {
+template <int OP> static uzu_status p2p_launch(Comm* c, hipStream_t s, void* buf, uint32_t count, uint16_t* bf16_out = nullptr) {
     P2PArgs a{};
     for (int r = 0; r < c->size; ++r) a.box[r] = c->p2p.peer[r];
     a.rank = c->rank, a.size = c->size;
-    return launch_check([&] { hipLaunchKernelGGL(p2p_all_reduce_kernel<OP>, dim3(1), dim3(256), 0, s, a, buf, count); }, "tp_p2p_all_reduce");
+    return launch_check([&] { hipLaunchKernelGGL(p2p_all_reduce_kernel<OP>, dim3(1), dim3(256), 0, s, a, buf, count, bf16_out); }, "tp_p2p_all_reduce");
 }
 int comm_rank(const Comm* c) { return c->rank; }
 int comm_size(const Comm* c) { return c->size; }
 
-uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count) {
-    if (c->p2p.connected && count <= kMailboxFloats) return p2p_launch<0>(c, s, buf, (uint32_t)count); // decode rows: one hop
+uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count, uint16_t* bf16_out) {
+    if (c->p2p.connected && count <= kMailboxFloats) return p2p_launch<0>(c, s, buf, (uint32_t)count, bf16_out); // decode rows: one hop
     UZU_REQUIRE(c->comm, "tp: no RCCL communicator for a %zu-float all-reduce", count);
-    return check(g_api.AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->comm, s), "ncclAllReduce(sum,f32)");
+    UZU_PROPAGATE(check(g_api.AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->comm, s), "ncclAllReduce(sum,f32)"));
+    return bf16_out ? cast_f32_bf16(s, buf, bf16_out, count) : UZU_OK;
 }
 uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count) {
     if (c->p2p.connected && count * 2 <= kMailboxFloats) return p2p_launch<1>(c, s, buf, (uint32_t)count);
