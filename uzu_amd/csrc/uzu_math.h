@@ -175,7 +175,7 @@ UZU_HD float activate_bf16(uint32_t act, float x) {
     }
 }
 // same, with the exp table parked in LDS by the caller (kExp2fTab, 32 entries): no dependent global-memory load per element
-__device__ __forceinline__ float activate_bf16_tab(uint32_t act, float x, const uint64_t* tab) {
+UZU_HD float activate_bf16_tab(uint32_t act, float x, const uint64_t* tab) {
     switch (act) {
     case 0: return round_bf16(x / (1.0f + expf_glibc_tab(-1.0f * x, tab)));
     case 4: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc_tab(x, tab)));
