@@ -118,6 +118,24 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     return None, None
 
 
+def committed_kernel_avg(traffic_source):
+    """rocprofv3 begin->end average of the kernel instance the counter pass matched (profiles/<round>_kernel_stats.csv of the same
+    round): the cross-check for the live HIP-event duration, which carries ~2 us of event bracketing per launch."""
+    import csv
+    if not traffic_source or ":" not in traffic_source:
+        return None
+    fname, key = traffic_source.split(":", 1)
+    instance = key.rsplit("|", 1)[0]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname.replace("_pmc_fetch.json", "_kernel_stats.csv"))
+    try:
+        for row in csv.DictReader(open(path)):
+            if row.get("kernel") == instance:
+                return {"avg_launch_us": float(row["avg_us"]), "calls": int(row["calls"]), "source": f"{os.path.basename(path)}:{instance}"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def timed_decode(model, ctx, args, dist, prompt):
     """prefill -> `warmup` untimed steps -> EXACTLY `steps` timed greedy decode steps between barrier + device sync on
     both sides; elapsed = max over ranks.  Returns (elapsed_s, gpu_ms, start_ctx, end_ctx, prefill_s)."""
@@ -367,9 +385,15 @@ def main():
         "decode_step": {"algorithmic_bytes_per_token_per_gpu": int(bytes_per_token), "algorithmic_bytes_per_token_job": int(job_bytes_per_token),
                         "achieved_per_gpu": round(per_gpu_gbps, 1), "unit": "GB/s", "frac_per_gpu": round(per_gpu_gbps / HBM_PEAK_GBPS, 4),
                         "kernels_per_step": len(prof), "sum_kernel_us": round(sum(p[2] for p in prof) * 1e3, 1)},
-        "method": "HIP events on the context stream around every kernel of one decode step of rank 0 (uzu_hip_model_profile_decode_step); "
-                  "event bracketing adds ~2 us per launch over the rocprofv3 begin->end duration (profiles/*_kernel_stats.csv)",
+        "method": "HIP events stamped by each launch of one decode step of rank 0 with the kernel's own begin / end (hipExtLaunchKernel inside "
+                  "uzu_hip_model_profile_decode_step): the dispatch timestamps rocprofv3 reports; roofline.rocprofv3 = the committed "
+                  "profiles/*_kernel_stats.csv average of the same kernel instance",
     }
+    committed = committed_kernel_avg(traffic_src)
+    if committed:  # the same kernel instance in the committed rocprofv3 --kernel-trace --stats pass
+        committed["achieved"] = round(roofline["bytes_per_launch"] / (committed["avg_launch_us"] * 1e-6) / 1e9, 1)
+        committed["frac"] = round(committed["achieved"] / HBM_PEAK_GBPS, 4)
+        roofline["rocprofv3"] = committed
     per_kernel = {k: {"calls": v[0], "us": round(v[2] * 1e3, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
     parallelism = {"single": "1 GPU", "tp": f"tp{world}: one sequence, column/row-parallel shards, RCCL all-reduce after out-proj and down-proj "
                    f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]

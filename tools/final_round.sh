@@ -1,0 +1,30 @@
+#!/bin/bash
+# GPU box (gpurun): the end-of-round measurement set -- full GPU test suite, smoke, the bench line of every BASELINE configuration,
+# the three rocprofv3 passes behind profiles/<round>_*, the per-workgroup timelines.  Results under gpurun_out/final and
+# gpurun_out/<round>_*; afterwards, locally: python tools/summarize_profile.py <round> gpurun_out/<round>_trace gpurun_out/<round>_pmc gpurun_out/<round>_mfma
+R=${1:-r2}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+O=gpurun_out/final; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E    +" | tail -15 > $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 300 python bench.py --model llama-3-8b --steps 64 --warmup 4 --no-cpu-baseline > $O/bench_llama_int4.json 2> $O/bench_llama_int4.err
+timeout 600 python bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 300 python bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
+bash tools/refresh_profiles.sh $R > $O/refresh.log 2>&1
+cd $ROOT
+[ -f uzu_amd/lib_tl/libuzu_hip.so ] && bash tools/timeline_run.sh $O > $O/timeline.log 2>&1
+tail -4 $O/pytest.log; tail -2 $O/smoke.log
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/final/bench_*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d.get('roofline') or {}
+        print(f.split('/')[-1], d['value'], d['unit'], 'ms/step', d.get('ms_per_step'), 'prefill', d.get('prefill_tokens_per_s'), 'frac', r.get('frac'), (r.get('rocprofv3') or {}).get('frac'),
+              'cpu', (d.get('cpu_baseline') or {}).get('value'))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "gemv_core.h"
@@ -101,6 +102,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) t += red[i]; // fixed order => deterministic
     return t;
 }
+
+// Per-launch timing for uzu_hip_model_profile_decode_step: while `tl_launch_timer` is set, a launch goes through hipExtLaunchKernel,
+// which stamps the kernel's own begin / end into the two events (the dispatch packet's timestamps -- what rocprofv3 reports),
+// instead of events recorded around it on the stream (those add ~2 us of barrier packets to a 3-5 us kernel).
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                                   \
+    do {                                                                                                                                    \
+        if (::uzu::tl_launch_timer)                                                                                                         \
+            hipExtLaunchKernelGGL((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), ::uzu::tl_launch_timer->start,        \
+                                  ::uzu::tl_launch_timer->stop, 0, __VA_ARGS__);                                                            \
+        else                                                                                                                                \
+            (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                                            \
+    } while (0)
 
 template <class F> uzu_status launch_check(F&& f, const char* what) {
     f();

@@ -360,7 +360,8 @@ void rope_tables(const uzu_rope_desc& r, uint32_t n_pos, std::vector<float>& cos
 struct ProfEntry {
     const char* name;
     size_t bytes;
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1; // recorded on the stream around the launch (fallback)
+    hipEvent_t x0, x1; // stamped by the launch itself (hipExtLaunchKernel): the kernel's begin -> end
 };
 struct Enc {
     uzu_hip_model* m;
@@ -368,20 +369,25 @@ struct Enc {
     uzu_status st = UZU_OK;
     std::vector<ProfEntry>* prof = nullptr;
     hipEvent_t pending = nullptr;
+    LaunchTimer timer{nullptr, nullptr};
     // begin(): called before a launch when profiling; run(): after it
     void begin() {
         if (!prof) return;
         (void)hipEventCreate(&pending);
         (void)hipEventRecord(pending, s);
+        (void)hipEventCreate(&timer.start);
+        (void)hipEventCreate(&timer.stop);
+        tl_launch_timer = &timer;
     }
     void run(uzu_status r, const char* name = "other", size_t bytes = 0) {
         if (st == UZU_OK) st = r;
         ++m->launches;
         if (prof && pending) {
+            tl_launch_timer = nullptr;
             hipEvent_t e1;
             (void)hipEventCreate(&e1);
             (void)hipEventRecord(e1, s);
-            prof->push_back({name, bytes, pending, e1});
+            prof->push_back({name, bytes, pending, e1, timer.start, timer.stop});
             pending = nullptr;
         }
     }
@@ -1278,11 +1284,14 @@ uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity
     if (st == UZU_OK) m->context_length += 1;
     uint32_t n = 0;
     for (auto& p : prof) {
-        float t = 0.f;
+        float t = 0.f, tx = 0.f;
         (void)hipEventElapsedTime(&t, p.e0, p.e1);
+        // the launch's own begin -> end where the launch went through the timed path (every kernel of this library does); a
+        // launch that did not (a library call such as an RCCL collective) keeps the bracketed time
+        if (hipEventElapsedTime(&tx, p.x0, p.x1) == hipSuccess && tx > 0.f && tx <= t) t = tx;
+        else (void)hipGetLastError();
         if (n < capacity) names[n] = p.name, bytes[n] = p.bytes, ms[n] = t, ++n;
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
+        for (hipEvent_t ev : {p.e0, p.e1, p.x0, p.x1}) (void)hipEventDestroy(ev);
     }
     *count = n;
     return st;

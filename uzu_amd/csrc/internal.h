@@ -15,6 +15,12 @@ namespace uzu {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// while set, kernel launches of this library stamp their own begin / end into the two events (device_utils.h: hipLaunchKernelGGL)
+struct LaunchTimer {
+    hipEvent_t start, stop;
+};
+extern thread_local LaunchTimer* tl_launch_timer; // runtime.hip
+
 #define UZU_HIP_TRY(expr)                                                                                  \
     do {                                                                                                   \
         hipError_t _e = (expr);                                                                            \

@@ -17,6 +17,7 @@
 namespace uzu {
 
 static thread_local char g_error[1024] = "";
+thread_local LaunchTimer* tl_launch_timer = nullptr;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
