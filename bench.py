@@ -97,9 +97,18 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
     (profiles/*_pmc_fetch.json, written by tools/summarize_profile.py with the gfx950 x2 KiB correction).
     bench.py cannot run rocprofv3 around itself, so this is the last committed counter pass: the entry of
     the same kernel family whose byte count is closest to the algorithmic bytes (the family is launched
-    with one grid per matrix shape).  None when no pass is committed or nothing is within 25 %."""
+    with one grid per matrix shape).  None when no pass is committed or nothing is within 12 %."""
     import glob
+    import re
     family = kernel_name.split("[")[0]
+    # the profile label names the fused prologue / epilogue; the kernel instance carries them as template arguments
+    # <BITS, CPLT, R, ACT, KIND, PRO, CONV, NW>: only instances with the same (ACT, PRO, CONV) are candidates
+    want = None
+    if kernel_name.startswith("gemv_dec["):
+        inner = kernel_name[len("gemv_dec["):-1]
+        want = ("true" if "+act" in inner else "false", "2" if inner.startswith("gate+") else "1" if "norm+" in inner else "0",
+                "true" if "+conv" in inner else "false")
+    inst = re.compile(r"gemv_dec_kernel<\d+, \d+, \d+, (true|false), \d+, (\d+), (true|false), \d+>")
     # newest round first: an older pass is only consulted when the newer ones hold nothing for this kernel family / size
     for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_fetch.json")), reverse=True):
         try:
@@ -110,15 +119,19 @@ def pmc_traffic(kernel_name, algorithmic_bytes):
         for key, nbytes in table.items():
             if not key.startswith(family):
                 continue
+            if want is not None:
+                mt = inst.match(key)
+                if not mt or mt.groups() != want:
+                    continue
             err = abs(nbytes - algorithmic_bytes) / max(algorithmic_bytes, 1)
-            if err < 0.25 and (best is None or err < best[0]):
+            if err < 0.12 and (best is None or err < best[0]):
                 best = (err, nbytes, f"{os.path.basename(path)}:{key}")
         if best:
             return best[1], best[2]
     return None, None
 
 
-def committed_kernel_avg(traffic_source):
+def committed_kernel_avg(traffic_source, launches_per_step=None):
     """rocprofv3 begin->end average of the kernel instance the counter pass matched (profiles/<round>_kernel_stats.csv of the same
     round): the cross-check for the live HIP-event duration, which carries ~2 us of event bracketing per launch."""
     import csv
@@ -128,9 +141,16 @@ def committed_kernel_avg(traffic_source):
     instance = key.rsplit("|", 1)[0]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname.replace("_pmc_fetch.json", "_kernel_stats.csv"))
     try:
-        for row in csv.DictReader(open(path)):
-            if row.get("kernel") == instance:
-                return {"avg_launch_us": float(row["avg_us"]), "calls": int(row["calls"]), "source": f"{os.path.basename(path)}:{instance}"}
+        rows = list(csv.DictReader(open(path)))
+        steps = next((int(r["calls"]) for r in rows if r.get("kernel") == "argmax_commit_kernel"), None)  # one per decode step
+        for row in rows:
+            if row.get("kernel") != instance:
+                continue
+            # the stats are keyed by kernel instance: only usable when this instance is launched by this label alone
+            # (the read-out shares its instance with the qkv projection, for example)
+            if launches_per_step and steps and int(row["calls"]) != launches_per_step * steps:
+                return None
+            return {"avg_launch_us": float(row["avg_us"]), "calls": int(row["calls"]), "source": f"{os.path.basename(path)}:{instance}"}
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -389,7 +409,7 @@ def main():
                   "uzu_hip_model_profile_decode_step): the dispatch timestamps rocprofv3 reports; roofline.rocprofv3 = the committed "
                   "profiles/*_kernel_stats.csv average of the same kernel instance",
     }
-    committed = committed_kernel_avg(traffic_src)
+    committed = committed_kernel_avg(traffic_src, calls)
     if committed:  # the same kernel instance in the committed rocprofv3 --kernel-trace --stats pass
         committed["achieved"] = round(roofline["bytes_per_launch"] / (committed["avg_launch_us"] * 1e-6) / 1e9, 1)
         committed["frac"] = round(committed["achieved"] / HBM_PEAK_GBPS, 4)
