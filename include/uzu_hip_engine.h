@@ -101,6 +101,23 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
 /* Asynchronous form used by bench.py: enqueue `steps` decode steps, do not wait. */
 uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps);
 uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, uint32_t count, uint32_t* out_tokens);
+/* SamplingMethod::Stochastic for the engine's own loop (the default is greedy).  As in LanguageModelStream, the seed of the row
+ * at absolute position p is PRng::new(seed).derive(p) (encodable_block/sampling/prng.rs:12-24; stream.rs:248-258 for the last
+ * row of a prefill, :598-600 for a decode step), derived on the device from the resident context length so that a replayed graph
+ * draws a fresh seed every step; the token then comes from UnifiedSampling (unified_sampling.rs:33-98: temperature, top-k, top-p,
+ * min-p, Gumbel-max).  NULL returns to greedy.  Captured decode graphs of every state are rebuilt at their next decode.  Not
+ * available for a vocab-sharded (tensor-parallel) read-out. */
+typedef struct {
+    uint64_t seed;
+    uint32_t has_temperature;
+    float temperature;
+    uint32_t has_top_k, top_k;
+    uint32_t has_top_p;
+    float top_p;
+    uint32_t has_min_p;
+    float min_p;
+} uzu_sampling_config;
+uzu_status uzu_hip_model_set_sampling(uzu_hip_model* m, const uzu_sampling_config* cfg);
 /* Teacher forcing for parity tests: overwrite the next input token. */
 uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
 

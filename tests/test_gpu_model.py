@@ -11,6 +11,8 @@ rel 0.05 / abs 0.4 for a SINGLE quantised matmul, quant_dispatch_test.rs:124).
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -160,6 +162,57 @@ def test_gated_act_mul_in_the_gemm_epilogue_is_bit_identical(hip_ctx):
         outs.append((hm.prefill(prompt), hm.read_logits()))
         hm.close()
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def prng_derive(seed, index):
+    """PRng::derive (encodable_block/sampling/prng.rs:12-24)."""
+    mask = (1 << 64) - 1
+    h = (seed + index) & mask
+    h ^= h >> 33
+    h = (h * 0xff51afd7ed558ccd) & mask
+    h ^= h >> 33
+    h = (h * 0xc4ceb9fe1a85ec53) & mask
+    h ^= h >> 33
+    return h
+
+
+@pytest.mark.parametrize("flags", [0, MODEL_NO_FUSION])
+@pytest.mark.parametrize("settings", [dict(temperature=30.0), dict(temperature=25.0, top_k=40), dict(top_p=0.9, min_p=0.02), dict(temperature=20.0, top_k=50, top_p=0.95)])
+def test_stochastic_sampling_in_the_engine_loop(hip_ctx, flags, settings):
+    """uzu_hip_model_set_sampling: SamplingMethod::Stochastic inside the engine's prefill / chained decode (graph replay and the
+    unfused path).  Every token must be exactly what the CPU restatement of UnifiedSampling draws from the GPU's OWN logits of that
+    step with the seed PRng::new(seed).derive(position of the sampled row) (stream.rs:248-258, 598-600) -- the sampler is an
+    integer / fixed-point algorithm, so this is bit-exact; then back to greedy on the same model."""
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(27, cfg.vocab_size)
+    seed = 0x1234_5678_9ABC_DEF0
+    hm = HipModel(hip_ctx, bundle, flags)
+    hm.set_sampling(seed=seed, **settings)
+
+    def expected(logits, position):
+        out = np.zeros(1, np.uint32)
+        seeds = np.array([prng_derive(seed, position)], np.uint64)
+        O.lib().orc_unified_sampling(O.p(logits), O.BF16, O.p(out), O.p(seeds), None,
+                                     int("temperature" in settings), C.c_float(settings.get("temperature", 0.0)), int("top_k" in settings), settings.get("top_k", 0),
+                                     int("top_p" in settings), C.c_float(settings.get("top_p", 0.0)), int("min_p" in settings), C.c_float(settings.get("min_p", 0.0)),
+                                     cfg.vocab_size, 1)
+        return int(out[0])
+
+    first = hm.prefill(prompt)
+    assert first == expected(hm.read_logits(), len(prompt) - 1)
+    drawn = [first]
+    for step in range(12):  # one step per call: the logits of every step are read back
+        tok, _ = hm.decode(1)
+        assert int(tok[0]) == expected(hm.read_logits(), len(prompt) + step), f"step {step}"
+        drawn.append(int(tok[0]))
+    # the synthetic read-out is peaked (log-normal row multipliers): only a high temperature lets the Gumbel noise move the arg-max
+    assert "temperature" not in settings or len(set(drawn)) > 3, f"a stochastic stream that never moves: {drawn}"
+    many, _ = hm.decode(6)  # several replays of the captured graph in one call: a fresh seed per step
+    hm.set_sampling(None)
+    tok, _ = hm.decode(1)
+    assert int(tok[0]) == int(np.argmax(f32(hm.read_logits())))
+    hm.close()
 
 
 def test_fused_decode_matches_unfused(hip_ctx):

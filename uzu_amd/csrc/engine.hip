@@ -74,6 +74,7 @@ struct uzu_hip_state {
     uint32_t *d_ctx_len = nullptr, *d_tokens = nullptr, *d_out_token = nullptr, *d_sampled = nullptr;
     uint32_t context_length = 0;
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
+    uint32_t graph_epoch = 0; // sampling_epoch of the model when the graphs were captured (they bake the sampling kernels in)
     std::vector<void*> allocations;
     size_t bytes = 0;
 };
@@ -112,6 +113,15 @@ struct uzu_hip_model {
     uint32_t partial_rows = 0;
     uint16_t *last_normed = nullptr, *logits = nullptr;
     void* argmax_scratch = nullptr;
+    // SamplingMethod::Stochastic for the engine's own prefill / decode loop (uzu_hip_model_set_sampling); greedy when !on
+    struct {
+        bool on = false;
+        uint64_t seed = 0;
+        k::UnifiedSamplingParams p{};
+    } sampling;
+    uint64_t* d_seed = nullptr;
+    void* sampling_scratch = nullptr;
+    uint32_t sampling_epoch = 0;
     uint16_t* taps = nullptr; // [layers][1024][d]
     uint32_t tap_rows = 0;
 
@@ -134,6 +144,7 @@ struct uzu_hip_model {
     unsigned long long* tp_key = nullptr;
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
+    uint32_t graph_epoch = 0; // sampling_epoch of the model when the graphs were captured (they bake the sampling kernels in)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool hidden_ready = false; // row 0 of `hidden` already holds the embedding of the next input token (written by the fused commit)
     uint32_t launches = 0; // kernel launches of the last encoded forward
@@ -241,7 +252,7 @@ void bind_state(uzu_hip_model* m, uzu_hip_state* st) {
     if (m->bound == st) return;
     if (m->bound) {
         m->bound->context_length = m->context_length;
-        m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two;
+        m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two, m->bound->graph_epoch = m->graph_epoch;
     }
     for (size_t l = 0; l < m->layers.size(); ++l) {
         m->layers[l].keys = st->layers[l].keys, m->layers[l].values = st->layers[l].values;
@@ -249,7 +260,7 @@ void bind_state(uzu_hip_model* m, uzu_hip_state* st) {
     }
     m->d_ctx_len = st->d_ctx_len, m->d_tokens = st->d_tokens, m->d_out_token = st->d_out_token, m->d_sampled = st->d_sampled;
     m->context_length = st->context_length;
-    m->graph_single = st->graph_single, m->graph_two = st->graph_two;
+    m->graph_single = st->graph_single, m->graph_two = st->graph_two, m->graph_epoch = st->graph_epoch;
     m->hidden_ready = false; // row 0 of the scratch `hidden` belongs to whoever ran last
     m->bound = st;
 }
@@ -668,7 +679,14 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             linear(e, ro, m->last_normed, m->logits, 1);
             if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
                 RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, ro.n, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
-            RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
+            if (m->sampling.on) { // stream.rs:248-258: seed = PRng::derive(position of the sampled row), then UnifiedSampling
+                RUN("derive_seed", 0, k::derive_seed(s, m->sampling.seed, m->d_ctx_len, count - 1, m->d_seed));
+                k::UnifiedSamplingParams sp = m->sampling.p;
+                sp.logits = m->logits, sp.dt = UZU_BF16, sp.output = m->d_out_token, sp.seeds = m->d_seed, sp.vocab_size = ro.n, sp.batch_size = 1;
+                RUN("unified_sampling", (size_t)ro.n * 2, k::unified_sampling(s, sp, m->sampling_scratch));
+            } else {
+                RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
+            }
             if (m->tp) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
                 RUN("tp_key", 0, tp::key_from_token(s, m->logits, m->d_out_token, m->vocab_offset, m->tp_key));
                 RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
@@ -862,6 +880,13 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
         eb.biases = (const uint16_t*)m->embedding.biases, eb.output = hidden;
         eb.vocab_size = m->d.vocab_size, eb.model_dim = d, eb.group_size = m->embedding.group, eb.bits = m->embedding.bits, eb.method = m->embedding.method;
         eb.input_scale = m->d.input_scale;
+        if (m->sampling.on) { // stream.rs:598-600: the seed of a decode step is derived from the context length before it
+            RUN("derive_seed", 0, k::derive_seed(s, m->sampling.seed, m->d_ctx_len, 0, m->d_seed));
+            k::UnifiedSamplingParams sp = m->sampling.p;
+            sp.logits = m->logits, sp.dt = UZU_BF16, sp.output = m->d_out_token, sp.seeds = m->d_seed, sp.vocab_size = ro.n, sp.batch_size = 1;
+            RUN("unified_sampling", (size_t)ro.n * 2, k::unified_sampling(s, sp, m->sampling_scratch));
+            eb.token_in = m->d_out_token;
+        }
         RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, &eb));
     }
     if (e.st != UZU_OK) return e.st;
@@ -1089,6 +1114,9 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         ALLOC(tp_key, unsigned long long, 1);
     }
     TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
+    TRY(dev_alloc(m, k::unified_sampling_scratch_bytes(1), &m->sampling_scratch));
+    TRY(dev_alloc(m, 8, &p));
+    m->d_seed = (uint64_t*)p;
     if (flags & UZU_MODEL_DEBUG_TAPS) ALLOC(taps, uint16_t, (size_t)desc->num_layers * C * d);
 #undef ALLOC
 #undef TRY
@@ -1237,9 +1265,11 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
     return UZU_OK;
 }
 
+static void drop_stale_graphs(uzu_hip_model* m);
 uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps) {
     UZU_REQUIRE(m, "model_decode: null model");
     UZU_REQUIRE(m->context_length > 0, "model_decode: prefill first (no input token)");
+    drop_stale_graphs(m);
     return enqueue_decode(m, steps);
 }
 
@@ -1255,6 +1285,7 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
     UZU_REQUIRE(m, "model_decode: null model");
     if (!steps) return UZU_OK;
     // make sure graph construction is not inside the timed region
+    drop_stale_graphs(m);
     if (!(m->flags & UZU_MODEL_NO_GRAPH)) {
         if (m->context_length + 1 <= 1024 && !m->graph_single) UZU_PROPAGATE(build_decode_graph(m, &m->graph_single, false));
         if (m->context_length + steps > 1024 && !m->graph_two) UZU_PROPAGATE(build_decode_graph(m, &m->graph_two, true));
@@ -1295,6 +1326,38 @@ uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity
     }
     *count = n;
     return st;
+}
+
+// graphs captured under another sampling configuration are stale: drop them (they are rebuilt on the next decode)
+static void drop_stale_graphs(uzu_hip_model* m) {
+    if (m->graph_epoch == m->sampling_epoch) return;
+    if (m->graph_single) (void)hipGraphExecDestroy(m->graph_single);
+    if (m->graph_two) (void)hipGraphExecDestroy(m->graph_two);
+    m->graph_single = m->graph_two = nullptr;
+    m->graph_epoch = m->sampling_epoch;
+}
+
+uzu_status uzu_hip_model_set_sampling(uzu_hip_model* m, const uzu_sampling_config* cfg) {
+    UZU_REQUIRE(m, "model_set_sampling: null model");
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    if (!cfg) {
+        if (m->sampling.on) ++m->sampling_epoch;
+        m->sampling.on = false;
+        return UZU_OK;
+    }
+    UZU_UNSUPPORTED(m->tp != nullptr, "model_set_sampling: stochastic sampling over a vocab-sharded read-out is not implemented");
+    UZU_REQUIRE(!cfg->has_temperature || cfg->temperature > 0.0f, "model_set_sampling: temperature must be positive");
+    UZU_REQUIRE(!cfg->has_top_k || cfg->top_k > 0, "model_set_sampling: top_k must be positive");
+    m->sampling.on = true;
+    m->sampling.seed = cfg->seed;
+    k::UnifiedSamplingParams& p = m->sampling.p;
+    p = k::UnifiedSamplingParams{};
+    p.has_temperature = cfg->has_temperature, p.temperature = cfg->temperature;
+    p.has_top_k = cfg->has_top_k, p.top_k = cfg->top_k;
+    p.has_top_p = cfg->has_top_p, p.top_p = cfg->top_p;
+    p.has_min_p = cfg->has_min_p, p.min_p = cfg->min_p;
+    ++m->sampling_epoch;
+    return UZU_OK;
 }
 
 uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token) {

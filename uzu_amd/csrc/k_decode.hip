@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(256) argmax_commit_kernel(const float* pv, con
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) bv = sv[w], bi = si[w];
-        const uint32_t t = bi == 0xFFFFFFFFu ? 0u : bi;
+        const uint32_t t = eb.token_in ? *eb.token_in : (bi == 0xFFFFFFFFu ? 0u : bi);
         const uint32_t len = *ctx_len;
         *out_token = t;
         sampled[len] = t;

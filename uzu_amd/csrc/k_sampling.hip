@@ -50,6 +50,19 @@ __device__ __forceinline__ float gumbel_of(uint64_t seed, uint32_t i, uint32_t v
     return -logf_glibc(-logf_glibc(u));
 }
 
+// PRng::derive (encodable_block/sampling/prng.rs:12-24): the seed of the row at absolute position `index` -- a 64-bit finaliser of
+// seed + index.  The engine's chained decode reads the position from the device-resident context length (+ `offset` for a prefill
+// chunk's last row), so a replayed hipGraph derives a fresh seed every step.
+__global__ void derive_seed_kernel(uint64_t base, const uint32_t* position, uint32_t offset, uint64_t* out) {
+    uint64_t hash = base + (uint64_t)(*position + offset);
+    hash ^= hash >> 33;
+    hash *= 0xff51afd7ed558ccdull;
+    hash ^= hash >> 33;
+    hash *= 0xc4ceb9fe1a85ec53ull;
+    hash ^= hash >> 33;
+    *out = hash;
+}
+
 struct SampleArgs {
     const void* logits;
     uint32_t* output;
@@ -320,6 +333,10 @@ uzu_status unified_sampling(hipStream_t s, const UnifiedSamplingParams& p, void*
         return launch_check([&] { hipLaunchKernelGGL((sample_plain_pass1<T>), dim3(parts, p.batch_size), dim3(256), 0, s, a, pv, pi); }, "unified_sampling[pass1]");
     }));
     return launch_check([&] { hipLaunchKernelGGL(sample_plain_pass2, dim3(p.batch_size), dim3(256), 0, s, pv, pi, parts, p.output); }, "unified_sampling[pass2]");
+}
+
+uzu_status derive_seed(hipStream_t s, uint64_t base, const uint32_t* position, uint32_t offset, uint64_t* out) {
+    return launch_check([&] { hipLaunchKernelGGL(derive_seed_kernel, dim3(1), dim3(1), 0, s, base, position, offset, out); }, "derive_seed");
 }
 
 } // namespace k

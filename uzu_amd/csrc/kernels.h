@@ -149,6 +149,8 @@ struct UnifiedSamplingParams {
     uint32_t vocab_size, batch_size;
 };
 uzu_status unified_sampling(hipStream_t s, const UnifiedSamplingParams& p, void* scratch);
+// PRng::derive (sampling/prng.rs): *out = finaliser(base + *position + offset)
+uzu_status derive_seed(hipStream_t s, uint64_t base, const uint32_t* position, uint32_t offset, uint64_t* out);
 size_t unified_sampling_scratch_bytes(uint32_t batch_size);
 
 // ---------------------------------------------------------------- gated delta net

@@ -96,6 +96,7 @@ struct CommitEmbed {
     uint16_t* output;            // bf16 [dim]
     uint32_t vocab_size, model_dim, group_size, bits, method;
     float input_scale;
+    const uint32_t* token_in;    // non-null: the token was sampled by another kernel (stochastic UnifiedSampling); the partials are ignored
 };
 uzu_status argmax_commit(hipStream_t s, const float* pv, const uint32_t* pi, uint32_t parts, uint32_t* ctx_len, uint32_t* tokens,
                          uint32_t* out_token, uint32_t* sampled, const CommitEmbed* embed = nullptr);

@@ -138,6 +138,21 @@ class HipModel:
         call("uzu_hip_model_read_tokens", self._h, C.c_uint32(first_position), C.c_uint32(count), C.c_void_p(out.ctypes.data))
         return out
 
+    def set_sampling(self, seed: Optional[int] = None, temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
+                     min_p: Optional[float] = None):
+        """SamplingMethod::Stochastic { temperature, top_k, top_p, min_p } with PRng::new(seed) (stream.rs:248-258, 598-600);
+        seed None = back to greedy."""
+        if seed is None:
+            call("uzu_hip_model_set_sampling", self._h, None)
+            return
+
+        class Cfg(C.Structure):
+            _fields_ = [("seed", C.c_uint64), ("has_temperature", C.c_uint32), ("temperature", C.c_float), ("has_top_k", C.c_uint32), ("top_k", C.c_uint32),
+                        ("has_top_p", C.c_uint32), ("top_p", C.c_float), ("has_min_p", C.c_uint32), ("min_p", C.c_float)]
+        cfg = Cfg(int(seed) & (2 ** 64 - 1), int(temperature is not None), float(temperature or 0.0), int(top_k is not None), int(top_k or 0),
+                  int(top_p is not None), float(top_p or 0.0), int(min_p is not None), float(min_p or 0.0))
+        call("uzu_hip_model_set_sampling", self._h, C.byref(cfg))
+
     def set_next_token(self, token: int):
         call("uzu_hip_model_set_next_token", self._h, C.c_uint32(int(token)))
 
