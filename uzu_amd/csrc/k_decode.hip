@@ -631,7 +631,8 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         R = (cpl == 2 && !p.act_mul) ? 2 : 1;
         // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/ab_decode_env.sh): int4 kernels with K >= 4096 5-25 % faster
         // (up 22.3 -> 20.2 us, down 13.1 -> 11.1, read-out 62 -> 55, 14B read-out 113 -> 100); K = 1024 (Qwen3.5 read-out: dozens of
-        // batches per wave, a 2 KB activation row) 5 % slower and the int8 kernels (128-register cap at 16 waves) 10 % slower
+        // batches per wave, a 2 KB activation row) 5 % slower; int8 10 % slower at 16 waves (128-register cap) and 1-2 % slower at 8
+        // waves (up 27.0 -> 26.3 us but qkv 11.8 -> 13.5): int8 stays on 4-wave workgroups
         *wide_out = wide_on && force_r <= 0 && (wide_on == 2 || (p.bits == 4 && cpl >= 2));
     } else {
         R = p.act_mul ? 2 : 4;
@@ -679,7 +680,8 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
     } while (0)
     if constexpr (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))) {
         if (wide) { // bandwidth regime (gemv_dec_plan: R <= 2): one wide workgroup per CU shares the prologue
-            constexpr int NWV = CPLT == 4 ? (BITS == 8 ? 8 : 12) : 16; // 150-190 registers on the 4-step path: 3 (int8: 2) waves per SIMD
+            // 150-190 registers on the 4-step path: 3 waves per SIMD; int8 rows need 100-170 registers: 8 waves (two workgroups per CU)
+            constexpr int NWV = BITS == 8 ? 8 : (CPLT == 4 ? 12 : 16);
             if (R >= 2) UZU_LAUNCH_N(2, NWV);
             UZU_LAUNCH_N(1, NWV);
         }
