@@ -626,8 +626,15 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         const char* e = getenv("UZU_DEC_WIDE");
         return e ? atoi(e) : 1;
     }();
+    static const uint64_t big_bytes = [] { // UZU_DEC_BIG_MB: where the bandwidth regime (persistent grid) starts
+        const char* e = getenv("UZU_DEC_BIG_MB");
+        return (uint64_t)(e && atoi(e) > 0 ? atoi(e) : 16) << 20;
+    }();
     *wide_out = false;
-    if (weight_bytes >= (16u << 20)) {
+    // a normalisation prologue at K >= 4096 is worth sharing from ~10 MB on (Llama-3-8B qkv, 12.6 MB: 9.4 -> 8.1 us); a plain
+    // 13 MB out-projection is not (Qwen3-14B-class: 7.5 -> 8.2 us)
+    const bool normed_mid = (p.norm_scales || p.norm_plain) && p.bits == 4 && cpl >= 2 && weight_bytes >= (10u << 20) && big_bytes == (16u << 20);
+    if (weight_bytes >= big_bytes || normed_mid) {
         R = (cpl == 2 && !p.act_mul) ? 2 : 1;
         // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/ab_decode_env.sh): int4 kernels with K >= 4096 5-25 % faster
         // (up 22.3 -> 20.2 us, down 13.1 -> 11.1, read-out 62 -> 55, 14B read-out 113 -> 100); K = 1024 (Qwen3.5 read-out: dozens of
