@@ -22,10 +22,16 @@
 // workgroups than the reference's 32 blocks) and is tolerance-equal.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_utils.h"
 #include "gemv_core.h"
 #include "kernels.h"
 #include "kernels_decode.h"
+
+#ifndef UZU_GEMV_PRELOAD2
+#define UZU_GEMV_PRELOAD2 1 // 0 = the second step of a wave's first batch is requested after the prologue (A/B builds)
+#endif
 
 namespace uzu {
 namespace k {
@@ -228,6 +234,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     if (ACT || CONV) exp_entry = kExp2fTab[tid & 31];
     __builtin_amdgcn_sched_barrier(0); // keep the issue order: the scheduler would hoist the weight loads above the staging
     load_item(b0, 0, itA); // in flight during the whole prologue
+    // ... and so is the batch's second step where there is one (K > 2048, or the streaming path): issued after the prologue it is a
+    // second exposed round trip for a wave that owns a single batch (latency regime: Qwen3.5-0.8B decode +1.1 %, same-box A/B of
+    // two builds).  Not in the wide workgroups of the bandwidth regime: there the extra requests in front of the shared prologue
+    // cost more than they hide (Llama-3-8B 572 -> 545 tok/s), and not with two rows per wave (its 8 MB out-projection: 5.2 ->
+    // 5.5 us): one row per wave is what the plan gives the small matrices.
+    constexpr bool PRELOAD2 = UZU_GEMV_PRELOAD2 && NW == 4 && R == 1 && (CPLT == 0 || CPL >= 2);
+    if constexpr (PRELOAD2) load_item(b0, 1, itB);
     __builtin_amdgcn_sched_barrier(0);
     ConvPre cp_cur[CONV ? R : 1]; // conv operands of the wave's first batch: in flight during the prologue as well
     if (CONV) conv_prefetch(b0, cp_cur);
@@ -525,7 +538,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     };
     // one batch whose first item sits in `first`; returns the wave's next batch, whose first item then sits in `first` (even
     // number of steps) or in `second` (odd number of steps)
-    auto batch = [&](uint32_t b, Item& first, Item& second) -> uint32_t {
+    auto batch = [&](uint32_t b, Item& first, Item& second, auto have_second) -> uint32_t { // have_second: step 1 is loaded already
+        constexpr bool HAVE2 = decltype(have_second)::value;
         const uint32_t bn = next_batch(b);
         float acc[R][NPHYS];
 #pragma unroll
@@ -537,8 +551,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             for (int j = 0; j < CPL; ++j) {
                 Item& cur = (j & 1) ? second : first;
                 Item& nxt = (j & 1) ? first : second;
-                if (j + 1 < CPL) load_item(b, j + 1, nxt);
-                else load_item(bn, 0, nxt);
+                if (j + 1 < CPL) {
+                    if (!(HAVE2 && j == 0)) load_item(b, j + 1, nxt);
+                } else {
+                    load_item(bn, 0, nxt);
+                }
                 const uint32_t c = sl + lpr * j;
                 if (c < C) {
                     if constexpr (BITS == 4) compute(cur, c, xq[j], xsm[j], acc);
@@ -549,7 +566,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             for (uint32_t j = 0; j < steps_per_lane; j += 2) {
                 {
                     const bool last = j + 1 == steps_per_lane;
-                    load_item(last ? bn : b, last ? 0 : j + 1, second);
+                    if (!(HAVE2 && j == 0)) load_item(last ? bn : b, last ? 0 : j + 1, second); // (the streaming path has >= 3 steps)
                     const uint32_t c = sl + lpr * j;
                     if (c < C) stream_step(first, c, acc);
                     if (last) { // odd step count: hand the prefetched item over (one copy per batch)
@@ -572,11 +589,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         return bn;
     };
     if (CPLT == 0 || (CPL & 1) == 0) {
-        for (uint32_t b = b0; b < num_batches;) b = batch(b, itA, itB);
+        uint32_t b = b0;
+        if (PRELOAD2 && b < num_batches) b = batch(b, itA, itB, std::true_type{});
+        while (b < num_batches) b = batch(b, itA, itB, std::false_type{});
     } else {
         for (uint32_t b = b0; b < num_batches;) {
-            b = batch(b, itA, itB);
-            if (b < num_batches) b = batch(b, itB, itA);
+            b = batch(b, itA, itB, std::false_type{});
+            if (b < num_batches) b = batch(b, itB, itA, std::false_type{});
         }
     }
     UZU_TL_STAMP(3);
