@@ -694,9 +694,16 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         if (p.part_val && p.part_capacity && cap > p.part_capacity) cap = p.part_capacity; /* one arg-max partial per workgroup */  \
         const uint32_t want_n = (want * 4 + NWV - 1) / NWV;                                                                         \
         const uint32_t grid = want_n > cap ? cap : want_n;                                                                          \
-        if (lds > 65536) { /* K > ~24k on the LDS-resident-row path */                                                              \
-            static bool raised = false;                                                                                             \
-            if (!raised) raised = hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; \
+        if (lds > 65536) { /* K > ~24k on the LDS-resident-row path: raise the instance's dynamic-LDS limit to what this call needs */ \
+            static size_t raised_to = 0;                                                                                            \
+            if (lds > raised_to) {                                                                                                  \
+                if (hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+                    (void)hipGetLastError();                                                                                        \
+                    set_error("gemv_dec: %zu bytes of LDS for the activation row of K = %u are not available", lds, p.k);           \
+                    return UZU_ERR_UNSUPPORTED;                                                                                     \
+                }                                                                                                                   \
+                raised_to = lds;                                                                                                    \
+            }                                                                                                                       \
         }                                                                                                                           \
         if (grid_out) *grid_out = grid;                                                                                             \
         const void* a0 = PRO == 2 ? (const void*)p.dg_o : (const void*)p.x;                                                         \
