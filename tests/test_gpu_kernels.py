@@ -597,6 +597,25 @@ def test_attention_prefill_matrix_core_path(hip_ctx, heads, kv_heads, hd, seq, s
     assert (want == got).mean() >= 0.97
 
 
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(32, 8, 128, 1100, 1024), (40, 8, 128, 700, 640), (16, 4, 128, 800, 768), (24, 8, 64, 1030, 1024)])
+def test_attention_prefill_matrix_core_path_full_chunks(hip_ctx, heads, kv_heads, hd, seq, suffix):
+    """Chunk-sized suffixes, i.e. grids large enough for four (Llama-3-8B: 32 q / 8 kv; Qwen3-14B: 40 / 8; GQA factor 3) or two wave
+    tasks per workgroup -- the small cases above all end up with one task per workgroup.  Same bar as there."""
+    rng = np.random.default_rng(heads + hd + suffix)
+    q, k, v, a = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    kern = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 0, 0)
+    bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
+    run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, 1.0 / np.sqrt(hd),
+                                        None, None, None, heads, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+    assert (want == got).mean() >= 0.97
+
+
 @pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(8, 2, 256, 2048, 1), (32, 8, 128, 1500, 1), (8, 2, 256, 1100, 3), (4, 2, 64, 40, 1)])
 def test_attention_two_pass(hip_ctx, heads, kv_heads, hd, seq, suffix):
     """Split-KV: pass 1 partials have the reference's meaning (block b = keys b, b+32, ...), pass 2 is bit-exact
