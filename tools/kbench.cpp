@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
             time_graph(sp == 32 ? "attn_dec ctx2048 S=32" : sp == 64 ? "attn_dec ctx2048 S=64" : "attn_dec ctx2048 S=128", (size_t)2 * ctx * nkv * hd * 2, reps, [&](int i) {
                 AttnDecParams p{}; p.qkv = qkv, p.keys = K[i % NBUF], p.values = V[i % NBUF], p.cosines = cosr, p.sines = sinr, p.ctx_len = len;
                 p.q_norm = {1, 1, 1e-6f, 1.f, qs}; p.k_norm = {1, 1, 1e-6f, 1.f, qs}; p.num_heads = nq, p.gqa_factor = 4, p.head_dim = hd, p.rope_dim = 64, p.scale = 0.0625f;
-                p.partials = parts, p.sums = sums, p.maxs = maxs; return attn_dec(s, p, sp); });
+                p.partials = parts, p.sums = sums, p.maxs = maxs, p.cache_rows = ctx + 8; return attn_dec(s, p, sp); });
         time_graph("attn_merge S=64", (size_t)nq * 64 * hd * 4, reps, [&](int) { return attn_merge(s, parts, sums, maxs, gate, out, nq, hd, 64); });
     }
     return 0;

@@ -834,7 +834,7 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
             a.k_norm = {L.kn.present, L.kn.full_layer, L.kn.eps, L.kn.offset, L.kn.scales};
             a.num_heads = nq, a.gqa_factor = nq / nkv, a.head_dim = hd, a.rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
             a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
-            a.partials = m->dec_partials, a.sums = m->dec_sums, a.maxs = m->dec_maxs;
+            a.partials = m->dec_partials, a.sums = m->dec_sums, a.maxs = m->dec_maxs, a.cache_rows = m->max_positions;
             const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
             RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
             RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));

@@ -30,6 +30,12 @@
 #include "kernels_decode.h"
 
 #ifndef UZU_GEMV_PRELOAD2
+#ifndef UZU_GEMV_RAWX
+#define UZU_GEMV_RAWX 1 // 0 = a plain bf16 activation row goes through f32 registers before it is packed for the dot unit (A/B builds)
+#endif
+#ifndef UZU_ATTN_SPEC
+#define UZU_ATTN_SPEC 1 // 0 = attn_dec waits for the context length before its first K / V loads (A/B builds)
+#endif
 #define UZU_GEMV_PRELOAD2 1 // 0 = the second step of a wave's first batch is requested after the prologue (A/B builds)
 #endif
 
@@ -247,8 +253,15 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- prologue ---------------------------------------------------------------------------------------
-    float xf[CPL][32];
+    // int4, plain bf16 activation row: bf16 pairs go straight into packed-dot order and the step sums through the dot unit (as for
+    // K > 8192) -- 32 VALU per step instead of 79 through f32 registers (Llama-3-8B out-projection 5.18 -> 4.94 us, same-box A/B).
+    // (Measured and dropped: converting the NORMED row once per workgroup -- one thread per step packs it in LDS, the lanes fetch
+    // 4 x b128 + the sum -- instead of once per wave: Llama-3-8B up-projection 17.5 -> 17.1 us, but the extra serial phase and
+    // barrier cost the K = 1024 kernels, where a lane converts a single step, 0.1-0.5 us each: Qwen3.5-0.8B 1664 -> 1605 tok/s.)
+    constexpr bool RAWX = UZU_GEMV_RAWX && BITS == 4 && CPLT != 0 && PRO == 0;
+    float xf[RAWX ? 1 : CPL][32];
     float xsm[CPL];
+    XPack xq[BITS == 4 ? CPL : 1];
     if (CPLT != 0) {
         if (PRO == 2) {
             // DeltaNet norm-gate (tail of update.rs:30-143) as the out-proj prologue: thread t owns `per` chunks of 8
@@ -301,22 +314,36 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float4 t = xv[i];
-                        xf[j][4 * i] = t.x, xf[j][4 * i + 1] = t.y, xf[j][4 * i + 2] = t.z, xf[j][4 * i + 3] = t.w;
+                        xf[RAWX ? 0 : j][4 * i] = t.x, xf[RAWX ? 0 : j][4 * i + 1] = t.y, xf[RAWX ? 0 : j][4 * i + 2] = t.z, xf[RAWX ? 0 : j][4 * i + 3] = t.w;
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                    for (int i = 0; i < 32; ++i) xf[RAWX ? 0 : j][i] = 0.f;
                 }
             }
         } else if (PRO == 0) { // plain activation row: every lane fetches its own steps
+            if constexpr (RAWX) { // int4: bf16 pairs straight into packed-dot order, step sums through the dot unit (as for K > 8192)
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const uint32_t c = sl + lpr * j;
+                    XPack& x = xq[BITS == 4 ? j : 0];
+                    if (c < C) xsm[j] = xpack_load(x, p.x + (size_t)c * 32);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) x.v[i] = 0u;
+                        xsm[j] = 0.f;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
-                if (c < C) load32_bf16(p.x + (size_t)c * 32, xf[j]);
+                if (c < C) load32_bf16(p.x + (size_t)c * 32, xf[RAWX ? 0 : j]);
                 else {
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                    for (int i = 0; i < 32; ++i) xf[RAWX ? 0 : j][i] = 0.f;
                 }
+            }
             }
         } else {
             // Normalization (normalization.rs:56-125) once per workgroup through LDS; element/thread mapping and
@@ -395,16 +422,18 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float4 t = xv[i];
-                        xf[j][4 * i] = t.x, xf[j][4 * i + 1] = t.y, xf[j][4 * i + 2] = t.z, xf[j][4 * i + 3] = t.w;
+                        xf[RAWX ? 0 : j][4 * i] = t.x, xf[RAWX ? 0 : j][4 * i + 1] = t.y, xf[RAWX ? 0 : j][4 * i + 2] = t.z, xf[RAWX ? 0 : j][4 * i + 3] = t.w;
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) xf[j][i] = 0.f;
+                    for (int i = 0; i < 32; ++i) xf[RAWX ? 0 : j][i] = 0.f;
                 }
             }
         }
+        if constexpr (!RAWX) {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) xsm[j] = sum32(xf[j]);
+            for (int j = 0; j < CPL; ++j) xsm[j] = sum32(xf[j]);
+        }
     }
     // K > 8192 (CPLT == 0), int4: the whole activation row is parked once per workgroup in LDS, already in packed-dot order
     // (step c = 16 words at a stride of 20 words: conflict-free ds_read_b128 for 16 consecutive steps) together with the
@@ -434,8 +463,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     }
     // int4: the row goes through the packed-dot unit (gemv_core.h: dot32p) -- bf16 pairs, 16 registers per step; the
     // f32 copy is dead from here on
-    XPack xq[BITS == 4 ? CPL : 1];
-    if (BITS == 4 && CPLT != 0) {
+    if constexpr (BITS == 4 && CPLT != 0 && !RAWX) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) xpack_from_f32(xq[BITS == 4 ? j : 0], xf[j]);
     }
@@ -1016,14 +1044,16 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     __shared__ float s_knew[HD], s_vnew[HD];
     __shared__ float s_o[NGRP][GS][HD];
     __shared__ float s_m[NGRP][GS], s_l[NGRP][GS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     UZU_TL_DECL;
     UZU_TL_STAMP(0);
     const uint32_t subs = p.gqa_factor / GS;
     const uint32_t kvh = blockIdx.x / subs, sub = blockIdx.x % subs;
     const uint32_t head0 = kvh * p.gqa_factor + sub * GS;
     const uint32_t split = blockIdx.y, S = gridDim.y;
+#if !UZU_ATTN_SPEC
     const uint32_t L = __builtin_amdgcn_readfirstlane(*p.ctx_len); // position of the new token = number of cached keys
+#endif
     const uint32_t nq = p.num_heads, nkv = p.num_heads / p.gqa_factor;
     const uint32_t rope_dim = p.rope_dim, half_rope = rope_dim / 2;
 
@@ -1045,8 +1075,10 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         const bool is_q = job < GS, is_k = job == GS;
         const uint32_t head_idx = is_q ? head0 + job : (is_k ? nq + kvh : nq + nkv + kvh);
         const uint16_t* src = p.qkv + (size_t)head_idx * HD;
-        const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
-        const float* nsrc = nm.scales ? nm.scales : (const float*)p.qkv; // dummy source (>= 2 head rows long), never consumed
+        // (field by field: a reference picked between the two argument structs is a pointer into the kernel-argument segment, and
+        // its `scales` a dependent vector load at the head of the kernel)
+        const float* nscales = is_q ? p.q_norm.scales : p.k_norm.scales;
+        const float* nsrc = nscales ? nscales : (const float*)p.qkv; // dummy source (>= 2 head rows long), never consumed
 #pragma unroll
         for (int j = 0; j < HD / 64; ++j) {
             vals[jj][j] = bf16_to_f32(src[lane + 64 * j]);
@@ -1054,16 +1086,27 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         }
     }
     u32x4_v kq[TB], vq[TB];
-    const uint32_t last_row = L ? L - 1 : 0;
-    auto fetch = [&](uint32_t first) {
+    auto fetch_upto = [&](uint32_t first, uint32_t row_limit) {
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-            const uint32_t i = min(first + t * key_step, last_row); // clamped rows are loaded (cache hit) and never consumed
+            const uint32_t i = min(first + t * key_step, row_limit); // clamped rows are loaded (cache hit) and never consumed
             kq[t] = *(const u32x4_v*)(kbase + (size_t)i * seq_stride);
             vq[t] = *(const u32x4_v*)(vbase + (size_t)i * seq_stride);
         }
     };
-    fetch(key0);
+#if UZU_ATTN_SPEC
+    // The first K / V batch does not wait for the context length (a dependent round trip to the memory-side cache, ~1 us, at the
+    // head of a kernel that is one latency chain): its rows are clamped to the cache's capacity instead -- rows past the context
+    // are allocated, loaded and, like the clamped ones, never consumed.  The context length is requested right behind them (scalar
+    // loads return out of order, so a wait for any kernel argument would wait for it as well: it goes last).
+    fetch_upto(key0, p.cache_rows - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(*p.ctx_len); // position of the new token = number of cached keys
+#else
+    fetch_upto(key0, L ? L - 1 : 0);
+#endif
+    const uint32_t last_row = L ? L - 1 : 0;
+    auto fetch = [&](uint32_t first) { fetch_upto(first, last_row); };
     float rc[NROPE][4];
     if (rope_dim) {
         const float* cosr = p.cosines + (size_t)L * rope_dim;
@@ -1086,7 +1129,10 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         float total = 0.f;
 #pragma unroll
         for (int j = 0; j < HD / 64; ++j) total += vals[jj][j] * vals[jj][j];
-        const DecNorm& nm = is_q ? p.q_norm : p.k_norm;
+        DecNorm nm;
+        nm.present = is_q ? p.q_norm.present : p.k_norm.present, nm.full_layer = is_q ? p.q_norm.full_layer : p.k_norm.full_layer;
+        nm.eps = is_q ? p.q_norm.eps : p.k_norm.eps, nm.offset = is_q ? p.q_norm.offset : p.k_norm.offset;
+        nm.scales = is_q ? p.q_norm.scales : p.k_norm.scales;
         if ((is_q || is_k) && nm.present) {
             total = wave_sum(total);
             const float rms_norm = 1.0f / sqrtf(total / (float)HD + nm.eps);
@@ -1228,6 +1274,10 @@ uzu_status attn_dec(hipStream_t s, const AttnDecParams& p_in, uint32_t splits) {
 #endif
     if (p.rope_dim > p.head_dim || (p.rope_dim & 1)) {
         set_error("attn_dec: bad rope_dim %u", p.rope_dim);
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    if (!p.cache_rows) {
+        set_error("attn_dec: cache_rows (allocated rows of the K / V caches) must be given");
         return UZU_ERR_INVALID_ARGUMENT;
     }
     switch (p.head_dim) {

@@ -127,6 +127,7 @@ struct AttnDecParams {
     float* partials;       // [heads, splits, hd]
     float* sums;           // [heads, splits]
     float* maxs;
+    uint32_t cache_rows;   // rows the K / V caches are allocated for (> context length): the first loads are clamped to it, not to the context
 };
 uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits);
 // query heads of one KV head a workgroup of attn_dec serves together (the K / V rows are read once for all of them):
