@@ -53,6 +53,8 @@ def main():
     print("# gap = first entry - previous launch's last exit; ramp = last entry - first entry; the other columns are medians over the workgroups:")
     print("# x = entry -> activation vector consumed; pro = entry -> prologue done; dots = prologue done -> last batch's dot products done;")
     print("# fin = reduction + epilogue of the last batch; span = first entry -> last exit")
+    print("# attn_dec rows (256 workgroups, no dots-only phase): x = entry -> context length arrived; pro = entry -> q / new k normalised, roped, appended;")
+    print("# dots = prologue done -> K / V rows arrived and folded in; fin = merge of the key groups through LDS + partial stores")
     print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'x':>6} {'pro':>6} {'dots':>6} {'fin':>6} {'exit':>6} {'span':>6}")
     tot = dict(gap=0.0, span=0.0)
     first = None

@@ -1053,6 +1053,16 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     const uint32_t split = blockIdx.y, S = gridDim.y;
 #if !UZU_ATTN_SPEC
     const uint32_t L = __builtin_amdgcn_readfirstlane(*p.ctx_len); // position of the new token = number of cached keys
+#else
+    // The context length lives in device memory (a replayed graph cannot carry it) and everything position-dependent hangs on it.
+    // It is requested FIRST and through the vector pipe: vector loads return in issue order, so nothing issued behind it -- the new
+    // token's rows, the first K / V batch -- delays it, and waiting for it does not wait for them (a scalar load would tie it to
+    // every kernel-argument fetch: scalar loads return out of order and can only be waited for all at once; requested behind the
+    // K / V batch it arrived after 1.9-2.4 us instead of ~1, tools/timeline.py column x).
+    uint32_t lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero)); // opaque per-lane zero: keeps the load on the vector pipe
+    const uint32_t L_v = p.ctx_len[lane_zero];
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     const uint32_t nq = p.num_heads, nkv = p.num_heads / p.gqa_factor;
     const uint32_t rope_dim = p.rope_dim, half_rope = rope_dim / 2;
@@ -1097,11 +1107,10 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
 #if UZU_ATTN_SPEC
     // The first K / V batch does not wait for the context length (a dependent round trip to the memory-side cache, ~1 us, at the
     // head of a kernel that is one latency chain): its rows are clamped to the cache's capacity instead -- rows past the context
-    // are allocated, loaded and, like the clamped ones, never consumed.  The context length is requested right behind them (scalar
-    // loads return out of order, so a wait for any kernel argument would wait for it as well: it goes last).
+    // are allocated, loaded and, like the clamped ones, never consumed.
     fetch_upto(key0, p.cache_rows - 1);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t L = __builtin_amdgcn_readfirstlane(*p.ctx_len); // position of the new token = number of cached keys
+    const uint32_t L = __builtin_amdgcn_readfirstlane(L_v); // position of the new token = number of cached keys
 #else
     fetch_upto(key0, L ? L - 1 : 0);
 #endif
@@ -1118,6 +1127,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    UZU_TL_STAMP(1); // the context length has arrived (the RoPE row's loads are out)
 
     // ---- prologue: normalised + roped q heads (one wave per head, elements lane + 64 j), new k and v rows ----
     // (QKVNorm: qkv_norm.rs:45-76 ; AttentionPrepare: attention_prepare.rs:7-31,104-121)
@@ -1223,7 +1233,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
             }
         }
     }
-    UZU_TL_STAMP(3);
+    UZU_TL_STAMP(5); // K / V rows have arrived and are folded in
     // every key group parks its state in LDS; the merge below runs over the NGRP groups in group order
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
@@ -1248,6 +1258,7 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
         p.partials[row * HD + e] = acc;
         if (e == 0) p.sums[row] = l, p.maxs[row] = m;
     }
+    UZU_TL_STAMP(6);
     UZU_TL_STAMP(4);
     UZU_TL_FLUSH(p);
 }
