@@ -93,12 +93,14 @@ def test_gemv_int4_scale_bias_qwen_shapes(hip_ctx, n, k):
     assert (want == got).mean() >= 0.99
 
 
-@pytest.mark.parametrize("n,k,bits,method", [(2048, 16384, 4, 0), (1184, 28672, 4, 1), (4096, 4096, 4, 0), (6144, 8192, 4, 2), (2304, 16384, 8, 0)])
+@pytest.mark.parametrize("n,k,bits,method", [(2048, 16384, 4, 0), (1184, 28672, 4, 1), (4096, 4096, 4, 0), (6144, 8192, 4, 2), (2304, 16384, 8, 0),
+                                             (5001, 17408, 4, 1)])
 def test_gemv_bandwidth_regime(hip_ctx, n, k, bits, method):
     """M = 1 over >= 16 MB of weights: the persistent-grid plan of the decode GEMV -- K > 8192 on the LDS-resident activation row with
     16-wave workgroups and batches drawn from an LDS counter (int4), the register-resident paths for K <= 8192, int8 on 4-wave
-    workgroups -- and an 8 MB matrix just below it.  Which wave computes a row does not change the row: <= 1 bf16 ulp, >= 99 %
-    bit-identical to the CPU restatement, ragged row counts included."""
+    workgroups -- and an 8 MB matrix just below it; 5001 x 17408 is the Qwen3-14B-class down-projection (20 rows per 16-wave workgroup:
+    the plan takes two rows per lane group).  Which wave computes a row does not change the row: <= 1 bf16 ulp, >= 99 % bit-identical
+    to the CPU restatement, ragged row counts included."""
     rng = np.random.default_rng(n + k + bits)
     q = quant_matrix(rng, n, k, bits, 128, method)
     a = activations(rng, 1, k)

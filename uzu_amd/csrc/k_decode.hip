@@ -688,6 +688,23 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         // batches per wave, a 2 KB activation row) 5 % slower; int8 10 % slower at 16 waves (128-register cap) and 1-2 % slower at 8
         // waves (up 27.0 -> 26.3 us but qkv 11.8 -> 13.5): int8 stays on 4-wave workgroups
         *wide_out = wide_on && force_r <= 0 && (wide_on == 2 || (p.bits == 4 && cpl >= 2));
+        static const int wide_r = [] { // UZU_DEC_WIDE_R: rows per lane group of the wide workgroups (A/B runs; 0 = the rule above)
+            const char* e = getenv("UZU_DEC_WIDE_R");
+            return e ? atoi(e) : 0;
+        }();
+        if (*wide_out && wide_r > 0 && !(p.act_mul && cpl > 2)) R = wide_r > 2 ? 2 : wide_r;
+        else if (*wide_out && R == 1 && !p.act_mul) { // (the fused up / gate rows already are two rows in flight per lane group: R = 2 cost Llama-3-8B's up-projection 17.4 -> 19.2 us)
+            // Rows per lane group by the round count.  A wave streams at a latency-bound rate (two items in flight), so a workgroup
+            // of NW waves with B batches takes ceil(B / NW) rounds, the last one with whatever is left; two rows per lane group halve
+            // the batches and keep twice the bytes in flight per wave.  Taken when that does not add row-rounds: Qwen3-14B-class
+            // down-projection (20 rows per workgroup of 16 waves: 16 + 4 -> 10 x 2) 17.0 -> 14.5 us, its read-out (594 rows per
+            // 12 waves) 100 -> 89; not Llama-3-8B (down: 16 rows = one full round, 8.5 -> 11.7 us with half the waves idle; up: 28
+            // row pairs per 12 waves, 3 rounds against 2 x 2, 17.4 -> 19.0) -- same-box A/B, tools/ab_wide_r.sh.
+            const uint32_t nw = (cpl > 2 && (p.norm_scales || p.norm_plain)) ? 12u : 16u; // launch_gemv_dec_c: NWV
+            const uint32_t per_wg = (nb(1) + (uint32_t)num_cus - 1) / (uint32_t)num_cus;
+            const uint32_t rounds1 = (per_wg + nw - 1) / nw, rounds2 = (per_wg + 2 * nw - 1) / (2 * nw) * 2;
+            if (rounds2 <= rounds1) R = 2;
+        }
     } else {
         R = p.act_mul ? 2 : 4;
         const uint32_t target_waves = (uint32_t)num_cus * tw;
