@@ -682,7 +682,10 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     // 13 MB out-projection is not (Qwen3-14B-class: 7.5 -> 8.2 us)
     const bool normed_mid = (p.norm_scales || p.norm_plain) && p.bits == 4 && cpl >= 2 && weight_bytes >= (10u << 20) && big_bytes == (16u << 20);
     if (weight_bytes >= big_bytes || normed_mid) {
-        R = (cpl == 2 && !p.act_mul) ? 2 : 1;
+        // int8 rows (4-wave workgroups, below) take two rows per lane group: 32 bytes of codes per lane and step leave a wave with 4 KB
+        // in flight (Llama-3-8B int8, same-box sweep of UZU_DEC_R: down 19.7 -> 16.8 us, qkv 12.0 -> 11.7, read-out 101.5 -> 98.8;
+        // the fused up / gate kernel already streams two rows: 26.4 -> 28.5 with four)
+        R = ((cpl == 2 || p.bits == 8) && !p.act_mul) ? 2 : 1;
         // measured (Llama-3-8B, Qwen3-14B-class, same box A/B, tools/ab_decode_env.sh): int4 kernels with K >= 4096 5-25 % faster
         // (up 22.3 -> 20.2 us, down 13.1 -> 11.1, read-out 62 -> 55, 14B read-out 113 -> 100); K = 1024 (Qwen3.5 read-out: dozens of
         // batches per wave, a 2 KB activation row) 5 % slower; int8 10 % slower at 16 waves (128-register cap) and 1-2 % slower at 8
