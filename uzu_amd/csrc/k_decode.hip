@@ -110,7 +110,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     const uint32_t batches0 = (n_log0 + rows_per_batch - 1) / rows_per_batch;
     const uint32_t batches1 = ACT ? 0 : (p.n[1] + rows_per_batch - 1) / rows_per_batch;
     const uint32_t num_batches = batches0 + batches1;
-    const uint32_t total_waves = gridDim.x * NW;
+    // wide workgroups: `bpw` batches per workgroup and round -- fewer than waves when the whole matrix is less than one round of the
+    // resident waves, so that every CU streams (2560 two-row batches: 256 workgroups x 10 busy waves instead of 160 x 16)
+    const uint32_t bpw = (NW > 4 && p.wg_batches) ? p.wg_batches : NW;
+    const uint32_t total_waves = gridDim.x * bpw;
     const uint32_t steps_per_lane = CPLT == 0 ? (C + lpr - 1) / lpr : CPL;
     const uint32_t gshift = 31 - __builtin_clz(p.group_size); // group_size is a power of two (checked at launch)
 
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     };
     // Loads of one (batch, step) item.  Batches [0, batches0) belong to matrix 0, the rest to matrix 1 (wave-uniform:
     // the base pointers stay in SGPRs and the per-lane part of every address is a 32-bit byte offset -- host-checked).
-    const uint32_t b_own = min((uint32_t)(blockIdx.x * NW + wave), num_batches - 1);
+    const uint32_t b_own = min((uint32_t)(blockIdx.x * bpw + min((uint32_t)wave, bpw - 1)), num_batches - 1);
     auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
         // Unconditional: batch and step are clamped into range and a clamped reload is never consumed.  VMEM returns in
         // issue order and the compiler only emits counted waits (vmcnt(N)) across loads that are always issued; even a
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             c4.bias = p.conv_b ? bias : 0.0f;
         }
     };
-    const uint32_t b0 = blockIdx.x * NW + wave;
+    const uint32_t b0 = (uint32_t)wave < bpw ? blockIdx.x * bpw + wave : num_batches;
     // Wide workgroups hand their batches out dynamically.  On a CU the oldest waves win the issue arbitration: with a static
     // assignment the first-dispatched quarter of a 1024-workgroup grid finishes after 10.4 us, the last after 17.2 us
     // (Llama-3-8B up-projection, tools/timeline.py --detail; no difference between XCDs), and the CU idles towards the end with
@@ -180,13 +183,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     // waves keep streaming neighbouring rows -- are drawn from an LDS counter (round 0 is the static b0): every wave stays busy
     // until the workgroup's share is done.  Which wave computes a row does not change the row's arithmetic.
     __shared__ uint32_t s_next_slot;
-    if (NW > 4 && tid == 0) s_next_slot = NW; // published by the prologue's barrier, first drawn after it
+    if (NW > 4 && tid == 0) s_next_slot = bpw; // published by the prologue's barrier, first drawn after it
     auto next_batch = [&](uint32_t b) -> uint32_t {
         if constexpr (NW > 4) {
             uint32_t n = 0;
             if (lane == 0) n = atomicAdd(&s_next_slot, 1u);
             n = __builtin_amdgcn_readfirstlane(n);
-            return blockIdx.x * NW + n % NW + (n / NW) * total_waves;
+            return blockIdx.x * bpw + n % bpw + (n / bpw) * total_waves;
         } else {
             return b + total_waves;
         }
@@ -725,6 +728,10 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
     const size_t lds = (p.norm_scales || p.norm_plain || p.dg_o) ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float)
                        : (CPLT == 0 && BITS == 4)                  ? ((size_t)(p.k / 32) * 21 + 16) * sizeof(float) // packed row + per-step sums
                                                                    : 0;
+    static const int spread_on = [] { // UZU_DEC_SPREAD=0: a partial round keeps 16 busy waves per workgroup on fewer CUs (A/B runs)
+        const char* c = getenv("UZU_DEC_SPREAD");
+        return c ? atoi(c) : 1;
+    }();
     static const int cap_override = [] {
         const char* c = getenv("UZU_DEC_CAP");
         return c ? atoi(c) : 0;
@@ -741,7 +748,12 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         uint32_t cap = (uint32_t)num_cus * (uint32_t)(cap_override > 0 ? cap_override : occ);                                       \
         if (p.part_val && p.part_capacity && cap > p.part_capacity) cap = p.part_capacity; /* one arg-max partial per workgroup */  \
         const uint32_t want_n = (want * 4 + NWV - 1) / NWV;                                                                         \
-        const uint32_t grid = want_n > cap ? cap : want_n;                                                                          \
+        uint32_t grid = want_n > cap ? cap : want_n;                                                                                \
+        DecGemvParams pl = p;                                                                                                       \
+        if (NWV > 4 && spread_on && grid < (uint32_t)num_cus && !(p.part_val && p.part_capacity && (uint32_t)num_cus > p.part_capacity)) { /* less than one round for the chip: spread it over every CU */     \
+            pl.wg_batches = (want * 4 + (uint32_t)num_cus - 1) / (uint32_t)num_cus;                                                 \
+            grid = (want * 4 + pl.wg_batches - 1) / pl.wg_batches;                                                                  \
+        }                                                                                                                           \
         if (lds > 65536) { /* K > ~24k on the LDS-resident-row path: raise the instance's dynamic-LDS limit to what this call needs */ \
             static size_t raised_to = 0;                                                                                            \
             if (lds > raised_to) {                                                                                                  \
@@ -757,7 +769,7 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         const void* a0 = PRO == 2 ? (const void*)p.dg_o : (const void*)p.x;                                                         \
         const void* a1 = PRO == 2 ? (const void*)p.dg_sz : (const void*)p.shortcut_in;                                              \
         const void* a2 = PRO == 2 ? (const void*)p.dg_w : (const void*)p.norm_scales;                                               \
-        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], p); }, "gemv_dec"); \
+        return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], pl); }, "gemv_dec"); \
     } while (0)
     if constexpr (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))) {
         if (wide) { // bandwidth regime (gemv_dec_plan: R <= 2): one wide workgroup per CU shares the prologue

@@ -69,6 +69,7 @@ struct DecGemvParams {
     uint32_t* part_idx;
     uint32_t part_capacity;       // entries in part_val / part_idx: the grid is clamped to it (0 = unchecked, 8192 in tools)
     float* out_f32;               // tensor parallel: matrix 0 writes f32 partial sums here instead of bf16 into out[0]
+    uint32_t wg_batches;          // set by the launcher: batches a wide workgroup owns per round (0 = one per wave)
     // DeltaNetConvUpdate epilogue (in-proj): rows < conv_dim of matrix 0 go through the causal conv + SiLU of their
     // channel (one lane owns a channel: taps read, shifted and written by that lane only) -- conv_update.rs:17-55
     const float* conv_w;          // [conv_dim, ks]
