@@ -136,6 +136,17 @@ uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity
 void uzu_hip_set_exact_matmul(int32_t enabled);
 /* Number of kernel launches / graph nodes of one decode step (reported by bench.py). */
 uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m);
+/* The launch plan of the decode GEMV (csrc/k_decode.hip: gemv_dec_plan) for a quantized linear of n0 (+ n1: a second matrix in the same
+ * launch) rows over k columns on a device with `num_cus` compute units -- host arithmetic only, no GPU needed; the CPU tests pin the
+ * decisions DESIGN.md section 3 quotes measurements for.  workgroup_batches / workgroups are non-zero when a matrix smaller than one
+ * round of the resident waves is spread over every CU; otherwise the grid is the persistent one (occupancy x CUs, known at launch). */
+typedef struct {
+    uint32_t lanes_per_row, rows_per_lane_group, steps_per_lane, waves_per_workgroup;
+    uint32_t batches; /* rounded up to a multiple of four */
+    uint32_t workgroup_batches, workgroups;
+} uzu_decode_gemv_plan;
+uzu_status uzu_hip_decode_gemv_plan(uint32_t n0, uint32_t n1, uint32_t k, uint32_t bits, uint32_t normed, uint32_t gated_act, uint32_t num_cus,
+                                    uzu_decode_gemv_plan* out);
 
 #ifdef __cplusplus
 }

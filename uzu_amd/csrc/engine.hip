@@ -1237,6 +1237,22 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
 uint32_t uzu_hip_model_context_length(const uzu_hip_model* m) { return m ? m->context_length : 0; }
 size_t uzu_hip_model_weight_bytes(const uzu_hip_model* m) { return m ? m->weight_bytes : 0; }
 uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m) { return m ? m->launches : 0; }
+uzu_status uzu_hip_decode_gemv_plan(uint32_t n0, uint32_t n1, uint32_t k, uint32_t bits, uint32_t normed, uint32_t gated_act, uint32_t num_cus,
+                                    uzu_decode_gemv_plan* out) {
+    if (!out || !n0 || !k || k % 32 || (bits != 4 && bits != 8) || !num_cus || (gated_act && (n0 & 1))) {
+        set_error("decode_gemv_plan: bad arguments");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    k::DecGemvParams p{};
+    static const float one = 1.0f;
+    p.n[0] = n0, p.n[1] = n1, p.k = k, p.bits = bits, p.group_size = 128, p.act_mul = gated_act ? 1 : 0;
+    if (normed) p.norm_scales = &one; // only tested for presence
+    k::DecGemvPlan pl{};
+    k::gemv_dec_plan_query(p, (int)num_cus, &pl);
+    out->lanes_per_row = 1u << pl.lpr_log2, out->rows_per_lane_group = (uint32_t)pl.rows_per_lane_group, out->steps_per_lane = pl.steps_per_lane;
+    out->waves_per_workgroup = pl.waves, out->batches = pl.wave_batches, out->workgroup_batches = pl.wg_batches, out->workgroups = pl.workgroups;
+    return UZU_OK;
+}
 
 uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, uint32_t count, uint32_t* first_token) {
     UZU_REQUIRE(m && token_ids && count > 0, "model_prefill: null / empty input");

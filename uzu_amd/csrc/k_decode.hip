@@ -699,13 +699,13 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
             return e ? atoi(e) : 0;
         }();
         if (*wide_out && wide_r > 0 && !(p.act_mul && cpl > 2)) R = wide_r > 2 ? 2 : wide_r;
-        else if (*wide_out && R == 1 && !p.act_mul) { // (the fused up / gate rows already are two rows in flight per lane group: R = 2 cost Llama-3-8B's up-projection 17.4 -> 19.2 us)
+        else if (*wide_out && R == 1 && !p.act_mul) { // (the fused up / gate rows already are two rows in flight per lane group: Llama-3-8B's up-projection, 56 row pairs per 16 waves = 4 rounds either way, 17.4 -> 19.2 us with two pairs)
             // Rows per lane group by the round count.  A wave streams at a latency-bound rate (two items in flight), so a workgroup
             // of NW waves with B batches takes ceil(B / NW) rounds, the last one with whatever is left; two rows per lane group halve
             // the batches and keep twice the bytes in flight per wave.  Taken when that does not add row-rounds: Qwen3-14B-class
             // down-projection (20 rows per workgroup of 16 waves: 16 + 4 -> 10 x 2) 17.0 -> 14.5 us, its read-out (594 rows per
-            // 12 waves) 100 -> 89; not Llama-3-8B (down: 16 rows = one full round, 8.5 -> 11.7 us with half the waves idle; up: 28
-            // row pairs per 12 waves, 3 rounds against 2 x 2, 17.4 -> 19.0) -- same-box A/B, tools/ab_wide_r.sh.
+            // 12 waves) 100 -> 89; not Llama-3-8B's down-projection (16 rows = one full round, 8.5 -> 11.7 us with half the waves
+            // idle) nor the 14B-class qkv (28 rows per 12 waves: 3 rounds against 2 x 2, 13.1 -> 14.2) -- same-box A/B, tools/ab_wide_r.sh.
             const uint32_t nw = (cpl > 2 && (p.norm_scales || p.norm_plain)) ? 12u : 16u; // launch_gemv_dec_c: NWV
             const uint32_t per_wg = (nb(1) + (uint32_t)num_cus - 1) / (uint32_t)num_cus;
             const uint32_t rounds1 = (per_wg + nw - 1) / nw, rounds2 = (per_wg + 2 * nw - 1) / (2 * nw) * 2;
@@ -880,6 +880,30 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint3
     }
     if (p.bits == 4) return launch_gemv_dec_cpl<4, false>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     return launch_gemv_dec_cpl<8, false>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+}
+
+// The launch plan gemv_dec takes for a shape, without launching (host arithmetic only: callable without a GPU).  `wide_waves` is the
+// launcher's workgroup width (launch_gemv_dec_c: 16 waves, 12 on the 4-step register path, 4 otherwise); `wg_batches` / `workgroups`
+// are the spread of a partial round (0 / 0 when the grid is the persistent one, whose size depends on the instance's occupancy).
+void gemv_dec_plan_query(const DecGemvParams& p, int num_cus, DecGemvPlan* out) {
+    int lpr_log2 = 0, R = 1;
+    bool wide = false;
+    const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R, &wide);
+    const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
+    const bool normed = p.norm_scales || p.norm_plain;
+    const bool four_step = cpl > 2 && cpl <= 4 && (normed || p.dg_o);
+    const bool wide_instance = wide && !p.conv_w && !p.dg_o && (normed || (p.bits == 4 && !four_step && cpl != 1 && cpl != 2));
+    out->lpr_log2 = lpr_log2, out->rows_per_lane_group = R, out->steps_per_lane = cpl;
+    out->waves = wide_instance ? (p.bits == 8 ? 8u : (four_step ? 12u : 16u)) : 4u;
+    out->wave_batches = want * 4; // batches, rounded up to a multiple of four
+    out->wg_batches = 0, out->workgroups = 0;
+    if (out->waves > 4) {
+        const uint32_t want_n = (want * 4 + out->waves - 1) / out->waves;
+        if (want_n < (uint32_t)num_cus) {
+            out->wg_batches = (want * 4 + (uint32_t)num_cus - 1) / (uint32_t)num_cus;
+            out->workgroups = (want * 4 + out->wg_batches - 1) / out->wg_batches;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- argmax_commit

@@ -112,6 +112,15 @@ struct DeltaDecParams {
     float* sz;                // [Hv * Dv] f32 SiLU(z)
     uint32_t num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim;
 };
+struct DecGemvPlan {
+    int lpr_log2;                  // lanes per row = 1 << lpr_log2
+    int rows_per_lane_group;       // R
+    uint32_t steps_per_lane;       // 32-element steps of the row a lane owns
+    uint32_t waves;                // waves per workgroup
+    uint32_t wave_batches;         // batches (rows_per_lane_group x (64 >> lpr_log2) rows each), rounded up to a multiple of four
+    uint32_t wg_batches, workgroups; // a partial round spread over every CU (0, 0: the persistent grid)
+};
+void gemv_dec_plan_query(const DecGemvParams& p, int num_cus, DecGemvPlan* out); // host arithmetic only
 uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p);
 
 struct AttnDecParams {
