@@ -18,6 +18,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -158,7 +159,7 @@ def committed_kernel_avg(traffic_source, launches_per_step=None):
 
 def timed_decode(model, ctx, args, dist, prompt):
     """prefill -> `warmup` untimed steps -> EXACTLY `steps` timed greedy decode steps between barrier + device sync on
-    both sides; elapsed = max over ranks.  Returns (elapsed_s, gpu_ms, start_ctx, end_ctx, prefill_s)."""
+    both sides; elapsed = max over ranks.  Returns (elapsed_s, gpu_ms, start_ctx, end_ctx, prefill_s, tokens of the timed steps)."""
     def sync():
         ctx.synchronize()
         if dist is not None:
@@ -178,7 +179,7 @@ def timed_decode(model, ctx, args, dist, prompt):
     start_ctx = model.context_length
     sync()
     t0 = time.perf_counter()
-    _, gpu_ms = model.decode(args.steps)  # K graph replays, chained on the device; returns after the last one
+    tokens, gpu_ms = model.decode(args.steps)  # K graph replays, chained on the device; returns after the last one
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -186,7 +187,7 @@ def timed_decode(model, ctx, args, dist, prompt):
         t = torch.tensor([elapsed, prefill_s], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, prefill_s = float(t[0].item()), float(t[1].item())
-    return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s
+    return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s, tokens
 
 
 def bench_c3(args):
@@ -372,7 +373,7 @@ def main():
     else:
         model = HipModel(ctx, bundle, flags)
 
-    elapsed, gpu_ms, start_ctx, end_ctx, prefill_s = timed_decode(model, ctx, args, dist, prompt)
+    elapsed, gpu_ms, start_ctx, end_ctx, prefill_s, timed_tokens = timed_decode(model, ctx, args, dist, prompt)
     mean_ctx = (start_ctx + end_ctx - 1) / 2.0
     sequences = world if mode == "replicas" else 1
     tokens_per_s = sequences * args.steps / elapsed
@@ -427,6 +428,8 @@ def main():
         "config": {"workload": f"{cfg.name} int{cfg.bits} ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
                    "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or use_graph), "parallelism": parallelism},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
+        # the timed steps' token ids: two builds / plan switches that only move rows between waves must agree on it (same-box A/B runs)
+        "timed_tokens_crc32": zlib.crc32(np.asarray(timed_tokens, dtype="<u4").tobytes()),
         "prefill_tokens_per_s": round(sequences * prompt_len / prefill_s, 1),
         "prefill_roofline": {"bound": "mfma", "achieved": round(sequences * bundle.prefill_flops(prompt_len) / prefill_s / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(sequences * bundle.prefill_flops(prompt_len) / prefill_s / 1e12 / (MFMA_BF16_PEAK_TFLOPS * max(world, 1)), 5),
@@ -446,7 +449,7 @@ def main():
         model.close()
         try:
             replica = HipModel(ctx, bundle, flags)
-            r_elapsed, _, _, _, r_prefill = timed_decode(replica, ctx, args, dist, prompt)
+            r_elapsed, _, _, _, r_prefill, _ = timed_decode(replica, ctx, args, dist, prompt)
             result["replicas"] = {"value": round(world * args.steps / r_elapsed, 2), "unit": "tokens/s", "scaling": "weak",
                                   "prefill_tokens_per_s": round(world * prompt_len / r_prefill, 1),
                                   "note": f"{world} independent sequences, one per GPU, no collective (not the headline value)"}
