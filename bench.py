@@ -45,6 +45,9 @@ def parse_args():
                     "stream launches, the conservative form for a multi-rank collective that could not be exercised on the 1-GPU dev box")
     ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep every all-reduce on RCCL (default: decode-sized ones use the one-shot peer-to-peer exchange)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path even with one rank (self-test on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="DRY RUN of the tensor-parallel path on a 1-GPU box: the N ranks all use GPU 0 (gloo rendezvous, "
+                    "hipIpc mailboxes for every exchange -- RCCL refuses duplicate devices).  The line says so (physical_gpus 1); it is a correctness / "
+                    "plumbing run of the p2p + hipGraph decode path, not a scaling measurement")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="BASELINE.json configs[1..4]: c2 (default, the headline) Qwen3.5-0.8B int4 ctx-2048 decode; c3 Llama-3-8B int4, 4k prefill x 8 "
@@ -163,8 +166,9 @@ def timed_decode(model, ctx, args, dist, prompt):
     def sync():
         ctx.synchronize()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if not args.share_gpu:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     model.prefill(prompt)  # warm-up run, discarded (the reference's bench does the same: cli/src/bench/runner.rs:67-68);
@@ -184,7 +188,7 @@ def timed_decode(model, ctx, args, dist, prompt):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, prefill_s], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, prefill_s], device="cpu" if args.share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, prefill_s = float(t[0].item()), float(t[1].item())
     return elapsed, gpu_ms, start_ctx, model.context_length, prefill_s, tokens
@@ -220,11 +224,11 @@ def bench_c3(args):
     elapsed = time.perf_counter() - t0
     # the same prompts one sequence at a time (M = 1024 per pass): what batching buys
     t1 = time.perf_counter()
+    single_firsts = []
     for i, st in enumerate(states):
         st.reset()
         model.bind(st)
-        single_first = model.prefill(prompts[i])
-        assert single_first == int(first[i]) or True
+        single_firsts.append(int(model.prefill(prompts[i])))
     ctx.synchronize()
     single = time.perf_counter() - t1
     model.bind(None)
@@ -242,7 +246,9 @@ def bench_c3(args):
                      "traffic": None, "note": "whole batched prefill (GEMMs + attention + element-wise) over its wall time; algorithmic FLOPs = 2 M sum(N K) + causal "
                                               "attention (SURVEY.md section 8d)"},
         "single_sequence_prefill_tokens_per_s": round(tokens / single, 1),
-        "first_tokens": [int(t) for t in first], "device": ctx.device_name(),
+        # a batched pass may split K of a GEMM differently from the single-sequence pass (tolerance-class logits): reported, not asserted
+        "first_tokens": [int(t) for t in first], "single_sequence_first_tokens": single_firsts,
+        "first_tokens_agree": sum(int(a) == b for a, b in zip(first, single_firsts)), "device": ctx.device_name(),
     }
     for st in states:
         st.close()
@@ -283,7 +289,7 @@ def spawn_ranks(n):
         visible = torch.cuda.device_count()
     except Exception as exc:  # noqa: BLE001
         sys.exit(f"bench.py --gpus {n}: cannot count GPUs ({exc})")
-    if visible < n:
+    if visible < n and "--share-gpu" not in sys.argv:
         sys.exit(f"bench.py --gpus {n}: only {visible} GPU(s) visible -- refusing to report a {n}-GPU line from fewer devices")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -313,11 +319,15 @@ def main():
         import datetime
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=300))
+        if args.share_gpu:
+            local_rank = 0  # every rank on GPU 0; host-side rendezvous only
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
 
     from uzu_amd import synthetic as S
     from uzu_amd import tp as TP
@@ -350,7 +360,12 @@ def main():
             local_bundle, vocab_offset = TP.shard_bundle(bundle, rank, world)
         except AssertionError as exc:  # deterministic on every rank: the planner only looks at shapes
             mode, note, local_bundle = "replicas", f"tp{world} not applicable: {exc}", bundle
-    if mode == "tp":
+    if mode == "tp" and args.share_gpu:
+        group = TP.TpGroup.local(ctx, rank, world)
+        group.enable_p2p(TP.torch_all_gather_bytes(dist))  # no fallback: without the mailboxes ranks on one device cannot exchange
+        p2p, use_graph = True, not args.no_graph
+        model = HipModel(ctx, local_bundle, flags, tp_group=group, vocab_offset=vocab_offset)
+    elif mode == "tp":
         import torch
         group = TP.TpGroup(ctx, rank, world, TP.torch_broadcast(dist, device=torch.device("cuda", local_rank)))
         # decode-sized all-reduces go through the one-shot peer-to-peer exchange (mailboxes over hipIpc, csrc/tp.hip) when every
@@ -374,6 +389,11 @@ def main():
         model = HipModel(ctx, bundle, flags)
 
     elapsed, gpu_ms, start_ctx, end_ctx, prefill_s, timed_tokens = timed_decode(model, ctx, args, dist, prompt)
+    tokens_agree = True
+    if args.share_gpu and dist is not None:  # every rank must have committed the same stream (rank-order sums, one arg-max key)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [int(t) for t in timed_tokens])
+        tokens_agree = all(g == gathered[0] for g in gathered)
     mean_ctx = (start_ctx + end_ctx - 1) / 2.0
     sequences = world if mode == "replicas" else 1
     tokens_per_s = sequences * args.steps / elapsed
@@ -439,6 +459,10 @@ def main():
         "kernel_us_per_step": per_kernel,
         "device": ctx.device_name(),
     }
+    if args.share_gpu:
+        result["physical_gpus"] = 1
+        note = (note + "; " if note else "") + f"DRY RUN: {world} ranks share ONE physical GPU (bench.py --share-gpu): plumbing of the p2p + hipGraph TP decode path, not a scaling point"
+        result["all_ranks_tokens_agree"] = bool(tokens_agree)
     if note:
         result["config"]["note"] = note
     if mode == "tp":
@@ -446,8 +470,14 @@ def main():
         result["tp"] = {"exchange": "one-shot peer-to-peer (hipIpc mailboxes) for decode rows, RCCL for prefill" if p2p else "RCCL", "all_reduces_per_token": ar[0], "all_reduce_us_per_token": round(ar[2] * 1e3, 1),
                         "share_of_kernel_time": round(ar[2] / max(sum(p[2] for p in prof), 1e-9), 3)}
         # the serving-throughput view of the same N GPUs: N independent sequences, one whole model per GPU
-        model.close()
+        if args.share_gpu:
+            raise_replicas = False
+        else:
+            raise_replicas = True
+            model.close()
         try:
+            if not raise_replicas:
+                raise RuntimeError("skipped: the ranks of a --share-gpu dry run share one device")
             replica = HipModel(ctx, bundle, flags)
             r_elapsed, _, _, _, r_prefill, _ = timed_decode(replica, ctx, args, dist, prompt)
             result["replicas"] = {"value": round(world * args.steps / r_elapsed, 2), "unit": "tokens/s", "scaling": "weak",
@@ -456,7 +486,7 @@ def main():
             model = replica
         except Exception as exc:  # noqa: BLE001 -- the secondary figure must never take the headline down
             result["replicas"] = {"error": str(exc)[:200]}
-            model = None
+            model = model if args.share_gpu else None
     if args.config == "c5" and mode == "single" and model is not None:
         result["mixed_prefill_decode"] = bench_c5_mixed(args, model, ctx, cfg, bundle, end_ctx)
     if args.config != "c2":

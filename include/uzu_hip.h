@@ -270,8 +270,10 @@ uzu_status uzu_hip_sigmoid_gate_create(uzu_hip_context* ctx, uint32_t t, uzu_hip
 uzu_status uzu_hip_sigmoid_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf gate, uzu_buf output,
                                        uint32_t total_elements);
 
-/* ---- GatedActMul (cpu/kernel/gated_act_mul/gated_act_mul.rs:13-35); ops != FullPrecision or
- *      use_hadamard: UZU_ERR_UNSUPPORTED ("next": RHT / A8 path) */
+/* ---- GatedActMul (cpu/kernel/gated_act_mul/gated_act_mul.rs:13-35).  ops: 0 FullPrecision, 1 Quantize,
+ *      2 QuantizeWithGroupSums; the quantized ops require use_hadamard (gated_act_mul.rs:36-42) and
+ *      activation_scale_group_size (and sum_group_size for op 2) in {32, 64, 128, 256}.  RHT variants: the rounded
+ *      gated product goes through ActivationTransform{InputRht | Quantize | QuantizeWithGroupSums}; bit-exact. */
 uzu_status uzu_hip_gated_act_mul_create(uzu_hip_context* ctx, uint32_t t, uint32_t ops, uint32_t interleaved,
                                         uint32_t use_hadamard, uint32_t activation_scale_group_size,
                                         uint32_t sum_group_size, uzu_hip_kernel** out);
@@ -314,8 +316,9 @@ uzu_status uzu_hip_tensor_copy_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_
 uzu_status uzu_hip_tensor_copy_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf src, uzu_buf dst,
                                       uint32_t length);
 
-/* ---- UnifiedSampling (cpu/kernel/sampling/unified_sampling.rs:13-32); greedy (argmax, ties -> lowest id)
- *      only: stochastic / top-k / top-p / min-p / temperature / bitmask: UZU_ERR_UNSUPPORTED */
+/* ---- UnifiedSampling (cpu/kernel/sampling/unified_sampling.rs:13-32): greedy (argmax, ties -> lowest id) and
+ *      every stochastic specialisation -- bitmask, temperature, top-k, top-p, min-p, Gumbel-max with the
+ *      Philox4x32-10 noise of (seed, index); token-identical to the CPU kernel (tests/golden/sampling.json). */
 uzu_status uzu_hip_unified_sampling_create(uzu_hip_context* ctx, uint32_t t, uint32_t is_stochastic,
                                            uint32_t has_bitmask, uint32_t has_temperature, uint32_t has_top_k,
                                            uint32_t has_top_p, uint32_t has_min_p, uzu_hip_kernel** out);

@@ -83,6 +83,7 @@ struct uzu_hip_model {
     uzu_hip_context* ctx = nullptr;
     uzu_hip_state* state0 = nullptr; // the model's own sequence state (uzu_hip_model_create); owned
     uzu_hip_state* bound = nullptr;  // state whose pointers the fields below currently mirror
+    std::vector<uzu_hip_state*> user_states; // live states of uzu_hip_state_create (neutralised if the model is destroyed first)
     uint32_t flags = 0;
     uzu_model_desc d; // scalars only
     std::vector<DLayer> layers;
@@ -202,13 +203,21 @@ uzu_status state_alloc(uzu_hip_state* st, size_t bytes, void** out) {
     return UZU_OK;
 }
 
-void state_free(uzu_hip_state* st) {
-    if (!st) return;
+// device side of a state (graphs, caches); the host struct stays
+void state_release(uzu_hip_state* st) {
+    if (!st || !st->m) return;
     if (st->graph_single) (void)hipGraphExecDestroy(st->graph_single);
     if (st->graph_two) (void)hipGraphExecDestroy(st->graph_two);
+    st->graph_single = st->graph_two = nullptr;
     for (void* p : st->allocations) (void)hipFree(p);
+    st->allocations.clear();
     uzu_hip_context* ctx = st->m->ctx;
     ctx->current_bytes -= st->bytes < ctx->current_bytes ? st->bytes : ctx->current_bytes;
+    st->bytes = 0;
+}
+void state_free(uzu_hip_state* st) {
+    if (!st) return;
+    state_release(st);
     delete st;
 }
 
@@ -481,11 +490,9 @@ void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint1
 
 uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
     if (rows <= m->partial_rows) return UZU_OK;
-    if (m->partials) { // regrow: earlier passes may still read the old blocks
-        HIPCHK(hipStreamSynchronize(m->ctx->stream));
-        for (void* old : {(void*)m->partials, (void*)m->sums, (void*)m->maxs}) dev_free(m, old);
-        m->partials = m->sums = m->maxs = nullptr, m->partial_rows = 0;
-    }
+    // regrow: the old blocks stay allocated until the model is destroyed -- captured decode graphs (this state's and every
+    // other uzu_hip_state's graph_two on the unfused path) carry their addresses in attention_two_pass1/2 nodes, and nothing
+    // re-captures them on a regrow.  They are small (decode rows) next to the prefill-sized blocks that replace them.
     void* p;
     UZU_PROPAGATE(dev_alloc(m, (size_t)rows * 32 * head_dim * 4, &p));
     m->partials = (float*)p;
@@ -1134,7 +1141,13 @@ void uzu_hip_model_destroy(uzu_hip_model* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->bound) m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two;
-    state_free(m->state0); // (states created with uzu_hip_state_create belong to the caller and must be destroyed first)
+    state_free(m->state0);
+    // states created with uzu_hip_state_create belong to the caller; one that outlives its model loses its device memory here and
+    // is neutralised (m = null), so that the caller's later uzu_hip_state_destroy only deletes the host struct
+    for (uzu_hip_state* st : m->user_states) {
+        state_release(st);
+        st->m = nullptr;
+    }
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (void* p : m->allocations) (void)hipFree(p);
@@ -1160,11 +1173,22 @@ uzu_status uzu_hip_model_reset(uzu_hip_model* m) {
 uzu_status uzu_hip_state_create(uzu_hip_model* m, uzu_hip_state** out) {
     UZU_REQUIRE(m && out, "state_create: null argument");
     (void)hipSetDevice(m->ctx->device);
-    return state_build(m, out);
+    UZU_PROPAGATE(state_build(m, out));
+    m->user_states.push_back(*out);
+    return UZU_OK;
 }
 void uzu_hip_state_destroy(uzu_hip_state* st) {
     if (!st) return;
     uzu_hip_model* m = st->m;
+    if (!m) { // the model went first (uzu_hip_model_destroy released the device side)
+        delete st;
+        return;
+    }
+    for (size_t i = 0; i < m->user_states.size(); ++i)
+        if (m->user_states[i] == st) {
+            m->user_states.erase(m->user_states.begin() + i);
+            break;
+        }
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->bound == st) { // hand the model back to its own state first
@@ -1181,7 +1205,7 @@ uzu_status uzu_hip_model_bind_state(uzu_hip_model* m, uzu_hip_state* st) {
     return UZU_OK;
 }
 uzu_status uzu_hip_state_reset(uzu_hip_state* st) {
-    UZU_REQUIRE(st, "state_reset: null state");
+    UZU_REQUIRE(st && st->m, "state_reset: null state (or its model was destroyed)");
     uzu_hip_model* m = st->m;
     uzu_hip_state* prev = m->bound;
     bind_state(m, st);
@@ -1190,7 +1214,7 @@ uzu_status uzu_hip_state_reset(uzu_hip_state* st) {
     return r;
 }
 uint32_t uzu_hip_state_context_length(const uzu_hip_state* st) {
-    if (!st) return 0;
+    if (!st || !st->m) return 0;
     return st->m->bound == st ? st->m->context_length : st->context_length;
 }
 
@@ -1223,6 +1247,7 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
         if (max_heads) UZU_PROPAGATE(ensure_partials(m, n * max_heads, max_hd)); // any sequence may be past 1024 keys
         UZU_PROPAGATE(encode_forward(m, s, n, last, states, nseq));
         HIPCHK(hipStreamSynchronize(s)); // the staging buffer is reused; also surfaces kernel faults per chunk
+        if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
         for (uint32_t i = 0; i < nseq; ++i) {
             bind_state(m, states[i]);
             m->context_length += n;
@@ -1275,6 +1300,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
         }
         UZU_PROPAGATE(encode_forward(m, s, n, last));
         HIPCHK(hipStreamSynchronize(s)); // token_ids is caller memory; also surfaces kernel faults per chunk
+        if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
         m->context_length += n;
     }
     if (first_token) HIPCHK(hipMemcpy(first_token, m->d_out_token, 4, hipMemcpyDeviceToHost));
@@ -1293,6 +1319,7 @@ uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, 
     UZU_REQUIRE(m && out_tokens, "model_read_tokens: null argument");
     UZU_REQUIRE(first_position + count <= m->max_positions, "model_read_tokens: range out of bounds");
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     HIPCHK(hipMemcpy(out_tokens, m->d_sampled + first_position, (size_t)count * 4, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
@@ -1311,6 +1338,7 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
     UZU_PROPAGATE(uzu_hip_model_decode_enqueue(m, steps));
     HIPCHK(hipEventRecord(m->ev1, m->ctx->stream));
     HIPCHK(hipEventSynchronize(m->ev1));
+    if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     if (gpu_ms) HIPCHK(hipEventElapsedTime(gpu_ms, m->ev0, m->ev1));
     if (out_tokens) UZU_PROPAGATE(uzu_hip_model_read_tokens(m, first, steps, out_tokens));
     return UZU_OK;

@@ -256,8 +256,8 @@ uzu_status uzu_hip_sparse_buffer_create(uzu_hip_context* ctx, size_t capacity, u
     b->size = ((capacity ? capacity : 1) + gran - 1) / gran * gran;
     hipError_t e = hipMemAddressReserve(&b->dptr, b->size, gran, nullptr, 0);
     if (e != hipSuccess) {
-        delete b;
         set_error("sparse_buffer_create: hipMemAddressReserve(%zu) failed: %s", b->size, hipGetErrorString(e));
+        delete b;
         return UZU_ERR_HIP;
     }
     b->pages.assign(b->size / gran, (hipMemGenericAllocationHandle_t) nullptr);

@@ -23,6 +23,7 @@ uzu_status p2p_connect(Comm* c, const uint8_t* handles);
 bool p2p_connected(const Comm* c);
 void p2p_disable(Comm* c);
 uzu_status p2p_error(Comm* c, uint32_t* out);
+uzu_status p2p_check(Comm* c); // UZU_ERR_HIP (sticky) once a bounded wait gave up; called at the engine's host sync points
 uzu_status comm_create_local(int rank, int size, Comm** out); // no RCCL communicator: P2P exchanges only (tests; small groups)
 
 uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count, uint16_t* bf16_out = nullptr); // in place; optional bf16 copy of the sums

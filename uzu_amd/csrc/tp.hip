@@ -9,6 +9,7 @@
 //   * librccl is loaded with dlopen only when a communicator is created: the single-GPU library has no RCCL
 //     dependency and fails loudly (UZU_ERR_UNSUPPORTED) if a TP group is requested where RCCL is absent.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include "device_utils.h"
@@ -168,6 +169,7 @@ namespace {
 struct P2PArgs {
     Mailbox* box[kMaxRanks];
     int rank, size;
+    unsigned long long timeout_ticks; // bounded wait, in ticks of the 100 MHz s_memrealtime clock
 };
 // OP 0: f32 sum over `count` floats (in place on buf; `bf16_out` (optional) also receives the sums rounded to bf16: the cast the
 // engine would otherwise launch as its own kernel); OP 1: u64 max over `count` keys (buf = unsigned long long*).
@@ -185,9 +187,14 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
     __shared__ uint32_t s_seq, s_ok;
     Mailbox* mine = a.box[a.rank];
     const uint32_t tid = threadIdx.x, words = OP == 0 ? count : 2 * count, pairs = (words + 1) / 2;
-    if (tid == 0) s_seq = mine->seq[0] + 1u, s_ok = 1u;
+    // A failed exchange is STICKY: the error word stays set, every later exchange of this rank skips its wait and poisons its
+    // output (NaN sums / a zero key), and its peers run into their own bounded wait -- the group fails as a whole and every host
+    // finds the error word at its next sync point (p2p_check) instead of carrying on with un-reduced partial sums.
+    if (tid == 0) s_seq = mine->seq[0] + 1u, s_ok = __hip_atomic_load(&mine->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u ? 1u : 0u;
     __syncthreads();
     const uint32_t seq = s_seq, par = seq & 1u;
+    const bool poisoned = s_ok == 0u; // uniform
+    __syncthreads();
     // 1. push: this rank's row into slot [parity][rank] of every mailbox (an odd tail word travels with a zero partner)
     const uint32_t* src = (const uint32_t*)buf;
     for (uint32_t i = tid; i < pairs; i += 256) {
@@ -199,11 +206,11 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
     __syncthreads();
     if (tid < (uint32_t)a.size) __hip_atomic_store(&a.box[tid]->flags[par][a.rank][0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // 3. wait for every rank's contribution in the local mailbox (bounded: ~2 s of the 100 MHz clock)
-    if (tid < (uint32_t)a.size) {
+    if (!poisoned && tid < (uint32_t)a.size) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&mine->flags[par][tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                 s_ok = 0u;
                 break;
             }
@@ -211,8 +218,27 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
     }
     __syncthreads();
     if (!s_ok) {
-        if (tid == 0) mine->error[0] = seq;
-        return; // leave buf untouched: the host sees the error flag
+        // gave up (or an earlier exchange did): record the first failing sequence number, poison the result, and still advance the
+        // sequence number so that this rank keeps its parity / slot discipline
+        for (uint32_t i = tid; i < pairs; i += 256) {
+            if (OP == 0) {
+                float* out = (float*)buf;
+                out[2 * i] = __builtin_nanf("");
+                if (bf16_out) bf16_out[2 * i] = 0x7FC0u;
+                if (2 * i + 1 < words) {
+                    out[2 * i + 1] = __builtin_nanf("");
+                    if (bf16_out) bf16_out[2 * i + 1] = 0x7FC0u;
+                }
+            } else {
+                ((u64*)buf)[i] = 0ull;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (!poisoned) __hip_atomic_store(&mine->error[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            mine->seq[0] = seq;
+        }
+        return;
     }
     // 4. reduce in rank order (the same order on every rank: bit-identical results)
     for (uint32_t i = tid; i < pairs; i += 256) {
@@ -340,10 +366,33 @@ uzu_status p2p_error(Comm* c, uint32_t* out) { // sequence number of the exchang
     UZU_HIP_TRY(hipMemcpy(out, c->p2p.local->error, 4, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
+// Bounded wait of one exchange: UZU_TP_TIMEOUT_MS (default 20 s).  Ranks are independent host processes and skew by seconds around
+// graph builds and first launches; a host barrier in front of the first exchange (bench.py, the tests) keeps the skew below this.
+static unsigned long long p2p_timeout_ticks() {
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("UZU_TP_TIMEOUT_MS");
+        const long ms = e && atol(e) > 0 ? atol(e) : 20000;
+        return (unsigned long long)ms * 100000ull; // 100 MHz
+    }();
+    return ticks;
+}
+// Host sync points of the TP engine (prefill chunk, decode, read_tokens) call this: a bounded wait that gave up anywhere since the
+// last check turns into an error status here instead of silently wrong tokens.
+uzu_status p2p_check(Comm* c) {
+    if (!c || !c->p2p.local) return UZU_OK;
+    uint32_t e = 0;
+    UZU_HIP_TRY(hipMemcpy(&e, c->p2p.local->error, 4, hipMemcpyDeviceToHost));
+    if (e) {
+        set_error("tp: peer-to-peer exchange %u of rank %d timed out waiting for a peer (UZU_TP_TIMEOUT_MS); results since then are poisoned", e, c->rank);
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
 template <int OP> static uzu_status p2p_launch(Comm* c, hipStream_t s, void* buf, uint32_t count, uint16_t* bf16_out = nullptr) {
     P2PArgs a{};
     for (int r = 0; r < c->size; ++r) a.box[r] = c->p2p.peer[r];
     a.rank = c->rank, a.size = c->size;
+    a.timeout_ticks = p2p_timeout_ticks();
     return launch_check([&] { hipLaunchKernelGGL(p2p_all_reduce_kernel<OP>, dim3(1), dim3(256), 0, s, a, buf, count, bf16_out); }, "tp_p2p_all_reduce");
 }
 int comm_rank(const Comm* c) { return c->rank; }
@@ -351,6 +400,16 @@ int comm_size(const Comm* c) { return c->size; }
 
 uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count, uint16_t* bf16_out) {
     if (c->p2p.connected && count <= kMailboxFloats) return p2p_launch<0>(c, s, buf, (uint32_t)count, bf16_out); // decode rows: one hop
+    if (c->p2p.connected && !c->comm) {
+        // a group without an RCCL communicator (comm_create_local: ranks that share one device, which RCCL refuses): prefill-sized
+        // rows go through the mailboxes in slices of one slot.  Slow (one exchange kernel per 32 KB) and only meant for small groups
+        // and the single-GPU multi-rank tests; same rank-order sums as the one-hop exchange.
+        for (size_t off = 0; off < count; off += kMailboxFloats) {
+            const size_t n = count - off < kMailboxFloats ? count - off : kMailboxFloats;
+            UZU_PROPAGATE(p2p_launch<0>(c, s, buf + off, (uint32_t)n, bf16_out ? bf16_out + off : nullptr));
+        }
+        return UZU_OK;
+    }
     UZU_REQUIRE(c->comm, "tp: no RCCL communicator for a %zu-float all-reduce", count);
     UZU_PROPAGATE(check(g_api.AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->comm, s), "ncclAllReduce(sum,f32)"));
     return bf16_out ? cast_f32_bf16(s, buf, bf16_out, count) : UZU_OK;

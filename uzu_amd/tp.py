@@ -185,6 +185,20 @@ def shard_layer(l: D.LayerWeights, rank: int, size: int) -> D.LayerWeights:
 def shard_bundle(bundle: D.ModelBundle, rank: int, size: int) -> Tuple[D.ModelBundle, int]:
     """-> (shard bundle, vocab_offset).  size == 1 still produces the untied-readout form the TP engine expects."""
     assert 0 <= rank < size
+    # HybridSpec (RHT) linears: the Hadamard sign vectors would have to be cut with the rows / k slices (32-aligned) and the
+    # output transform of a row-parallel linear moved behind the all-reduce.  Not planned here: refuse instead of silently running
+    # plain matmuls on RHT-space weights (the slicing helpers below rebuild LinearWeights without the sign vectors).
+    def _lin(b):
+        yield b.embedding
+        if b.output_embedding is not None:
+            yield b.output_embedding
+        for l in b.layers:
+            for name in ("up_projection", "down_projection", "qkv_projection", "gate_projection", "out_projection", "dn_in_proj", "dn_out_proj"):
+                w = getattr(l, name, None)
+                if w is not None:
+                    yield w
+    if any(w.input_signs is not None or w.output_signs is not None for w in _lin(bundle)):
+        raise NotImplementedError("tensor-parallel shards of HybridSpec (RHT) linears are not planned: input_signs / output_signs would be dropped")
     V = bundle.vocab_size
     assert V % size == 0, f"vocab {V} does not split over {size} ranks"
     lo, hi = rank * V // size, (rank + 1) * V // size
