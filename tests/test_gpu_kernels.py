@@ -1118,3 +1118,47 @@ def test_matmul_output_rht_then_bias_and_the_rht_linear_chain(hip_ctx):
     assert ulps8.max() <= 4.0 and (ulps8 <= 1.0).mean() >= 0.98
     # the two chains agree with each other within the int8 quantisation noise of the activations (~1 %)
     assert np.abs(f32(want8) - f32(want)).max() <= 0.05 * np.abs(f32(want)).max()
+
+
+# ------------------------------------------------------------------------------------------------ weight-streaming engine
+def _set_stream(mode):
+    """csrc/k_stream.hip: -1 environment / default (bandwidth regime only), 0 never, 2 every supported shape."""
+    fn = _ffi.lib().uzu_hip_debug_set_decode_stream
+    fn.restype, fn.argtypes = None, [C.c_int]
+    fn(mode)
+
+
+def _stream_error():
+    fn = _ffi.lib().uzu_hip_debug_decode_stream_error
+    fn.restype, fn.argtypes = C.c_uint32, []
+    return int(fn())
+
+
+STREAM_SHAPES = [  # (n, k, group): steps per lane 1 (two and one rows per wave), 2, 3, 4, 7, 9; ragged last slots; less than one slot per CU
+    (6144, 4096, 128), (4096, 14336, 128), (1000, 1024, 128), (777, 2048, 64), (515, 5120, 128), (300, 17408, 128), (97, 8192, 32), (8224, 1024, 128),
+    (33, 4096, 128), (2, 512, 64),
+]
+
+
+@pytest.mark.parametrize("n,k,group", STREAM_SHAPES)
+def test_stream_gemv_is_bit_identical_to_register_gemv(hip_ctx, n, k, group):
+    """The LDS-staged weight stream (loader wave + LDS-DMA ring + consumer waves, csrc/k_stream.hip) against the register GEMV of
+    k_decode.hip on the same matrix: same lane mapping and arithmetic, so every output is BIT-identical whichever wave / slot / kernel
+    computes the row -- and both are within 1 bf16 ulp of the CPU restatement (kernel.rs:190-293).  No bounded wait may give up."""
+    rng = np.random.default_rng(n * 3 + k)
+    q = quant_matrix(rng, n, k, 4, group, 0)
+    a = activations(rng, 1, k)
+    bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
+    try:
+        _set_stream(0)
+        base = hip_matmul(hip_ctx, a, q, 1, bias=bias)
+        _set_stream(2)
+        got = hip_matmul(hip_ctx, a, q, 1, bias=bias)
+        again = hip_matmul(hip_ctx, a, q, 1, bias=bias)
+    finally:
+        _set_stream(-1)
+    assert _stream_error() == 0, "a bounded wait of the streaming kernel gave up"
+    assert np.array_equal(got, again), "the streaming kernel is not deterministic"
+    assert np.array_equal(base, got), f"{(base != got).sum()} of {n} outputs differ from the register GEMV"
+    want = oracle_matmul(a, q, 1, bias=bias)
+    assert ulp_diff_bf16(want, got).max() <= 1.0

@@ -500,3 +500,38 @@ def test_sequence_states_are_independent_and_batched_prefill_matches_single(hip_
     for st in states:
         st.close()
     hm.close()
+
+
+# ------------------------------------------------------------------------------------------ weight-streaming engine
+@pytest.mark.parametrize("preset,kw", [("tiny-qwen", {}), ("tiny-llama", {"method": D.QUANT_SCALE_BIAS, "group_size": 64}),
+                                       ("llama-3-8b", {"max_context_length": 256, "layer_kinds": [D.MIXER_ATTENTION] * 2, "seed": 7})])
+def test_streaming_decode_engine_is_bit_identical(hip_ctx, preset, kw):
+    """Decode with every supported GEMV on the LDS-staged weight stream (csrc/k_stream.hip: Normalization prologue on the consumer
+    waves, GatedActMul and arg-max epilogues, two-matrix qkv + gate launches) against the same model on the register GEMVs of
+    k_decode.hip: tokens AND logits bit-identical over prefill + 10 chained decode steps (graph replay)."""
+    fn = _ffi.lib().uzu_hip_debug_set_decode_stream
+    fn.restype, fn.argtypes = None, [C.c_int]
+    err = _ffi.lib().uzu_hip_debug_decode_stream_error
+    err.restype, err.argtypes = C.c_uint32, []
+    cfg = S.PRESETS[preset](**kw)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(35, cfg.vocab_size)
+    outs = []
+    try:
+        for mode in (0, 2):
+            fn(mode)
+            hm = HipModel(hip_ctx, bundle)
+            first = hm.prefill(prompt)
+            toks, logits = [first], []
+            for _ in range(10):
+                t, _ = hm.decode(1)
+                toks.append(int(t[0]))
+                logits.append(hm.read_logits())
+            outs.append((toks, logits))
+            hm.close()
+    finally:
+        fn(-1)
+    assert int(err()) == 0, "a bounded wait of the streaming kernel gave up"
+    assert outs[0][0] == outs[1][0], f"register {outs[0][0]}\nstream   {outs[1][0]}"
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)

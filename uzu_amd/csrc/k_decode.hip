@@ -24,6 +24,7 @@
 
 #include <type_traits>
 
+#include "decode_epilogue.h"
 #include "device_utils.h"
 #include "gemv_core.h"
 #include "kernels.h"
@@ -41,17 +42,6 @@
 
 namespace uzu {
 namespace k {
-
-// ---------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ float act_bf16(uint32_t act, float x, const uint64_t* exp_tab) { // activation_type.rs, T = bf16
-    switch (act) {
-    case 0: return round_bf16(x / (1.0f + expf_glibc_tab(-1.0f * x, exp_tab)));
-    case 1: return round_bf16(0.5f * x * (1.0f + tanhf(0.7978846f * (x + 0.044715f * x * x * x))));
-    case 2: return round_bf16(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
-    case 3: return x;
-    default: return x > 20.0f ? x : round_bf16(logf_glibc(1.0f + expf_glibc_tab(x, exp_tab)));
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- gemv_dec
 // No LDS, no workgroup barrier: a wave is self-sufficient.
@@ -871,6 +861,7 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint3
             set_error("gemv_dec: weight matrix of %u x %u exceeds 4 GiB", p.n[i], p.k);
             return UZU_ERR_UNSUPPORTED;
         }
+    if (gemv_stream_wanted(p)) return gemv_stream(s, p_in, num_cus, grid_out); // bandwidth regime: LDS-staged weight stream (k_stream.hip)
     int lpr_log2, R;
     bool wide = false;
     const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R, &wide);

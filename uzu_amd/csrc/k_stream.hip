@@ -1,0 +1,563 @@
+// k_stream.hip -- the weight-streaming engine of the decode GEMVs (bandwidth regime): LDS-staged weight tiles.
+//
+// gemv_dec (k_decode.hip) keeps its weights in registers: a wave has two 16-byte items per lane in flight and the loads of a
+// workgroup start only when its waves do, so the HBM pipe idles through the 3-4 us Normalization prologue and through every
+// ragged last round (Llama-3-8B up-projection: 62.5 MB in 17.9 us although its dot phase streams at 6.2 TB/s).  Here the
+// stream is decoupled from the arithmetic:
+//
+//   * one workgroup per CU = 1 LOADER wave + 7 CONSUMER waves;
+//   * the loader walks the CU's share of the weight matrix in SLOTS of <= 16 KiB (a few whole rows of packed codes + their
+//     bf16 scales / biases, contiguous in HBM because the reference layout is [N, K/2] row-major) and moves them with LDS-DMA
+//     (global_load_lds_dwordx4, 64 lanes x 16 B = 1 KiB per instruction, non-temporal) into a ring of up to 8 slots -- no
+//     registers, no waits on behalf of the arithmetic: it starts at kernel entry, runs through the prologue and stays <= 2-3
+//     slots (40 VMEM operations) ahead of what has landed.  vmcnt is the only completion signal LDS-DMA has, so the loader
+//     publishes "slots < f have landed" in an LDS word after a counted s_waitcnt (loads return in issue order);
+//   * consumers draw work items (a few rows of a slot) from an LDS counter, wait for the slot's publication, read codes /
+//     scales / biases with ds_read, run the SAME per-lane arithmetic as gemv_dec (gemv_core.h: lane sl of a row's lpr lanes owns
+//     the 32-element steps sl + lpr j, packed bf16 dot, xor-butterfly row sum, same rounding points => bit-identical results
+//     whichever kernel, wave or slot computes a row), and count the item done; the loader reuses a ring position when all items
+//     of its previous slot are done;
+//   * the activation row lives in registers (CPL x 16 packed-bf16 registers per lane: with 8 waves per CU every wave has 256);
+//     the Normalization prologue (normalization.rs:56-125) runs on consumer waves 0-3 with the element mapping / reduction
+//     order of normalization_kernel and synchronises through LDS counters, never through s_barrier -- the loader does not stop.
+//
+// Every spin is bounded (a stuck protocol sets the error word and lets the kernel end with garbage instead of hanging the GPU).
+// Instantiated for int4 ScaleBias (the MLX layout of the BASELINE configs), one or two matrices, plain / Normalization
+// prologue, plain / GatedActMul / arg-max epilogues.  gemv_dec routes here (gemv_stream_wanted) and stays the fallback.
+#include <stdlib.h>
+
+#include "decode_epilogue.h"
+#include "device_utils.h"
+#include "gemv_core.h"
+#include "kernels.h"
+#include "kernels_decode.h"
+
+namespace uzu {
+namespace k {
+
+namespace {
+
+constexpr int kWaves = 8;       // 1 loader + 7 consumers
+constexpr uint32_t kMaxRing = 8;
+constexpr uint32_t kSpinLimit = 1u << 22; // x s_sleep(1) ~ 64 cycles: ~0.1-0.3 s, then give up (error word, garbage, no hang)
+
+struct StreamGeo {
+    uint32_t lpr_log2;
+    uint32_t rows_per_slot;  // logical rows (ACT: up / gate pairs) per slot; multiple of the item's rows
+    uint32_t items_per_slot;
+    uint32_t chunk_stride;   // LDS bytes of one chunk of codes (rows_per_slot * row_bytes rounded up to 1 KiB)
+    uint32_t sb_stride;      // LDS bytes of one chunk of scales (or biases): rows_per_slot * G * 2 rounded up to 256 B
+    uint32_t off_scales, off_biases;
+    uint32_t slot_bytes;
+    uint32_t ring_slots;
+    uint32_t slots0, slots1; // slots of matrix 0 / 1
+    uint32_t ops_per_slot;   // VMEM operations per slot (constant: partial slots issue clamped re-reads)
+    uint32_t depth;          // landed-before-published window of the loader, in slots (1 or 2)
+    uint32_t xs_off;         // dynamic-LDS offset of the f32 activation staging (Normalization prologue)
+    uint32_t* err;           // device word: set when a bounded spin gave up
+};
+
+// ---- LDS-DMA (cdna_hip_programming.md 5.7: M0 is written in the statement that reads it and restored)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(uint32_t n) {
+#define UZU_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define UZU_VM8(B) UZU_VM(B) UZU_VM(B + 1) UZU_VM(B + 2) UZU_VM(B + 3) UZU_VM(B + 4) UZU_VM(B + 5) UZU_VM(B + 6) UZU_VM(B + 7)
+    switch (n) {
+        UZU_VM(0) UZU_VM(1) UZU_VM(2) UZU_VM(3) UZU_VM(4) UZU_VM(5) UZU_VM(6) UZU_VM(7)
+        UZU_VM(8) UZU_VM(9) UZU_VM(10) UZU_VM(11) UZU_VM(12) UZU_VM(13) UZU_VM(14) UZU_VM(15)
+        UZU_VM(16) UZU_VM(17) UZU_VM(18) UZU_VM(19) UZU_VM(20) UZU_VM(21) UZU_VM(22) UZU_VM(23)
+        UZU_VM(24) UZU_VM(25) UZU_VM(26) UZU_VM(27) UZU_VM(28) UZU_VM(29) UZU_VM(30) UZU_VM(31)
+        UZU_VM(32) UZU_VM(33) UZU_VM(34) UZU_VM(35) UZU_VM(36) UZU_VM(37) UZU_VM(38) UZU_VM(39)
+        UZU_VM(40) UZU_VM(41) UZU_VM(42) UZU_VM(43) UZU_VM(44) UZU_VM(45) UZU_VM(46) UZU_VM(47)
+        UZU_VM(48) UZU_VM(49) UZU_VM(50) UZU_VM(51) UZU_VM(52) UZU_VM(53) UZU_VM(54) UZU_VM(55)
+        UZU_VM(56) UZU_VM(57) UZU_VM(58) UZU_VM(59) UZU_VM(60) UZU_VM(61) UZU_VM(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef UZU_VM8
+#undef UZU_VM
+}
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// bounded wait for *flag >= target; false = gave up
+__device__ __forceinline__ bool wait_ge(const uint32_t* flag, uint32_t target, uint32_t* err, uint32_t code) {
+    uint32_t spins = 0;
+    while (lds_load(flag) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) {
+            if (err && (threadIdx.x & 63) == 0) atomicOr(err, code);
+            return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; } // LDS aperture: the low 32 bits are the LDS byte address
+
+} // namespace
+
+template <int CPL, bool ACT, int PRO>
+__global__ void __launch_bounds__(64 * kWaves) gemv_stream_kernel(DecGemvParams p, StreamGeo g) {
+    constexpr int NPHYS = ACT ? 2 : 1;
+    constexpr int RR = ACT ? (CPL >= 2 ? 1 : 2) : (CPL >= 3 ? 1 : (CPL == 2 ? 2 : 4)); // row iterations of a work item: ~4 steps per lane
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t s_filled, s_next_item, s_sync, s_done[kMaxRing];
+    __shared__ float s_red[4];
+    __shared__ uint64_t s_exp_tab[32];
+    __shared__ float s_bv[kWaves];
+    __shared__ uint32_t s_bi[kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    UZU_TL_DECL;
+    UZU_TL_STAMP(0);
+    if (tid == 0) {
+        s_filled = 0, s_next_item = 0, s_sync = 0;
+        for (uint32_t i = 0; i < kMaxRing; ++i) s_done[i] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t K = p.k;
+    const uint32_t C = K / 32, row_bytes = K / 2;
+    const uint32_t G = (K + p.group_size - 1) / p.group_size;
+    const uint32_t n_log0 = ACT ? p.n[0] / 2 : p.n[0];
+    const uint32_t R = g.rows_per_slot, S = g.ring_slots;
+    const uint32_t T = g.slots0 + g.slots1;
+    const uint32_t my_T = blockIdx.x < T ? (T - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t smem_base = lds_addr(smem);
+
+    if (wave == 0) {
+        // ================================================================================================ loader
+        const uint32_t P = g.ops_per_slot, D = g.depth;
+        const uint32_t code_pieces = g.chunk_stride / 1024, sb_pieces = g.sb_stride / 256;
+        for (uint32_t t = 0; t < my_T; ++t) {
+            const uint32_t pos = t % S;
+            if (t >= S && !wait_ge(&s_done[pos], (t / S) * g.items_per_slot, g.err, 1u)) break; // the slot's previous tenant is consumed
+            const uint32_t gs = blockIdx.x + t * gridDim.x;
+            const int mat = __builtin_amdgcn_readfirstlane(gs >= g.slots0 ? 1 : 0);
+            const uint32_t ls = mat ? gs - g.slots0 : gs;
+            const uint32_t nl = mat ? p.n[1] : n_log0;
+            const uint32_t r0 = ls * R;
+            const uint32_t rows_valid = nl - r0 < R ? nl - r0 : R;
+            const uint32_t slot_lds = __builtin_amdgcn_readfirstlane(smem_base + pos * g.slot_bytes);
+#pragma unroll
+            for (int h = 0; h < NPHYS; ++h) {
+                const uint32_t prow0 = ACT ? r0 + (h ? p.n[0] / 2 : 0) : r0;
+                // codes: whole rows, contiguous; a partial slot re-reads its last 16 bytes into the unused tail (constant operation count)
+                const uint8_t* src = p.w[mat] + (size_t)prow0 * row_bytes;
+                const uint32_t valid = rows_valid * row_bytes;
+                for (uint32_t piece = 0; piece < code_pieces; ++piece) {
+                    const uint32_t off = piece * 1024 + lane * 16;
+                    glds16_nt(src + (off < valid ? off : valid - 16), __builtin_amdgcn_readfirstlane(slot_lds + h * g.chunk_stride + piece * 1024));
+                }
+                const uint8_t* ssrc = (const uint8_t*)(p.scales[mat] + (size_t)prow0 * G);
+                const uint8_t* bsrc = (const uint8_t*)(p.biases[mat] + (size_t)prow0 * G);
+                const uint32_t svalid = rows_valid * G * 2;
+                for (uint32_t piece = 0; piece < sb_pieces; ++piece) {
+                    const uint32_t off = piece * 256 + lane * 4;
+                    const uint32_t o = off < svalid ? off : svalid - 4;
+                    glds4(ssrc + o, __builtin_amdgcn_readfirstlane(slot_lds + g.off_scales + h * g.sb_stride + piece * 256));
+                    glds4(bsrc + o, __builtin_amdgcn_readfirstlane(slot_lds + g.off_biases + h * g.sb_stride + piece * 256));
+                }
+            }
+            // loads return in issue order: <= D * P outstanding  =>  slots <= t - D have landed
+            wait_vmcnt(D * P);
+            if (t >= D) lds_store(&s_filled, t - D + 1);
+#ifdef UZU_TIMELINE
+            if (t == 0) UZU_TL_STAMP(1); // first slot issued
+#endif
+        }
+        // drain: publish the last slots as they land
+        if (my_T) {
+            if (g.depth > 1 && my_T >= 1) {
+                wait_vmcnt(P);
+                lds_store(&s_filled, my_T - 1);
+            }
+            wait_vmcnt(0);
+            lds_store(&s_filled, my_T);
+        }
+        UZU_TL_STAMP(3); // the whole share has landed
+    } else {
+        // ============================================================================================== consumers
+        const int cw = wave - 1; // consumer index 0..6
+        const int lpr = 1 << g.lpr_log2, rpw = 64 >> g.lpr_log2;
+        const int sl = lane & (lpr - 1), rsub = lane >> g.lpr_log2;
+        const uint32_t gshift = 31 - __builtin_clz(p.group_size);
+        XPack xq[CPL];
+        float xsm[CPL];
+        // ---- the activation row -> registers -----------------------------------------------------------------------
+        if constexpr (PRO == 0) {
+            if (ACT && cw == 0) {
+                if (lane < 32) s_exp_tab[lane] = kExp2fTab[lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_sync, 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const uint32_t c = sl + lpr * j;
+                if (c < C) xsm[j] = xpack_load(xq[j], p.x + (size_t)c * 32);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) xq[j].v[i] = 0u;
+                    xsm[j] = 0.f;
+                }
+            }
+            if (ACT) wait_ge(&s_sync, 1u, g.err, 2u);
+        } else {
+            // Normalization (normalization.rs:56-125), element / thread mapping and reduction order of normalization_kernel and of
+            // gemv_dec's prologue: thread t of 256 owns elements [t E, t E + E), E = K / 256; sum of squares: sequential fma per
+            // thread, xor butterfly per wave, ((w0 + w1) + w2) + w3.
+            float* xs = (float*)(smem + g.xs_off); // C slots of 36 floats
+            const uint32_t E = K / 256;
+            const bool pro = cw < 4;
+            const uint32_t pt = (uint32_t)tid - 64u; // thread index inside the 256-thread prologue
+            if (pro) {
+                if (ACT && cw == 0 && lane < 32) s_exp_tab[lane] = kExp2fTab[lane];
+                float ss = 0.f;
+                for (uint32_t q = 0; q < E; q += 4) {
+                    const uint32_t e = pt * E + q;
+                    const u32x2_v xr = *(const u32x2_v*)(p.x + e);
+                    float v[4] = {bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u)};
+                    if (p.residual_add) {
+                        const u32x2_v sr = *(const u32x2_v*)(p.shortcut_in + e);
+                        const float sc[4] = {bits_to_f32(sr.x << 16), bits_to_f32(sr.x & 0xFFFF0000u), bits_to_f32(sr.y << 16), bits_to_f32(sr.y & 0xFFFF0000u)};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = round_bf16(v[i] + sc[i]);
+                    }
+                    if (p.shortcut_out && blockIdx.x == 0) {
+                        uint2 o;
+                        o.x = (f32_to_bits(v[0]) >> 16) | (f32_to_bits(v[1]) & 0xFFFF0000u);
+                        o.y = (f32_to_bits(v[2]) >> 16) | (f32_to_bits(v[3]) & 0xFFFF0000u);
+                        *(uint2*)(p.shortcut_out + e) = o;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ss = fmaf(v[i], v[i], ss);
+                    *(float4*)(xs + (size_t)(e / 32) * 36 + e % 32) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                ss = wave_sum(ss);
+                if (lane == 0) s_red[cw] = ss;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_sync, 1u);
+                wait_ge(&s_sync, 4u, g.err, 2u);
+                const float total = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+                const float variance = total / (float)K - 0.0f * 0.0f;
+                const float rms_inv = 1.0f / sqrtf(variance + p.norm_eps);
+                for (uint32_t q = 0; q < E; q += 4) {
+                    const uint32_t e = pt * E + q;
+                    float* slot = xs + (size_t)(e / 32) * 36 + e % 32;
+                    const float4 vv = *(const float4*)slot; // own elements
+                    float v[4] = {vv.x, vv.y, vv.z, vv.w};
+                    const f32x4_v t4 = *(const f32x4_v*)(p.norm_scales ? p.norm_scales + e : (const float*)p.x);
+                    const float scl[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float normalized = (v[i] - 0.0f) * rms_inv;
+                        if (!p.norm_scales) v[i] = round_bf16(normalized);
+                        else if (p.norm_full_layer) v[i] = round_bf16(normalized * (scl[i] + p.norm_offset));
+                        else v[i] = round_bf16(round_bf16(normalized) * round_bf16(scl[i] + p.norm_offset));
+                    }
+                    *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.normed_out && blockIdx.x == 0) {
+                        uint2 o;
+                        o.x = (f32_to_bits(v[0]) >> 16) | (f32_to_bits(v[1]) & 0xFFFF0000u);
+                        o.y = (f32_to_bits(v[2]) >> 16) | (f32_to_bits(v[3]) & 0xFFFF0000u);
+                        *(uint2*)(p.normed_out + e) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_sync, 1u);
+            }
+            wait_ge(&s_sync, 8u, g.err, 2u); // the normalised row is complete in LDS
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const uint32_t c = sl + lpr * j;
+                float xf[32];
+                if (c < C) {
+                    const float4* xv = (const float4*)(xs + (size_t)c * 36);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 t = xv[i];
+                        xf[4 * i] = t.x, xf[4 * i + 1] = t.y, xf[4 * i + 2] = t.z, xf[4 * i + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) xf[i] = 0.f;
+                }
+                xsm[j] = sum32(xf);
+                xpack_from_f32(xq[j], xf);
+            }
+        }
+        if (cw == 0) UZU_TL_STAMP(2); // the activation row is in registers
+
+        // ---- work items ----------------------------------------------------------------------------------------------
+        float best_v = -INFINITY;
+        uint32_t best_i = 0xFFFFFFFFu;
+        const uint32_t item_rows = (uint32_t)(RR * rpw);
+        const uint32_t total_items = my_T * g.items_per_slot;
+        for (;;) {
+            uint32_t item = 0;
+            if (lane == 0) item = atomicAdd(&s_next_item, 1u);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= total_items) break;
+            const uint32_t t = item / g.items_per_slot, it_in_slot = item % g.items_per_slot;
+            if (!wait_ge(&s_filled, t + 1, g.err, 4u)) break;
+            const uint32_t pos = t % S;
+            const uint8_t* slot = smem + (size_t)pos * g.slot_bytes;
+            const uint32_t gs = blockIdx.x + t * gridDim.x;
+            const int mat = __builtin_amdgcn_readfirstlane(gs >= g.slots0 ? 1 : 0);
+            const uint32_t ls = mat ? gs - g.slots0 : gs;
+            const uint32_t nl = mat ? p.n[1] : n_log0;
+            Codes4 w[RR][NPHYS][CPL];
+            uint16_t sraw[RR][NPHYS][CPL], braw[RR][NPHYS][CPL];
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) {
+                const uint32_t row_local = it_in_slot * item_rows + rr * rpw + rsub;
+#pragma unroll
+                for (int h = 0; h < NPHYS; ++h)
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const uint32_t c_raw = sl + lpr * j;
+                        const uint32_t c = c_raw < C ? c_raw : C - 1; // clamped: read, never consumed
+                        w[rr][h][j].a = *(const uint4*)(slot + h * g.chunk_stride + row_local * row_bytes + c * 16);
+                        const uint32_t gi = (row_local * G + ((c * 32) >> gshift)) * 2;
+                        sraw[rr][h][j] = *(const uint16_t*)(slot + g.off_scales + h * g.sb_stride + gi);
+                        braw[rr][h][j] = *(const uint16_t*)(slot + g.off_biases + h * g.sb_stride + gi);
+                    }
+            }
+            // the item's bytes are in registers: hand the ring position back before the arithmetic
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&s_done[pos], 1u);
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) {
+                float acc[NPHYS];
+#pragma unroll
+                for (int h = 0; h < NPHYS; ++h) {
+                    acc[h] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const uint32_t c = sl + lpr * j;
+                        if (c < C) {
+                            const float sc = bf16_to_f32(sraw[rr][h][j]);
+                            float of = bf16_to_f32(braw[rr][h][j]);
+                            const float dq = dot32p(w[rr][h][j], xq[j]); // sum (16 + q) x
+                            of = fmaf(-kQ4Offset, sc, of);
+                            acc[h] = fmaf(sc, dq, fmaf(of, xsm[j], acc[h]));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // one row at a time (register pressure)
+                }
+                const float v0 = row_sum_rt(acc[0], lpr);
+                const float v1 = ACT ? row_sum_rt(acc[NPHYS - 1], lpr) : 0.f;
+                const uint32_t lrow = ls * R + it_in_slot * item_rows + rr * rpw + rsub;
+                if (sl == 0 && lrow < nl) {
+                    // MatmulKernel epilogue with ab_scale = 1, no accumulate / soft-cap (kernel.rs:281-292)
+                    float value = 1.0f * v0;
+                    if (p.out_bias[mat]) value += bf16_to_f32(p.out_bias[mat][lrow]);
+                    if (ACT) {
+                        float gate = 1.0f * v1;
+                        if (p.out_bias[0]) gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
+                        const float up_b = round_bf16(value), gate_b = round_bf16(gate);
+                        p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b, s_exp_tab))); // gated_act_mul/mod.rs:5-12
+                    } else {
+                        const uint16_t ob = f32_to_bf16(value);
+                        if (p.out_f32) p.out_f32[lrow] = value;
+                        else p.out[mat][lrow] = ob;
+                        if (p.part_val) {
+                            const float lv = bf16_to_f32(ob);
+                            if (lv > best_v || (lv == best_v && lrow < best_i)) best_v = lv, best_i = lrow;
+                        }
+                    }
+                }
+            }
+        }
+        if (cw == 0) UZU_TL_STAMP(4); // this consumer has run out of items
+        if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(best_v, off, 64);
+                const uint32_t oi = __shfl_xor(best_i, off, 64);
+                if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+            }
+            if (lane == 0) s_bv[wave] = best_v, s_bi[wave] = best_i;
+        }
+    }
+    if (p.part_val) {
+        __syncthreads(); // every wave, the loader included, comes through here exactly once
+        if (tid == 64) {
+            float bv = s_bv[1];
+            uint32_t bi = s_bi[1];
+            for (int w2 = 2; w2 < kWaves; ++w2)
+                if (s_bv[w2] > bv || (s_bv[w2] == bv && s_bi[w2] < bi)) bv = s_bv[w2], bi = s_bi[w2];
+            p.part_val[blockIdx.x] = bv;
+            p.part_idx[blockIdx.x] = bi;
+        }
+    }
+#ifdef UZU_TIMELINE
+    // loader (thread 0): stamps 0 (entry), 1 (first slot issued), 3 (whole share landed); first consumer (thread 64): 2 (activation row
+    // in registers), 4 (out of items) -- merged through LDS into thread 0's record in tools/timeline.py's slot order
+    __shared__ unsigned long long s_tl[2];
+    if (tid == 64) s_tl[0] = tl_t[2], s_tl[1] = tl_t[4];
+    __syncthreads();
+    if (tid == 0) tl_t[2] = s_tl[0], tl_t[5] = tl_t[6] = s_tl[1], tl_t[4] = __builtin_amdgcn_s_memrealtime(); // tools/timeline.py: 4 = exit, 5 = dots done
+#endif
+    UZU_TL_FLUSH(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+static int stream_mode() { // UZU_DEC_STREAM: 0 = never, 1 (default) = the bandwidth regime, 2 = every supported shape (tests / A-B runs)
+    static const int env = [] {
+        const char* e = getenv("UZU_DEC_STREAM");
+        return e ? atoi(e) : 1;
+    }();
+    return env;
+}
+static int g_stream_override = -1;
+extern "C" void uzu_hip_debug_set_decode_stream(int mode) { g_stream_override = mode; } // -1 = environment / default
+static uint32_t* g_stream_err = nullptr;
+extern "C" uint32_t uzu_hip_debug_decode_stream_error(void) { // bit mask of bounded spins that gave up since the last call (0 = none)
+    if (!g_stream_err) return 0;
+    uint32_t v = 0;
+    (void)hipMemcpy(&v, g_stream_err, 4, hipMemcpyDeviceToHost);
+    if (v) (void)hipMemset(g_stream_err, 0, 4);
+    return v;
+}
+
+static int stream_cpl(const DecGemvParams& p) {
+    const int lpr_log2 = gemv_lpr_log2(p.k);
+    const uint32_t C = p.k / 32, lpr = 1u << lpr_log2;
+    return (int)((C + lpr - 1) / lpr);
+}
+
+bool gemv_stream_supported(const DecGemvParams& p) {
+    if (p.bits != 4 || p.b_kind != UZU_MATMUL_B_SCALE_BIAS || p.conv_w || p.dg_o) return false;
+    if (p.k % 32 || p.group_size % 32 || (p.group_size & (p.group_size - 1))) return false;
+    const uint32_t G = (p.k + p.group_size - 1) / p.group_size;
+    if (p.k % p.group_size || (G & 1)) return false; // scale rows are fetched in 4-byte units
+    const bool normed = p.norm_scales || p.norm_plain;
+    if (normed && (p.k % 1024 || p.k > 8192)) return false;
+    if (p.act_mul && (p.n[1] || (p.n[0] & 1))) return false;
+    const int cpl = stream_cpl(p);
+    if (!(cpl == 1 || cpl == 2 || cpl == 3 || cpl == 4 || cpl == 7 || cpl == 9)) return false;
+    if (normed && cpl > 4) return false;
+    for (int i = 0; i < 2; ++i) {
+        if (!p.n[i]) continue;
+        if ((uintptr_t)p.w[i] % 16 || (uintptr_t)p.scales[i] % 4 || (uintptr_t)p.biases[i] % 4) return false;
+    }
+    if ((uintptr_t)p.x % 16) return false;
+    return true;
+}
+
+bool gemv_stream_wanted(const DecGemvParams& p) {
+    const int mode = g_stream_override >= 0 ? g_stream_override : stream_mode();
+    if (mode == 0 || !gemv_stream_supported(p)) return false;
+    if (mode >= 2) return true;
+    const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
+    return weight_bytes >= (8ull << 20); // the bandwidth regime: >= 2 slots per CU
+}
+
+template <int CPL, bool ACT, int PRO>
+static uzu_status launch_stream(hipStream_t s, const DecGemvParams& p, const StreamGeo& g, uint32_t grid, size_t lds) {
+    static size_t raised_to = 0;
+    if (lds > raised_to) {
+        if (hipFuncSetAttribute((const void*)gemv_stream_kernel<CPL, ACT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("gemv_stream: %zu bytes of LDS are not available", lds);
+            return UZU_ERR_UNSUPPORTED;
+        }
+        raised_to = lds;
+    }
+    return launch_check([&] { hipLaunchKernelGGL((gemv_stream_kernel<CPL, ACT, PRO>), dim3(grid), dim3(64 * kWaves), lds, s, p, g); }, "gemv_stream");
+}
+template <int CPL> static uzu_status launch_stream_c(hipStream_t s, const DecGemvParams& p, const StreamGeo& g, uint32_t grid, size_t lds) {
+    const bool normed = p.norm_scales || p.norm_plain;
+    if constexpr (CPL <= 4) {
+        if (normed) return p.act_mul ? launch_stream<CPL, true, 1>(s, p, g, grid, lds) : launch_stream<CPL, false, 1>(s, p, g, grid, lds);
+    }
+    return p.act_mul ? launch_stream<CPL, true, 0>(s, p, g, grid, lds) : launch_stream<CPL, false, 0>(s, p, g, grid, lds);
+}
+
+uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint32_t* grid_out) {
+    DecGemvParams p = p_in;
+#ifdef UZU_TIMELINE
+    p.tl = timeline_next_slot();
+#endif
+    if (!gemv_stream_supported(p)) {
+        set_error("gemv_stream: unsupported shape (bits %u, k %u, group %u)", p.bits, p.k, p.group_size);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    if (!g_stream_err) {
+        UZU_HIP_TRY(hipMalloc((void**)&g_stream_err, 256));
+        UZU_HIP_TRY(hipMemset(g_stream_err, 0, 256));
+    }
+    const bool act = p.act_mul != 0, normed = p.norm_scales || p.norm_plain;
+    const int cpl = stream_cpl(p);
+    const int nphys = act ? 2 : 1;
+    StreamGeo g{};
+    g.lpr_log2 = (uint32_t)gemv_lpr_log2(p.k);
+    const uint32_t rpw = 64u >> g.lpr_log2;
+    const uint32_t rr = act ? (cpl >= 2 ? 1u : 2u) : (cpl >= 3 ? 1u : (cpl == 2 ? 2u : 4u));
+    const uint32_t item_rows = rr * rpw;
+    const uint32_t row_bytes = p.k / 2, G = p.k / p.group_size;
+    static const uint32_t slot_target = [] { // UZU_STREAM_SLOT_KB: bytes of codes per slot (A/B runs)
+        const char* e = getenv("UZU_STREAM_SLOT_KB");
+        return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 16) << 10;
+    }();
+    uint32_t items = slot_target / (nphys * item_rows * row_bytes);
+    if (items < 1) items = 1;
+    g.items_per_slot = items;
+    g.rows_per_slot = items * item_rows;
+    g.chunk_stride = (g.rows_per_slot * row_bytes + 1023) / 1024 * 1024;
+    g.sb_stride = (g.rows_per_slot * G * 2 + 255) / 256 * 256;
+    g.off_scales = nphys * g.chunk_stride;
+    g.off_biases = g.off_scales + nphys * g.sb_stride;
+    g.slot_bytes = g.off_biases + nphys * g.sb_stride;
+    g.ops_per_slot = nphys * (g.chunk_stride / 1024 + 2 * (g.sb_stride / 256));
+    static const int depth_env = [] {
+        const char* e = getenv("UZU_STREAM_DEPTH");
+        return e ? atoi(e) : 2;
+    }();
+    g.depth = (depth_env >= 2 && 2 * g.ops_per_slot <= 62) ? 2 : 1;
+    if (g.ops_per_slot > 62) {
+        set_error("gemv_stream: %u VMEM operations per slot exceed the vmcnt range", g.ops_per_slot);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    const size_t xs_bytes = normed ? ((size_t)(p.k / 32) * 36 + 16) * sizeof(float) : 0;
+    const size_t lds_budget = 160u * 1024 - 2048; // static LDS of the kernel (flags, tables) + margin
+    uint32_t ring = (uint32_t)((lds_budget - xs_bytes) / g.slot_bytes);
+    static const uint32_t ring_cap = [] {
+        const char* e = getenv("UZU_STREAM_RING");
+        return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : (int)kMaxRing);
+    }();
+    if (ring > ring_cap) ring = ring_cap;
+    if (ring > kMaxRing) ring = kMaxRing;
+    if (ring < g.depth + 2) {
+        set_error("gemv_stream: a ring of %u slots of %u bytes is too short", ring, g.slot_bytes);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    g.ring_slots = ring;
+    const uint32_t n_log0 = act ? p.n[0] / 2 : p.n[0];
+    g.slots0 = (n_log0 + g.rows_per_slot - 1) / g.rows_per_slot;
+    g.slots1 = (p.n[1] + g.rows_per_slot - 1) / g.rows_per_slot;
+    g.xs_off = ring * g.slot_bytes;
+    g.err = g_stream_err;
+    const uint32_t T = g.slots0 + g.slots1;
+    uint32_t grid = T < (uint32_t)num_cus ? T : (uint32_t)num_cus;
+    if (p.part_val && p.part_capacity && grid > p.part_capacity) grid = p.part_capacity;
+    if (grid_out) *grid_out = grid;
+    const size_t lds = (size_t)ring * g.slot_bytes + xs_bytes;
+    switch (cpl) {
+    case 1: return launch_stream_c<1>(s, p, g, grid, lds);
+    case 2: return launch_stream_c<2>(s, p, g, grid, lds);
+    case 3: return launch_stream_c<3>(s, p, g, grid, lds);
+    case 4: return launch_stream_c<4>(s, p, g, grid, lds);
+    case 7: return launch_stream_c<7>(s, p, g, grid, lds);
+    default: return launch_stream_c<9>(s, p, g, grid, lds);
+    }
+}
+
+} // namespace k
+} // namespace uzu

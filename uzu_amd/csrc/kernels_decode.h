@@ -86,6 +86,11 @@ struct DecGemvParams {
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
+// The weight-streaming engine (k_stream.hip): LDS-DMA loader wave + consumer waves per CU; same arithmetic as gemv_dec.  gemv_dec
+// routes to it when gemv_stream_wanted (bandwidth regime, int4 ScaleBias, UZU_DEC_STREAM / uzu_hip_debug_set_decode_stream).
+bool gemv_stream_supported(const DecGemvParams& p);
+bool gemv_stream_wanted(const DecGemvParams& p);
+uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
 // Embedding row of the token the commit kernel has just sampled (the next decode step's input row): the lookup of
 // quant_embedding.rs:36-116 / full_precision_embedding.rs:17-31 for one token, done by the committing workgroup instead
 // of a launch of its own at the head of the next step.  `output` null => plain commit.
