@@ -861,7 +861,10 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint3
             set_error("gemv_dec: weight matrix of %u x %u exceeds 4 GiB", p.n[i], p.k);
             return UZU_ERR_UNSUPPORTED;
         }
-    if (gemv_stream_wanted(p)) return gemv_stream(s, p_in, num_cus, grid_out); // bandwidth regime: LDS-staged weight stream (k_stream.hip)
+    if (gemv_stream_wanted(p)) { // bandwidth regime: LDS-staged weight stream (k_stream.hip); a geometry it does not cover falls through
+        const uzu_status st = gemv_stream(s, p_in, num_cus, grid_out);
+        if (st != UZU_ERR_UNSUPPORTED) return st;
+    }
     int lpr_log2, R;
     bool wide = false;
     const uint32_t want = gemv_dec_plan(p, num_cus, &lpr_log2, &R, &wide);
