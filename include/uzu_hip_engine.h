@@ -130,9 +130,13 @@ uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uin
  * Used by bench.py for the per-kernel roofline of the dominant kernel. */
 uzu_status uzu_hip_model_profile_decode_step(uzu_hip_model* m, uint32_t capacity, const char** names, uint64_t* bytes, float* ms,
                                              uint32_t* count);
-/* Diagnostic switch: route every matmul through the reference-order kernel (one thread per output, the
- * reference CPU loop order) so that results can be compared BIT-EXACTLY with the CPU path.  Also enabled by
- * the environment variable UZU_HIP_EXACT=1.  Slow; never used for measurements. */
+/* Reference-ORDER mode (diagnostic; also UZU_HIP_EXACT=1): every reduction kernel of the forward path -- matmul, Normalization,
+ * QKVNorm, attention single / two pass, DeltaNet update / prefill / norm-gate -- runs one thread per reduction in the reference CPU
+ * kernel's loop order (csrc/k_exact.hip, k_matmul.hip::matmul_ref_kernel); the fused decode kernels, the matrix-core GEMMs /
+ * attention, the chunked DeltaNet scan and the LDS weight stream are bypassed and decode runs eagerly.  A forward pass then
+ * reproduces the CPU backend BIT FOR BIT (tests/test_gpu_model.py::test_exact_mode_*): what separates "reduction order" from real
+ * defects.  Slow by construction; never used for measurements.  uzu_hip_set_exact_matmul is the older name of the same switch. */
+void uzu_hip_set_exact(int32_t enabled);
 void uzu_hip_set_exact_matmul(int32_t enabled);
 /* Number of kernel launches / graph nodes of one decode step (reported by bench.py). */
 uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m);

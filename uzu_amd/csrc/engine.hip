@@ -905,7 +905,8 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
     return UZU_OK;
 }
 
-bool decode_is_fused(const uzu_hip_model* m) { return m->fusable && !(m->flags & UZU_MODEL_NO_FUSION); }
+// (the reference-order mode runs the one-kernel-per-reference-kernel path, eagerly: its kernels take scratch from the stream workspace)
+bool decode_is_fused(const uzu_hip_model* m) { return m->fusable && !(m->flags & UZU_MODEL_NO_FUSION) && !k::exact_mode(); }
 
 // eager decode step; keeps `hidden_ready` in step with what the step left behind
 uzu_status encode_decode(uzu_hip_model* m, hipStream_t s) {
@@ -945,7 +946,7 @@ uzu_status enqueue_decode(uzu_hip_model* m, uint32_t steps) {
     for (uint32_t i = 0; i < steps; ++i) {
         UZU_REQUIRE(m->context_length + 1 <= m->d.max_context_length, "decode: context length %u exceeds max_context_length %u", m->context_length + 1,
                     m->d.max_context_length);
-        if (m->flags & UZU_MODEL_NO_GRAPH) {
+        if ((m->flags & UZU_MODEL_NO_GRAPH) || k::exact_mode()) {
             UZU_PROPAGATE(encode_decode(m, m->ctx->stream));
         } else {
             const bool two = m->context_length + 1 > 1024;
@@ -1329,7 +1330,7 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
     if (!steps) return UZU_OK;
     // make sure graph construction is not inside the timed region
     drop_stale_graphs(m);
-    if (!(m->flags & UZU_MODEL_NO_GRAPH)) {
+    if (!(m->flags & UZU_MODEL_NO_GRAPH) && !k::exact_mode()) {
         if (m->context_length + 1 <= 1024 && !m->graph_single) UZU_PROPAGATE(build_decode_graph(m, &m->graph_single, false));
         if (m->context_length + steps > 1024 && !m->graph_two) UZU_PROPAGATE(build_decode_graph(m, &m->graph_two, true));
     }

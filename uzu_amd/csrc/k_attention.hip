@@ -16,36 +16,10 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+#include "attention_mask.h"
+
 namespace uzu {
 namespace k {
-
-__device__ __forceinline__ bool should_use_key(const AttentionParams& a, uint32_t q_seq_idx, uint32_t prefix_length,
-                                               uint32_t suffix_position, uint32_t query_position, uint32_t i) {
-    bool use_key = true;
-    uint32_t key_position;
-    if (i >= prefix_length) {
-        const uint32_t key_position_in_suffix = i - prefix_length;
-        key_position = suffix_position + key_position_in_suffix;
-        if (a.is_causal) use_key &= key_position_in_suffix <= q_seq_idx;
-    } else {
-        if (a.is_kv_cache_ring) {
-            key_position = (prefix_length + i - a.ring_offset) % prefix_length;
-            use_key &= key_position < a.ring_length;
-        } else {
-            key_position = i;
-        }
-    }
-    if (a.is_sliding_window) {
-        const uint32_t w = a.sliding_window_size;
-        if (a.is_causal)
-            use_key &= key_position <= query_position && (query_position - key_position) < w;
-        else if (key_position <= query_position)
-            use_key &= (query_position - key_position) <= w / 2;
-        else
-            use_key &= (key_position - query_position) <= w / 2;
-    }
-    return use_key;
-}
 
 template <class T> __device__ __forceinline__ void load8(const T* p, float (&f)[8]);
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&f)[8]) {
@@ -248,6 +222,7 @@ static uzu_status check_attention(const AttentionParams& a) {
 uzu_status attention_single_pass(hipStream_t s, const AttentionParams& a, void* out) {
     if (!a.suffix_length || !a.num_heads) return UZU_OK;
     UZU_PROPAGATE(check_attention(a));
+    if (exact_mode()) return attention_single_pass_exact(s, a, out);
     if (attention_prefill_mfma_supported(a)) return attention_prefill_mfma(s, a, out); // prefill-sized causal tiles
     return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status { return dispatch_hd<T>(s, a, 1, -INFINITY, out, nullptr, nullptr, nullptr); });
 }
@@ -255,6 +230,7 @@ uzu_status attention_single_pass(hipStream_t s, const AttentionParams& a, void* 
 uzu_status attention_two_pass1(hipStream_t s, const AttentionParams& a, float* partials, float* sums, float* maxs) {
     if (!a.suffix_length || !a.num_heads) return UZU_OK;
     UZU_PROPAGATE(check_attention(a));
+    if (exact_mode()) return attention_two_pass1_exact(s, a, partials, sums, maxs);
     return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status { return dispatch_hd<T>(s, a, 32, -1e9f, nullptr, partials, sums, maxs); });
 }
 
@@ -287,6 +263,7 @@ uzu_status attention_two_pass2(hipStream_t s, const float* partials, const float
                                uint32_t dt, uint32_t head_dim, uint32_t num_heads, uint32_t suffix_length) {
     const uint32_t rows = num_heads * suffix_length;
     if (!rows) return UZU_OK;
+    if (exact_mode()) return attention_two_pass2_exact(s, partials, sums, maxs, out, dt, head_dim, num_heads, suffix_length);
     return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
         return launch_check([&] {
             hipLaunchKernelGGL((attention_two_pass2_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, partials, sums, maxs, (T*)out, head_dim, rows);

@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
 }
 
 bool attention_prefill_mfma_supported(const AttentionParams& a) {
+    if (exact_mode()) return false; // reference-order mode: the scalar-order kernels of k_exact.hip
     static const uint32_t min_m = [] {
         const char* e = getenv("UZU_ATTN_MFMA_MIN_M");
         return e ? (uint32_t)atoi(e) : 16u;

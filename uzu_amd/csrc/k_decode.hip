@@ -514,6 +514,17 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             compute(it, c, x, sum32(x), acc);
         }
     };
+    // GatedActMul epilogue, batched: a finished (up, gate) pair parks in the registers of lane `act_cnt` and the activation (a glibc-exact
+    // expf in double precision: ~150 instructions) runs once per 64 pairs on all lanes instead of once per pair on one lane with 63 idle
+    // -- the VALU is what bounds these kernels once the bytes are on chip (tools/valu_rate.hip).  Same arithmetic per value.
+    float keep_up = 0.f, keep_gate = 0.f;
+    uint32_t keep_row = 0xFFFFFFFFu, act_cnt = 0;
+    auto act_flush = [&]() {
+        if constexpr (ACT) {
+            if (keep_row != 0xFFFFFFFFu) p.out[0][keep_row] = f32_to_bf16(round_bf16(keep_up * act_bf16(p.act_type, keep_gate, s_exp_tab))); // gated_act_mul/mod.rs:5-12
+            keep_row = 0xFFFFFFFFu, act_cnt = 0;
+        }
+    };
     auto finish = [&](uint32_t b, float (&acc)[R][NPHYS], const ConvPre (&cp)[CONV ? R : 1]) {
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
@@ -523,17 +534,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             const float v0 = row_sum_rt(acc[r][0], lpr);
             const float v1 = ACT ? row_sum_rt(acc[r][NPHYS - 1], lpr) : 0.f;
             const uint32_t lrow = lb * rows_per_batch + r * rpw + rsub;
-            if (sl == 0 && lrow < nl) {
+            if constexpr (ACT) {
+                // every lane of a row's group holds the row sums; MatmulKernel epilogue with ab_scale = 1 (kernel.rs:281-292), rounded to bf16
+                float value = 1.0f * v0, gate = 1.0f * v1;
+                if (p.out_bias[0] && lrow < nl) value += bf16_to_f32(p.out_bias[0][lrow]), gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
+                const float up_b = round_bf16(value), gate_b = round_bf16(gate);
+                for (int gsub = 0; gsub < rpw; ++gsub) { // the rpw rows of this pass go to lanes act_cnt .. act_cnt + rpw - 1
+                    const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, up_b), gsub << lpr_log2));
+                    const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gate_b), gsub << lpr_log2));
+                    const uint32_t row_g = lb * rows_per_batch + r * rpw + (uint32_t)gsub;
+                    if ((uint32_t)lane == act_cnt + (uint32_t)gsub && row_g < nl) keep_up = u, keep_gate = g2, keep_row = row_g;
+                }
+                act_cnt += (uint32_t)rpw;
+                if (act_cnt + (uint32_t)rpw > 64u) act_flush();
+            } else if (sl == 0 && lrow < nl) {
                 // MatmulKernel epilogue with ab_scale = 1, no accumulate / soft-cap (kernel.rs:281-292)
                 float value = 1.0f * v0;
                 if (p.out_bias[mat]) value += bf16_to_f32(p.out_bias[mat][lrow]);
-                if (ACT) {
-                    float gate = 1.0f * v1;
-                    if (p.out_bias[0]) gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
-                    const float up_b = round_bf16(value), gate_b = round_bf16(gate);
-                    // GatedActMul (gated_act_mul/mod.rs:5-12): (up * act(gate)) in bf16
-                    p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b, s_exp_tab)));
-                } else if (CONV && mat == 0 && lrow < p.conv_dim) {
+                if (CONV && mat == 0 && lrow < p.conv_dim) {
                     // DeltaNetConvUpdate (conv_update.rs:17-55), kernel size 4, operands prefetched at batch start
                     float* st_row = p.conv_state + (size_t)lrow * 3;
                     const float xin = round_bf16(value);
@@ -619,6 +637,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             if (b < num_batches) b = batch(b, itB, itA, std::false_type{});
         }
     }
+    act_flush();
     UZU_TL_STAMP(3);
     if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
         __shared__ float sv[NW];

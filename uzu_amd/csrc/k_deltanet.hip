@@ -134,6 +134,7 @@ uzu_status delta_net_update(hipStream_t s, const uint16_t* in_proj, const float*
                             const float* norm_weight, float* state, uint16_t* out, uint32_t num_v_heads,
                             uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim,
                             uint32_t value_dim, float norm_epsilon) {
+    if (exact_mode()) return delta_net_update_exact(s, in_proj, a_log, dt_bias, norm_weight, state, out, num_v_heads, num_k_heads, head_k_dim, head_v_dim, key_dim, value_dim, norm_epsilon);
     if (head_k_dim != 128 || head_v_dim > 512 || head_v_dim < 8 || (head_v_dim & (head_v_dim - 1)) || num_k_heads == 0 || num_v_heads % num_k_heads) {
         set_error("delta_net_update: needs head_k_dim == 128, head_v_dim a power of two in [8, 512], Hv %% Hk == 0");
         return UZU_ERR_UNSUPPORTED;
@@ -329,6 +330,7 @@ uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const 
                                   float* q_norm_out, float* k_norm_out, float* beta_out, float* decay_out,
                                   uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim,
                                   uint32_t value_dim, uint32_t suffix_len) {
+    if (exact_mode()) return delta_net_prefill_prep_exact(s, in_proj, a_log, dt_bias, q_norm_out, k_norm_out, beta_out, decay_out, num_v_heads, num_k_heads, head_k_dim, key_dim, value_dim, suffix_len);
     if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads || num_v_heads / num_k_heads > 64) {
         set_error("delta_net_prefill_prep: needs head_k_dim == 128 and Hv/Hk <= 64");
         return UZU_ERR_UNSUPPORTED;
@@ -501,6 +503,7 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
                              const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
                              uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim,
                              uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
+    if (exact_mode()) return delta_net_prefill_exact(s, q_norm, k_norm, beta, decay, in_proj, state, out, num_v_heads, num_k_heads, head_k_dim, head_v_dim, key_dim, value_dim, suffix_len);
     if (head_k_dim != 128 || num_k_heads == 0 || num_v_heads % num_k_heads || head_v_dim % DNP_ROWS) {
         set_error("delta_net_prefill: needs head_k_dim == 128 and head_v_dim %% 8 == 0");
         return UZU_ERR_UNSUPPORTED;
@@ -547,6 +550,7 @@ uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* 
                                uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len) {
     const uint32_t waves = suffix_len * num_v_heads;
     if (!waves) return UZU_OK;
+    if (exact_mode()) return delta_net_norm_gate_exact(s, in_out, in_proj, norm_weight, num_v_heads, head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
     return launch_check([&] {
         hipLaunchKernelGGL(delta_net_norm_gate_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in_out, in_proj, norm_weight, num_v_heads,
                            head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);

@@ -552,6 +552,7 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_
 }
 
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
+    if (exact_mode()) return false; // reference-order mode: the token-by-token recurrence in the reference's own loop order (k_exact.hip)
     static const uint32_t min_t = [] {
         const char* e = getenv("UZU_DN_CHUNK_MIN_T");
         return e ? (uint32_t)atoi(e) : 64u;

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
 
 uzu_status normalization(hipStream_t s, const NormParams& p) {
     if (p.batch_size == 0) return UZU_OK;
+    if (exact_mode()) return normalization_exact(s, p);
     return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
         if (p.affine_dt == UZU_F32)
             return launch_check([&] { hipLaunchKernelGGL((normalization_kernel<T, float>), dim3(p.batch_size), dim3(256), 0, s, p); }, "normalization");
@@ -116,6 +117,7 @@ uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, 
                     uint32_t head_count, uint32_t full_layer) {
     const uint32_t waves = batch_size * head_count;
     if (!waves) return UZU_OK;
+    if (exact_mode()) return qkv_norm_exact(s, qkv, dt, scales, batch_size, total_heads, head_dim, epsilon, scale_offset, head_offset, head_count, full_layer);
     return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
         return launch_check([&] {
             hipLaunchKernelGGL((qkv_norm_kernel<T>), dim3((waves + 3) / 4), dim3(256), 0, s, (T*)qkv, scales, batch_size,

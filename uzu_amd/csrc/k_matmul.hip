@@ -219,7 +219,7 @@ static uzu_status launch_gemv(hipStream_t s, const MatmulParams& p, int num_cus,
 }
 
 static int g_exact = -1;
-static bool exact_mode() {
+bool exact_mode() {
     if (g_exact < 0) {
         const char* e = getenv("UZU_HIP_EXACT");
         g_exact = (e && e[0] == '1') ? 1 : 0;
@@ -306,3 +306,5 @@ uzu_status matmul_full_precision(hipStream_t s, const MatmulParams& p, uint32_t 
 } // namespace uzu
 
 extern "C" void uzu_hip_set_exact_matmul(int32_t enabled) { uzu::k::set_exact_matmul(enabled != 0); }
+// the whole reference-order mode: every reduction kernel, not only the matmul (same switch; the older name is kept)
+extern "C" void uzu_hip_set_exact(int32_t enabled) { uzu::k::set_exact_matmul(enabled != 0); }

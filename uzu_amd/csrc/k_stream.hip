@@ -402,6 +402,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(DecGemvParams p, S
                     }
             }
         };
+        float keep_up = 0.f, keep_gate = 0.f;
+        uint32_t keep_row = 0xFFFFFFFFu, act_cnt = 0;
+        auto act_flush = [&]() {
+            if constexpr (ACT) {
+                if (keep_row != 0xFFFFFFFFu) p.out[0][keep_row] = f32_to_bf16(round_bf16(keep_up * act_bf16(p.act_type, keep_gate, s_exp_tab))); // gated_act_mul/mod.rs:5-12
+                keep_row = 0xFFFFFFFFu, act_cnt = 0;
+            }
+        };
         auto compute_item = [&](uint32_t item, const Buf& bf) {
             const uint32_t t = item / g.items_per_slot, it_in_slot = item % g.items_per_slot;
             const uint32_t gs = blockIdx.x + t * gridDim.x;
@@ -430,16 +438,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(DecGemvParams p, S
                 const float v0 = row_sum_rt(acc[0], lpr);
                 const float v1 = ACT ? row_sum_rt(acc[NPHYS - 1], lpr) : 0.f;
                 const uint32_t lrow = ls * R + it_in_slot * item_rows + rr * rpw + rsub;
-                if (sl == 0 && lrow < nl) {
+                if constexpr (ACT) {
+                    // batched GatedActMul (see gemv_dec): the pair parks in lane act_cnt, the activation runs once per 64 pairs
+                    float value = 1.0f * v0, gate = 1.0f * v1;
+                    if (p.out_bias[0] && lrow < nl) value += bf16_to_f32(p.out_bias[0][lrow]), gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
+                    const float up_b = round_bf16(value), gate_b = round_bf16(gate);
+                    for (int gsub = 0; gsub < rpw; ++gsub) {
+                        const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, up_b), gsub << g.lpr_log2));
+                        const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gate_b), gsub << g.lpr_log2));
+                        const uint32_t row_g = ls * R + it_in_slot * item_rows + rr * rpw + (uint32_t)gsub;
+                        if ((uint32_t)lane == act_cnt + (uint32_t)gsub && row_g < nl) keep_up = u, keep_gate = g2, keep_row = row_g;
+                    }
+                    act_cnt += (uint32_t)rpw;
+                    if (act_cnt + (uint32_t)rpw > 64u) act_flush();
+                } else if (sl == 0 && lrow < nl) {
                     // MatmulKernel epilogue with ab_scale = 1, no accumulate / soft-cap (kernel.rs:281-292)
                     float value = 1.0f * v0;
                     if (p.out_bias[mat]) value += bf16_to_f32(p.out_bias[mat][lrow]);
-                    if (ACT) {
-                        float gate = 1.0f * v1;
-                        if (p.out_bias[0]) gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
-                        const float up_b = round_bf16(value), gate_b = round_bf16(gate);
-                        p.out[0][lrow] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b, s_exp_tab))); // gated_act_mul/mod.rs:5-12
-                    } else {
+                    {
                         const uint16_t ob = f32_to_bf16(value);
                         if (p.out_f32) p.out_f32[lrow] = value;
                         else p.out[mat][lrow] = ob;
@@ -493,6 +509,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(DecGemvParams p, S
                 compute_item(cur, buf);
             }
         }
+        act_flush();
         if (cw == 0) UZU_TL_STAMP(4); // this consumer has run out of items
         if (p.part_val) { // UnifiedSampling (greedy) pass 1: one (value, index) partial per workgroup
             for (int off = 32; off > 0; off >>= 1) {
@@ -576,7 +593,7 @@ bool gemv_stream_supported(const DecGemvParams& p) {
 
 bool gemv_stream_wanted(const DecGemvParams& p) {
     const int mode = g_stream_override >= 0 ? g_stream_override : stream_mode();
-    if (mode == 0 || !gemv_stream_supported(p)) return false;
+    if (mode == 0 || exact_mode() || !gemv_stream_supported(p)) return false;
     if (mode >= 2) return true;
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
     return weight_bytes >= (8ull << 20); // the bandwidth regime: >= 2 slots per CU

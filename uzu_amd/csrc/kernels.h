@@ -187,6 +187,28 @@ uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* 
                                uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
                                uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
 
+// ---------------------------------------------------------------- reference-order mode (k_exact.hip, k_matmul.hip::matmul_ref_kernel)
+// UZU_HIP_EXACT=1 / uzu_hip_set_exact(1): every reduction kernel (matmul, Normalization, QKVNorm, attention, DeltaNet) runs one thread
+// per reduction in the reference's loop order => a forward pass reproduces the CPU backend bit for bit.  The launchers above route to
+// these themselves; the fused / matrix-core / streaming variants report "not supported" while the mode is on.
+bool exact_mode();
+void set_exact_matmul(bool enabled);
+uzu_status normalization_exact(hipStream_t s, const NormParams& p);
+uzu_status qkv_norm_exact(hipStream_t s, void* qkv, uint32_t dt, const float* scales, uint32_t batch_size, uint32_t total_heads, uint32_t head_dim, float epsilon,
+                          float scale_offset, uint32_t head_offset, uint32_t head_count, uint32_t full_layer);
+uzu_status attention_single_pass_exact(hipStream_t s, const AttentionParams& a, void* out);
+uzu_status attention_two_pass1_exact(hipStream_t s, const AttentionParams& a, float* partials, float* sums, float* maxs);
+uzu_status attention_two_pass2_exact(hipStream_t s, const float* partials, const float* sums, const float* maxs, void* out, uint32_t dt, uint32_t head_dim, uint32_t num_heads,
+                                     uint32_t suffix_length);
+uzu_status delta_net_update_exact(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, const float* norm_weight, float* state, uint16_t* out,
+                                  uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, float norm_epsilon);
+uzu_status delta_net_prefill_prep_exact(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* beta_out,
+                                        float* decay_out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+uzu_status delta_net_prefill_exact(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
+                                   uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+uzu_status delta_net_norm_gate_exact(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight, uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim,
+                                     uint32_t conv_dim, uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
+
 // ---------------------------------------------------------------- engine helpers
 uzu_status advance_u32(hipStream_t s, uint32_t* counter, uint32_t amount); // *counter += amount
 uzu_status fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, uint32_t count);
