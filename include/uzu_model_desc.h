@@ -123,6 +123,9 @@ typedef struct {
     uzu_linear_desc out_projection;  /* k = heads*head_dim */
     uzu_norm_desc query_norm;        /* scales f32 [head_dim] */
     uzu_norm_desc key_norm;
+    uint32_t sliding_window_size;    /* 0 = none; causal + window => the ring KV state of mixer/attention/state.rs:20-106 */
+    uint32_t has_sinks;
+    const void* sinks;               /* bf16 [heads] (mixer.sinks, mixer/attention/mod.rs:162-165) or NULL */
 
     /* --- gated delta net (config/token_mixer/delta_net.rs) --- */
     uint32_t dn_num_heads;      /* value heads Hv */

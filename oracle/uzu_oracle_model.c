@@ -29,7 +29,8 @@
 typedef struct {
     uint16_t* keys;   /* bf16 [max_ctx + 1024, kv_heads*hd] */
     uint16_t* values;
-    uint32_t length;  /* AttentionStateType::Full { length } */
+    uint32_t length;  /* AttentionStateType::Full { length } | Ring { length } */
+    uint32_t ring_offset, ring_max; /* AttentionStateType::Ring { offset, .., max_length } (ring_max == 0: Full), state.rs:16-55 */
     float* conv_state; /* f32 [conv_dim, k-1] */
     float* ssm_state;  /* f32 [Hv, Dv, Dk] */
 } layer_state;
@@ -62,10 +63,13 @@ orc_model* orc_model_create(const uzu_model_desc* desc) {
     m->states = (layer_state*)xcalloc(desc->num_layers, sizeof(layer_state));
     m->layer_outputs = (uint16_t**)xcalloc(desc->num_layers, sizeof(uint16_t*));
     m->final_hidden = (uint16_t*)xcalloc(desc->model_dim, 2);
-    const size_t max_elements = (size_t)desc->max_context_length + ATTENTION_SUFFIX_CAPACITY;
     for (uint32_t l = 0; l < desc->num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
         if (L->mixer_kind == UZU_MIXER_ATTENTION) {
+            /* AttentionState::create_empty (state.rs:69-136): causal + sliding window => Ring with max_length = the window */
+            const size_t max_prefix = L->sliding_window_size ? L->sliding_window_size : desc->max_context_length;
+            const size_t max_elements = max_prefix + ATTENTION_SUFFIX_CAPACITY;
+            m->states[l].ring_max = L->sliding_window_size;
             const size_t element_size = (size_t)L->num_groups * L->head_dim;
             m->states[l].keys = (uint16_t*)xcalloc(max_elements * element_size, 2);
             m->states[l].values = (uint16_t*)xcalloc(max_elements * element_size, 2);
@@ -85,6 +89,7 @@ void orc_model_reset(orc_model* m) {
     for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
         m->states[l].length = 0;
+        m->states[l].ring_offset = 0;
         if (L->mixer_kind == UZU_MIXER_DELTA_NET) {
             const size_t key_dim = (size_t)L->dn_num_groups * L->dn_head_dim;
             const size_t value_dim = (size_t)L->dn_num_heads * L->dn_value_head_dim;
@@ -119,12 +124,14 @@ void orc_model_fill_synthetic_context(orc_model* m, uint32_t n) {
         const uzu_layer_desc* L = &m->layers[l];
         if (L->mixer_kind != UZU_MIXER_ATTENTION) continue;
         const size_t element_size = (size_t)L->num_groups * L->head_dim;
-        for (size_t i = 0; i < (size_t)n * element_size; ++i) {
+        const uint32_t rows = m->states[l].ring_max && n > m->states[l].ring_max ? m->states[l].ring_max : n; /* a ring holds its window */
+        for (size_t i = 0; i < (size_t)rows * element_size; ++i) {
             const uint32_t h = (uint32_t)(i * 2654435761u + l * 40503u);
             m->states[l].keys[i] = (uint16_t)(0x3C00u + (h >> 26));           /* bf16 in [0.0078, 0.0156) */
             m->states[l].values[i] = (uint16_t)(0xBC00u + ((h >> 20) & 63u)); /* small negative values */
         }
-        m->states[l].length = n;
+        m->states[l].length = rows;
+        if (m->states[l].ring_max && n > m->states[l].ring_max) m->states[l].ring_offset = (n - m->states[l].ring_max) % m->states[l].ring_max;
     }
     m->context_length = n;
 }
@@ -219,7 +226,9 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     /* prepare_kv_and_queries (mode.rs:200-232): kv_token_offset = physical_prefix_length */
     uint16_t* queries = (uint16_t*)xcalloc((size_t)nq * batch * hd, 2);
     const uint32_t rope_dim = L->use_rope ? m->desc.rope.head_dim : 0;
-    orc_attention_prepare(qkv, queries, st->keys, st->values, cosines, sines, nq, nkv, hd, rope_dim, st->length, batch, 1);
+    /* kv_token_offset = state_type.physical_prefix_length(): the length of a Full cache, max_length of a Ring (state.rs:26-37) */
+    const uint32_t physical_prefix = st->ring_max ? st->ring_max : st->length;
+    orc_attention_prepare(qkv, queries, st->keys, st->values, cosines, sines, nq, nkv, hd, rope_dim, physical_prefix, batch, 1);
     free(qkv);
     /* AttentionCores::encode (core/mod.rs:81-93) */
     orc_attention_args a;
@@ -230,7 +239,12 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     a.dtype = ORC_BF16;
     a.head_dim = hd;
     a.gqa_factor = nq / nkv;
-    a.sequence_length = st->length + batch;
+    a.sequence_length = physical_prefix + batch; /* core/single_pass.rs:60 */
+    if (st->ring_max) { /* ring_params (state.rs:39-54), sliding window (core/mod.rs:17-28) */
+        a.is_kv_cache_ring = 1, a.ring_offset = st->ring_offset, a.ring_length = st->length;
+        a.is_sliding_window = 1, a.sliding_window_size = L->sliding_window_size;
+    }
+    if (L->has_sinks) a.sinks = L->sinks;
     a.k_head_stride = hd;
     a.k_seq_stride = nkv * hd;
     a.v_head_stride = hd;
@@ -240,7 +254,7 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     a.suffix_length = batch;
     a.is_causal = 1;
     uint16_t* out = (uint16_t*)xcalloc((size_t)batch * nq * hd, 2);
-    if (st->length + batch > 1024) {
+    if (physical_prefix + batch > 1024) { /* core/mod.rs:89-92 */
         const size_t rows = (size_t)batch * nq;
         float* partials = (float*)xcalloc(rows * 32 * hd, 4);
         float* sums = (float*)xcalloc(rows * 32, 4);
@@ -390,9 +404,24 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
     orc_argmax(logits, ORC_BF16, &token, D->vocab_size, 1);
     if (logits_out) memcpy(logits_out, logits, (size_t)D->vocab_size * 2);
     free(logits);
-    /* encode_accept: flat full accept on a Full cache */
-    for (uint32_t l = 0; l < D->num_layers; ++l)
-        if (m->layers[l].mixer_kind == UZU_MIXER_ATTENTION) m->states[l].length += count;
+    /* encode_accept (state.rs:174-236), flat full accept: nothing to copy on a Full cache; a Ring takes the suffix rows in order */
+    for (uint32_t l = 0; l < D->num_layers; ++l) {
+        if (m->layers[l].mixer_kind != UZU_MIXER_ATTENTION) continue;
+        layer_state* st = &m->states[l];
+        if (!st->ring_max) {
+            st->length += count;
+            continue;
+        }
+        orc_copy* copies = (orc_copy*)xcalloc(count, sizeof(orc_copy));
+        for (uint32_t idx = 0; idx < count; ++idx) {
+            copies[idx].source = st->ring_max + idx;
+            copies[idx].destination = (st->ring_offset + st->length) % st->ring_max;
+            if (st->length < st->ring_max) st->length += 1;
+            else st->ring_offset = (st->ring_offset + 1) % st->ring_max;
+        }
+        orc_kv_cache_update(st->keys, st->values, ORC_BF16, copies, count, m->layers[l].num_groups * m->layers[l].head_dim);
+        free(copies);
+    }
     m->context_length += count;
     return token;
 }

@@ -49,8 +49,10 @@ template <int N> __device__ __forceinline__ void merge_state(float& m, float& l,
 
 // grid: (kv_head * head_subgroups + sub, block, q_seq_idx); 256 threads
 template <class T, int HD, int GS>
-__global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a, uint32_t num_blocks, float init_max,
+__global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a_in, uint32_t num_blocks, float init_max,
                                                               T* out, float* partials, float* sums, float* maxs) {
+    AttentionParams a = a_in;
+    attention_resolve_dyn(a); // context length / ring parameters from device memory (graph replay)
     constexpr int LPK = HD / 8;  // lanes per key
     constexpr int KG = 64 / LPK; // key groups per wave
     constexpr int NGRP = 4 * KG; // key groups per workgroup
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a,
     const uint32_t kv_head_idx = blockIdx.x / subs, sub = blockIdx.x % subs;
     const uint32_t head0 = kv_head_idx * a.gqa_factor + sub * GS;
     const uint32_t block_idx = blockIdx.y, q_seq_idx = blockIdx.z;
-    const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
+    const uint32_t sequence_length = a.sequence_length;
     const uint32_t prefix_length = sequence_length - a.suffix_length;
     const uint32_t suffix_position = a.is_kv_cache_ring ? a.ring_length : prefix_length;
     const uint32_t query_position = suffix_position + q_seq_idx;

@@ -133,10 +133,11 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ queries, uint16_t* __restrict__ keys,
     uint16_t* __restrict__ values, const float* __restrict__ cosines, const float* __restrict__ sines,
     uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset,
-    uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn) {
+    uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed) {
     const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
     const size_t total = (size_t)batch_dim * total_heads * head_dim;
     const uint32_t pos0 = dyn ? *dyn : 0u;
+    const uint32_t kv_row0 = kv_token_offset + (kv_rows_fixed ? 0u : pos0);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const uint32_t d = idx % head_dim;
         const uint32_t head_idx = (idx / head_dim) % total_heads;
@@ -157,10 +158,10 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
         if (is_query) {
             queries[(size_t)head_idx * batch_dim * head_dim + (size_t)batch_idx * head_dim + d] = element;
         } else if (is_key) {
-            keys[(size_t)(kv_token_offset + pos0 + batch_idx) * num_kv_heads * head_dim +
+            keys[(size_t)(kv_row0 + batch_idx) * num_kv_heads * head_dim +
                  (size_t)(head_idx - num_q_heads) * head_dim + d] = element;
         } else {
-            values[(size_t)(kv_token_offset + pos0 + batch_idx) * num_kv_heads * head_dim +
+            values[(size_t)(kv_row0 + batch_idx) * num_kv_heads * head_dim +
                    (size_t)(head_idx - num_q_heads - num_kv_heads) * head_dim + d] = element;
         }
     }
@@ -168,14 +169,14 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
 uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
                              const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
                              uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
-                             uint32_t has_kv, const uint32_t* dyn) {
+                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed) {
     const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
     const size_t total = (size_t)batch_dim * total_heads * head_dim;
     if (!total) return UZU_OK;
     const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     return launch_check([&] {
         hipLaunchKernelGGL(attention_prepare_kernel, dim3(blocks), dim3(256), 0, s, qkv, queries, keys, values, cosines,
-                           sines, num_q_heads, num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn);
+                           sines, num_q_heads, num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn, kv_rows_fixed);
     }, "attention_prepare");
 }
 
@@ -221,6 +222,29 @@ uzu_status kv_cache_update(hipStream_t s, void* keys, void* values, uint32_t dt,
         if (st != UZU_OK) return st;
     }
     return UZU_OK;
+}
+
+// Ring insert = AttentionState::encode_accept on a Ring (state.rs:200-219), full flat accept, with the accepted-token count read on the device
+template <class T>
+__global__ void kv_ring_insert_kernel(T* keys, T* values, const uint32_t* accepted, uint32_t batch, uint32_t W, uint32_t element_dim) {
+    const uint32_t n = *accepted;
+    const uint32_t first = batch > W ? batch - W : 0u; // earlier suffix rows would be overwritten by later ones (sequential copies)
+    const size_t total = (size_t)(batch - first) * element_dim;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t e = idx % element_dim, i = first + (uint32_t)(idx / element_dim);
+        const size_t sidx = (size_t)(W + i) * element_dim + e, didx = (size_t)((n + i) % W) * element_dim + e;
+        keys[didx] = keys[sidx];
+        values[didx] = values[sidx];
+    }
+}
+uzu_status kv_ring_insert(hipStream_t s, void* keys, void* values, uint32_t dt, const uint32_t* accepted, uint32_t batch, uint32_t ring_window, uint32_t element_dim) {
+    if (!batch || !ring_window) return UZU_OK;
+    const size_t total = (size_t)(batch > ring_window ? ring_window : batch) * element_dim;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+        return launch_check([&] { hipLaunchKernelGGL((kv_ring_insert_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)keys, (T*)values, accepted, batch, ring_window, element_dim); },
+                            "kv_ring_insert");
+    });
 }
 
 // =============================================================== SigmoidGate (sigmoid_gate.rs:9-22)

@@ -120,9 +120,11 @@ uzu_status qkv_norm_exact(hipStream_t s, void* qkv, uint32_t dt, const float* sc
 // stride-interleaved key blocks, init max -1e9, f32 partials): one thread per (head, query[, block]); q / o live in private memory.
 constexpr uint32_t kExactMaxHeadDim = 512;
 template <class T>
-__global__ void __launch_bounds__(64) attention_exact_kernel(AttentionParams a, uint32_t num_blocks, float init_max, T* out, float* partials, float* sums, float* maxs) {
+__global__ void __launch_bounds__(64) attention_exact_kernel(AttentionParams a_in, uint32_t num_blocks, float init_max, T* out, float* partials, float* sums, float* maxs) {
+    AttentionParams a = a_in;
+    attention_resolve_dyn(a);
     const uint32_t HD = a.head_dim;
-    const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
+    const uint32_t sequence_length = a.sequence_length;
     const uint32_t prefix_length = sequence_length - a.suffix_length;
     const uint32_t suffix_position = a.is_kv_cache_ring ? a.ring_length : prefix_length;
     const size_t total = (size_t)a.num_heads * a.suffix_length * num_blocks;

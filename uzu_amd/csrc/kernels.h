@@ -77,10 +77,17 @@ uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, 
                     uint32_t head_count, uint32_t full_layer);
 
 // dyn: kv_token_offset += *dyn; cos/sin row index += *dyn (tables indexed by absolute position)
+// kv_rows_fixed: the K / V rows are kv_token_offset + batch_idx whatever *dyn says (ring state: the suffix region sits behind the ring);
+// the cos / sin row index still moves with *dyn (absolute token positions)
 uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
                              const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
                              uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
-                             uint32_t has_kv, const uint32_t* dyn);
+                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed = 0);
+// AttentionState::encode_accept on a Ring (state.rs:200-219) for a flat full accept of `batch` suffix rows, driven by the device-resident
+// count n = *accepted of tokens accepted before: suffix row idx (at ring_window + idx) -> ring slot (n + idx) % ring_window; when batch >
+// ring_window only the last ring_window rows survive (the reference's sequential copies overwrite the earlier ones)
+uzu_status kv_ring_insert(hipStream_t s, void* keys, void* values, uint32_t dt, const uint32_t* accepted, uint32_t batch, uint32_t ring_window,
+                          uint32_t element_dim);
 
 struct AttentionParams {
     const void* queries;
@@ -95,7 +102,30 @@ struct AttentionParams {
     const void* sinks;
     uint32_t num_heads, suffix_length, is_causal;
     const uint32_t* dyn;
+    // Ring KV state driven from the device-resident context length (engine; AttentionStateType::Ring, state.rs:16-55): when non-zero (with
+    // `dyn`), the prefix is a ring of `ring_window` rows and n = *dyn tokens have been accepted so far, so sequence_length = ring_window +
+    // suffix_length, ring_length = min(n, W), ring_offset = n > W ? (n - W) % W : 0 (what encode_accept's offset / length bookkeeping
+    // amounts to, state.rs:200-219) -- a replayed graph cannot carry host-side ring parameters.
+    uint32_t ring_window;
 };
+// the (sequence_length, ring_offset, ring_length) a kernel works with: `dyn` applied (host code only reads the fields)
+__host__ __device__ inline void attention_resolve_dyn(AttentionParams& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (a.dyn) {
+        const uint32_t n = *a.dyn;
+        if (a.ring_window) {
+            const uint32_t W = a.ring_window;
+            a.sequence_length = W + a.suffix_length;
+            a.is_kv_cache_ring = 1;
+            a.ring_length = n < W ? n : W;
+            a.ring_offset = n > W ? (n - W) % W : 0u;
+        } else {
+            a.sequence_length += n;
+        }
+        a.dyn = nullptr;
+    }
+#endif
+}
 uzu_status attention_single_pass(hipStream_t s, const AttentionParams& p, void* out);
 bool attention_prefill_mfma_supported(const AttentionParams& p); // k_attention_mfma.hip: causal bf16 prefill tiles on the matrix cores
 uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& p, void* out);

@@ -60,6 +60,7 @@ class LayerDesc(C.Structure):
         ("attention_scale", C.c_float), ("use_rope", C.c_uint32),
         ("qkv_projection", LinearDesc), ("gate_projection", LinearDesc), ("out_projection", LinearDesc),
         ("query_norm", NormDesc), ("key_norm", NormDesc),
+        ("sliding_window_size", C.c_uint32), ("has_sinks", C.c_uint32), ("sinks", C.c_void_p),
         ("dn_num_heads", C.c_uint32), ("dn_num_groups", C.c_uint32), ("dn_head_dim", C.c_uint32),
         ("dn_value_head_dim", C.c_uint32), ("dn_kernel_size", C.c_uint32), ("dn_norm_epsilon", C.c_float),
         ("dn_in_proj", LinearDesc), ("dn_out_proj", LinearDesc),
@@ -165,6 +166,8 @@ class LayerWeights:
     out_projection: Optional[LinearWeights] = None
     query_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
     key_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    sliding_window_size: int = 0          # 0 = full attention; causal sliding window => ring KV state (state.rs:20-106)
+    sinks: Optional[np.ndarray] = None    # bf16 bits (uint16) [num_heads] or None
     # delta net
     dn_num_heads: int = 0
     dn_num_groups: int = 0
@@ -191,6 +194,7 @@ class LayerWeights:
             int(self.use_rope),
             ld(self.qkv_projection), ld(self.gate_projection), ld(self.out_projection),
             self.query_norm.desc(), self.key_norm.desc(),
+            int(self.sliding_window_size), int(self.sinks is not None), _ptr(self.sinks),
             self.dn_num_heads, self.dn_num_groups, self.dn_head_dim, self.dn_value_head_dim, self.dn_kernel_size,
             self.dn_norm_epsilon,
             ld(self.dn_in_proj), ld(self.dn_out_proj),
