@@ -601,3 +601,63 @@ def test_exact_mode_bench_config_stream_is_identical_to_the_fixture(hip_ctx):
         hm.close()
     finally:
         _set_exact(False)
+
+
+# ------------------------------------------------------------------------------------------ sliding-window (ring KV) / sinks in the engine
+@pytest.mark.parametrize("windows,sinks,prompt_len", [([48], False, 130), ([64, 0, 32], True, 70), ([0], True, 40), ([1040], False, 1100)])
+@pytest.mark.parametrize("exact", [0, 1])
+def test_sliding_window_ring_state_and_sinks_in_the_engine(hip_ctx, windows, sinks, prompt_len, exact):
+    """Causal sliding-window attention layers keep a RING KV state (mixer/attention/state.rs:16-106, 200-219): the new rows go to the
+    suffix region behind the ring (kv_token_offset = window), the kernels see window + suffix rows with ring offset / length and the
+    sliding-window mask (mask.rs:3-61), and encode_accept moves the rows into the ring -- here with offset / length derived on the
+    device from the accepted-token count, so the decode graph replays.  Prompts longer than the window wrap the ring inside one prefill
+    chunk and across chunks (window 1040: two-pass attention, 1100-token prompt = two chunks); mixed full / windowed layers and sink
+    logits (mixer/attention/mod.rs:162-165) included.  Against the oracle with the same ring bookkeeping restated from the reference:
+    teacher-forced arg-max identical outside near-ties, logits within tolerance; in reference-order mode logits BIT-identical."""
+    cfg = S.tiny_llama(sliding_windows=windows, sinks=sinks, max_context_length=1400, seed=47)
+    steps = 10
+    if exact:
+        fn = _ffi.lib().uzu_hip_set_exact
+        fn.restype, fn.argtypes = None, [C.c_int32]
+        fn(1)
+    try:
+        o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, prompt_len, steps, teacher_forced=True)
+        if exact:
+            bundle = S.build_model(cfg)
+            prompt = S.synthetic_prompt(prompt_len, cfg.vocab_size)
+            om2 = O.OracleModel(bundle)
+            hm2 = HipModel(hip_ctx, bundle)
+            tok, lg = om2.prefill(prompt, True)
+            assert hm2.prefill(prompt) == tok and np.array_equal(hm2.read_logits(), lg), "prefill logits differ from the oracle in reference-order mode"
+            for _ in range(steps):
+                tok, lg = om2.forward([tok], True)
+                t, _ = hm2.decode(1)
+                assert np.array_equal(hm2.read_logits(), lg) and int(t[0]) == tok
+            hm2.close()
+            om2.close()
+    finally:
+        if exact:
+            fn(0)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+
+
+def test_sliding_window_model_directory_round_trip(hip_ctx, tmp_path):
+    """config.json `sliding_window_size` / `has_sinks` + the `mixer.sinks` tensor survive save -> load (the loader refused both until
+    round 3) and the loaded model runs identically."""
+    from uzu_amd import loader as L
+    cfg = S.tiny_llama(sliding_windows=[40, 0], sinks=True, seed=48)
+    bundle = S.build_model(cfg)
+    L.save_model_dir(bundle, str(tmp_path / "sw"))
+    loaded = L.load_model_dir(str(tmp_path / "sw"), max_context_length=cfg.max_context_length)
+    assert [l.sliding_window_size for l in loaded.layers] == [l.sliding_window_size for l in bundle.layers]
+    assert all(np.array_equal(a.sinks, b.sinks) for a, b in zip(loaded.layers, bundle.layers))
+    prompt = S.synthetic_prompt(90, cfg.vocab_size)
+    outs = []
+    for b in (bundle, loaded):
+        hm = HipModel(hip_ctx, b)
+        first = hm.prefill(prompt)
+        toks, _ = hm.decode(6)
+        outs.append(([first] + [int(t) for t in toks], hm.read_logits()))
+        hm.close()
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])

@@ -156,8 +156,19 @@ def test_strictness_matches_the_reference(tmp_path):
     with pytest.raises(L.UnsupportedModelError, match="mixture-of-experts"):
         L.load_model_dir(d)
     fresh()
+    # sliding windows load since round 3 (ring KV state in the engine); a non-positive window is a format error, sinks need their tensor
     edit_config(d, lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][3]["mixer_config"].update(sliding_window_size=128))
-    with pytest.raises(L.UnsupportedModelError, match="sliding-window"):
+    assert L.load_model_dir(d).layers[3].sliding_window_size == 128
+    edit_config(d, lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][3]["mixer_config"].update(sliding_window_size=0))
+    with pytest.raises(L.ModelFormatError, match="sliding_window_size must be positive"):
+        L.load_model_dir(d)
+    fresh()
+    edit_config(d, lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][3]["mixer_config"].update(has_sinks=True))
+    with pytest.raises(L.ModelFormatError, match="sinks' not found"):
+        L.load_model_dir(d)
+    fresh()
+    edit_config(d, lambda c: c["decoder_config"]["transformer_config"]["layer_configs"][3]["mixer_config"].update(logit_soft_cap=30.0))
+    with pytest.raises(L.UnsupportedModelError, match="soft-capping"):
         L.load_model_dir(d)
 
 

@@ -53,6 +53,7 @@ struct DLayer {
     DNorm pre_mixer, post_mixer, pre_mlp, post_mlp, qn, kn;
     DLinear qkv, gate, out, in_proj, out_proj, up, down;
     float *conv_w = nullptr, *conv_b = nullptr, *a_log = nullptr, *dt_bias = nullptr, *dn_norm = nullptr;
+    uint16_t* sinks = nullptr; // bf16 [heads] (has_sinks)
     uint16_t *keys = nullptr, *values = nullptr;
     float *conv_state = nullptr, *ssm_state = nullptr;
     size_t conv_state_bytes = 0, ssm_state_bytes = 0;
@@ -234,7 +235,9 @@ uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
         const uzu_layer_desc& h = m->layers[l].d;
         void* p = nullptr;
         if (h.mixer_kind == UZU_MIXER_ATTENTION) {
-            const size_t kv_bytes = (size_t)m->max_positions * h.num_groups * h.head_dim * 2;
+            // AttentionState::create_empty (state.rs:69-136): a causal sliding-window layer keeps a RING of `window` rows + the suffix region
+            const size_t kv_rows = h.sliding_window_size ? (size_t)h.sliding_window_size + kSuffixCapacity : (size_t)m->max_positions;
+            const size_t kv_bytes = kv_rows * h.num_groups * h.head_dim * 2;
             need(kv_bytes, &p), st->layers[l].keys = (uint16_t*)p;
             need(kv_bytes, &p), st->layers[l].values = (uint16_t*)p;
         } else {
@@ -548,8 +551,12 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     uint16_t* queries = m->queries + row0 * nq * hd;
     uint16_t* attn_out = m->attn_out + row0 * nq * hd;
     const uint32_t rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
-    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, 0, batch, 1,
-                               m->d_ctx_len));
+    // Ring state (causal sliding window; state.rs:16-55, mode.rs:66-78): the new rows go to the suffix region behind the ring
+    // (kv_token_offset = physical_prefix_length = window), the attention sees window + batch rows with ring parameters derived on the
+    // device from the accepted-token count, and the rows enter the ring afterwards (encode_accept, state.rs:200-219).
+    const uint32_t W = L.d.sliding_window_size;
+    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, W, batch, 1,
+                               m->d_ctx_len, W ? 1u : 0u));
     k::AttentionParams a{};
     a.queries = queries, a.keys = L.keys, a.values = L.values;
     a.dt = UZU_BF16, a.head_dim = hd, a.gqa_factor = nq / nkv;
@@ -558,8 +565,11 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
     a.num_heads = nq, a.suffix_length = batch, a.is_causal = 1;
     a.dyn = m->d_ctx_len;
-    const size_t kv_bytes = (size_t)2 * (m->context_length + batch) * nkv * hd * 2; // K and V rows read once
-    const bool two_pass = m->regime_override >= 0 ? m->regime_override == 1 : m->context_length + batch > 1024;
+    if (W) a.ring_window = W, a.is_kv_cache_ring = 1, a.is_sliding_window = 1, a.sliding_window_size = W;
+    if (L.sinks) a.sinks = L.sinks;
+    const uint32_t physical_prefix = W ? W : m->context_length; // AttentionStateType::physical_prefix_length (state.rs:26-37)
+    const size_t kv_bytes = (size_t)2 * (physical_prefix + batch) * nkv * hd * 2; // K and V rows read once
+    const bool two_pass = (m->regime_override >= 0 && !W) ? m->regime_override == 1 : physical_prefix + batch > 1024; // core/mod.rs:89-92
     if (k::attention_prefill_mfma_supported(a)) { // prefill chunk: flash-attention tiles on the matrix cores, any context length
         RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, attn_out));
     } else if (two_pass) { // core/mod.rs:89-92
@@ -568,6 +578,7 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     } else {
         RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, attn_out));
     }
+    if (W) RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
 }
 
 void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
@@ -786,6 +797,7 @@ bool model_fusable(const uzu_hip_model* m) {
             if (!linear_fusable(L.qkv) || !linear_fusable(L.out)) return false;
             if (L.d.has_gate && (!linear_fusable(L.gate) || L.gate.bits != L.qkv.bits || L.gate.group != L.qkv.group || L.gate.method != L.qkv.method)) return false;
             if (!(L.d.head_dim == 64 || L.d.head_dim == 128 || L.d.head_dim == 256)) return false;
+            if (L.d.sliding_window_size || L.d.has_sinks) return false; // ring KV state / sinks: the one-kernel-per-reference-kernel path (attn_dec has neither)
             if ((L.qn.present && (L.qn.subtract_mean || L.qn.biases)) || (L.kn.present && (L.kn.subtract_mean || L.kn.biases))) return false;
         } else {
             if (!linear_fusable(L.in_proj) || !linear_fusable(L.out_proj)) return false;
@@ -1028,6 +1040,10 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             TRY(upload_linear(m, h.out_projection, &L.out));
             TRY(upload_norm(m, h.query_norm, h.head_dim, &L.qn));
             TRY(upload_norm(m, h.key_norm, h.head_dim, &L.kn));
+            if (h.has_sinks) {
+                if (!h.sinks) return fail((set_error("model_create: layer %u has_sinks without a sinks tensor", l), UZU_ERR_INVALID_ARGUMENT));
+                TRY(upload(m, h.sinks, (size_t)h.num_heads * 2, &L.sinks));
+            }
             const uint32_t qdim = h.num_heads * h.head_dim;
             max_qkv = max_qkv > h.qkv_projection.n ? max_qkv : h.qkv_projection.n;
             max_qdim = max_qdim > qdim ? max_qdim : qdim;
@@ -1290,14 +1306,16 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
         const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
         const bool last = start + n == count;
         HIPCHK(hipMemcpyAsync(m->d_tokens, token_ids + start, (size_t)n * 4, hipMemcpyHostToDevice, s));
-        if (m->context_length + n > 1024) {
+        {   // two-pass attention over this chunk (core/mod.rs:89-92: physical prefix + suffix > 1024; a ring's prefix is its window)
             uint32_t max_heads = 0, max_hd = 0;
+            bool two_pass = false;
             for (auto& L : m->layers)
                 if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
                     max_heads = max_heads > L.d.num_heads ? max_heads : L.d.num_heads;
                     max_hd = max_hd > L.d.head_dim ? max_hd : L.d.head_dim;
+                    two_pass = two_pass || (L.d.sliding_window_size ? L.d.sliding_window_size : m->context_length) + n > 1024;
                 }
-            if (max_heads) UZU_PROPAGATE(ensure_partials(m, n * max_heads, max_hd));
+            if (max_heads && two_pass) UZU_PROPAGATE(ensure_partials(m, n * max_heads, max_hd));
         }
         UZU_PROPAGATE(encode_forward(m, s, n, last));
         HIPCHK(hipStreamSynchronize(s)); // token_ids is caller memory; also surfaces kernel faults per chunk

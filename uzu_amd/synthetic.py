@@ -66,6 +66,8 @@ class ModelConfig:
     seed: int = 42
     logit_row_sigma: float = 0.6   # log-normal spread of per-token readout row norms (peaked logits)
     rht: bool = False              # every layer linear is a HybridSpec InputOutput linear (random +-1 sign vectors; not the embeddings)
+    sliding_windows: Optional[List[int]] = None  # per attention layer (in layer order): window size, 0 = full attention (Gemma / gpt-oss pattern)
+    sinks: bool = False            # every attention layer carries per-head sink logits (mixer.sinks)
 
     @property
     def num_layers(self) -> int:
@@ -209,6 +211,7 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
     if not cfg.tied_embeddings:
         output_embedding = make_linear(cfg, "output_embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
     layers: List[D.LayerWeights] = []
+    attn_index = 0
     for li, kind in enumerate(cfg.layer_kinds):
         p = f"layers.{li}."
         lw = D.LayerWeights(
@@ -231,6 +234,11 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
             if cfg.qk_norm:
                 lw.query_norm = make_norm(cfg, p + "mixer.query_norm", cfg.head_dim)
                 lw.key_norm = make_norm(cfg, p + "mixer.key_norm", cfg.head_dim)
+            if cfg.sliding_windows is not None:
+                lw.sliding_window_size = int(cfg.sliding_windows[attn_index % len(cfg.sliding_windows)])
+            if cfg.sinks:
+                lw.sinks = f32_to_bf16_bits(_rng(cfg.seed, p + "mixer.sinks").normal(0.0, 1.0, cfg.num_heads).astype(np.float32))
+            attn_index += 1
         else:
             Hv, Hk, Dk, Dv = cfg.dn_num_heads, cfg.dn_num_groups, cfg.dn_head_dim, cfg.dn_value_head_dim
             key_dim, value_dim = Hk * Dk, Hv * Dv

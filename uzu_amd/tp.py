@@ -155,6 +155,8 @@ def shard_layer(l: D.LayerWeights, rank: int, size: int) -> D.LayerWeights:
         if l.gate_projection is not None:
             out.gate_projection = take_rows(l.gate_projection, rows(0, q_lo, q_hi))
         out.out_projection = take_k(l.out_projection, q_lo * hd, q_hi * hd, owns_out_bias=rank == 0)
+        if l.sinks is not None:
+            out.sinks = np.ascontiguousarray(l.sinks[q_lo:q_hi])
     else:
         Hv, Hk, Dk, Dv = l.dn_num_heads, l.dn_num_groups, l.dn_head_dim, l.dn_value_head_dim
         assert Hv % size == 0, f"{Hv} DeltaNet value heads do not split over {size} ranks"
