@@ -90,10 +90,10 @@ int main() {
         float *out, *accs;
         uint32_t *err, *rows;
         CK(hipMalloc(&gran, (size_t)2 * n_gran * 8));
-        CK(hipMalloc(&out, cus * 4)), CK(hipMalloc(&accs, cus * 4)), CK(hipMalloc(&err, 4)), CK(hipMalloc(&rows, (size_t)2 * n_gran * 4));
-        CK(hipMemset(err, 0, 4)), CK(hipMemset(accs, 0, cus * 4)), CK(hipMemset(rows, 0, (size_t)2 * n_gran * 4));
+        CK(hipMalloc(&out, cus * 4)); CK(hipMalloc(&accs, cus * 4)); CK(hipMalloc(&err, 4)); CK(hipMalloc(&rows, (size_t)2 * n_gran * 4));
+        CK(hipMemset(err, 0, 4)); CK(hipMemset(accs, 0, cus * 4)); CK(hipMemset(rows, 0, (size_t)2 * n_gran * 4));
         hipEvent_t e0, e1;
-        CK(hipEventCreate(&e0)), CK(hipEventCreate(&e1));
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         float best_p = 1e9f, best_l = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipMemsetAsync(gran, 0, (size_t)2 * n_gran * 8, s)); // tags must start below every epoch
@@ -128,8 +128,8 @@ int main() {
         }
         printf("row of %5u bf16 (%4u granules, %5.1f KB swept per workgroup): in-launch edge %6.2f us   kernel boundary edge %6.2f us   (%u ops, %d workgroups%s)\n", elems, n_gran,
                n_gran * 8 / 1024.0, best_p * 1e3 / ops, best_l * 1e3 / ops, ops, cus, herr ? "; A BOUNDED SPIN GAVE UP" : "");
-        CK(hipGraphExecDestroy(ge)), CK(hipGraphDestroy(g));
-        CK(hipFree(gran)), CK(hipFree(out)), CK(hipFree(accs)), CK(hipFree(err)), CK(hipFree(rows));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        CK(hipFree(gran)); CK(hipFree(out)); CK(hipFree(accs)); CK(hipFree(err)); CK(hipFree(rows));
     }
     return 0;
 }
