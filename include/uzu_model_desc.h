@@ -48,6 +48,10 @@ typedef enum {
  * method == UZU_QUANT_NONE: weights is bf16 [n,k], bits == 16, everything else NULL.
  * HybridSpec { incoherence_processing_mode: InputOutput, block 32, no adapter } (RHTLinearWrapper, linear/rht_wrapper.rs:140-298):
  *   input_signs  i32 [k], output_signs i32 [n] (+-1): y = OutputRht(W InputRht(x)) + out_biases; NULL = a plain linear.
+ * Embedding tables (encodable_block/embedding.rs:126-341) reuse the struct with their own reading of the sign vectors:
+ *   `embedding` / input table, HybridSpec { Output, block 32 }: output_signs i32 [model_dim]: lookup = OutputRht(dequantised row); a TIED
+ *   table's read-out takes InputRht(row, the same signs) in front of the matmul (embedding.rs:161-188, 385-400);
+ *   `output_embedding`, HybridSpec { Input, block 32 }: input_signs i32 [model_dim]: read-out = W InputRht(x) (embedding.rs:243-283).
  */
 typedef struct {
     uint32_t n;          /* output_dim */
@@ -63,6 +67,13 @@ typedef struct {
     const uint16_t* out_biases;
     const int32_t* input_signs;
     const int32_t* output_signs;
+    /* HybridSpec { adapter_spec: LowRankSpec { rank } } (QLoRALinearWrapper, linear/qlora_wrapper.rs:61-252): bf16 adapters next to the
+     * quantized base; y = [OutputRht]( W [InputRht](x) + (x down^T) up^T ); lora_rank == 0 = no adapter.  The sign vectors are optional
+     * here (incoherence_block_size None); out_biases must be NULL (the reference asserts it). */
+    uint32_t lora_rank;
+    uint32_t reserved2;
+    const uint16_t* adapter_down; /* bf16 [rank, k]  (weights.adapter.down_projection) */
+    const uint16_t* adapter_up;   /* bf16 [n, rank]  (weights.adapter.up_projection) */
 } uzu_linear_desc;
 
 /* config/normalization.rs:10-18 + tensor `scales` f32 [dim] (encodable_block/normalization.rs:67-74) */

@@ -144,7 +144,43 @@ const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint3
 const uint16_t* orc_model_final_hidden(const orc_model* m) { return m->final_hidden; }
 
 /* Linear::encode -> MatmulKernel::encode with b_transpose = true (linear/matmul.rs:122-148) */
+static void fp_matmul(const uint16_t* a, const uint16_t* b, uint16_t* d, uint32_t m, uint32_t n, uint32_t k, int accumulate) {
+    orc_matmul_args g;
+    memset(&g, 0, sizeof(g));
+    g.a = a, g.a_dtype = ORC_BF16, g.b = b, g.w_dtype = ORC_BF16, g.method = UZU_QUANT_NONE, g.bits = 16, g.b_transpose = 1;
+    g.d = d, g.d_dtype = ORC_BF16, g.ab_scale = 1.0f, g.accumulate = accumulate, g.m = m, g.n = n, g.k = k;
+    orc_matmul(&g);
+}
+
+/* QLoRALinearWrapper::encode (linear/qlora_wrapper.rs:177-251): intermediate = x down^T (bf16); base input = InputRht(copy of x) when the
+ * spec carries incoherence signs; output = base(x') (no bias, no output D-op); output += intermediate up^T (MatmulDOps::accumulate);
+ * OutputRht in place. */
+static uint16_t* linear_qlora(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) {
+    uint16_t* out = (uint16_t*)xcalloc((size_t)batch * lin->n, 2);
+    uint16_t* intermediate = (uint16_t*)xcalloc((size_t)batch * lin->lora_rank, 2);
+    fp_matmul(input, lin->adapter_down, intermediate, batch, lin->lora_rank, lin->k, 0);
+    uint16_t* transformed = NULL;
+    const uint16_t* base_input = input;
+    if (lin->input_signs) {
+        transformed = (uint16_t*)xcalloc((size_t)batch * lin->k, 2);
+        orc_activation_transform(input, transformed, NULL, NULL, NULL, lin->input_signs, ORC_BF16, batch, lin->k, 0, 0, 0);
+        base_input = transformed;
+    }
+    orc_matmul_args g;
+    memset(&g, 0, sizeof(g));
+    g.a = base_input, g.a_dtype = ORC_BF16, g.b = lin->weights, g.scales = lin->scales, g.biases = lin->biases, g.zero_points = lin->zero_points;
+    g.w_dtype = ORC_BF16, g.method = lin->method, g.bits = lin->bits, g.group_size = lin->group_size, g.b_transpose = 1;
+    g.d = out, g.d_dtype = ORC_BF16, g.ab_scale = 1.0f, g.m = batch, g.n = lin->n, g.k = lin->k;
+    orc_matmul(&g);
+    fp_matmul(intermediate, lin->adapter_up, out, batch, lin->n, lin->lora_rank, 1);
+    if (lin->output_signs) orc_activation_transform(NULL, out, NULL, NULL, NULL, lin->output_signs, ORC_BF16, batch, lin->n, 1, 0, 0);
+    free(transformed);
+    free(intermediate);
+    return out;
+}
+
 static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) {
+    if (lin->lora_rank) return linear_qlora(lin, input, batch);
     uint16_t* out = (uint16_t*)xcalloc((size_t)batch * lin->n, 2);
     /* RHTLinearWrapper::encode_input (linear/rht_wrapper.rs:215-298), full-precision activation format: InputRht of the rows
      * (encode_fp_in_place on the wrapper's own allocation), the inner LinearMatmul with MatmulDOps::rht_factors = output signs */
@@ -336,6 +372,9 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
                                        D->embedding.zero_points, D->embedding.biases, hidden, ORC_BF16, count,
                                        D->vocab_size, d, D->input_scale, D->embedding.group_size, D->embedding.bits,
                                        D->embedding.method);
+    /* EmbeddingTable with output Hadamard factors (embedding_table.rs:34-125, quant_embedding.metal use_hadamard): OutputRht of the row */
+    if (D->embedding.output_signs)
+        orc_activation_transform(NULL, hidden, NULL, NULL, NULL, D->embedding.output_signs, ORC_BF16, count, d, 1, 0, 0);
     uint16_t* shortcut = (uint16_t*)xcalloc((size_t)count * d, 2);
     /* host RoPE tables for this pass (transformer.rs:247-254) */
     float *cosines = NULL, *sines = NULL;
@@ -395,8 +434,12 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
     free(hidden);
     free(shortcut);
     /* readout (embedding.rs:374-456) */
-    const uzu_linear_desc* ro = D->tied_embeddings ? &D->embedding : &D->output_embedding;
-    uint16_t* logits = linear(ro, normed, 1);
+    /* Embedding::encode_readout (embedding.rs:374-456): readout_input_hadamard = the tied table's output signs (embedding.rs:167-173) or
+     * the untied output embedding's input signs (embedding.rs:255-274): InputRht on a private copy of the row, then the plain matmul */
+    uzu_linear_desc ro = D->tied_embeddings ? D->embedding : D->output_embedding;
+    ro.input_signs = D->tied_embeddings ? D->embedding.output_signs : D->output_embedding.input_signs;
+    ro.output_signs = NULL;
+    uint16_t* logits = linear(&ro, normed, 1);
     free(normed);
     if (D->logit_scale != 1.0f || D->logit_soft_cap != 0.0f)
         orc_logit_transform(logits, ORC_BF16, D->vocab_size, D->logit_scale, D->logit_soft_cap, D->logit_soft_cap != 0.0f);

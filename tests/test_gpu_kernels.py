@@ -1162,3 +1162,62 @@ def test_stream_gemv_is_bit_identical_to_register_gemv(hip_ctx, n, k, group):
     assert np.array_equal(base, got), f"{(base != got).sum()} of {n} outputs differ from the register GEMV"
     want = oracle_matmul(a, q, 1, bias=bias)
     assert ulp_diff_bf16(want, got).max() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------ HybridSpec: Hadamard hoisted into the norm / the embedding
+def test_normalization_with_hoisted_input_hadamard(hip_ctx):
+    """Normalization { use_hadamard } (normalization.metal:134-140): the input RHT of the linear behind the norm applied to the rounded
+    result.  The reference's own CPU kernel is `unimplemented!` here (normalization.rs:46-48), so the expectation is the Metal source's
+    composition restated with the oracle's pieces: orc_normalization, then ActivationTransform::InputRht on its output -- in
+    reference-order mode BIT-identical, in production mode within the norm's own tolerance class."""
+    rng = np.random.default_rng(77)
+    rows, dim = 5, 1024
+    x, sc = bf16(rng.normal(0, 1.5, size=(rows, dim))), bf16(rng.normal(0, 1.5, size=(rows, dim)))
+    scales = rng.uniform(-0.2, 0.2, size=(dim,)).astype(np.float32)
+    signs = rng.choice(np.array([-1, 1], np.int32), dim).astype(np.int32)
+    normed, want_sc = np.zeros_like(x), sc.copy()
+    args = O.NormArgs(x.ctypes.data, scales.ctypes.data, None, normed.ctypes.data, want_sc.ctypes.data, O.BF16, O.F32, rows, dim, 1e-6, 1.0, 1.0, 0, 1, 1, 1, 0, 0)
+    O.lib().orc_normalization(C.byref(args))
+    want = np.zeros_like(x)
+    O.call("orc_activation_transform", normed, want, None, None, None, signs, O.BF16, rows, dim, 0, 0, 0)
+    kern = B.NormalizationKernel.new(hip_ctx, B.BF16, B.F32, B.BF16, B.F32, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1)  # use_hadamard = 1
+    fn = _ffi.lib().uzu_hip_set_exact
+    fn.restype, fn.argtypes = None, [C.c_int32]
+    for exact in (1, 0):
+        fn(exact)
+        try:
+            bx, bs, bo, bsc, bh = hip_ctx.buffer_from(x), hip_ctx.buffer_from(scales), hip_ctx.create_buffer(x.nbytes), hip_ctx.buffer_from(sc), hip_ctx.buffer_from(signs)
+            run(hip_ctx, lambda cb: kern.encode(bx, bs, None, bo, bsc, bh, rows, dim, 1e-6, 1.0, 1.0, cb))
+            got = bo.download(np.uint16, rows * dim).reshape(rows, dim)
+        finally:
+            fn(0)
+        assert np.array_equal(bsc.download(np.uint16, rows * dim).reshape(rows, dim), want_sc)
+        if exact:
+            assert np.array_equal(got, want)
+        else:  # a 1-ulp difference of a normalised element spreads over its 32-element Hadamard block
+            w, g = f32(want).astype(np.float64), f32(got).astype(np.float64)
+            assert np.abs(w - g).max() <= 0.02 * np.abs(w).max()
+    with pytest.raises(B.UzuHipError):  # the combination the Metal kernel orders differently is refused, not approximated
+        B.NormalizationKernel.new(hip_ctx, B.BF16, B.F32, B.BF16, B.F32, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1)
+
+
+@pytest.mark.parametrize("bits,method", [(4, 0), (8, 1)])
+def test_quantized_embedding_lookup_with_output_hadamard(hip_ctx, bits, method):
+    """QuantizedEmbeddingLookup { use_hadamard } (quant_embedding.metal:92-98; `unimplemented!` in the reference's CPU kernel): the
+    dequantised, rounded row through ActivationTransform::OutputRht -- bit-exact against that composition of the oracle's kernels."""
+    rng = np.random.default_rng(19 + bits)
+    vocab, dim, g = 300, 256, 64
+    q = quant_matrix(rng, vocab, dim, bits, g, method, scale_mag=1.0)
+    ids = np.array([0, 299, 17, 5, 123], np.uint32)
+    signs = rng.choice(np.array([-1, 1], np.int32), dim).astype(np.int32)
+    rows = np.zeros((ids.size, dim), np.uint16)
+    O.call("orc_quantized_embedding_lookup", ids, q["weights"], q["scales"], q["zero_points"], q["biases"], rows, O.BF16, ids.size, vocab, dim, 1.5, g, bits, method)
+    want = rows.copy()
+    O.call("orc_activation_transform", None, want, None, None, None, signs, O.BF16, ids.size, dim, 1, 0, 0)
+    kern = B.QuantizedEmbeddingLookupKernel.new(hip_ctx, B.BF16, g, B.QMODE_U4 if bits == 4 else B.QMODE_U8, method, 1)
+    bid, bw, bs = hip_ctx.buffer_from(ids), hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"])
+    bz = hip_ctx.buffer_from(q["zero_points"]) if q["zero_points"] is not None else None
+    bb = hip_ctx.buffer_from(q["biases"]) if q["biases"] is not None else None
+    bo, bh = hip_ctx.create_buffer(want.nbytes), hip_ctx.buffer_from(signs)
+    run(hip_ctx, lambda cb: kern.encode(bid, bw, bs, bz, bb, bo, bh, ids.size, vocab, dim, 1.5, cb))
+    assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)

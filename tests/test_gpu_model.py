@@ -661,3 +661,53 @@ def test_sliding_window_model_directory_round_trip(hip_ctx, tmp_path):
         outs.append(([first] + [int(t) for t in toks], hm.read_logits()))
         hm.close()
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------------------ HybridSpec completeness: QLoRA adapters, RHT embeddings
+@pytest.mark.parametrize("preset,kw", [
+    ("tiny-llama", {"qlora_rank": 8}), ("tiny-llama", {"qlora_rank": 8, "rht": True}), ("tiny-qwen", {"qlora_rank": 4, "rht": True}),
+    ("tiny-llama", {"rht_embeddings": True}), ("tiny-qwen", {"rht_embeddings": True}), ("tiny-llama", {"rht_embeddings": True, "rht": True, "qlora_rank": 4}),
+])
+def test_qlora_adapters_and_rht_embeddings_end_to_end(hip_ctx, preset, kw):
+    """QLoRALinearWrapper (linear/qlora_wrapper.rs:177-251: x down^T, the quantized base on the [InputRht'd] rows, + (x down^T) up^T
+    accumulated, [OutputRht]) and HybridSpec embeddings (embedding.rs:126-341: OutputRht of the looked-up row; the read-out's private
+    InputRht with a tied table's output signs / an untied output embedding's input signs) in prefill and decode, against the oracle's
+    restatement of the same compositions: reference-order mode BIT-identical logits, production mode tolerance + arg-max outside near-ties."""
+    cfg = S.PRESETS[preset](seed=49, **kw)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 33, 6, teacher_forced=True)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(33, cfg.vocab_size)
+    _set_exact(True)
+    try:
+        om2, hm2 = O.OracleModel(bundle), HipModel(hip_ctx, bundle)
+        tok, lg = om2.prefill(prompt, True)
+        assert hm2.prefill(prompt) == tok and np.array_equal(hm2.read_logits(), lg)
+        for _ in range(4):
+            tok, lg = om2.forward([tok], True)
+            t, _ = hm2.decode(1)
+            assert np.array_equal(hm2.read_logits(), lg) and int(t[0]) == tok
+        hm2.close()
+        om2.close()
+    finally:
+        _set_exact(False)
+
+
+def test_hybrid_spec_model_directory_round_trip(hip_ctx, tmp_path):
+    """weights.quantized.* + weights.adapter.{down,up}_projection + weights.incoherence_signs.* (QLoRA), embedding.quantized.* +
+    embedding.incoherence_signs.output_signs (RHT embedding): save -> load -> identical tokens and logits."""
+    from uzu_amd import loader as L
+    cfg = S.tiny_qwen(rht=True, qlora_rank=4, rht_embeddings=True, seed=50)
+    bundle = S.build_model(cfg)
+    L.save_model_dir(bundle, str(tmp_path / "h"))
+    loaded = L.load_model_dir(str(tmp_path / "h"), max_context_length=cfg.max_context_length)
+    prompt = S.synthetic_prompt(21, cfg.vocab_size)
+    outs = []
+    for b in (bundle, loaded):
+        hm = HipModel(hip_ctx, b)
+        first = hm.prefill(prompt)
+        toks, _ = hm.decode(5)
+        outs.append(([first] + [int(t) for t in toks], hm.read_logits()))
+        hm.close()
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])

@@ -85,13 +85,22 @@ def test_rht_linears_change_the_forward_and_are_refused_where_unsupported(tmp_pa
     st = L.SafeTensors(path)
     tensors = {k: (st.index[k][0], st.tensor(k, st.index[k][1], st.index[k][0])) for k in st.index}
     key = "decoder.transformer.layers.0.mlp.down_projection.weights.spec"
-    for field, value, what in (("incoherence_processing_mode", "input", "incoherence processing"), ("incoherence_block_size", 64, "incoherence processing"),
-                               ("adapter_spec", {"type": "LowRankSpec", "rank": 8}, "QLoRA")):
+    for field, value, what in (("incoherence_processing_mode", "input", "incoherence processing"), ("incoherence_block_size", 64, "incoherence processing")):
         meta = dict(st.metadata)
         meta[key] = json.dumps({**json.loads(meta[key]), field: value})
         L.write_safetensors(path, tensors, meta)
         with pytest.raises(L.UnsupportedModelError, match=what):
             L.load_model_dir(d)
+    # a LowRankSpec adapter selects QLoRALinearWrapper (linear/mod.rs:133-158): its tensors must be there, the rank positive, the base quantized
+    meta = dict(st.metadata)
+    meta[key] = json.dumps({**json.loads(meta[key]), "adapter_spec": {"type": "LowRankSpec", "rank": 8, "layout": "output_input"}})
+    L.write_safetensors(path, tensors, meta)
+    with pytest.raises(L.ModelFormatError, match="adapter.down_projection' not found"):
+        L.load_model_dir(d)
+    meta[key] = json.dumps({**json.loads(meta[key]), "adapter_spec": {"type": "LowRankSpec", "rank": 0, "layout": "output_input"}})
+    L.write_safetensors(path, tensors, meta)
+    with pytest.raises(L.ModelFormatError, match="adapter rank must be positive"):
+        L.load_model_dir(d)
     with pytest.raises(NotImplementedError):  # tensor-parallel shards of RHT linears are not planned yet
         bundle.layers[0].up_projection.rows(0, 64)
 

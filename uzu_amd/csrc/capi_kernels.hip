@@ -148,13 +148,17 @@ uzu_status uzu_hip_normalization_create(uzu_hip_context* ctx, uint32_t input_t, 
     REQ_DT(affine_t, "normalization");
     UZU_UNSUPPORTED(input_t != output_t, "normalization: InputT != OutputT is not instantiated");
     UZU_UNSUPPORTED(accum_t != UZU_F32, "normalization: AccumT must be F32");
-    UZU_UNSUPPORTED(use_hadamard, "normalization: fused Hadamard (RHT checkpoints) is not implemented yet");
+    // use_hadamard (normalization.metal:134-140; `unimplemented!` in the reference's own CPU kernel, normalization.rs:46-48): the input RHT of
+    // the linear behind the norm, hoisted into it -- OutputT(hadamard32(float(val) * factor)) on the rounded result, i.e. exactly
+    // ActivationTransform::InputRht on the norm's output: run as those two kernels (bit-identical to the fused Metal form).  The Metal kernel
+    // applies scale_output AFTER the transform: that combination is not instantiated.
+    UZU_UNSUPPORTED(use_hadamard && scale_output, "normalization: use_hadamard with scale_output is not instantiated");
     UZU_REQUIRE(copy_to_shortcut || !residual_add, "normalization: residual_add requires copy_to_shortcut");
     uzu_hip_kernel* k;
     UZU_PROPAGATE(make_kernel(ctx, KK_NORMALIZATION, out, &k));
     k->t[0] = input_t, k->t[1] = affine_t;
-    const uint32_t f[] = {in_place, subtract_mean, full_layer, copy_to_shortcut, residual_add, scale_residual_sum, scale_output, has_biases, has_scales};
-    for (int i = 0; i < 9; ++i) k->f[i] = f[i];
+    const uint32_t f[] = {in_place, subtract_mean, full_layer, copy_to_shortcut, residual_add, scale_residual_sum, scale_output, has_biases, has_scales, use_hadamard};
+    for (int i = 0; i < 10; ++i) k->f[i] = f[i];
     return UZU_OK;
 }
 
@@ -168,7 +172,9 @@ uzu_status uzu_hip_normalization_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, u
     UZU_REQUIRE((shortcut.buffer != nullptr) == copy_to_shortcut, "normalization: shortcut presence must equal copy_to_shortcut");
     UZU_REQUIRE((biases.buffer != nullptr) == has_biases, "normalization: biases presence must equal has_biases");
     UZU_REQUIRE((scales.buffer != nullptr) == has_scales, "normalization: scales presence must equal has_scales");
-    UZU_REQUIRE(hadamard_factors.buffer == nullptr, "normalization: hadamard_factors given but use_hadamard is false");
+    const bool use_hadamard = k->f[9];
+    UZU_REQUIRE((hadamard_factors.buffer != nullptr) == use_hadamard, "normalization: hadamard_factors presence must equal use_hadamard");
+    UZU_REQUIRE(!use_hadamard || element_count % 32u == 0, "normalization: use_hadamard needs element_count %% 32 == 0 (got %u)", element_count);
     k::NormParams p{};
     p.input = bptr(input), p.scales = bptr(scales), p.biases = bptr(biases), p.output = bptr(output), p.shortcut = bptr(shortcut);
     p.io_dt = k->t[0], p.affine_dt = k->t[1];
@@ -176,7 +182,10 @@ uzu_status uzu_hip_normalization_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, u
     p.epsilon = epsilon, p.scale_offset = scale_offset, p.post_layer_scalar = post_layer_scalar;
     p.subtract_mean = k->f[1], p.full_layer = k->f[2], p.copy_to_shortcut = k->f[3], p.residual_add = k->f[4];
     p.scale_residual_sum = k->f[5], p.scale_output = k->f[6];
-    return k::normalization(cb_stream(cb), p);
+    UZU_PROPAGATE(k::normalization(cb_stream(cb), p));
+    if (!use_hadamard) return UZU_OK;
+    return k::activation_transform(cb_stream(cb), nullptr, p.output, nullptr, nullptr, nullptr, (const int32_t*)bptr(hadamard_factors), k->t[0], batch_size, element_count,
+                                   UZU_ACTIVATION_TRANSFORM_INPUT_RHT, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------- QKVNorm
@@ -468,13 +477,14 @@ uzu_status uzu_hip_gated_act_mul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, u
 uzu_status uzu_hip_quantized_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uint32_t group_size, uint32_t quantization_mode,
                                                      uint32_t quantization_method, uint32_t use_hadamard, uzu_hip_kernel** out) {
     REQ_DT(t, "quantized_embedding_lookup");
-    UZU_UNSUPPORTED(use_hadamard, "quantized_embedding_lookup: output Hadamard is not implemented (the CPU reference rejects it too, quant_embedding.rs:32-34)");
+    // use_hadamard (quant_embedding.metal:92-98; `unimplemented!` in the reference's CPU kernel, quant_embedding.rs:32-34): OutputRht of the
+    // dequantised, rounded row = the lookup followed by ActivationTransform::OutputRht in place (bit-identical to the fused Metal form)
     UZU_UNSUPPORTED(quantization_mode == UZU_QMODE_I8, "quantized_embedding_lookup: I8 mode is not produced by weight matrices");
     UZU_REQUIRE(group_size > 0 && quantization_method <= 2, "quantized_embedding_lookup: bad group size / method");
     uzu_hip_kernel* k;
     UZU_PROPAGATE(make_kernel(ctx, KK_QUANT_EMBEDDING, out, &k));
     k->t[0] = t;
-    k->f[0] = group_size, k->f[1] = quantization_mode == UZU_QMODE_U4 ? 4 : 8, k->f[2] = quantization_method;
+    k->f[0] = group_size, k->f[1] = quantization_mode == UZU_QMODE_U4 ? 4 : 8, k->f[2] = quantization_method, k->f[3] = use_hadamard;
     return UZU_OK;
 }
 uzu_status uzu_hip_quantized_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf token_ids, uzu_buf weights, uzu_buf scales,
@@ -484,10 +494,15 @@ uzu_status uzu_hip_quantized_embedding_lookup_encode(uzu_hip_kernel* k, uzu_hip_
     UZU_REQUIRE(token_ids.buffer && weights.buffer && scales.buffer && output.buffer, "quantized_embedding_lookup: null buffer");
     UZU_REQUIRE((zero_points.buffer != nullptr) == (k->f[2] == 1), "ScaleZeroPoint quantized embedding requires zero_points");
     UZU_REQUIRE((biases.buffer != nullptr) == (k->f[2] == 0), "ScaleBias quantized embedding requires biases");
-    UZU_REQUIRE(!output_hadamard_factors.buffer, "quantized_embedding_lookup: hadamard factors given but use_hadamard is false");
-    return k::quantized_embedding_lookup(cb_stream(cb), (const uint32_t*)bptr(token_ids), (const uint8_t*)bptr(weights), bptr(scales),
-                                         (const uint8_t*)bptr(zero_points), bptr(biases), bptr(output), k->t[0], batch_size, vocab_size, model_dim,
-                                         input_scale, k->f[0], k->f[1], k->f[2]);
+    const bool use_hadamard = k->f[3];
+    UZU_REQUIRE((output_hadamard_factors.buffer != nullptr) == use_hadamard, "quantized_embedding_lookup: hadamard factors presence must equal use_hadamard");
+    UZU_REQUIRE(!use_hadamard || model_dim % 32u == 0, "quantized_embedding_lookup: use_hadamard needs model_dim %% 32 == 0 (got %u)", model_dim);
+    UZU_PROPAGATE(k::quantized_embedding_lookup(cb_stream(cb), (const uint32_t*)bptr(token_ids), (const uint8_t*)bptr(weights), bptr(scales),
+                                                (const uint8_t*)bptr(zero_points), bptr(biases), bptr(output), k->t[0], batch_size, vocab_size, model_dim,
+                                                input_scale, k->f[0], k->f[1], k->f[2]));
+    if (!use_hadamard) return UZU_OK;
+    return k::activation_transform(cb_stream(cb), nullptr, bptr(output), nullptr, nullptr, nullptr, (const int32_t*)bptr(output_hadamard_factors), k->t[0], batch_size, model_dim,
+                                   UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0);
 }
 uzu_status uzu_hip_full_precision_embedding_lookup_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
     REQ_DT(t, "full_precision_embedding_lookup");

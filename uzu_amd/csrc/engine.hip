@@ -40,6 +40,8 @@ struct DLinear {
     void* out_biases = nullptr;
     int32_t* in_signs = nullptr;  // HybridSpec InputOutput (RHTLinearWrapper): sign factors of the input / output Hadamard transforms
     int32_t* out_signs = nullptr;
+    uint32_t lora_rank = 0;       // HybridSpec with a LowRankSpec adapter (QLoRALinearWrapper): bf16 [rank, k] and [n, rank]
+    uint16_t *adapter_down = nullptr, *adapter_up = nullptr;
 };
 struct DNorm {
     bool present = false;
@@ -132,6 +134,8 @@ struct uzu_hip_model {
     uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
     uint16_t* rht_scratch = nullptr; // [rows][widest RHT input]: InputRht works on a copy of the rows
     uint32_t rht_max_k = 0;
+    uint16_t* lora_scratch = nullptr; // [rows][widest adapter rank]: x down^T of a QLoRA linear
+    uint32_t lora_max_rank = 0;
     float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
     float* dn_ws = nullptr; // chunked DeltaNet prefill: T / P matrices of one 1024-token pass (k_deltanet_chunk.hip)
     float *dn_o = nullptr, *dn_sz = nullptr; // raw DeltaNet outputs and SiLU(z) of the decode token (f32 [value_dim])
@@ -290,7 +294,7 @@ template <class T> uzu_status upload(uzu_hip_model* m, const void* host, size_t 
     return UZU_OK;
 }
 
-uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o) {
+uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o, bool is_embedding = false) {
     o->n = h.n, o->k = h.k, o->bits = h.bits, o->group = h.group_size, o->method = h.method;
     if (!h.weights) return UZU_OK;
     if (h.method == UZU_QUANT_NONE) {
@@ -307,11 +311,22 @@ uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o)
     }
     UZU_PROPAGATE(upload(m, h.out_biases, (size_t)h.n * 2, &o->out_biases));
     if (h.input_signs || h.output_signs) {
-        UZU_REQUIRE(h.input_signs && h.output_signs, "engine: an RHT linear needs both input_signs and output_signs (HybridSpec InputOutput)");
-        UZU_REQUIRE(h.n % 32 == 0 && h.k % 32 == 0, "engine: RHT linear %u x %u is not a whole number of 32-wide Hadamard blocks", h.n, h.k);
-        UZU_PROPAGATE(upload(m, h.input_signs, (size_t)h.k * 4, &o->in_signs));
-        UZU_PROPAGATE(upload(m, h.output_signs, (size_t)h.n * 4, &o->out_signs));
+        UZU_REQUIRE(is_embedding || (h.input_signs && h.output_signs), "engine: an RHT linear needs both input_signs and output_signs (HybridSpec InputOutput)");
+        UZU_REQUIRE(h.k % 32 == 0 && (is_embedding || h.n % 32 == 0), "engine: RHT linear %u x %u is not a whole number of 32-wide Hadamard blocks", h.n, h.k);
+        // embedding tables: both vectors run over model_dim = k (the table's output side is the lookup's row, embedding.rs:161-188)
+        if (h.input_signs) UZU_PROPAGATE(upload(m, h.input_signs, (size_t)h.k * 4, &o->in_signs));
+        if (h.output_signs) UZU_PROPAGATE(upload(m, h.output_signs, (size_t)(is_embedding ? h.k : h.n) * 4, &o->out_signs));
         m->rht_max_k = m->rht_max_k > h.k ? m->rht_max_k : h.k;
+    }
+    if (h.lora_rank) { // QLoRALinearWrapper::new (qlora_wrapper.rs:61-175)
+        UZU_REQUIRE(!is_embedding && h.method != UZU_QUANT_NONE, "engine: a QLoRA adapter needs a quantized base linear");
+        UZU_REQUIRE(!h.out_biases, "engine: QLoRA linear with biases is not supported (the reference asserts the same)");
+        UZU_REQUIRE(h.adapter_down && h.adapter_up, "engine: QLoRA linear of rank %u without adapter tensors", h.lora_rank);
+        o->lora_rank = h.lora_rank;
+        UZU_PROPAGATE(upload(m, h.adapter_down, (size_t)h.lora_rank * h.k * 2, &o->adapter_down));
+        UZU_PROPAGATE(upload(m, h.adapter_up, (size_t)h.n * h.lora_rank * 2, &o->adapter_up));
+        m->lora_max_rank = m->lora_max_rank > h.lora_rank ? m->lora_max_rank : h.lora_rank;
+        m->rht_max_k = m->rht_max_k > h.k ? m->rht_max_k : h.k; // the base input is a transformed COPY (the adapter reads the original)
     }
     return UZU_OK;
 }
@@ -424,7 +439,43 @@ struct Enc {
 // RHT linears (RHTLinearWrapper::encode_input, linear/rht_wrapper.rs:215-298, full-precision activation format): InputRht on a
 // copy of the rows (the reference transforms its own allocation in place), the inner matmul without its bias, OutputRht in place
 // on the result, then the bias (MatmulDOps::rht_factors, kernel.rs:296-303).
+// QLoRALinearWrapper::encode (linear/qlora_wrapper.rs:177-251): intermediate = x down^T; base input = InputRht of a copy of the rows (when the
+// spec carries signs); output = base matmul (no bias); output += intermediate up^T (MatmulDOps::accumulate); OutputRht in place.
+void linear_qlora(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch) {
+    uzu_hip_model* m = e.m;
+    auto fp = [&](const uint16_t* a, const uint16_t* b, uint16_t* d, uint32_t n, uint32_t k, bool accumulate) {
+        k::MatmulParams p{};
+        p.a = a, p.b = b, p.d = d, p.w_dt = p.a_dt = p.d_dt = UZU_BF16, p.b_kind = UZU_MATMUL_B_FULL_PRECISION, p.bits = 16, p.ab_scale = 1.0f;
+        p.accumulate = accumulate ? 1u : 0u, p.m = batch, p.n = n, p.k = k;
+        const char* variant = "matmul";
+        e.begin();
+        const uzu_status r = k::matmul(e.s, p, m->ctx->num_cus, &variant);
+        e.run(r, "matmul_adapter", k::matmul_algorithmic_bytes(p));
+    };
+    fp(input, L.adapter_down, m->lora_scratch, L.lora_rank, L.k, false);
+    const uint16_t* base_input = input;
+    if (L.in_signs) {
+        RUN("activation_transform", 0, k::activation_transform(e.s, input, m->rht_scratch, nullptr, nullptr, nullptr, L.in_signs, UZU_BF16, batch, L.k,
+                                                                UZU_ACTIVATION_TRANSFORM_INPUT_RHT, 0, 0));
+        base_input = m->rht_scratch;
+    }
+    k::MatmulParams p{};
+    p.a = base_input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = output;
+    p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    p.b_kind = L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+    p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f, p.m = batch, p.n = L.n, p.k = L.k;
+    const char* variant = "matmul";
+    e.begin();
+    const uzu_status r = k::matmul(e.s, p, m->ctx->num_cus, &variant);
+    e.run(r, variant, k::matmul_algorithmic_bytes(p));
+    fp(m->lora_scratch, L.adapter_up, output, L.n, L.lora_rank, true);
+    if (L.out_signs)
+        RUN("activation_transform", 0, k::activation_transform(e.s, nullptr, output, nullptr, nullptr, nullptr, L.out_signs, UZU_BF16, batch, L.n,
+                                                                UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
+}
+
 void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false) {
+    if (L.lora_rank) return linear_qlora(e, L, input, output, batch); // (tensor-parallel shards of QLoRA linears are refused by the planner)
     const bool exchange = row_parallel && e.m->tp != nullptr;
     if (L.in_signs) {
         RUN("activation_transform", 0, k::activation_transform(e.s, input, e.m->rht_scratch, nullptr, nullptr, nullptr, L.in_signs, UZU_BF16, batch, L.k,
@@ -657,6 +708,10 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, token_ids, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
                                             hidden, UZU_BF16, rows, m->d.vocab_size, d, m->d.input_scale, m->embedding.group, m->embedding.bits,
                                             m->embedding.method));
+    // EmbeddingTable with output Hadamard factors (embedding_table.rs:34-125; quant_embedding.metal, use_hadamard): OutputRht of the rows
+    if (m->embedding.out_signs)
+        RUN("activation_transform", 0, k::activation_transform(s, nullptr, hidden, nullptr, nullptr, nullptr, m->embedding.out_signs, UZU_BF16, rows, d,
+                                                                UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
     for (uint32_t l = 0; l < m->d.num_layers; ++l) {
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
@@ -693,7 +748,11 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         if (sample) {
             const size_t last = ((size_t)i * count + count - 1) * d;
             norm(e, m->output_norm, hidden + last, m->last_normed, m->shortcut + last, 2, 1, d);
-            const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+            // Embedding::encode_readout (embedding.rs:374-456): the read-out's private InputRht -- a tied table's output signs
+            // (embedding.rs:167-173) or the untied output embedding's input signs (embedding.rs:255-274) -- then the plain matmul
+            DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+            ro.in_signs = m->d.tied_embeddings ? m->embedding.out_signs : m->output_embedding.in_signs;
+            ro.out_signs = nullptr;
             linear(e, ro, m->last_normed, m->logits, 1);
             if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
                 RUN("logit_transform", 0, k::logit_transform(s, m->logits, UZU_BF16, ro.n, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
@@ -777,7 +836,7 @@ void dec_gemv_row_parallel(Enc& e, k::DecGemvParams p, const char* name) {
 }
 
 bool linear_fusable(const DLinear& L) {
-    if (!L.w || L.in_signs || L.out_signs) return false; // RHT linears run as transform + matmul + transform (unfused decode)
+    if (!L.w || L.in_signs || L.out_signs || L.lora_rank) return false; // RHT / QLoRA linears run as their wrappers compose them (unfused decode)
     if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
     return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
 }
@@ -790,6 +849,7 @@ bool model_fusable(const uzu_hip_model* m) {
     if (!dim_fusable(m->d.model_dim)) return false;
     if (!norm_fusable(m->output_norm)) return false;
     if (!linear_fusable(m->d.tied_embeddings ? m->embedding : m->output_embedding)) return false;
+    if (m->embedding.in_signs || m->embedding.out_signs) return false; // RHT embedding rows: the commit kernel's lookup has no transform
     for (const DLayer& L : m->layers) {
         if (!norm_fusable(L.pre_mixer) || !norm_fusable(L.pre_mlp) || L.post_mixer.present || L.post_mlp.present) return false;
         if (!linear_fusable(L.up) || !linear_fusable(L.down)) return false;
@@ -1009,8 +1069,8 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         return s;
     };
 #define TRY(x) do { st = (x); if (st != UZU_OK) return fail(st); } while (0)
-    TRY(upload_linear(m, desc->embedding, &m->embedding));
-    if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding));
+    TRY(upload_linear(m, desc->embedding, &m->embedding, true));
+    if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding, true));
     TRY(upload_norm(m, desc->output_norm, d, &m->output_norm));
     m->max_positions = desc->max_context_length + kSuffixCapacity;
     m->layers.resize(desc->num_layers);
@@ -1111,6 +1171,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     }
     ALLOC(shortcut_b, uint16_t, C * d);
     if (m->rht_max_k) ALLOC(rht_scratch, uint16_t, CB * m->rht_max_k);
+    if (m->lora_max_rank) ALLOC(lora_scratch, uint16_t, CB * m->lora_max_rank);
     ALLOC(amax_val, float, kArgmaxPartials);
     ALLOC(amax_idx, uint32_t, kArgmaxPartials);
     if (max_qkv) {

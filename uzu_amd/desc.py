@@ -29,6 +29,7 @@ class LinearDesc(C.Structure):
         ("weights", C.c_void_p), ("scales", C.c_void_p), ("biases", C.c_void_p),
         ("zero_points", C.c_void_p), ("out_biases", C.c_void_p),
         ("input_signs", C.c_void_p), ("output_signs", C.c_void_p),
+        ("lora_rank", C.c_uint32), ("reserved2", C.c_uint32), ("adapter_down", C.c_void_p), ("adapter_up", C.c_void_p),
     ]
 
 
@@ -105,20 +106,26 @@ class LinearWeights:
     out_biases: Optional[np.ndarray] = None   # uint16 [n]
     input_signs: Optional[np.ndarray] = None  # int32 [k]  (HybridSpec InputOutput: RHTLinearWrapper, rht_wrapper.rs:140-298)
     output_signs: Optional[np.ndarray] = None  # int32 [n]
+    adapter_down: Optional[np.ndarray] = None  # bf16 bits [rank, k]  (HybridSpec adapter_spec LowRankSpec: QLoRALinearWrapper, qlora_wrapper.rs:61-252)
+    adapter_up: Optional[np.ndarray] = None    # bf16 bits [n, rank]
+
+    @property
+    def lora_rank(self) -> int:
+        return 0 if self.adapter_down is None else int(self.adapter_down.shape[0])
 
     def desc(self) -> LinearDesc:
         return LinearDesc(self.n, self.k, self.bits, self.group_size, self.method, 0, _ptr(self.weights),
                           _ptr(self.scales), _ptr(self.biases), _ptr(self.zero_points), _ptr(self.out_biases),
-                          _ptr(self.input_signs), _ptr(self.output_signs))
+                          _ptr(self.input_signs), _ptr(self.output_signs), self.lora_rank, 0, _ptr(self.adapter_down), _ptr(self.adapter_up))
 
     def nbytes(self) -> int:
         return sum(a.nbytes for a in (self.weights, self.scales, self.biases, self.zero_points, self.out_biases, self.input_signs,
-                                      self.output_signs) if a is not None)
+                                      self.output_signs, self.adapter_down, self.adapter_up) if a is not None)
 
     def rows(self, lo: int, hi: int) -> "LinearWeights":
         """Column-parallel shard: output rows [lo, hi) (any split is layout-safe, groups run along k)."""
-        if self.input_signs is not None or self.output_signs is not None:
-            raise NotImplementedError("tensor-parallel shards of RHT (HybridSpec) linears")
+        if self.input_signs is not None or self.output_signs is not None or self.adapter_down is not None:
+            raise NotImplementedError("tensor-parallel shards of RHT / QLoRA (HybridSpec) linears")
         sl = slice(lo, hi)
         cp = lambda a: None if a is None else np.ascontiguousarray(a[sl])
         return LinearWeights(hi - lo, self.k, self.bits, self.group_size, self.method, cp(self.weights),

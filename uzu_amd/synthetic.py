@@ -66,6 +66,8 @@ class ModelConfig:
     seed: int = 42
     logit_row_sigma: float = 0.6   # log-normal spread of per-token readout row norms (peaked logits)
     rht: bool = False              # every layer linear is a HybridSpec InputOutput linear (random +-1 sign vectors; not the embeddings)
+    rht_embeddings: bool = False   # HybridSpec Output / Input embeddings (embedding.rs:126-341): sign vectors over model_dim on the tables
+    qlora_rank: int = 0            # every layer linear carries a bf16 low-rank adapter of this rank (QLoRALinearWrapper); with `rht` also the signs
     sliding_windows: Optional[List[int]] = None  # per attention layer (in layer order): window size, 0 = full attention (Gemma / gpt-oss pattern)
     sinks: bool = False            # every attention layer carries per-head sink logits (mixer.sinks)
 
@@ -187,6 +189,11 @@ def make_linear(cfg: ModelConfig, name: str, n: int, k: int, gain: float = 1.0,
     if cfg.rht and name.startswith("layers.") and n % 32 == 0 and k % 32 == 0:  # whole 32-wide Hadamard blocks on both sides
         signs = np.array([-1, 1], np.int32)
         lw.input_signs, lw.output_signs = np.ascontiguousarray(rng.choice(signs, k)), np.ascontiguousarray(rng.choice(signs, n))
+    if cfg.qlora_rank and name.startswith("layers."):  # bf16 low-rank adapter next to the quantized base (a small correction: ~10 % of the base's output)
+        r2 = _rng(cfg.seed, name + ".adapter")
+        rank = cfg.qlora_rank
+        lw.adapter_down = f32_to_bf16_bits((r2.normal(0.0, 1.0, size=(rank, k)) / np.sqrt(k)).astype(np.float32))
+        lw.adapter_up = f32_to_bf16_bits((r2.normal(0.0, 0.1 * gain, size=(n, rank)) / np.sqrt(rank)).astype(np.float32))
     return lw
 
 
@@ -210,6 +217,11 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
     output_embedding = None
     if not cfg.tied_embeddings:
         output_embedding = make_linear(cfg, "output_embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
+    if cfg.rht_embeddings:  # HybridSpec Output mode on the (input) table, Input mode on an untied output embedding (embedding.rs:126-341)
+        signs = np.array([-1, 1], np.int32)
+        embedding.output_signs = np.ascontiguousarray(_rng(cfg.seed, "embedding.signs").choice(signs, d))
+        if output_embedding is not None:
+            output_embedding.input_signs = np.ascontiguousarray(_rng(cfg.seed, "output_embedding.signs").choice(signs, d))
     layers: List[D.LayerWeights] = []
     attn_index = 0
     for li, kind in enumerate(cfg.layer_kinds):
