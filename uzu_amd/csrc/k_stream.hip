@@ -559,27 +559,51 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(DecGemvParams p, S
 //     the same outputs --, streamed in SLICES of ks = 2048 (RGS 1) or 1024 (RGS 2) k: a slot = one slice of one unit = 16 KiB of codes in 16
 //     one-KiB pieces (a piece = one row's 1 KiB / two rows' 512 B; pieces are padded by 16 / 32 B in LDS so that the 16 rows of a B-operand read
 //     fall on 16 different bank quads) + 512 B of scales + 512 B of biases = kOpsPerSlot operations;
-//   * consumers form TEAMS of `ways` waves; team t owns units t, t + teams, ... of the CU and member j the slices j, j + ways, ... of its
-//     unit: every slot has ONE owner, who walks its slices in k order with the accumulator in a register -- no partial buffers, no atomics
-//     on the data path; with ways > 1 the members' partial sums meet in LDS and are added in member order by member 0 (fixed order:
-//     deterministic).  The loader issues slice-major over the teams' current units, so that all teams stream concurrently;
-//   * per 128-k super-step (= one quant group at group_size 128, the only one instantiated): 1 ds_read_b128 of codes, 4 ds_read_b128 of the
-//     activation row in packed-dot order (XPack, shared through LDS: 64 B per 32-k step), 16 conversions, 4 MFMAs in two chains, then
-//     acc = fma(scale, D, fma(bias - 16 scale, sum(x_group), acc)) -- the grouped form of gemv_core.h with the group's dot product from the
-//     matrix core.  Summation order differs from the register GEMV (MFMA tree inside a group, slices in k order): tolerance class, <= 1 bf16 ulp
-//     against the reference like every other production kernel; NOT bit-identical to gemv_dec.
+//   * the 15 consumer waves all help with the prologue; 12 of them stream, as 3 GANGS of 4: slot q belongs to gang q % 3, member m of the gang
+//     takes the items (16-row group, 128-k super-step) m, m + 4, m + 8, m + 12 of the slot's 16 -- four independent chains per wave and visit;
+//   * per item: 1 ds_read_b128 of codes, 4 ds_read_b128 of the activation row in packed-dot order (XPack, shared through LDS: 64 B per 32-k
+//     step; written directly by the Normalization prologue threads where a thread owns whole 8-blocks of the row), 16 conversions, 4 MFMAs in
+//     two chains, then acc = fma(scale, D, fma(bias - 16 scale, sum(x_group), acc)) -- the grouped form of gemv_core.h with the group's dot
+//     product from the matrix core and sum(x_group) from a table the prologue fills;
+//   * a unit's partial sums (<= 12 waves) meet in LDS; one member of the gang of the unit's last slice adds them in wave order (fixed:
+//     deterministic) and runs the epilogue.  Summation order differs from the register GEMV (MFMA tree inside a group, slices in k order):
+//     tolerance class, <= 1 bf16 ulp against the reference like every other production kernel; NOT bit-identical to gemv_dec;
+//   * the loader issues a full unit's 16 pieces as 4 runs of 4 (one M0 round trip per run, scalar row bases) and runs at the LDS-DMA rate
+//     (0.68 us per 16 KiB slot = 24 GB/s per CU = 6.2 TB/s: tools/timeline.py on the `down` shape).
+// Measured (r3, tools/kbench, us per launch, register GEMV in brackets): qkv 9.6 (7.9), out 5.3 (5.2), up+act 19.1 (16.5), down 9.0 (8.7),
+// Llama read-out 59.2 (53.3), Qwen3.5 read-out 37.6 (36.4): the matrix cores take the dot products off the VALU (the consumers keep up with the
+// loader), but every hand-off of a slot between loader and consumers costs >= 1 us of LDS-flag latency per visit, and nothing is left of the
+// run-ahead: NOT the default (UZU_STREAM_MFMA=1 / debug mode 3 select it; DESIGN.md section 3 has the other three decompositions tried).
 struct MfmaGeo {
     uint32_t ks;          // k per slice: 2048 (RGS 1) / 1024 (RGS 2)
     uint32_t n_slices;    // K / ks
-    uint32_t ways, teams; // consumers per unit; concurrent units (teams * ways <= consumers)
     uint32_t ring_slots, depth;
-    uint32_t piece_stride; // LDS bytes from piece to piece (1024 + pad)
     uint32_t off_scales, off_biases, slot_bytes;
     uint32_t units;       // units of the matrix (logical rows / rows per unit, rounded up)
-    uint32_t xp_off, st_off, xs_off, part_off; // dynamic-LDS offsets: packed activation row, per-step sums, f32 staging (PRO 1), partial sums
+    uint32_t direct;      // PRO 1: the prologue threads own whole 8-blocks of the row (K / 256 in {8, 16, 32}) and write it packed themselves
+    uint32_t pro_delay;   // PRO 1: s_sleep units the prologue waves wait before their first loads (the loader's first slot goes ahead of them)
+    uint32_t xp_off, sg_off, xs_off, part_off; // dynamic-LDS offsets: packed activation row, its sums per quant group, f32 staging (PRO 1), unit partials
 };
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
+
+// four LDS-DMA pieces with one M0 round trip: scalar bases b0 .. b3, LDS destinations lds_dst + {0, 1, 2, 3} * STEP
+template <uint32_t STEP>
+__device__ __forceinline__ void glds16p4_nt(uint32_t voff, const void* b0, const void* b1, const void* b2, const void* b3, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %4 nt\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5 nt\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %6 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "n"(STEP)
+                 : "memory", "scc");
+}
 
 template <bool ACT, int PRO, int RGS>
 __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p, MfmaGeo g) {
@@ -588,8 +612,11 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
     constexpr uint32_t ROWS = 16u * RGS;              // physical rows per unit
     constexpr uint32_t SUPER = KS / 128;              // super-steps (quant groups) per slice and row: 16 / 8
     constexpr uint32_t ROW_BYTES_SLICE = KS / 2;      // 1024 / 512
+    constexpr uint32_t PIECE = RGS == 1 ? 1040u : 1056u; // LDS bytes from piece to piece: 1 KiB + a pad that spreads the 16 rows of a B read over the banks
+    constexpr uint32_t kConsumers = 15;               // consumer waves: every one helps with the prologue ...
+    constexpr uint32_t NG = 3, GW = 4;                // ... and 3 gangs of 4 stream: slot q belongs to gang q % 3, each member takes 4 of its 16 items
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ uint32_t s_filled, s_sync, s_done[kMaxRing], s_team_cnt[16], s_team_rd[16];
+    __shared__ uint32_t s_filled, s_sync, s_done[kMaxRing], s_unit_cnt[2], s_unit_rd;
     __shared__ float s_red[4];
     __shared__ uint64_t s_exp_tab[32];
     __shared__ float s_bv[NW];
@@ -600,11 +627,8 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
     UZU_TL_STAMP(0);
     const uint32_t K = p.k, C = K / 32, row_bytes = K / 2, G = K / 128;
     const uint32_t half = p.n[0] / 2;                        // ACT: gate rows start here
-    const uint32_t n_log = ACT ? half : p.n[0];              // logical outputs
-    const uint32_t out_per_unit = ACT ? ROWS / 2 : ROWS;     // logical outputs per unit
-    const uint32_t S = g.ring_slots, teams = g.teams, ways = g.ways, n_slices = g.n_slices;
+    const uint32_t S = g.ring_slots, n_slices = g.n_slices;
     const uint32_t my_units = blockIdx.x < g.units ? (g.units - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t batches = (my_units + teams - 1) / teams;
     const uint32_t smem_base = lds_addr(smem);
     // physical row of unit-local row r (0 .. ROWS - 1) of global unit u; clamped into the matrix (a clamped row is streamed and never stored)
     auto phys_row = [&](uint32_t u, uint32_t r) -> uint32_t {
@@ -617,34 +641,61 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
         const uint32_t row = u * ROWS + r;
         return row < p.n[0] ? row : p.n[0] - 1;
     };
-    // slots of a batch are numbered slice-major over the batch's teams: q = first(b) + s * tb + t
-    auto teams_in_batch = [&](uint32_t b) -> uint32_t { return my_units - b * teams < teams ? my_units - b * teams : teams; };
-
-    auto issue_slot = [&](uint32_t b, uint32_t sl, uint32_t t, uint32_t pos) {
-        const uint32_t u = blockIdx.x + (b * teams + t) * gridDim.x;
-        const uint32_t slot_lds = __builtin_amdgcn_readfirstlane(smem_base + pos * g.slot_bytes);
-        const uint32_t voff16 = (uint32_t)lane * 16;
-        if constexpr (RGS == 1) { // a piece = 1 KiB of one row: scalar base + per-lane offset
-#pragma unroll 4
-            for (uint32_t piece = 0; piece < 16; ++piece) {
-                const uint8_t* src = p.w[0] + (size_t)phys_row(u, piece) * row_bytes + (size_t)sl * ROW_BYTES_SLICE;
-                glds16s_nt(voff16, src, slot_lds + piece * g.piece_stride);
-            }
-        } else { // a piece = 512 B of two consecutive unit rows
-            for (uint32_t piece = 0; piece < 16; ++piece) {
-                const uint32_t r = piece * 2 + ((uint32_t)lane >> 5);
-                const uint8_t* src = p.w[0] + (size_t)phys_row(u, r) * row_bytes + (size_t)sl * ROW_BYTES_SLICE + ((uint32_t)lane & 31) * 16;
-                glds16_nt(src, __builtin_amdgcn_readfirstlane(slot_lds + piece * g.piece_stride));
-            }
+    // ---- loader side: a unit's constants (scalar: the unit's four runs of consecutive rows; per lane: where its scale / bias words live)
+    struct UnitCtx {
+        uint32_t u, full;
+        uint32_t run_row[4]; // first physical row of pieces 4i .. 4i + 3
+        uint32_t sb_off[2];  // per lane: byte offset of its dword of slice 0 in the scale / bias tables, for the two 256-byte operations
+    };
+    constexpr uint32_t DW_PER_ROW = SUPER / 2; // dwords of scales per row and slice: 8 / 4
+    auto unit_ctx = [&](uint32_t ui) -> UnitCtx {
+        UnitCtx c;
+        c.u = blockIdx.x + ui * gridDim.x;
+        if (ACT) {
+            const uint32_t o0 = c.u * RGS * 8;
+            c.full = o0 + RGS * 8 <= half;
+            if (RGS == 1) c.run_row[0] = o0, c.run_row[1] = o0 + 4, c.run_row[2] = half + o0, c.run_row[3] = half + o0 + 4;
+            else c.run_row[0] = o0, c.run_row[1] = half + o0, c.run_row[2] = o0 + 8, c.run_row[3] = half + o0 + 8;
+        } else {
+            const uint32_t r0 = c.u * ROWS;
+            c.full = r0 + ROWS <= p.n[0];
+            for (int i = 0; i < 4; ++i) c.run_row[i] = r0 + (uint32_t)i * (ROWS / 4);
         }
-        // scales / biases of the slice: SUPER bf16 per row, rows side by side: [row][SUPER] -- 512 B each, two 256-byte operations
-        constexpr uint32_t DW_PER_ROW = SUPER / 2; // 8 / 4 dwords
 #pragma unroll
         for (uint32_t op = 0; op < 2; ++op) {
             const uint32_t flat = op * 64 + (uint32_t)lane, r = flat / DW_PER_ROW, dw = flat % DW_PER_ROW;
-            const size_t off = ((size_t)phys_row(u, r) * G + (size_t)sl * SUPER) * 2 + dw * 4;
-            glds4((const uint8_t*)p.scales[0] + off, __builtin_amdgcn_readfirstlane(slot_lds + g.off_scales + op * 256));
-            glds4((const uint8_t*)p.biases[0] + off, __builtin_amdgcn_readfirstlane(slot_lds + g.off_biases + op * 256));
+            c.sb_off[op] = phys_row(c.u, r) * G * 2 + dw * 4; // < 2^32: rows * groups * 2 bytes of one matrix
+        }
+        return c;
+    };
+    auto issue_slot = [&](const UnitCtx& c, uint32_t sl, uint32_t pos) {
+        const uint32_t slot_lds = __builtin_amdgcn_readfirstlane(smem_base + pos * g.slot_bytes);
+        const uint8_t* wsl = p.w[0] + (size_t)sl * ROW_BYTES_SLICE;
+        if (c.full) {
+            // RGS 1: a piece = 1 KiB of one row; RGS 2: a piece = 512 B of two consecutive rows (lanes 32.. take the second)
+            const uint32_t voff = RGS == 1 ? (uint32_t)lane * 16 : ((uint32_t)lane >> 5) * row_bytes + ((uint32_t)lane & 31) * 16;
+            const size_t step = (size_t)row_bytes * RGS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint8_t* b = wsl + (size_t)c.run_row[i] * row_bytes;
+                glds16p4_nt<PIECE>(voff, b, b + step, b + 2 * step, b + 3 * step, slot_lds + (uint32_t)i * 4 * PIECE);
+            }
+        } else if constexpr (RGS == 1) {
+            for (uint32_t piece = 0; piece < 16; ++piece)
+                glds16s_nt((uint32_t)lane * 16, wsl + (size_t)phys_row(c.u, piece) * row_bytes, slot_lds + piece * PIECE);
+        } else {
+            for (uint32_t piece = 0; piece < 16; ++piece) {
+                const uint32_t r = piece * 2 + ((uint32_t)lane >> 5);
+                glds16_nt(wsl + (size_t)phys_row(c.u, r) * row_bytes + ((uint32_t)lane & 31) * 16, __builtin_amdgcn_readfirstlane(slot_lds + piece * PIECE));
+            }
+        }
+        // scales / biases of the slice: SUPER bf16 per row, rows side by side: [row][SUPER] -- 512 B each, two 256-byte operations
+        const uint8_t* sc = (const uint8_t*)p.scales[0] + (size_t)sl * SUPER * 2;
+        const uint8_t* bi = (const uint8_t*)p.biases[0] + (size_t)sl * SUPER * 2;
+#pragma unroll
+        for (uint32_t op = 0; op < 2; ++op) {
+            glds4s(c.sb_off[op], sc, slot_lds + g.off_scales + op * 256);
+            glds4s(c.sb_off[op], bi, slot_lds + g.off_biases + op * 256);
         }
     };
 
@@ -654,14 +705,17 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
     f32x4_v n_pre[NPRE];
     uint64_t exp_entry = 0;
     if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
         if (tid == 0) {
-            s_filled = 0, s_sync = 0;
+            s_filled = 0, s_sync = 0, s_unit_cnt[0] = 0, s_unit_cnt[1] = 0, s_unit_rd = 0;
             for (uint32_t i = 0; i < kMaxRing; ++i) s_done[i] = 0;
-            for (uint32_t i = 0; i < 16; ++i) s_team_cnt[i] = 0, s_team_rd[i] = 0;
         }
-        if (my_units) issue_slot(0, 0, 0, 0);
+        if (my_units) issue_slot(unit_ctx(0), 0, 0);
         UZU_TL_STAMP(1);
     } else if (PRO == 1 && wave <= 4) {
+        // the vector memory path of a CU returns in order: let the loader's first slot go in front of the activation row (which has just been
+        // written by the previous launch and is slow to arrive), not behind it
+        for (uint32_t i = 0; i < g.pro_delay; ++i) __builtin_amdgcn_s_sleep(1);
         const uint32_t E = K / 256, pt = (uint32_t)tid - 64u;
 #pragma unroll
         for (int qi = 0; qi < NPRE; ++qi) {
@@ -681,22 +735,21 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
         UZU_TL_STAMP(7);
         uint32_t pos = 0, round = 0, q = 0;
         bool ok = true;
-        for (uint32_t b = 0; b < batches && ok; ++b) {
-            const uint32_t tb = teams_in_batch(b);
-            for (uint32_t sl = 0; sl < n_slices && ok; ++sl)
-                for (uint32_t t = 0; t < tb; ++t, ++q) {
-                    if (q) {
-                        if (round && !wait_ge(&s_done[pos], round, err, 1u)) { // one owner per slot: `round` completions so far
-                            ok = false;
-                            break;
-                        }
-                        issue_slot(b, sl, t, pos);
+        for (uint32_t ui = 0; ui < my_units && ok; ++ui) {
+            const UnitCtx c = unit_ctx(ui);
+            for (uint32_t sl = 0; sl < n_slices; ++sl, ++q) {
+                if (q) {
+                    if (round && !wait_ge(&s_done[pos], round * GW, err, 1u)) { // one gang per slot
+                        ok = false;
+                        break;
                     }
-                    if (D > 1) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                    if (q >= D) lds_store(&s_filled, q - D + 1);
-                    if (++pos == S) pos = 0, ++round;
+                    issue_slot(c, sl, pos);
                 }
+                if (D > 1) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                if (q >= D) lds_store(&s_filled, q - D + 1);
+                if (++pos == S) pos = 0, ++round;
+            }
         }
         if (q && ok) {
             if (D > 1) {
@@ -712,9 +765,8 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
         const int cw = wave - 1;                      // 0 .. 14
         const uint32_t ci = (uint32_t)cw * 64 + lane; // consumer-thread index, 960 of them
         uint32_t* xp = (uint32_t*)(smem + g.xp_off);  // [C][16] packed-dot words
-        float* st = (float*)(smem + g.st_off);        // [C] per-step sums
-        constexpr uint32_t kConsumers = 15;
-        // ---- the activation row -> LDS in packed-dot order + per-step sums ------------------------------------------------
+        float* sg = (float*)(smem + g.sg_off);        // [K / 128] sum of the activation row per quant group
+        // ---- the activation row -> LDS in packed-dot order + its partial sums ------------------------------------------------
         if constexpr (PRO == 0) {
             if (ACT && cw == 0 && lane < 32) s_exp_tab[lane] = kExp2fTab[lane];
             for (uint32_t c = ci; c < C; c += kConsumers * 64) {
@@ -727,7 +779,10 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
                     v.x = x.v[4 * w4], v.y = x.v[4 * w4 + 1], v.z = x.v[4 * w4 + 2], v.w = x.v[4 * w4 + 3];
                     dst[w4] = v;
                 }
-                st[c] = sx;
+                // a quant group = four steps = four neighbouring lanes (all of them in the loop together: C % 4 == 0)
+                float gs = sx + __shfl_xor(sx, 1, 64);
+                gs += __shfl_xor(gs, 2, 64);
+                if ((lane & 3) == 0) sg[c / 4] = gs;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) atomicAdd(&s_sync, 1u);
@@ -736,6 +791,7 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
             float* xs = (float*)(smem + g.xs_off); // C slots of 36 floats (normalization staging)
             const uint32_t E = K / 256;
             const uint32_t pt = (uint32_t)tid - 64u;
+            const bool direct = g.direct != 0; // the prologue threads write the packed row themselves (E in {8, 16, 32})
             if (cw < 4) {
                 if (ACT && cw == 0 && lane < 32) s_exp_tab[lane] = exp_entry;
                 float ss = 0.f;
@@ -771,6 +827,7 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
                 const float total = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
                 const float variance = total / (float)K - 0.0f * 0.0f;
                 const float rms_inv = 1.0f / sqrtf(variance + p.norm_eps);
+                float psum = 0.f, lo[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int qi = 0; qi < NPRE; ++qi) {
                     const uint32_t q = (uint32_t)qi * 4;
@@ -788,7 +845,22 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
                             else if (p.norm_full_layer) v[i] = round_bf16(normalized * (scl[i] + p.norm_offset));
                             else v[i] = round_bf16(round_bf16(normalized) * round_bf16(scl[i] + p.norm_offset));
                         }
-                        *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
+                        if (direct) {
+                            // packed-dot order: word s of an 8-block = (x[s], x[4 + s]); this thread owns whole 8-blocks (E % 8 == 0)
+                            if (qi & 1) {
+                                u32x4_v wv;
+                                wv.x = pack_bf16_pair(lo[0], v[0]), wv.y = pack_bf16_pair(lo[1], v[1]);
+                                wv.z = pack_bf16_pair(lo[2], v[2]), wv.w = pack_bf16_pair(lo[3], v[3]);
+                                *(u32x4_v*)(xp + (size_t)((e - 4) / 8) * 4) = wv;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) lo[i] = v[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) psum += v[i];
+                        } else {
+                            *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
+                        }
                         if (p.normed_out && blockIdx.x == 0) {
                             uint2 o;
                             o.x = (f32_to_bits(v[0]) >> 16) | (f32_to_bits(v[1]) & 0xFFFF0000u);
@@ -797,147 +869,164 @@ __global__ void __launch_bounds__(1024) gemv_stream_mfma_kernel(DecGemvParams p,
                         }
                     }
                 }
+                if (direct) { // a quant group = 128 / E neighbouring prologue threads (4, 8 or 16 lanes)
+                    const uint32_t nsum = 128u / E;
+                    psum += __shfl_xor(psum, 1, 64);
+                    psum += __shfl_xor(psum, 2, 64);
+                    if (nsum >= 8) psum += __shfl_xor(psum, 4, 64);
+                    if (nsum >= 16) psum += __shfl_xor(psum, 8, 64);
+                    if ((pt & (nsum - 1)) == 0) sg[pt / nsum] = psum;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(&s_sync, 1u);
             }
-            wait_ge(&s_sync, 8u, err, 2u); // the normalised row is complete in the f32 staging
-            for (uint32_t c = ci; c < C; c += kConsumers * 64) {
-                float xf[32];
-                const float4* xv = (const float4*)(xs + (size_t)c * 36);
+            wait_ge(&s_sync, 8u, err, 2u); // the normalised row is complete (packed, or in the f32 staging)
+            if (!direct) {
+                for (uint32_t c = ci; c < C; c += kConsumers * 64) {
+                    float xf[32];
+                    const float4* xv = (const float4*)(xs + (size_t)c * 36);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 t = xv[i];
-                    xf[4 * i] = t.x, xf[4 * i + 1] = t.y, xf[4 * i + 2] = t.z, xf[4 * i + 3] = t.w;
-                }
-                XPack x;
-                xpack_from_f32(x, xf);
-                u32x4_v* dst = (u32x4_v*)(xp + (size_t)c * 16);
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 t = xv[i];
+                        xf[4 * i] = t.x, xf[4 * i + 1] = t.y, xf[4 * i + 2] = t.z, xf[4 * i + 3] = t.w;
+                    }
+                    XPack x;
+                    xpack_from_f32(x, xf);
+                    u32x4_v* dst = (u32x4_v*)(xp + (size_t)c * 16);
 #pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) {
-                    u32x4_v v;
-                    v.x = x.v[4 * w4], v.y = x.v[4 * w4 + 1], v.z = x.v[4 * w4 + 2], v.w = x.v[4 * w4 + 3];
-                    dst[w4] = v;
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        u32x4_v v;
+                        v.x = x.v[4 * w4], v.y = x.v[4 * w4 + 1], v.z = x.v[4 * w4 + 2], v.w = x.v[4 * w4 + 3];
+                        dst[w4] = v;
+                    }
+                    const float sx = sum32(xf);
+                    float gs = sx + __shfl_xor(sx, 1, 64);
+                    gs += __shfl_xor(gs, 2, 64);
+                    if ((lane & 3) == 0) sg[c / 4] = gs;
                 }
-                st[c] = sum32(xf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_sync, 1u);
+                wait_ge(&s_sync, 8u + kConsumers, err, 2u);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) atomicAdd(&s_sync, 1u);
-            wait_ge(&s_sync, 8u + kConsumers, err, 2u);
         }
         if (cw == 0) UZU_TL_STAMP(2);
 
-        // ---- streaming ------------------------------------------------------------------------------------------------------
+        // ---- streaming: slot q belongs to gang q % 3; member m of the gang takes items m, m + 4, m + 8, m + 12 of its 16 --------------
         float best_v = -INFINITY;
         uint32_t best_i = 0xFFFFFFFFu;
-        const uint32_t team = (uint32_t)cw / ways, member = (uint32_t)cw % ways;
         const uint32_t jcol = (uint32_t)lane & 15, kb = (uint32_t)lane >> 4;
+        const uint32_t gang = (uint32_t)cw / GW, member = (uint32_t)cw % GW; // consumers 12 .. 14 only helped with the prologue
+        const uint32_t inv_gangs = n_slices < NG ? n_slices : NG;           // gangs that meet in a unit
+        const uint32_t others = inv_gangs * GW - 1;                          // partial sums a unit's combiner waits for
         uint32_t mask = 0x00780078u, magic = 0x41804180u;
         asm("" : "+s"(mask));
         asm("" : "+v"(magic));
-        if (team < teams) {
-            uint32_t q0 = 0; // slot number of (batch b, slice 0, team 0)
-            bool ok = true;
-            for (uint32_t b = 0; b < batches && ok; ++b) {
-                const uint32_t tb = teams_in_batch(b);
-                if (team < tb) {
-                    const uint32_t u = blockIdx.x + (b * teams + team) * gridDim.x;
-                    float acc[RGS];
+        uint32_t pos = 0, q = 0, qg = 0; // qg = q % NG
+        bool ok = gang < NG;
+        for (uint32_t ui = 0; ui < my_units && ok; ++ui) {
+            const uint32_t u = blockIdx.x + ui * gridDim.x;
+            const uint32_t g_first = qg;                                     // gang of the unit's first slice
+            float acc[RGS];
 #pragma unroll
-                    for (int rq = 0; rq < RGS; ++rq) acc[rq] = 0.f;
-                    for (uint32_t sl = member; sl < n_slices; sl += ways) {
-                        const uint32_t q = q0 + sl * tb + team;
-                        if (!wait_ge(&s_filled, q + 1, err, 4u)) {
-                            ok = false;
-                            break;
-                        }
-                        const uint32_t pos = q % S;
-                        const uint8_t* slot = smem + (size_t)pos * g.slot_bytes;
-#pragma unroll
-                        for (int rq = 0; rq < RGS; ++rq) {
-                            const uint32_t r = (uint32_t)rq * 16 + jcol; // this lane's B column = unit row r
-                            const uint8_t* rowp = RGS == 1 ? slot + r * g.piece_stride : slot + (r >> 1) * g.piece_stride + (r & 1) * 512;
-                            const uint16_t* scp = (const uint16_t*)(slot + g.off_scales) + r * SUPER;
-                            const uint16_t* bip = (const uint16_t*)(slot + g.off_biases) + r * SUPER;
-#pragma unroll 2
-                            for (uint32_t ss = 0; ss < SUPER; ++ss) {
-                                const u32x4_v wl = *(const u32x4_v*)(rowp + ss * 64 + kb * 16);
-                                const uint32_t cstep = (sl * KS) / 32 + ss * 4 + kb; // this lane's 32-k step of the activation row
-                                const u32x4_v* xa = (const u32x4_v*)(xp + (size_t)cstep * 16);
-                                const uint32_t ws[4] = {wl.x, wl.y, wl.z, wl.w};
-                                mf_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                for (int w = 0; w < 4; ++w) {
-                                    u32x4_v bv;
-                                    bv.x = ((ws[w] << 3) & mask) | magic, bv.y = ((ws[w] >> 1) & mask) | magic;
-                                    bv.z = ((ws[w] >> 5) & mask) | magic, bv.w = ((ws[w] >> 9) & mask) | magic;
-                                    const u32x4_v av = xa[w];
-                                    if (w & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bv), d1, 0, 0, 0);
-                                    else d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bv), d0, 0, 0, 0);
-                                }
-                                const uint32_t gidx = sl * SUPER + ss; // quant group = super-step
-                                const float sxg = (st[4 * gidx] + st[4 * gidx + 1]) + (st[4 * gidx + 2] + st[4 * gidx + 3]);
-                                const float sc = bf16_to_f32(scp[ss]);
-                                float of = bf16_to_f32(bip[ss]);
-                                of = fmaf(-kQ4Offset, sc, of);
-                                acc[rq] = fmaf(sc, d0.x + d1.x, fmaf(of, sxg, acc[rq]));
-                            }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) atomicAdd(&s_done[pos], 1u);
+            for (int rq = 0; rq < RGS; ++rq) acc[rq] = 0.f;
+            for (uint32_t sl = 0; sl < n_slices; ++sl, ++q) {
+                if (qg == gang) {
+                    if (!wait_ge(&s_filled, q + 1, err, 4u)) {
+                        ok = false;
+                        break;
                     }
-                    if (!ok) break;
-                    // members' partial sums meet in LDS, member 0 adds them in member order (deterministic)
-                    if (ways > 1) {
-                        float* part = (float*)(smem + g.part_off) + (size_t)(b & 1) * 16 * 32; // [parity][consumer][32]
-                        if (member) {
-                            // two parities: batch b's partial may only be written once member 0 has read batch b - 2's
-                            if (b >= 2 && !wait_ge(&s_team_rd[team], b - 1, err, 16u)) break;
-                            if (kb == 0) {
+                    const uint8_t* slot = smem + (size_t)pos * g.slot_bytes;
 #pragma unroll
-                                for (int rq = 0; rq < RGS; ++rq) part[(size_t)cw * 32 + rq * 16 + jcol] = acc[rq];
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (lane == 0) atomicAdd(&s_team_cnt[team], 1u);
-                        } else {
-                            if (!wait_ge(&s_team_cnt[team], (b + 1) * (ways - 1), err, 16u)) break;
-                            for (uint32_t m2 = 1; m2 < ways; ++m2) {
+                    for (int it = 0; it < 4; ++it) {
+                        constexpr int kHalf = RGS == 1 ? 4 : 2;                  // items per row group: 16 / 8 super-steps over 4 members
+                        const int rq = it / kHalf;
+                        const uint32_t ss = (uint32_t)(it % kHalf) * 4 + member;
+                        const uint32_t r = (uint32_t)rq * 16 + jcol; // this lane's B column = unit row r
+                        const uint8_t* rowp = RGS == 1 ? slot + r * PIECE : slot + (r >> 1) * PIECE + (r & 1) * 512;
+                        const u32x4_v wl = *(const u32x4_v*)(rowp + ss * 64 + kb * 16);
+                        const uint32_t cstep = (sl * KS) / 32 + ss * 4 + kb; // this lane's 32-k step of the activation row
+                        const u32x4_v* xa = (const u32x4_v*)(xp + (size_t)cstep * 16);
+                        const float sxg = sg[sl * SUPER + ss];               // quant group = super-step
+                        const float sc = bf16_to_f32(((const uint16_t*)(slot + g.off_scales))[r * SUPER + ss]);
+                        float of = bf16_to_f32(((const uint16_t*)(slot + g.off_biases))[r * SUPER + ss]);
+                        const uint32_t ws[4] = {wl.x, wl.y, wl.z, wl.w};
+                        mf_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                                for (int rq = 0; rq < RGS; ++rq) acc[rq] += part[(size_t)(cw + m2) * 32 + rq * 16 + jcol];
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (lane == 0) atomicAdd(&s_team_rd[team], 1u);
+                        for (int w = 0; w < 4; ++w) {
+                            u32x4_v bv;
+                            bv.x = ((ws[w] << 3) & mask) | magic, bv.y = ((ws[w] >> 1) & mask) | magic;
+                            bv.z = ((ws[w] >> 5) & mask) | magic, bv.w = ((ws[w] >> 9) & mask) | magic;
+                            const u32x4_v av = xa[w];
+                            if (w & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bv), d1, 0, 0, 0);
+                            else d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bv), d0, 0, 0, 0);
                         }
+                        of = fmaf(-kQ4Offset, sc, of);
+                        acc[rq] = fmaf(sc, d0.x + d1.x, fmaf(of, sxg, acc[rq]));
                     }
-                    if (member == 0) {
-                        // epilogue: lane j (< 16) holds row j of every 16-row group (all lanes with lane & 15 == j hold the same value)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(&s_done[pos], 1u);
+                }
+                if (++pos == S) pos = 0;
+                if (++qg == NG) qg = 0;
+            }
+            if (!ok) break;
+            // does this gang hold a part of the unit?  (slices went to gangs g_first, g_first + 1, ... mod 3)
+            const uint32_t dist = gang >= g_first ? gang - g_first : gang + NG - g_first;
+            if (dist >= inv_gangs) continue;
+            // the partial sums of the unit meet in LDS; one member of the gang of the LAST slice adds them in consumer order (fixed:
+            // deterministic) and writes the unit's outputs.  Two parities: unit ui's partials may be written once unit ui - 2's have been read
+            // (the read acknowledgements are handed on in unit order).
+            float* part = (float*)(smem + g.part_off) + (size_t)(ui & 1) * 16 * 32; // [parity][consumer][32]
+            const uint32_t g_last = (g_first + n_slices - 1) % NG;
+            const uint32_t comb = g_last * GW + (ui & (GW - 1));
+            if ((uint32_t)cw != comb) {
+                if (ui >= 2 && !wait_ge(&s_unit_rd, ui - 1, err, 16u)) break;
+                if (kb == 0) {
 #pragma unroll
-                        for (int rq = 0; rq < RGS; ++rq) {
-                            if constexpr (ACT) {
-                                const uint32_t o = (u * RGS + (uint32_t)rq) * 8 + (jcol & 7);
-                                float value = 1.0f * acc[rq];
-                                const bool valid = o < half;
-                                if (p.out_bias[0] && valid) value += bf16_to_f32(p.out_bias[0][jcol < 8 ? o : half + o]);
-                                const float vb = round_bf16(value);
-                                const float gate_b = __shfl(vb, (lane & 7) + 8, 64); // the gate row of output (lane & 7) sits 8 lanes up
-                                if (lane < 8 && valid) p.out[0][o] = f32_to_bf16(round_bf16(vb * act_bf16(p.act_type, gate_b, s_exp_tab))); // gated_act_mul/mod.rs:5-12
-                            } else {
-                                const uint32_t row = u * ROWS + (uint32_t)rq * 16 + jcol;
-                                if (lane < 16 && row < p.n[0]) {
-                                    float value = 1.0f * acc[rq];
-                                    if (p.out_bias[0]) value += bf16_to_f32(p.out_bias[0][row]);
-                                    const uint16_t ob = f32_to_bf16(value);
-                                    if (p.out_f32) p.out_f32[row] = value;
-                                    else p.out[0][row] = ob;
-                                    if (p.part_val) {
-                                        const float lv = bf16_to_f32(ob);
-                                        if (lv > best_v || (lv == best_v && row < best_i)) best_v = lv, best_i = row;
-                                    }
-                                }
-                            }
+                    for (int rq = 0; rq < RGS; ++rq) part[(size_t)cw * 32 + rq * 16 + jcol] = acc[rq];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_unit_cnt[ui & 1], 1u);
+                continue;
+            }
+            if (!wait_ge(&s_unit_cnt[ui & 1], ((ui >> 1) + 1) * others, err, 16u)) break;
+            float tot[RGS];
+#pragma unroll
+            for (int rq = 0; rq < RGS; ++rq) tot[rq] = 0.f;
+            for (uint32_t m2 = 0; m2 < NG * GW; ++m2) {
+                const uint32_t g2 = m2 / GW, d2 = g2 >= g_first ? g2 - g_first : g2 + NG - g_first;
+                if (d2 >= inv_gangs) continue;
+#pragma unroll
+                for (int rq = 0; rq < RGS; ++rq) tot[rq] += m2 == (uint32_t)cw ? acc[rq] : part[(size_t)m2 * 32 + rq * 16 + jcol];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ui && !wait_ge(&s_unit_rd, ui, err, 16u)) break; // acknowledge in unit order
+            if (lane == 0) atomicAdd(&s_unit_rd, 1u);
+            // epilogue: lane j (< 16) holds row j of every 16-row group (all lanes with lane & 15 == j hold the same value)
+#pragma unroll
+            for (int rq = 0; rq < RGS; ++rq) {
+                if constexpr (ACT) {
+                    const uint32_t o = (u * RGS + (uint32_t)rq) * 8 + (jcol & 7);
+                    float value = 1.0f * tot[rq];
+                    const bool valid = o < half;
+                    if (p.out_bias[0] && valid) value += bf16_to_f32(p.out_bias[0][jcol < 8 ? o : half + o]);
+                    const float vb = round_bf16(value);
+                    const float gate_b = __shfl(vb, (lane & 7) + 8, 64); // the gate row of output (lane & 7) sits 8 lanes up
+                    if (lane < 8 && valid) p.out[0][o] = f32_to_bf16(round_bf16(vb * act_bf16(p.act_type, gate_b, s_exp_tab))); // gated_act_mul/mod.rs:5-12
+                } else {
+                    const uint32_t row = u * ROWS + (uint32_t)rq * 16 + jcol;
+                    if (lane < 16 && row < p.n[0]) {
+                        float value = 1.0f * tot[rq];
+                        if (p.out_bias[0]) value += bf16_to_f32(p.out_bias[0][row]);
+                        const uint16_t ob = f32_to_bf16(value);
+                        if (p.out_f32) p.out_f32[row] = value;
+                        else p.out[0][row] = ob;
+                        if (p.part_val) {
+                            const float lv = bf16_to_f32(ob);
+                            if (lv > best_v || (lv == best_v && row < best_i)) best_v = lv, best_i = row;
                         }
                     }
                 }
-                q0 += n_slices * tb;
             }
         }
         if (cw == 0) UZU_TL_STAMP(4);
@@ -1018,10 +1107,10 @@ bool gemv_stream_supported(const DecGemvParams& p) {
     return true;
 }
 
-static bool stream_mfma_on() { // UZU_STREAM_MFMA=0: dot2 consumers everywhere (A/B runs); debug mode 3 forces the matrix-core consumers
+static bool stream_mfma_on() { // UZU_STREAM_MFMA=1 / debug mode 3: matrix-core consumers where supported (measured slower: A/B runs and tests)
     static const int env = [] {
         const char* e = getenv("UZU_STREAM_MFMA");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 0;
     }();
     return g_stream_override == 3 || (g_stream_override < 0 && env != 0);
 }
@@ -1039,8 +1128,10 @@ bool gemv_stream_wanted(const DecGemvParams& p) {
     const int mode = g_stream_override >= 0 ? g_stream_override : stream_mode();
     if (mode == 0 || exact_mode() || !(gemv_stream_supported(p) || (stream_mfma_on() && gemv_stream_mfma_supported(p)))) return false;
     if (mode >= 2) return true;
+    // default: only where the LDS stream measured faster than the register GEMV -- short rows in the bandwidth regime (the Qwen3.5 read-out,
+    // 248320 x 1024: 33.0 against 36.4 us); at K >= 4096 it ties or loses (profiles/r3_kbench_stream_ab.txt)
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
-    return weight_bytes >= (8ull << 20); // the bandwidth regime: >= 2 slots per CU
+    return weight_bytes >= (64ull << 20) && p.k <= 2048;
 }
 
 template <int CPL, bool ACT, int PRO, int NW>
@@ -1103,27 +1194,22 @@ uzu_status gemv_stream_mfma(hipStream_t s, const DecGemvParams& p_in, int num_cu
     g.units = (n_log + out_per_unit - 1) / out_per_unit;
     uint32_t grid = g.units < (uint32_t)num_cus ? g.units : (uint32_t)num_cus;
     if (p.part_val && p.part_capacity && grid > p.part_capacity) grid = p.part_capacity;
-    const uint32_t upc = (g.units + grid - 1) / grid; // units per CU
-    static const int ways_env = [] { // UZU_STREAM_WAYS: consumers per unit (A/B runs); 0 = by the CU's unit count
-        const char* e = getenv("UZU_STREAM_WAYS");
-        return e ? atoi(e) : 0;
-    }();
-    uint32_t ways = 1;
-    if (upc < 15) ways = 15 / upc;
-    if (ways > 4) ways = 4;
-    if (ways_env > 0) ways = (uint32_t)ways_env;
-    if (ways > g.n_slices) ways = g.n_slices;
-    if (ways < 1) ways = 1;
-    g.ways = ways, g.teams = 15 / ways;
-    g.piece_stride = rgs == 1 ? 1040u : 1056u;
-    g.off_scales = 16 * g.piece_stride, g.off_biases = g.off_scales + 512, g.slot_bytes = g.off_biases + 512;
+    const uint32_t piece_stride = rgs == 1 ? 1040u : 1056u;
+    g.off_scales = 16 * piece_stride, g.off_biases = g.off_scales + 512, g.slot_bytes = g.off_biases + 512;
     static const int depth_env = [] {
         const char* e = getenv("UZU_STREAM_DEPTH");
         return e ? atoi(e) : 2;
     }();
     g.depth = depth_env >= 2 ? 2 : 1;
     const size_t C = p.k / 32;
-    const size_t xp_bytes = (size_t)p.k * 2, st_bytes = (C * 4 + 15) / 16 * 16, xs_bytes = normed ? (C * 36 + 16) * sizeof(float) : 0, part_bytes = 2 * 16 * 32 * 4;
+    const uint32_t E = p.k / 256;
+    g.direct = normed && (E == 8 || E == 16 || E == 32); // the prologue threads own whole 8-blocks of the row: they pack it themselves
+    static const int delay_env = [] { // UZU_STREAM_PRO_DELAY: s_sleep units before the prologue waves' first loads (A/B runs)
+        const char* e = getenv("UZU_STREAM_PRO_DELAY");
+        return e ? atoi(e) : 8;
+    }();
+    g.pro_delay = delay_env > 0 ? (uint32_t)delay_env : 0;
+    const size_t xp_bytes = (size_t)p.k * 2, st_bytes = ((size_t)p.k / 128 * 4 + 15) / 16 * 16, xs_bytes = normed ? (C * 36 + 16) * sizeof(float) : 0, part_bytes = 2 * 16 * 32 * 4;
     const size_t budget = 160u * 1024 - 2048;
     uint32_t ring = (uint32_t)((budget - xp_bytes - st_bytes - xs_bytes - part_bytes) / g.slot_bytes);
     if (ring > kMaxRing) ring = kMaxRing;
@@ -1133,8 +1219,8 @@ uzu_status gemv_stream_mfma(hipStream_t s, const DecGemvParams& p_in, int num_cu
     }
     g.ring_slots = ring;
     g.xp_off = ring * g.slot_bytes;
-    g.st_off = g.xp_off + (uint32_t)xp_bytes;
-    g.xs_off = g.st_off + (uint32_t)st_bytes;
+    g.sg_off = g.xp_off + (uint32_t)xp_bytes;
+    g.xs_off = g.sg_off + (uint32_t)st_bytes;
     g.part_off = g.xs_off + (uint32_t)xs_bytes;
     const size_t lds = (size_t)g.part_off + part_bytes;
     if (grid_out) *grid_out = grid;
