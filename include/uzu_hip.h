@@ -211,7 +211,8 @@ uzu_status uzu_hip_attention_prepare_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* c
                                             uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim);
 
 /* ---- AttentionSinglePass / TwoPass1 / TwoPass2 (cpu/kernel/attention/attention_{single,two}_pass.rs)
- * trie (speculative tree) variants: UZU_ERR_UNSUPPORTED. */
+ * is_trie: `trie` holds one TrieNode {uint32 trie_start, trie_end, height} (BU/gpu_types/trie.rs) per suffix token -- a speculated tree in
+ * depth-first order; mask.rs:21-29.  `trie` must be given iff the kernel was created with is_trie. */
 typedef struct { uint32_t ring_offset, ring_length; } uzu_ring_params; /* BU/gpu_types/ring.rs */
 uzu_status uzu_hip_attention_single_pass_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_dim,
                                                 uint32_t has_sinks, uint32_t is_kv_cache_ring, uint32_t is_causal,

@@ -65,6 +65,7 @@ class AttentionArgs(C.Structure):
         ("is_kv_cache_ring", C.c_uint32), ("ring_offset", C.c_uint32), ("ring_length", C.c_uint32),
         ("scale", C.c_float), ("is_sliding_window", C.c_uint32), ("sliding_window_size", C.c_uint32),
         ("sinks", C.c_void_p), ("num_heads", C.c_uint32), ("suffix_length", C.c_uint32), ("is_causal", C.c_uint32),
+        ("trie", C.c_void_p),  # uint32 [suffix, 3] = {trie_start, trie_end, height} per suffix token, or None
     ]
 
 

@@ -121,7 +121,7 @@ void orc_attention_prepare(const uint16_t* qkv, uint16_t* queries, uint16_t* key
                            uint32_t head_dim, uint32_t rope_dim /* 0 => no rope */, uint32_t kv_token_offset,
                            uint32_t batch_dim, uint32_t has_kv);
 
-/* ---- attention cores (attention_single_pass.rs / attention_two_pass.rs / mask.rs), non-trie ---- */
+/* ---- attention cores (attention_single_pass.rs / attention_two_pass.rs / mask.rs) ---- */
 typedef struct {
     const void* queries; /* [heads, suffix, hd] */
     const void* keys;
@@ -134,6 +134,7 @@ typedef struct {
     uint32_t is_sliding_window, sliding_window_size;
     const void* sinks; /* dtype [heads] or NULL */
     uint32_t num_heads, suffix_length, is_causal;
+    const uint32_t* trie; /* is_trie: {trie_start, trie_end, height} per suffix token (gpu_types/trie.rs), or NULL */
 } orc_attention_args;
 void orc_attention_single_pass(const orc_attention_args* a, void* out /* [suffix, heads, hd] */);
 void orc_attention_two_pass1(const orc_attention_args* a, float* partials, float* sums, float* maxs);

@@ -408,15 +408,21 @@ void orc_attention_prepare(const uint16_t* qkv, uint16_t* queries, uint16_t* key
 }
 
 /* ------------------------------------------------------------------ attention mask
- * BU/cpu/kernel/attention/mask.rs:3-61 (trie == None). */
+ * BU/cpu/kernel/attention/mask.rs:3-61. */
 static inline int should_use_key(const orc_attention_args* a, uint32_t q_seq_idx, uint32_t prefix_length,
                                  uint32_t suffix_position, uint32_t query_position, uint32_t i) {
     int use_key = 1;
     uint32_t key_position;
     if (i >= prefix_length) {
         const uint32_t key_position_in_suffix = i - prefix_length;
-        key_position = suffix_position + key_position_in_suffix;
-        if (a->is_causal) use_key &= key_position_in_suffix <= q_seq_idx;
+        if (a->trie) {
+            const uint32_t* trie_node = a->trie + 3 * (size_t)key_position_in_suffix; /* {trie_start, trie_end, height} */
+            key_position = suffix_position + trie_node[2];
+            if (a->is_causal) use_key &= q_seq_idx >= trie_node[0] && q_seq_idx <= trie_node[1];
+        } else {
+            key_position = suffix_position + key_position_in_suffix;
+            if (a->is_causal) use_key &= key_position_in_suffix <= q_seq_idx;
+        }
     } else {
         if (a->is_kv_cache_ring) {
             key_position = (prefix_length + i - a->ring_offset) % prefix_length;
@@ -450,7 +456,7 @@ void orc_attention_single_pass(const orc_attention_args* a, void* out) {
         const uint32_t kv_head_idx = head_idx / a->gqa_factor;
         const size_t o_offset = (size_t)q_seq_idx * a->num_heads + head_idx;
         const size_t q_offset = (size_t)head_idx * a->suffix_length + q_seq_idx;
-        const uint32_t query_position = suffix_position + q_seq_idx;
+        const uint32_t query_position = suffix_position + (a->trie ? a->trie[3 * (size_t)q_seq_idx + 2] : q_seq_idx); /* attention_single_pass.rs:55-61 */
         float* q = (float*)malloc(sizeof(float) * HD * 2);
         float* o = q + HD;
         for (uint32_t j = 0; j < HD; ++j) {
@@ -493,7 +499,7 @@ void orc_attention_two_pass1(const orc_attention_args* a, float* partials, float
         const uint32_t block_idx = (uint32_t)(idx % ORC_TOTAL_BLOCKS_COUNT);
         const size_t hq = idx / ORC_TOTAL_BLOCKS_COUNT;
         const uint32_t head_idx = (uint32_t)(hq / a->suffix_length), q_seq_idx = (uint32_t)(hq % a->suffix_length);
-        const uint32_t query_position = suffix_position + q_seq_idx;
+        const uint32_t query_position = suffix_position + (a->trie ? a->trie[3 * (size_t)q_seq_idx + 2] : q_seq_idx); /* attention_single_pass.rs:55-61 */
         const size_t o_offset = (size_t)q_seq_idx * a->num_heads + head_idx;
         const size_t q_offset = (size_t)head_idx * a->suffix_length + q_seq_idx;
         const uint32_t kv_head_idx = head_idx / a->gqa_factor;

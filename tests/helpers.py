@@ -120,8 +120,34 @@ def mask_case(variant, seq, suffix, heads, window_scale=1, ring_scale=1):
     return is_causal, (window * window_scale if window else None), ring_params, sinks
 
 
-def attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, k_head_stride, k_seq_stride, scale, is_causal, window, ring_params, sinks):
-    """Independent float64 statement of attention_single_pass.rs:37-127 + mask.rs:3-61 (non-trie): returns [suffix, heads, hd]."""
+def trie_from_parents(parents):
+    """Flat trie buffer (gpu_types/trie.rs: {trie_start, trie_end, height} per node) of a speculated tree given as parent indices in
+    depth-first order (parents[i] < i, -1 = a root): a node's subtree is the index range [i, trie_end]."""
+    n = len(parents)
+    height = [0] * n
+    end = list(range(n))
+    for i in range(n):
+        assert parents[i] < i
+        if parents[i] >= 0:
+            height[i] = height[parents[i]] + 1
+    for i in range(n - 1, -1, -1):
+        if parents[i] >= 0:
+            assert end[parents[i]] <= end[i] or end[parents[i]] >= i, "parents must be in depth-first order"
+            end[parents[i]] = max(end[parents[i]], end[i])
+    return np.array([[i, end[i], height[i]] for i in range(n)], np.uint32)
+
+
+def attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, k_head_stride, k_seq_stride, scale, is_causal, window, ring_params, sinks, parents=None):
+    """Independent float64 statement of attention_single_pass.rs:37-127 + mask.rs:3-61: returns [suffix, heads, hd].  `parents` (a speculated
+    tree as parent indices): a query sees the suffix keys on its own root path, every token sits at prefix + its depth."""
+    depth, anc = None, None
+    if parents is not None:
+        depth = [0] * suffix
+        anc = [set([i]) for i in range(suffix)]
+        for i in range(suffix):
+            if parents[i] >= 0:
+                depth[i] = depth[parents[i]] + 1
+                anc[i] |= anc[parents[i]]
     qf, kf, vf = f32(q).astype(np.float64), f32(k).astype(np.float64), f32(v).astype(np.float64)
     prefix = seq - suffix
     suffix_position = ring_params[1] if ring_params else prefix
@@ -131,11 +157,15 @@ def attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, k_head_stride, 
         kvh = h // gqa
         for qi in range(suffix):
             qv = qf.reshape(-1)[(h * suffix + qi) * hd:(h * suffix + qi + 1) * hd] * scale
-            query_position = suffix_position + qi
+            query_position = suffix_position + (depth[qi] if parents is not None else qi)
             scores, vals = [], []
             for i in range(seq):
                 use = True
-                if i >= prefix:
+                if i >= prefix and parents is not None:
+                    key_position = suffix_position + depth[i - prefix]
+                    if is_causal:
+                        use &= (i - prefix) in anc[qi]
+                elif i >= prefix:
                     key_position = suffix_position + (i - prefix)
                     if is_causal:
                         use &= (i - prefix) <= qi

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import MASK_VARIANTS, bf16, f32, mask_case, quant_matrix, ref_attention_inputs, ulp_diff_bf16
+from helpers import MASK_VARIANTS, bf16, f32, mask_case, quant_matrix, ref_attention_inputs, trie_from_parents, ulp_diff_bf16
 from oracle import oracle as O
 from uzu_amd import _ffi
 from uzu_amd import backend as B
@@ -715,6 +715,114 @@ def test_attention_two_pass_mask_variants(hip_ctx, variant, heads, kv_heads, hd,
     err = np.abs(f32(want) - f32(got))
     assert err.max() <= 1e-2
     assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+
+
+TRIE_PARENTS = {
+    "chain": [-1, 0, 1, 2, 3],
+    "two_branches": [-1, 0, 1, 1, 0, 4],
+    "bushy": [-1, 0, 1, 2, 1, 0, 5, 5, 7, -1, 9],
+}
+
+
+@pytest.mark.parametrize("tree", sorted(TRIE_PARENTS))
+@pytest.mark.parametrize("window", [None, 6])
+@pytest.mark.parametrize("heads,kv_heads,hd,prefix", [(8, 2, 128, 70), (4, 4, 64, 0), (8, 2, 256, 1200)])
+def test_attention_trie_mask(hip_ctx, tree, window, heads, kv_heads, hd, prefix):
+    """is_trie (mask.rs:21-29, attention_single_pass.rs:55-61): the tokens of a speculated tree as the suffix, through the single-pass and the
+    split-KV kernels against the restatement (pinned by tests/test_oracle_kernels.py::test_attention_trie_mask_against_float64)."""
+    parents = TRIE_PARENTS[tree]
+    suffix = len(parents)
+    seq = prefix + suffix
+    trie = trie_from_parents(parents)
+    rng = np.random.default_rng(prefix + hd + suffix)
+    q, k, v, _ = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    scale = 1.0 / np.sqrt(hd)
+    w = (window * 40 if prefix > 400 else window) if window else None
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd,
+                        0, 0, 0, scale, 1 if w else 0, w or 0, None, heads, suffix, 1, trie.ctypes.data)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    bq, bk, bv, bt = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.buffer_from(trie)
+    bo = hip_ctx.create_buffer(want.nbytes)
+    kern = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 1, int(w is not None))
+    with pytest.raises(B.UzuHipError):  # is_trie without the trie buffer
+        run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, None, w, None, heads, suffix, cb))
+    run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, bt, w, None, heads, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or np.abs(f32(want) - f32(got)).max() <= 2e-3
+    # split-KV
+    rows = suffix * heads
+    k1 = B.AttentionTwoPass1Kernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 1, int(w is not None))
+    k2 = B.AttentionTwoPass2Kernel.new(hip_ctx, B.BF16, hd)
+    bp, bsum, bm, bo2 = hip_ctx.create_buffer(rows * 32 * hd * 4), hip_ctx.create_buffer(rows * 32 * 4), hip_ctx.create_buffer(rows * 32 * 4), hip_ctx.create_buffer(want.nbytes)
+
+    def enc(cb):
+        k1.encode(bq, bk, bv, bp, bsum, bm, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, heads, suffix, bt, w, None, cb)
+        k2.encode(bp, bsum, bm, bo2, heads, suffix, cb)
+    run(hip_ctx, enc)
+    got2 = bo2.download(np.uint16, want.size).reshape(want.shape)
+    assert ulp_diff_bf16(want, got2).max() <= 2.0 or np.abs(f32(want) - f32(got2)).max() <= 2e-3
+    # reference-order mode: bit-identical
+    set_exact = _ffi.lib().uzu_hip_set_exact
+    set_exact.argtypes, set_exact.restype = [C.c_uint32], None
+    set_exact(1)
+    try:
+        run(hip_ctx, lambda cb: kern.encode(bq, bk, bv, bo, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, bt, w, None, heads, suffix, cb))
+    finally:
+        set_exact(0)
+    assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
+
+
+def test_trie_verify_then_compaction_equals_linear_decode(hip_ctx):
+    """The speculative-decoding round trip at the kernel boundary (f4 starter): the K / V rows of a speculated tree sit behind the prefix in
+    depth-first order; trie-masked attention gives every node the output a LINEAR sequence ending in its root path would give (same keys, same
+    positions prefix + height); after the verifier accepts one root path, KVCacheUpdate moves the accepted rows to prefix + depth
+    (kv_cache_update.rs; the copies the reference derives from the accepted trie nodes) and the compacted cache is the cache linear decoding
+    would have built: the next token's plain causal attention over it equals the linear one bit for bit."""
+    rng = np.random.default_rng(77)
+    heads, kv_heads, hd, prefix = 8, 2, 128, 50
+    parents = TRIE_PARENTS["bushy"]
+    suffix = len(parents)
+    trie = trie_from_parents(parents)
+    accepted = [0, 5, 7, 8]  # a root path: 0 -> 5 -> 7 -> 8
+    cap = prefix + suffix + 4
+    q, k, v, _ = attention_case(rng, heads, kv_heads, hd, prefix + suffix, suffix, cap)
+    scale = 1.0 / np.sqrt(hd)
+    bq, bk, bv, bt = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.buffer_from(trie)
+    out_tree = hip_ctx.create_buffer(suffix * heads * hd * 2)
+    kt = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 1, 0)
+    run(hip_ctx, lambda cb: kt.encode(bq, bk, bv, out_tree, heads // kv_heads, prefix + suffix, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, bt, None, None, heads, suffix, cb))
+    tree_out = out_tree.download(np.uint16, suffix * heads * hd).reshape(suffix, heads, hd)
+    # the linear sequence of the accepted path: prefix rows + the accepted nodes' rows, queries of the accepted nodes
+    n_acc = len(accepted)
+    k_lin, v_lin = k.copy(), v.copy()
+    for d, node in enumerate(accepted):
+        k_lin[prefix + d], v_lin[prefix + d] = k[prefix + node], v[prefix + node]
+    q_lin = np.ascontiguousarray(q[:, accepted, :])
+    bql, bkl, bvl = hip_ctx.buffer_from(q_lin), hip_ctx.buffer_from(k_lin), hip_ctx.buffer_from(v_lin)
+    out_lin = hip_ctx.create_buffer(n_acc * heads * hd * 2)
+    kl = B.AttentionSinglePassKernel.new(hip_ctx, B.BF16, hd, 0, 0, 1, 0, 0)
+    run(hip_ctx, lambda cb: kl.encode(bql, bkl, bvl, out_lin, heads // kv_heads, prefix + n_acc, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, None, None, None, heads, n_acc, cb))
+    lin_out = out_lin.download(np.uint16, n_acc * heads * hd).reshape(n_acc, heads, hd)
+    # same keys and values in a different visiting order: the online softmax may differ in the last bit
+    assert ulp_diff_bf16(lin_out, tree_out[accepted]).max() <= 1.0
+    # compaction: accepted node at suffix index i -> row prefix + depth (skipping rows already in place)
+    copies = [(prefix + node, prefix + d) for d, node in enumerate(accepted) if node != d]
+    ku = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16)
+    run(hip_ctx, lambda cb: ku.encode(bk, bv, copies, len(copies), kv_heads * hd, cb))
+    rows = (prefix + n_acc) * kv_heads * hd
+    assert np.array_equal(bk.download(np.uint16, rows), k_lin.reshape(-1)[:rows])
+    assert np.array_equal(bv.download(np.uint16, rows), v_lin.reshape(-1)[:rows])
+    # the next token over the compacted cache == over the linear cache, bit for bit
+    qn = bf16(rng.normal(size=(heads, 1, hd)))
+    bqn = hip_ctx.buffer_from(qn)
+    o1, o2 = hip_ctx.create_buffer(heads * hd * 2), hip_ctx.create_buffer(heads * hd * 2)
+
+    def enc(cb):
+        kl.encode(bqn, bk, bv, o1, heads // kv_heads, prefix + n_acc, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, None, None, None, heads, 1, cb)
+        kl.encode(bqn, bkl, bvl, o2, heads // kv_heads, prefix + n_acc, hd, kv_heads * hd, hd, kv_heads * hd, None, scale, None, None, None, heads, 1, cb)
+    run(hip_ctx, enc)
+    assert np.array_equal(o1.download(np.uint16, heads * hd), o2.download(np.uint16, heads * hd))
 
 
 # ------------------------------------------------------------------------------------------ gated delta net

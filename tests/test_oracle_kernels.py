@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import MASK_VARIANTS, attention_float64, bf16, dequantize, f32, mask_case, quant_matrix, ref_attention_inputs
+from helpers import MASK_VARIANTS, attention_float64, bf16, dequantize, f32, mask_case, quant_matrix, ref_attention_inputs, trie_from_parents
 from oracle import oracle as O
 from uzu_amd import synthetic as S
 
@@ -555,3 +555,49 @@ def test_matmul_int8_activations_and_output_rht_against_float64(bits, method):
             want[r, s0:s0 + 32] = hadamard32_np(plain[r, s0:s0 + 32]) * factors[s0:s0 + 32]
     want = f32(bf16(want.astype(np.float32))).astype(np.float64) + f32(bias).astype(np.float64)
     assert np.abs(f32(d) - want).max() <= 0.03 * np.abs(want).max()
+
+
+TRIE_PARENTS = {
+    # speculated trees as parent indices in depth-first order (-1 = child of the last accepted token)
+    "chain": [-1, 0, 1, 2, 3],
+    "two_branches": [-1, 0, 1, 1, 0, 4],
+    "bushy": [-1, 0, 1, 2, 1, 0, 5, 5, 7, -1, 9],
+}
+
+
+@pytest.mark.parametrize("tree", sorted(TRIE_PARENTS))
+@pytest.mark.parametrize("window", [None, 6])
+@pytest.mark.parametrize("heads,kv_heads,hd,prefix", [(4, 2, 64, 19), (4, 4, 64, 0)])
+def test_attention_trie_mask_against_float64(tree, window, heads, kv_heads, hd, prefix):
+    """mask.rs:21-29 + attention_single_pass.rs:55-61 (is_trie): a speculated tree's tokens as the suffix -- a query sees the prefix and the
+    suffix keys on its own root path (trie_start <= q <= trie_end), positions are prefix + height (what the sliding window measures).  The
+    independent statement works from parent pointers, not from the flat {start, end, height} encoding; a chain equals the plain causal mask."""
+    parents = TRIE_PARENTS[tree]
+    suffix = len(parents)
+    seq = prefix + suffix
+    trie = trie_from_parents(parents)
+    q, k, v = ref_attention_inputs(heads, kv_heads, seq, suffix, hd)
+    scale = 1.0 / np.sqrt(hd)
+
+    def args(with_trie):
+        return O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, seq * hd, hd, seq * hd, hd, 0, 0, 0, scale,
+                               1 if window else 0, window or 0, None, heads, suffix, 1, trie.ctypes.data if with_trie else None)
+    a = args(True)
+    got = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(got))
+    want = attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, seq * hd, hd, np.float32(scale), 1, window, None, None, parents=parents)
+    assert np.abs(f32(got) - want).max() <= 4e-3
+    rows = suffix * heads
+    wp, ws, wm = np.zeros((rows, 32, hd), np.float32), np.zeros((rows, 32), np.float32), np.zeros((rows, 32), np.float32)
+    O.lib().orc_attention_two_pass1(C.byref(a), O.p(wp), O.p(ws), O.p(wm))
+    got2 = np.zeros((suffix, heads, hd), np.uint16)
+    O.call("orc_attention_two_pass2", wp, ws, wm, got2, O.BF16, hd, heads, suffix)
+    assert np.abs(f32(got2) - want).max() <= 4e-3
+    if tree == "chain":
+        plain = np.zeros_like(got)
+        b = args(False)
+        O.lib().orc_attention_single_pass(C.byref(b), O.p(plain))
+        assert np.array_equal(plain, got)
+    else:
+        linear = attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, seq * hd, hd, np.float32(scale), 1, window, None, None)
+        assert np.abs(linear - want).max() > 1e-2  # the tree mask is not the linear one

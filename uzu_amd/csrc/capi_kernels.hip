@@ -247,18 +247,17 @@ static uzu_status attention_core_create(uzu_hip_context* ctx, uint32_t kind, uin
                                         uzu_hip_kernel** out) {
     REQ_DT(t, "attention");
     UZU_UNSUPPORTED(!(head_dim == 64 || head_dim == 128 || head_dim == 256 || head_dim == 512), "attention: HEAD_DIM variants are 64/128/256/512");
-    UZU_UNSUPPORTED(is_trie, "attention: trie (speculative tree) masks are not implemented on the hip path");
     uzu_hip_kernel* k;
     UZU_PROPAGATE(make_kernel(ctx, kind, out, &k));
     k->t[0] = t;
-    k->f[0] = head_dim, k->f[1] = has_sinks, k->f[2] = is_kv_cache_ring, k->f[3] = is_causal, k->f[4] = is_sliding_window;
+    k->f[0] = head_dim, k->f[1] = has_sinks, k->f[2] = is_kv_cache_ring, k->f[3] = is_causal, k->f[4] = is_sliding_window, k->f[5] = is_trie;
     return UZU_OK;
 }
 
 static k::AttentionParams attention_params(uzu_hip_kernel* k, uzu_buf queries, uzu_buf keys, uzu_buf values, uint32_t gqa_factor,
                                            uint32_t sequence_length, uint32_t k_head_stride, uint32_t k_seq_stride, uint32_t v_head_stride,
                                            uint32_t v_seq_stride, uzu_ring_params ring, float scale, uint32_t sliding_window_size, uzu_buf sinks,
-                                           uint32_t num_heads, uint32_t suffix_length) {
+                                           uint32_t num_heads, uint32_t suffix_length, uzu_buf trie) {
     k::AttentionParams a{};
     a.queries = bptr(queries), a.keys = bptr(keys), a.values = bptr(values);
     a.dt = k->t[0];
@@ -271,6 +270,7 @@ static k::AttentionParams attention_params(uzu_hip_kernel* k, uzu_buf queries, u
     a.sinks = bptr(sinks);
     a.num_heads = num_heads, a.suffix_length = suffix_length, a.is_causal = k->f[3];
     a.dyn = nullptr;
+    a.trie = (const uint32_t*)bptr(trie);
     return a;
 }
 
@@ -285,11 +285,11 @@ uzu_status uzu_hip_attention_single_pass_encode(uzu_hip_kernel* k, uzu_hip_cmdbu
                                                 uint32_t sliding_window_size, uzu_buf sinks, uint32_t num_heads, uint32_t suffix_length) {
     UZU_PROPAGATE(check(k, KK_ATTENTION_SINGLE_PASS, cb));
     UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out.buffer, "attention_single_pass: queries/keys/values/out are required");
-    UZU_REQUIRE(trie.buffer == nullptr, "attention_single_pass: trie given but is_trie is false");
+    UZU_REQUIRE((trie.buffer != nullptr) == (k->f[5] != 0), "attention_single_pass: trie presence must equal is_trie");
     UZU_REQUIRE((sinks.buffer != nullptr) == (k->f[1] != 0), "attention_single_pass: sinks presence must equal has_sinks");
     UZU_REQUIRE(sequence_length >= suffix_length, "attention_single_pass: sequence_length < suffix_length");
     const k::AttentionParams a = attention_params(k, queries, keys, values, gqa_factor, sequence_length, k_head_stride, k_seq_stride, v_head_stride,
-                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length);
+                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length, trie);
     return k::attention_single_pass(cb_stream(cb), a, bptr(out));
 }
 
@@ -306,11 +306,11 @@ uzu_status uzu_hip_attention_two_pass1_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
     UZU_PROPAGATE(check(k, KK_ATTENTION_TWO_PASS1, cb));
     UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out_partials.buffer && sums.buffer && maxs.buffer,
                 "attention_two_pass1: queries/keys/values/out/sums/maxs are required");
-    UZU_REQUIRE(trie.buffer == nullptr, "attention_two_pass1: trie given but is_trie is false");
+    UZU_REQUIRE((trie.buffer != nullptr) == (k->f[5] != 0), "attention_two_pass1: trie presence must equal is_trie");
     UZU_REQUIRE((sinks.buffer != nullptr) == (k->f[1] != 0), "attention_two_pass1: sinks presence must equal has_sinks");
     UZU_REQUIRE(sequence_length >= suffix_length, "attention_two_pass1: sequence_length < suffix_length");
     const k::AttentionParams a = attention_params(k, queries, keys, values, gqa_factor, sequence_length, k_head_stride, k_seq_stride, v_head_stride,
-                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length);
+                                                  v_seq_stride, ring_params, scale, sliding_window_size, sinks, num_heads, suffix_length, trie);
     return k::attention_two_pass1(cb_stream(cb), a, (float*)bptr(out_partials), (float*)bptr(sums), (float*)bptr(maxs));
 }
 

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) attention_block_kernel(AttentionParams a_
     const uint32_t sequence_length = a.sequence_length;
     const uint32_t prefix_length = sequence_length - a.suffix_length;
     const uint32_t suffix_position = a.is_kv_cache_ring ? a.ring_length : prefix_length;
-    const uint32_t query_position = suffix_position + q_seq_idx;
+    const uint32_t query_position = attention_query_position(a, suffix_position, q_seq_idx);
 
     const T* queries = (const T*)a.queries;
     const T* keys = (const T*)a.keys + (size_t)kv_head_idx * a.k_head_stride + sl * 8;

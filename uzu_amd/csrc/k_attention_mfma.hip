@@ -231,7 +231,7 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
         const char* e = getenv("UZU_ATTN_MFMA_MIN_M");
         return e ? (uint32_t)atoi(e) : 16u;
     }();
-    if (a.dt != UZU_BF16 || !a.is_causal || a.sinks || a.is_sliding_window || a.is_kv_cache_ring) return false;
+    if (a.dt != UZU_BF16 || !a.is_causal || a.sinks || a.is_sliding_window || a.is_kv_cache_ring || a.trie) return false;
     if (a.suffix_length < min_m || !(a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256)) return false;
     if (a.gqa_factor == 0 || a.num_heads % a.gqa_factor) return false;
     if (a.k_head_stride % 8 || a.k_seq_stride % 8 || a.v_head_stride % 8 || a.v_seq_stride % 8) return false;

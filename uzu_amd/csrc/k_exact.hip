@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) attention_exact_kernel(AttentionParams a_i
     const uint32_t kv_head_idx = head_idx / a.gqa_factor;
     const size_t o_offset = (size_t)q_seq_idx * a.num_heads + head_idx;
     const size_t q_offset = (size_t)head_idx * a.suffix_length + q_seq_idx;
-    const uint32_t query_position = suffix_position + q_seq_idx;
+    const uint32_t query_position = attention_query_position(a, suffix_position, q_seq_idx);
     const T* queries = (const T*)a.queries;
     const T* keys = (const T*)a.keys;
     const T* values = (const T*)a.values;

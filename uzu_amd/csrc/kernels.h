@@ -107,6 +107,9 @@ struct AttentionParams {
     // suffix_length, ring_length = min(n, W), ring_offset = n > W ? (n - W) % W : 0 (what encode_accept's offset / length bookkeeping
     // amounts to, state.rs:200-219) -- a replayed graph cannot carry host-side ring parameters.
     uint32_t ring_window;
+    // Speculative tree (is_trie): one {trie_start, trie_end, height} node per suffix token (gpu_types/trie.rs); a suffix key sits at position
+    // suffix_position + height and is visible to the queries trie_start .. trie_end (mask.rs:21-29); null = linear suffix
+    const uint32_t* trie;
 };
 // the (sequence_length, ring_offset, ring_length) a kernel works with: `dyn` applied (host code only reads the fields)
 __host__ __device__ inline void attention_resolve_dyn(AttentionParams& a) {
