@@ -412,7 +412,19 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_
     __shared__ float sR[CC * RPP], sD[CC * RPP], sDw[CC * RPP];
     __shared__ float sA[CC], sW[CC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kq = lane >> 4;
-    const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVT, hk = hv / (num_v_heads / num_k_heads);
+    // XCD-aware (head, value tile) <- workgroup: consecutive workgroup ids go round the 8 XCDs, and the Dv / 16 workgroups of a head all walk
+    // the head's K / Q rows: with the plain (x = tile, y = head) numbering every one of them sits on another XCD and the rows are fetched
+    // 8 times (r2_pmc_fetch_size.csv: 186 MB against ~28 MB).  Here XCD x takes the pairs [x * total / 8, (x + 1) * total / 8): a head's tiles
+    // share one L2.
+    uint32_t hv = blockIdx.y, tile = blockIdx.x;
+    {
+        const uint32_t nx = gridDim.x, total = nx * gridDim.y, lin = blockIdx.x + nx * blockIdx.y;
+        if (total % 8 == 0) {
+            const uint32_t pair = (lin % 8) * (total / 8) + lin / 8;
+            hv = pair / nx, tile = pair % nx;
+        }
+    }
+    const uint32_t dv_base = tile * DVT, hk = hv / (num_v_heads / num_k_heads);
     const uint32_t conv_dim = 2 * key_dim + value_dim;
     const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
