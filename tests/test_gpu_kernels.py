@@ -177,13 +177,9 @@ def test_gemm_mfma_qwen_shapes(hip_ctx, n, k):
 
 @pytest.mark.parametrize("bits,method,group_size", [(4, 0, 128), (4, 1, 256), (4, 2, 64), (8, 0, 64), (8, 1, 128), (8, 2, 256)])
 @pytest.mark.parametrize("splits", ["1", "2", ""])
-@pytest.mark.parametrize("prepass", ["0", "1"])
-def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, prepass, monkeypatch):
+def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeypatch):
     """M >= 128 takes the 128 x 128 tile kernel (k_gemm128.hip): weights straight from global memory into the MFMA
-    operand, the offset term (group row sums of A x per-group coefficients) from the in-kernel table (<= 32 groups per
-    workgroup: the sums are taken while the tiles are staged) or from the separate pre-pass launch (UZU_GEMM_PREPASS=1), optional
-    split-K.  Ragged M (300) and N (520)."""
-    monkeypatch.setenv("UZU_GEMM_PREPASS", prepass)
+    operand, the offset term as extra k-steps of bf16 pieces, optional split-K.  Ragged M (300) and N (520)."""
     if splits:
         monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
     else:

@@ -34,11 +34,9 @@ namespace k {
 #define UZU_GEMM_PAIR_DEQUANT 1 // int4: bf16(16 + u) pairs (gemm_convert.h::dequant4_pairs); 0 = centred (u - 8) / 16 per code (A/B builds)
 #endif
 namespace {
-typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BK = 64, BM = 128, BN = 128;
 constexpr int A_PITCH = 144;
 constexpr bool kPairs = UZU_GEMM_PAIR_DEQUANT != 0;
-constexpr int kInlineGroups = 32; // quant groups per workgroup whose row sums fit the in-kernel table (16 KB)
 #ifndef UZU_GEMM_PIPE
 #define UZU_GEMM_PIPE 1 // software-pipelined k16 steps (operands one step ahead of the MFMAs); 0 = operands right in front of them
 #endif
@@ -109,11 +107,6 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
     __shared__ uint64_t s_exp_tab[32]; // gated epilogue only
-    // rowsum == null: the group row sums of this workgroup's 128 activation rows are taken from the tiles on their way into LDS (the staging
-    // threads hold them in registers anyway: 4 packed dot products per row and k-step) and the offset coefficients come straight from the
-    // scale / bias tables -- no pre-pass launch (host: groups per split <= kInlineGroups)
-    __shared__ float s_rs[kInlineGroups][BM];
-    const bool inline_rs = rowsum == nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
@@ -155,30 +148,10 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) st[j] = *(const u32x4_v*)(a_base + (size_t)a_off[j] + kt * BK);
     };
-    auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[4], bool group_first) {
+    auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[4]) {
         uint8_t* dst = &s_a[kt & 1][rpass * A_PITCH + chunk * 16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) *(u32x4_v*)(dst + j * 32 * A_PITCH) = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
-        if (inline_rs && kt < KTz) { // (the tile past the end is a re-read of the last one)
-            // no registers live across k-steps (the kernel sits at the 256-VGPR budget): every k-step's 64-k sums are reduced over the row's 8
-            // chunk lanes (neighbours: fixed-order butterfly) and lane 0 of the 8 keeps the running group sum in LDS (single owner: deterministic)
-            uint32_t ones = 0x3F803F80u;
-            asm("" : "+s"(ones));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rs_bf16x2, st[j].x), __builtin_bit_cast(rs_bf16x2, ones), 0.f, false);
-                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rs_bf16x2, st[j].y), __builtin_bit_cast(rs_bf16x2, ones), a, false);
-                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rs_bf16x2, st[j].z), __builtin_bit_cast(rs_bf16x2, ones), a, false);
-                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rs_bf16x2, st[j].w), __builtin_bit_cast(rs_bf16x2, ones), a, false);
-                a += __shfl_xor(a, 1, 64);
-                a += __shfl_xor(a, 2, 64);
-                a += __shfl_xor(a, 4, 64);
-                if (chunk == 0) {
-                    float* e = &s_rs[kt / GS][32 * j + rpass];
-                    *e = group_first ? a : *e + a;
-                }
-            }
-        }
     };
 
     // ---- weight role: lane -> column c of each of the wave's two 32-column blocks, k half h
@@ -299,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
         for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
         load_scale(0, sc_cur);
         load_scale(1, sc_nxt);
-        stage_a(0, first, true);
+        stage_a(0, first);
     }
     lds_barrier();
     ts[1] = wall_clock64();
@@ -310,7 +283,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
             const uint32_t kt = kt0 + u;
             load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
             mfma_codes(kt, ring[u % DB], u % GS == 0);
-            stage_a(kt + 1, a_st[(u + 1) % DA], (u + 1) % GS == 0); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
+            stage_a(kt + 1, a_st[(u + 1) % DA]); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
             load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
             if ((u + 1) % GS == 0) {
                 fold();
@@ -336,32 +309,10 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
             const uint32_t g = min(g2 + h, g_end - 1);
             const bool live = g2 + h < g_end;
             float av[2], bv[2];
-            if (inline_rs) {
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) av[mb] = s_rs[g - g_lo][wm * 64 + mb * 32 + c];
-                // coefficient of (column, group): what gemm_prepass_kernel would have tabulated
-                const float mid = (kPairs && BITS == 4) ? -16.0f : (float)(1u << (BITS - 1));
+            for (int mb = 0; mb < 2; ++mb) av[mb] = rowsum[(size_t)g * Mp + arow[mb]];
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const float scale = bf16_to_f32(scales[(size_t)ncol[nb] * G + g]);
-                    float cf;
-                    if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
-                        const uint32_t zp_stride = BITS == 4 ? (G + 1) / 2 : G;
-                        const uint32_t zb = p.zero_points[(size_t)ncol[nb] * zp_stride + (BITS == 4 ? (g >> 1) : g)];
-                        cf = scale * (mid - (float)(BITS == 4 ? ((g & 1) ? (zb >> 4) : (zb & 0xF)) : zb));
-                    } else if (p.b_kind == UZU_MATMUL_B_SCALE_SYMMETRIC) {
-                        cf = scale * (mid - (float)(1u << (BITS - 1)));
-                    } else {
-                        cf = fmaf(mid, scale, bf16_to_f32(((const uint16_t*)p.biases)[(size_t)ncol[nb] * G + g]));
-                    }
-                    bv[nb] = live ? cf : 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) av[mb] = rowsum[(size_t)g * Mp + arow[mb]];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bv[nb] = live ? coef[(size_t)g * N + ncol[nb]] : 0.f;
-            }
+            for (int nb = 0; nb < 2; ++nb) bv[nb] = live ? coef[(size_t)g * N + ncol[nb]] : 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -525,11 +476,7 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     float* coef = (float*)((uint8_t*)workspace + rowsum_bytes);
     float* partials = splits > 1 ? (float*)((uint8_t*)workspace + rowsum_bytes + coef_bytes) : nullptr;
     uzu_status st = UZU_OK;
-    // row sums + coefficients inside the main kernel when a workgroup's groups fit its table (UZU_GEMM_PREPASS=1: the separate pre-pass, A/B runs)
-    const char* pre_env = getenv("UZU_GEMM_PREPASS");
-    const bool inline_rs = G / splits <= (uint32_t)kInlineGroups && !(pre_env && atoi(pre_env) == 1);
-    if (inline_rs) rowsum = nullptr, coef = nullptr;
-    else if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && p.bits == 4)) {
+    if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && p.bits == 4)) {
         const uint32_t rowsum_blocks = (((p.m + 3) & ~3u) + 3) / 4, coef_blocks = (p.n * G + 255) / 256;
         st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
         if (st != UZU_OK) return st;
