@@ -599,10 +599,12 @@ def test_attention_prefill_matrix_core_path(hip_ctx, heads, kv_heads, hd, seq, s
     assert (want == got).mean() >= 0.97
 
 
-@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(32, 8, 128, 1100, 1024), (40, 8, 128, 700, 640), (16, 4, 128, 800, 768), (24, 8, 64, 1030, 1024)])
+@pytest.mark.parametrize("heads,kv_heads,hd,seq,suffix", [(32, 8, 128, 1100, 1024), (40, 8, 128, 700, 640), (16, 4, 128, 800, 768), (24, 8, 64, 1030, 1024),
+                                                          (8, 2, 256, 1100, 1024), (8, 2, 256, 2048, 1024)])
 def test_attention_prefill_matrix_core_path_full_chunks(hip_ctx, heads, kv_heads, hd, seq, suffix):
-    """Chunk-sized suffixes, i.e. grids large enough for four (Llama-3-8B: 32 q / 8 kv; Qwen3-14B: 40 / 8; GQA factor 3) or two wave
-    tasks per workgroup -- the small cases above all end up with one task per workgroup.  Same bar as there."""
+    """Chunk-sized suffixes: grids large enough for four wave tasks per workgroup without help (Llama-3-8B: 32 q / 8 kv; Qwen3-14B: 40 / 8;
+    GQA factor 3), and the few-head shape of the benchmark model (Qwen3.5-0.8B: 8 q / 2 kv heads of 256) where the keys are split over 4
+    workgroups per task group and merged by attention_prefill_merge_kernel -- as in every small case above.  Same bar as there."""
     rng = np.random.default_rng(heads + hd + suffix)
     q, k, v, a = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
     want = np.zeros((suffix, heads, hd), np.uint16)

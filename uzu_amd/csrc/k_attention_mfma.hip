@@ -48,8 +48,11 @@ __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 
 // grid: (kv heads, ceil(gqa * query tiles / tpw)); 256 threads.  Workgroups with the longest key ranges are numbered first.
 // tpw = wave tasks per workgroup (4, 2 or 1): models with few heads (Qwen3.5-0.8B: 8 q heads -> 256 tasks per 1024-token chunk)
 // would fill 64 CUs at four tasks per workgroup; with fewer tasks the idle waves still help staging the K / V tiles.
+// Key split (few-head models: Qwen3.5-0.8B has 2 kv heads -> 64 workgroups of four tasks per 1024-token chunk): gridDim.z workgroups share a
+// task group, each takes an equal share of the key tiles ITS queries can see and leaves the unnormalised O^T, the running maximum and the
+// sum as f32 partials ([split][query][head]); attention_prefill_merge_kernel folds them (the AttentionTwoPass2 step of the decode path).
 template <int HD>
-__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t tpw) {
+__global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t tpw, float* part_o, float* part_ml) {
     constexpr int KP = HD * 2 + 16;  // K tile row pitch in bytes (conflict-free ds_read_b128)
     constexpr int VP = TK * 2 + 8;   // V^T tile row pitch in bytes: 32 keys + 8 bytes of pad (conflict-free ds_read_b64)
     constexpr int NS = HD / 16;      // k16 steps of the QK^T contraction
@@ -93,7 +96,9 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     const uint32_t last_tile = ((task0 + tpw - 1 < n_tasks ? task0 + tpw - 1 : n_tasks - 1) / a.gqa_factor + 1) * TQ;
     const uint32_t wg_last_q = (last_tile < M ? last_tile : M) - 1;
     const uint32_t key_end = prefix + wg_last_q + 1;
-    const uint32_t n_tiles = (key_end + TK - 1) / TK;
+    const uint32_t n_tiles_all = (key_end + TK - 1) / TK;
+    const uint32_t per_split = (n_tiles_all + gridDim.z - 1) / gridDim.z;
+    const uint32_t t_lo = min(blockIdx.z * per_split, n_tiles_all), n_tiles = min(t_lo + per_split, n_tiles_all); // this workgroup: tiles [t_lo, n_tiles)
     auto load_tile = [&](uint32_t t) {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -141,10 +146,12 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     float m_run = -INFINITY, l_run = 0.f; // l_run: this lane's half of the keys only (merged at the end)
     const uint32_t my_last_key = prefix + qi; // causal: keys 0 .. prefix + qi
 
-    load_tile(0);
-    store_tile(0);
+    if (t_lo < n_tiles) {
+        load_tile(t_lo);
+        store_tile(t_lo & 1);
+    }
     __syncthreads();
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t t = t_lo; t < n_tiles; ++t) {
         const int buf = t & 1;
         load_tile(t + 1 < n_tiles ? t + 1 : t); // unconditional: the compiler can count the loads in flight
         // a wave whose queries all end before this tile has nothing to add (causal), but must keep the barriers
@@ -210,6 +217,19 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     }
     // ---- finish: l = both halves' sums (same maximum), out[q][head][hd] = O / l
     const float l_tot = l_run + other_half(l_run);
+    if (part_o) { // key split: f32 partials, row = (split, query, head)
+        if (q_live) {
+            const size_t row = ((size_t)blockIdx.z * M + qi) * a.num_heads + head;
+            float* po = part_o + row * HD;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(float4*)(po + b * 32 + 8 * j + 4 * half) = make_float4(o[b][4 * j], o[b][4 * j + 1], o[b][4 * j + 2], o[b][4 * j + 3]);
+            if (half == 0) part_ml[2 * row] = m_run, part_ml[2 * row + 1] = l_tot;
+        }
+        return;
+    }
     if (q_live) {
         const float inv = 1.0f / l_tot;
         uint16_t* orow = out + ((size_t)qi * a.num_heads + head) * HD;
@@ -238,6 +258,38 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
     return true;
 }
 
+// out[q][head][:] = sum_s w_s O_s / sum_s w_s l_s, w_s = exp(m_s - max m) (a split that saw no key has m = -inf, l = 0: weight 0).
+// grid = rows / 4, 256 threads: 64 threads per (query, head) row, HD / 64 elements each.
+template <int HD>
+__global__ void __launch_bounds__(256) attention_prefill_merge_kernel(const float* part_o, const float* part_ml, uint16_t* out, uint32_t rows, uint32_t splits) {
+    constexpr int EPT = HD / 64;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), e0 = (threadIdx.x & 63) * EPT;
+    if (row >= rows) return;
+    float m = -INFINITY;
+    for (uint32_t sp = 0; sp < splits; ++sp) m = fmaxf(m, part_ml[2 * ((size_t)sp * rows + row)]);
+    float acc[EPT], l = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+    for (uint32_t sp = 0; sp < splits; ++sp) {
+        const size_t r = (size_t)sp * rows + row;
+        const float ms = part_ml[2 * r];
+        if (ms == -INFINITY) continue;
+        const float w = fast_exp(ms - m);
+        l = fmaf(part_ml[2 * r + 1], w, l);
+        const float* po = part_o + r * HD + e0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[e] = fmaf(po[e], w, acc[e]);
+    }
+    const float inv = 1.0f / l;
+    uint16_t* orow = out + (size_t)row * HD + e0;
+    if constexpr (EPT == 1) {
+        orow[0] = (uint16_t)pack2(acc[0] * inv, 0.f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e += 2) *(uint32_t*)(orow + e) = pack2(acc[e] * inv, acc[e + 1] * inv);
+    }
+}
+
 uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out) {
     const uint32_t kv_heads = a.num_heads / a.gqa_factor;
     const uint32_t n_tasks = a.gqa_factor * ((a.suffix_length + TQ - 1) / TQ);
@@ -245,11 +297,43 @@ uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void*
         const char* e = getenv("UZU_ATTN_TPW");
         return e ? (uint32_t)atoi(e) : 0u;
     }();
-    uint32_t tpw = 4; // fewer tasks per workgroup until the grid covers most of the chip
-    while (tpw > 1 && kv_heads * ((n_tasks + tpw - 1) / tpw) < 192) tpw >>= 1;
+    static const int force_split = [] { // UZU_ATTN_KSPLIT: 1 = never split the keys (A/B runs), n = that many splits
+        const char* e = getenv("UZU_ATTN_KSPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    // Few task groups (few kv heads x short chunks): keep four tasks per workgroup -- they share every staged K / V tile -- and split the KEYS
+    // over workgroups until the chip is covered, instead of thinning the workgroups to one MFMA wave each (r2: 3.4 % MFMA busy at the 0.8B shape).
+    uint32_t tpw = 4, splits = 1;
+    float* part = nullptr;
+    const uint32_t groups4 = kv_heads * ((n_tasks + 3) / 4);
+    const uint32_t max_tiles = (a.sequence_length + TK - 1) / TK; // (host view: without the device-side dyn term -- only bounds the split count)
+    if (force_split != 1 && groups4 < 192) { // (a.dyn: the context length joins on the device -- the tile count here is a lower bound, a split may come up empty)
+        splits = (256 + groups4 - 1) / groups4;
+        if (splits > 8) splits = 8;
+        if (force_split > 1) splits = (uint32_t)force_split;
+        while (splits > 1 && max_tiles / splits < 2) --splits;
+        if (splits > 1) {
+            const size_t rows = (size_t)a.suffix_length * a.num_heads;
+            part = (float*)stream_workspace(s, (size_t)splits * rows * (a.head_dim + 2) * sizeof(float)); // null while a graph is being captured
+            if (!part) splits = 1;
+        }
+    }
+    if (splits == 1) { // fewer tasks per workgroup until the grid covers most of the chip
+        while (tpw > 1 && kv_heads * ((n_tasks + tpw - 1) / tpw) < 192) tpw >>= 1;
+    }
     if (force_tpw == 1 || force_tpw == 2 || force_tpw == 4) tpw = force_tpw;
-    const dim3 grid(kv_heads, (n_tasks + tpw - 1) / tpw);
-#define UZU_LAUNCH(H) return launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, tpw); }, "attention_prefill_mfma")
+    const dim3 grid(kv_heads, (n_tasks + tpw - 1) / tpw, splits);
+    const size_t rows = (size_t)a.suffix_length * a.num_heads;
+    float* part_o = part;
+    float* part_ml = part ? part + (size_t)splits * rows * a.head_dim : nullptr;
+#define UZU_LAUNCH(H)                                                                                                                                              \
+    {                                                                                                                                                              \
+        UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, tpw, part_o, part_ml); }, \
+                                   "attention_prefill_mfma"));                                                                                                     \
+        if (!part) return UZU_OK;                                                                                                                                  \
+        return launch_check([&] { hipLaunchKernelGGL(attention_prefill_merge_kernel<H>, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, s, part_o, part_ml, (uint16_t*)out, (uint32_t)rows, splits); }, \
+                            "attention_prefill_merge");                                                                                                            \
+    }
     switch (a.head_dim) {
     case 64: UZU_LAUNCH(64);
     case 128: UZU_LAUNCH(128);
