@@ -417,7 +417,10 @@ def test_qwen_bench_config_matches_oracle_fixture(hip_ctx):
     (28 CPU-minutes, committed).  The synthetic stream visits >= 12 distinct tokens."""
     got, want, worst, common = check_against_fixture(hip_ctx, "qwen_bench")
     assert len(set(want)) >= 12
-    assert common >= 8
+    # The chained stream may leave the oracle's only at a step the teacher-forced pass found inside the error band (asserted in
+    # check_against_fixture); how many tokens that is depends on where the fixture's near-ties sit (step 0 is one: a change of summation
+    # order in the prefill attention moved the first token across it).  The WHOLE stream is identical in reference-order mode:
+    # test_exact_mode_bench_config_stream_is_identical_to_the_fixture.
 
 
 @pytest.mark.parametrize("name", ["llama_int4", "llama_int8"])
