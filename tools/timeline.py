@@ -80,7 +80,7 @@ def main():
         landed = med(e[:, 3] - t0) if (e[:, 3] > 0).all() else nan  # streaming kernels (k_stream.hip): the loader's whole share has landed in LDS
         ex = med(t_end - t0)
         span = (t_end.max() - t0.min()) * 0.01
-        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f}" + (f"   stream: first slot issued {x:.2f}, past the start barrier {med(e[:, 7] - t0):.2f}, share landed {landed:.2f}, consumers done {med(e[:, 5] - t0):.2f}" if landed == landed else ""))
+        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f}" + (f"   stream: first slot issued {x:.2f}, past the start barrier {med(e[:, 7] - t0):.2f}, share landed {landed:.2f}, consumers done {med(e[:, 5] - t0):.2f}" if landed == landed and (e[:, 7] > 0).all() else ""))
         if args.detail and span >= args.detail:
             # who finishes late?  exit times (relative to the first entry) by XCD (workgroup id % 8: dispatch is round-robin over the
             # XCDs) and by position in the grid (quarters of the workgroup-id range: the first workgroups own one batch more)
