@@ -42,6 +42,7 @@ struct DLinear {
     int32_t* out_signs = nullptr;
     uint32_t lora_rank = 0;       // HybridSpec with a LowRankSpec adapter (QLoRALinearWrapper): bf16 [rank, k] and [n, rank]
     uint16_t *adapter_down = nullptr, *adapter_up = nullptr;
+    float* coef = nullptr;        // [groups][n] f32: the prefill GEMM's offset coefficients (MatmulParams::pre_coef), tabulated once at load
 };
 struct DNorm {
     bool present = false;
@@ -133,6 +134,11 @@ struct uzu_hip_model {
     bool fusable = false;
     uint16_t* shortcut_b = nullptr; // ping-pong partner of `shortcut`
     uint16_t* rht_scratch = nullptr; // [rows][widest RHT input]: InputRht works on a copy of the rows
+    // group row sums of `normed`, written by the normalisation that produced it (MatmulParams::pre_rowsum of the GEMMs that read it):
+    // valid for (rs_rows rows, rs_k elements, groups of rs_group) until `normed` is written again
+    float* rowsum = nullptr;
+    size_t rowsum_floats = 0;
+    uint32_t rs_rows = 0, rs_k = 0, rs_group = 0;
     uint32_t rht_max_k = 0;
     uint16_t* lora_scratch = nullptr; // [rows][widest adapter rank]: x down^T of a QLoRA linear
     uint32_t lora_max_rank = 0;
@@ -310,6 +316,18 @@ uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o,
             UZU_PROPAGATE(upload(m, h.zero_points, (size_t)h.n * (h.bits == 4 ? (groups + 1) / 2 : groups), &o->zp));
     }
     UZU_PROPAGATE(upload(m, h.out_biases, (size_t)h.n * 2, &o->out_biases));
+    if (h.method != UZU_QUANT_NONE && !is_embedding) { // prefill GEMM: coefficient half of its pre-pass, once (k_gemm128.hip)
+        k::MatmulParams cp{};
+        cp.b = o->w, cp.scales = o->scales, cp.biases = o->biases, cp.zero_points = o->zp;
+        cp.b_kind = h.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS : h.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+        cp.bits = h.bits, cp.group_size = h.group_size, cp.n = h.n, cp.k = h.k;
+        if (k::gemm_coef_table_supported(cp)) {
+            void* cptr;
+            UZU_PROPAGATE(dev_alloc(m, (size_t)h.n * (h.k / h.group_size) * sizeof(float), &cptr));
+            UZU_PROPAGATE(k::gemm_coef_table(m->ctx->stream, cp, (float*)cptr));
+            o->coef = (float*)cptr;
+        }
+    }
     if (h.input_signs || h.output_signs) {
         UZU_REQUIRE(is_embedding || (h.input_signs && h.output_signs), "engine: an RHT linear needs both input_signs and output_signs (HybridSpec InputOutput)");
         UZU_REQUIRE(h.k % 32 == 0 && (is_embedding || h.n % 32 == 0), "engine: RHT linear %u x %u is not a whole number of 32-wide Hadamard blocks", h.n, h.k);
@@ -474,6 +492,17 @@ void linear_qlora(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* out
                                                                 UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
 }
 
+// the large-tile GEMM's offset tables where the engine has them: coefficients from load time, row sums of `normed` from its normalisation
+static void offset_tables(uzu_hip_model* m, const DLinear& L, const uint16_t* input, uint32_t batch, k::MatmulParams* p) {
+    static const bool enabled = [] { // UZU_GEMM_TABLES=0: the GEMM's own pre-pass launch every time (A/B runs)
+        const char* v = getenv("UZU_GEMM_TABLES");
+        return !v || atoi(v) != 0;
+    }();
+    if (!enabled || batch < 128) return;
+    p->pre_coef = L.coef;
+    if (input == m->normed && m->rs_rows == batch && m->rs_k == L.k && m->rs_group == L.group) p->pre_rowsum = m->rowsum;
+}
+
 void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false) {
     if (L.lora_rank) return linear_qlora(e, L, input, output, batch); // (tensor-parallel shards of QLoRA linears are refused by the planner)
     const bool exchange = row_parallel && e.m->tp != nullptr;
@@ -492,6 +521,7 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
              : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
     p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f;
     p.m = batch, p.n = L.n, p.k = L.k;
+    offset_tables(e.m, L, input, batch, &p);
     const char* variant = "matmul";
     e.begin();
     const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
@@ -523,6 +553,7 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
     p.m = batch, p.n = L.n, p.k = L.k;
     if (!k::matmul_act_mul_supported(e.s, p, e.m->ctx->num_cus)) return false;
     p.act_mul = 1, p.act_type = act_type;
+    offset_tables(e.m, L, input, batch, &p);
     const char* variant = "matmul";
     e.begin();
     const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
@@ -531,7 +562,8 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
 }
 
 // mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
-void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim) {
+// `consumer`: the quantised linear that reads `output` next as a prefill GEMM: the kernel then files the group row sums of the rows it writes
+void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr) {
     k::NormParams p{};
     p.input = input, p.scales = N.scales, p.biases = N.biases, p.output = output, p.shortcut = mode ? shortcut : nullptr;
     p.io_dt = UZU_BF16, p.affine_dt = UZU_F32;
@@ -539,6 +571,13 @@ void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint1
     p.epsilon = N.eps, p.scale_offset = N.offset, p.post_layer_scalar = 1.0f;
     p.subtract_mean = N.subtract_mean, p.full_layer = N.full_layer;
     p.copy_to_shortcut = mode != 0, p.residual_add = mode == 2;
+    uzu_hip_model* m = e.m;
+    if (output == m->normed) m->rs_rows = 0; // whatever was filed for the old rows is stale
+    if (consumer && consumer->coef && !consumer->in_signs && !consumer->lora_rank && output == m->normed && rows >= 128 && consumer->k == dim && !k::exact_mode() &&
+        k::normalization_rowsum_supported(dim, consumer->group) && (size_t)(dim / consumer->group) * ((rows + 3) & ~3u) <= m->rowsum_floats) {
+        p.rowsum_out = m->rowsum, p.rowsum_group = consumer->group;
+        m->rs_rows = rows, m->rs_k = dim, m->rs_group = consumer->group;
+    }
     RUN("normalization", 0, k::normalization(e.s, p));
 }
 
@@ -716,7 +755,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
         if (L.pre_mixer.present) {
-            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d);
+            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d, L.d.mixer_kind == UZU_MIXER_ATTENTION ? &L.qkv : &L.in_proj);
             h = m->normed;
         } else {
             RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, rows * d));
@@ -730,7 +769,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, rows * d));
         }
-        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d);
+        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
         if (!linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
             linear(e, L.up, m->normed, m->up, rows);
             RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
@@ -1146,6 +1185,8 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     ALLOC(batch_tokens, uint32_t, CB);
     ALLOC(hidden, uint16_t, CB * d);
     ALLOC(normed, uint16_t, CB * d);
+    m->rowsum_floats = (size_t)(d / 32) * (CB + 4); // groups of >= 32 elements
+    ALLOC(rowsum, float, m->rowsum_floats);
     ALLOC(mixed, uint16_t, CB * d);
     ALLOC(shortcut, uint16_t, CB * d);
     if (max_qkv) {

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
     const TA* scales = (const TA*)p.scales;
     const TA* biases = (const TA*)p.biases;
     const T* src = p.residual_add ? (const T*)shortcut : input; // normalization.rs:95-99 (own elements: same thread wrote them)
+    float gsum = 0.f; // rowsum_out: this thread's share of one group sum of the output row
     for (uint32_t i = e0; i < e1; ++i) {
         const float normalized = (ld(src, off + i) - mean) * rms_inv;
         float result;
@@ -66,11 +67,31 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
         if (biases) result = rnd<T>(result + ld(biases, i));
         if (p.scale_output) result = rnd<T>(result * rnd<T>(p.post_layer_scalar));
         st(out, off + i, result);
+        gsum += result;
     }
+    if (p.rowsum_out) { // normalization_rowsum_supported: a thread's E elements lie inside one group, group / E neighbouring threads hold it
+        const uint32_t lanes = p.rowsum_group / E, Mp = (p.batch_size + 3) & ~3u;
+        for (uint32_t o = 1; o < lanes; o <<= 1) gsum += __shfl_xor(gsum, (int)o, 64);
+        if (threadIdx.x % lanes == 0) p.rowsum_out[(size_t)(e0 / p.rowsum_group) * Mp + blockIdx.x] = gsum;
+        if (blockIdx.x == p.batch_size - 1)
+            for (uint32_t r = p.batch_size; r < Mp; ++r)
+                for (uint32_t g = threadIdx.x; g < n / p.rowsum_group; g += 256) p.rowsum_out[(size_t)g * Mp + r] = 0.f;
+    }
+}
+bool normalization_rowsum_supported(uint32_t n, uint32_t group) {
+    if (!group || n % 256 || n % group) return false;
+    const uint32_t E = n / 256;
+    if (group % E) return false;
+    const uint32_t lanes = group / E;
+    return lanes >= 1 && lanes <= 64 && (lanes & (lanes - 1)) == 0;
 }
 
 uzu_status normalization(hipStream_t s, const NormParams& p) {
     if (p.batch_size == 0) return UZU_OK;
+    if (p.rowsum_out && (exact_mode() || !normalization_rowsum_supported(p.element_count, p.rowsum_group))) {
+        set_error("normalization: rowsum_out is not available for %u elements in groups of %u (or in reference-order mode)", p.element_count, p.rowsum_group);
+        return UZU_ERR_UNSUPPORTED;
+    }
     if (exact_mode()) return normalization_exact(s, p);
     return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
         if (p.affine_dt == UZU_F32)

@@ -461,6 +461,16 @@ bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if ((uint64_t)p.m * p.k >= (1ull << 32) || (uint64_t)p.n * p.k * p.bits / 8 >= (1ull << 32)) return false; // 32-bit element offsets
     return gemm128_splits(p, num_cus) != 0;
 }
+bool gemm_coef_table_supported(const MatmulParams& p) {
+    if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || !(p.bits == 4 || p.bits == 8)) return false;
+    if (p.group_size != 64 && p.group_size != 128 && p.group_size != 256) return false;
+    if (p.k % p.group_size) return false;
+    return p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && p.bits == 4);
+}
+uzu_status gemm_coef_table(hipStream_t s, const MatmulParams& p, float* coef) {
+    const uint32_t G = p.k / p.group_size;
+    return launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3((p.n * G + 255) / 256), dim3(256), 0, s, p, (float*)nullptr, coef, 0u); }, "gemm_coef_table");
+}
 size_t gemm_q_mfma128_workspace_bytes(const MatmulParams& p, int num_cus) {
     const uint32_t G = p.k / p.group_size;
     const uint32_t splits = gemm128_splits(p, num_cus);
@@ -477,13 +487,18 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     float* partials = splits > 1 ? (float*)((uint8_t*)workspace + rowsum_bytes + coef_bytes) : nullptr;
     uzu_status st = UZU_OK;
     if (p.b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC || (kPairs && p.bits == 4)) {
-        const uint32_t rowsum_blocks = (((p.m + 3) & ~3u) + 3) / 4, coef_blocks = (p.n * G + 255) / 256;
-        st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
-        if (st != UZU_OK) return st;
+        // the caller may bring either table (engine: coefficients tabulated at load, row sums written by the normalisation that produced A)
+        const uint32_t rowsum_blocks = p.pre_rowsum ? 0u : (((p.m + 3) & ~3u) + 3) / 4, coef_blocks = p.pre_coef ? 0u : (p.n * G + 255) / 256;
+        if (rowsum_blocks + coef_blocks) {
+            st = launch_check([&] { hipLaunchKernelGGL(gemm_prepass_kernel, dim3(rowsum_blocks + coef_blocks), dim3(256), 0, s, p, rowsum, coef, rowsum_blocks); }, "gemm_prepass");
+            if (st != UZU_OK) return st;
+        }
     }
+    const float* rowsum_in = p.pre_rowsum ? p.pre_rowsum : rowsum;
+    const float* coef_in = p.pre_coef ? p.pre_coef : coef;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
     const dim3 grid(gemm_grid_x(m_tiles, n_tiles), splits);
-#define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum, coef, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
+#define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
     const uint32_t gs = p.group_size / BK;
     if (p.bits == 4) {
         if (gs == 1) UZU_LAUNCH(4, 1);

@@ -40,7 +40,14 @@ struct MatmulParams {
     // ---- fused prologue / epilogue options used by the engine (all 0 through the C ABI) ----
     uint32_t act_mul;   // epilogue: rows [0,n/2) = up, [n/2,n) = gate; writes d[m, n/2] = up * act(gate)
     uint32_t act_type;
+    // Offset-term tables of the large-tile prefill GEMM (k_gemm128.hip) supplied by the caller instead of its pre-pass launch:
+    // pre_coef [groups][n] f32 depends on the weights only (gemm_coef_table, once at load); pre_rowsum [groups][Mp] f32, Mp = m rounded up
+    // to 4, pad rows zero = the group row sums of A, written by the kernel that produced A (NormParams::rowsum_out).  Both given: no pre-pass.
+    const float* pre_rowsum;
+    const float* pre_coef;
 };
+bool gemm_coef_table_supported(const MatmulParams& p);                          // the large-tile kernel's quantisation family
+uzu_status gemm_coef_table(hipStream_t s, const MatmulParams& p, float* coef); // coef[g][n]; p needs b / scales / biases / zero_points, n, k, bits, group_size, b_kind
 // runtime.hip: grow-only per-stream scratch block; nullptr while `s` is being captured (or when the allocation fails)
 void* stream_workspace(hipStream_t s, size_t bytes);
 void stream_workspace_release(hipStream_t s);
@@ -69,8 +76,13 @@ struct NormParams {
     uint32_t batch_size, element_count;
     float epsilon, scale_offset, post_layer_scalar;
     uint32_t subtract_mean, full_layer, copy_to_shortcut, residual_add, scale_residual_sum, scale_output;
+    // optional: the sums of the OUTPUT row over groups of `rowsum_group` elements, f32 [element_count / rowsum_group][Mp], Mp = batch_size
+    // rounded up to 4 (pad rows zeroed) -- MatmulParams::pre_rowsum of the GEMM that consumes the rows (see normalization_rowsum_supported)
+    float* rowsum_out;
+    uint32_t rowsum_group;
 };
 uzu_status normalization(hipStream_t s, const NormParams& p);
+bool normalization_rowsum_supported(uint32_t element_count, uint32_t group);
 
 uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, uint32_t batch_size,
                     uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset, uint32_t head_offset,
