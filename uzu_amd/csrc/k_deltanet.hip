@@ -230,6 +230,10 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const uint16_t* in_proj,
 }
 __global__ void __launch_bounds__(256) conv_apply_kernel(uint16_t* in_proj, const float* conv_weight, const float* bias, const float* halo, float* state,
                                                          uint32_t suffix_len, uint32_t ks, uint32_t conv_dim, uint32_t out_stride, uint32_t nblocks) {
+    // exp table of the SiLU in LDS: read from memory it is a dependent round trip per element, 16 of them in a row per thread
+    __shared__ uint64_t s_exp_tab[32];
+    if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
     const uint32_t taps = ks - 1;
     const size_t total = (size_t)nblocks * conv_dim;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256) conv_apply_kernel(uint16_t* in_proj, cons
             for (uint32_t tap = 0; tap < CONV_MAXK; ++tap)
                 if (tap < taps) acc += w[tap] * win[tap];
             acc += w[taps] * x;
-            *px = f32_to_bf16(silu_f32(acc));
+            *px = f32_to_bf16(silu_f32_tab(acc, s_exp_tab));
 #pragma unroll
             for (uint32_t tap = 0; tap + 1 < CONV_MAXK; ++tap)
                 if (tap + 1 < taps) win[tap] = win[tap + 1];
@@ -288,6 +292,9 @@ __global__ void __launch_bounds__(256) delta_net_prefill_prep_kernel(const uint1
                                                                      uint32_t key_dim, uint32_t value_dim,
                                                                      uint32_t suffix_len) {
     constexpr int DK = 128;
+    __shared__ uint64_t s_exp_tab[32]; // three chained exponentials per (token, value head): table reads from LDS, not dependent global loads
+    if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= suffix_len * num_k_heads) return;
     const uint32_t token = wave / num_k_heads, hk = wave % num_k_heads;
@@ -317,13 +324,13 @@ __global__ void __launch_bounds__(256) delta_net_prefill_prep_kernel(const uint1
     if (lane < groups_per_head) {
         const uint32_t hv = hk * groups_per_head + lane;
         const float beta_raw = bf16_to_f32(in_proj[tok_offset + conv_dim + value_dim + hv]);
-        const float beta = 1.0f / (1.0f + expf_glibc(-beta_raw));
+        const float beta = 1.0f / (1.0f + expf_glibc_tab(-beta_raw, s_exp_tab));
         const float a_raw = bf16_to_f32(in_proj[tok_offset + conv_dim + value_dim + num_v_heads + hv]);
         const float sp_in = a_raw + dt_bias[hv];
-        const float sp = sp_in > 20.0f ? sp_in : logf_glibc(1.0f + expf_glibc(sp_in));
-        const float log_decay = -expf_glibc(a_log[hv]) * sp;
+        const float sp = sp_in > 20.0f ? sp_in : logf_glibc(1.0f + expf_glibc_tab(sp_in, s_exp_tab));
+        const float log_decay = -expf_glibc_tab(a_log[hv], s_exp_tab) * sp;
         beta_out[(size_t)token * num_v_heads + hv] = beta;
-        decay_out[(size_t)token * num_v_heads + hv] = expf_glibc(log_decay);
+        decay_out[(size_t)token * num_v_heads + hv] = expf_glibc_tab(log_decay, s_exp_tab);
     }
 }
 uzu_status delta_net_prefill_prep(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias,
@@ -528,6 +535,9 @@ __global__ void __launch_bounds__(256) delta_net_norm_gate_kernel(uint16_t* in_o
                                                                   uint32_t head_v_dim, uint32_t value_dim,
                                                                   uint32_t conv_dim, uint32_t total_proj_dim,
                                                                   float norm_epsilon, uint32_t suffix_len) {
+    __shared__ uint64_t s_exp_tab[32]; // the SiLU's exp table: an LDS read instead of a dependent global load behind the reduction
+    if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= suffix_len * num_v_heads) return;
     const uint32_t token = wave / num_v_heads, hv = wave % num_v_heads;
@@ -542,7 +552,7 @@ __global__ void __launch_bounds__(256) delta_net_norm_gate_kernel(uint16_t* in_o
     for (uint32_t i = lane; i < head_v_dim; i += 64) {
         const float o_i = bf16_to_f32(in_out[base + i]);
         const float z_i = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + conv_dim + hv * head_v_dim + i]);
-        in_out[base + i] = f32_to_bf16(o_i * inv_rms * norm_weight[i] * silu_f32(z_i));
+        in_out[base + i] = f32_to_bf16(o_i * inv_rms * norm_weight[i] * silu_f32_tab(z_i, s_exp_tab));
     }
 }
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
