@@ -1367,6 +1367,7 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
         UZU_PROPAGATE(encode_forward(m, s, n, last, states, nseq));
         HIPCHK(hipStreamSynchronize(s)); // the staging buffer is reused; also surfaces kernel faults per chunk
         if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
+        UZU_PROPAGATE(k::gemv_stream_check());
         for (uint32_t i = 0; i < nseq; ++i) {
             bind_state(m, states[i]);
             m->context_length += n;
@@ -1422,6 +1423,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
         UZU_PROPAGATE(encode_forward(m, s, n, last));
         HIPCHK(hipStreamSynchronize(s)); // token_ids is caller memory; also surfaces kernel faults per chunk
         if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
+        UZU_PROPAGATE(k::gemv_stream_check());
         m->context_length += n;
     }
     if (first_token) HIPCHK(hipMemcpy(first_token, m->d_out_token, 4, hipMemcpyDeviceToHost));
@@ -1441,6 +1443,7 @@ uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, 
     UZU_REQUIRE(first_position + count <= m->max_positions, "model_read_tokens: range out of bounds");
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
+    UZU_PROPAGATE(k::gemv_stream_check());
     HIPCHK(hipMemcpy(out_tokens, m->d_sampled + first_position, (size_t)count * 4, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
@@ -1460,6 +1463,7 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
     HIPCHK(hipEventRecord(m->ev1, m->ctx->stream));
     HIPCHK(hipEventSynchronize(m->ev1));
     if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
+    UZU_PROPAGATE(k::gemv_stream_check());
     if (gpu_ms) HIPCHK(hipEventElapsedTime(gpu_ms, m->ev0, m->ev1));
     if (out_tokens) UZU_PROPAGATE(uzu_hip_model_read_tokens(m, first, steps, out_tokens));
     return UZU_OK;

@@ -1082,6 +1082,17 @@ extern "C" uint32_t uzu_hip_debug_decode_stream_error(void) { // bit mask of bou
     return v;
 }
 
+static bool g_stream_launched = false;
+uzu_status gemv_stream_check() {
+    if (!g_stream_launched) return UZU_OK;
+    const uint32_t v = uzu_hip_debug_decode_stream_error();
+    if (v) {
+        set_error("gemv_stream: a bounded wait inside a weight-stream kernel gave up (mask 0x%x): its outputs are invalid", v);
+        return UZU_ERR_HIP;
+    }
+    return UZU_OK;
+}
+
 static int stream_cpl(const DecGemvParams& p) {
     const int lpr_log2 = gemv_lpr_log2(p.k);
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2;
@@ -1233,6 +1244,7 @@ uzu_status gemv_stream_mfma(hipStream_t s, const DecGemvParams& p_in, int num_cu
 }
 
 uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint32_t* grid_out) {
+    g_stream_launched = true;
     if (stream_mfma_on() && gemv_stream_mfma_supported(p_in)) return gemv_stream_mfma(s, p_in, num_cus, grid_out); // matrix-core consumers
     DecGemvParams p = p_in;
 #ifdef UZU_TIMELINE

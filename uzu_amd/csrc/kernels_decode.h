@@ -91,6 +91,9 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t
 bool gemv_stream_supported(const DecGemvParams& p);
 bool gemv_stream_wanted(const DecGemvParams& p);
 uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
+// host synchronisation points: UZU_ERR_HIP if a bounded spin of a stream kernel gave up since the last check (its outputs are then
+// garbage); costs nothing until a stream kernel has been launched in this process
+uzu_status gemv_stream_check();
 // Embedding row of the token the commit kernel has just sampled (the next decode step's input row): the lookup of
 // quant_embedding.rs:36-116 / full_precision_embedding.rs:17-31 for one token, done by the committing workgroup instead
 // of a launch of its own at the head of the next step.  `output` null => plain commit.
