@@ -316,6 +316,38 @@ def test_normalization(hip_ctx, full_layer, mode, dim, rows):
     assert (want == got).mean() >= 0.99
 
 
+@pytest.mark.parametrize("dim", [1024, 2048, 4096, 5120])
+@pytest.mark.parametrize("mode,full_layer", [("add", 1), ("add", 0), ("copy", 1), ("none", 1)])
+def test_normalization_prefill_rows_kernel_is_bit_identical_to_the_row_at_a_time_kernel(hip_ctx, dim, mode, full_layer):
+    """Batches of >= 16 bf16 rows of 1024 NV elements take normalization_rows_kernel (row in registers between the two passes, 8-byte
+    accesses); its arithmetic and reduction order are the general kernel's: the same rows normalised one call per row (batch 1: the
+    general kernel) give the same bits -- output and shortcut.  Against the oracle: the tolerance of test_normalization."""
+    rng = np.random.default_rng(dim + len(mode) + full_layer)
+    rows = 37
+    x, sc = bf16(rng.normal(0, 1.5, size=(rows, dim))), bf16(rng.normal(0, 1.5, size=(rows, dim)))
+    scales = rng.uniform(-0.2, 0.2, size=(dim,)).astype(np.float32)
+    copy, add = mode != "none", mode == "add"
+    kern = B.NormalizationKernel.new(hip_ctx, B.BF16, B.F32, B.BF16, B.F32, 0, 0, full_layer, int(copy), int(add), 0, 0, 0, 0, 1)
+    bs = hip_ctx.buffer_from(scales)
+    bx, bo, bsc = hip_ctx.buffer_from(x), hip_ctx.create_buffer(x.nbytes), hip_ctx.buffer_from(sc)
+    run(hip_ctx, lambda cb: kern.encode(bx, bs, None, bo, bsc if copy else None, None, rows, dim, 1e-6, 1.0, 1.0, cb))
+    got, got_sc = bo.download(np.uint16, rows * dim).reshape(rows, dim), bsc.download(np.uint16, rows * dim).reshape(rows, dim)
+    one, one_sc = np.zeros_like(x), np.zeros_like(x)
+    for r in range(0, rows, 6):  # a sample of the rows, one launch each
+        bx1, bo1, bsc1 = hip_ctx.buffer_from(x[r:r + 1]), hip_ctx.create_buffer(dim * 2), hip_ctx.buffer_from(sc[r:r + 1])
+        run(hip_ctx, lambda cb: kern.encode(bx1, bs, None, bo1, bsc1 if copy else None, None, 1, dim, 1e-6, 1.0, 1.0, cb))
+        assert np.array_equal(bo1.download(np.uint16, dim), got[r])
+        if copy:
+            assert np.array_equal(bsc1.download(np.uint16, dim), got_sc[r])
+    want, want_sc = np.zeros_like(x), sc.copy()
+    args = O.NormArgs(x.ctypes.data, scales.ctypes.data, None, want.ctypes.data, want_sc.ctypes.data if copy else None, O.BF16, O.F32,
+                      rows, dim, 1e-6, 1.0, 1.0, 0, full_layer, int(copy), int(add), 0, 0)
+    O.lib().orc_normalization(C.byref(args))
+    if copy:
+        assert np.array_equal(got_sc, want_sc)
+    assert ulp_diff_bf16(want, got).max() <= (1.0 if full_layer else 2.0)
+
+
 def test_qkv_norm(hip_ctx):
     """Per-head RMSNorm in place on packed QKV (qkv_norm_test.rs:52-186)."""
     rng = np.random.default_rng(3)

@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 O=gpurun_out/r3p; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "delta or conv or gdn" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "norm" 2>&1 | tail -3
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/trace -o r3p -- python $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $ROOT/$O/prof.log 2>&1
 cd $ROOT
