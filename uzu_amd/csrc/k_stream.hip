@@ -86,24 +86,6 @@ __device__ __forceinline__ void glds4s(uint32_t voff, const void* sbase, uint32_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 constexpr uint32_t kOpsPerSlot = 20; // VMEM operations per slot, padded with dummy reads: the counted waits below need immediates
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vmcnt(uint32_t n) {
-#define UZU_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-#define UZU_VM8(B) UZU_VM(B) UZU_VM(B + 1) UZU_VM(B + 2) UZU_VM(B + 3) UZU_VM(B + 4) UZU_VM(B + 5) UZU_VM(B + 6) UZU_VM(B + 7)
-    switch (n) {
-        UZU_VM(0) UZU_VM(1) UZU_VM(2) UZU_VM(3) UZU_VM(4) UZU_VM(5) UZU_VM(6) UZU_VM(7)
-        UZU_VM(8) UZU_VM(9) UZU_VM(10) UZU_VM(11) UZU_VM(12) UZU_VM(13) UZU_VM(14) UZU_VM(15)
-        UZU_VM(16) UZU_VM(17) UZU_VM(18) UZU_VM(19) UZU_VM(20) UZU_VM(21) UZU_VM(22) UZU_VM(23)
-        UZU_VM(24) UZU_VM(25) UZU_VM(26) UZU_VM(27) UZU_VM(28) UZU_VM(29) UZU_VM(30) UZU_VM(31)
-        UZU_VM(32) UZU_VM(33) UZU_VM(34) UZU_VM(35) UZU_VM(36) UZU_VM(37) UZU_VM(38) UZU_VM(39)
-        UZU_VM(40) UZU_VM(41) UZU_VM(42) UZU_VM(43) UZU_VM(44) UZU_VM(45) UZU_VM(46) UZU_VM(47)
-        UZU_VM(48) UZU_VM(49) UZU_VM(50) UZU_VM(51) UZU_VM(52) UZU_VM(53) UZU_VM(54) UZU_VM(55)
-        UZU_VM(56) UZU_VM(57) UZU_VM(58) UZU_VM(59) UZU_VM(60) UZU_VM(61) UZU_VM(62)
-    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
-    }
-#undef UZU_VM8
-#undef UZU_VM
-}
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // bounded wait for *flag >= target; false = gave up
