@@ -1157,12 +1157,15 @@ def test_gated_act_mul_rht_variants_bit_exact(hip_ctx, ops, scale_group, sum_gro
         B.GatedActMulKernel.new(hip_ctx, B.BF16, 1, 0, 0, 64, 0)
 
 
-@pytest.mark.parametrize("bits,method,group_size,a_group", [(4, 0, 128, 128), (4, 1, 64, 32), (4, 2, 32, 64), (8, 0, 128, 64), (8, 1, 64, 128)])
-@pytest.mark.parametrize("m,n,k", [(1, 1024, 1024), (70, 200, 512), (256, 3072, 1024)])
+@pytest.mark.parametrize("bits,method,group_size,a_group", [(4, 0, 128, 128), (4, 1, 64, 32), (4, 2, 32, 64), (8, 0, 128, 64), (8, 1, 64, 128),
+                                                            (4, 1, 128, 128), (4, 2, 64, 128), (8, 2, 128, 128)])
+@pytest.mark.parametrize("m,n,k", [(1, 1024, 1024), (70, 200, 512), (256, 3072, 1024), (300, 520, 2048)])
 def test_matmul_int8_symmetric_activations(hip_ctx, bits, method, group_size, a_group, m, n, k):
     """MatmulA::Int8Symmetric (matmul_a.rs:9-14; CPU semantics kernel.rs:190-200) against the CPU restatement: the integer part of
-    every 32-element step is exact, the f32 scaling is summation-order class: <= 1 bf16 ulp (the reference's own CPU-vs-GPU bar for
-    quantised matmuls is rel 0.05 / abs 0.4, quant_dispatch_test.rs:124)."""
+    every step is exact, the f32 scaling is summation-order class: <= 1 bf16 ulp (the reference's own CPU-vs-GPU bar for
+    quantised matmuls is rel 0.05 / abs 0.4, quant_dispatch_test.rs:124).  M >= 128 with min(activation group, weight group) in
+    {64, 128} runs on the int8 matrix cores (gemm_a8_mfma_kernel: v_mfma_i32_32x32x32_i8, one f32 fold per 64 / 128-element stage;
+    ragged M = 300 / N = 520 included), everything else on the packed-dot VALU kernel."""
     rng = np.random.default_rng(bits * 100 + method * 10 + m)
     q = quant_matrix(rng, n, k, bits, group_size, method)
     x = bf16(rng.normal(0, 1.0, (m, k)))
@@ -1192,6 +1195,48 @@ def test_matmul_int8_symmetric_activations(hip_ctx, bits, method, group_size, a_
     ulps = ulp_diff_bf16(want, got)
     assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
     assert (ulps == 0).mean() >= 0.97
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 7168, 1024), (4096, 14336, 4096)])
+def test_matmul_int8_activations_throughput_report(hip_ctx, m, n, k, capsys):
+    """Not a parity test (that is test_matmul_int8_symmetric_activations): the int8-MFMA A8 GEMM next to the bf16-activation GEMM on the
+    same int4 g128 weights, GPU time of one command buffer of 5 launches each (uzu_hip_cmdbuf_gpu_execution_time_ns) -- the figure DESIGN.md
+    quotes.  Asserts only that both ran and that the two results agree to the activation-quantisation error (int8 codes: ~1 % rms)."""
+    rng = np.random.default_rng(m + n)
+    q = quant_matrix(rng, n, k, 4, 128, 0)
+    x = bf16(rng.normal(0, 1.0, (m, k)))
+    factors = np.ones(k, np.int32)
+    kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
+    bw, bsc, bbi = hip_ctx.buffer_from(q["weights"]), hip_ctx.buffer_from(q["scales"]), hip_ctx.buffer_from(q["biases"])
+    bx, bd16, bd8 = hip_ctx.buffer_from(x), hip_ctx.create_buffer(m * n * 2), hip_ctx.create_buffer(m * n * 2)
+    bq, bs_ = hip_ctx.create_buffer(m * k), hip_ctx.create_buffer(m * (k // 128) * 4)
+    tk = B.ActivationTransformKernel.new(hip_ctx, B.BF16, 2, 0, 128, 0)
+    bf = hip_ctx.buffer_from(factors)
+    run(hip_ctx, lambda cb: tk.encode(bx, None, bq, bs_, None, bf, m, k, cb))
+    # Quantize includes the Hadamard transform: the bf16 leg gets the same rows transformed (InputRht), as RHTLinearWrapper feeds either
+    bxh = hip_ctx.create_buffer(m * k * 2)
+    th = B.ActivationTransformKernel.new(hip_ctx, B.BF16, B.ATX_INPUT_RHT, 0, 0, 0)
+    run(hip_ctx, lambda cb: th.encode(bx, bxh, None, None, None, bf, m, k, cb))
+    bx = bxh
+
+    def bf16_path(cb):
+        for _ in range(5):
+            kern.encode(cb, a=bx, b=bw, d=bd16, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=B.QMODE_U4, group_size=128)
+
+    def a8_path(cb):
+        for _ in range(5):
+            kern.encode(cb, a=bq, b=bw, d=bd8, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=B.QMODE_U4, group_size=128,
+                        a_int8_scales=bs_, a_group_size=128)
+    for fn in (bf16_path, a8_path):
+        run(hip_ctx, fn)  # warm-up (workspace growth, code load)
+    t16 = run(hip_ctx, bf16_path).gpu_execution_time() / 5
+    t8 = run(hip_ctx, a8_path).gpu_execution_time() / 5
+    flops = 2.0 * m * n * k
+    with capsys.disabled():
+        print(f"\nA8 report {m}x{n}x{k}: bf16-activation GEMM {t16 * 1e6:.1f} us = {flops / t16 / 1e12:.0f} TFLOP/s; int8-MFMA A8 GEMM {t8 * 1e6:.1f} us = {flops / t8 / 1e12:.0f} TOP/s")
+    d16, d8 = f32(bd16.download(np.uint16, m * n)), f32(bd8.download(np.uint16, m * n))
+    assert t16 > 0 and t8 > 0
+    assert np.sqrt(np.mean((d16 - d8) ** 2)) <= 0.03 * np.sqrt(np.mean(d16 ** 2))
 
 
 def test_matmul_output_rht_then_bias_and_the_rht_linear_chain(hip_ctx):

@@ -14,6 +14,7 @@
 // like every other matmul here).  An int8-MFMA tile kernel (v_mfma_i32_32x32x32_i8, 2x the bf16 rate) is the planned next step
 // for prefill-sized M; this kernel is the functional path and the parity anchor.
 #include "device_utils.h"
+#include "gemm_tile_map.h"
 #include "kernels.h"
 
 namespace uzu {
@@ -189,6 +190,191 @@ __global__ void __launch_bounds__(256) matmul_a8_kernel(MatmulParams p, const in
         }
 }
 
+// ---------------------------------------------------------------------------------------------- the same on the int8 matrix cores
+// Prefill-sized M: 128 x 128 output tile per workgroup, four waves as 2 x 2 (64 x 64 each = 2 x 2 blocks of v_mfma_i32_32x32x32_i8), K in
+// STAGES of GK = min(activation group, weight group) in {64, 128} elements: inside a stage every (row, column) pair has ONE activation scale
+// and ONE weight scale / offset, so the integer dot product of the stage is exact on the matrix core and the f32 work is one fold per stage:
+//     acc += s_a[m] * (s_w[n] * D[m, n] + (s_w[n] * c + beta_w[n]) * S[m]),   D = sum a (u - c),  S = sum a  (i32, exact)
+// -- the VALU kernel's formula with a 64 / 128-element step instead of 32.  int4 codes go in UNSIGNED (0 .. 15 fits an int8: c = 0, no
+// centring arithmetic), int8 codes as u - 128 (one xor).  Both operands are staged through LDS as int8 rows (the unpack of the int4 codes to
+// k order is the VALU kernel's two permutes per 8 codes); the stage's row sums S come from the staging threads (packed dot with ones + a
+// DPP butterfly over the 8 threads of a row), the activation scales of the stage's 128 rows sit beside them.
+// MFMA operand layout (32x32x32 i8): A lane l = row l % 32, k bytes 16 (l / 32) .. + 15; B lane l = column l % 32, same k bytes;
+// C / D register r = row (r & 3) + 8 (r >> 2) + 4 (l / 32) of column l % 32.
+typedef int a8_i32x4 __attribute__((ext_vector_type(4)));
+typedef int a8_i32x16 __attribute__((ext_vector_type(16)));
+typedef float a8_f32x2 __attribute__((ext_vector_type(2)));
+template <int BITS, int GK>
+__global__ void __launch_bounds__(256, 2) gemm_a8_mfma_kernel(MatmulParams p, const int8_t* a_q, const float* a_scales, uint32_t a_group) {
+    constexpr int PITCH = GK + 16;  // bytes per LDS row: odd multiple of 16 (GK 64 -> 80, 128 -> 144)
+    constexpr int KS = GK / 32;     // MFMA k-steps per stage
+    constexpr int VPR = GK / 16;    // 16-byte vectors per row and stage
+    constexpr int RPT = 128 * VPR / 256; // vectors a thread stages per operand and stage: 2 (GK 64) / 4 (GK 128): all of ONE row
+    constexpr int TPR = VPR / RPT;       // threads per row: 2
+    // two stages in LDS: the operands of stage st + 1 are requested from memory before the products of stage st and parked after them
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][128 * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[2][128 * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_sa[2][128], s_rs[2][128]; // activation scale and scale * row sum of the stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
+    // XCD-aware tile numbering (gemm_tile_map.h, as the bf16 kernel): the ~64 workgroups an XCD runs at a time share 8 x 8 panels in its L2
+    // (plain x = column tile, y = row tile: every workgroup-stage went to the memory side, 3.4 TB/s of operand traffic at 4096 x 14336 x 4096)
+    uint32_t m_t, n_t;
+    if (!gemm_tile_of_block(blockIdx.x, (p.m + 127u) / 128u, (p.n + 127u) / 128u, &m_t, &n_t)) return;
+    const uint32_t n0 = n_t * 128u, m0 = m_t * 128u, K = p.k, stages = K / GK;
+    const uint32_t a_groups = K / a_group, w_groups = K / p.group_size;
+    const uint32_t zp_stride = BITS == 4 ? (w_groups + 1) / 2 : w_groups;
+    const float centre = BITS == 4 ? 0.0f : 128.0f;                        // what the staged weight bytes are short of the unsigned code
+    const uint32_t flip = p.signed_codes ? (BITS == 4 ? 0x88888888u : 0x80808080u) : 0u;
+    float acc[2][2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    uint32_t ncol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) ncol[nb] = min(n0 + wn * 64 + nb * 32 + c, p.n - 1);
+    // staging role: the RPT vectors [tid * RPT, + RPT) of the tile = a contiguous piece of row tid / TPR (clamped rows are computed, never stored)
+    const uint32_t srow = (uint32_t)tid / TPR, sv0 = ((uint32_t)tid % TPR) * RPT;
+    const int8_t* a_src = a_q + (size_t)min(m0 + srow, p.m - 1) * K + sv0 * 16;
+    const uint8_t* w_src = (const uint8_t*)p.b + (size_t)min(n0 + srow, p.n - 1) * K * BITS / 8 + sv0 * 16 * BITS / 8;
+    const float* sa_src = a_scales + (size_t)min(m0 + srow, p.m - 1) * a_groups;
+    a8_i32x4 ra[RPT];
+    uint2 rw4[BITS == 4 ? RPT : 1];
+    a8_i32x4 rw8[BITS == 8 ? RPT : 1];
+    float r_sa = 0.f;
+    auto fetch = [&](uint32_t st) { // memory -> registers (stage st; past the end: the last stage again, never parked)
+        const uint32_t k0 = min(st, stages - 1) * GK;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            ra[i] = *(const a8_i32x4*)(a_src + k0 + i * 16);
+            if constexpr (BITS == 4) rw4[i] = *(const uint2*)(w_src + k0 / 2 + i * 8);
+            else rw8[i] = *(const a8_i32x4*)(w_src + k0 + i * 16);
+        }
+        r_sa = sa_src[k0 / a_group];
+    };
+    auto park = [&](int buf) { // registers -> LDS buffer `buf`
+        int32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            *(a8_i32x4*)(&s_a[buf][srow * PITCH + (sv0 + i) * 16]) = ra[i];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t = dot4((uint32_t)ra[i][w], 0x01010101u, t);
+            a8_i32x4 wv;
+            if constexpr (BITS == 4) {
+                const uint32_t w2[2] = {rw4[i].x ^ flip, rw4[i].y ^ flip};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t lo = w2[q] & 0x0F0F0F0Fu, hi = (w2[q] >> 4) & 0x0F0F0F0Fu;   // codes 0,2,4,6 / 1,3,5,7
+                    wv[2 * q] = (int)__builtin_amdgcn_perm(hi, lo, 0x05010400u);                 // k order, unsigned 0 .. 15
+                    wv[2 * q + 1] = (int)__builtin_amdgcn_perm(hi, lo, 0x07030602u);
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) wv[w] = (int)(((uint32_t)rw8[i][w] ^ flip) ^ 0x80808080u); // bytewise u - 128
+            }
+            *(a8_i32x4*)(&s_w[buf][srow * PITCH + (sv0 + i) * 16]) = wv;
+        }
+        t += __shfl_xor(t, 1, 64); // the row's other thread (TPR = 2)
+        if (tid % TPR == 0) s_sa[buf][srow] = r_sa, s_rs[buf][srow] = r_sa * (float)t;
+    };
+    // weight scale and offset coefficient of this lane's two columns for a stage: requested one stage ahead as well (read in the fold they
+    // are four dependent memory round trips behind the MFMAs of every stage: 3.5 us per stage at 4096 x 14336 x 4096)
+    float sw[2], cf[2], sw_n[2], cf_n[2];
+    auto fetch_cols = [&](uint32_t st, float (&o_sw)[2], float (&o_cf)[2]) {
+        const uint32_t gw = min(st, stages - 1) * GK / p.group_size;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint32_t n = ncol[nb];
+            const float s_w_f = ldt(p.scales, p.w_dt, (size_t)n * w_groups + gw);
+            float beta;
+            if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) beta = ldt(p.biases, p.w_dt, (size_t)n * w_groups + gw);
+            else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                const uint8_t zb = p.zero_points[(size_t)n * zp_stride + (BITS == 4 ? gw >> 1 : gw)];
+                const uint32_t zp = BITS == 4 ? ((gw & 1) ? (zb >> 4) : (zb & 0x0F)) : zb;
+                beta = -s_w_f * (float)zp;
+            } else beta = -s_w_f * (BITS == 4 ? 8.0f : 128.0f);
+            o_sw[nb] = s_w_f, o_cf[nb] = fmaf(s_w_f, centre, beta);
+        }
+    };
+    fetch(0);
+    fetch_cols(0, sw, cf);
+    park(0);
+    __syncthreads();
+    for (uint32_t st = 0; st < stages; ++st) {
+        const int buf = st & 1;
+        fetch(st + 1); // unconditional: in flight during the products
+        fetch_cols(st + 1, sw_n, cf_n);
+        // ---- integer products of the stage
+        a8_i32x16 d[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[mb][nb][r] = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a8_i32x4 af[2], bf[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = *(const a8_i32x4*)(&s_a[buf][(wm * 64 + mb * 32 + c) * PITCH + ks * 32 + h * 16]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bf[nb] = *(const a8_i32x4*)(&s_w[buf][(wn * 64 + nb * 32 + c) * PITCH + ks * 32 + h * 16]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) d[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mb], bf[nb], d[mb][nb], 0, 0, 0);
+        }
+        // ---- fold: this lane's two columns, rows (r & 3) + 8 (r >> 2) + 4 h of each block
+        // packed f32 math (two rows per instruction): u = s_a * D, acc = fma(s_w, u, acc), acc = fma(coef, s_a * S, acc) -- 2 converts + 3 packed
+        // operations per pair of outputs; the fold is what bounds this kernel (64 outputs per lane and stage against 16 MFMAs)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = wm * 64 + mb * 32 + 8 * r4 + 4 * h; // rows row .. row + 3 = registers 4 r4 .. 4 r4 + 3
+                const float4 sa4 = *(const float4*)(&s_sa[buf][row]), rs4 = *(const float4*)(&s_rs[buf][row]);
+                const a8_f32x2 sa2[2] = {{sa4.x, sa4.y}, {sa4.z, sa4.w}}, rs2[2] = {{rs4.x, rs4.y}, {rs4.z, rs4.w}};
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const a8_f32x2 sw2 = {sw[nb], sw[nb]}, cf2 = {cf[nb], cf[nb]};
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int r = 4 * r4 + 2 * i2;
+                        const a8_f32x2 dv = {(float)d[mb][nb][r], (float)d[mb][nb][r + 1]};
+                        a8_f32x2 av = {acc[mb][nb][r], acc[mb][nb][r + 1]};
+                        av = __builtin_elementwise_fma(sw2, dv * sa2[i2], av);
+                        av = __builtin_elementwise_fma(cf2, rs2[i2], av);
+                        acc[mb][nb][r] = av.x, acc[mb][nb][r + 1] = av.y;
+                    }
+                }
+            }
+        if (st + 1 < stages) park(buf ^ 1); // the other buffer: its readers finished before the last barrier
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) sw[nb] = sw_n[nb], cf[nb] = cf_n[nb];
+        __syncthreads();
+    }
+    // ---- epilogue (kernel.rs:281-292)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint32_t n = n0 + wn * 64 + nb * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.m || n >= p.n) continue;
+                const size_t output_index = (size_t)m * p.n + n;
+                float value = p.ab_scale * acc[mb][nb][r];
+                if (p.accumulate) value += ldt(p.d, p.d_dt, output_index);
+                if (p.bias) value += ldt(p.bias, p.w_dt, n);
+                if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
+                stt(p.d, p.d_dt, output_index, value);
+            }
+        }
+}
+
 } // namespace
 
 uzu_status activation_transform(hipStream_t s, const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
@@ -231,6 +417,24 @@ uzu_status matmul_a8(hipStream_t s, const MatmulParams& p, const int8_t* a_q, co
     if (p.gather) {
         set_error("matmul: gather_indices with int8 activations is not supported");
         return UZU_ERR_UNSUPPORTED;
+    }
+    // prefill-sized M: the int8 matrix cores (stages of min(activation group, weight group) = 64 or 128 elements)
+    static const bool mfma_on = [] { // UZU_A8_MFMA=0: the VALU kernel everywhere (A/B runs)
+        const char* e = getenv("UZU_A8_MFMA");
+        return !e || atoi(e) != 0;
+    }();
+    const uint32_t gk = a_group_size < p.group_size ? a_group_size : p.group_size;
+    if (mfma_on && p.m >= 128 && (gk == 64 || gk == 128) && p.k % gk == 0 && (p.bits == 8 || p.k % 32 == 0) && (uintptr_t)a_q % 16 == 0 && (uintptr_t)p.b % 16 == 0 &&
+        p.k % 16 == 0) {
+        const dim3 g2(gemm_grid_x((p.m + 127u) / 128u, (p.n + 127u) / 128u));
+#define UZU_A8(B, G) return launch_check([&] { hipLaunchKernelGGL((gemm_a8_mfma_kernel<B, G>), g2, dim3(256), 0, s, p, a_q, a_scales, a_group_size); }, "gemm_a8_mfma")
+        if (p.bits == 4) {
+            if (gk == 64) UZU_A8(4, 64);
+            UZU_A8(4, 128);
+        }
+        if (gk == 64) UZU_A8(8, 64);
+        UZU_A8(8, 128);
+#undef UZU_A8
     }
     const dim3 grid((p.n + 63u) / 64u, (p.m + 63u) / 64u);
     if (p.bits == 4) return launch_check([&] { hipLaunchKernelGGL(matmul_a8_kernel<4>, grid, dim3(256), 0, s, p, a_q, a_scales, a_group_size); }, "matmul_a8<4>");
