@@ -388,7 +388,24 @@ def main():
     else:
         model = HipModel(ctx, bundle, flags)
 
-    elapsed, gpu_ms, start_ctx, end_ctx, prefill_s, timed_tokens = timed_decode(model, ctx, args, dist, prompt)
+    try:
+        elapsed, gpu_ms, start_ctx, end_ctx, prefill_s, timed_tokens = timed_decode(model, ctx, args, dist, prompt)
+    except Exception as exc:  # noqa: BLE001
+        # A failed peer-to-peer exchange is sticky and poisons the peers' mailboxes (csrc/tp.hip): every rank lands here within the
+        # bounded spin.  Real multi-GPU runs then fall back to RCCL for every all-reduce, eager launches -- slower, but a measured line
+        # instead of none; the note says so.  (Nothing to fall back to on one GPU or with ranks sharing a device.)
+        if not (mode == "tp" and p2p and not args.share_gpu):
+            raise
+        note = (note + "; " if note else "") + f"p2p + graph TP decode failed ({str(exc)[:160]}): rerun on RCCL, eager"
+        try:
+            model.close()
+        except Exception:  # noqa: BLE001
+            pass
+        group.disable_p2p()
+        p2p, use_graph = False, False
+        dist.barrier()
+        model = HipModel(ctx, local_bundle, flags | MODEL_NO_GRAPH, tp_group=group, vocab_offset=vocab_offset)
+        elapsed, gpu_ms, start_ctx, end_ctx, prefill_s, timed_tokens = timed_decode(model, ctx, args, dist, prompt)
     tokens_agree = True
     if args.share_gpu and dist is not None:  # every rank must have committed the same stream (rank-order sums, one arg-max key)
         gathered = [None] * world

@@ -379,7 +379,7 @@ static unsigned long long p2p_timeout_ticks() {
 // Host sync points of the TP engine (prefill chunk, decode, read_tokens) call this: a bounded wait that gave up anywhere since the
 // last check turns into an error status here instead of silently wrong tokens.
 uzu_status p2p_check(Comm* c) {
-    if (!c || !c->p2p.local) return UZU_OK;
+    if (!c || !c->p2p.local || !c->p2p.connected) return UZU_OK; // (after p2p_disable the mailboxes are out of use: an old timeout there does not concern the RCCL path)
     uint32_t e = 0;
     UZU_HIP_TRY(hipMemcpy(&e, c->p2p.local->error, 4, hipMemcpyDeviceToHost));
     if (e) {
