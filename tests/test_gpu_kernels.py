@@ -1197,13 +1197,15 @@ def test_matmul_int8_symmetric_activations(hip_ctx, bits, method, group_size, a_
     assert (ulps == 0).mean() >= 0.97
 
 
+@pytest.mark.parametrize("bits", [4, 8])
 @pytest.mark.parametrize("m,n,k", [(1024, 7168, 1024), (4096, 14336, 4096)])
-def test_matmul_int8_activations_throughput_report(hip_ctx, m, n, k, capsys):
+def test_matmul_int8_activations_throughput_report(hip_ctx, m, n, k, bits, capsys):
     """Not a parity test (that is test_matmul_int8_symmetric_activations): the int8-MFMA A8 GEMM next to the bf16-activation GEMM on the
     same int4 g128 weights, GPU time of one command buffer of 5 launches each (uzu_hip_cmdbuf_gpu_execution_time_ns) -- the figure DESIGN.md
     quotes.  Asserts only that both ran and that the two results agree to the activation-quantisation error (int8 codes: ~1 % rms)."""
     rng = np.random.default_rng(m + n)
-    q = quant_matrix(rng, n, k, 4, 128, 0)
+    q = quant_matrix(rng, n, k, bits, 128, 0)
+    mode = B.QMODE_U4 if bits == 4 else B.QMODE_U8
     x = bf16(rng.normal(0, 1.0, (m, k)))
     factors = np.ones(k, np.int32)
     kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
@@ -1221,11 +1223,11 @@ def test_matmul_int8_activations_throughput_report(hip_ctx, m, n, k, capsys):
 
     def bf16_path(cb):
         for _ in range(5):
-            kern.encode(cb, a=bx, b=bw, d=bd16, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=B.QMODE_U4, group_size=128)
+            kern.encode(cb, a=bx, b=bw, d=bd16, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=mode, group_size=128)
 
     def a8_path(cb):
         for _ in range(5):
-            kern.encode(cb, a=bq, b=bw, d=bd8, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=B.QMODE_U4, group_size=128,
+            kern.encode(cb, a=bq, b=bw, d=bd8, m=m, n=n, k=k, b_kind=B.B_SCALE_BIAS, scales=bsc, biases=bbi, zero_points=None, mode=mode, group_size=128,
                         a_int8_scales=bs_, a_group_size=128)
     for fn in (bf16_path, a8_path):
         run(hip_ctx, fn)  # warm-up (workspace growth, code load)
@@ -1233,7 +1235,7 @@ def test_matmul_int8_activations_throughput_report(hip_ctx, m, n, k, capsys):
     t8 = run(hip_ctx, a8_path).gpu_execution_time() / 5
     flops = 2.0 * m * n * k
     with capsys.disabled():
-        print(f"\nA8 report {m}x{n}x{k}: bf16-activation GEMM {t16 * 1e6:.1f} us = {flops / t16 / 1e12:.0f} TFLOP/s; int8-MFMA A8 GEMM {t8 * 1e6:.1f} us = {flops / t8 / 1e12:.0f} TOP/s")
+        print(f"\nA8 report int{bits} weights {m}x{n}x{k}: bf16-activation GEMM {t16 * 1e6:.1f} us = {flops / t16 / 1e12:.0f} TFLOP/s; int8-MFMA A8 GEMM {t8 * 1e6:.1f} us = {flops / t8 / 1e12:.0f} TOP/s")
     d16, d8 = f32(bd16.download(np.uint16, m * n)), f32(bd8.download(np.uint16, m * n))
     assert t16 > 0 and t8 > 0
     assert np.sqrt(np.mean((d16 - d8) ** 2)) <= 0.03 * np.sqrt(np.mean(d16 ** 2))
