@@ -715,6 +715,19 @@ def test_qlora_adapters_and_rht_embeddings_end_to_end(hip_ctx, preset, kw):
         _set_exact(False)
 
 
+@pytest.mark.parametrize("preset,kw", [("tiny-llama", {"qlora_rank": 8, "group_size": 64}), ("tiny-qwen", {"qlora_rank": 4})])
+def test_qlora_without_signs_keeps_its_adapter_in_a_prefill_of_128_rows_or_more(hip_ctx, preset, kw):
+    """A QLoRA linear WITHOUT incoherence signs and a prefill chunk of >= 128 rows at group 64: the shape for which the up projection
+    would take the fused matrix-core GEMM + GatedActMul path (engine.hip::linear_gated), which knows nothing of the adapter term
+    (x down^T) up^T (qlora_wrapper.rs:177-251).  Teacher-forced against the oracle: prefill logits and six decode steps."""
+    cfg = S.PRESETS[preset](seed=51, **kw)
+    o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 200, 6, teacher_forced=True)
+    for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
+        assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
+    om.close()
+    hm.close()
+
+
 def test_hybrid_spec_model_directory_round_trip(hip_ctx, tmp_path):
     """weights.quantized.* + weights.adapter.{down,up}_projection + weights.incoherence_signs.* (QLoRA), embedding.quantized.* +
     embedding.incoherence_signs.output_signs (RHT embedding): save -> load -> identical tokens and logits."""

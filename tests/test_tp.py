@@ -60,6 +60,71 @@ def small_cfg(method=D.QUANT_SCALE_BIAS, hidden=384, group=64):
     return S.tiny_qwen(hidden_dim=hidden, group_size=group, method=method, num_heads=4, num_groups=2, dn_num_heads=4, dn_num_groups=2)
 
 
+def _rht(v, signs):
+    """float64 InputRht / OutputRht on whole 32-element blocks: H32 (Sylvester, orthonormal) applied to sign-flipped values
+    (activation_transform.rs:43-136: input mode multiplies by the factors first, output mode after -- H is symmetric)."""
+    H = np.array([[1.0]])
+    while H.shape[0] < 32:
+        H = np.block([[H, H], [H, -H]])
+    H /= np.sqrt(32.0)
+    return v.reshape(-1, 32), H, signs.reshape(-1, 32).astype(np.float64)
+
+
+def in_rht(x, signs):
+    b, H, s = _rht(x, signs)
+    return ((b * s) @ H).reshape(-1)
+
+
+def out_rht(y, signs):
+    b, H, s = _rht(y, signs)
+    return ((b @ H) * s).reshape(-1)
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_rht_linears_shard_with_their_hadamard_factors(size):
+    """HybridSpec linears: y = OutRht(W InRht(x)) (rht_wrapper.rs:215-298).  Column-parallel shards are the matching rows of y; the
+    row-parallel shards' partial products sum to W InRht(x) and the (whole) output factors are applied once behind the sum."""
+    cfg = S.tiny_llama(rht=True, hidden_dim=256, group_size=32)
+    bundle = S.build_model(cfg)
+    shards = [TP.shard_bundle(bundle, r, size)[0] for r in range(size)]
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(cfg.model_dim,))
+    for li, full in enumerate(bundle.layers):
+        parts = [s.layers[li] for s in shards]
+        up = full.up_projection
+        assert up.input_signs is not None and up.output_signs is not None
+        want = out_rht(dequant(up) @ in_rht(x, up.input_signs), up.output_signs)
+        h = full.hidden_dim
+        for r, p in enumerate(parts):
+            hp = p.hidden_dim
+            got = out_rht(dequant(p.up_projection) @ in_rht(x, p.up_projection.input_signs), p.up_projection.output_signs)
+            close(got[:hp], want[r * hp:(r + 1) * hp])
+            close(got[hp:], want[h + r * hp:h + (r + 1) * hp])
+        y = rng.normal(size=(h,))
+        down = full.down_projection
+        want = out_rht(dequant(down) @ in_rht(y, down.input_signs), down.output_signs)
+        acc = np.zeros(cfg.model_dim)
+        for r, p in enumerate(parts):
+            hp = p.hidden_dim
+            acc += dequant(p.down_projection) @ in_rht(y[r * hp:(r + 1) * hp], p.down_projection.input_signs)
+            assert np.array_equal(p.down_projection.output_signs, down.output_signs)
+            assert (p.down_projection.out_biases is None) == (down.out_biases is None)  # the bias sits behind OutputRht: on every rank
+        np.testing.assert_allclose(out_rht(acc, down.output_signs), want, rtol=1e-10, atol=1e-11)
+
+
+def test_planner_refuses_what_it_would_get_wrong():
+    # QLoRA adapters would be dropped by the slicing helpers; a DeltaNet in-proj's beta / a rows cut a 32-row OutputRht block
+    with pytest.raises(NotImplementedError, match="QLoRA"):
+        TP.shard_bundle(S.build_model(S.tiny_llama(qlora_rank=4)), 0, 2)
+    up = S.build_model(S.tiny_llama(rht=True)).layers[0].up_projection
+    with pytest.raises(NotImplementedError, match="OutputRht block"):
+        TP.take_rows(up, np.arange(8, 40))
+    assert np.array_equal(TP.take_rows(up, np.arange(32, 96)).output_signs, up.output_signs[32:96])
+    TP.shard_bundle(S.build_model(S.tiny_qwen(rht=True)), 0, 2)  # (the synthetic in-proj, n % 32 != 0, carries no factors)
+    with pytest.raises(NotImplementedError, match="RHT embeddings"):
+        TP.shard_bundle(S.build_model(S.tiny_llama(rht_embeddings=True)), 0, 2)
+
+
 @pytest.mark.parametrize("size", [2, 4])
 @pytest.mark.parametrize("method", [D.QUANT_SCALE_BIAS, D.QUANT_SCALE_ZERO_POINT, D.QUANT_SCALE_SYMMETRIC])
 def test_shards_reassemble_the_full_layer(size, method):
@@ -333,6 +398,9 @@ TP_CASES = [
     ("tiny-qwen", {}, 40, 8, 0.25, 0.05),
     ("tiny-llama", {}, 40, 8, 0.25, 0.05),
     ("llama-3-8b", {"max_context_length": 256, "layer_kinds": ["MIXER_ATTENTION", "MIXER_ATTENTION"], "seed": 7}, 48, 5, 0.25, 0.05),
+    # HybridSpec (RHT) linears under TP: the Hadamard factors are cut with their rows / k slices (tp.py::take_rows / take_k), OutputRht of a
+    # row-parallel linear runs behind the all-reduce (rht_wrapper.rs:215-298)
+    ("tiny-llama", {"rht": True}, 40, 8, 0.25, 0.05),
 ]
 
 

@@ -544,7 +544,8 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
         const char* v = getenv("UZU_GEMM_ACT");
         return !v || atoi(v) != 0;
     }();
-    if (!enabled || L.in_signs || L.out_signs || L.out_biases || L.method == UZU_QUANT_NONE || (e.m->flags & UZU_MODEL_NO_FUSION)) return false;
+    // RHT / QLoRA linears run as their wrappers compose them: the fused GEMM knows nothing of the adapter term (x down^T) up^T
+    if (!enabled || L.in_signs || L.out_signs || L.out_biases || L.lora_rank || L.method == UZU_QUANT_NONE || (e.m->flags & UZU_MODEL_NO_FUSION)) return false;
     k::MatmulParams p{};
     p.a = input, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = gated_out;
     p.w_dt = p.a_dt = p.d_dt = UZU_BF16;

@@ -46,6 +46,24 @@ extern thread_local LaunchTimer* tl_launch_timer; // runtime.hip
         }                                    \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: the "already raised" cache of a launch site is
+// keyed by the current device (a process may hold contexts on several GPUs)
+struct LdsLimit {
+    size_t raised_to[16] = {0};
+};
+inline bool raise_lds_limit(LdsLimit& st, const void* fn, size_t lds) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& have = st.raised_to[dev & 15];
+    if (lds <= have) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    have = lds;
+    return true;
+}
+
 #define UZU_PROPAGATE(expr)            \
     do {                               \
         uzu_status _s = (expr);        \

@@ -577,14 +577,10 @@ __global__ void __launch_bounds__(256, BITS == 4 ? 2 : 1) gemm_a8_dma_kernel(Mat
 }
 template <int BITS, int GK> static uzu_status launch_a8_dma(hipStream_t s, const MatmulParams& p, const int8_t* a_q, const float* a_scales, uint32_t a_group_size) {
     constexpr size_t lds = 3 * (128 * GK + 128 * GK * BITS / 8 + 1536) + 3 * 128 * 4;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void*)gemm_a8_dma_kernel<BITS, GK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("matmul_a8: %zu bytes of LDS are not available", lds);
-            return UZU_ERR_UNSUPPORTED;
-        }
-        raised = true;
+    static LdsLimit lim;
+    if (!raise_lds_limit(lim, (const void*)gemm_a8_dma_kernel<BITS, GK>, lds)) {
+        set_error("matmul_a8: %zu bytes of LDS are not available", lds);
+        return UZU_ERR_UNSUPPORTED;
     }
     const dim3 grid(gemm_grid_x((p.m + 127u) / 128u, (p.n + 127u) / 128u));
     return launch_check([&] { hipLaunchKernelGGL((gemm_a8_dma_kernel<BITS, GK>), grid, dim3(256), lds, s, p, a_q, a_scales, a_group_size); }, "gemm_a8_dma");
@@ -646,7 +642,11 @@ uzu_status matmul_a8(hipStream_t s, const MatmulParams& p, const int8_t* a_q, co
             const char* e = getenv("UZU_A8_MFMA");
             return !e || atoi(e) != 2;
         }();
-        if (dma_on && p.w_dt == UZU_BF16 && (uintptr_t)p.scales % 4 == 0 && (uintptr_t)a_scales % 4 == 0 &&
+        // the DMA kernel fetches table entries as the aligned dword that holds them: a table whose byte size is not a multiple of 4 (odd
+        // n * groups of bf16 entries, n * zp_stride of u8 zero points) would be read 1-3 bytes past its end on a tightly packed buffer
+        const uint32_t w_groups = (p.k + p.group_size - 1) / p.group_size, zp_stride = p.bits == 4 ? (w_groups + 1) / 2 : w_groups;
+        const bool tables_whole = ((uint64_t)p.n * w_groups * 2) % 4 == 0 && (p.b_kind != UZU_MATMUL_B_SCALE_ZERO_POINT || ((uint64_t)p.n * zp_stride) % 4 == 0);
+        if (dma_on && tables_whole && p.w_dt == UZU_BF16 && (uintptr_t)p.scales % 4 == 0 && (uintptr_t)a_scales % 4 == 0 &&
             (p.b_kind != UZU_MATMUL_B_SCALE_BIAS || (uintptr_t)p.biases % 4 == 0) && (p.b_kind != UZU_MATMUL_B_SCALE_ZERO_POINT || (uintptr_t)p.zero_points % 4 == 0)) {
             if (p.bits == 4) return gk == 64 ? launch_a8_dma<4, 64>(s, p, a_q, a_scales, a_group_size) : launch_a8_dma<4, 128>(s, p, a_q, a_scales, a_group_size);
             return gk == 64 ? launch_a8_dma<8, 64>(s, p, a_q, a_scales, a_group_size) : launch_a8_dma<8, 128>(s, p, a_q, a_scales, a_group_size);

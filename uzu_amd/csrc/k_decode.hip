@@ -764,14 +764,10 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
             grid = (want * 4 + pl.wg_batches - 1) / pl.wg_batches;                                                                  \
         }                                                                                                                           \
         if (lds > 65536) { /* K > ~24k on the LDS-resident-row path: raise the instance's dynamic-LDS limit to what this call needs */ \
-            static size_t raised_to = 0;                                                                                            \
-            if (lds > raised_to) {                                                                                                  \
-                if (hipFuncSetAttribute((const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-                    (void)hipGetLastError();                                                                                        \
-                    set_error("gemv_dec: %zu bytes of LDS for the activation row of K = %u are not available", lds, p.k);           \
-                    return UZU_ERR_UNSUPPORTED;                                                                                     \
-                }                                                                                                                   \
-                raised_to = lds;                                                                                                    \
+            static LdsLimit lim;                                                                                                    \
+            if (!raise_lds_limit(lim, (const void*)gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>, lds)) {             \
+                set_error("gemv_dec: %zu bytes of LDS for the activation row of K = %u are not available", lds, p.k);               \
+                return UZU_ERR_UNSUPPORTED;                                                                                         \
             }                                                                                                                       \
         }                                                                                                                           \
         if (grid_out) *grid_out = grid;                                                                                             \

@@ -1064,9 +1064,13 @@ extern "C" uint32_t uzu_hip_debug_decode_stream_error(void) { // bit mask of bou
     return v;
 }
 
-static bool g_stream_launched = false;
+// per device: which devices have run a weight-stream kernel (bit d); the error word is a __device__ symbol, i.e. one per device, and
+// the symbol copy acts on the CURRENT device -- callers make their context's device current first (engine.hip does)
+static uint32_t g_stream_launched = 0;
 uzu_status gemv_stream_check() {
-    if (!g_stream_launched) return UZU_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(g_stream_launched & (1u << (dev & 31)))) return UZU_OK;
     const uint32_t v = uzu_hip_debug_decode_stream_error();
     if (v) {
         set_error("gemv_stream: a bounded wait inside a weight-stream kernel gave up (mask 0x%x): its outputs are invalid", v);
@@ -1129,14 +1133,10 @@ bool gemv_stream_wanted(const DecGemvParams& p) {
 
 template <int CPL, bool ACT, int PRO, int NW>
 static uzu_status launch_stream(hipStream_t s, const DecGemvParams& p, const StreamGeo& g, uint32_t grid, size_t lds) {
-    static size_t raised_to = 0;
-    if (lds > raised_to) {
-        if (hipFuncSetAttribute((const void*)gemv_stream_kernel<CPL, ACT, PRO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gemv_stream: %zu bytes of LDS are not available", lds);
-            return UZU_ERR_UNSUPPORTED;
-        }
-        raised_to = lds;
+    static LdsLimit lim;
+    if (!raise_lds_limit(lim, (const void*)gemv_stream_kernel<CPL, ACT, PRO, NW>, lds)) {
+        set_error("gemv_stream: %zu bytes of LDS are not available", lds);
+        return UZU_ERR_UNSUPPORTED;
     }
     return launch_check([&] { hipLaunchKernelGGL((gemv_stream_kernel<CPL, ACT, PRO, NW>), dim3(grid), dim3(64 * NW), lds, s, p, g); }, "gemv_stream");
 }
@@ -1161,14 +1161,10 @@ static int stream_waves(int cpl) {
 
 template <bool ACT, int PRO, int RGS>
 static uzu_status launch_stream_mfma(hipStream_t s, const DecGemvParams& p, const MfmaGeo& g, uint32_t grid, size_t lds) {
-    static size_t raised_to = 0;
-    if (lds > raised_to) {
-        if (hipFuncSetAttribute((const void*)gemv_stream_mfma_kernel<ACT, PRO, RGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gemv_stream_mfma: %zu bytes of LDS are not available", lds);
-            return UZU_ERR_UNSUPPORTED;
-        }
-        raised_to = lds;
+    static LdsLimit lim;
+    if (!raise_lds_limit(lim, (const void*)gemv_stream_mfma_kernel<ACT, PRO, RGS>, lds)) {
+        set_error("gemv_stream_mfma: %zu bytes of LDS are not available", lds);
+        return UZU_ERR_UNSUPPORTED;
     }
     return launch_check([&] { hipLaunchKernelGGL((gemv_stream_mfma_kernel<ACT, PRO, RGS>), dim3(grid), dim3(1024), lds, s, p, g); }, "gemv_stream_mfma");
 }
@@ -1226,7 +1222,11 @@ uzu_status gemv_stream_mfma(hipStream_t s, const DecGemvParams& p_in, int num_cu
 }
 
 uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint32_t* grid_out) {
-    g_stream_launched = true;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        g_stream_launched |= 1u << (dev & 31);
+    }
     if (stream_mfma_on() && gemv_stream_mfma_supported(p_in)) return gemv_stream_mfma(s, p_in, num_cus, grid_out); // matrix-core consumers
     DecGemvParams p = p_in;
 #ifdef UZU_TIMELINE

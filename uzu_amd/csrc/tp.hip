@@ -187,9 +187,11 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
     __shared__ uint32_t s_seq, s_ok;
     Mailbox* mine = a.box[a.rank];
     const uint32_t tid = threadIdx.x, words = OP == 0 ? count : 2 * count, pairs = (words + 1) / 2;
-    // A failed exchange is STICKY: the error word stays set, every later exchange of this rank skips its wait and poisons its
-    // output (NaN sums / a zero key), and its peers run into their own bounded wait -- the group fails as a whole and every host
-    // finds the error word at its next sync point (p2p_check) instead of carrying on with un-reduced partial sums.
+    // A failed exchange is STICKY and GROUP-WIDE: the rank whose wait gave up writes the failing sequence number into the error word
+    // of EVERY mailbox (its own and its peers', system scope).  A slow peer -- the realistic skew case: it finds every flag it waits
+    // for, because the rank that gave up had already pushed its row -- therefore still sees the failure: its next exchange starts
+    // poisoned (NaN sums / a zero key, no wait) and its host finds the error word at its next sync point (p2p_check), so that every
+    // rank raises instead of one rank sitting in a host barrier while the others carry on with garbage sums.
     if (tid == 0) s_seq = mine->seq[0] + 1u, s_ok = __hip_atomic_load(&mine->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u ? 1u : 0u;
     __syncthreads();
     const uint32_t seq = s_seq, par = seq & 1u;
@@ -234,10 +236,9 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            if (!poisoned) __hip_atomic_store(&mine->error[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            mine->seq[0] = seq;
-        }
+        if (!poisoned && tid < (uint32_t)a.size) // first failure on this rank: tell the whole group (own word included)
+            __hip_atomic_store(&a.box[tid]->error[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) mine->seq[0] = seq;
         return;
     }
     // 4. reduce in rank order (the same order on every rank: bit-identical results)

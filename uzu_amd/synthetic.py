@@ -273,7 +273,12 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
         tied_embeddings=cfg.tied_embeddings, output_embedding=output_embedding)
 
 
-def synthetic_prompt(length: int, vocab_size: int) -> np.ndarray:
-    """token ids = (i*7919 + 13) mod vocab."""
+def synthetic_prompt(length: int, vocab_size: int, variant: int = 0, suffix: int = 16) -> np.ndarray:
+    """token ids = (i*7919 + 13) mod vocab.  `variant` != 0 shifts the last `suffix` ids by variant * 15485863 (mod vocab): a
+    family of prompts that share all but their tail, used to pick a prompt whose greedy continuation has no near-tie (tools/stream_search.py)."""
     i = np.arange(length, dtype=np.int64)
-    return ((i * 7919 + 13) % vocab_size).astype(np.uint32)
+    ids = (i * 7919 + 13) % vocab_size
+    if variant:
+        tail = i >= length - suffix
+        ids[tail] = (ids[tail] + int(variant) * 15485863) % vocab_size
+    return ids.astype(np.uint32)

@@ -35,20 +35,54 @@ from . import desc as D
 
 
 # ------------------------------------------------------------------------------------------------ slicing helpers
+RHT_BLOCK = 32  # HybridSpec incoherence block (rht_wrapper.rs:140-160): the Hadamard factors act on 32 consecutive elements
+
+
+def _refuse_adapters(w: D.LinearWeights):
+    # QLoRA (qlora_wrapper.rs:177-251): a row-parallel shard would need `down` cut along k plus an all-reduce of the rank-r
+    # intermediate in front of `up`; not planned -- refuse instead of dropping the adapter term (the helpers below rebuild
+    # LinearWeights field by field)
+    if w.adapter_down is not None or w.adapter_up is not None:
+        raise NotImplementedError("tensor-parallel shards of QLoRA (HybridSpec + LowRankSpec) linears are not planned: the adapters would be dropped")
+
+
+def _whole_rht_blocks(idx: np.ndarray) -> bool:
+    """True iff `idx` is a concatenation of whole, aligned 32-row blocks (then OutputRht of the shard == shard of OutputRht)."""
+    if len(idx) % RHT_BLOCK:
+        return False
+    blocks = np.asarray(idx).reshape(-1, RHT_BLOCK)
+    return bool(np.all(blocks[:, 0] % RHT_BLOCK == 0) and np.all(blocks == blocks[:, :1] + np.arange(RHT_BLOCK)))
+
+
 def take_rows(w: D.LinearWeights, idx: np.ndarray) -> D.LinearWeights:
-    """Column-parallel shard: keep output rows `idx` (in that order)."""
+    """Column-parallel shard: keep output rows `idx` (in that order).  HybridSpec linears (RHTLinearWrapper): the input factors stay
+    whole (k is not cut), the output factors follow their rows -- which must then be whole 32-row Hadamard blocks."""
+    _refuse_adapters(w)
     cp = lambda a: None if a is None else np.ascontiguousarray(a[idx])
+    if w.output_signs is not None and not _whole_rht_blocks(idx):
+        raise NotImplementedError("tensor-parallel shard cuts a 32-row OutputRht block of a HybridSpec linear")
     return D.LinearWeights(int(len(idx)), w.k, w.bits, w.group_size, w.method, cp(w.weights), cp(w.scales), cp(w.biases),
-                           cp(w.zero_points), cp(w.out_biases))
+                           cp(w.zero_points), cp(w.out_biases), input_signs=w.input_signs, output_signs=cp(w.output_signs))
 
 
 def take_k(w: D.LinearWeights, k0: int, k1: int, owns_out_bias: bool) -> D.LinearWeights:
     """Row-parallel shard: keep input columns [k0, k1).  k0, k1 must be quant-group boundaries (nibble-packed int4
     zero-points are repacked).  The Linear's output bias is added by one rank only."""
+    _refuse_adapters(w)
+    # HybridSpec: InputRht is block-diagonal along k, so a 32-aligned k slice takes its own factors; OutputRht (and the bias behind
+    # it, rht_wrapper.rs:281-298) runs on the all-reduced rows on EVERY rank, so the output factors and the bias stay whole everywhere
+    isg = None
+    if w.input_signs is not None:
+        if k0 % RHT_BLOCK or k1 % RHT_BLOCK:
+            raise NotImplementedError("tensor-parallel K split cuts a 32-element InputRht block of a HybridSpec linear")
+        isg = np.ascontiguousarray(w.input_signs[k0:k1])
+    if w.output_signs is not None:
+        owns_out_bias = True
     if w.method == D.QUANT_NONE:
         assert w.bits == 16
         wt = np.ascontiguousarray(w.weights.reshape(w.n, w.k)[:, k0:k1])
-        return D.LinearWeights(w.n, k1 - k0, 16, 0, w.method, wt, None, None, None, w.out_biases if owns_out_bias else None)
+        return D.LinearWeights(w.n, k1 - k0, 16, 0, w.method, wt, None, None, None, w.out_biases if owns_out_bias else None,
+                               input_signs=isg, output_signs=w.output_signs)
     g = w.group_size
     assert k0 % g == 0 and k1 % g == 0, f"K split [{k0},{k1}) is not on group boundaries (group {g})"
     g0, g1 = k0 // g, k1 // g
@@ -69,28 +103,32 @@ def take_k(w: D.LinearWeights, k0: int, k1: int, owns_out_bias: bool) -> D.Linea
             zp = np.ascontiguousarray(cut[:, 0::2] | (cut[:, 1::2] << 4))
         else:
             zp = np.ascontiguousarray(z[:, g0:g1])
-    return D.LinearWeights(w.n, k1 - k0, w.bits, g, w.method, wt, sc, bi, zp, w.out_biases if owns_out_bias else None)
+    return D.LinearWeights(w.n, k1 - k0, w.bits, g, w.method, wt, sc, bi, zp, w.out_biases if owns_out_bias else None,
+                           input_signs=isg, output_signs=w.output_signs)
 
 
 def _zero_rows(w: D.LinearWeights, count: int) -> D.LinearWeights:
     """`count` extra output rows that dequantise to exactly 0 (scale = bias = 0) -- MLP hidden padding."""
     z = lambda a: None if a is None else np.zeros((count,) + a.shape[1:], dtype=a.dtype)
+    ones = None if w.output_signs is None else np.ones(count, dtype=w.output_signs.dtype)  # H * 0 = 0 whatever the factors
     return D.LinearWeights(count, w.k, w.bits, w.group_size, w.method, z(w.weights), z(w.scales), z(w.biases), z(w.zero_points),
-                           z(w.out_biases))
+                           z(w.out_biases), input_signs=w.input_signs, output_signs=ones)
 
 
 def _concat_rows(parts: List[D.LinearWeights]) -> D.LinearWeights:
     first = parts[0]
     cat = lambda name: None if getattr(first, name) is None else np.ascontiguousarray(np.concatenate([getattr(p, name) for p in parts], axis=0))
     return D.LinearWeights(sum(p.n for p in parts), first.k, first.bits, first.group_size, first.method, cat("weights"), cat("scales"),
-                           cat("biases"), cat("zero_points"), cat("out_biases"))
+                           cat("biases"), cat("zero_points"), cat("out_biases"), input_signs=first.input_signs, output_signs=cat("output_signs"))
 
 
 def _pad_k(w: D.LinearWeights, new_k: int) -> D.LinearWeights:
     """Extend the input dimension with columns that contribute exactly 0 (their activations are 0 as well)."""
     if new_k == w.k:
         return w
+    _refuse_adapters(w)
     assert w.method != D.QUANT_NONE and (new_k - w.k) % w.group_size == 0
+    isg = None if w.input_signs is None else np.concatenate([w.input_signs, np.ones(new_k - w.k, dtype=w.input_signs.dtype)])  # the padded inputs are 0
     extra_groups = (new_k - w.k) // w.group_size
     extra_bytes = (new_k - w.k) * w.bits // 8
     wt = np.concatenate([w.weights.reshape(w.n, -1), np.zeros((w.n, extra_bytes), dtype=np.uint8)], axis=1)
@@ -103,7 +141,8 @@ def _pad_k(w: D.LinearWeights, new_k: int) -> D.LinearWeights:
         z = w.zero_points.reshape(w.n, -1)
         zp = np.concatenate([z, np.zeros((w.n, zp_cols - z.shape[1]), dtype=np.uint8)], axis=1)
     return D.LinearWeights(w.n, new_k, w.bits, w.group_size, w.method, np.ascontiguousarray(wt), np.ascontiguousarray(sc),
-                           None if bi is None else np.ascontiguousarray(bi), None if zp is None else np.ascontiguousarray(zp), w.out_biases)
+                           None if bi is None else np.ascontiguousarray(bi), None if zp is None else np.ascontiguousarray(zp), w.out_biases,
+                           input_signs=isg, output_signs=w.output_signs)
 
 
 def _head_range(total: int, rank: int, size: int) -> Tuple[int, int]:
@@ -187,20 +226,15 @@ def shard_layer(l: D.LayerWeights, rank: int, size: int) -> D.LayerWeights:
 def shard_bundle(bundle: D.ModelBundle, rank: int, size: int) -> Tuple[D.ModelBundle, int]:
     """-> (shard bundle, vocab_offset).  size == 1 still produces the untied-readout form the TP engine expects."""
     assert 0 <= rank < size
-    # HybridSpec (RHT) linears: the Hadamard sign vectors would have to be cut with the rows / k slices (32-aligned) and the
-    # output transform of a row-parallel linear moved behind the all-reduce.  Not planned here: refuse instead of silently running
-    # plain matmuls on RHT-space weights (the slicing helpers below rebuild LinearWeights without the sign vectors).
-    def _lin(b):
-        yield b.embedding
-        if b.output_embedding is not None:
-            yield b.output_embedding
-        for l in b.layers:
-            for name in ("up_projection", "down_projection", "qkv_projection", "gate_projection", "out_projection", "dn_in_proj", "dn_out_proj"):
-                w = getattr(l, name, None)
-                if w is not None:
-                    yield w
-    if any(w.input_signs is not None or w.output_signs is not None for w in _lin(bundle)):
-        raise NotImplementedError("tensor-parallel shards of HybridSpec (RHT) linears are not planned: input_signs / output_signs would be dropped")
+    # HybridSpec linears shard with their Hadamard factors (take_rows / take_k: 32-aligned cuts only, refused otherwise).  Not planned:
+    # QLoRA adapters (refused by the helpers) and RHT embeddings (the read-out is cut by vocabulary rows, its InputRht form and the
+    # lookup's OutputRht would each need the factors of the other cut).
+    if bundle.embedding.input_signs is not None or bundle.embedding.output_signs is not None or (
+            bundle.output_embedding is not None and (bundle.output_embedding.input_signs is not None or bundle.output_embedding.output_signs is not None)):
+        raise NotImplementedError("tensor-parallel shards of RHT embeddings are not planned")
+    for w in (bundle.embedding, bundle.output_embedding):
+        if w is not None:
+            _refuse_adapters(w)
     V = bundle.vocab_size
     assert V % size == 0, f"vocab {V} does not split over {size} ranks"
     lo, hi = rank * V // size, (rank + 1) * V // size
