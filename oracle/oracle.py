@@ -20,7 +20,7 @@ BF16, F32 = 0, 2
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("uzu_oracle_kernels.c", "uzu_oracle_model.c", "uzu_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzu_oracle_kernels.c", "uzu_oracle_tree_verify.c", "uzu_oracle_model.c", "uzu_oracle.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "uzu_model_desc.h"))
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
@@ -180,6 +180,25 @@ class OracleModel:
         for s in range(0, tokens.size, 1024):
             out = self.forward(tokens[s:s + 1024], want_logits)
         return out
+
+    def verify_tree(self, tokens, trie, want_logits: bool = False):
+        """One NOT-accepted pass over a speculated tree (DFS order; trie uint32 [n, 3] = {start, end, height} per node):
+        -> greedy token of every node [, logits bf16 [n, vocab]].  Follow with accept()."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        trie = np.ascontiguousarray(trie, dtype=np.uint32).reshape(tokens.size, 3)
+        sampled = np.empty(tokens.size, dtype=np.uint32)
+        logits = np.empty((tokens.size, self.vocab_size), dtype=np.uint16) if want_logits else None
+        fn = lib().orc_model_verify_tree
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        fn(self._h, p(tokens), p(trie), C.c_uint32(tokens.size), p(sampled), p(logits))
+        return (sampled, logits) if want_logits else sampled
+
+    def accept(self, indices):
+        """TransformerState::encode_accept with a root path of the pending tree (FlatTrie::accept's indices)."""
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        fn = lib().orc_model_accept
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint32]
+        fn(self._h, p(indices), C.c_uint32(indices.size))
 
     def layer_output(self, layer: int) -> np.ndarray:
         rows = C.c_uint32(0)

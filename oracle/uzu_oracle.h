@@ -208,6 +208,28 @@ void orc_delta_net_norm_gate(uint16_t* in_out, const uint16_t* in_proj, const fl
                              uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
                              uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
 
+/* ---- Gated DeltaNet over a speculated token tree (cpu/kernel/gdn/tree_verify/*.rs; uzu_oracle_tree_verify.c).  `dt` = element type of the
+ *      activation tensors (ORC_BF16 in the model; the reference's kernel tests also run f32); trie = 3 u32 per node {start, end, height} ---- */
+void orc_conv_tree_scan(const void* in_proj, const float* conv_weight, const float* bias, const float* base_state, const int32_t* parents,
+                        void* out_proj, float* suffix_state, uint32_t dt, uint32_t suffix_len, uint32_t kernel_size, uint32_t total_proj_dim,
+                        uint32_t conv_dim);
+void orc_delta_net_tree_prep(const void* in_proj, const float* a_log, const float* dt_bias, void* q_norm_out, void* k_norm_out,
+                             void* compact_v_out, float* beta_out, float* log_decay_out, uint32_t dt, uint32_t num_v_heads,
+                             uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+void orc_build_tree_prefix(const uint32_t* trie, const float* log_decay, float* prefix, uint32_t batch_size, uint32_t tree_size,
+                           uint32_t value_heads);
+void orc_build_tree_gram(const void* q, const void* k, uint32_t dt, const uint32_t* trie, const float* prefix, const float* beta, const float* h0,
+                         const int32_t* h0_idx, float* a_packed, float* qkd, float* a_inv, float* kh0, float scale, uint32_t batch_size,
+                         uint32_t tree_size, uint32_t k_heads, uint32_t value_heads, uint32_t head_k_dim, uint32_t head_v_dim);
+void orc_tree_update_solve(const float* kh0, const void* v, uint32_t dt, const float* prefix, const float* beta, const float* a_packed,
+                           const float* a_inv, const int32_t* h0_idx, float* u, uint32_t batch_size, uint32_t tree_size, uint32_t value_heads,
+                           uint32_t head_v_dim);
+void orc_build_tree_out(const void* q, uint32_t qk_dt, const float* prefix, const float* qkd, const float* u, const float* h0, const int32_t* h0_indices,
+                        void* o, uint32_t out_dt, float scale, uint32_t batch_size, uint32_t tree_size, uint32_t qk_heads, uint32_t value_heads,
+                        uint32_t head_k_dim, uint32_t head_v_dim);
+void orc_state_advance(const void* k_norm, const void* v, uint32_t dt, const float* log_decay_buf, const float* beta_buf, const uint32_t* accepted_indices,
+                       float* state, uint32_t accepted_len, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim);
+
 /* ---- model driver: Decoder::encode + greedy Sampling + encode_accept
  *      (decoder.rs:138-203, transformer.rs:226-329, transformer_layer.rs:194-238,
  *       engine/language_model/stream/stream.rs:190-345,593-751) ---- */
@@ -221,6 +243,12 @@ uint32_t orc_model_context_length(const orc_model* m);
  * length; writes logits (bf16 [vocab]) of the LAST row if logits_out != NULL, returns greedy token of the
  * last row.  This is one prefill chunk (count > 1) or one decode step (count == 1). */
 uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t count, uint16_t* logits_out);
+/* One forward pass over a speculated TREE of `tree_size` tokens (DFS order; trie = {start, end, height} per node) hanging off the current
+ * context, NOT accepted (stream.rs:556-628 with full_accept = false): greedy token of every node into sampled_out [tree_size], logits of
+ * every node (bf16 [tree_size, vocab]) if logits_out != NULL.  Follow with orc_model_accept. */
+void orc_model_verify_tree(orc_model* m, const uint32_t* token_ids, const uint32_t* trie, uint32_t tree_size, uint32_t* sampled_out, uint16_t* logits_out);
+/* TransformerState::encode_accept (stream.rs:441-444): `accepted` = a root path of the pending tree (FlatTrie::accept, trie.rs:271-305) */
+void orc_model_accept(orc_model* m, const uint32_t* accepted, uint32_t n);
 /* Debug taps: copy the last forward's per-layer outputs (bf16 [count, model_dim]) */
 const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint32_t* rows);
 const uint16_t* orc_model_final_hidden(const orc_model* m); /* output_norm of last row, bf16 [model_dim] */

@@ -33,6 +33,10 @@ typedef struct {
     uint32_t ring_offset, ring_max; /* AttentionStateType::Ring { offset, .., max_length } (ring_max == 0: Full), state.rs:16-55 */
     float* conv_state; /* f32 [conv_dim, k-1] */
     float* ssm_state;  /* f32 [Hv, Dv, Dk] */
+    /* DeltaNetSuffixStatus::Tree (delta_net.rs:39-46): what an unaccepted tree pass leaves behind for encode_accept */
+    float* tree_conv_states; /* f32 [tree, conv_dim, k-1] */
+    uint16_t *tree_k, *tree_v; /* bf16 [tree, key_dim] / [tree, value_dim] */
+    float *tree_log_decay, *tree_beta; /* f32 [tree, Hv] */
 } layer_state;
 
 struct orc_model {
@@ -43,6 +47,9 @@ struct orc_model {
     uint16_t** layer_outputs; /* debug taps: per layer [rows, d] of the last forward */
     uint32_t last_rows;
     uint16_t* final_hidden;
+    /* an unaccepted speculated tree (orc_model_verify_tree ... orc_model_accept) */
+    uint32_t tree_size;
+    int32_t* tree_parents;
 };
 
 static void* xcalloc(size_t n, size_t sz) {
@@ -86,6 +93,8 @@ orc_model* orc_model_create(const uzu_model_desc* desc) {
 
 void orc_model_reset(orc_model* m) {
     m->context_length = 0;
+    free(m->tree_parents);
+    m->tree_parents = NULL, m->tree_size = 0; /* a pending tree is dropped (its per-layer buffers are replaced by the next tree pass) */
     for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
         m->states[l].length = 0;
@@ -106,8 +115,14 @@ void orc_model_destroy(orc_model* m) {
         free(m->states[l].values);
         free(m->states[l].conv_state);
         free(m->states[l].ssm_state);
+        free(m->states[l].tree_conv_states);
+        free(m->states[l].tree_k);
+        free(m->states[l].tree_v);
+        free(m->states[l].tree_log_decay);
+        free(m->states[l].tree_beta);
         free(m->layer_outputs[l]);
     }
+    free(m->tree_parents);
     free(m->layer_outputs);
     free(m->final_hidden);
     free(m->states);
@@ -243,7 +258,7 @@ static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* 
 }
 
 static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch, const float* cosines,
-                                 const float* sines) {
+                                 const float* sines, const uint32_t* trie) {
     const uzu_layer_desc* L = &m->layers[l];
     layer_state* st = &m->states[l];
     const uint32_t hd = L->head_dim, nq = L->num_heads, nkv = L->num_groups;
@@ -289,6 +304,7 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     a.num_heads = nq;
     a.suffix_length = batch;
     a.is_causal = 1;
+    a.trie = trie; /* mode.rs:178-192: a non-flat batch runs the is_trie cores with the nodes as the mask's suffix topology */
     uint16_t* out = (uint16_t*)xcalloc((size_t)batch * nq * hd, 2);
     if (physical_prefix + batch > 1024) { /* core/mod.rs:89-92 */
         const size_t rows = (size_t)batch * nq;
@@ -313,7 +329,49 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     return projected;
 }
 
-static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch) {
+/* DeltaNet::encode_tree_verify (delta_net.rs:334-437) with the Metal composition of DeltaNetTreeVerify::encode
+ * (metal/kernel/gdn/tree_verify.rs:92-187: prefix -> gram -> solve -> out, batch 1, scale 1, h0 = the ssm state, slot 0). */
+static uint16_t* delta_net_tree_verify(orc_model* m, uint32_t l, uint16_t* in_projected, uint32_t tree, const uint32_t* trie, const int32_t* parents) {
+    const uzu_layer_desc* L = &m->layers[l];
+    layer_state* st = &m->states[l];
+    const uint32_t Hv = L->dn_num_heads, Hk = L->dn_num_groups, Dk = L->dn_head_dim, Dv = L->dn_value_head_dim;
+    const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
+    const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv;
+    const uint32_t ks = L->dn_kernel_size;
+    free(st->tree_conv_states), free(st->tree_k), free(st->tree_v), free(st->tree_log_decay), free(st->tree_beta);
+    st->tree_conv_states = (float*)xcalloc((size_t)tree * conv_dim * (ks - 1), 4);
+    st->tree_k = (uint16_t*)xcalloc((size_t)tree * key_dim, 2);
+    st->tree_v = (uint16_t*)xcalloc((size_t)tree * value_dim, 2);
+    st->tree_beta = (float*)xcalloc((size_t)tree * Hv, 4);
+    st->tree_log_decay = (float*)xcalloc((size_t)tree * Hv, 4);
+    uint16_t* tree_projected = (uint16_t*)xcalloc((size_t)tree * total_proj_dim, 2);
+    uint16_t* q = (uint16_t*)xcalloc((size_t)tree * key_dim, 2);
+    orc_conv_tree_scan(in_projected, L->dn_conv_weights, L->dn_conv_biases, st->conv_state, parents, tree_projected, st->tree_conv_states, ORC_BF16,
+                       tree, ks, total_proj_dim, conv_dim);
+    orc_delta_net_tree_prep(tree_projected, L->dn_a_log, L->dn_dt_bias, q, st->tree_k, st->tree_v, st->tree_beta, st->tree_log_decay, ORC_BF16, Hv,
+                            Hk, Dk, key_dim, value_dim, tree);
+    const uint32_t nb = (tree + 15) / 16, ncp = (nb + 1) / 2;
+    const int32_t h0_idx = 0;
+    float* prefix = (float*)xcalloc((size_t)tree * Hv, 4);
+    float* a_packed = (float*)xcalloc((size_t)Hv * nb * ncp * 16 * 32, 4);
+    float* qkd = (float*)xcalloc((size_t)Hv * tree * tree, 4);
+    float* a_inv = (float*)xcalloc((size_t)Hv * nb * 16 * 16, 4);
+    float* kh0 = (float*)xcalloc((size_t)tree * Hv * Dv, 4);
+    float* u = (float*)xcalloc((size_t)Hv * tree * Dv, 4);
+    uint16_t* delta_output = (uint16_t*)xcalloc((size_t)tree * value_dim, 2);
+    orc_build_tree_prefix(trie, st->tree_log_decay, prefix, 1, tree, Hv);
+    orc_build_tree_gram(q, st->tree_k, ORC_BF16, trie, prefix, st->tree_beta, st->ssm_state, &h0_idx, a_packed, qkd, a_inv, kh0, 1.0f, 1, tree, Hk, Hv, Dk, Dv);
+    orc_tree_update_solve(kh0, st->tree_v, ORC_BF16, prefix, st->tree_beta, a_packed, a_inv, &h0_idx, u, 1, tree, Hv, Dv);
+    orc_build_tree_out(q, ORC_BF16, prefix, qkd, u, st->ssm_state, &h0_idx, delta_output, ORC_BF16, 1.0f, 1, tree, Hk, Hv, Dk, Dv);
+    free(prefix), free(a_packed), free(qkd), free(a_inv), free(kh0), free(u), free(q);
+    orc_delta_net_norm_gate(delta_output, tree_projected, L->dn_norm_scales, Hv, Dv, value_dim, conv_dim, total_proj_dim, L->dn_norm_epsilon, tree);
+    free(tree_projected);
+    uint16_t* projected = linear(&L->dn_out_proj, delta_output, tree);
+    free(delta_output);
+    return projected;
+}
+
+static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch, const uint32_t* trie, const int32_t* parents) {
     const uzu_layer_desc* L = &m->layers[l];
     layer_state* st = &m->states[l];
     const uint32_t Hv = L->dn_num_heads, Hk = L->dn_num_groups, Dk = L->dn_head_dim, Dv = L->dn_value_head_dim;
@@ -321,6 +379,11 @@ static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv;
     const uint32_t ks = L->dn_kernel_size;
     uint16_t* in_projected = linear(&L->dn_in_proj, hidden, batch);
+    if (trie) { /* !batch_dim.full_accept() (delta_net.rs:496-502) */
+        uint16_t* out = delta_net_tree_verify(m, l, in_projected, batch, trie, parents);
+        free(in_projected);
+        return out;
+    }
     uint16_t* delta_output = (uint16_t*)xcalloc((size_t)batch * value_dim, 2);
     if (batch == 1) {
         orc_delta_net_conv_update(L->dn_conv_weights, L->dn_conv_biases, in_projected, st->conv_state, ks, conv_dim, ks - 1);
@@ -355,9 +418,33 @@ static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     return projected;
 }
 
-uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t count, uint16_t* logits_out) {
+/* `trie` == NULL: a flat, fully accepted pass (prefill chunk / decode step): logits + greedy token of the LAST row, then encode_accept.
+ * `trie` != NULL (3 u32 per node): a speculated tree, not accepted (stream.rs:556-566,618-628): token positions = context + height, logits
+ * and greedy tokens of EVERY row (output_range 0..size), the states keep the unaccepted suffix for orc_model_accept. */
+static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t count, const uint32_t* trie, uint16_t* logits_out, uint32_t* tokens_out) {
     const uzu_model_desc* D = &m->desc;
     const uint32_t d = D->model_dim;
+    if (m->tree_size) {
+        fprintf(stderr, "oracle: forward with an unaccepted tree pending\n");
+        abort();
+    }
+    int32_t* parents = NULL;
+    if (trie) { /* BatchTopology::new (batch_topology.rs:11-37) */
+        parents = (int32_t*)xcalloc(count, 4);
+        uint32_t* stack = (uint32_t*)xcalloc(count + 1, 4);
+        uint32_t depth = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t height = trie[3 * i + 2];
+            if (height > depth) {
+                fprintf(stderr, "oracle: trie node %u at height %u does not follow a node of height >= %u\n", i, height, height - 1);
+                abort();
+            }
+            depth = height;
+            parents[i] = depth ? (int32_t)stack[depth - 1] : -1;
+            stack[depth++] = i;
+        }
+        free(stack);
+    }
     if (count == 0 || count > ATTENTION_SUFFIX_CAPACITY) {
         fprintf(stderr, "oracle: forward chunk must be 1..1024 tokens\n");
         abort();
@@ -380,7 +467,7 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
     float *cosines = NULL, *sines = NULL;
     if (D->rope.kind != UZU_ROPE_NONE) {
         uint32_t* pos = (uint32_t*)xcalloc(count, 4);
-        for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + i;
+        for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + (trie ? trie[3 * i + 2] : i); /* transformer.rs:247: context + height */
         cosines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
         sines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
         orc_rope_tables(&D->rope, pos, count, cosines, sines);
@@ -397,8 +484,8 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
             memcpy(shortcut, hidden, (size_t)count * d * 2);
             h = hidden;
         }
-        uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines)
-                                                               : delta_net_mixer(m, l, h, count);
+        uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines, trie)
+                                                               : delta_net_mixer(m, l, h, count, trie, parents);
         free(h);
         if (L->post_mixer_norm.present) {
             uint16_t* t = norm(&L->post_mixer_norm, mixed, NULL, 0, count, d);
@@ -427,26 +514,34 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
     }
     free(cosines);
     free(sines);
-    /* output_norm over the last row only, shortcut add (transformer.rs:317-323) */
-    const size_t last = (size_t)(count - 1) * d;
-    uint16_t* normed = norm(&D->output_norm, hidden + last, shortcut + last, 2, 1, d);
-    memcpy(m->final_hidden, normed, (size_t)d * 2);
+    /* output_norm over the output range, shortcut add (transformer.rs:317-323): the last row of a flat pass, every row of a tree */
+    const uint32_t out_rows = trie ? count : 1;
+    const size_t first = (size_t)(count - out_rows) * d;
+    uint16_t* normed = norm(&D->output_norm, hidden + first, shortcut + first, 2, out_rows, d);
+    memcpy(m->final_hidden, normed + (size_t)(out_rows - 1) * d, (size_t)d * 2);
     free(hidden);
     free(shortcut);
-    /* readout (embedding.rs:374-456) */
     /* Embedding::encode_readout (embedding.rs:374-456): readout_input_hadamard = the tied table's output signs (embedding.rs:167-173) or
      * the untied output embedding's input signs (embedding.rs:255-274): InputRht on a private copy of the row, then the plain matmul */
     uzu_linear_desc ro = D->tied_embeddings ? D->embedding : D->output_embedding;
     ro.input_signs = D->tied_embeddings ? D->embedding.output_signs : D->output_embedding.input_signs;
     ro.output_signs = NULL;
-    uint16_t* logits = linear(&ro, normed, 1);
+    uint16_t* logits = linear(&ro, normed, out_rows);
     free(normed);
     if (D->logit_scale != 1.0f || D->logit_soft_cap != 0.0f)
-        orc_logit_transform(logits, ORC_BF16, D->vocab_size, D->logit_scale, D->logit_soft_cap, D->logit_soft_cap != 0.0f);
-    uint32_t token = 0;
-    orc_argmax(logits, ORC_BF16, &token, D->vocab_size, 1);
-    if (logits_out) memcpy(logits_out, logits, (size_t)D->vocab_size * 2);
+        orc_logit_transform(logits, ORC_BF16, D->vocab_size * out_rows, D->logit_scale, D->logit_soft_cap, D->logit_soft_cap != 0.0f);
+    uint32_t* sampled = (uint32_t*)xcalloc(out_rows, 4);
+    orc_argmax(logits, ORC_BF16, sampled, D->vocab_size, out_rows);
+    const uint32_t token = sampled[out_rows - 1];
+    if (tokens_out) memcpy(tokens_out, sampled, (size_t)out_rows * 4);
+    free(sampled);
+    if (logits_out) memcpy(logits_out, logits, (size_t)D->vocab_size * out_rows * 2);
     free(logits);
+    if (trie) { /* not accepted: the suffix rows stay behind the caches' logical end, the DeltaNet layers hold their Tree status */
+        m->tree_size = count;
+        m->tree_parents = parents;
+        return token;
+    }
     /* encode_accept (state.rs:174-236), flat full accept: nothing to copy on a Full cache; a Ring takes the suffix rows in order */
     for (uint32_t l = 0; l < D->num_layers; ++l) {
         if (m->layers[l].mixer_kind != UZU_MIXER_ATTENTION) continue;
@@ -467,4 +562,62 @@ uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t cou
     }
     m->context_length += count;
     return token;
+}
+
+uint32_t orc_model_forward(orc_model* m, const uint32_t* token_ids, uint32_t count, uint16_t* logits_out) {
+    return forward_core(m, token_ids, count, NULL, logits_out, NULL);
+}
+
+void orc_model_verify_tree(orc_model* m, const uint32_t* token_ids, const uint32_t* trie, uint32_t tree_size, uint32_t* sampled_out, uint16_t* logits_out) {
+    forward_core(m, token_ids, tree_size, trie, logits_out, sampled_out);
+}
+
+/* TransformerState::encode_accept over the layers (stream.rs:441-444): attention caches compact the accepted rows
+ * (mixer/attention/state.rs:174-236), DeltaNet layers take the accepted node's conv state and advance the SSM state along the
+ * accepted path (delta_net.rs:65-120). */
+void orc_model_accept(orc_model* m, const uint32_t* accepted, uint32_t n) {
+    if (!m->tree_size || !n) {
+        fprintf(stderr, "oracle: accept without a pending tree / of zero indices\n");
+        abort();
+    }
+    for (uint32_t i = 0; i < n; ++i) { /* delta_net.rs:88-90, state.rs:179 */
+        const int32_t want_parent = i ? (int32_t)accepted[i - 1] : -1;
+        if (accepted[i] >= m->tree_size || m->tree_parents[accepted[i]] != want_parent) {
+            fprintf(stderr, "oracle: accepted indices are not a root path of the tree\n");
+            abort();
+        }
+    }
+    for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        layer_state* st = &m->states[l];
+        if (L->mixer_kind == UZU_MIXER_ATTENTION) {
+            orc_copy* copies = (orc_copy*)xcalloc(n, sizeof(orc_copy));
+            uint32_t nc = 0;
+            if (!st->ring_max) {
+                for (uint32_t i = 0; i < n; ++i)
+                    if (accepted[i] != i) copies[nc].source = st->length + accepted[i], copies[nc].destination = st->length + i, ++nc;
+                st->length += n;
+            } else {
+                for (uint32_t i = 0; i < n; ++i) {
+                    copies[nc].source = st->ring_max + accepted[i];
+                    copies[nc].destination = (st->ring_offset + st->length) % st->ring_max;
+                    ++nc;
+                    if (st->length < st->ring_max) st->length += 1;
+                    else st->ring_offset = (st->ring_offset + 1) % st->ring_max;
+                }
+            }
+            if (nc) orc_kv_cache_update(st->keys, st->values, ORC_BF16, copies, nc, L->num_groups * L->head_dim);
+            free(copies);
+        } else {
+            const uint32_t Hv = L->dn_num_heads, Hk = L->dn_num_groups, Dk = L->dn_head_dim, Dv = L->dn_value_head_dim;
+            const size_t conv_state_elems = (size_t)(2 * Hk * Dk + Hv * Dv) * (L->dn_kernel_size - 1);
+            memcpy(st->conv_state, st->tree_conv_states + (size_t)accepted[n - 1] * conv_state_elems, conv_state_elems * 4);
+            orc_state_advance(st->tree_k, st->tree_v, ORC_BF16, st->tree_log_decay, st->tree_beta, accepted, st->ssm_state, n, Hv, Hk, Dk);
+            free(st->tree_conv_states), free(st->tree_k), free(st->tree_v), free(st->tree_log_decay), free(st->tree_beta);
+            st->tree_conv_states = NULL, st->tree_k = st->tree_v = NULL, st->tree_log_decay = st->tree_beta = NULL;
+        }
+    }
+    free(m->tree_parents);
+    m->tree_parents = NULL, m->tree_size = 0;
+    m->context_length += n;
 }

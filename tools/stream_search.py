@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""GPU box: look for a (seed, logit_row_sigma, prompt variant) whose greedy continuation has NO near-tie for `--steps` tokens, so that the
-chained production stream and the CPU oracle's stream must agree token for token (the benchmarked configuration's parity
-fixture).  Every candidate = one prefill of the prompt (uzu_amd.synthetic.synthetic_prompt(variant=v): all candidates share all but the last
-16 token ids) + greedy decode steps, each followed by a read of the logits; a candidate is dropped at its first step whose DECIDABILITY MARGIN is
-below --min-gap.  The margin is measured in the units the parity tests use (tests/test_gpu_model.py::check_against_fixture): the synthetic
-read-out rows carry log-normal multipliers m_i, logit i and its numerical error both scale with m_i, so
-    margin = min over t != best of (l_best - l_t) / (sigma_n (m_best + m_t)),   sigma_n = std(l / m).
-With a measured production-vs-oracle error of <= 0.2 sigma_n per competing logit, a GPU-side margin >= 0.4 means the oracle's arg-max is the
-same token with an oracle-side margin >= 0.2.  Prints the survivors; the chosen one is then re-run by the CPU oracle
-(tests/golden/make_bench_stream.py), which is what the fixture holds.
+"""GPU box: pick the prompt of the benchmarked configuration's parity fixture.
 
-  python tools/stream_search.py --prompt 2043 --steps 48 --min-gap 0.8 --variants 4000 --seeds 45 --sigma 0.6
+What round 4 measured first (profiles/r4_stream_search.txt): a random-weight transformer has no greedy stream that is both VARIED and
+robustly decided.  In the units the parity tests use -- margin = min over t != best of (l_best - l_t) / (sigma_n (m_best + m_t)), the
+synthetic read-out rows carrying log-normal multipliers m_i -- the per-token margin of varied streams has a median of 0.15 (20 % of the
+steps are below 0.045) against a measured production-vs-oracle error of up to 0.15-0.19 per competing logit; making the logits peakier
+(logit_row_sigma 0.7 ... 1.0) turns every surviving stream into a fixed point (one token repeated: 750 of 750 survivors).  So a fixture
+cannot be chosen by a margin threshold; it is chosen by OUTCOME:
+
+  1. production pass (fused kernels, graph replay -- what bench.py times): prefill the candidate prompt
+     (uzu_amd.synthetic.synthetic_prompt(variant=v): all candidates share all but the last 16 token ids), `--steps` chained greedy tokens,
+     margins from the logits; keep candidates with >= --min-distinct tokens and no margin below --min-gap;
+  2. reference-order pass (uzu_hip_set_exact(1): every reduction in the reference's own loop order, logits bit-identical to the CPU
+     oracle's -- tests/test_gpu_model.py::test_exact_mode_*): the same prompt, chained; the candidate survives iff BOTH streams are the same
+     tokens, i.e. no step's decision lies inside that step's actual numerical error.
+
+The survivor with the largest worst-step slack is then re-run by the CPU oracle itself (tests/golden/make_bench_stream.py), which is what
+the committed fixture holds.
+
+  python tools/stream_search.py --prompt 2043 --steps 32 --min-gap 0.03 --min-distinct 10 --budget-s 300
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -29,70 +38,100 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3.5-0.8b")
     ap.add_argument("--prompt", type=int, default=2043)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--min-gap", type=float, default=0.4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--min-gap", type=float, default=0.03)
     ap.add_argument("--min-distinct", type=int, default=10)
-    ap.add_argument("--variants", type=int, default=2000)
+    ap.add_argument("--variants", type=int, default=1000000)
     ap.add_argument("--first-variant", type=int, default=1)
-    ap.add_argument("--seeds", type=int, nargs="+", default=[45])
-    ap.add_argument("--sigma", type=float, nargs="+", default=[0.6])
-    ap.add_argument("--budget-s", type=float, default=240.0, help="wall-clock budget for the whole search")
+    ap.add_argument("--seed", type=int, default=45)
+    ap.add_argument("--sigma", type=float, default=0.6)
+    ap.add_argument("--budget-s", type=float, default=300.0, help="wall-clock budget for the whole search")
+    ap.add_argument("--max-survivors", type=int, default=6)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     from helpers import f32
+    from uzu_amd import _ffi
     from uzu_amd import synthetic as S
     from uzu_amd.backend import Context
     from uzu_amd.engine import HipModel
+
+    def set_exact(on):
+        fn = _ffi.lib().uzu_hip_set_exact
+        fn.restype, fn.argtypes = None, [C.c_int32]
+        fn(1 if on else 0)
+
     ctx = Context.new(0)
     t_start = time.time()
-    found = []
-    hist = np.zeros(args.steps + 2, dtype=np.int64)  # run length histogram
-    gap_samples = []
+    cfg = S.PRESETS[args.model](max_context_length=args.prompt + args.steps + 8, seed=args.seed, logit_row_sigma=args.sigma)
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg).astype(np.float64)
+    prod = HipModel(ctx, bundle)
+    set_exact(True)
+    exact = HipModel(ctx, bundle)
+    set_exact(False)
 
-    def gap_of(hm):
-        w = f32(hm.read_logits()).astype(np.float64)
+    def margin_of(logit_bits):
+        w = f32(logit_bits).astype(np.float64)
         best = int(np.argmax(w))
         sigma_n = (w / row_mult).std()
         d = (w[best] - w) / (sigma_n * (row_mult[best] + row_mult))
         d[best] = np.inf
         return float(d.min())
 
-    for sigma in args.sigma:
-        for seed in args.seeds:
-            cfg = S.PRESETS[args.model](max_context_length=args.prompt + args.steps + 8, seed=seed, logit_row_sigma=sigma)
-            hm = HipModel(ctx, S.build_model(cfg))
-            row_mult = S.readout_row_multipliers(cfg).astype(np.float64)
-            tried = 0
-            for v in range(args.first_variant, args.first_variant + args.variants):
-                if time.time() - t_start > args.budget_s:
-                    break
-                hm.reset()
-                tok = hm.prefill(S.synthetic_prompt(args.prompt, cfg.vocab_size, variant=v))
-                toks, gaps = [tok], [gap_of(hm)]
-                while gaps[-1] >= args.min_gap and len(toks) <= args.steps:
-                    t, _ = hm.decode(1)
-                    toks.append(int(t[0]))
-                    gaps.append(gap_of(hm))
-                tried += 1
-                run = len(toks) - (0 if gaps[-1] >= args.min_gap else 1)
-                hist[min(run, args.steps + 1)] += 1
-                if len(gap_samples) < 4000:
-                    gap_samples.extend(gaps)
-                if gaps[-1] >= args.min_gap and len(toks) > args.steps and len(set(toks)) >= args.min_distinct:
-                    rec = {"seed": seed, "sigma": sigma, "variant": v, "prompt": args.prompt, "distinct": len(set(toks)), "min_margin": round(min(gaps), 3),
-                           "median_margin": round(float(np.median(gaps)), 3), "tokens": toks, "margins": [round(g, 3) for g in gaps]}
-                    found.append(rec)
-                    print(json.dumps(rec), flush=True)
-            hm.close()
-            print(f"# seed {seed} sigma {sigma}: {tried} variants tried, {len(found)} survivors so far, {time.time() - t_start:.0f} s", flush=True)
-    g = np.asarray(gap_samples)
-    if g.size:
-        print("# per-token margin quantiles: " + ", ".join(f"p{q}={np.percentile(g, q):.3f}" for q in (5, 10, 20, 30, 50, 80)), flush=True)
-        print("# P(margin >= x): " + ", ".join(f"{x}: {(g >= x).mean():.3f}" for x in (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.8)), flush=True)
-    print("# run-length histogram (index = tokens before the first near-tie): " + " ".join(str(int(x)) for x in hist), flush=True)
+    tried = filtered = verified = 0
+    t_prod = t_exact = 0.0
+    survivors = []
+    prefix_hist = np.zeros(args.steps + 2, dtype=np.int64)
+    for v in range(args.first_variant, args.first_variant + args.variants):
+        if time.time() - t_start > args.budget_s or len(survivors) >= args.max_survivors:
+            break
+        prompt = S.synthetic_prompt(args.prompt, cfg.vocab_size, variant=v)
+        # ---- 1. production, chained, with margins; dropped at the first margin below the floor
+        t0 = time.time()
+        set_exact(False)
+        prod.reset()
+        toks = [prod.prefill(prompt)]
+        margins = [margin_of(prod.read_logits())]
+        while margins[-1] >= args.min_gap and len(toks) <= args.steps:
+            t, _ = prod.decode(1)
+            toks.append(int(t[0]))
+            margins.append(margin_of(prod.read_logits()))
+        t_prod += time.time() - t0
+        tried += 1
+        if margins[-1] < args.min_gap or len(set(toks)) < args.min_distinct:
+            continue
+        filtered += 1
+        # ---- 2. reference-order mode, chained: must reproduce the production stream token for token
+        t0 = time.time()
+        set_exact(True)
+        exact.reset()
+        e_toks = [exact.prefill(prompt)]
+        e_margins = [margin_of(exact.read_logits())]
+        while e_toks[-1] == toks[len(e_toks) - 1] and len(e_toks) <= args.steps:
+            t, _ = exact.decode(1)
+            e_toks.append(int(t[0]))
+            e_margins.append(margin_of(exact.read_logits()))
+        set_exact(False)
+        t_exact += time.time() - t0
+        verified += 1
+        same = 0
+        while same < len(e_toks) and e_toks[same] == toks[same]:
+            same += 1
+        prefix_hist[min(same, args.steps + 1)] += 1
+        if same == args.steps + 1:
+            rec = {"seed": args.seed, "sigma": args.sigma, "variant": v, "prompt": args.prompt, "distinct": len(set(toks)), "tokens": toks,
+                   "min_margin_production": round(min(margins), 4), "min_margin_exact": round(min(e_margins), 4),
+                   "margins_exact": [round(g, 4) for g in e_margins], "margins_production": [round(g, 4) for g in margins]}
+            survivors.append(rec)
+            print(json.dumps(rec), flush=True)
+    print(f"# seed {args.seed} sigma {args.sigma}: {tried} variants through the production pass ({t_prod:.0f} s), {filtered} passed the filter (margin >= {args.min_gap}, "
+          f">= {args.min_distinct} distinct tokens in {args.steps + 1}), {verified} through the reference-order pass ({t_exact:.0f} s), {len(survivors)} identical streams", flush=True)
+    print("# identical-prefix histogram of the verified candidates (index = tokens before the two streams part): " + " ".join(str(int(x)) for x in prefix_hist), flush=True)
     if args.out:
         with open(args.out, "w") as f:
-            json.dump(found, f, indent=1)
+            json.dump(survivors, f, indent=1)
+    prod.close()
+    exact.close()
     ctx.close()
 
 
