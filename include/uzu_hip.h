@@ -370,6 +370,32 @@ uzu_status uzu_hip_delta_net_norm_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
                                               uint32_t value_dim, uint32_t conv_dim, uint32_t total_proj_dim,
                                               float norm_epsilon, uint32_t suffix_len);
 
+/* ---- Gated DeltaNet over a speculated token tree (speculative decoding; BU/src/backends/cpu/kernel/gdn/tree_verify/) ----
+ * ConvTreeScanKernel::{new(context, data_type, kernel_size, has_bias), encode}  (tree_verify/conv_scan.rs:13-72): the causal conv walked
+ * through `parents` (i32 [suffix_len], -1 = child of the accepted context) instead of the previous row; suffix_state f32 [suffix_len,
+ * conv_dim, kernel_size - 1] = the conv state after the root path that ends in each node.  Rows are DeltaNet in-projection rows with
+ * 128-wide heads (the only shape the block instantiates).
+ * DeltaNetPrefillPrepKernel's tree instantiation (T = QKT = BF16, write_log_decay, write_compact_v: delta_net.rs:257-265) is
+ * uzu_hip_delta_net_prefill_prep_create(.., UZU_BF16, UZU_BF16, 128, 1, 1, ..) above.
+ * DeltaNetTreeVerify::{new(TreeVerifyNewArguments), encode(TreeVerifyEncodeArguments)}  (backends/common/kernel/delta_net_tree_verify.rs,
+ * encodable_block/mixer/delta_net/tree_verify.rs:7-26; the Metal backend composes it from BuildTreePrefix / BuildTreeGram / TreeUpdateSolve /
+ * BuildTreeOut, metal/kernel/gdn/tree_verify.rs:92-187 -- here it is ONE kernel whose results are bit-identical to the CPU kernels'
+ * composition): q / k bf16 [tree, k_heads, 128], v bf16 [tree, v_heads, 128], trie u32 [tree, 3], log_decay / beta f32 [tree, v_heads],
+ * h0 f32 [v_heads, 128, 128] -> output bf16 [tree, v_heads, 128].  tree_size <= 32.
+ * StateAdvanceKernel::{new(context, data_type, head_k_dim, num_v_heads, num_k_heads), encode}  (tree_verify/state_advance.rs:9-59). */
+uzu_status uzu_hip_conv_tree_scan_create(uzu_hip_context* ctx, uint32_t t, uint32_t kernel_size, uint32_t has_bias, uzu_hip_kernel** out);
+uzu_status uzu_hip_conv_tree_scan_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf conv_weight, uzu_buf bias /* optional */,
+                                         uzu_buf base_state, uzu_buf parents, uzu_buf out_proj, uzu_buf suffix_state, uint32_t suffix_len,
+                                         uint32_t total_proj_dim, uint32_t conv_dim);
+uzu_status uzu_hip_delta_net_tree_verify_create(uzu_hip_context* ctx, uint32_t t, uint32_t num_k_heads, uint32_t num_v_heads, uint32_t head_k_dim,
+                                                uint32_t head_v_dim, uzu_hip_kernel** out);
+uzu_status uzu_hip_delta_net_tree_verify_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf q, uzu_buf k_norm, uzu_buf v, uzu_buf trie, uzu_buf log_decay,
+                                                uzu_buf beta, uzu_buf h0, uzu_buf output, uint32_t tree_size);
+uzu_status uzu_hip_state_advance_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim, uint32_t num_v_heads, uint32_t num_k_heads,
+                                        uzu_hip_kernel** out);
+uzu_status uzu_hip_state_advance_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf k_norm, uzu_buf v, uzu_buf log_decay, uzu_buf beta,
+                                        uzu_buf accepted_indices, uzu_buf state, uint32_t accepted_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,26 @@ uzu_status uzu_hip_model_set_sampling(uzu_hip_model* m, const uzu_sampling_confi
 /* Teacher forcing for parity tests: overwrite the next input token. */
 uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
 
+/* ---- speculative decoding: verify a speculated token tree in one pass, accept a root path ----
+ * LanguageModelStream with a speculator (engine/language_model/stream/stream.rs:556-628 propose / verify, :380-470 accept).  The tree
+ * arrives linearised in DFS order as the reference hands it to the decoder (trie.rs:154-172, 200-212): token_ids[i] and trie_nodes[3 i ..]
+ * = {trie_start, trie_end, height} of node i (gpu_types/trie.rs: node j is an ancestor-or-self of i iff trie_start_j <= i <= trie_end_j);
+ * node 0 is the root = the last sampled token of the sequence.  One forward pass over all nodes: token positions = context + height
+ * (transformer.rs:247), attention under the trie mask (mask.rs:21-29; the nodes' K / V rows go behind the cache's logical end),
+ * Gated DeltaNet layers through ConvTreeScan + tree prep + DeltaNetTreeVerify (encodable_block/mixer/delta_net.rs:334-437,
+ * cpu/kernel/gdn/tree_verify/*.rs) with their Tree suffix status kept for the accept, output norm + read-out + greedy sampling of EVERY
+ * node (sampled_out[tree_size]).  At most 32 nodes per pass (the reference speculates <= 16).  Greedy sampling, full KV caches (no
+ * sliding-window ring), single GPU.
+ *
+ * uzu_hip_model_accept: TransformerState::encode_accept with the accepted root path (FlatTrie::accept, trie.rs:271-305; the host mirror
+ * is uzu_amd/trie.py): KV rows of the accepted nodes compacted to context .. context + count - 1 (mixer/attention/state.rs:174-198),
+ * DeltaNet conv state of the last accepted node + StateAdvance along the path (delta_net.rs:65-120); the context grows by `count` and
+ * the token sampled at the last accepted node is the next input token (decode / the next verify_tree's root). */
+uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, uint32_t tree_size, uint32_t* sampled_out);
+uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indices, uint32_t count);
+/* bf16 logits [tree_size, vocab] of the pending tree's nodes (between verify_tree and accept). */
+uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out);
+
 /* bf16 logits [vocab] of the last sampled row. */
 uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out);
 /* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass. */

@@ -1,0 +1,290 @@
+"""GPU parity tests of the speculative-verification path: Gated DeltaNet over a speculated token tree
+(csrc/k_deltanet_tree.hip <- cpu/kernel/gdn/tree_verify/*.rs) through the C ABI against the CPU oracle, and the engine's
+verify_tree -> accept protocol (stream.rs:380-470, 556-628) against the oracle model and against plain decoding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import bf16, f32, ulp_diff_bf16
+from oracle import oracle as O
+from test_gpu_kernels import run
+from test_oracle_tree_verify import linear_stream, logit_error_sigma, random_tree
+from uzu_amd import _ffi
+from uzu_amd import backend as B
+from uzu_amd import synthetic as S
+from uzu_amd.engine import HipModel
+from uzu_amd.trie import TrieNode
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_exact(on):
+    fn = _ffi.lib().uzu_hip_set_exact
+    fn.restype, fn.argtypes = None, [C.c_int32]
+    fn(1 if on else 0)
+
+
+# ------------------------------------------------------------------------------------------ kernels, through the C ABI
+@pytest.mark.parametrize("n,Hk,Hv", [(1, 16, 16), (16, 16, 16), (23, 2, 4), (32, 4, 8)])
+def test_conv_tree_scan_and_tree_prep_bit_exact(hip_ctx, n, Hk, Hv):
+    """ConvTreeScan (tree_verify/conv_scan.rs) and DeltaNetPrefillPrep's tree instantiation (prefill_prep.rs with QKT = T, log decays,
+    compact V) -- Qwen3.5 shape first -- BIT-EXACT against the CPU kernels: same tap order, glibc-exact exp / log, and the l2 norms
+    summed by one thread in the reference's order."""
+    rng = np.random.default_rng(200 + n)
+    D, ks = 128, 4
+    key_dim, value_dim = Hk * D, Hv * D
+    conv_dim = 2 * key_dim + value_dim
+    total = conv_dim + value_dim + 2 * Hv
+    _, parents = random_tree(n, rng)
+    x = bf16(rng.normal(size=(n, total)))
+    w = rng.uniform(-0.6, 0.6, size=(conv_dim, ks)).astype(np.float32)
+    bias = rng.uniform(-0.1, 0.1, size=(conv_dim,)).astype(np.float32)
+    base = rng.normal(size=(conv_dim, ks - 1)).astype(np.float32)
+    a_log, dt_bias = rng.uniform(-1, 1, Hv).astype(np.float32), rng.uniform(-1, 1, Hv).astype(np.float32)
+    # oracle
+    w_out = np.zeros_like(x)
+    w_states = np.zeros((n, conv_dim, ks - 1), np.float32)
+    O.call("orc_conv_tree_scan", x, w, bias, base, parents, w_out, w_states, O.BF16, n, ks, total, conv_dim)
+    w_q, w_k = np.zeros((n, key_dim), np.uint16), np.zeros((n, key_dim), np.uint16)
+    w_v = np.zeros((n, value_dim), np.uint16)
+    w_beta, w_ld = np.zeros((n, Hv), np.float32), np.zeros((n, Hv), np.float32)
+    O.call("orc_delta_net_tree_prep", w_out, a_log, dt_bias, w_q, w_k, w_v, w_beta, w_ld, O.BF16, Hv, Hk, D, key_dim, value_dim, n)
+    # HIP: the two kernels of the trait surface
+    scan = B.ConvTreeScanKernel.new(hip_ctx, B.BF16, ks, 1)
+    prep = B.DeltaNetPrefillPrepKernel.new(hip_ctx, B.BF16, B.BF16, 128, 1, 1)
+    bx, bw, bb, bbase, bpar = (hip_ctx.buffer_from(z) for z in (x, w, bias, base, parents))
+    bout, bst = hip_ctx.buffer_from(np.zeros_like(x)), hip_ctx.buffer_from(np.zeros_like(w_states))
+    bq, bk, bv = (hip_ctx.buffer_from(np.zeros_like(z)) for z in (w_q, w_k, w_v))
+    bbeta, bld = hip_ctx.buffer_from(np.zeros_like(w_beta)), hip_ctx.buffer_from(np.zeros_like(w_ld))
+    ba, bdt = hip_ctx.buffer_from(a_log), hip_ctx.buffer_from(dt_bias)
+
+    def encode(cb):
+        scan.encode(bx, bw, bb, bbase, bpar, bout, bst, n, total, conv_dim, cb)
+        prep.encode(bout, ba, bdt, bq, bk, bv, bbeta, bld, Hv, Hk, key_dim, value_dim, n, cb)
+    run(hip_ctx, encode)
+    assert np.array_equal(bout.download(np.uint16, x.size).reshape(x.shape), w_out)
+    assert np.array_equal(bst.download(np.float32, w_states.size).reshape(w_states.shape), w_states)
+    assert np.array_equal(bq.download(np.uint16, w_q.size).reshape(w_q.shape), w_q)
+    assert np.array_equal(bk.download(np.uint16, w_k.size).reshape(w_k.shape), w_k)
+    assert np.array_equal(bv.download(np.uint16, w_v.size).reshape(w_v.shape), w_v)
+    assert np.array_equal(bbeta.download(np.float32, w_beta.size).reshape(w_beta.shape), w_beta)
+    assert np.array_equal(bld.download(np.float32, w_ld.size).reshape(w_ld.shape), w_ld)
+
+
+def tree_verify_inputs(rng, n, Hk, Hv):
+    D = 128
+    nodes, parents = random_tree(n, rng)
+    q = bf16(rng.normal(size=(n, Hk, D)) / np.sqrt(D) / np.sqrt(D) * 8)
+    k = rng.normal(size=(n, Hk, D))
+    k = bf16(k / np.linalg.norm(k, axis=-1, keepdims=True))
+    v = bf16(rng.normal(size=(n, Hv, D)))
+    log_decay = -rng.uniform(0.01, 0.6, size=(n, Hv)).astype(np.float32)
+    beta = rng.uniform(0.1, 0.9, size=(n, Hv)).astype(np.float32)
+    h0 = (rng.normal(size=(Hv, D, D)) * 0.3).astype(np.float32)
+    return nodes, parents, q, k, v, log_decay, beta, h0
+
+
+def oracle_tree_verify(nodes, q, k, v, log_decay, beta, h0, n, Hk, Hv):
+    D = 128
+    nb = (n + 15) // 16
+    ncp = (nb + 1) // 2
+    h0_idx = np.zeros(1, np.int32)
+    prefix = np.zeros((n, Hv), np.float32)
+    a_packed = np.zeros((Hv, nb, ncp, 16, 32), np.float32)
+    qkd = np.zeros((Hv, n, n), np.float32)
+    a_inv = np.zeros((Hv, nb, 16, 16), np.float32)
+    kh0 = np.zeros((n, Hv, D), np.float32)
+    u = np.zeros((Hv, n, D), np.float32)
+    out = np.zeros((n, Hv, D), np.uint16)
+    O.call("orc_build_tree_prefix", nodes, log_decay, prefix, 1, n, Hv)
+    O.call("orc_build_tree_gram", q, k, O.BF16, nodes, prefix, beta, h0, h0_idx, a_packed, qkd, a_inv, kh0, 1.0, 1, n, Hk, Hv, D, D)
+    O.call("orc_tree_update_solve", kh0, v, O.BF16, prefix, beta, a_packed, a_inv, h0_idx, u, 1, n, Hv, D)
+    O.call("orc_build_tree_out", q, O.BF16, prefix, qkd, u, h0, h0_idx, out, O.BF16, 1.0, 1, n, Hk, Hv, D, D)
+    return out
+
+
+@pytest.mark.parametrize("n,Hk,Hv", [(1, 16, 16), (4, 16, 16), (8, 16, 16), (16, 16, 16), (17, 2, 4), (32, 4, 8)])
+def test_delta_net_tree_verify_bit_exact(hip_ctx, n, Hk, Hv):
+    """DeltaNetTreeVerify (prefix -> Gram -> solve -> out as the Metal backend composes the CPU-tested kernels,
+    metal/kernel/gdn/tree_verify.rs:92-187) as ONE kernel: every output element is computed by one thread walking the reference's loops in
+    the reference's order -> BIT-IDENTICAL to the composition of the CPU kernels (tree_gram_test.rs / tree_update_solve_test.rs compare
+    Metal with them at 2e-4 ... 5e-3)."""
+    rng = np.random.default_rng(300 + n)
+    nodes, _, q, k, v, log_decay, beta, h0 = tree_verify_inputs(rng, n, Hk, Hv)
+    want = oracle_tree_verify(nodes, q, k, v, log_decay, beta, h0, n, Hk, Hv)
+    kern = B.DeltaNetTreeVerify.new(hip_ctx, B.BF16, Hk, Hv, 128, 128)
+    bufs = [hip_ctx.buffer_from(z) for z in (q, k, v, nodes, log_decay, beta, h0)]
+    bo = hip_ctx.buffer_from(np.zeros_like(want))
+    run(hip_ctx, lambda cb: kern.encode(*bufs, bo, n, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} outputs differ (max {ulp_diff_bf16(want, got).max():.2f} bf16 ulps)"
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_state_advance(hip_ctx, exact):
+    """StateAdvance (state_advance.rs) over an accepted path of 9 nodes, Qwen3.5 shape.  Production: a state row per half-wave (f32
+    butterfly sums): <= 1e-5 against the CPU kernel; reference-order mode: bit-identical."""
+    rng = np.random.default_rng(17)
+    n, Hk, Hv, D = 16, 16, 16, 128
+    _, parents, _, k, v, log_decay, beta, h0 = tree_verify_inputs(rng, n, Hk, Hv)
+    node = n - 1
+    path = []
+    while node >= 0:
+        path.append(node)
+        node = int(parents[node])
+    accepted = np.array(path[::-1], np.uint32)
+    want = h0.copy()
+    O.call("orc_state_advance", k, v, O.BF16, log_decay, beta, accepted, want, len(accepted), Hv, Hk, D)
+    kern = B.StateAdvanceKernel.new(hip_ctx, B.BF16, 128, Hv, Hk)
+    bufs = [hip_ctx.buffer_from(z) for z in (k, v, log_decay, beta, accepted)]
+    bs = hip_ctx.buffer_from(h0)
+    _set_exact(exact)
+    try:
+        run(hip_ctx, lambda cb: kern.encode(*bufs, bs, len(accepted), cb))
+    finally:
+        _set_exact(False)
+    got = bs.download(np.float32, h0.size).reshape(h0.shape)
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_kv_cache_update_with_dependent_copies_runs_in_the_reference_order(hip_ctx):
+    """The accept compaction of a speculated path (state.rs:180-196): copy i moves row a_i down to row i, so a later copy's destination
+    can be an earlier copy's source ([0, 2, 3] -> (2 -> 1), (3 -> 2)); the reference runs the copies sequentially per element column
+    (kv_cache_update.rs:14-27)."""
+    rng = np.random.default_rng(5)
+    rows, dim = 12, 512
+    keys, values = bf16(rng.normal(size=(rows, dim))), bf16(rng.normal(size=(rows, dim)))
+    copies = [(6, 5), (7, 6), (9, 7), (10, 8)]  # accepted nodes [0, 2, 3, 5, 6] behind a context of 4 rows
+    wk, wv = keys.copy(), values.copy()
+    for s, d in copies:
+        wk[d], wv[d] = wk[s], wv[s]
+    kern = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16, len(copies))
+    bk, bv = hip_ctx.buffer_from(keys), hip_ctx.buffer_from(values)
+    run(hip_ctx, lambda cb: kern.encode(bk, bv, copies, len(copies), dim, cb))
+    assert np.array_equal(bk.download(np.uint16, keys.size).reshape(keys.shape), wk)
+    assert np.array_equal(bv.download(np.uint16, values.size).reshape(values.shape), wv)
+
+
+# ------------------------------------------------------------------------------------------ the engine's verify -> accept
+def speculative_tree(got_last, want, i, depth, vocab):
+    """the true continuation want[i+1 .. i+depth] as a chain, a wrong sibling at every level, one of them with a child"""
+    root = TrieNode(got_last)
+    node = root
+    for d in range(1, depth + 1):
+        wrong = TrieNode((want[i + d] + 17 * d) % vocab)
+        if d == 2:
+            wrong.add(TrieNode((want[i + d] + 5) % vocab))
+        node.add(wrong)
+        true_child = TrieNode(want[i + d])
+        node.add(true_child)
+        node = true_child
+    return root
+
+
+@pytest.mark.parametrize("preset,mult", [("tiny-qwen", 81), ("tiny-qwen", 121), ("tiny-qwen", 151), ("tiny-llama", 191)])
+def test_engine_verify_then_accept_matches_the_oracle_and_linear_decoding(hip_ctx, preset, mult):
+    """uzu_hip_model_verify_tree / uzu_hip_model_accept against the oracle model's verify_tree / accept on the same trees (the prompts
+    of tests/test_oracle_tree_verify.py): per round the logits of EVERY node -- right and wrong branches -- within 0.25 sigma
+    (row-normalised) of the oracle's, the sampled tokens equal wherever the oracle's decision is not a near-tie, the accepted path the
+    same; after three rounds plain (graph-replayed, fused) decoding carries on with the linear stream's tokens: the KV compaction, the
+    DeltaNet conv state and the advanced SSM state are those of linear decoding."""
+    cfg = S.PRESETS[preset]()
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg)
+    base = S.synthetic_prompt(37, cfg.vocab_size).astype(np.int64)
+    prompt = ((base * mult + 11 * mult) % cfg.vocab_size).astype(np.uint32)
+    om = O.OracleModel(bundle)
+    depth, rounds = 4, 3
+    want, _ = linear_stream(om, prompt, rounds * (depth + 1) + 6)
+    om.reset()
+    om.prefill(prompt)
+    hm = HipModel(hip_ctx, bundle)
+    got = [hm.prefill(prompt)]
+    assert got[0] == want[0]
+    worst = 0.0
+    for rnd in range(rounds):
+        i = len(got) - 1
+        flat = speculative_tree(got[-1], want, i, depth, cfg.vocab_size).linearize()
+        o_sampled, o_logits = om.verify_tree(flat.token_ids(), flat.nodes(), True)
+        h_sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+        h_logits = hm.read_tree_logits()
+        for node in range(len(flat)):
+            worst = max(worst, logit_error_sigma(o_logits[node], h_logits[node], row_mult))
+            if int(h_sampled[node]) != int(o_sampled[node]):
+                w = np.sort(f32(o_logits[node]).astype(np.float64))
+                assert (w[-1] - w[-2]) / w.std() < 0.05, f"round {rnd} node {node}: oracle {o_sampled[node]}, hip {h_sampled[node]} without a near-tie"
+        o_acc, h_acc = flat.accept(o_sampled), flat.accept(h_sampled)
+        assert h_acc == o_acc and len(h_acc) == depth + 1
+        om.accept([idx for idx, _, _ in o_acc])
+        hm.accept([idx for idx, _, _ in h_acc])
+        got.extend(int(s) for _, _, s in h_acc)
+        assert hm.context_length == om.context_length
+    assert worst <= 0.25, f"tree-pass logits {worst:.3f} sigma off the oracle's"
+    assert got == want[:len(got)]
+    toks, _ = hm.decode(len(want) - len(got))
+    assert [int(t) for t in toks] == want[len(got):], "decoding after the accepts leaves the linear stream"
+    assert [int(t) for t in hm.read_tokens(len(prompt), len(got) - 1)] == got[1:]  # the accepted tokens sit at their positions
+    print(f"{preset} x{mult}: tree-pass logits within {worst:.3f} sigma of the oracle's")
+    hm.close()
+    om.close()
+
+
+@pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
+def test_engine_tree_pass_is_bit_identical_to_the_oracle_in_reference_order_mode(hip_ctx, preset):
+    """uzu_hip_set_exact(1): the whole tree pass -- trie-masked attention at positions context + height, ConvTreeScan, tree prep,
+    DeltaNetTreeVerify, norm-gate, every node's read-out -- gives logits BIT-IDENTICAL to the oracle's for every node, and after the
+    accept (reference-order StateAdvance) so do the logits of the decode steps that follow."""
+    cfg = S.PRESETS[preset]()
+    bundle = S.build_model(cfg)
+    prompt = ((S.synthetic_prompt(37, cfg.vocab_size).astype(np.int64) * 81 + 891) % cfg.vocab_size).astype(np.uint32)
+    om = O.OracleModel(bundle)
+    want, _ = linear_stream(om, prompt, 12)
+    om.reset()
+    _set_exact(True)
+    try:
+        hm = HipModel(hip_ctx, bundle)
+        assert hm.prefill(prompt) == om.prefill(prompt)
+        flat = speculative_tree(want[0], want, 0, 5, cfg.vocab_size).linearize()
+        o_sampled, o_logits = om.verify_tree(flat.token_ids(), flat.nodes(), True)
+        h_sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+        h_logits = hm.read_tree_logits()
+        assert np.array_equal(h_logits, o_logits), f"{(h_logits != o_logits).sum()} of {o_logits.size} tree logits differ"
+        assert np.array_equal(h_sampled, o_sampled)
+        acc = [idx for idx, _, _ in flat.accept(o_sampled)]
+        om.accept(acc)
+        hm.accept(acc)
+        tok = int(o_sampled[acc[-1]])
+        for _ in range(3):
+            tok, lg = om.forward([tok], True)
+            t, _ = hm.decode(1)
+            assert np.array_equal(hm.read_logits(), lg) and int(t[0]) == tok
+        hm.close()
+    finally:
+        _set_exact(False)
+    om.close()
+
+
+def test_engine_verify_guards(hip_ctx):
+    from uzu_amd._ffi import UzuHipError
+    cfg = S.tiny_qwen()
+    hm = HipModel(hip_ctx, S.build_model(cfg))
+    with pytest.raises(UzuHipError):  # nothing to hang the tree off
+        hm.verify_tree([1, 2], [[0, 1, 0], [1, 1, 1]])
+    tok = hm.prefill(S.synthetic_prompt(9, cfg.vocab_size))
+    with pytest.raises(UzuHipError):  # not DFS order: node 1 claims height 2 under a root of height 0
+        hm.verify_tree([tok, 2], [[0, 1, 0], [1, 1, 2]])
+    with pytest.raises(UzuHipError):  # nothing pending
+        hm.accept([0])
+    flat = TrieNode.flat([tok, 5, 6]).linearize()
+    hm.verify_tree(flat.token_ids(), flat.nodes())
+    with pytest.raises(UzuHipError):  # a second tree before the accept
+        hm.verify_tree(flat.token_ids(), flat.nodes())
+    with pytest.raises(UzuHipError):  # not a root path
+        hm.accept([0, 2])
+    hm.accept([0, 1])
+    assert hm.context_length == 11
+    hm.close()

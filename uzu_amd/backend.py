@@ -524,3 +524,27 @@ class DeltaNetNormGateKernel(_Kernel):
                suffix_len, encoder):
         self._enc(encoder, _buf(in_out), _buf(in_proj), _buf(norm_weight), _u(num_v_heads), _u(head_v_dim), _u(value_dim), _u(conv_dim),
                   _u(total_proj_dim), _f(norm_epsilon), _u(suffix_len))
+
+
+# ---- Gated DeltaNet over a speculated token tree (cpu/kernel/gdn/tree_verify/*.rs) ----
+class ConvTreeScanKernel(_Kernel):
+    _create, _encode = "uzu_hip_conv_tree_scan_create", "uzu_hip_conv_tree_scan_encode"
+
+    def encode(self, in_proj, conv_weight, bias, base_state, parents, out_proj, suffix_state, suffix_len, total_proj_dim, conv_dim, encoder):
+        self._enc(encoder, _buf(in_proj), _buf(conv_weight), _buf(bias), _buf(base_state), _buf(parents), _buf(out_proj), _buf(suffix_state), _u(suffix_len),
+                  _u(total_proj_dim), _u(conv_dim))
+
+
+class DeltaNetTreeVerify(_Kernel):
+    """DeltaNetTreeVerify::{new, encode} (backends/common/kernel/delta_net_tree_verify.rs)"""
+    _create, _encode = "uzu_hip_delta_net_tree_verify_create", "uzu_hip_delta_net_tree_verify_encode"
+
+    def encode(self, q, k, v, trie, log_decay, beta, h0, output, tree_size, encoder):
+        self._enc(encoder, _buf(q), _buf(k), _buf(v), _buf(trie), _buf(log_decay), _buf(beta), _buf(h0), _buf(output), _u(tree_size))
+
+
+class StateAdvanceKernel(_Kernel):
+    _create, _encode = "uzu_hip_state_advance_create", "uzu_hip_state_advance_encode"
+
+    def encode(self, k_norm, v, log_decay, beta, accepted_indices, state, accepted_len, encoder):
+        self._enc(encoder, _buf(k_norm), _buf(v), _buf(log_decay), _buf(beta), _buf(accepted_indices), _buf(state), _u(accepted_len))

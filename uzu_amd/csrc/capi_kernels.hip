@@ -16,6 +16,7 @@ enum KernelKind : uint32_t {
     KK_ATTENTION_TWO_PASS2, KK_ATTENTION_GEMM, KK_ACTIVATION_TRANSFORM, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
     KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
     KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
+    KK_CONV_TREE_SCAN, KK_DN_TREE_VERIFY, KK_STATE_ADVANCE,
 };
 
 bool is_float_dt(uint32_t dt) { return dt == UZU_BF16 || dt == UZU_F32; }
@@ -695,10 +696,15 @@ uzu_status uzu_hip_delta_net_conv_scan_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
 }
 uzu_status uzu_hip_delta_net_prefill_prep_create(uzu_hip_context* ctx, uint32_t t, uint32_t qk_t, uint32_t head_k_dim, uint32_t write_log_decay,
                                                  uint32_t write_compact_v, uzu_hip_kernel** out) {
-    UZU_UNSUPPORTED(t != UZU_BF16 || qk_t != UZU_F32 || head_k_dim != 128 || write_log_decay || write_compact_v,
-                    "delta_net_prefill_prep: only the flat-prefill variant (T = BF16, QKT = F32, decay, no compact V) is implemented");
+    // the two instantiations the DeltaNet block creates (delta_net.rs:246-265): flat prefill (QKT = f32, decay, no compact V) and the
+    // speculated-tree prep (QKT = T, log decay, compact V)
+    const bool flat = qk_t == UZU_F32 && !write_log_decay && !write_compact_v, tree = qk_t == UZU_BF16 && write_log_decay && write_compact_v;
+    UZU_UNSUPPORTED(t != UZU_BF16 || head_k_dim != 128 || !(flat || tree),
+                    "delta_net_prefill_prep: variants are (T = BF16, QKT = F32, decay, no compact V) and (T = QKT = BF16, log decay, compact V)");
     uzu_hip_kernel* k;
-    return make_kernel(ctx, KK_DN_PREFILL_PREP, out, &k);
+    UZU_PROPAGATE(make_kernel(ctx, KK_DN_PREFILL_PREP, out, &k));
+    k->f[0] = tree ? 1u : 0u;
+    return UZU_OK;
 }
 uzu_status uzu_hip_delta_net_prefill_prep_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf a_log, uzu_buf dt_bias, uzu_buf q_norm_out,
                                                  uzu_buf k_norm_out, uzu_buf compact_v_out, uzu_buf beta_out, uzu_buf decay_out, uint32_t num_v_heads,
@@ -706,7 +712,13 @@ uzu_status uzu_hip_delta_net_prefill_prep_encode(uzu_hip_kernel* k, uzu_hip_cmdb
     UZU_PROPAGATE(check(k, KK_DN_PREFILL_PREP, cb));
     UZU_REQUIRE(in_proj.buffer && a_log.buffer && dt_bias.buffer && q_norm_out.buffer && k_norm_out.buffer && beta_out.buffer && decay_out.buffer,
                 "delta_net_prefill_prep: null buffer");
-    UZU_REQUIRE(!compact_v_out.buffer, "compact V output presence mismatch");
+    UZU_REQUIRE((compact_v_out.buffer != nullptr) == (k->f[0] != 0), "compact V output presence mismatch");
+    if (k->f[0]) { // tree prep: q / k rounded to the activation type, log decays, the value section copied out
+        UZU_REQUIRE(num_k_heads && key_dim == num_k_heads * 128 && num_v_heads && value_dim == num_v_heads * 128, "delta_net_prefill_prep: head_k_dim and head_v_dim are 128");
+        return k::delta_net_tree_prep(cb_stream(cb), (const uint16_t*)bptr(in_proj), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const float*)bptr(a_log),
+                                      (const float*)bptr(dt_bias), (uint16_t*)bptr(q_norm_out), (uint16_t*)bptr(k_norm_out), (uint16_t*)bptr(compact_v_out), (float*)bptr(beta_out),
+                                      (float*)bptr(decay_out), suffix_len, 0, num_k_heads, num_v_heads, 128, 128, false, true);
+    }
     return k::delta_net_prefill_prep(cb_stream(cb), (const uint16_t*)bptr(in_proj), (const float*)bptr(a_log), (const float*)bptr(dt_bias),
                                      (float*)bptr(q_norm_out), (float*)bptr(k_norm_out), (float*)bptr(beta_out), (float*)bptr(decay_out), num_v_heads,
                                      num_k_heads, 128, key_dim, value_dim, suffix_len);
@@ -738,6 +750,62 @@ uzu_status uzu_hip_delta_net_norm_gate_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
     UZU_REQUIRE(in_out.buffer && in_proj.buffer && norm_weight.buffer, "delta_net_norm_gate: null buffer");
     return k::delta_net_norm_gate(cb_stream(cb), (uint16_t*)bptr(in_out), (const uint16_t*)bptr(in_proj), (const float*)bptr(norm_weight), num_v_heads,
                                   head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
+}
+
+// ---- Gated DeltaNet over a speculated tree (cpu/kernel/gdn/tree_verify/*.rs; csrc/k_deltanet_tree.hip) ----
+uzu_status uzu_hip_conv_tree_scan_create(uzu_hip_context* ctx, uint32_t t, uint32_t kernel_size, uint32_t has_bias, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16, "conv_tree_scan: only T = BF16 is instantiated");
+    UZU_REQUIRE(kernel_size >= 2, "conv_tree_scan: kernel_size must be >= 2");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_CONV_TREE_SCAN, out, &k));
+    k->f[0] = kernel_size, k->f[1] = has_bias;
+    return UZU_OK;
+}
+uzu_status uzu_hip_conv_tree_scan_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf in_proj, uzu_buf conv_weight, uzu_buf bias, uzu_buf base_state, uzu_buf parents,
+                                         uzu_buf out_proj, uzu_buf suffix_state, uint32_t suffix_len, uint32_t total_proj_dim, uint32_t conv_dim) {
+    UZU_PROPAGATE(check(k, KK_CONV_TREE_SCAN, cb));
+    UZU_REQUIRE(in_proj.buffer && conv_weight.buffer && base_state.buffer && parents.buffer && out_proj.buffer && suffix_state.buffer, "conv_tree_scan: null buffer");
+    UZU_REQUIRE((bias.buffer != nullptr) == (k->f[1] != 0), "conv_tree_scan: bias presence must equal has_bias");
+    // the DeltaNet in-projection row: [q | k | v | z | beta | a] with 128-wide heads => total - conv = 130 Hv, conv = 256 Hk + 128 Hv
+    const uint32_t rest = total_proj_dim - conv_dim;
+    UZU_UNSUPPORTED(total_proj_dim <= conv_dim || rest % 130 || conv_dim <= (rest / 130) * 128 || (conv_dim - (rest / 130) * 128) % 256,
+                    "conv_tree_scan: rows are not a DeltaNet in-projection with 128-wide heads (conv_dim %u of %u)", conv_dim, total_proj_dim);
+    const uint32_t Hv = rest / 130, Hk = (conv_dim - Hv * 128) / 256;
+    return k::delta_net_tree_prep(cb_stream(cb), (const uint16_t*)bptr(in_proj), (const float*)bptr(conv_weight), (const float*)bptr(bias), (const float*)bptr(base_state),
+                                  (const int32_t*)bptr(parents), (uint16_t*)bptr(out_proj), (float*)bptr(suffix_state), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, suffix_len, k->f[0], Hk, Hv, 128, 128, true, false);
+}
+uzu_status uzu_hip_delta_net_tree_verify_create(uzu_hip_context* ctx, uint32_t t, uint32_t num_k_heads, uint32_t num_v_heads, uint32_t head_k_dim, uint32_t head_v_dim,
+                                                uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16 || head_k_dim != 128 || head_v_dim != 128, "delta_net_tree_verify: T = BF16 with 128-wide heads");
+    UZU_REQUIRE(num_k_heads && num_v_heads && num_v_heads % num_k_heads == 0, "delta_net_tree_verify: value heads must be a multiple of key heads");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_DN_TREE_VERIFY, out, &k));
+    k->f[0] = num_k_heads, k->f[1] = num_v_heads;
+    return UZU_OK;
+}
+uzu_status uzu_hip_delta_net_tree_verify_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf q, uzu_buf k_norm, uzu_buf v, uzu_buf trie, uzu_buf log_decay, uzu_buf beta,
+                                                uzu_buf h0, uzu_buf output, uint32_t tree_size) {
+    UZU_PROPAGATE(check(k, KK_DN_TREE_VERIFY, cb));
+    UZU_REQUIRE(q.buffer && k_norm.buffer && v.buffer && trie.buffer && log_decay.buffer && beta.buffer && h0.buffer && output.buffer, "delta_net_tree_verify: null buffer");
+    return k::delta_net_tree_verify(cb_stream(cb), (const uint16_t*)bptr(q), (const uint16_t*)bptr(k_norm), (const uint16_t*)bptr(v), (const uint32_t*)bptr(trie),
+                                    (const float*)bptr(log_decay), (const float*)bptr(beta), (const float*)bptr(h0), (uint16_t*)bptr(output), tree_size, k->f[0], k->f[1], 128,
+                                    128);
+}
+uzu_status uzu_hip_state_advance_create(uzu_hip_context* ctx, uint32_t t, uint32_t head_k_dim, uint32_t num_v_heads, uint32_t num_k_heads, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(t != UZU_BF16 || head_k_dim != 128, "state_advance: variants are (T = BF16, HEAD_K_DIM = 128)");
+    UZU_REQUIRE(num_k_heads && num_v_heads && num_v_heads % num_k_heads == 0, "state_advance: value heads must be a multiple of key heads");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_STATE_ADVANCE, out, &k));
+    k->f[0] = num_v_heads, k->f[1] = num_k_heads;
+    return UZU_OK;
+}
+uzu_status uzu_hip_state_advance_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf k_norm, uzu_buf v, uzu_buf log_decay, uzu_buf beta, uzu_buf accepted_indices,
+                                        uzu_buf state, uint32_t accepted_len) {
+    UZU_PROPAGATE(check(k, KK_STATE_ADVANCE, cb));
+    UZU_REQUIRE(k_norm.buffer && v.buffer && log_decay.buffer && beta.buffer && accepted_indices.buffer && state.buffer, "state_advance: null buffer");
+    return k::delta_net_state_advance(cb_stream(cb), (const uint16_t*)bptr(k_norm), (const uint16_t*)bptr(v), (const float*)bptr(log_decay), (const float*)bptr(beta),
+                                      (const uint32_t*)bptr(accepted_indices), (float*)bptr(state), accepted_len, k->f[0], k->f[1], 128);
 }
 
 } // extern "C"

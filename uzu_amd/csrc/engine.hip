@@ -155,6 +155,31 @@ struct uzu_hip_model {
     float* tp_buf = nullptr;     // [1024 rows][model_dim] f32 partial sums
     unsigned long long* tp_key = nullptr;
 
+    // A speculated tree between uzu_hip_model_verify_tree and uzu_hip_model_accept (stream.rs:556-628, 380-470): the attention layers
+    // keep the suffix rows behind the caches' logical end, a DeltaNet layer keeps its DeltaNetSuffixStatus::Tree (delta_net.rs:39-46).
+    struct TreeLayer {
+        float* conv_states = nullptr;             // f32 [nodes, conv_dim, k-1]
+        uint16_t *k = nullptr, *v = nullptr;      // bf16 [nodes, key_dim] / [nodes, value_dim]
+        float *log_decay = nullptr, *beta = nullptr; // f32 [nodes, Hv]
+    };
+    struct {
+        std::vector<TreeLayer> layers;
+        uint32_t* d_trie = nullptr;     // [kDnTreeMaxNodes][3]
+        int32_t* d_parents = nullptr;   // [kDnTreeMaxNodes]
+        uint32_t* d_sampled = nullptr;  // [kDnTreeMaxNodes] token sampled at every node
+        uint32_t* d_accepted = nullptr; // [kDnTreeMaxNodes] accepted node indices of the accept in flight
+        uint16_t* q = nullptr;          // bf16 [nodes, widest key_dim] (scratch of one layer)
+        uint16_t* normed = nullptr;     // bf16 [nodes, model_dim]: output norm of every node
+        uint16_t* logits = nullptr;     // bf16 [nodes, vocab rows of this rank]
+        void* argmax_scratch = nullptr;
+        bool allocated = false;
+        bool active = false;            // the forward pass being encoded is a tree pass
+        uint32_t size = 0;              // nodes of the pending tree (0 = none)
+        uzu_hip_state* state = nullptr; // the state it hangs off
+        std::vector<int32_t> parents;
+        std::vector<uint32_t> sampled;
+    } tree;
+
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
     uint32_t graph_epoch = 0; // sampling_epoch of the model when the graphs were captured (they bake the sampling kernels in)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -646,8 +671,9 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     // (kv_token_offset = physical_prefix_length = window), the attention sees window + batch rows with ring parameters derived on the
     // device from the accepted-token count, and the rows enter the ring afterwards (encode_accept, state.rs:200-219).
     const uint32_t W = L.d.sliding_window_size;
+    const uint32_t* trie = m->tree.active ? m->tree.d_trie : nullptr; // a speculated tree: RoPE positions = context + height, trie mask (mode.rs:178-192)
     RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, W, batch, 1,
-                               m->d_ctx_len, W ? 1u : 0u));
+                               m->d_ctx_len, W ? 1u : 0u, trie));
     k::AttentionParams a{};
     a.queries = queries, a.keys = L.keys, a.values = L.values;
     a.dt = UZU_BF16, a.head_dim = hd, a.gqa_factor = nq / nkv;
@@ -656,6 +682,7 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
     a.num_heads = nq, a.suffix_length = batch, a.is_causal = 1;
     a.dyn = m->d_ctx_len;
+    a.trie = trie;
     if (W) a.ring_window = W, a.is_kv_cache_ring = 1, a.is_sliding_window = 1, a.sliding_window_size = W;
     if (L.sinks) a.sinks = L.sinks;
     const uint32_t physical_prefix = W ? W : m->context_length; // AttentionStateType::physical_prefix_length (state.rs:26-37)
@@ -669,16 +696,33 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     } else {
         RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, attn_out));
     }
-    if (W) RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
+    if (W && !trie) RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
 }
 
 void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
+
+// DeltaNet::encode_tree_verify (delta_net.rs:334-437): conv tree scan + tree prep (one launch), the tree-verify composite, norm-gate;
+// the layer's DeltaNetSuffixStatus::Tree stays in m->tree.layers[layer] for uzu_hip_model_accept
+void delta_net_tree_core(Enc& e, DLayer& L, uint32_t layer, uint32_t n) {
+    uzu_hip_model* m = e.m;
+    const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
+    const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
+    const uint32_t total_proj_dim = conv_dim + value_dim + 2 * Hv, ks = L.d.dn_kernel_size;
+    uzu_hip_model::TreeLayer& T = m->tree.layers[layer];
+    RUN("dn_tree_prep", 0, k::delta_net_tree_prep(e.s, m->in_proj, L.conv_w, L.conv_b, L.conv_state, m->tree.d_parents, nullptr, T.conv_states, L.a_log, L.dt_bias, m->tree.q,
+                                                   T.k, T.v, T.beta, T.log_decay, n, ks, Hk, Hv, Dk, Dv, true, true));
+    RUN("dn_tree_verify", (size_t)Hv * Dv * Dk * 4, k::delta_net_tree_verify(e.s, m->tree.q, T.k, T.v, m->tree.d_trie, T.log_decay, T.beta, L.ssm_state, m->delta_out, n, Hk, Hv, Dk, Dv));
+    // the norm-gate reads z from the rows' pass-through section: ConvTreeScan copies those channels unchanged, so the in-proj rows serve
+    RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, n));
+}
 
 void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q) {
     uzu_hip_model* m = e.m;
     const uint32_t rows = q.rows();
     linear(e, L.in_proj, hidden, m->in_proj, rows);
-    if (q.n == 0) {
+    if (m->tree.active) { // !batch_dim.full_accept() (delta_net.rs:496-502)
+        delta_net_tree_core(e, L, (uint32_t)(&L - m->layers.data()), q.count);
+    } else if (q.n == 0) {
         delta_net_core(e, L, q.count, 0);
     } else {
         for (uint32_t i = 0; i < q.n; ++i) {
@@ -783,6 +827,24 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, count * d));
     }
     m->tap_rows = count;
+    if (m->tree.active) {
+        // a tree pass: output norm, read-out and greedy sampling of EVERY node (output_range 0..size, stream.rs:618-628), no commit
+        norm(e, m->output_norm, hidden, m->tree.normed, m->shortcut, 2, count, d);
+        DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
+        ro.in_signs = m->d.tied_embeddings ? m->embedding.out_signs : m->output_embedding.in_signs;
+        ro.out_signs = nullptr;
+        linear(e, ro, m->tree.normed, m->tree.logits, count);
+        if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
+            RUN("logit_transform", 0, k::logit_transform(s, m->tree.logits, UZU_BF16, ro.n * count, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
+        RUN("argmax", (size_t)ro.n * 2 * count, k::argmax(s, m->tree.logits, UZU_BF16, m->tree.d_sampled, ro.n, count, m->tree.argmax_scratch));
+        if (e.st != UZU_OK) return e.st;
+        hipError_t terr = hipGetLastError();
+        if (terr != hipSuccess) {
+            set_error("engine: tree pass launch failed: %s", hipGetErrorString(terr));
+            return UZU_ERR_HIP;
+        }
+        return UZU_OK;
+    }
     for (uint32_t i = 0; i < (seqs ? nseq : 1u); ++i) { // per sequence: sample from its last row, then commit
         if (seqs) bind_state(m, seqs[i]);
         if (sample) {
@@ -1286,6 +1348,7 @@ uzu_status uzu_hip_model_reset(uzu_hip_model* m) {
     HIPCHK(hipStreamSynchronize(s));
     m->context_length = 0;
     m->hidden_ready = false;
+    if (m->tree.state == m->bound) m->tree.size = 0, m->tree.state = nullptr; // a pending tree of this sequence is dropped
     return UZU_OK;
 }
 
@@ -1542,6 +1605,165 @@ uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out) {
     UZU_REQUIRE(m && logits_out, "model_read_logits: null argument");
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     HIPCHK(hipMemcpy(logits_out, m->logits, (size_t)(m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n) * 2, hipMemcpyDeviceToHost));
+    return UZU_OK;
+}
+
+// ---- speculative decoding: one pass over a speculated tree, then accept a root path (stream.rs:380-470, 556-628) ----
+static uzu_status ensure_tree(uzu_hip_model* m) {
+    if (m->tree.allocated) return UZU_OK;
+    const uint32_t N = k::kDnTreeMaxNodes;
+    void* p = nullptr;
+    m->tree.layers.resize(m->layers.size());
+    uint32_t max_key = 0;
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+        const uzu_layer_desc& h = m->layers[l].d;
+        if (h.mixer_kind != UZU_MIXER_DELTA_NET) continue;
+        const uint32_t key_dim = h.dn_num_groups * h.dn_head_dim, value_dim = h.dn_num_heads * h.dn_value_head_dim, conv_dim = 2 * key_dim + value_dim;
+        auto& T = m->tree.layers[l];
+        UZU_PROPAGATE(dev_alloc(m, (size_t)N * conv_dim * (h.dn_kernel_size - 1) * 4, &p));
+        T.conv_states = (float*)p;
+        UZU_PROPAGATE(dev_alloc(m, (size_t)N * key_dim * 2, &p));
+        T.k = (uint16_t*)p;
+        UZU_PROPAGATE(dev_alloc(m, (size_t)N * value_dim * 2, &p));
+        T.v = (uint16_t*)p;
+        UZU_PROPAGATE(dev_alloc(m, (size_t)N * h.dn_num_heads * 4, &p));
+        T.log_decay = (float*)p;
+        UZU_PROPAGATE(dev_alloc(m, (size_t)N * h.dn_num_heads * 4, &p));
+        T.beta = (float*)p;
+        max_key = max_key > key_dim ? max_key : key_dim;
+    }
+    const uint32_t vocab_rows = m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * 3 * 4, &p));
+    m->tree.d_trie = (uint32_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * 4, &p));
+    m->tree.d_parents = (int32_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * 4, &p));
+    m->tree.d_sampled = (uint32_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * 4, &p));
+    m->tree.d_accepted = (uint32_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * (max_key ? max_key : 1) * 2, &p));
+    m->tree.q = (uint16_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * m->d.model_dim * 2, &p));
+    m->tree.normed = (uint16_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * vocab_rows * 2, &p));
+    m->tree.logits = (uint16_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, k::argmax_scratch_bytes(N), &p));
+    m->tree.argmax_scratch = p; // the arg-max partials of N rows
+    m->tree.allocated = true;
+    return UZU_OK;
+}
+
+// One forward pass over `tree_size` speculated tokens in DFS order hanging off the bound sequence (trie_nodes: {trie_start, trie_end,
+// height} per node, FlatTrie::token_subtrie_ranges; node 0 = the root = the last sampled token): token positions = context + height,
+// attention under the trie mask, DeltaNet layers through tree-verify, greedy token of EVERY node into sampled_out.  Nothing is accepted:
+// follow with uzu_hip_model_accept.
+uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, uint32_t tree_size, uint32_t* sampled_out) {
+    UZU_REQUIRE(m && token_ids && trie_nodes && tree_size > 0, "model_verify_tree: null / empty input");
+    (void)hipSetDevice(m->ctx->device);
+    UZU_UNSUPPORTED(tree_size > k::kDnTreeMaxNodes, "model_verify_tree: %u nodes (at most %u per pass)", tree_size, k::kDnTreeMaxNodes);
+    UZU_UNSUPPORTED(m->tp != nullptr, "model_verify_tree: speculative verification on a tensor-parallel shard is not implemented");
+    UZU_UNSUPPORTED(m->sampling.on, "model_verify_tree: stochastic sampling over a tree (per-node seeds) is not implemented: greedy only");
+    UZU_REQUIRE(m->tree.size == 0, "model_verify_tree: a speculated tree is already pending (accept it first)");
+    UZU_REQUIRE(m->context_length > 0, "model_verify_tree: prefill first");
+    UZU_REQUIRE(m->context_length + tree_size <= m->d.max_context_length, "model_verify_tree: %u + %u tokens exceed max_context_length %u", m->context_length, tree_size,
+                m->d.max_context_length);
+    for (auto& L : m->layers)
+        UZU_UNSUPPORTED(L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.sliding_window_size, "model_verify_tree: ring (sliding-window) KV states are not supported");
+    // BatchTopology::new (batch_topology.rs:11-37): parents from the heights of the DFS order; also validates the nodes
+    std::vector<int32_t> parents(tree_size);
+    {
+        std::vector<uint32_t> stack;
+        for (uint32_t i = 0; i < tree_size; ++i) {
+            const uint32_t start = trie_nodes[3 * i], end = trie_nodes[3 * i + 1], height = trie_nodes[3 * i + 2];
+            UZU_REQUIRE(start == i && end >= i && end < tree_size && height <= stack.size() && (i > 0 || height == 0), "model_verify_tree: node %u {%u, %u, %u} is not a DFS-ordered trie node", i, start,
+                        end, height);
+            stack.resize(height);
+            parents[i] = stack.empty() ? -1 : (int32_t)stack.back();
+            UZU_REQUIRE(i == 0 || parents[i] >= 0, "model_verify_tree: node %u is a second root", i);
+            stack.push_back(i);
+        }
+    }
+    UZU_PROPAGATE(ensure_tree(m));
+    hipStream_t s = m->ctx->stream;
+    m->hidden_ready = false;
+    HIPCHK(hipMemcpyAsync(m->d_tokens, token_ids, (size_t)tree_size * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->tree.d_trie, trie_nodes, (size_t)tree_size * 12, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->tree.d_parents, parents.data(), (size_t)tree_size * 4, hipMemcpyHostToDevice, s));
+    {
+        uint32_t max_heads = 0, max_hd = 0;
+        bool two_pass = false;
+        for (auto& L : m->layers)
+            if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+                max_heads = max_heads > L.d.num_heads ? max_heads : L.d.num_heads;
+                max_hd = max_hd > L.d.head_dim ? max_hd : L.d.head_dim;
+                two_pass = two_pass || m->context_length + tree_size > 1024;
+            }
+        if (max_heads && two_pass) UZU_PROPAGATE(ensure_partials(m, tree_size * max_heads, max_hd));
+    }
+    m->tree.active = true;
+    const uzu_status st = encode_forward(m, s, tree_size, true);
+    m->tree.active = false;
+    UZU_PROPAGATE(st);
+    m->tree.sampled.resize(tree_size);
+    HIPCHK(hipMemcpyAsync(m->tree.sampled.data(), m->tree.d_sampled, (size_t)tree_size * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    UZU_PROPAGATE(k::gemv_stream_check());
+    if (sampled_out) memcpy(sampled_out, m->tree.sampled.data(), (size_t)tree_size * 4);
+    m->tree.size = tree_size, m->tree.state = m->bound, m->tree.parents = parents;
+    return UZU_OK;
+}
+
+// TransformerState::encode_accept (stream.rs:441-444) with the accepted root path of the pending tree (FlatTrie::accept, trie.rs:271-305):
+// attention caches compact the accepted rows (mixer/attention/state.rs:174-198), DeltaNet layers take the last accepted node's conv state
+// and advance the SSM state along the path (delta_net.rs:65-120).  The token sampled at the last accepted node becomes the next input.
+uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indices, uint32_t count) {
+    UZU_REQUIRE(m && accepted_indices && count > 0, "model_accept: null / empty input");
+    (void)hipSetDevice(m->ctx->device);
+    UZU_REQUIRE(m->tree.size > 0 && m->tree.state == m->bound, "model_accept: no speculated tree is pending on the bound sequence");
+    for (uint32_t i = 0; i < count; ++i) { // delta_net.rs:88-90, state.rs:179
+        UZU_REQUIRE(accepted_indices[i] < m->tree.size, "model_accept: index %u out of the tree", accepted_indices[i]);
+        UZU_REQUIRE(m->tree.parents[accepted_indices[i]] == (i ? (int32_t)accepted_indices[i - 1] : -1), "model_accept: the accepted indices are not a root path of the tree");
+    }
+    hipStream_t s = m->ctx->stream;
+    Enc e{m, s};
+    HIPCHK(hipMemcpyAsync(m->tree.d_accepted, accepted_indices, (size_t)count * 4, hipMemcpyHostToDevice, s));
+    std::vector<uzu_kv_copy> copies;
+    for (uint32_t i = 0; i < count; ++i)
+        if (accepted_indices[i] != i) copies.push_back({m->context_length + accepted_indices[i], m->context_length + i});
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+        DLayer& L = m->layers[l];
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+            if (!copies.empty()) RUN("kv_cache_update", 0, k::kv_cache_update(s, L.keys, L.values, UZU_BF16, copies.data(), (uint32_t)copies.size(), L.d.num_groups * L.d.head_dim));
+        } else {
+            const auto& T = m->tree.layers[l];
+            HIPCHK(hipMemcpyAsync(L.conv_state, (const char*)T.conv_states + (size_t)accepted_indices[count - 1] * L.conv_state_bytes, L.conv_state_bytes, hipMemcpyDeviceToDevice, s));
+            RUN("dn_state_advance", L.ssm_state_bytes * 2, k::delta_net_state_advance(s, T.k, T.v, T.log_decay, T.beta, m->tree.d_accepted, L.ssm_state, count, L.d.dn_num_heads,
+                                                                                     L.d.dn_num_groups, L.d.dn_head_dim));
+        }
+    }
+    UZU_PROPAGATE(e.st);
+    // control block: context length, the sampled tokens of the accepted nodes at their positions, the next input token
+    std::vector<uint32_t> toks(count);
+    for (uint32_t i = 0; i < count; ++i) toks[i] = m->tree.sampled[accepted_indices[i]];
+    const uint32_t new_len = m->context_length + count;
+    HIPCHK(hipMemcpyAsync(m->d_sampled + m->context_length, toks.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->d_tokens, &toks[count - 1], 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->d_out_token, &toks[count - 1], 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->d_ctx_len, &new_len, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    m->context_length = new_len;
+    m->hidden_ready = false;
+    m->tree.size = 0, m->tree.state = nullptr;
+    return UZU_OK;
+}
+
+// logits (bf16 [tree_size, vocab rows]) of the pending tree's nodes
+uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out) {
+    UZU_REQUIRE(m && logits_out, "model_read_tree_logits: null argument");
+    UZU_REQUIRE(m->tree.size > 0, "model_read_tree_logits: no speculated tree is pending");
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    const uint32_t vocab_rows = m->d.tied_embeddings ? m->embedding.n : m->output_embedding.n;
+    HIPCHK(hipMemcpy(logits_out, m->tree.logits, (size_t)m->tree.size * vocab_rows * 2, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
 

@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ queries, uint16_t* __restrict__ keys,
     uint16_t* __restrict__ values, const float* __restrict__ cosines, const float* __restrict__ sines,
     uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset,
-    uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed) {
+    uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed, const uint32_t* __restrict__ trie) {
     const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
     const size_t total = (size_t)batch_dim * total_heads * head_dim;
     const uint32_t pos0 = dyn ? *dyn : 0u;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
             const float input = bf16_to_f32(head[d]);
             const float paired = bf16_to_f32(head[paired_idx]);
             const float signed_paired = d < half ? -paired : paired;
-            const size_t r = (size_t)(batch_idx + pos0) * rope_dim + d;
+            const size_t r = (size_t)((trie ? trie[3 * (size_t)batch_idx + 2] : batch_idx) + pos0) * rope_dim + d; // tree: position = base + height
             element = f32_to_bf16(input * cosines[r] + signed_paired * sines[r]);
         }
         if (is_query) {
@@ -302,14 +302,14 @@ __global__ void __launch_bounds__(256) attention_prepare_kernel(
 uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
                              const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
                              uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
-                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed) {
+                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed, const uint32_t* trie) {
     const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
     const size_t total = (size_t)batch_dim * total_heads * head_dim;
     if (!total) return UZU_OK;
     const uint32_t blocks = (uint32_t)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     return launch_check([&] {
         hipLaunchKernelGGL(attention_prepare_kernel, dim3(blocks), dim3(256), 0, s, qkv, queries, keys, values, cosines,
-                           sines, num_q_heads, num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn, kv_rows_fixed);
+                           sines, num_q_heads, num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn, kv_rows_fixed, trie);
     }, "attention_prepare");
 }
 
@@ -331,6 +331,18 @@ __global__ void kv_cache_update_kernel(T* keys, T* values, CopyList list, uint32
         values[didx] = values[sidx];
     }
 }
+// the reference's own shape: one thread per element column walks the copies in order (kv_cache_update.rs:14-27) -- for lists whose
+// copies depend on each other
+template <class T>
+__global__ void kv_cache_update_ordered_kernel(T* keys, T* values, CopyList list, uint32_t copy_count, uint32_t element_dim) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= element_dim) return;
+    for (uint32_t i = 0; i < copy_count; ++i) {
+        const size_t sidx = (size_t)list.c[i].source * element_dim + e, didx = (size_t)list.c[i].destination * element_dim + e;
+        keys[didx] = keys[sidx];
+        values[didx] = values[sidx];
+    }
+}
 uzu_status kv_cache_update(hipStream_t s, void* keys, void* values, uint32_t dt, const uzu_kv_copy* copies,
                            uint32_t copy_count, uint32_t element_dim) {
     constexpr uint32_t kMax = sizeof(CopyList) / sizeof(uzu_kv_copy);
@@ -338,18 +350,22 @@ uzu_status kv_cache_update(hipStream_t s, void* keys, void* values, uint32_t dt,
         const uint32_t n = copy_count - base < kMax ? copy_count - base : kMax;
         CopyList list;
         for (uint32_t i = 0; i < n; ++i) list.c[i] = copies[base + i];
-        // a destination that is a later source would need the reference's sequential order
-        for (uint32_t i = 0; i < n; ++i)
-            for (uint32_t j = i + 1; j < n; ++j)
-                if (list.c[j].source == list.c[i].destination || list.c[j].destination == list.c[i].destination) {
-                    set_error("kv_cache_update: chained copy list is not supported");
-                    return UZU_ERR_UNSUPPORTED;
+        // A row that one copy writes and another copy reads or writes (the accept compaction of a speculated path does that: copy i
+        // moves row a_i down to row i, and a later copy's destination j can be an earlier copy's source a_i) needs the reference's
+        // sequential order per element column; independent lists run one thread per (copy, element).
+        bool ordered = false;
+        for (uint32_t i = 0; i < n && !ordered; ++i)
+            for (uint32_t j = 0; j < n; ++j)
+                if (i != j && (list.c[j].source == list.c[i].destination || list.c[j].destination == list.c[i].destination)) {
+                    ordered = true;
+                    break;
                 }
         const size_t total = (size_t)n * element_dim;
-        const uint32_t blocks = (uint32_t)((total + 255) / 256);
+        const uint32_t blocks = (uint32_t)(((ordered ? element_dim : total) + 255) / 256);
         uzu_status st = UZU_DISPATCH_T(dt, [&]() -> uzu_status {
             return launch_check([&] {
-                hipLaunchKernelGGL((kv_cache_update_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)keys, (T*)values, list, n, element_dim);
+                if (ordered) hipLaunchKernelGGL((kv_cache_update_ordered_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)keys, (T*)values, list, n, element_dim);
+                else hipLaunchKernelGGL((kv_cache_update_kernel<T>), dim3(blocks), dim3(256), 0, s, (T*)keys, (T*)values, list, n, element_dim);
             }, "kv_cache_update");
         });
         if (st != UZU_OK) return st;

@@ -94,7 +94,9 @@ uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, 
 uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values,
                              const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
                              uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
-                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed = 0);
+                             uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed = 0, const uint32_t* trie = nullptr);
+// trie (speculated tree, {trie_start, trie_end, height} per row): the RoPE position of row i is the base + height_i (transformer.rs:247)
+// instead of base + i; the K / V rows still go to consecutive cache rows (DFS order)
 // AttentionState::encode_accept on a Ring (state.rs:200-219) for a flat full accept of `batch` suffix rows, driven by the device-resident
 // count n = *accepted of tokens accepted before: suffix row idx (at ring_window + idx) -> ring slot (n + idx) % ring_window; when batch >
 // ring_window only the last ring_window rows survive (the reference's sequential copies overwrite the earlier ones)
@@ -247,6 +249,22 @@ uzu_status attention_two_pass2_exact(hipStream_t s, const float* partials, const
                                      uint32_t suffix_length);
 uzu_status delta_net_update_exact(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, const float* norm_weight, float* state, uint16_t* out,
                                   uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, float norm_epsilon);
+// ---- Gated DeltaNet over a speculated token tree (k_deltanet_tree.hip; cpu/kernel/gdn/tree_verify/*.rs, delta_net.rs:334-437) ----
+constexpr uint32_t kDnTreeMaxNodes = 32; // nodes of one verify pass (the reference's stream speculates <= 16: stream.rs:550-554)
+// ConvTreeScan (do_conv) and / or DeltaNetPrefillPrep in its tree instantiation (do_prep: QKT = bf16, log decays, compact v).  in_proj
+// [n, total_proj_dim] bf16; base_state f32 [conv_dim, k-1]; parents i32 [n]; out_proj (optional) = ConvTreeScan's full output rows;
+// suffix_state f32 [n, conv_dim, k-1]; q_out / k_out bf16 [n, key_dim]; v_out bf16 [n, value_dim]; beta_out / log_decay_out f32 [n, Hv].
+uzu_status delta_net_tree_prep(hipStream_t s, const uint16_t* in_proj, const float* conv_w, const float* conv_b, const float* base_state, const int32_t* parents,
+                               uint16_t* out_proj, float* suffix_state, const float* a_log, const float* dt_bias, uint16_t* q_out, uint16_t* k_out, uint16_t* v_out,
+                               float* beta_out, float* log_decay_out, uint32_t n, uint32_t kernel_size, uint32_t Hk, uint32_t Hv, uint32_t Dk, uint32_t Dv, bool do_conv,
+                               bool do_prep);
+// DeltaNetTreeVerify::encode (metal/kernel/gdn/tree_verify.rs:92-187: prefix -> Gram -> solve -> out, batch 1, scale 1, h0 = the SSM state):
+// out bf16 [n, Hv, Dv], bit-identical to the CPU kernels' composition
+uzu_status delta_net_tree_verify(hipStream_t s, const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint32_t* trie, const float* log_decay, const float* beta,
+                                 const float* h0, uint16_t* out, uint32_t n, uint32_t Hk, uint32_t Hv, uint32_t Dk, uint32_t Dv);
+// StateAdvance (state_advance.rs): the delta rule over the accepted path on the SSM state in place
+uzu_status delta_net_state_advance(hipStream_t s, const uint16_t* k_norm, const uint16_t* v, const float* log_decay, const float* beta, const uint32_t* accepted_indices,
+                                   float* state, uint32_t accepted_len, uint32_t Hv, uint32_t Hk, uint32_t Dk);
 uzu_status delta_net_prefill_prep_exact(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* beta_out,
                                         float* decay_out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
 uzu_status delta_net_prefill_exact(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,

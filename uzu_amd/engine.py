@@ -161,6 +161,38 @@ class HipModel:
         call("uzu_hip_model_read_logits", self._h, C.c_void_p(out.ctypes.data))
         return out
 
+    # ---- speculative decoding (stream.rs:380-470, 556-628; host trie: uzu_amd/trie.py) ----
+    def verify_tree(self, token_ids, trie_nodes) -> np.ndarray:
+        """One forward pass over a speculated tree (DFS order; trie_nodes uint32 [n, 3] = {start, end, height}) hanging off the
+        sequence; nothing is accepted.  -> the greedy token sampled at every node."""
+        token_ids = np.ascontiguousarray(token_ids, dtype=np.uint32)
+        trie_nodes = np.ascontiguousarray(trie_nodes, dtype=np.uint32).reshape(token_ids.size, 3)
+        sampled = np.empty(token_ids.size, dtype=np.uint32)
+        call("uzu_hip_model_verify_tree", self._h, C.c_void_p(token_ids.ctypes.data), C.c_void_p(trie_nodes.ctypes.data), C.c_uint32(token_ids.size),
+             C.c_void_p(sampled.ctypes.data))
+        self._tree_size = int(token_ids.size)
+        return sampled
+
+    def accept(self, indices):
+        """encode_accept with a root path of the pending tree (FlatTrie.accept)."""
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        call("uzu_hip_model_accept", self._h, C.c_void_p(indices.ctypes.data), C.c_uint32(indices.size))
+
+    def read_tree_logits(self) -> np.ndarray:
+        out = np.empty((self._tree_size, self.logit_count), dtype=np.uint16)
+        call("uzu_hip_model_read_tree_logits", self._h, C.c_void_p(out.ctypes.data))
+        return out
+
+    def speculative_step(self, root_token: int, propose):
+        """One round of LanguageModelStream's speculative loop: `propose(root_token)` returns a uzu_amd.trie.TrieNode whose root carries
+        `root_token` (the last sampled token); the tree is verified in one pass, the accepted path taken.  -> the tokens gained (the
+        tokens sampled along the accepted path: at least one, whatever the proposal)."""
+        flat = propose(root_token).linearize()
+        sampled = self.verify_tree(flat.token_ids(), flat.nodes())
+        accepted = flat.accept(sampled)
+        self.accept([index for index, _, _ in accepted])
+        return [int(out) for _, _, out in accepted]
+
     def read_layer_output(self, layer: int) -> np.ndarray:
         out = np.empty(1024 * self.model_dim, dtype=np.uint16)
         rows = C.c_uint32()
