@@ -162,7 +162,7 @@ def test_kv_cache_update_with_dependent_copies_runs_in_the_reference_order(hip_c
     wk, wv = keys.copy(), values.copy()
     for s, d in copies:
         wk[d], wv[d] = wk[s], wv[s]
-    kern = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16, len(copies))
+    kern = B.KVCacheUpdateKernel.new(hip_ctx, B.BF16)
     bk, bv = hip_ctx.buffer_from(keys), hip_ctx.buffer_from(values)
     run(hip_ctx, lambda cb: kern.encode(bk, bv, copies, len(copies), dim, cb))
     assert np.array_equal(bk.download(np.uint16, keys.size).reshape(keys.shape), wk)
