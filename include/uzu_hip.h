@@ -168,6 +168,26 @@ typedef struct {
 uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint32_t input_dt, uint32_t output_dt,
                                  uzu_hip_kernel** out);
 uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* args);
+/* MatmulKernel::{a8_activation_plan, select_activation_format} (backends/common/kernel/matmul/kernel.rs:28-42): the backend's say on the
+ * activation format of a linear layer, asked once per shape by the HybridSpec linear wrappers (MatmulShape: routing.rs:20-33).
+ * a8_activation_plan: *has_plan = 0 (None) when the backend cannot run the shape with symmetric int8 activations; otherwise the activation
+ * scale group and (prologues with an offset term) the group-sum group ActivationTransform must produce.  select_activation_format:
+ * UZU_ACTIVATION_FORMAT_BF16 / _INT8 for the shape as it would run with bf16 activations.  The HIP backend plans A8 for every quantised B it
+ * supports and SELECTS Bf16 throughout: measured on MI355X the int8-activation GEMM runs at the bf16-activation GEMM's rate. */
+typedef struct {
+    uint32_t m, n, k;
+    uint32_t b_transpose, has_b_leading_dimension, b_leading_dimension;
+    uint32_t b_kind;       /* uzu_matmul_b_kind: the B prologue (GemmBPrologueKind) */
+    uint32_t b_bits, b_group_size, signed_codes;
+    uint32_t a_full_precision, gathered;
+} uzu_matmul_shape;
+typedef struct {
+    uint32_t activation_group_size;
+    uint32_t has_sum_group_size, sum_group_size;
+} uzu_a8_activation_plan;
+typedef enum { UZU_ACTIVATION_FORMAT_BF16 = 0, UZU_ACTIVATION_FORMAT_INT8 = 1 } uzu_activation_format;
+uzu_status uzu_hip_matmul_a8_activation_plan(uzu_hip_kernel* k, const uzu_matmul_shape* shape, uint32_t* has_plan, uzu_a8_activation_plan* out);
+uzu_status uzu_hip_matmul_select_activation_format(uzu_hip_kernel* k, const uzu_matmul_shape* bf16_shape, uint32_t* format_out);
 
 /* ---- ActivationTransform (cpu/kernel/activation_transform/activation_transform.rs:43-60): randomised Hadamard transform over
  * stripes of 32 elements with +-1 factors (i32 [element_count]), optionally followed by symmetric int8 quantisation.
@@ -242,7 +262,8 @@ uzu_status uzu_hip_attention_two_pass2_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
 /* ---- AttentionGemmCore, a manual trait (BU/backends/common/kernel/attention_gemm/kernel.rs:8-24): the prefill attention
  * core on the matrix cores.  `uzu_attention_core_arguments` = AttentionCoreNewArguments (encodable_block/mixer/attention/
  * core/mod.rs:17-28; Option<T> as has_* + value).  is_supported is the trait's static query (causal bf16, head_dim 64 / 128 /
- * 256, no sinks / ring / trie / sliding window, any GQA factor).  encode = AttentionCoreEncodeArguments
+ * 256, with or without attention sinks, a sliding window, a ring KV prefix; any GQA factor; NOT the speculated-tree mask, which stays on
+ * the single- / two-pass cores).  encode = AttentionCoreEncodeArguments
  * (core/mod.rs:30-38) for AttentionStateType::Full { length = prefix_length }: queries [q_heads, suffix, hd] as written by
  * AttentionPrepare, keys / values = the KV cache [tokens, kv_heads, hd] already holding the suffix rows, out [suffix, q_heads,
  * hd] (the Rust trait returns a fresh Allocation; in C the caller passes it). */
@@ -258,6 +279,12 @@ uzu_status uzu_hip_attention_gemm_is_supported(uzu_hip_context* ctx, const uzu_a
 uzu_status uzu_hip_attention_gemm_create(uzu_hip_context* ctx, const uzu_attention_core_arguments* arguments, uzu_hip_kernel** out);
 uzu_status uzu_hip_attention_gemm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out,
                                          uint32_t prefix_length, uint32_t suffix_length);
+/* The full AttentionCoreEncodeArguments: `sinks` (bf16 [q_heads], iff has_sinks) and the state type -- Full { length } (is_ring = 0, `length`
+ * = the prefix length) or Ring { offset, length, max_length } (mixer/attention/state.rs:16-55: keys / values hold `ring_max_length` ring
+ * slots followed by the suffix rows). */
+uzu_status uzu_hip_attention_gemm_encode_state(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf sinks,
+                                               uzu_buf out, uint32_t is_ring, uint32_t length, uint32_t ring_offset, uint32_t ring_max_length,
+                                               uint32_t suffix_length);
 
 /* ---- KVCacheUpdate (cpu/kernel/attention/kv_cache_update.rs:7-15); copies are inline constants */
 typedef struct { uint32_t source, destination; } uzu_kv_copy; /* BU/gpu_types/kv_cache_update.rs */

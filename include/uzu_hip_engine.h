@@ -138,6 +138,8 @@ uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
  * the token sampled at the last accepted node is the next input token (decode / the next verify_tree's root). */
 uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, uint32_t tree_size, uint32_t* sampled_out);
 uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indices, uint32_t count);
+/* Device time of the last verify_tree pass, ms (HIP events around the pass; the call itself adds three small uploads, one download and a sync). */
+uzu_status uzu_hip_model_verify_gpu_ms(uzu_hip_model* m, float* out_ms);
 /* bf16 logits [tree_size, vocab] of the pending tree's nodes (between verify_tree and accept). */
 uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out);
 

@@ -34,6 +34,26 @@ def main():
         return out
 
     group.enable_p2p(all_gather)
+    if len(sys.argv) > 4 and sys.argv[4] == "skew":
+        # A rank that is late by more than the bounded wait (UZU_TP_TIMEOUT_MS, set short by the test): the punctual rank gives up, and the
+        # failure must reach EVERY rank -- the late one finds each flag it waits for (the punctual rank had pushed its row before it gave
+        # up) and would otherwise carry on with a sum it cannot trust.  Both ranks must end with a non-zero error word.
+        vec = np.full(1024, float(rank + 1), np.float32)
+        for it in range(4):
+            if it == 2 and rank == 1:
+                time.sleep(1.5)
+            buf = ctx.buffer_from(vec)
+            group.all_reduce_sum_f32(buf, 1024)
+            ctx.synchronize()
+            got = buf.download(np.float32, 1024)
+            if it < 2 and not np.all(got == np.float32(sum(range(1, size + 1)))):
+                print(f"rank {rank}: exchange {it} wrong before the skew")
+                sys.exit(1)
+        err = group.p2p_error()
+        print(f"rank {rank}: error word {err}, last sums {'NaN' if np.isnan(got).all() else got[0]}")
+        group.close()
+        ctx.close()
+        sys.exit(0 if err != 0 and np.isnan(got).all() else 1)
     rng = [np.random.default_rng(100 + r) for r in range(size)]
     ok = True
     for it, count in enumerate([1024, 4096, 5120, 8192, 7, 1024, 1024, 2048]):

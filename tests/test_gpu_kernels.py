@@ -126,6 +126,23 @@ def test_gemv_quant_variants(hip_ctx, bits, method, group_size, m):
     assert (want == got).mean() >= 0.98
 
 
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("n,k,m", [(8224, 1024, 16), (1024, 3584, 16), (7168, 1024, 9), (1024, 2048, 2), (1000, 1024, 5), (31040, 1024, 16), (4096, 4096, 13)])
+def test_matmul_few_rows_on_the_matrix_cores(hip_ctx, n, k, m, method):
+    """2 <= M <= 16 activation rows, int4 g128 (csrc/k_gemv_rows.hip: the weights as the A operand of v_mfma_f32_16x16x32_bf16 straight
+    from memory, the rows as its B operand, one quant group per four MFMAs): the Qwen3.5-0.8B linears at the row counts of a speculative
+    verify pass, a ragged N, a slice of the read-out, all three quantisation schemes, with the Linear bias.  <= 1 bf16 ulp against the CPU
+    kernel, >= 97 % bit-identical (the matrix core sums in another order, like the prefill GEMMs)."""
+    rng = np.random.default_rng(n + k + m + method)
+    q = quant_matrix(rng, n, k, 4, 128, method)
+    a = activations(rng, m, k)
+    bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
+    want, got = oracle_matmul(a, q, m, bias=bias), hip_matmul(hip_ctx, a, q, m, bias=bias)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
 def test_gemv_epilogue_and_ragged(hip_ctx):
     """ab_scale + accumulate + bias + soft-cap epilogue, N not a multiple of the tile, signed codes, gather."""
     rng = np.random.default_rng(5)
@@ -1059,7 +1076,7 @@ def test_attention_gemm_core(hip_ctx, heads, kv_heads, hd, prefix, suffix):
     CPU backend has no GEMM core, its prefill IS the single-pass kernel)."""
     args = B.AttentionCoreArguments(hd, kv_heads, heads, 0, 0, 1, 0, 0, 0, 0, 0.0, B.BF16)
     assert B.AttentionGemmCore.is_supported(hip_ctx, args)
-    for bad in (dict(is_causal=0), dict(has_sinks=1), dict(is_trie=1), dict(has_sliding_window=1, sliding_window_size=64), dict(head_dim=96)):
+    for bad in (dict(is_causal=0), dict(is_trie=1), dict(is_kv_cache_ring=1), dict(has_sliding_window=1, sliding_window_size=0), dict(head_dim=96)):
         a2 = B.AttentionCoreArguments(hd, kv_heads, heads, 0, 0, 1, 0, 0, 0, 0, 0.0, B.BF16)
         for k_, v_ in bad.items():
             setattr(a2, k_, v_)
@@ -1074,6 +1091,41 @@ def test_attention_gemm_core(hip_ctx, heads, kv_heads, hd, prefix, suffix):
     core = B.AttentionGemmCore.new(hip_ctx, args)
     bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
     run(hip_ctx, lambda cb: core.encode(bq, bk, bv, bo, prefix, suffix, cb))
+    got = bo.download(np.uint16, want.size).reshape(want.shape)
+    err = np.abs(f32(want) - f32(got))
+    assert err.max() <= 1e-2
+    assert ulp_diff_bf16(want, got).max() <= 2.0 or err.max() <= 2e-3
+
+
+@pytest.mark.parametrize("variant", ["sliding_causal", "ring_full", "ring_partial", "ring_sliding", "sinks", "sinks_sliding"])
+@pytest.mark.parametrize("heads,kv_heads,hd,prefix,suffix", [(8, 2, 256, 700, 300), (32, 8, 128, 96, 160), (4, 4, 64, 333, 70), (8, 2, 128, 0, 64)])
+def test_attention_gemm_core_sliding_window_ring_and_sinks(hip_ctx, variant, heads, kv_heads, hd, prefix, suffix):
+    """The prefill core with the masks attention_gemm.metal takes besides the causal one (AttnParams, gpu_types/attention.rs:12-36): a
+    sliding window, a ring KV prefix (AttentionStateType::Ring: slot i holds position (prefix + i - offset) mod prefix, live below
+    ring_length), attention sinks -- on the matrix cores, against the CPU single-pass kernel with the same arguments (mask.rs:3-61).
+    A ring comes with its window (state.rs:69-136), so the ring-only variants run with a window as wide as the ring."""
+    is_causal, window, ring_params, sinks = mask_case(variant, prefix + suffix, suffix, heads, window_scale=16, ring_scale=37)
+    if prefix == 0:
+        ring_params = None if variant.startswith("ring") else ring_params
+        if variant.startswith("ring"):
+            pytest.skip("an empty ring prefix is the plain causal case")
+    if ring_params is not None and window is None:
+        window = prefix
+    rng = np.random.default_rng(hd + suffix + len(variant))
+    seq = prefix + suffix
+    q, k, v, _ = attention_case(rng, heads, kv_heads, hd, seq, suffix, seq + 8)
+    a = O.AttentionArgs(q.ctypes.data, k.ctypes.data, v.ctypes.data, O.BF16, hd, heads // kv_heads, seq, hd, kv_heads * hd, hd, kv_heads * hd,
+                        1 if ring_params else 0, ring_params[0] if ring_params else 0, ring_params[1] if ring_params else 0, 1.0 / np.sqrt(hd),
+                        1 if window else 0, window or 0, sinks.ctypes.data if sinks is not None else None, heads, suffix, 1)
+    want = np.zeros((suffix, heads, hd), np.uint16)
+    O.lib().orc_attention_single_pass(C.byref(a), O.p(want))
+    args = B.AttentionCoreArguments(hd, kv_heads, heads, int(sinks is not None), int(ring_params is not None), 1, 0, int(window is not None), window or 0, 0, 0.0, B.BF16)
+    assert B.AttentionGemmCore.is_supported(hip_ctx, args)
+    core = B.AttentionGemmCore.new(hip_ctx, args)
+    bq, bk, bv, bo = hip_ctx.buffer_from(q), hip_ctx.buffer_from(k), hip_ctx.buffer_from(v), hip_ctx.create_buffer(want.nbytes)
+    bs = hip_ctx.buffer_from(sinks) if sinks is not None else None
+    state = ("ring", ring_params[0], ring_params[1], prefix) if ring_params else ("full", prefix)
+    run(hip_ctx, lambda cb: core.encode_state(bq, bk, bv, bs, bo, state, suffix, cb))
     got = bo.download(np.uint16, want.size).reshape(want.shape)
     err = np.abs(f32(want) - f32(got))
     assert err.max() <= 1e-2
@@ -1438,3 +1490,21 @@ def test_stream_gemv_with_matrix_core_consumers(hip_ctx, n, k):
     ulps = ulp_diff_bf16(want, got)
     assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps ({(ulps > 1).sum()} of {n} outputs)"
     assert (want == got).mean() >= 0.99
+
+
+def test_matmul_activation_format_policy(hip_ctx):
+    """MatmulKernel::{a8_activation_plan, select_activation_format} (kernel.rs:28-42) through the C ABI: the plan exists for every
+    quantised B the A8 matmul takes (activation group = ACTIVATION_SCALE_GROUP_SIZE = 128; a sum group for the prologues with an offset
+    term: metal/kernel/matmul/mod.rs:154-165), not for full-precision B / full-precision-only kernels / k off the group grid; the selected
+    format is Bf16 for decode and prefill shapes alike (the int8 matrix-core GEMM measured at the bf16 GEMM's rate: DESIGN.md section 3)."""
+    kern = B.MatmulKernel.new(hip_ctx, B.BF16, B.BF16, B.BF16)
+    shape = lambda **kw: B.MatmulShape(**{**dict(m=1024, n=7168, k=1024, b_transpose=1, b_kind=B.B_SCALE_BIAS, b_bits=4, b_group_size=128), **kw})
+    assert kern.a8_activation_plan(shape()) == (128, 128)
+    assert kern.a8_activation_plan(shape(b_group_size=64, b_kind=B.B_SCALE_ZERO_POINT, b_bits=8)) == (128, 64)
+    assert kern.a8_activation_plan(shape(b_kind=B.B_SCALE_SYMMETRIC)) == (128, None)
+    assert kern.a8_activation_plan(shape(b_kind=B.B_FULL_PRECISION)) is None
+    assert kern.a8_activation_plan(shape(k=1024 + 64)) is None
+    assert kern.a8_activation_plan(shape(a_full_precision=1)) is None
+    assert B.MatmulKernel.new(hip_ctx, B.F32, B.F32, B.F32).a8_activation_plan(shape()) is None
+    for m in (1, 16, 128, 4096):
+        assert kern.select_activation_format(shape(m=m, a_full_precision=1)) == B.ACTIVATION_FORMAT_BF16

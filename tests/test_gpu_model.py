@@ -423,6 +423,53 @@ def test_qwen_bench_config_matches_oracle_fixture(hip_ctx):
     # test_exact_mode_bench_config_stream_is_identical_to_the_fixture.
 
 
+def test_bench_config_whole_chained_stream_equals_the_oracle_in_production_mode(hip_ctx):
+    """north_star's first bar on the BENCHMARKED configuration, in the mode bench.py times: full-size Qwen3.5-0.8B int4 g128, the
+    2043-token prompt bench.py's default run prefills (two chunks, matrix-core GEMMs, chunked DeltaNet scan), then chained greedy decode
+    through the captured two-pass graph with the fused decode kernels -- the WHOLE stream token for token equal to the CPU oracle's
+    (tests/golden/bench_qwen_stream.json, generator make_bench_stream.py; bench.py compares its own run with the same file and reports
+    "parity").  The prompt is a variant picked by outcome (tools/stream_search.py; profiles/r4_stream_search.txt says why no margin
+    threshold can pick one); the stream is varied (>= 12 distinct tokens).  Teacher-forced on top: the oracle's top-8 logits matched
+    within 0.25 sigma (row-normalised) at every step, and at every step the measured error of the two leading logits is below the
+    oracle's margin (printed: the worst step's slack)."""
+    path = os.path.join(GOLDEN, "bench_qwen_stream.json")
+    if not os.path.exists(path):
+        pytest.fail("tests/golden/bench_qwen_stream.json is missing: run python tests/golden/make_bench_stream.py <variant>")
+    fx = json.load(open(path))
+    want = fx["tokens"]
+    cfg = S.PRESETS[fx["preset"]](max_context_length=fx["prompt_tokens"] + len(want) + 8)
+    assert cfg.seed == fx["seed"] and cfg.bits == fx["bits"] and abs(cfg.logit_row_sigma - fx["logit_row_sigma"]) < 1e-12
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg)
+    prompt = S.synthetic_prompt(fx["prompt_tokens"], cfg.vocab_size, variant=fx["prompt_variant"])
+    hm = HipModel(hip_ctx, bundle)
+    first = hm.prefill(prompt)
+    toks, _ = hm.decode(len(want) - 1)
+    got = [first] + [int(t) for t in toks]
+    assert got == want, f"the chained production stream leaves the oracle's at token {next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)}\noracle {want}\nhip    {got}"
+    assert len(set(want)) >= 12
+    hm.reset()
+    hm.prefill(prompt)
+    worst, min_slack = 0.0, float("inf")
+    for step, r in enumerate(fx["rows"]):
+        if step > 0:
+            hm.set_next_token(fx["rows"][step - 1]["token"])
+            hm.decode(1)
+        lg = f32(hm.read_logits()).astype(np.float64)
+        sigma = (lg / row_mult).std()
+        errs = {}
+        for tok, bits in r["top8"]:
+            errs[tok] = abs(lg[tok] - float(f32(np.array([bits], np.uint16))[0])) / row_mult[tok] / sigma
+            assert errs[tok] <= 0.25, f"step {step}: logit of token {tok} off by {errs[tok]:.3f} sigma (row-normalised)"
+        worst = max(worst, max(errs.values()))
+        assert int(np.argmax(lg)) == r["token"]
+        best, runner = r["top8"][0][0], r["top8"][1][0]
+        band = (errs[best] * row_mult[best] + errs[runner] * row_mult[runner]) / (row_mult[best] + row_mult[runner])  # in the margin's units
+        min_slack = min(min_slack, r["margin"] - band)
+    print(f"bench stream: {len(want)} tokens identical ({len(set(want))} distinct), top-8 logits within {worst:.3f} sigma, oracle margin - measured error >= {min_slack:.4f} at every step")
+    hm.close()
+
+
 @pytest.mark.parametrize("name", ["llama_int4", "llama_int8"])
 def test_llama3_8b_full_depth_matches_oracle_fixture(hip_ctx, name):
     """BASELINE configs[2] / [3] weights at full depth: all 32 layers of Llama-3-8B (int4 MLX ScaleBias; int8 asymmetric),

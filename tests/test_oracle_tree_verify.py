@@ -314,3 +314,33 @@ def test_model_verify_with_nothing_right_accepts_the_root_only():
     om.accept([0])
     assert om.forward([want[1]]) == want[2]
     om.close()
+
+
+def test_oracle_tree_verify_matches_the_committed_fixture():
+    """tests/golden/tree_verify.json (make_tree_verify_golden.py): the oracle's verify / accept path frozen -- sampled tokens, a digest of
+    every node's logits, the accepted paths, the tokens decoded afterwards."""
+    import hashlib
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tree_verify.json")))
+    for preset, case in fx.items():
+        cfg = S.PRESETS[preset]()
+        bundle = S.build_model(cfg)
+        mult = case["prompt_multiplier"]
+        prompt = ((S.synthetic_prompt(case["prompt_len"], cfg.vocab_size).astype(np.int64) * mult + 11 * mult) % cfg.vocab_size).astype(np.uint32)
+        om = O.OracleModel(bundle)
+        assert linear_stream(om, prompt, len(case["linear_stream"]) - 1)[0] == case["linear_stream"]
+        om.reset()
+        om.prefill(prompt)
+        for rnd in case["rounds"]:
+            sampled, logits = om.verify_tree(np.array(rnd["token_ids"], np.uint32), np.array(rnd["nodes"], np.uint32), True)
+            assert [int(t) for t in sampled] == rnd["sampled"]
+            assert [hashlib.sha256(logits[n].tobytes()).hexdigest()[:16] for n in range(len(rnd["sampled"]))] == rnd["logit_sha256_16"]
+            om.accept(rnd["accepted"])
+        tok = rnd["sampled"][rnd["accepted"][-1]]
+        after = []
+        for _ in range(len(case["decoded_after"])):
+            tok = om.forward([tok])
+            after.append(tok)
+        assert after == case["decoded_after"]
+        om.close()

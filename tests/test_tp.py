@@ -392,6 +392,27 @@ def test_p2p_all_reduce_two_processes_one_gpu(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+@pytest.mark.gpu
+def test_p2p_failure_reaches_every_rank(tmp_path):
+    """A rank that arrives later than the bounded wait: the punctual rank's exchange gives up and writes the failing sequence number into
+    EVERY mailbox (csrc/tp.hip), so the late rank -- which finds all the flags it waits for -- starts its next exchange poisoned as well:
+    both ranks end with a non-zero error word and NaN sums, i.e. every host raises at its next sync point instead of one rank sitting in a
+    host barrier while the other carries on (the hang an 8-GPU run would otherwise risk)."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), UZU_TP_TIMEOUT_MS="150")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), "2", str(tmp_path), "skew"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("p2p workers timed out")
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
 # ------------------------------------------------------------------------------------------------ N ranks on ONE GPU
 TP_CASES = [
     # (preset, kwargs, prompt_len, steps, logit tolerance in sigma, near-tie gap)

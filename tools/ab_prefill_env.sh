@@ -1,6 +1,5 @@
 #!/bin/bash
 # GPU box (gpurun): same-box A/B of the prefill switches of one library build.
-#   UZU_DN_CHUNK_MFMA=0|1  chunked DeltaNet scan on the VALU | on v_mfma_f32_16x16x4_f32 (shipping)
 #   UZU_GEMM_ACT=0|1       GatedActMul as its own kernel | in the up projection's GEMM epilogue (shipping)
 #   UZU_ATTN_TPW=4|2|1|0   wave tasks per workgroup of the flash-attention prefill kernel (0 = chosen by grid size, shipping)
 # The GEMM loop variants (pair-form conversion, pipelined k16 steps) are compile-time: build k_gemm128.hip with
@@ -9,7 +8,6 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 run() { "$@" 2> /dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'tok/s decode,', d.get('prefill_tokens_per_s'), 'tok/s prefill')"; }
-for v in 1 0; do echo "UZU_DN_CHUNK_MFMA=$v qwen3.5-0.8b:"; UZU_DN_CHUNK_MFMA=$v run python bench.py --steps 16 --warmup 2 --no-cpu-baseline; done
 for v in 1 0; do
   echo "UZU_GEMM_ACT=$v qwen3.5-0.8b:"; UZU_GEMM_ACT=$v run python bench.py --steps 16 --warmup 2 --no-cpu-baseline
   echo "UZU_GEMM_ACT=$v llama-3-8b:"; UZU_GEMM_ACT=$v run python bench.py --model llama-3-8b --steps 8 --warmup 2 --no-cpu-baseline

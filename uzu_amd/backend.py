@@ -265,9 +265,36 @@ class _Kernel:
         call(self._encode, self._h, encoder._h, *args)
 
 
+class MatmulShape(C.Structure):
+    """MatmulShape (backends/common/kernel/matmul/routing.rs:20-33) as include/uzu_hip.h::uzu_matmul_shape lays it out"""
+    _fields_ = [(n, C.c_uint32) for n in ("m", "n", "k", "b_transpose", "has_b_leading_dimension", "b_leading_dimension", "b_kind", "b_bits", "b_group_size",
+                                           "signed_codes", "a_full_precision", "gathered")]
+
+
+class A8ActivationPlan(C.Structure):
+    _fields_ = [("activation_group_size", C.c_uint32), ("has_sum_group_size", C.c_uint32), ("sum_group_size", C.c_uint32)]
+
+
+ACTIVATION_FORMAT_BF16, ACTIVATION_FORMAT_INT8 = 0, 1
+
+
 class MatmulKernel(_Kernel):
-    """kernel/matmul/kernel.rs:12-43: new(context, weights_dt, input_dt, output_dt); encode(MatmulArguments, encoder)"""
+    """kernel/matmul/kernel.rs:12-43: new(context, weights_dt, input_dt, output_dt); encode(MatmulArguments, encoder);
+    a8_activation_plan(shape) -> Option<A8ActivationPlan>; select_activation_format(bf16_shape) -> ActivationFormat"""
     _create, _encode = "uzu_hip_matmul_create", "uzu_hip_matmul_encode"
+
+    def a8_activation_plan(self, shape: "MatmulShape"):
+        """-> (activation_group_size, sum_group_size | None), or None when the backend cannot run the shape with int8 activations"""
+        has, plan = C.c_uint32(), A8ActivationPlan()
+        call("uzu_hip_matmul_a8_activation_plan", self._h, C.byref(shape), C.byref(has), C.byref(plan))
+        if not has.value:
+            return None
+        return plan.activation_group_size, (plan.sum_group_size if plan.has_sum_group_size else None)
+
+    def select_activation_format(self, bf16_shape: "MatmulShape") -> int:
+        fmt = C.c_uint32()
+        call("uzu_hip_matmul_select_activation_format", self._h, C.byref(bf16_shape), C.byref(fmt))
+        return fmt.value
 
     def encode(self, encoder: CommandBuffer, *, a: BufArg, b: BufArg, d: BufArg, m: int, n: int, k: int, a_offset: int = 0,
                b_kind: int = B_FULL_PRECISION, scales: BufArg = None, biases: BufArg = None, zero_points: BufArg = None,
@@ -373,6 +400,16 @@ class AttentionGemmCore:
 
     def encode(self, queries, keys, values, out, prefix_length, suffix_length, encoder):
         call("uzu_hip_attention_gemm_encode", self._h, encoder._h, _buf(queries), _buf(keys), _buf(values), _buf(out), _u(prefix_length), _u(suffix_length))
+
+    def encode_state(self, queries, keys, values, sinks, out, state, suffix_length, encoder):
+        """AttentionCoreEncodeArguments with the state type: state = ("full", length) | ("ring", offset, length, max_length) (state.rs:16-24)"""
+        if state[0] == "ring":
+            _, offset, length, max_length = state
+            ring = (1, length, offset, max_length)
+        else:
+            ring = (0, state[1], 0, 0)
+        call("uzu_hip_attention_gemm_encode_state", self._h, encoder._h, _buf(queries), _buf(keys), _buf(values), _buf(sinks), _buf(out), *[_u(x) for x in ring],
+             _u(suffix_length))
 
 
 class AttentionTwoPass2Kernel(_Kernel):

@@ -64,6 +64,41 @@ uzu_status uzu_hip_matmul_create(uzu_hip_context* ctx, uint32_t weights_dt, uint
     return UZU_OK;
 }
 
+// MatmulKernel::a8_activation_plan (kernel.rs:28-34; Metal's policy: metal/kernel/matmul/mod.rs:132-166): whether THIS backend can run the
+// shape with symmetric int8 activations, and with which quantisation groups.  The HIP matmul takes MatmulA::Int8Symmetric for every
+// quantised B (int4 / int8 codes, signed or not, all three prologues, groups of 32 / 64 / 128) with bf16 tables (k_activation_transform.hip:
+// matmul_a8); the activation group is the reference's ACTIVATION_SCALE_GROUP_SIZE, the sum group min(weight group, activation group) for the
+// prologues that carry an offset term.
+uzu_status uzu_hip_matmul_a8_activation_plan(uzu_hip_kernel* k, const uzu_matmul_shape* shape, uint32_t* has_plan, uzu_a8_activation_plan* out) {
+    UZU_REQUIRE(k && k->kind == KK_MATMUL && shape && has_plan && out, "matmul_a8_activation_plan: bad argument");
+    constexpr uint32_t kActivationGroup = 128; // ACTIVATION_SCALE_GROUP_SIZE (backends/common/kernel/activation_transform.rs:17)
+    *has_plan = 0;
+    out->activation_group_size = 0, out->has_sum_group_size = 0, out->sum_group_size = 0;
+    const bool quant = shape->b_kind != UZU_MATMUL_B_FULL_PRECISION;
+    if (k->t[1] != UZU_BF16 || k->t[2] != UZU_BF16 || k->t[0] != UZU_BF16 || shape->a_full_precision || !quant || !shape->b_transpose || shape->has_b_leading_dimension ||
+        shape->gathered || !(shape->b_bits == 4 || shape->b_bits == 8) || !(shape->b_group_size == 32 || shape->b_group_size == 64 || shape->b_group_size == 128) ||
+        shape->k % kActivationGroup || shape->k % shape->b_group_size)
+        return UZU_OK;
+    *has_plan = 1;
+    out->activation_group_size = kActivationGroup;
+    if (shape->b_kind != UZU_MATMUL_B_SCALE_SYMMETRIC) {
+        out->has_sum_group_size = 1;
+        out->sum_group_size = shape->b_group_size < kActivationGroup ? shape->b_group_size : kActivationGroup;
+    }
+    return UZU_OK;
+}
+// MatmulKernel::select_activation_format (kernel.rs:36-42; Metal: mod.rs:168-183 answers Int8 only where its GEMM runs on the matrix unit
+// AND is faster there).  MI355X, measured (tests/test_gpu_kernels.py::test_matmul_int8_activations_throughput_report): the
+// int8-activation GEMM on v_mfma_i32_32x32x32_i8 runs at the bf16-activation GEMM's rate (721 vs 746 T(FL)OP/s at 4096x14336x4096 on int4
+// weights, 501 vs 612 on int8 weights) -- both are bound by the per-group scale fold / int4 conversion on the vector unit, not by the matrix
+// pipe -- and decode GEMVs gain nothing from quantised activations.  With no speed to buy for the activation-quantisation error the answer
+// is Bf16 for every shape; the entry exists so that a Rust shim forwards the trait method instead of hard-coding the default.
+uzu_status uzu_hip_matmul_select_activation_format(uzu_hip_kernel* k, const uzu_matmul_shape* bf16_shape, uint32_t* format_out) {
+    UZU_REQUIRE(k && k->kind == KK_MATMUL && bf16_shape && format_out, "matmul_select_activation_format: bad argument");
+    *format_out = UZU_ACTIVATION_FORMAT_BF16;
+    return UZU_OK;
+}
+
 uzu_status uzu_hip_matmul_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, const uzu_matmul_arguments* a) {
     UZU_PROPAGATE(check(k, KK_MATMUL, cb));
     UZU_REQUIRE(a && a->a.buffer && a->b.buffer && a->d.buffer, "matmul: a, b and d are required");
@@ -319,7 +354,10 @@ uzu_status uzu_hip_attention_two_pass1_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
 // core/mod.rs:17-38): the prefill attention on the matrix cores (k_attention_mfma.hip).  is_supported mirrors the trait's
 // static query; a backend that answers false is never constructed by AttentionCores::new (core/mod.rs:53-61).
 static bool attention_gemm_args_supported(const uzu_attention_core_arguments* a) {
-    if (a->data_type != UZU_BF16 || !a->is_causal || a->has_sinks || a->is_kv_cache_ring || a->is_trie || a->has_sliding_window) return false;
+    // causal bf16 with or without sinks, a sliding window and a ring KV prefix (a ring always comes with its window, state.rs:69-136);
+    // the speculated-tree mask stays on the single- / two-pass cores
+    if (a->data_type != UZU_BF16 || !a->is_causal || a->is_trie || (a->is_kv_cache_ring && !a->has_sliding_window)) return false;
+    if (a->has_sliding_window && !a->sliding_window_size) return false;
     if (!(a->head_dim == 64 || a->head_dim == 128 || a->head_dim == 256)) return false;
     if (a->num_groups == 0 || a->num_q_heads % a->num_groups) return false;
     const uint32_t gqa = a->num_q_heads / a->num_groups;
@@ -338,17 +376,45 @@ uzu_status uzu_hip_attention_gemm_create(uzu_hip_context* ctx, const uzu_attenti
     k->t[0] = arguments->data_type;
     k->f[0] = arguments->head_dim, k->f[1] = arguments->num_groups, k->f[2] = arguments->num_q_heads, k->f[3] = arguments->has_scale;
     k->f[4] = uzu::f32_to_bits(arguments->scale);
+    k->f[5] = arguments->has_sinks, k->f[6] = arguments->is_kv_cache_ring, k->f[7] = arguments->has_sliding_window ? arguments->sliding_window_size : 0u;
     return UZU_OK;
 }
+// AttentionCoreEncodeArguments (core/mod.rs:30-38) with the state type spelled out: Full { length } (is_ring = 0, `length` = the prefix
+// length) or Ring { offset, length, max_length } (state.rs:16-55: the prefix region is `ring_max_length` slots, `length` of them live).
+uzu_status uzu_hip_attention_gemm_encode_state(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf sinks, uzu_buf out,
+                                               uint32_t is_ring, uint32_t length, uint32_t ring_offset, uint32_t ring_max_length, uint32_t suffix_length) {
+    UZU_PROPAGATE(check(k, KK_ATTENTION_GEMM, cb));
+    UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out.buffer, "attention_gemm: queries/keys/values/out are required");
+    UZU_REQUIRE(suffix_length > 0, "attention_gemm: empty suffix");
+    UZU_REQUIRE((sinks.buffer != nullptr) == (k->f[5] != 0), "attention_gemm: sinks presence must equal has_sinks");
+    UZU_REQUIRE((is_ring != 0) == (k->f[6] != 0), "attention_gemm: the state type must match is_kv_cache_ring");
+    UZU_REQUIRE(!is_ring || (ring_max_length > 0 && length <= ring_max_length && ring_offset < ring_max_length), "attention_gemm: bad ring parameters");
+    const uint32_t hd = k->f[0], nkv = k->f[1], nq = k->f[2];
+    k::AttentionParams a{};
+    a.queries = bptr(queries), a.keys = bptr(keys), a.values = bptr(values), a.sinks = bptr(sinks);
+    a.dt = k->t[0], a.head_dim = hd, a.gqa_factor = nq / nkv;
+    a.sequence_length = (is_ring ? ring_max_length : length) + suffix_length; // physical_prefix_length + the suffix being attended (state.rs:26-37)
+    if (is_ring) a.is_kv_cache_ring = 1, a.ring_offset = ring_offset, a.ring_length = length;
+    if (k->f[7]) a.is_sliding_window = 1, a.sliding_window_size = k->f[7];
+    a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;
+    if (k->f[3]) a.scale = uzu::bits_to_f32(k->f[4]);
+    else a.scale = 1.0f / sqrtf((float)hd);
+    a.num_heads = nq, a.suffix_length = suffix_length, a.is_causal = 1;
+    if (!k::attention_prefill_mfma_supported(a)) return k::attention_single_pass(cb_stream(cb), a, bptr(out)); // suffixes too short for a tile
+    return k::attention_prefill_mfma(cb_stream(cb), a, bptr(out));
+}
+// the plain Full-state form (no sinks)
 uzu_status uzu_hip_attention_gemm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf queries, uzu_buf keys, uzu_buf values, uzu_buf out,
                                          uint32_t prefix_length, uint32_t suffix_length) {
     UZU_PROPAGATE(check(k, KK_ATTENTION_GEMM, cb));
     UZU_REQUIRE(queries.buffer && keys.buffer && values.buffer && out.buffer, "attention_gemm: queries/keys/values/out are required");
     UZU_REQUIRE(suffix_length > 0, "attention_gemm: empty suffix");
+    UZU_REQUIRE(!k->f[5] && !k->f[6], "attention_gemm: a kernel with sinks or a ring state is encoded with uzu_hip_attention_gemm_encode_state");
     const uint32_t hd = k->f[0], nkv = k->f[1], nq = k->f[2];
     k::AttentionParams a{};
     a.queries = bptr(queries), a.keys = bptr(keys), a.values = bptr(values);
     a.dt = k->t[0], a.head_dim = hd, a.gqa_factor = nq / nkv;
+    if (k->f[7]) a.is_sliding_window = 1, a.sliding_window_size = k->f[7];
     a.sequence_length = prefix_length + suffix_length; // AttentionStateType::Full { length } + the suffix being attended
     // strides of the KV cache layout [tokens, kv_heads, head_dim] (core/single_pass.rs:44-73)
     a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;

@@ -174,10 +174,21 @@ struct uzu_hip_model {
         void* argmax_scratch = nullptr;
         bool allocated = false;
         bool active = false;            // the forward pass being encoded is a tree pass
+        float last_gpu_ms = 0.f;        // device time of the last tree pass (events around the launches / the graph replay)
         uint32_t size = 0;              // nodes of the pending tree (0 = none)
         uzu_hip_state* state = nullptr; // the state it hangs off
         std::vector<int32_t> parents;
         std::vector<uint32_t> sampled;
+        // the tree pass of (sequence state, node count, attention regime) as a hipGraph: everything that changes from pass to pass --
+        // token ids, trie nodes, parents, context length -- sits in device buffers the kernels read, so the captured pass is replayable
+        struct Graph {
+            uzu_hip_state* state;
+            uint32_t nodes;
+            bool two_pass;
+            hipGraphExec_t exec;
+            uint32_t launches;
+        };
+        std::vector<Graph> graphs;
     } tree;
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
@@ -1318,10 +1329,23 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     return UZU_OK;
 }
 
+static void drop_tree_graphs(uzu_hip_model* m, uzu_hip_state* st) { // st == nullptr: all of them
+    auto& gs = m->tree.graphs;
+    for (size_t i = 0; i < gs.size();) {
+        if (!st || gs[i].state == st) {
+            (void)hipGraphExecDestroy(gs[i].exec);
+            gs.erase(gs.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+}
+
 void uzu_hip_model_destroy(uzu_hip_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    drop_tree_graphs(m, nullptr);
     if (m->bound) m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two;
     state_free(m->state0);
     // states created with uzu_hip_state_create belong to the caller; one that outlives its model loses its device memory here and
@@ -1374,6 +1398,8 @@ void uzu_hip_state_destroy(uzu_hip_state* st) {
         }
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    drop_tree_graphs(m, st); // captured tree passes carry this state's cache pointers
+    if (m->tree.state == st) m->tree.size = 0, m->tree.state = nullptr;
     if (m->bound == st) { // hand the model back to its own state first
         st->graph_single = m->graph_single, st->graph_two = m->graph_two;
         m->bound = nullptr;
@@ -1700,13 +1726,42 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
             }
         if (max_heads && two_pass) UZU_PROPAGATE(ensure_partials(m, tree_size * max_heads, max_hd));
     }
-    m->tree.active = true;
-    const uzu_status st = encode_forward(m, s, tree_size, true);
-    m->tree.active = false;
-    UZU_PROPAGATE(st);
+    const bool two_pass_regime = m->context_length + tree_size > 1024;
+    HIPCHK(hipEventRecord(m->ev0, s));
+    if ((m->flags & UZU_MODEL_NO_GRAPH) || k::exact_mode()) {
+        m->tree.active = true;
+        const uzu_status st = encode_forward(m, s, tree_size, true);
+        m->tree.active = false;
+        UZU_PROPAGATE(st);
+    } else {
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : m->tree.graphs)
+            if (g.state == m->bound && g.nodes == tree_size && g.two_pass == two_pass_regime) exec = g.exec, m->launches = g.launches;
+        if (!exec) {
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            m->regime_override = two_pass_regime ? 1 : 0;
+            m->tree.active = true;
+            const uzu_status st = encode_forward(m, s, tree_size, true);
+            m->tree.active = false;
+            m->regime_override = -1;
+            hipGraph_t g = nullptr;
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (st != UZU_OK || ce != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                if (st == UZU_OK) set_error("model_verify_tree: graph capture failed: %s", hipGetErrorString(ce));
+                return st != UZU_OK ? st : UZU_ERR_HIP;
+            }
+            HIPCHK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(g));
+            m->tree.graphs.push_back({m->bound, tree_size, two_pass_regime, exec, m->launches});
+        }
+        HIPCHK(hipGraphLaunch(exec, s));
+    }
+    HIPCHK(hipEventRecord(m->ev1, s));
     m->tree.sampled.resize(tree_size);
     HIPCHK(hipMemcpyAsync(m->tree.sampled.data(), m->tree.d_sampled, (size_t)tree_size * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&m->tree.last_gpu_ms, m->ev0, m->ev1);
     UZU_PROPAGATE(k::gemv_stream_check());
     if (sampled_out) memcpy(sampled_out, m->tree.sampled.data(), (size_t)tree_size * 4);
     m->tree.size = tree_size, m->tree.state = m->bound, m->tree.parents = parents;
@@ -1754,6 +1809,13 @@ uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indic
     m->context_length = new_len;
     m->hidden_ready = false;
     m->tree.size = 0, m->tree.state = nullptr;
+    return UZU_OK;
+}
+
+// device time of the last tree pass in milliseconds (HIP events on the engine's stream around the pass)
+uzu_status uzu_hip_model_verify_gpu_ms(uzu_hip_model* m, float* out_ms) {
+    UZU_REQUIRE(m && out_ms, "model_verify_gpu_ms: null argument");
+    *out_ms = m->tree.last_gpu_ms;
     return UZU_OK;
 }
 

@@ -51,7 +51,11 @@ __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 
 // Key split (few-head models: Qwen3.5-0.8B has 2 kv heads -> 64 workgroups of four tasks per 1024-token chunk): gridDim.z workgroups share a
 // task group, each takes an equal share of the key tiles ITS queries can see and leaves the unnormalised O^T, the running maximum and the
 // sum as f32 partials ([split][query][head]); attention_prefill_merge_kernel folds them (the AttentionTwoPass2 step of the decode path).
-template <int HD>
+// GEN: the general mask of mask.rs:3-61 without the trie -- sliding window, ring KV prefix (AttentionStateType::Ring: the prefix rows are a
+// ring of `prefix` slots, key position = (prefix + i - ring_offset) mod prefix, live iff < ring_length) and attention sinks (the running
+// maximum starts at the head's sink logit with a unit of mass: attention_single_pass.rs:70-74) -- evaluated per key on its POSITION; the
+// plain causal instantiation keeps its one comparison per key.
+template <int HD, bool GEN>
 __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionParams a, uint16_t* out, uint32_t tpw, float* part_o, float* part_ml) {
     constexpr int KP = HD * 2 + 16;  // K tile row pitch in bytes (conflict-free ds_read_b128)
     constexpr int VP = TK * 2 + 8;   // V^T tile row pitch in bytes: 32 keys + 8 bytes of pad (conflict-free ds_read_b64)
@@ -69,8 +73,10 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
     const bool wave_live = (uint32_t)wave < tpw && task < n_tasks;
     const uint32_t task_c = wave_live ? task : n_tasks - 1;
     const uint32_t head = kv_head * a.gqa_factor + task_c % a.gqa_factor;
+    if constexpr (GEN) attention_resolve_dyn(a); // ring parameters / sequence length from the device-resident accepted-token count
     const uint32_t sequence_length = a.sequence_length + (a.dyn ? *a.dyn : 0u);
     const uint32_t prefix = sequence_length - M;
+    const uint32_t suffix_position = (GEN && a.is_kv_cache_ring) ? a.ring_length : prefix; // attention_single_pass.rs:52-61
     const uint32_t q0 = (task_c / a.gqa_factor) * TQ; // first query of this wave
     const uint32_t qi = q0 + l32;                           // this lane's query (suffix index)
     const bool q_live = wave_live && qi < M;
@@ -145,6 +151,13 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f; // l_run: this lane's half of the keys only (merged at the end)
     const uint32_t my_last_key = prefix + qi; // causal: keys 0 .. prefix + qi
+    if constexpr (GEN) {
+        if (a.sinks && blockIdx.z == 0) { // the sink's unit of mass is counted once: by half 0 of the first key split
+            m_run = bf16_to_f32(((const uint16_t*)a.sinks)[head]);
+            l_run = half == 0 ? 1.0f : 0.0f;
+        }
+    }
+    const uint32_t query_position = suffix_position + qi;
 
     if (t_lo < n_tiles) {
         load_tile(t_lo);
@@ -174,7 +187,20 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t key = t * TK + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool vis = q_live && key <= my_last_key;
+                bool vis = q_live && key <= my_last_key;
+                if constexpr (GEN) { // mask.rs:31-60 on positions
+                    uint32_t key_position;
+                    if (key >= prefix) {
+                        key_position = suffix_position + (key - prefix);
+                    } else if (a.is_kv_cache_ring) {
+                        key_position = prefix + key - a.ring_offset;
+                        if (key_position >= prefix) key_position -= prefix;
+                        vis = vis && key_position < a.ring_length;
+                    } else {
+                        key_position = key;
+                    }
+                    if (a.is_sliding_window) vis = vis && key_position <= query_position && query_position - key_position < a.sliding_window_size;
+                }
                 sc[r] = vis ? a.scale * sacc[r] : -INFINITY;
                 m_loc = fmaxf(m_loc, sc[r]);
             }
@@ -251,7 +277,13 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
         const char* e = getenv("UZU_ATTN_MFMA_MIN_M");
         return e ? (uint32_t)atoi(e) : 16u;
     }();
-    if (a.dt != UZU_BF16 || !a.is_causal || a.sinks || a.is_sliding_window || a.is_kv_cache_ring || a.trie) return false;
+    static const bool general_on = [] { // UZU_ATTN_MFMA_GENERAL=0: sliding-window / ring / sink layers back on the VALU kernels (A/B runs)
+        const char* e = getenv("UZU_ATTN_MFMA_GENERAL");
+        return !e || atoi(e) != 0;
+    }();
+    if (a.dt != UZU_BF16 || !a.is_causal || a.trie) return false;
+    if (!general_on && (a.sinks || a.is_sliding_window || a.is_kv_cache_ring)) return false;
+    if (a.is_kv_cache_ring && !a.is_sliding_window) return false; // a ring without a window does not occur (state.rs:69-136)
     if (a.suffix_length < min_m || !(a.head_dim == 64 || a.head_dim == 128 || a.head_dim == 256)) return false;
     if (a.gqa_factor == 0 || a.num_heads % a.gqa_factor) return false;
     if (a.k_head_stride % 8 || a.k_seq_stride % 8 || a.v_head_stride % 8 || a.v_seq_stride % 8) return false;
@@ -326,10 +358,13 @@ uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void*
     const size_t rows = (size_t)a.suffix_length * a.num_heads;
     float* part_o = part;
     float* part_ml = part ? part + (size_t)splits * rows * a.head_dim : nullptr;
+    const bool general = a.sinks || a.is_sliding_window || a.is_kv_cache_ring;
 #define UZU_LAUNCH(H)                                                                                                                                              \
     {                                                                                                                                                              \
-        UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(attention_prefill_mfma_kernel<H>, grid, dim3(256), 0, s, a, (uint16_t*)out, tpw, part_o, part_ml); }, \
-                                   "attention_prefill_mfma"));                                                                                                     \
+        UZU_PROPAGATE(launch_check([&] {                                                                                                                           \
+            if (general) hipLaunchKernelGGL((attention_prefill_mfma_kernel<H, true>), grid, dim3(256), 0, s, a, (uint16_t*)out, tpw, part_o, part_ml);             \
+            else hipLaunchKernelGGL((attention_prefill_mfma_kernel<H, false>), grid, dim3(256), 0, s, a, (uint16_t*)out, tpw, part_o, part_ml);                    \
+        }, "attention_prefill_mfma"));                                                                                                                             \
         if (!part) return UZU_OK;                                                                                                                                  \
         return launch_check([&] { hipLaunchKernelGGL(attention_prefill_merge_kernel<H>, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, s, part_o, part_ml, (uint16_t*)out, (uint32_t)rows, splits); }, \
                             "attention_prefill_merge");                                                                                                            \

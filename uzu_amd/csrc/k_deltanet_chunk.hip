@@ -9,7 +9,7 @@
 //     O = diag(A) Q S_0^T + P D              P_ti = (A_t / A_i) q_t.k_i                                   (i <= t)
 //     S_C = A_C S_0 + D^T diag(A_C / A_i) K
 // T and P do not involve the state: `dn_chunk_prep_kernel` builds them for all chunks and heads in parallel (two
-// 32 x 32 Gram matrices + one 32 x 32 forward substitution each).  `dn_chunk_scan_kernel` then walks the chunks with
+// 32 x 32 Gram matrices + one 32 x 32 forward substitution each).  `dn_chunk_scan_mfma_kernel` then walks the chunks with
 // four small dense products per chunk instead of 32 dependent steps; a workgroup owns 16 of a head's Dv columns, so
 // 128 workgroups are busy and every product has hundreds of independent FMAs per thread.
 // Same algebra, different rounding order: results agree with the one-token recurrence to ~1e-6 relative in f32
@@ -114,286 +114,8 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
     }
 }
 
-// grid (Dv / DVS, Hv), 256 threads; walks the chunks sequentially.  The operands of chunk c + 1 are requested from
-// memory while chunk c is computed (registers), and moved to LDS between two barriers at the chunk boundary.
-template <int DVS>
-__global__ void __launch_bounds__(256) dn_chunk_scan_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
-                                                            uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
-                                                            uint32_t value_dim, uint32_t suffix_len) {
-    constexpr int NV = DVS / 8;          // value columns per thread in the token-major products (stages 1-3)
-    constexpr int SD = DVS * DKC / 256;  // state elements per thread (stage 4): 4 or 8 consecutive dk
-    constexpr int RP = DVS + 1;          // LDS pitch of R / D
-    __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVS * KP];
-    __shared__ float sT[CC * TP], sP[CC * TP];
-    __shared__ float sR[CC * RP], sD[CC * RP];
-    __shared__ float sA[CC], sW[CC];
-    const int tid = threadIdx.x;
-    const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVS, hk = hv / (num_v_heads / num_k_heads);
-    const uint32_t conv_dim = 2 * key_dim + value_dim;
-    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
-    const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
-
-    // state slice: thread -> (dv, SD consecutive dk): registers for the whole scan, mirrored in LDS per chunk
-    const int s_dv = tid / (DKC / SD), s_dk = (tid % (DKC / SD)) * SD;
-    float* srow = state + ((size_t)hv * head_v_dim + dv_base + s_dv) * DKC + s_dk;
-    float sreg[SD];
-#pragma unroll
-    for (int e = 0; e < SD; e += 4) {
-        const float4 a = *(const float4*)(srow + e);
-        sreg[e] = a.x, sreg[e + 1] = a.y, sreg[e + 2] = a.z, sreg[e + 3] = a.w;
-    }
-    // product mapping of stages 1-3: thread -> (token t = tid / 8, NV value columns)
-    const int p_t = tid >> 3, p_dv = (tid & 7) * NV;
-
-    // ---- operand staging: registers <- memory (chunk c), LDS <- registers
-    float4 st_k[4], st_q[4];
-    float st_t[4], st_p[4], st_a = 0.f, st_w = 0.f, st_v[NV];
-    auto fetch = [&](uint32_t c) {
-        const uint32_t t0 = c * CC;
-        const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
-            st_k[r] = make_float4(0.f, 0.f, 0.f, 0.f), st_q[r] = st_k[r];
-            if (t0 + t < suffix_len) {
-                st_k[r] = *(const float4*)(k_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
-                st_q[r] = *(const float4*)(q_norm + (size_t)(t0 + t) * key_dim + hk * DKC + c4 * 4);
-            }
-            st_t[r] = w_t[idx], st_p[r] = w_t[CC * CC + idx];
-        }
-        if (tid < CC) st_a = w_t[2 * CC * CC + tid], st_w = w_t[2 * CC * CC + CC + tid];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) st_v[j] = 0.f;
-        if (t0 + p_t < suffix_len) {
-            const uint16_t* vp = in_proj + (size_t)(t0 + p_t) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + p_dv;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) st_v[j] = bf16_to_f32(vp[j]);
-        }
-    };
-    float vreg[NV];
-    auto publish = [&]() {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = tid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
-            *(float4*)(sK + t * KP + c4 * 4) = st_k[r];
-            *(float4*)(sQ + t * KP + c4 * 4) = st_q[r];
-            sT[(idx / CC) * TP + idx % CC] = st_t[r];
-            sP[(idx / CC) * TP + idx % CC] = st_p[r];
-        }
-        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
-#pragma unroll
-        for (int e = 0; e < SD; e += 4) *(float4*)(sS + s_dv * KP + s_dk + e) = make_float4(sreg[e], sreg[e + 1], sreg[e + 2], sreg[e + 3]);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) vreg[j] = st_v[j];
-    };
-
-    fetch(0);
-    publish();
-    __syncthreads();
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        const uint32_t t0 = c * CC;
-        if (c + 1 < n_chunks) fetch(c + 1);
-        // ---- stage 1: K S^T and Q S^T for (t, NV value columns); R = V - A K S^T
-        float ks[NV], qs[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) ks[j] = 0.f, qs[j] = 0.f;
-#pragma unroll 8
-        for (int d4 = 0; d4 < DKC; d4 += 4) {
-            const float4 kt = *(const float4*)(sK + p_t * KP + d4), qt = *(const float4*)(sQ + p_t * KP + d4);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const float4 sv = *(const float4*)(sS + (p_dv + j) * KP + d4);
-                ks[j] = fmaf(kt.x, sv.x, ks[j]), ks[j] = fmaf(kt.y, sv.y, ks[j]), ks[j] = fmaf(kt.z, sv.z, ks[j]), ks[j] = fmaf(kt.w, sv.w, ks[j]);
-                qs[j] = fmaf(qt.x, sv.x, qs[j]), qs[j] = fmaf(qt.y, sv.y, qs[j]), qs[j] = fmaf(qt.z, sv.z, qs[j]), qs[j] = fmaf(qt.w, sv.w, qs[j]);
-            }
-        }
-        const float a_t = sA[p_t];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) sR[p_t * RP + p_dv + j] = vreg[j] - a_t * ks[j];
-        __syncthreads();
-        // ---- stage 2: D = T R (T is lower triangular; the stored zeros keep the trip count fixed)
-        float dd[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) dd[j] = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < CC; ++i) {
-            const float tv = sT[p_t * TP + i];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) dd[j] = fmaf(tv, sR[i * RP + p_dv + j], dd[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < NV; ++j) sD[p_t * RP + p_dv + j] = dd[j];
-        __syncthreads();
-        // ---- stage 3: O = A Q S^T + P D
-        float oo[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) oo[j] = a_t * qs[j];
-#pragma unroll 8
-        for (int i = 0; i < CC; ++i) {
-            const float pv = sP[p_t * TP + i];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) oo[j] = fmaf(pv, sD[i * RP + p_dv + j], oo[j]);
-        }
-        if (t0 + p_t < suffix_len) {
-            uint16_t* op = out + (size_t)(t0 + p_t) * value_dim + hv * head_v_dim + dv_base + p_dv;
-            if (NV == 2) *(uint32_t*)op = (uint32_t)f32_to_bf16(oo[0]) | ((uint32_t)f32_to_bf16(oo[NV - 1]) << 16);
-            else op[0] = f32_to_bf16(oo[0]);
-        }
-        // ---- stage 4: S = A_C S + D^T diag(W) K for (dv, SD dk)
-        {
-            const float a_c = sA[CC - 1];
-#pragma unroll
-            for (int e = 0; e < SD; ++e) sreg[e] *= a_c;
-#pragma unroll 8
-            for (int i = 0; i < CC; ++i) {
-                const float dw = sD[i * RP + s_dv] * sW[i];
-#pragma unroll
-                for (int e = 0; e < SD; e += 4) {
-                    const float4 kv = *(const float4*)(sK + i * KP + s_dk + e);
-                    sreg[e] = fmaf(dw, kv.x, sreg[e]), sreg[e + 1] = fmaf(dw, kv.y, sreg[e + 1]), sreg[e + 2] = fmaf(dw, kv.z, sreg[e + 2]),
-                    sreg[e + 3] = fmaf(dw, kv.w, sreg[e + 3]);
-                }
-            }
-        }
-        __syncthreads(); // all reads of this chunk's LDS operands are done
-        if (c + 1 < n_chunks) publish();
-        __syncthreads();
-    }
-#pragma unroll
-    for (int e = 0; e < SD; e += 4) *(float4*)(srow + e) = make_float4(sreg[e], sreg[e + 1], sreg[e + 2], sreg[e + 3]);
-}
-
-// Eight-wave variant for DVS = 8 (the 0.8B shape: 256 workgroups, one per CU).  With four waves every SIMD holds one
-// wave and the LDS latency of the short product loops is fully exposed; 512 threads halve each thread's share of the
-// two large products (stage 1: one 128-long dot per thread, stage 4: two state elements per thread) and give every
-// SIMD a second wave to switch to.  Stage 2 runs on the K-threads, stage 3 on the Q-threads (they hold Q S^T).
-__global__ void __launch_bounds__(512) dn_chunk_scan8w_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
-                                                              uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
-                                                              uint32_t value_dim, uint32_t suffix_len) {
-    constexpr int DVS = 8, RP = DVS + 1;
-    __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVS * KP];
-    __shared__ float sT[CC * TP], sP[CC * TP];
-    __shared__ float sR[CC * RP], sD[CC * RP];
-    __shared__ float sA[CC], sW[CC];
-    const int tid = threadIdx.x;
-    const uint32_t hv = blockIdx.y, dv_base = blockIdx.x * DVS, hk = hv / (num_v_heads / num_k_heads);
-    const uint32_t conv_dim = 2 * key_dim + value_dim;
-    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
-    const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
-
-    // state: thread -> (dv = tid / 64, two consecutive dk)
-    const int s_dv = tid >> 6, s_dk = (tid & 63) * 2;
-    float* srow = state + ((size_t)hv * head_v_dim + dv_base + s_dv) * DKC + s_dk;
-    float2 sreg = *(const float2*)srow;
-    // products: thread -> (token t = tid / 16, value column dv = tid % 8, operand: K (0) or Q (1))
-    const int p_t = tid >> 4, p_dv = tid & 7, p_q = (tid >> 3) & 1;
-
-    // staging registers: native vectors + UNCONDITIONAL loads (clamped token, zeroed by a select) so that the compiler can
-    // keep them in flight across the LDS-only barriers below
-    f32x4_v st_k[2], st_q[2];
-    float st_t[2], st_p[2], st_a = 0.f, st_w = 0.f, st_v = 0.f;
-    auto fetch = [&](uint32_t c) {
-        const uint32_t t0 = c * CC;
-        const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int idx = tid + 512 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
-            const bool live = t0 + t < suffix_len;
-            const size_t tok = live ? t0 + t : suffix_len - 1;
-            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4_v kv = *(const f32x4_v*)(k_norm + tok * key_dim + hk * DKC + c4 * 4);
-            const f32x4_v qv = *(const f32x4_v*)(q_norm + tok * key_dim + hk * DKC + c4 * 4);
-            st_k[r] = live ? kv : zero, st_q[r] = live ? qv : zero;
-            st_t[r] = w_t[idx], st_p[r] = w_t[CC * CC + idx];
-        }
-        st_a = w_t[2 * CC * CC + (tid & (CC - 1))], st_w = w_t[2 * CC * CC + CC + (tid & (CC - 1))];
-        {
-            const bool live = t0 + p_t < suffix_len;
-            const float vv = bf16_to_f32(in_proj[(size_t)(live ? t0 + p_t : suffix_len - 1) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + p_dv]);
-            st_v = live && !p_q ? vv : 0.f;
-        }
-    };
-    float vreg = 0.f;
-    auto publish = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int idx = tid + 512 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
-            *(f32x4_v*)(sK + t * KP + c4 * 4) = st_k[r];
-            *(f32x4_v*)(sQ + t * KP + c4 * 4) = st_q[r];
-            sT[(idx / CC) * TP + idx % CC] = st_t[r];
-            sP[(idx / CC) * TP + idx % CC] = st_p[r];
-        }
-        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
-        *(float2*)(sS + s_dv * KP + s_dk) = sreg;
-        vreg = st_v;
-    };
-
-    fetch(0);
-    publish();
-    __syncthreads();
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        const uint32_t t0 = c * CC;
-        fetch(c + 1 < n_chunks ? c + 1 : c); // unconditional (the last chunk refetches itself): countable loads
-        // ---- stage 1: one dot per thread: (K | Q)[t] . S[dv]
-        float dot;
-        {   // four independent chains (a single accumulator makes the 128 FMAs one dependent chain)
-            const float* xr = (p_q ? sQ : sK) + p_t * KP;
-            const float* sr = sS + p_dv * KP;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll 8
-            for (int d4 = 0; d4 < DKC; d4 += 4) {
-                const float4 xv = *(const float4*)(xr + d4), sv = *(const float4*)(sr + d4);
-                d0 = fmaf(xv.x, sv.x, d0), d1 = fmaf(xv.y, sv.y, d1), d2 = fmaf(xv.z, sv.z, d2), d3 = fmaf(xv.w, sv.w, d3);
-            }
-            dot = (d0 + d1) + (d2 + d3);
-        }
-        const float a_t = sA[p_t];
-        if (!p_q) sR[p_t * RP + p_dv] = vreg - a_t * dot;
-        lds_barrier();
-        // ---- stage 2 (K-threads): D = T R
-        if (!p_q) {
-            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < CC; i += 4) {
-                e0 = fmaf(sT[p_t * TP + i], sR[i * RP + p_dv], e0), e1 = fmaf(sT[p_t * TP + i + 1], sR[(i + 1) * RP + p_dv], e1);
-                e2 = fmaf(sT[p_t * TP + i + 2], sR[(i + 2) * RP + p_dv], e2), e3 = fmaf(sT[p_t * TP + i + 3], sR[(i + 3) * RP + p_dv], e3);
-            }
-            sD[p_t * RP + p_dv] = (e0 + e1) + (e2 + e3);
-        }
-        lds_barrier();
-        // ---- stage 3 (Q-threads): O = A Q S^T + P D
-        if (p_q) {
-            float e0 = a_t * dot, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < CC; i += 4) {
-                e0 = fmaf(sP[p_t * TP + i], sD[i * RP + p_dv], e0), e1 = fmaf(sP[p_t * TP + i + 1], sD[(i + 1) * RP + p_dv], e1);
-                e2 = fmaf(sP[p_t * TP + i + 2], sD[(i + 2) * RP + p_dv], e2), e3 = fmaf(sP[p_t * TP + i + 3], sD[(i + 3) * RP + p_dv], e3);
-            }
-            const float oo = (e0 + e1) + (e2 + e3);
-            if (t0 + p_t < suffix_len) out[(size_t)(t0 + p_t) * value_dim + hv * head_v_dim + dv_base + p_dv] = f32_to_bf16(oo);
-        }
-        // ---- stage 4: S = A_C S + D^T diag(W) K for (dv, two dk)
-        {
-            const float a_c = sA[CC - 1];
-            float2 u0 = make_float2(sreg.x * a_c, sreg.y * a_c), u1 = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < CC; i += 2) {
-                const float dw0 = sD[i * RP + s_dv] * sW[i], dw1 = sD[(i + 1) * RP + s_dv] * sW[i + 1];
-                const float2 k0 = *(const float2*)(sK + i * KP + s_dk), k1 = *(const float2*)(sK + (i + 1) * KP + s_dk);
-                u0.x = fmaf(dw0, k0.x, u0.x), u0.y = fmaf(dw0, k0.y, u0.y);
-                u1.x = fmaf(dw1, k1.x, u1.x), u1.y = fmaf(dw1, k1.y, u1.y);
-            }
-            sreg = make_float2(u0.x + u1.x, u0.y + u1.y);
-        }
-        lds_barrier();
-        if (c + 1 < n_chunks) publish();
-        lds_barrier();
-    }
-    *(float2*)srow = sreg;
-}
-
-// Matrix-core scan (the shipping one).  The VALU scans above read two LDS operands per four FMAs: 780 KB of LDS reads per chunk and
-// workgroup, 158 us per 1024 tokens at the 0.8B shape.  Here the four products of a chunk run on v_mfma_f32_16x16x4_f32 -- f32
+// Matrix-core scan.  (The VALU scans of rounds 1-2 read two LDS operands per four FMAs: 780 KB of LDS reads per chunk and workgroup,
+// 158 us per 1024 tokens at the 0.8B shape; removed in round 4, git history has them.)  The four products of a chunk run on v_mfma_f32_16x16x4_f32 -- f32
 // operands, exact f32 products, f32 accumulation: the arithmetic of the VALU scan in another summation order -- with operands
 // fetched once per chunk into registers.  A workgroup owns 16 value columns of a head (grid (Dv / 16, Hv), 4 waves):
 //   stage 1  [K; Q] S^T     wave w = one 16-token tile of K (w = 0, 1) or Q (w = 2, 3): 16 x 16 x 128, 32 MFMAs
@@ -580,38 +302,9 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         hipLaunchKernelGGL(dn_chunk_prep_kernel, dim3(n_chunks, num_v_heads), dim3(256), 0, s, q_norm, k_norm, beta, decay, workspace, num_v_heads, num_k_heads,
                            key_dim, suffix_len);
     }, "delta_net_chunk_prep"));
-    // 8 value columns per workgroup when that is what it takes to give every CU a workgroup (Hv * Dv / 8 = 256 at 0.8B)
-    static const int force = [] {
-        const char* e = getenv("UZU_DN_CHUNK_DVS");
-        return e ? atoi(e) : 0;
-    }();
-    static const int use_mfma = [] {
-        const char* e = getenv("UZU_DN_CHUNK_MFMA");
-        return e ? atoi(e) : 1;
-    }();
-    if (use_mfma && !force)
-        return launch_check([&] {
-            hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
-                               num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
-        }, "delta_net_chunk_scan");
-    const bool narrow = force ? force == 8 : num_v_heads * (head_v_dim / 16) < 200;
-    static const int waves8 = [] {
-        const char* e = getenv("UZU_DN_CHUNK_8W");
-        return e ? atoi(e) : 1;
-    }();
-    if (narrow && waves8)
-        return launch_check([&] {
-            hipLaunchKernelGGL(dn_chunk_scan8w_kernel, dim3(head_v_dim / 8, num_v_heads), dim3(512), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
-                               num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
-        }, "delta_net_chunk_scan");
-    if (narrow)
-        return launch_check([&] {
-            hipLaunchKernelGGL(dn_chunk_scan_kernel<8>, dim3(head_v_dim / 8, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
-                               num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
-        }, "delta_net_chunk_scan");
     return launch_check([&] {
-        hipLaunchKernelGGL(dn_chunk_scan_kernel<16>, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out, num_v_heads,
-                           num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+        hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
+                           num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
     }, "delta_net_chunk_scan");
 }
 

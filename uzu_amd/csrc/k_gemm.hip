@@ -12,7 +12,7 @@
 //     grouped form the decode GEMV uses (gemv_core.h), so prefill and decode see the same arithmetic up to summation
 //     order.  Nothing is ever rounded to a bf16 *weight*.
 //   * v_mfma_f32_32x32x16_bf16; workgroup tile 64 x 64 x 64, four waves as 2 x 2, each wave one 32 x 32 block (three
-//     workgroups per CU).  This is the kernel for 16 <= M < 128 and for shapes the large-tile kernel (k_gemm128.hip: 128 x 128
+//     workgroups per CU).  This is the kernel for 20 <= M < 128 and for shapes the large-tile kernel (k_gemm128.hip: 128 x 128
 //     tiles, weights straight from global memory into the MFMA operand) does not cover.
 //   * The k order inside an MFMA is irrelevant as long as A and B agree, so the kernel picks the order that makes the
 //     weight fetch one vector per lane: lanes 0..31 take k = 8s..8s+7, lanes 32..63 take k = 32+8s..32+8s+7 at step s
@@ -284,8 +284,10 @@ __global__ void __launch_bounds__(256) gemm_q_mfma_kernel(MatmulParams p, uint32
 // Shapes the matrix-core path covers; everything else stays on the GEMV-tiled / reference kernels of k_matmul.hip.
 bool gemm_q_mfma_supported(const MatmulParams& p) {
     static const uint32_t min_m = [] {
+        // below ~20 rows the GEMV in passes of four rows is faster than a 64-row tile a quarter full: a 16-node speculative tree pass of
+        // Qwen3.5-0.8B takes 2.93 ms with the GEMVs against 3.64 ms with the tiles (tools/verify_cost.py, profiles/r4_verify_cost.json)
         const char* e = getenv("UZU_GEMM_MIN_M");
-        return e ? (uint32_t)atoi(e) : 16u;
+        return e ? (uint32_t)atoi(e) : 20u;
     }();
     if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || (p.bits != 4 && p.bits != 8)) return false;
     if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || (p.d_dt != UZU_BF16 && p.d_dt != UZU_F32)) return false;

@@ -1,0 +1,190 @@
+// k_gemv_rows.hip -- quantised matmul for a HANDFUL of activation rows (2 <= M <= 16) on the matrix cores.
+//
+// Where it sits: between the decode GEMV (M = 1, k_decode.hip) and the tiled GEMMs (k_gemm.hip from ~20 rows).  A speculative
+// verify pass (uzu_hip_model_verify_tree: <= 16 tree nodes) and short prefill tails run every linear at such an M; the GEMV in passes
+// of four rows re-reads the weights per pass and pays 16 packed dots per row and step on the vector unit, a 64-row GEMM tile is a
+// quarter full and pays its LDS pipeline for nothing (profiles/r4_verify_cost.json: 2.9 / 3.6 ms for a 16-node pass of Qwen3.5-0.8B
+// against 1.3 ms at M = 1).
+//
+// Shape: 16 activation rows are exactly the N side of v_mfma_f32_16x16x32_bf16, so a wave computes a [16 weight rows] x [16 tokens] tile
+// per instruction with the WEIGHTS as the A operand straight from global memory (no LDS, coalesced 64-byte row pieces, `nt` like the
+// GEMV) and the activations as the B operand from LDS (staged once per workgroup, already in the k order of the code conversion):
+//   * lane (r = l % 16, g = l / 16) loads 16 bytes = 32 int4 codes of weight row r at k0 + 32 g; word i of them converts to the 8 bf16
+//     (16 + q) of MFMA i (gemv_core.h: two codes per v_and_or_b32) -- k order [n0 n4 n1 n5 n2 n6 n3 n7], which the staged activations share;
+//   * the four MFMAs of a step contract over k0 .. k0 + 127 = ONE quant group (group_size % 128 == 0), so the group's scale / offset
+//     fold is four packed multiply-adds per lane on the 16 x 16 result (rows 4 (l / 16) + v of token l % 16), the scalars broadcast inside
+//     a 16-lane row with DPP row_share;
+//   * sum_k x of the group (the offset term, and the 16 of the code trick) comes from the matrix core as well: the same B against an
+//     all-ones A -- no vector work;
+//   * the workgroup's waves split K (steps w, w + NW, ...) and add their tiles through LDS in wave order.
+// Per 1 KiB of codes: 32 conversions + ~24 fold / broadcast VALU + 8 MFMAs for ALL 16 rows -- the M = 1 GEMV's instruction budget.
+// Results are tolerance-class against the scalar reference like every reduction kernel (f32 accumulation in another order).
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace uzu {
+namespace k {
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 gr_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gr_f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t gr_u32x4;
+
+// value of lane `src` (0..15) of this lane's 16-lane row (DPP row_share: one VALU, no LDS)
+template <int SRC> __device__ __forceinline__ float row_share(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + SRC, 0xF, 0xF, false));
+}
+
+struct RowsParams {
+    const uint16_t* a; // [m, k] bf16
+    const uint8_t* w;  // [n, k / 2]
+    const uint16_t* scales;
+    const uint16_t* biases;
+    const uint8_t* zp;
+    const uint16_t* out_bias; // [n] or null
+    void* d;                  // [m, n] bf16 or f32
+    uint32_t m, n, k, group_size, kind, d_f32;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t gr_smem[];
+    const uint32_t K = p.k, pitch = K * 2 + 16; // bytes per activation row in LDS (+16: rows start 4 banks apart)
+    uint8_t* xs = gr_smem;                      // [16][pitch]
+    float* s_part = (float*)(gr_smem + 16 * pitch); // [NW][16 rows][16 tokens]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t row0 = blockIdx.x * 16;
+    const uint32_t steps = K / 128, G = K / p.group_size, gshift = 31 - __builtin_clz(p.group_size);
+    const uint32_t zp_stride = (G + 1) / 2;
+    // ---- weight row of this lane: clamped into range (a clamped row is computed and never stored)
+    const uint32_t wrow = min(row0 + r, p.n - 1);
+    const uint8_t* wp = p.w + (size_t)wrow * (K / 2) + 16 * g;
+    // rows whose scale / offset this lane-group folds: 4 g + (lane % 4) (lanes 0..3 of the row carry them, the rest duplicate)
+    const uint32_t frow = min(row0 + 4 * g + (r & 3), p.n - 1);
+    auto load_step = [&](uint32_t s, uint4& codes, uint16_t& sc, uint16_t& of) {
+        const uint32_t sc_ = min(s, steps - 1); // past the end: a reload that is never consumed (keeps the loads countable)
+        codes = load16_stream(wp + (size_t)sc_ * 64);
+        const uint32_t grp = (sc_ * 128) >> gshift;
+        sc = p.scales[(size_t)frow * G + grp];
+        if (p.kind == UZU_MATMUL_B_SCALE_BIAS) of = p.biases[(size_t)frow * G + grp];
+        else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+            const uint8_t z = p.zp[(size_t)frow * zp_stride + (grp >> 1)];
+            of = (grp & 1) ? (z >> 4) : (z & 0x0F);
+        } else of = 0;
+    };
+    uint4 cA, cB;
+    uint16_t scA, ofA, scB, ofB;
+    load_step(wave, cA, scA, ofA); // in flight while the activations are staged
+    // ---- stage the activation rows: 16-byte chunks (8 consecutive k) in the conversion's k order; rows >= m are zero
+    {
+        const uint32_t chunks_per_row = K / 8, total = 16 * chunks_per_row;
+        for (uint32_t idx = tid; idx < total; idx += 64 * NW) {
+            const uint32_t j = idx / chunks_per_row, c = idx % chunks_per_row;
+            gr_u32x4 o = {0u, 0u, 0u, 0u};
+            if (j < p.m) {
+                const gr_u32x4 u = *(const gr_u32x4*)(p.a + (size_t)j * K + (size_t)c * 8); // (x0,x1) (x2,x3) (x4,x5) (x6,x7)
+                o.x = __builtin_amdgcn_perm(u.z, u.x, 0x05040100u); // (x0, x4)
+                o.y = __builtin_amdgcn_perm(u.z, u.x, 0x07060302u); // (x1, x5)
+                o.z = __builtin_amdgcn_perm(u.w, u.y, 0x05040100u); // (x2, x6)
+                o.w = __builtin_amdgcn_perm(u.w, u.y, 0x07060302u); // (x3, x7)
+            }
+            *(gr_u32x4*)(xs + (size_t)j * pitch + (size_t)c * 16) = o;
+        }
+    }
+    lds_barrier();
+    uint32_t mask = 0x00780078u, magic = 0x41804180u, ones = 0x3F803F80u;
+    asm("" : "+s"(mask));
+    asm("" : "+v"(magic));
+    asm("" : "+v"(ones));
+    const gr_u32x4 ones4 = {ones, ones, ones, ones};
+    gr_f32x4 acc = {0.f, 0.f, 0.f, 0.f}; // rows 4 g + v of token r
+    const uint8_t* xlane = xs + (size_t)r * pitch + 64 * g; // this lane's B chunks: token r, k0 + 32 g + 8 i
+    auto compute = [&](uint32_t s, const uint4& codes, uint16_t sc_bits, uint16_t of_bits) {
+        const uint32_t ws[4] = {codes.x, codes.y, codes.z, codes.w};
+        gr_f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+        const uint8_t* xb = xlane + (size_t)s * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gr_u32x4 av;
+            av.x = ((ws[i] << 3) & mask) | magic, av.y = ((ws[i] >> 1) & mask) | magic, av.z = ((ws[i] >> 5) & mask) | magic, av.w = ((ws[i] >> 9) & mask) | magic;
+            const gr_u32x4 bv = *(const gr_u32x4*)(xb + 16 * i);
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gr_bf16x8, av), __builtin_bit_cast(gr_bf16x8, bv), dq, 0, 0, 0);
+            dx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gr_bf16x8, ones4), __builtin_bit_cast(gr_bf16x8, bv), dx, 0, 0, 0);
+        }
+        // group fold: acc[v] += scale_v * dq[v] + (offset_v - 16 scale_v) * sum_x   (dx[v] = sum_k x of token r, the same in every v)
+        const float sc = bf16_to_f32(sc_bits);
+        float of;
+        if (p.kind == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(of_bits);
+        else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) of = -sc * (float)of_bits;
+        else of = -sc * 8.0f;
+        of = fmaf(-kQ4Offset, sc, of);
+        const float s0 = row_share<0>(sc), s1 = row_share<1>(sc), s2 = row_share<2>(sc), s3 = row_share<3>(sc);
+        const float o0 = row_share<0>(of), o1 = row_share<1>(of), o2 = row_share<2>(of), o3 = row_share<3>(of);
+        acc.x = fmaf(s0, dq.x, fmaf(o0, dx.x, acc.x));
+        acc.y = fmaf(s1, dq.y, fmaf(o1, dx.x, acc.y));
+        acc.z = fmaf(s2, dq.z, fmaf(o2, dx.x, acc.z));
+        acc.w = fmaf(s3, dq.w, fmaf(o3, dx.x, acc.w));
+    };
+    for (uint32_t s = wave; s < steps; s += 2 * NW) {
+        load_step(s + NW, cB, scB, ofB);
+        compute(s, cA, scA, ofA);
+        load_step(s + 2 * NW, cA, scA, ofA);
+        if (s + NW < steps) compute(s + NW, cB, scB, ofB);
+    }
+    // ---- add the waves' tiles in wave order, bias, store: thread t = (row t / 16, token t % 16)
+    float* mine = s_part + (size_t)wave * 256;
+    mine[(4 * g + 0) * 16 + r] = acc.x, mine[(4 * g + 1) * 16 + r] = acc.y, mine[(4 * g + 2) * 16 + r] = acc.z, mine[(4 * g + 3) * 16 + r] = acc.w;
+    lds_barrier();
+    if (tid < 256) {
+        const uint32_t row = tid >> 4, j = tid & 15;
+        float v = s_part[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += s_part[w * 256 + tid];
+        if (j < p.m && row0 + row < p.n) {
+            float value = 1.0f * v; // MatmulKernel epilogue with ab_scale = 1 (kernel.rs:281-292)
+            if (p.out_bias) value += bf16_to_f32(p.out_bias[row0 + row]);
+            if (p.d_f32) ((float*)p.d)[(size_t)j * p.n + row0 + row] = value;
+            else ((uint16_t*)p.d)[(size_t)j * p.n + row0 + row] = f32_to_bf16(value);
+        }
+    }
+}
+} // namespace
+
+bool gemv_rows_mfma_supported(const MatmulParams& p) {
+    static const bool on = [] { // UZU_GEMV_ROWS=0: small M back on the GEMV passes / GEMM tiles (A/B runs)
+        const char* e = getenv("UZU_GEMV_ROWS");
+        return !e || atoi(e) != 0;
+    }();
+    if (!on || exact_mode()) return false;
+    if (p.m < 2 || p.m > 16 || p.bits != 4 || p.b_kind == UZU_MATMUL_B_FULL_PRECISION) return false;
+    if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || (p.d_dt != UZU_BF16 && p.d_dt != UZU_F32)) return false;
+    if (p.signed_codes || p.ab_scale != 1.0f || p.accumulate || p.has_soft_cap || p.gather || p.act_mul) return false;
+    if (p.k % 128 || p.group_size % 128 || (p.group_size & (p.group_size - 1)) || p.k % p.group_size) return false;
+    if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16) return false;
+    if ((size_t)16 * (p.k * 2 + 16) + 8 * 256 * 4 > 150 * 1024) return false; // the staged activations must fit the CU's LDS
+    return true;
+}
+
+uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p) {
+    RowsParams q{};
+    q.a = (const uint16_t*)p.a, q.w = (const uint8_t*)p.b, q.scales = (const uint16_t*)p.scales, q.biases = (const uint16_t*)p.biases, q.zp = p.zero_points;
+    q.out_bias = (const uint16_t*)p.bias, q.d = p.d, q.m = p.m, q.n = p.n, q.k = p.k, q.group_size = p.group_size, q.kind = p.b_kind, q.d_f32 = p.d_dt == UZU_F32;
+    const uint32_t blocks = (p.n + 15) / 16, steps = p.k / 128;
+    // eight waves split K where the row blocks alone leave most of the chip idle and there are steps to share
+    const bool wide = blocks < 256 && steps >= 16;
+    const int nw = wide ? 8 : 4;
+    const size_t lds = (size_t)16 * (p.k * 2 + 16) + (size_t)nw * 256 * 4;
+    static LdsLimit lim4, lim8;
+    if (!raise_lds_limit(wide ? lim8 : lim4, wide ? (const void*)gemv_rows_mfma_kernel<8> : (const void*)gemv_rows_mfma_kernel<4>, lds)) {
+        set_error("gemv_rows: %zu bytes of LDS are not available", lds);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    return launch_check([&] {
+        if (wide) hipLaunchKernelGGL(gemv_rows_mfma_kernel<8>, dim3(blocks), dim3(512), lds, s, q);
+        else hipLaunchKernelGGL(gemv_rows_mfma_kernel<4>, dim3(blocks), dim3(256), lds, s, q);
+    }, "gemv_rows_mfma");
+}
+
+} // namespace k
+} // namespace uzu

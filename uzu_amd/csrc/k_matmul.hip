@@ -272,6 +272,10 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
         if (variant) *variant = p.bits == 4 ? "gemv_dec<4>" : "gemv_dec<8>";
         return gemv_dec(s, q, num_cus, nullptr);
     }
+    if (gemv_rows_mfma_supported(p)) { // a handful of rows (speculative verify passes, prefill tails): one pass over the weights on the matrix cores
+        if (variant) *variant = "gemv_rows_mfma";
+        return gemv_rows_mfma(s, p);
+    }
     if (gemm_q_mfma_supported(p)) { // prefill-sized M: bf16 matrix cores (k_gemm.hip)
         if (variant) *variant = p.bits == 4 ? "gemm_q_mfma<4>" : "gemm_q_mfma<8>";
         return gemm_q_mfma(s, p, num_cus);

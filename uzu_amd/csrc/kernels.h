@@ -56,7 +56,10 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
 // true when matmul() can run `p` with the fused GatedActMul epilogue (act_mul = 1: D = [m, n/2]); otherwise run the matmul and
 // gated_act_mul separately
 bool matmul_act_mul_supported(hipStream_t s, const MatmulParams& p, int num_cus);
-bool gemm_q_mfma_supported(const MatmulParams& p);   // k_gemm.hip: M >= 16, bf16 activations, int4/int8 codes, group % 64 == 0
+// k_gemv_rows.hip: 2 <= M <= 16 activation rows against int4 codes (group % 128 == 0) as ONE pass over the weights on the matrix cores
+bool gemv_rows_mfma_supported(const MatmulParams& p);
+uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p);
+bool gemm_q_mfma_supported(const MatmulParams& p);   // k_gemm.hip: M >= 20, bf16 activations, int4/int8 codes, group % 64 == 0
 uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus);
 // k_gemm128.hip: 128 x 128 tiles, M >= 128, group 64 / 128 / 256; `workspace` holds the activation row-sum pieces (+ split-K partials)
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus);

@@ -173,6 +173,12 @@ class HipModel:
         self._tree_size = int(token_ids.size)
         return sampled
 
+    @property
+    def verify_gpu_ms(self) -> float:
+        out = C.c_float()
+        call("uzu_hip_model_verify_gpu_ms", self._h, C.byref(out))
+        return out.value
+
     def accept(self, indices):
         """encode_accept with a root path of the pending tree (FlatTrie.accept)."""
         indices = np.ascontiguousarray(indices, dtype=np.uint32)
