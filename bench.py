@@ -403,7 +403,7 @@ def main():
     # fixture's after the timed region (ids only: the oracle is not imported or executed here).
     fixture = stream_offset = None
     fx_path = os.path.join(ROOT, "tests", "golden", "bench_qwen_stream.json")
-    if args.config == "c2" and args.model == "qwen3.5-0.8b" and not args.model_dir and not args.bits and os.path.exists(fx_path):
+    if args.config == "c2" and args.model == "qwen3.5-0.8b" and not args.model_dir and not args.bits and args.context == 2048 and os.path.exists(fx_path):
         fx = json.load(open(fx_path))
         if fx["preset"] == args.model and fx["seed"] == cfg.seed and fx["bits"] == cfg.bits and abs(fx["logit_row_sigma"] - cfg.logit_row_sigma) < 1e-12:
             fixture = fx

@@ -430,8 +430,10 @@ def test_bench_config_whole_chained_stream_equals_the_oracle_in_production_mode(
     (tests/golden/bench_qwen_stream.json, generator make_bench_stream.py; bench.py compares its own run with the same file and reports
     "parity").  The prompt is a variant picked by outcome (tools/stream_search.py; profiles/r4_stream_search.txt says why no margin
     threshold can pick one); the stream is varied (>= 12 distinct tokens).  Teacher-forced on top: the oracle's top-8 logits matched
-    within 0.25 sigma (row-normalised) at every step, and at every step the measured error of the two leading logits is below the
-    oracle's margin (printed: the worst step's slack)."""
+    within 0.25 sigma (row-normalised) at every step and the arg-max is the oracle's token at every step (printed: the smallest margin
+    between the oracle's two leading tokens as the PRODUCTION logits see it, in the fixture's units).  Should a kernel change that
+    reorders a sum move a token across one of the small margins, re-run tools/stream_search.py (two GPU-minutes) and
+    tests/golden/make_bench_stream.py for a new prompt variant -- do not loosen the assertion."""
     path = os.path.join(GOLDEN, "bench_qwen_stream.json")
     if not os.path.exists(path):
         pytest.fail("tests/golden/bench_qwen_stream.json is missing: run python tests/golden/make_bench_stream.py <variant>")
@@ -464,9 +466,10 @@ def test_bench_config_whole_chained_stream_equals_the_oracle_in_production_mode(
         worst = max(worst, max(errs.values()))
         assert int(np.argmax(lg)) == r["token"]
         best, runner = r["top8"][0][0], r["top8"][1][0]
-        band = (errs[best] * row_mult[best] + errs[runner] * row_mult[runner]) / (row_mult[best] + row_mult[runner])  # in the margin's units
-        min_slack = min(min_slack, r["margin"] - band)
-    print(f"bench stream: {len(want)} tokens identical ({len(set(want))} distinct), top-8 logits within {worst:.3f} sigma, oracle margin - measured error >= {min_slack:.4f} at every step")
+        min_slack = min(min_slack, (lg[best] - lg[runner]) / (sigma * (row_mult[best] + row_mult[runner])))
+    assert min_slack > 0.0
+    print(f"bench stream: {len(want)} tokens identical ({len(set(want))} distinct), top-8 logits within {worst:.3f} sigma; smallest margin between the oracle's two "
+          f"leading tokens: {fx['min_margin']:.4f} in the oracle, {min_slack:.4f} in production")
     hm.close()
 
 

@@ -413,6 +413,24 @@ def test_p2p_failure_reaches_every_rank(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--no-graph"]])
+def test_bench_tensor_parallel_dry_run_two_ranks_one_gpu(extra):
+    """`bench.py --gpus 2 --share-gpu`: the multi-rank code path of the benchmark itself -- rank spawn on 127.0.0.1, gloo rendezvous, shard
+    planner, hipIpc mailboxes, the TP decode step replayed as a hipGraph (default) and launched eagerly (--no-graph), max-over-ranks timing,
+    ONE JSON line from rank 0 -- on the one GPU of the test box (both ranks on device 0; a plumbing run, not a scaling point: the line says
+    so).  Every rank must have committed the same tokens."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "1", "--context", "96", "--no-cpu-baseline"] + extra
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["physical_gpus"] == 1 and line["steps"] == 4 and line["scaling"] == "strong"
+    assert line["all_ranks_tokens_agree"] is True
+    assert line["config"]["graph"] == ("--no-graph" not in extra)
+    assert line["tp"]["all_reduces_per_token"] >= 2 * 24 and line["value"] > 0
+
+
 # ------------------------------------------------------------------------------------------------ N ranks on ONE GPU
 TP_CASES = [
     # (preset, kwargs, prompt_len, steps, logit tolerance in sigma, near-tie gap)
