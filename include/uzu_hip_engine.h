@@ -129,8 +129,9 @@ uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
  * (transformer.rs:247), attention under the trie mask (mask.rs:21-29; the nodes' K / V rows go behind the cache's logical end),
  * Gated DeltaNet layers through ConvTreeScan + tree prep + DeltaNetTreeVerify (encodable_block/mixer/delta_net.rs:334-437,
  * cpu/kernel/gdn/tree_verify/*.rs) with their Tree suffix status kept for the accept, output norm + read-out + greedy sampling of EVERY
- * node (sampled_out[tree_size]).  At most 32 nodes per pass (the reference speculates <= 16).  Greedy sampling, full KV caches (no
- * sliding-window ring), single GPU.
+ * node (sampled_out[tree_size]; greedy, or with uzu_hip_model_set_sampling the node's own seed PRng::derive(context + height),
+ * speculators/dflash_tfm.rs:267,304).  At most 32 nodes per pass (the reference speculates <= 16).  Full and ring (sliding-window) KV
+ * states; single GPU (not on a tensor-parallel shard).
  *
  * uzu_hip_model_accept: TransformerState::encode_accept with the accepted root path (FlatTrie::accept, trie.rs:271-305; the host mirror
  * is uzu_amd/trie.py): KV rows of the accepted nodes compacted to context .. context + count - 1 (mixer/attention/state.rs:174-198),

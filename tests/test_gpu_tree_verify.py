@@ -233,6 +233,68 @@ def test_engine_verify_then_accept_matches_the_oracle_and_linear_decoding(hip_ct
     om.close()
 
 
+def test_engine_verify_and_accept_on_ring_kv_states(hip_ctx):
+    """Sliding-window layers (AttentionStateType::Ring, state.rs:16-55, 200-219) under speculation: the tree's rows sit behind the ring
+    during the pass (trie mask + window on positions), the accepted ones enter the ring slot by slot.  A window of 40 with a 37-token
+    prompt wraps during the second round.  Against the oracle model round by round, then plain decoding continues identically."""
+    cfg = S.tiny_llama(sliding_windows=[40, 0], sinks=True, seed=48)
+    bundle = S.build_model(cfg)
+    prompt = ((S.synthetic_prompt(37, cfg.vocab_size).astype(np.int64) * 191 + 2101) % cfg.vocab_size).astype(np.uint32)
+    om = O.OracleModel(bundle)
+    want, _ = linear_stream(om, prompt, 20)
+    om.reset()
+    om.prefill(prompt)
+    hm = HipModel(hip_ctx, bundle)
+    got = [hm.prefill(prompt)]
+    for rnd in range(3):
+        flat = speculative_tree(got[-1], want, len(got) - 1, 4, cfg.vocab_size).linearize()
+        o_sampled = om.verify_tree(flat.token_ids(), flat.nodes())
+        h_sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+        o_acc, h_acc = flat.accept(o_sampled), flat.accept(h_sampled)
+        assert h_acc == o_acc, f"round {rnd}: oracle accepts {o_acc}, hip {h_acc}"
+        om.accept([i for i, _, _ in o_acc])
+        hm.accept([i for i, _, _ in h_acc])
+        got.extend(int(s_) for _, _, s_ in h_acc)
+    toks, _ = hm.decode(4)
+    tok = got[-1]
+    for t in toks:
+        tok = om.forward([tok])
+        assert int(t) == tok
+    hm.close()
+    om.close()
+
+
+def test_engine_tree_pass_with_stochastic_sampling_uses_each_nodes_own_seed(hip_ctx):
+    """SamplingMethod::Stochastic over a tree: node i draws with PRng::derive(context + height_i) (speculators/dflash_tfm.rs:267,304), i.e.
+    exactly the seed plain decoding uses at that position -- checked per node against the CPU restatement of UnifiedSampling applied to
+    the pass's own logits of that node."""
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(21, cfg.vocab_size)
+    hm = HipModel(hip_ctx, bundle)
+    seed = 0x1234567
+    hm.set_sampling(seed=seed, temperature=25.0, top_k=40)
+    tok = hm.prefill(prompt)
+    root = TrieNode(tok)
+    a, b = TrieNode(5), TrieNode(9)
+    root.add(a), root.add(b)
+    a.add(TrieNode(11)), b.add(TrieNode(13))
+    flat = root.linearize()
+    sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+    logits = hm.read_tree_logits()
+    from test_gpu_model import prng_derive
+    ctx_len = len(prompt)
+    for i, node in enumerate(flat.nodes()):
+        want = np.zeros(1, np.uint32)
+        seeds = np.array([prng_derive(seed, ctx_len + int(node[2]))], np.uint64)
+        O.lib().orc_unified_sampling(O.p(np.ascontiguousarray(logits[i])), O.BF16, O.p(want), O.p(seeds), None, 1, C.c_float(25.0), 1, 40, 0, C.c_float(0.0), 0, C.c_float(0.0),
+                                     cfg.vocab_size, 1)
+        assert int(sampled[i]) == int(want[0]), f"node {i} (height {node[2]}): {sampled[i]} != {want[0]}"
+    assert len(set(int(t) for t in sampled)) > 1
+    hm.accept([0])
+    hm.close()
+
+
 @pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
 def test_engine_tree_pass_is_bit_identical_to_the_oracle_in_reference_order_mode(hip_ctx, preset):
     """uzu_hip_set_exact(1): the whole tree pass -- trie-masked attention at positions context + height, ConvTreeScan, tree prep,

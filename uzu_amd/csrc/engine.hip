@@ -172,6 +172,8 @@ struct uzu_hip_model {
         uint16_t* normed = nullptr;     // bf16 [nodes, model_dim]: output norm of every node
         uint16_t* logits = nullptr;     // bf16 [nodes, vocab rows of this rank]
         void* argmax_scratch = nullptr;
+        uint64_t* d_seeds = nullptr;    // [kDnTreeMaxNodes] per-node sampling seeds (stochastic sampling)
+        void* sampling_scratch = nullptr;
         bool allocated = false;
         bool active = false;            // the forward pass being encoded is a tree pass
         float last_gpu_ms = 0.f;        // device time of the last tree pass (events around the launches / the graph replay)
@@ -189,6 +191,7 @@ struct uzu_hip_model {
             uint32_t launches;
         };
         std::vector<Graph> graphs;
+        uint32_t graph_epoch = 0; // sampling_epoch the graphs were captured under
     } tree;
 
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
@@ -847,7 +850,14 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         linear(e, ro, m->tree.normed, m->tree.logits, count);
         if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
             RUN("logit_transform", 0, k::logit_transform(s, m->tree.logits, UZU_BF16, ro.n * count, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
-        RUN("argmax", (size_t)ro.n * 2 * count, k::argmax(s, m->tree.logits, UZU_BF16, m->tree.d_sampled, ro.n, count, m->tree.argmax_scratch));
+        if (m->sampling.on) { // every node draws with the seed of ITS position: PRng::derive(context + height) (dflash_tfm.rs:267,304)
+            RUN("derive_tree_seeds", 0, k::derive_tree_seeds(s, m->sampling.seed, m->d_ctx_len, m->tree.d_trie, count, m->tree.d_seeds));
+            k::UnifiedSamplingParams sp = m->sampling.p;
+            sp.logits = m->tree.logits, sp.dt = UZU_BF16, sp.output = m->tree.d_sampled, sp.seeds = m->tree.d_seeds, sp.vocab_size = ro.n, sp.batch_size = count;
+            RUN("unified_sampling", (size_t)ro.n * 2 * count, k::unified_sampling(s, sp, m->tree.sampling_scratch));
+        } else {
+            RUN("argmax", (size_t)ro.n * 2 * count, k::argmax(s, m->tree.logits, UZU_BF16, m->tree.d_sampled, ro.n, count, m->tree.argmax_scratch));
+        }
         if (e.st != UZU_OK) return e.st;
         hipError_t terr = hipGetLastError();
         if (terr != hipSuccess) {
@@ -1675,6 +1685,10 @@ static uzu_status ensure_tree(uzu_hip_model* m) {
     m->tree.logits = (uint16_t*)p;
     UZU_PROPAGATE(dev_alloc(m, k::argmax_scratch_bytes(N), &p));
     m->tree.argmax_scratch = p; // the arg-max partials of N rows
+    UZU_PROPAGATE(dev_alloc(m, (size_t)N * 8, &p));
+    m->tree.d_seeds = (uint64_t*)p;
+    UZU_PROPAGATE(dev_alloc(m, k::unified_sampling_scratch_bytes(N), &p));
+    m->tree.sampling_scratch = p;
     m->tree.allocated = true;
     return UZU_OK;
 }
@@ -1688,13 +1702,10 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
     (void)hipSetDevice(m->ctx->device);
     UZU_UNSUPPORTED(tree_size > k::kDnTreeMaxNodes, "model_verify_tree: %u nodes (at most %u per pass)", tree_size, k::kDnTreeMaxNodes);
     UZU_UNSUPPORTED(m->tp != nullptr, "model_verify_tree: speculative verification on a tensor-parallel shard is not implemented");
-    UZU_UNSUPPORTED(m->sampling.on, "model_verify_tree: stochastic sampling over a tree (per-node seeds) is not implemented: greedy only");
     UZU_REQUIRE(m->tree.size == 0, "model_verify_tree: a speculated tree is already pending (accept it first)");
     UZU_REQUIRE(m->context_length > 0, "model_verify_tree: prefill first");
     UZU_REQUIRE(m->context_length + tree_size <= m->d.max_context_length, "model_verify_tree: %u + %u tokens exceed max_context_length %u", m->context_length, tree_size,
                 m->d.max_context_length);
-    for (auto& L : m->layers)
-        UZU_UNSUPPORTED(L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.sliding_window_size, "model_verify_tree: ring (sliding-window) KV states are not supported");
     // BatchTopology::new (batch_topology.rs:11-37): parents from the heights of the DFS order; also validates the nodes
     std::vector<int32_t> parents(tree_size);
     {
@@ -1735,6 +1746,10 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
         UZU_PROPAGATE(st);
     } else {
         hipGraphExec_t exec = nullptr;
+        if (m->tree.graph_epoch != m->sampling_epoch) { // the captured passes bake the sampling kernels in
+            drop_tree_graphs(m, nullptr);
+            m->tree.graph_epoch = m->sampling_epoch;
+        }
         for (auto& g : m->tree.graphs)
             if (g.state == m->bound && g.nodes == tree_size && g.two_pass == two_pass_regime) exec = g.exec, m->launches = g.launches;
         if (!exec) {
@@ -1787,7 +1802,14 @@ uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indic
         if (accepted_indices[i] != i) copies.push_back({m->context_length + accepted_indices[i], m->context_length + i});
     for (size_t l = 0; l < m->layers.size(); ++l) {
         DLayer& L = m->layers[l];
-        if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.sliding_window_size) {
+            // AttentionStateType::Ring (state.rs:200-219): the accepted suffix rows (behind the ring, at window + index) enter the ring one by
+            // one; with n tokens accepted so far the next slot is n mod window (what the offset / length bookkeeping amounts to)
+            const uint32_t W = L.d.sliding_window_size;
+            std::vector<uzu_kv_copy> ring(count);
+            for (uint32_t i = 0; i < count; ++i) ring[i] = {W + accepted_indices[i], (m->context_length + i) % W};
+            RUN("kv_cache_update", 0, k::kv_cache_update(s, L.keys, L.values, UZU_BF16, ring.data(), count, L.d.num_groups * L.d.head_dim));
+        } else if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
             if (!copies.empty()) RUN("kv_cache_update", 0, k::kv_cache_update(s, L.keys, L.values, UZU_BF16, copies.data(), (uint32_t)copies.size(), L.d.num_groups * L.d.head_dim));
         } else {
             const auto& T = m->tree.layers[l];

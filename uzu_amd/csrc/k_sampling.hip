@@ -335,6 +335,23 @@ uzu_status unified_sampling(hipStream_t s, const UnifiedSamplingParams& p, void*
     return launch_check([&] { hipLaunchKernelGGL(sample_plain_pass2, dim3(p.batch_size), dim3(256), 0, s, pv, pi, parts, p.output); }, "unified_sampling[pass2]");
 }
 
+// a speculated tree: node i samples with PRng::derive(root position + height_i) (speculators/dflash_tfm.rs:267,304; trie.rs:147-151)
+__global__ void derive_tree_seeds_kernel(uint64_t base, const uint32_t* position, const uint32_t* trie, uint32_t nodes, uint64_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes) return;
+    uint64_t hash = base + (uint64_t)(*position + trie[3 * i + 2]);
+    hash ^= hash >> 33;
+    hash *= 0xff51afd7ed558ccdull;
+    hash ^= hash >> 33;
+    hash *= 0xc4ceb9fe1a85ec53ull;
+    hash ^= hash >> 33;
+    out[i] = hash;
+}
+uzu_status derive_tree_seeds(hipStream_t s, uint64_t base, const uint32_t* position, const uint32_t* trie, uint32_t nodes, uint64_t* out) {
+    if (!nodes) return UZU_OK;
+    return launch_check([&] { hipLaunchKernelGGL(derive_tree_seeds_kernel, dim3((nodes + 63) / 64), dim3(64), 0, s, base, position, trie, nodes, out); }, "derive_tree_seeds");
+}
+
 uzu_status derive_seed(hipStream_t s, uint64_t base, const uint32_t* position, uint32_t offset, uint64_t* out) {
     return launch_check([&] { hipLaunchKernelGGL(derive_seed_kernel, dim3(1), dim3(1), 0, s, base, position, offset, out); }, "derive_seed");
 }

@@ -201,6 +201,8 @@ struct UnifiedSamplingParams {
 uzu_status unified_sampling(hipStream_t s, const UnifiedSamplingParams& p, void* scratch);
 // PRng::derive (sampling/prng.rs): *out = finaliser(base + *position + offset)
 uzu_status derive_seed(hipStream_t s, uint64_t base, const uint32_t* position, uint32_t offset, uint64_t* out);
+// seeds of the nodes of a speculated tree: out[i] = PRng(base).derive(*position + height_i)
+uzu_status derive_tree_seeds(hipStream_t s, uint64_t base, const uint32_t* position, const uint32_t* trie, uint32_t nodes, uint64_t* out);
 size_t unified_sampling_scratch_bytes(uint32_t batch_size);
 
 // ---------------------------------------------------------------- gated delta net
