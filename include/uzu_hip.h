@@ -423,6 +423,33 @@ uzu_status uzu_hip_state_advance_create(uzu_hip_context* ctx, uint32_t t, uint32
 uzu_status uzu_hip_state_advance_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf k_norm, uzu_buf v, uzu_buf log_decay, uzu_buf beta,
                                         uzu_buf accepted_indices, uzu_buf state, uint32_t accepted_len);
 
+/* ---- the tree speculators' kernels (speculators/dflash_tfm.rs, encodable_block/weaver_*.rs drive them; the drafter MODELS are out of scope) ----
+ * AncestorAttentionKernel::{new(context, HEAD_DIM = 128, num_heads), encode}  (cpu/kernel/attention/ancestor_attention.rs:8-139): per row (a node
+ * of the drafter's tree) half-rotation RoPE of q / k at position depth + 1, attention over the prefix rows + the node's ancestors' slots + the
+ * node itself, then the node's rotated key / value go to its node_kv slot.  prefix_kv bf16: keys [prefix, model_dim] then values; node_kv bf16:
+ * keys [capacity, model_dim] then values; current_qkv bf16 [rows, 3 model_dim]; cosines / sines f32 [max_depth + 1, head_dim]; node_metadata u32
+ * [MetadataIdx::COUNT, rows].  A row may attend to the slot of an EARLIER row of the same call (the reference's row-by-row order), never a later one.
+ * WeaverFrontierSelect / WeaverFrontierInsertChildren / WeaverTopChildren  (cpu/kernel/weaver/ *.rs; layouts: gpu_types/weaver.rs -- field f of
+ * slot s at [f * capacity + s]): bit-identical to the CPU kernels; shapes outside the reference kernels' own guards are no-ops, as there. */
+uzu_status uzu_hip_ancestor_attention_create(uzu_hip_context* ctx, uint32_t head_dim, uint32_t num_heads, uzu_hip_kernel** out);
+uzu_status uzu_hip_ancestor_attention_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf prefix_kv, uzu_buf node_kv, uzu_buf current_qkv, uzu_buf cosines, uzu_buf sines,
+                                             uzu_buf node_metadata, uzu_buf ancestor_indices, uzu_buf ancestor_counts, uzu_buf node_indices, uzu_buf output, uint32_t rows,
+                                             uint32_t prefix_length, uint32_t ancestor_stride, uint32_t node_capacity, uint32_t max_depth, float scale);
+uzu_status uzu_hip_weaver_frontier_select_create(uzu_hip_context* ctx, uzu_hip_kernel** out);
+uzu_status uzu_hip_weaver_frontier_select_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf frontier, uzu_buf packed_tree, uzu_buf slot_ancestors, uzu_buf node_token_ids,
+                                                 uzu_buf node_metadata, uzu_buf node_ancestor_indices, uzu_buf node_valid, uzu_buf candidate_pool_ids,
+                                                 uzu_buf candidate_pool_logits, uzu_buf node_candidate_ids, uzu_buf node_candidate_logits, uint32_t frontier_capacity,
+                                                 uint32_t tree_slot_count, uint32_t node_count, uint32_t batch_start_slot, uint32_t ancestor_stride, uint32_t max_depth,
+                                                 uint32_t lookahead_count, uint32_t candidate_depth_count, uint32_t candidates_per_depth);
+uzu_status uzu_hip_weaver_frontier_insert_children_create(uzu_hip_context* ctx, uzu_hip_kernel** out);
+uzu_status uzu_hip_weaver_frontier_insert_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf packed_tree, uzu_buf node_metadata, uzu_buf node_valid,
+                                                          uzu_buf child_ids, uzu_buf child_logprobs, uzu_buf frontier, uint32_t frontier_capacity, uint32_t tree_slot_count,
+                                                          uint32_t node_count, uint32_t expand_width);
+uzu_status uzu_hip_weaver_top_children_create(uzu_hip_context* ctx, uzu_hip_kernel** out);
+uzu_status uzu_hip_weaver_top_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf residual_logits, uzu_buf candidate_logits, uzu_buf candidate_ids,
+                                              uzu_buf depth_seeds, uzu_buf node_metadata, uzu_buf output_token_ids, uzu_buf output_model_logprobs, uint32_t rows,
+                                              uint32_t candidates, uint32_t expand_width, uint32_t vocab_size);
+
 #ifdef __cplusplus
 }
 #endif

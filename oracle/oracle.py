@@ -20,7 +20,7 @@ BF16, F32 = 0, 2
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("uzu_oracle_kernels.c", "uzu_oracle_tree_verify.c", "uzu_oracle_model.c", "uzu_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("uzu_oracle_kernels.c", "uzu_oracle_tree_verify.c", "uzu_oracle_speculator.c", "uzu_oracle_model.c", "uzu_oracle.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "uzu_model_desc.h"))
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)

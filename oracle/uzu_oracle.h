@@ -230,6 +230,24 @@ void orc_build_tree_out(const void* q, uint32_t qk_dt, const float* prefix, cons
 void orc_state_advance(const void* k_norm, const void* v, uint32_t dt, const float* log_decay_buf, const float* beta_buf, const uint32_t* accepted_indices,
                        float* state, uint32_t accepted_len, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim);
 
+/* ---- the tree speculators' kernels (cpu/kernel/attention/ancestor_attention.rs, cpu/kernel/weaver/*.rs; uzu_oracle_speculator.c);
+ *      structure-of-arrays layouts of backends/common/gpu_types/weaver.rs ---- */
+void orc_ancestor_attention(const uint16_t* prefix_kv, uint16_t* node_kv, const uint16_t* current_qkv, const float* cosines, const float* sines,
+                            const uint32_t* node_metadata, const uint32_t* ancestor_indices, const uint32_t* ancestor_counts, const uint32_t* node_indices,
+                            uint16_t* output, uint32_t rows, uint32_t prefix_length, uint32_t ancestor_stride, uint32_t node_capacity, uint32_t max_depth,
+                            float scale, uint32_t num_heads, uint32_t head_dim);
+void orc_weaver_frontier_select(uint32_t* frontier, uint32_t* packed_tree, uint32_t* slot_ancestors, uint32_t* node_token_ids, uint32_t* node_metadata,
+                                uint32_t* node_ancestor_indices, uint32_t* node_valid, const uint32_t* candidate_pool_ids, const float* candidate_pool_logits,
+                                uint32_t* node_candidate_ids, float* node_candidate_logits, uint32_t frontier_capacity, uint32_t tree_slot_count,
+                                uint32_t node_count, uint32_t batch_start_slot, uint32_t ancestor_stride, uint32_t max_depth, uint32_t lookahead_count,
+                                uint32_t candidate_depth_count, uint32_t candidates_per_depth);
+void orc_weaver_frontier_insert_children(const uint32_t* packed_tree, const uint32_t* node_metadata, const uint32_t* node_valid, const uint32_t* child_ids,
+                                         const float* child_logprobs, uint32_t* frontier, uint32_t frontier_capacity, uint32_t tree_slot_count,
+                                         uint32_t node_count, uint32_t expand_width);
+void orc_weaver_top_children(const uint16_t* residual_logits, const float* candidate_logits, const uint32_t* candidate_ids, const uint64_t* depth_seeds,
+                             const uint32_t* node_metadata, uint32_t* output_token_ids, float* output_model_logprobs, uint32_t rows, uint32_t candidates,
+                             uint32_t expand_width, uint32_t vocab_size);
+
 /* ---- model driver: Decoder::encode + greedy Sampling + encode_accept
  *      (decoder.rs:138-203, transformer.rs:226-329, transformer_layer.rs:194-238,
  *       engine/language_model/stream/stream.rs:190-345,593-751) ---- */

@@ -585,3 +585,43 @@ class StateAdvanceKernel(_Kernel):
 
     def encode(self, k_norm, v, log_decay, beta, accepted_indices, state, accepted_len, encoder):
         self._enc(encoder, _buf(k_norm), _buf(v), _buf(log_decay), _buf(beta), _buf(accepted_indices), _buf(state), _u(accepted_len))
+
+
+# ---- the tree speculators' kernels (cpu/kernel/attention/ancestor_attention.rs, cpu/kernel/weaver/*.rs) ----
+class AncestorAttentionKernel(_Kernel):
+    """new(context, HEAD_DIM, num_heads)"""
+    _create, _encode = "uzu_hip_ancestor_attention_create", "uzu_hip_ancestor_attention_encode"
+
+    def encode(self, prefix_kv, node_kv, current_qkv, cosines, sines, node_metadata, ancestor_indices, ancestor_counts, node_indices, output, rows, prefix_length,
+               ancestor_stride, node_capacity, max_depth, scale, encoder):
+        self._enc(encoder, _buf(prefix_kv), _buf(node_kv), _buf(current_qkv), _buf(cosines), _buf(sines), _buf(node_metadata), _buf(ancestor_indices), _buf(ancestor_counts),
+                  _buf(node_indices), _buf(output), _u(rows), _u(prefix_length), _u(ancestor_stride), _u(node_capacity), _u(max_depth), _f(scale))
+
+
+class WeaverFrontierSelectKernel(_Kernel):
+    _create, _encode = "uzu_hip_weaver_frontier_select_create", "uzu_hip_weaver_frontier_select_encode"
+
+    def encode(self, frontier, packed_tree, slot_ancestors, node_token_ids, node_metadata, node_ancestor_indices, node_valid, candidate_pool_ids, candidate_pool_logits,
+               node_candidate_ids, node_candidate_logits, frontier_capacity, tree_slot_count, node_count, batch_start_slot, ancestor_stride, max_depth, lookahead_count,
+               candidate_depth_count, candidates_per_depth, encoder):
+        self._enc(encoder, *[_buf(b) for b in (frontier, packed_tree, slot_ancestors, node_token_ids, node_metadata, node_ancestor_indices, node_valid, candidate_pool_ids,
+                                               candidate_pool_logits, node_candidate_ids, node_candidate_logits)],
+                  *[_u(v) for v in (frontier_capacity, tree_slot_count, node_count, batch_start_slot, ancestor_stride, max_depth, lookahead_count, candidate_depth_count,
+                                    candidates_per_depth)])
+
+
+class WeaverFrontierInsertChildrenKernel(_Kernel):
+    _create, _encode = "uzu_hip_weaver_frontier_insert_children_create", "uzu_hip_weaver_frontier_insert_children_encode"
+
+    def encode(self, packed_tree, node_metadata, node_valid, child_ids, child_logprobs, frontier, frontier_capacity, tree_slot_count, node_count, expand_width, encoder):
+        self._enc(encoder, *[_buf(b) for b in (packed_tree, node_metadata, node_valid, child_ids, child_logprobs, frontier)],
+                  *[_u(v) for v in (frontier_capacity, tree_slot_count, node_count, expand_width)])
+
+
+class WeaverTopChildrenKernel(_Kernel):
+    _create, _encode = "uzu_hip_weaver_top_children_create", "uzu_hip_weaver_top_children_encode"
+
+    def encode(self, residual_logits, candidate_logits, candidate_ids, depth_seeds, node_metadata, output_token_ids, output_model_logprobs, rows, candidates, expand_width,
+               vocab_size, encoder):
+        self._enc(encoder, *[_buf(b) for b in (residual_logits, candidate_logits, candidate_ids, depth_seeds, node_metadata, output_token_ids, output_model_logprobs)],
+                  *[_u(v) for v in (rows, candidates, expand_width, vocab_size)])

@@ -16,7 +16,7 @@ enum KernelKind : uint32_t {
     KK_ATTENTION_TWO_PASS2, KK_ATTENTION_GEMM, KK_ACTIVATION_TRANSFORM, KK_KV_CACHE_UPDATE, KK_SIGMOID_GATE, KK_GATED_ACT_MUL, KK_QUANT_EMBEDDING, KK_FP_EMBEDDING,
     KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
     KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
-    KK_CONV_TREE_SCAN, KK_DN_TREE_VERIFY, KK_STATE_ADVANCE,
+    KK_CONV_TREE_SCAN, KK_DN_TREE_VERIFY, KK_STATE_ADVANCE, KK_ANCESTOR_ATTENTION, KK_WEAVER_SELECT, KK_WEAVER_INSERT, KK_WEAVER_TOP_CHILDREN,
 };
 
 bool is_float_dt(uint32_t dt) { return dt == UZU_BF16 || dt == UZU_F32; }
@@ -872,6 +872,70 @@ uzu_status uzu_hip_state_advance_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, u
     UZU_REQUIRE(k_norm.buffer && v.buffer && log_decay.buffer && beta.buffer && accepted_indices.buffer && state.buffer, "state_advance: null buffer");
     return k::delta_net_state_advance(cb_stream(cb), (const uint16_t*)bptr(k_norm), (const uint16_t*)bptr(v), (const float*)bptr(log_decay), (const float*)bptr(beta),
                                       (const uint32_t*)bptr(accepted_indices), (float*)bptr(state), accepted_len, k->f[0], k->f[1], 128);
+}
+
+// ---- the tree speculators' kernels (cpu/kernel/attention/ancestor_attention.rs, cpu/kernel/weaver/*.rs; csrc/k_speculator.hip) ----
+uzu_status uzu_hip_ancestor_attention_create(uzu_hip_context* ctx, uint32_t head_dim, uint32_t num_heads, uzu_hip_kernel** out) {
+    UZU_UNSUPPORTED(head_dim != 128, "ancestor_attention: variants are HEAD_DIM = 128");
+    UZU_REQUIRE(num_heads > 0, "ancestor_attention: num_heads must be positive");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_ANCESTOR_ATTENTION, out, &k));
+    k->f[0] = head_dim, k->f[1] = num_heads;
+    return UZU_OK;
+}
+uzu_status uzu_hip_ancestor_attention_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf prefix_kv, uzu_buf node_kv, uzu_buf current_qkv, uzu_buf cosines, uzu_buf sines,
+                                             uzu_buf node_metadata, uzu_buf ancestor_indices, uzu_buf ancestor_counts, uzu_buf node_indices, uzu_buf output, uint32_t rows,
+                                             uint32_t prefix_length, uint32_t ancestor_stride, uint32_t node_capacity, uint32_t max_depth, float scale) {
+    UZU_PROPAGATE(check(k, KK_ANCESTOR_ATTENTION, cb));
+    UZU_REQUIRE((prefix_kv.buffer || !prefix_length) && node_kv.buffer && current_qkv.buffer && cosines.buffer && sines.buffer && node_metadata.buffer && ancestor_indices.buffer &&
+                    ancestor_counts.buffer && node_indices.buffer && output.buffer, "ancestor_attention: null buffer");
+    return k::ancestor_attention(cb_stream(cb), (const uint16_t*)bptr(prefix_kv), (uint16_t*)bptr(node_kv), (const uint16_t*)bptr(current_qkv), (const float*)bptr(cosines),
+                                 (const float*)bptr(sines), (const uint32_t*)bptr(node_metadata), (const uint32_t*)bptr(ancestor_indices), (const uint32_t*)bptr(ancestor_counts),
+                                 (const uint32_t*)bptr(node_indices), (uint16_t*)bptr(output), rows, prefix_length, ancestor_stride, node_capacity, max_depth, scale, k->f[1], k->f[0]);
+}
+uzu_status uzu_hip_weaver_frontier_select_create(uzu_hip_context* ctx, uzu_hip_kernel** out) {
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_WEAVER_SELECT, out, &k);
+}
+uzu_status uzu_hip_weaver_frontier_select_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf frontier, uzu_buf packed_tree, uzu_buf slot_ancestors, uzu_buf node_token_ids,
+                                                 uzu_buf node_metadata, uzu_buf node_ancestor_indices, uzu_buf node_valid, uzu_buf candidate_pool_ids, uzu_buf candidate_pool_logits,
+                                                 uzu_buf node_candidate_ids, uzu_buf node_candidate_logits, uint32_t frontier_capacity, uint32_t tree_slot_count, uint32_t node_count,
+                                                 uint32_t batch_start_slot, uint32_t ancestor_stride, uint32_t max_depth, uint32_t lookahead_count, uint32_t candidate_depth_count,
+                                                 uint32_t candidates_per_depth) {
+    UZU_PROPAGATE(check(k, KK_WEAVER_SELECT, cb));
+    UZU_REQUIRE(frontier.buffer && packed_tree.buffer && slot_ancestors.buffer && node_token_ids.buffer && node_metadata.buffer && node_ancestor_indices.buffer && node_valid.buffer &&
+                    candidate_pool_ids.buffer && candidate_pool_logits.buffer && node_candidate_ids.buffer && node_candidate_logits.buffer, "weaver_frontier_select: null buffer");
+    return k::weaver_frontier_select(cb_stream(cb), (uint32_t*)bptr(frontier), (uint32_t*)bptr(packed_tree), (uint32_t*)bptr(slot_ancestors), (uint32_t*)bptr(node_token_ids),
+                                     (uint32_t*)bptr(node_metadata), (uint32_t*)bptr(node_ancestor_indices), (uint32_t*)bptr(node_valid), (const uint32_t*)bptr(candidate_pool_ids),
+                                     (const float*)bptr(candidate_pool_logits), (uint32_t*)bptr(node_candidate_ids), (float*)bptr(node_candidate_logits), frontier_capacity,
+                                     tree_slot_count, node_count, batch_start_slot, ancestor_stride, max_depth, lookahead_count, candidate_depth_count, candidates_per_depth);
+}
+uzu_status uzu_hip_weaver_frontier_insert_children_create(uzu_hip_context* ctx, uzu_hip_kernel** out) {
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_WEAVER_INSERT, out, &k);
+}
+uzu_status uzu_hip_weaver_frontier_insert_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf packed_tree, uzu_buf node_metadata, uzu_buf node_valid, uzu_buf child_ids,
+                                                          uzu_buf child_logprobs, uzu_buf frontier, uint32_t frontier_capacity, uint32_t tree_slot_count, uint32_t node_count,
+                                                          uint32_t expand_width) {
+    UZU_PROPAGATE(check(k, KK_WEAVER_INSERT, cb));
+    UZU_REQUIRE(packed_tree.buffer && node_metadata.buffer && node_valid.buffer && child_ids.buffer && child_logprobs.buffer && frontier.buffer, "weaver_frontier_insert_children: null buffer");
+    return k::weaver_frontier_insert_children(cb_stream(cb), (const uint32_t*)bptr(packed_tree), (const uint32_t*)bptr(node_metadata), (const uint32_t*)bptr(node_valid),
+                                              (const uint32_t*)bptr(child_ids), (const float*)bptr(child_logprobs), (uint32_t*)bptr(frontier), frontier_capacity, tree_slot_count,
+                                              node_count, expand_width);
+}
+uzu_status uzu_hip_weaver_top_children_create(uzu_hip_context* ctx, uzu_hip_kernel** out) {
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_WEAVER_TOP_CHILDREN, out, &k);
+}
+uzu_status uzu_hip_weaver_top_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf residual_logits, uzu_buf candidate_logits, uzu_buf candidate_ids, uzu_buf depth_seeds,
+                                              uzu_buf node_metadata, uzu_buf output_token_ids, uzu_buf output_model_logprobs, uint32_t rows, uint32_t candidates,
+                                              uint32_t expand_width, uint32_t vocab_size) {
+    UZU_PROPAGATE(check(k, KK_WEAVER_TOP_CHILDREN, cb));
+    UZU_REQUIRE(residual_logits.buffer && candidate_logits.buffer && candidate_ids.buffer && depth_seeds.buffer && node_metadata.buffer && output_token_ids.buffer &&
+                    output_model_logprobs.buffer, "weaver_top_children: null buffer");
+    return k::weaver_top_children(cb_stream(cb), (const uint16_t*)bptr(residual_logits), (const float*)bptr(candidate_logits), (const uint32_t*)bptr(candidate_ids),
+                                  (const uint64_t*)bptr(depth_seeds), (const uint32_t*)bptr(node_metadata), (uint32_t*)bptr(output_token_ids), (float*)bptr(output_model_logprobs),
+                                  rows, candidates, expand_width, vocab_size);
 }
 
 } // extern "C"

@@ -254,6 +254,22 @@ uzu_status attention_two_pass2_exact(hipStream_t s, const float* partials, const
                                      uint32_t suffix_length);
 uzu_status delta_net_update_exact(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, const float* norm_weight, float* state, uint16_t* out,
                                   uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, float norm_epsilon);
+// ---- the tree speculators' kernels (k_speculator.hip; cpu/kernel/attention/ancestor_attention.rs, cpu/kernel/weaver/*.rs) ----
+uzu_status ancestor_attention(hipStream_t s, const uint16_t* prefix_kv, uint16_t* node_kv, const uint16_t* current_qkv, const float* cosines, const float* sines,
+                              const uint32_t* node_metadata, const uint32_t* ancestor_indices, const uint32_t* ancestor_counts, const uint32_t* node_indices,
+                              uint16_t* output, uint32_t rows, uint32_t prefix_length, uint32_t ancestor_stride, uint32_t node_capacity, uint32_t max_depth, float scale,
+                              uint32_t num_heads, uint32_t head_dim);
+uzu_status weaver_frontier_select(hipStream_t s, uint32_t* frontier, uint32_t* packed_tree, uint32_t* slot_ancestors, uint32_t* node_token_ids, uint32_t* node_metadata,
+                                  uint32_t* node_ancestor_indices, uint32_t* node_valid, const uint32_t* candidate_pool_ids, const float* candidate_pool_logits,
+                                  uint32_t* node_candidate_ids, float* node_candidate_logits, uint32_t frontier_capacity, uint32_t tree_slot_count, uint32_t node_count,
+                                  uint32_t batch_start_slot, uint32_t ancestor_stride, uint32_t max_depth, uint32_t lookahead_count, uint32_t candidate_depth_count,
+                                  uint32_t candidates_per_depth);
+uzu_status weaver_frontier_insert_children(hipStream_t s, const uint32_t* packed_tree, const uint32_t* node_metadata, const uint32_t* node_valid, const uint32_t* child_ids,
+                                           const float* child_logprobs, uint32_t* frontier, uint32_t frontier_capacity, uint32_t tree_slot_count, uint32_t node_count,
+                                           uint32_t expand_width);
+uzu_status weaver_top_children(hipStream_t s, const uint16_t* residual_logits, const float* candidate_logits, const uint32_t* candidate_ids, const uint64_t* depth_seeds,
+                               const uint32_t* node_metadata, uint32_t* output_token_ids, float* output_model_logprobs, uint32_t rows, uint32_t candidates,
+                               uint32_t expand_width, uint32_t vocab_size);
 // ---- Gated DeltaNet over a speculated token tree (k_deltanet_tree.hip; cpu/kernel/gdn/tree_verify/*.rs, delta_net.rs:334-437) ----
 constexpr uint32_t kDnTreeMaxNodes = 32; // nodes of one verify pass (the reference's stream speculates <= 16: stream.rs:550-554)
 // ConvTreeScan (do_conv) and / or DeltaNetPrefillPrep in its tree instantiation (do_prep: QKT = bf16, log decays, compact v).  in_proj
