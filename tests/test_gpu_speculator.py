@@ -147,7 +147,7 @@ def test_weaver_frontier_insert_children_random_bit_exact(hip_ctx, fc, ts, nc, e
     tree[3] = rng.normal(size=ts).astype(np.float32).view(np.uint32)
     tree[2] = rng.integers(0, 7, ts)
     metadata = np.zeros((3, nc), np.uint32)
-    metadata[2] = rng.integers(0, ts, nc)
+    metadata[2] = rng.permutation(ts)[:nc]  # a tree slot is the parent of one row only (two rows writing one frontier slot would race)
     scores = rng.normal(size=nc * ew).astype(np.float32)
     scores[::7] = -np.inf
     scores[3::11] = 0.0
