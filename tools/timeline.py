@@ -55,9 +55,12 @@ def main():
     print("# fin = reduction + epilogue of the last batch; span = first entry -> last exit")
     print("# attn_dec rows (256 workgroups, no dots-only phase): x = entry -> context length arrived; pro = entry -> q / new k normalised, roped, appended;")
     print("# dots = prologue done -> K / V rows arrived and folded in; fin = merge of the key groups through LDS + partial stores")
-    print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'x':>6} {'pro':>6} {'dots':>6} {'fin':>6} {'exit':>6} {'span':>6}")
+    print("# right of the bar (round 4: the stamps left of it are THREAD 0's): last = entry -> the workgroup's LAST wave done (median); end = first entry -> the last wave")
+    print("# of the last workgroup; gap* = first entry - the previous launch's true end = the kernel boundary proper")
+    print(f"{'#':>3} {'wgs':>5} {'gap':>6} {'ramp':>6} {'x':>6} {'pro':>6} {'dots':>6} {'fin':>6} {'exit':>6} {'span':>6} | {'last':>6} {'end':>6} {'gap*':>6}")
     tot = dict(gap=0.0, span=0.0)
     first = None
+    prev_true_end = None
 
     def med(a):
         return float(np.median(a)) * 0.01
@@ -80,7 +83,13 @@ def main():
         landed = med(e[:, 3] - t0) if (e[:, 3] > 0).all() else nan  # streaming kernels (k_stream.hip): the loader's whole share has landed in LDS
         ex = med(t_end - t0)
         span = (t_end.max() - t0.min()) * 0.01
-        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f}" + (f"   stream: first slot issued {x:.2f}, past the start barrier {med(e[:, 7] - t0):.2f}, share landed {landed:.2f}, consumers done {med(e[:, 5] - t0):.2f}" if landed == landed and (e[:, 7] > 0).all() else ""))
+        # slot 7: when the LAST wave of the workgroup was done (thread 0's stamps say nothing about the other waves)
+        has_last = (e[:, 7] > 0).all()
+        true_end = max(int(e[:, 7].max()), int(t_end.max())) if has_last else int(t_end.max())
+        gap2 = (t0.min() - prev_true_end) * 0.01 if prev_true_end is not None else nan
+        last = med(e[:, 7] - t0) if has_last else nan
+        end = (true_end - int(t0.min())) * 0.01
+        print(f"{i:3d} {int(live.sum()):5d} {gap:6.2f} {ramp:6.2f} {x:6.2f} {pro:6.2f} {dots:6.2f} {fin:6.2f} {ex:6.2f} {span:6.2f} | {last:6.2f} {end:6.2f} {gap2:6.2f}")
         if args.detail and span >= args.detail:
             # who finishes late?  exit times (relative to the first entry) by XCD (workgroup id % 8: dispatch is round-robin over the
             # XCDs) and by position in the grid (quarters of the workgroup-id range: the first workgroups own one batch more)
@@ -99,10 +108,14 @@ def main():
                   f"{np.bincount(cu[late], minlength=32).tolist()}")
         if gap == gap:
             tot["gap"] += gap
+        if gap2 == gap2:
+            tot["gap2"] = tot.get("gap2", 0.0) + gap2
         tot["span"] += span
+        tot["end"] = tot.get("end", 0.0) + end
         prev_end = t_end.max()
+        prev_true_end = true_end
     print(f"# stamped launches: sum of spans {tot['span']:.1f} us, sum of gaps {tot['gap']:.1f} us (gaps include the un-stamped kernels: attn_merge, commit, embedding), "
-          f"first entry -> last exit {(prev_end - first) * 0.01:.1f} us")
+          f"first entry -> last exit {(prev_end - first) * 0.01:.1f} us; to the true ends: {tot.get('end', 0.0):.1f} + {tot.get('gap2', 0.0):.1f} us")
 
 
 if __name__ == "__main__":

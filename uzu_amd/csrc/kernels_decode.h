@@ -24,14 +24,26 @@ struct DecNorm {
 #ifdef UZU_TIMELINE
 #define UZU_TL_FIELD unsigned long long* tl;
 #define UZU_TL_SLOTS 8
-#define UZU_TL_DECL unsigned long long tl_t[UZU_TL_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define UZU_TL_DECL                                                        \
+    unsigned long long tl_t[UZU_TL_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};      \
+    __shared__ unsigned long long tl_last_;                                \
+    __shared__ unsigned tl_cnt_;                                           \
+    if (threadIdx.x == 0) tl_last_ = 0ull, tl_cnt_ = 0u
 #define UZU_TL_STAMP(slot) (tl_t[slot] = __builtin_amdgcn_s_memrealtime())
+// slot 7 = when the LAST wave of the workgroup got here (thread 0's stamps say nothing about the other waves: with batches handed out
+// dynamically, or simply uneven rows, wave 0 can be done a microsecond before its workgroup is)
 #define UZU_TL_FLUSH(p)                                                                              \
     do {                                                                                             \
-        if ((p).tl && threadIdx.x == 0) {                                                            \
+        if ((p).tl) {                                                                                \
             const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                \
-            if (wg_ < 1024)                                                                          \
-                for (int i_ = 0; i_ < UZU_TL_SLOTS; ++i_) (p).tl[wg_ * UZU_TL_SLOTS + i_] = tl_t[i_]; \
+            if (threadIdx.x == 0 && wg_ < 1024)                                                      \
+                for (int i_ = 0; i_ < UZU_TL_SLOTS - 1; ++i_) (p).tl[wg_ * UZU_TL_SLOTS + i_] = tl_t[i_]; \
+            if ((threadIdx.x & 63) == 0) {                                                           \
+                const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                    \
+                atomicMax(&tl_last_, now_);                                                          \
+                const unsigned n_ = atomicAdd(&tl_cnt_, 1u);                                         \
+                if (n_ + 1 == (blockDim.x * blockDim.y + 63) / 64 && wg_ < 1024) (p).tl[wg_ * UZU_TL_SLOTS + 7] = atomicMax(&tl_last_, 0ull); \
+            }                                                                                        \
         }                                                                                            \
     } while (0)
 unsigned long long* timeline_next_slot(); // next per-launch block of 1024 x UZU_TL_SLOTS stamps, or null
