@@ -239,7 +239,10 @@ def test_engine_verify_and_accept_on_ring_kv_states(hip_ctx):
     prompt wraps during the second round.  Against the oracle model round by round, then plain decoding continues identically."""
     cfg = S.tiny_llama(sliding_windows=[40, 0], sinks=True, seed=48)
     bundle = S.build_model(cfg)
-    prompt = ((S.synthetic_prompt(37, cfg.vocab_size).astype(np.int64) * 191 + 2101) % cfg.vocab_size).astype(np.uint32)
+    # the multiplier: of 200 tried on the CPU oracle, the one whose accepted path and the four decode steps behind it are decided by the widest
+    # top-two gap (>= 0.46 sigma of the logit row, eleven distinct tokens) -- the production kernels sit 0.04-0.08 sigma off the oracle's logits,
+    # and the first choice (191) had a 0.04-sigma decision on the path (tools/scratch/diag_ring.py on the GPU: every node within 0.08 sigma)
+    prompt = ((S.synthetic_prompt(37, cfg.vocab_size).astype(np.int64) * 493 + 2101) % cfg.vocab_size).astype(np.uint32)
     om = O.OracleModel(bundle)
     want, _ = linear_stream(om, prompt, 20)
     om.reset()

@@ -28,7 +28,15 @@ using namespace uzu;
 
 namespace {
 
-constexpr uint32_t kSuffixCapacity = 1024; // ATTENTION_SUFFIX_CAPACITY, mixer/attention/state.rs:14
+constexpr uint32_t kSuffixCapacity = 1024; // ATTENTION_SUFFIX_CAPACITY, mixer/attention/state.rs:14: the reference's rows per forward pass (and its single- / two-pass rule)
+// Rows of one PREFILL pass here (uzu_hip_model::chunk; UZU_PREFILL_CHUNK = 1024 ... 8192, a multiple of 1024).  The reference feeds a prompt in
+// passes of <= 1024 tokens; on this chip a 1024-row GEMM of a 0.8B model is 64-128 tiles for 256 CUs, so the default pass is 2048 rows (same
+// results up to the order of a split-K sum: the DeltaNet chunks and the attention key tiles of a 1024-aligned boundary do not move).
+static uint32_t prefill_chunk_rows() {
+    const char* e = getenv("UZU_PREFILL_CHUNK");
+    const long v = e ? atol(e) : 2048;
+    return (v >= 1024 && v <= 8192 && v % 1024 == 0) ? (uint32_t)v : 2048u;
+}
 constexpr uint32_t kArgmaxPartials = 4096; // capacity of the read-out GEMV's per-workgroup arg-max partials (DecGemvParams::part_capacity)
 
 struct DLinear {
@@ -105,6 +113,7 @@ struct uzu_hip_model {
     uint32_t* d_sampled = nullptr;  // [max positions] token sampled from the row at absolute position p
     uint32_t context_length = 0;    // host mirror of *d_ctx_len
     uint32_t max_positions = 0;
+    uint32_t chunk = kSuffixCapacity; // rows of one prefill pass (prefill_chunk_rows())
     uint32_t max_seqs = 1;          // sequences one batched prefill pass may carry (UZU_MODEL_BATCH(n) at creation)
     uint32_t* batch_tokens = nullptr; // [max_seqs * 1024] token ids of a batched pass
 
@@ -285,7 +294,7 @@ uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
         void* p = nullptr;
         if (h.mixer_kind == UZU_MIXER_ATTENTION) {
             // AttentionState::create_empty (state.rs:69-136): a causal sliding-window layer keeps a RING of `window` rows + the suffix region
-            const size_t kv_rows = h.sliding_window_size ? (size_t)h.sliding_window_size + kSuffixCapacity : (size_t)m->max_positions;
+            const size_t kv_rows = h.sliding_window_size ? (size_t)h.sliding_window_size + m->chunk : (size_t)m->max_positions;
             const size_t kv_bytes = kv_rows * h.num_groups * h.head_dim * 2;
             need(kv_bytes, &p), st->layers[l].keys = (uint16_t*)p;
             need(kv_bytes, &p), st->layers[l].values = (uint16_t*)p;
@@ -296,7 +305,7 @@ uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
     }
     void* p = nullptr;
     need(4, &p), st->d_ctx_len = (uint32_t*)p;
-    need((size_t)kSuffixCapacity * 4, &p), st->d_tokens = (uint32_t*)p;
+    need((size_t)m->chunk * 4, &p), st->d_tokens = (uint32_t*)p;
     need(4, &p), st->d_out_token = (uint32_t*)p;
     need((size_t)m->max_positions * 4, &p), st->d_sampled = (uint32_t*)p;
     if (r != UZU_OK) {
@@ -760,7 +769,7 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
         RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
                                   L.d.dn_norm_epsilon));
     } else {
-        if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(kSuffixCapacity + 8) * total_proj_dim) {
+        if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(m->chunk + 8) * total_proj_dim) {
             RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
         } else {
             RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
@@ -838,7 +847,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, rows * d));
         }
-        if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, count * d));
+        if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, count * d));
     }
     m->tap_rows = count;
     if (m->tree.active) {
@@ -1062,7 +1071,7 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
         up.act_mul = 1, up.act_type = L.d.activation;
         dec_gemv(e, up, "gemv_dec[norm+up+act]");
         dec_gemv_row_parallel(e, dec_gemv_base(L.down, m->gated, hidden), "gemv_dec[down]");
-        if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * kSuffixCapacity) * d, UZU_BF16, d));
+        if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, d));
     }
     m->tap_rows = 1;
     const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
@@ -1195,7 +1204,8 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     TRY(upload_linear(m, desc->embedding, &m->embedding, true));
     if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding, true));
     TRY(upload_norm(m, desc->output_norm, d, &m->output_norm));
-    m->max_positions = desc->max_context_length + kSuffixCapacity;
+    m->chunk = prefill_chunk_rows();
+    m->max_positions = desc->max_context_length + m->chunk;
     m->layers.resize(desc->num_layers);
     uint32_t max_qkv = 0, max_qdim = 0, max_hidden = 0, max_proj = 0, max_value = 0, max_key = 0, max_hv = 0, max_hd = 0, max_heads = 0;
     for (uint32_t l = 0; l < desc->num_layers; ++l) {
@@ -1260,7 +1270,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         m->weight_bytes = saved;
     }
     void* p;
-    const size_t C = kSuffixCapacity;
+    const size_t C = m->chunk;
 #define ALLOC(field, type, elems) do { TRY(dev_alloc(m, (size_t)(elems) * sizeof(type), &p, true)); m->field = (type*)p; } while (0)
     TRY(state_build(m, &m->state0));
     bind_state(m, m->state0);
@@ -1457,9 +1467,10 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
             max_heads = max_heads > L.d.num_heads ? max_heads : L.d.num_heads;
             max_hd = max_hd > L.d.head_dim ? max_hd : L.d.head_dim;
         }
-    std::vector<uint32_t> staging((size_t)nseq * kSuffixCapacity);
-    for (uint32_t start = 0; start < count; start += kSuffixCapacity) {
-        const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
+    std::vector<uint32_t> staging((size_t)nseq * m->chunk);
+    const uint32_t pass_rows = k::exact_mode() ? kSuffixCapacity : m->chunk; // reference-order mode: the reference's own passes (bit-identical logits)
+    for (uint32_t start = 0; start < count; start += pass_rows) {
+        const uint32_t n = count - start < pass_rows ? count - start : pass_rows;
         const bool last = start + n == count;
         for (uint32_t i = 0; i < nseq; ++i) memcpy(&staging[(size_t)i * n], token_ids + (size_t)i * count + start, (size_t)n * 4);
         HIPCHK(hipMemcpyAsync(m->batch_tokens, staging.data(), (size_t)nseq * n * 4, hipMemcpyHostToDevice, s));
@@ -1505,8 +1516,9 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
                 m->context_length, count, m->d.max_context_length);
     hipStream_t s = m->ctx->stream;
     m->hidden_ready = false; // the prefill pass uses `hidden` for its own rows
-    for (uint32_t start = 0; start < count; start += kSuffixCapacity) {
-        const uint32_t n = count - start < kSuffixCapacity ? count - start : kSuffixCapacity;
+    const uint32_t pass_rows = k::exact_mode() ? kSuffixCapacity : m->chunk; // reference-order mode: the reference's own passes (bit-identical logits)
+    for (uint32_t start = 0; start < count; start += pass_rows) {
+        const uint32_t n = count - start < pass_rows ? count - start : pass_rows;
         const bool last = start + n == count;
         HIPCHK(hipMemcpyAsync(m->d_tokens, token_ids + start, (size_t)n * 4, hipMemcpyHostToDevice, s));
         {   // two-pass attention over this chunk (core/mod.rs:89-92: physical prefix + suffix > 1024; a ring's prefix is its window)
@@ -1855,7 +1867,7 @@ uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uin
     UZU_REQUIRE(m && out && layer < m->d.num_layers, "model_read_layer_output: bad argument");
     UZU_REQUIRE(m->taps, "model_read_layer_output: model was not created with UZU_MODEL_DEBUG_TAPS");
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
-    HIPCHK(hipMemcpy(out, m->taps + (size_t)layer * kSuffixCapacity * m->d.model_dim, (size_t)m->tap_rows * m->d.model_dim * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, m->taps + (size_t)layer * m->chunk * m->d.model_dim, (size_t)m->tap_rows * m->d.model_dim * 2, hipMemcpyDeviceToHost));
     if (rows) *rows = m->tap_rows;
     return UZU_OK;
 }
