@@ -138,12 +138,13 @@ def test_model_directory_round_trip_runs_identically(hip_ctx, tmp_path):
         assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
-def test_rht_linears_end_to_end(hip_ctx, preset):
+@pytest.mark.parametrize("preset,kw", [("tiny-qwen", {}), ("tiny-llama", {}), ("tiny-qwen", {"model_dim": 1024}), ("tiny-llama", {"model_dim": 1024, "linear_biases": True})])
+def test_rht_linears_end_to_end(hip_ctx, preset, kw):
     """HybridSpec InputOutput linears (RHTLinearWrapper, linear/rht_wrapper.rs:215-298) in every layer: InputRht on a copy of the
     rows, the inner quantised matmul, OutputRht, then the bias -- prefill (matrix-core GEMM) and decode (transform + GEMV +
-    transform, graph replay) against the oracle, teacher-forced, arg-max identical outside near-ties."""
-    cfg = S.PRESETS[preset](rht=True)
+    transform, graph replay; at model_dim 1024 the FUSED step with the transforms in the GEMV prologues) against the oracle,
+    teacher-forced, arg-max identical outside near-ties."""
+    cfg = S.PRESETS[preset](rht=True, **kw)
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 33, 8, teacher_forced=True)
     for step, (want, got, gap) in enumerate(zip(o_tokens, h_tokens, run_pair.gaps)):
         assert want == got or gap < 0.05, f"step {step}: oracle {want}, hip {got}, top-2 gap {gap:.4f} sigma"
@@ -232,10 +233,12 @@ def test_fused_decode_matches_unfused(hip_ctx):
     same arithmetic as the one-kernel-per-reference-kernel path: on a DeltaNet-only model tokens AND logits are
     bit-identical; with attention layers (own KV split) tokens are identical and logits within tolerance."""
     for kinds, exact in (([D.MIXER_DELTA_NET] * 3, True), (None, False)):
-        cfg = S.tiny_qwen() if kinds is None else S.tiny_qwen(layer_kinds=kinds)
+        # model_dim 1024: the fused step's Normalization prologue covers rows that are multiples of 1024 (engine.hip::dim_fusable); the
+        # launch counts prove which path each run took (round 4: at the presets' 256 both runs took the unfused one)
+        cfg = S.tiny_qwen(model_dim=1024) if kinds is None else S.tiny_qwen(model_dim=1024, layer_kinds=kinds)
         bundle = S.build_model(cfg)
         prompt = S.synthetic_prompt(21, cfg.vocab_size)
-        outs = []
+        outs, launches = [], []
         for flags in (0, MODEL_NO_FUSION):
             hm = HipModel(hip_ctx, bundle, flags)
             first = hm.prefill(prompt)
@@ -244,14 +247,48 @@ def test_fused_decode_matches_unfused(hip_ctx):
                 t, _ = hm.decode(1)
                 toks.append(int(t[0]))
                 logits.append(hm.read_logits())
+            launches.append(hm.decode_launch_count)
             outs.append((toks, logits))
             hm.close()
+        assert launches[0] < launches[1], f"the fused step was not taken ({launches})"
         assert outs[0][0] == outs[1][0]
         for a, b in zip(outs[0][1], outs[1][1]):
             if exact:
                 assert np.array_equal(a, b)
             else:
                 assert logits_close(a, b).all()
+
+
+@pytest.mark.parametrize("preset,kw,exact", [
+    ("tiny-qwen", {"rht": True, "model_dim": 1024, "layer_kinds": [D.MIXER_DELTA_NET] * 3}, True),   # DeltaNet only: every kernel of the two paths rounds at the same points
+    ("tiny-qwen", {"rht": True, "model_dim": 1024}, False),                                      # + a gated attention layer (gate behind its OWN input transform: a launch of its own)
+    ("tiny-llama", {"rht": True, "model_dim": 1024}, False),
+    ("tiny-llama", {"rht": True, "model_dim": 1024, "linear_biases": True}, False),                     # bias_after_rht: added behind the OutputRht, inside the next prologue
+])
+def test_fused_decode_with_rht_linears_matches_unfused(hip_ctx, preset, kw, exact):
+    """RHT linears inside the fused decode step (round 4; RHTLinearWrapper, linear/rht_wrapper.rs:215-298): InputRht and the previous linear's
+    OutputRht + bias in the Normalization prologue of the GEMV (gemv_dec_kernel, PRO == 3), the reference's own transform kernels around
+    the launches that cannot take them (attention rows, GatedActMul, the DeltaNet conv).  Same rounding points as the
+    one-kernel-per-reference-kernel path: bit-identical logits where no attention layer is involved (its fused kernel splits the keys
+    differently), identical tokens and logits within the usual band otherwise; the fused path must actually be the one taken."""
+    cfg = S.PRESETS[preset](**kw)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(21, cfg.vocab_size)
+    outs, launches = [], []
+    for flags in (0, MODEL_NO_FUSION):
+        hm = HipModel(hip_ctx, bundle, flags)
+        toks, logits = [hm.prefill(prompt)], []
+        for _ in range(10):
+            t, _ = hm.decode(1)
+            toks.append(int(t[0]))
+            logits.append(hm.read_logits())
+        launches.append(hm.decode_launch_count)
+        outs.append((toks, logits))
+        hm.close()
+    assert launches[0] < launches[1], f"the fused step was not taken for an RHT model ({launches})"
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b) if exact else logits_close(a, b).all()
 
 
 def test_long_context_two_pass_regime(hip_ctx):

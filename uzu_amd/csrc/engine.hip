@@ -48,6 +48,10 @@ struct DLinear {
     void* out_biases = nullptr;
     int32_t* in_signs = nullptr;  // HybridSpec InputOutput (RHTLinearWrapper): sign factors of the input / output Hadamard transforms
     int32_t* out_signs = nullptr;
+    // the same factors as one bit per element (bit i of word s: element 32 s + i is -1) for the fused decode step's Hadamard prologue
+    // (k_decode.hip, PRO == 3); null when a factor is not +-1 -- then the model decodes through the reference's kernel sequence
+    uint32_t *in_bits = nullptr, *out_bits = nullptr;
+    std::vector<uint32_t> in_words; // host copy of in_bits (two linears behind one prologue must share it)
     uint32_t lora_rank = 0;       // HybridSpec with a LowRankSpec adapter (QLoRALinearWrapper): bf16 [rank, k] and [n, rank]
     uint16_t *adapter_down = nullptr, *adapter_up = nullptr;
     float* coef = nullptr;        // [groups][n] f32: the prefill GEMM's offset coefficients (MatmulParams::pre_coef), tabulated once at load
@@ -383,6 +387,23 @@ uzu_status upload_linear(uzu_hip_model* m, const uzu_linear_desc& h, DLinear* o,
         if (h.input_signs) UZU_PROPAGATE(upload(m, h.input_signs, (size_t)h.k * 4, &o->in_signs));
         if (h.output_signs) UZU_PROPAGATE(upload(m, h.output_signs, (size_t)(is_embedding ? h.k : h.n) * 4, &o->out_signs));
         m->rht_max_k = m->rht_max_k > h.k ? m->rht_max_k : h.k;
+        auto pack = [&](const int32_t* f, size_t count, uint32_t** out) -> uzu_status {
+            std::vector<uint32_t> words(count / 32, 0u);
+            for (size_t i = 0; i < count; ++i) {
+                if (f[i] != 1 && f[i] != -1) return UZU_OK; // not a sign vector: no packed form (the fused step is then not taken)
+                if (f[i] < 0) words[i / 32] |= 1u << (i % 32);
+            }
+            return upload(m, words.data(), words.size() * 4, out);
+        };
+        if (h.input_signs) {
+            UZU_PROPAGATE(pack((const int32_t*)h.input_signs, h.k, &o->in_bits));
+            if (o->in_bits) {
+                o->in_words.assign(h.k / 32, 0u);
+                for (size_t i = 0; i < h.k; ++i)
+                    if (((const int32_t*)h.input_signs)[i] < 0) o->in_words[i / 32] |= 1u << (i % 32);
+            }
+        }
+        if (h.output_signs) UZU_PROPAGATE(pack((const int32_t*)h.output_signs, is_embedding ? h.k : h.n, &o->out_bits));
     }
     if (h.lora_rank) { // QLoRALinearWrapper::new (qlora_wrapper.rs:61-175)
         UZU_REQUIRE(!is_embedding && h.method != UZU_QUANT_NONE, "engine: a QLoRA adapter needs a quantized base linear");
@@ -920,7 +941,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
 k::DecGemvParams dec_gemv_base(const DLinear& L, const uint16_t* x, uint16_t* out) {
     k::DecGemvParams p{};
     p.w[0] = (const uint8_t*)L.w, p.scales[0] = (const uint16_t*)L.scales, p.biases[0] = (const uint16_t*)L.biases, p.zp[0] = L.zp;
-    p.out_bias[0] = (const uint16_t*)L.out_biases, p.out[0] = out, p.n[0] = L.n;
+    p.out_bias[0] = L.out_signs ? nullptr : (const uint16_t*)L.out_biases, p.out[0] = out, p.n[0] = L.n; // bias_after_rht: with the OutputRht, later
     p.k = L.k, p.bits = L.bits, p.group_size = L.group;
     p.b_kind = L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS
              : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
@@ -929,7 +950,7 @@ k::DecGemvParams dec_gemv_base(const DLinear& L, const uint16_t* x, uint16_t* ou
 }
 void dec_add_second(k::DecGemvParams& p, const DLinear& L, uint16_t* out) {
     p.w[1] = (const uint8_t*)L.w, p.scales[1] = (const uint16_t*)L.scales, p.biases[1] = (const uint16_t*)L.biases, p.zp[1] = L.zp;
-    p.out_bias[1] = (const uint16_t*)L.out_biases, p.out[1] = out, p.n[1] = L.n;
+    p.out_bias[1] = L.out_signs ? nullptr : (const uint16_t*)L.out_biases, p.out[1] = out, p.n[1] = L.n;
 }
 // mode: 1 copy, 2 add
 void dec_add_norm(k::DecGemvParams& p, const DNorm& N, int mode, const uint16_t* sc_in, uint16_t* sc_out) {
@@ -967,8 +988,12 @@ void dec_gemv_row_parallel(Enc& e, k::DecGemvParams p, const char* name) {
     RUN("all_reduce", (size_t)p.n[0] * 4, tp::all_reduce_sum_f32(m->tp, e.s, m->tp_buf, p.n[0], out));
 }
 
+bool linear_rht(const DLinear& L) { return L.in_signs || L.out_signs; }
 bool linear_fusable(const DLinear& L) {
-    if (!L.w || L.in_signs || L.out_signs || L.lora_rank) return false; // RHT / QLoRA linears run as their wrappers compose them (unfused decode)
+    if (!L.w || L.lora_rank) return false; // QLoRA linears run as their wrapper composes them (unfused decode)
+    // RHT linears (round 4): InputRht in the Normalization prologue of the GEMV or as a launch of its own in front of a plain-row GEMV, OutputRht
+    // (+ bias) in the prologue of the next normalised GEMV or as a launch of its own (encode_decode_fused); sign vectors of +-1 only
+    if (linear_rht(L) && !(L.in_bits && L.out_bits && L.n % 32 == 0)) return false;
     if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
     return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
 }
@@ -988,11 +1013,13 @@ bool model_fusable(const uzu_hip_model* m) {
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
             if (!linear_fusable(L.qkv) || !linear_fusable(L.out)) return false;
             if (L.d.has_gate && (!linear_fusable(L.gate) || L.gate.bits != L.qkv.bits || L.gate.group != L.qkv.group || L.gate.method != L.qkv.method)) return false;
+            // (the two matrices of the fused launch share one prologue: with different input transforms the gate gets a launch of its own)
             if (!(L.d.head_dim == 64 || L.d.head_dim == 128 || L.d.head_dim == 256)) return false;
             if (L.d.sliding_window_size || L.d.has_sinks) return false; // ring KV state / sinks: the one-kernel-per-reference-kernel path (attn_dec has neither)
             if ((L.qn.present && (L.qn.subtract_mean || L.qn.biases)) || (L.kn.present && (L.kn.subtract_mean || L.kn.biases))) return false;
         } else {
             if (!linear_fusable(L.in_proj) || !linear_fusable(L.out_proj)) return false;
+            if (linear_rht(L.in_proj) && m->tp) return false; // (the stand-alone conv / update kernels of the RHT route are not sharded here)
             if (L.d.dn_head_dim != 128 || L.d.dn_value_head_dim > 512 || L.d.dn_kernel_size != 4) return false; // conv epilogue of the in-proj GEMV
             {   // norm-gate prologue of the out-proj GEMV (k_decode.hip): chunks of 8 outputs, <= 4 chunks per thread
                 const uint32_t dv = L.d.dn_value_head_dim, kk = L.d.dn_num_heads * dv, nchunks = kk / 8, per = nchunks > 256 ? nchunks / 256 : 1;
@@ -1027,18 +1054,51 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
     if (with_embed) encode_embed_row0(e);
     uint16_t* sc[2] = {m->shortcut, m->shortcut_b};
     int cur = 1; // the first norm (copy mode) writes sc[0]
-    auto next_norm = [&](k::DecGemvParams& p, const DNorm& N, int mode) {
+    // RHT linears (RHTLinearWrapper, linear/rht_wrapper.rs:215-298) inside the fused step.  The raw output row of an out-projection / down
+    // projection with Hadamard factors stays `pending`: the next GEMV with a Normalization prologue applies its OutputRht + bias to the row it
+    // loads anyway (PRO == 3 instance of gemv_dec_kernel); a consumer that cannot (act-mul / conv epilogue) gets it flushed by the reference's
+    // own two kernels first.  Rounding points are the unfused path's, so the two stay bit-identical.
+    const DLinear* pending = nullptr;
+    uint16_t* pending_row = nullptr;
+    auto out_transform = [&](const DLinear& L, uint16_t* row) {
+        if (!L.out_signs) return;
+        RUN("activation_transform", 0, k::activation_transform(s, nullptr, row, nullptr, nullptr, nullptr, L.out_signs, UZU_BF16, 1, L.n, UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
+        if (L.out_biases) RUN("tensor_add_bias", 0, k::tensor_add_bias(s, row, L.out_biases, row, UZU_BF16, UZU_BF16, L.n, L.n));
+    };
+    auto flush_pending = [&]() {
+        if (pending) out_transform(*pending, pending_row);
+        pending = nullptr;
+    };
+    auto in_transform = [&](const DLinear& L, const uint16_t* row) -> const uint16_t* {
+        if (!L.in_signs) return row;
+        RUN("activation_transform", 0, k::activation_transform(s, row, m->rht_scratch, nullptr, nullptr, nullptr, L.in_signs, UZU_BF16, 1, L.k, UZU_ACTIVATION_TRANSFORM_INPUT_RHT, 0, 0));
+        return m->rht_scratch;
+    };
+    // `own`: the linear(s) behind this prologue; `epilogue`: the launch has an act-mul / conv epilogue (no Hadamard instance exists for those)
+    auto next_norm = [&](k::DecGemvParams& p, const DNorm& N, int mode, const DLinear* own = nullptr, bool epilogue = false) {
+        if (pending && epilogue) flush_pending();
         dec_add_norm(p, N, mode, sc[cur], sc[cur ^ 1]);
         cur ^= 1;
+        if (pending) p.x_rht_bits = pending->out_bits, p.x_rht_bias = (const uint16_t*)pending->out_biases, pending = nullptr;
+        if (own && own->in_bits) p.in_rht_bits = own->in_bits;
     };
     for (uint32_t l = 0; l < m->d.num_layers; ++l) {
         DLayer& L = m->layers[l];
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
             const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups;
             k::DecGemvParams p = dec_gemv_base(L.qkv, hidden, m->qkv);
-            if (L.d.has_gate) dec_add_second(p, L.gate, m->gate);
-            next_norm(p, L.pre_mixer, l > 0 ? 2 : 1);
-            dec_gemv(e, p, "gemv_dec[norm+qkv+gate]");
+            const bool own_gate = L.d.has_gate && (linear_rht(L.qkv) != linear_rht(L.gate) || L.qkv.in_words != L.gate.in_words);
+            if (L.d.has_gate && !own_gate) dec_add_second(p, L.gate, m->gate);
+            next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, &L.qkv);
+            dec_gemv(e, p, own_gate ? "gemv_dec[norm+qkv]" : "gemv_dec[norm+qkv+gate]");
+            if (own_gate) { // its own InputRht: the same Normalization again, of the residual row the launch above has just written (copy mode, nothing stored)
+                k::DecGemvParams g = dec_gemv_base(L.gate, sc[cur], m->gate);
+                dec_add_norm(g, L.pre_mixer, 1, nullptr, nullptr);
+                g.in_rht_bits = L.gate.in_bits;
+                dec_gemv(e, g, "gemv_dec[norm+gate]");
+            }
+            out_transform(L.qkv, m->qkv);
+            if (L.d.has_gate) out_transform(L.gate, m->gate);
             k::AttnDecParams a{};
             a.qkv = m->qkv, a.keys = L.keys, a.values = L.values, a.cosines = m->rope_cos, a.sines = m->rope_sin, a.ctx_len = m->d_ctx_len;
             a.q_norm = {L.qn.present, L.qn.full_layer, L.qn.eps, L.qn.offset, L.qn.scales};
@@ -1049,34 +1109,62 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
             const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
             RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
             RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
-            dec_gemv_row_parallel(e, dec_gemv_base(L.out, m->attn_out, m->mixed), "gemv_dec[out_proj]");
+            dec_gemv_row_parallel(e, dec_gemv_base(L.out, in_transform(L.out, m->attn_out), m->mixed), "gemv_dec[out_proj]");
+            if (L.out.out_signs) pending = &L.out, pending_row = m->mixed;
         } else {
             const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
             k::DecGemvParams p = dec_gemv_base(L.in_proj, hidden, m->in_proj);
-            next_norm(p, L.pre_mixer, l > 0 ? 2 : 1);
-            // DeltaNetConvUpdate rides in the in-proj epilogue: the lane that finishes a conv channel's row convolves it
-            p.conv_w = L.conv_w, p.conv_b = L.conv_b, p.conv_state = L.conv_state, p.conv_dim = 2 * Hk * Dk + Hv * Dv, p.conv_ks = L.d.dn_kernel_size;
-            dec_gemv(e, p, "gemv_dec[norm+in_proj+conv]");
-            k::DeltaDecParams q{};
-            q.in_proj = m->in_proj, q.a_log = L.a_log, q.dt_bias = L.dt_bias, q.state = L.ssm_state, q.o = m->dn_o, q.sz = m->dn_sz;
-            q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv;
-            RUN("delta_dec", (size_t)2 * Hv * Dv * Dk * 4, k::delta_dec(s, q));
-            // ... and the RMSNorm * SiLU(z) gate in the out-proj prologue (it needs all Dv outputs of a head)
-            k::DecGemvParams op = dec_gemv_base(L.out_proj, m->delta_out, m->mixed);
-            op.dg_o = m->dn_o, op.dg_sz = m->dn_sz, op.dg_w = L.dn_norm, op.dg_dv = Dv, op.dg_eps = L.d.dn_norm_epsilon;
-            dec_gemv_row_parallel(e, op, "gemv_dec[gate+out_proj]");
+            const uint32_t conv_dim = 2 * Hk * Dk + Hv * Dv;
+            if (linear_rht(L.in_proj)) {
+                // the conv needs the OutputRht of the row it convolves: projection, the transform, then DeltaNetConvUpdate as a launch of its own
+                next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, &L.in_proj);
+                dec_gemv(e, p, "gemv_dec[norm+in_proj]");
+                out_transform(L.in_proj, m->in_proj);
+                RUN("delta_net_conv_update", 0, k::delta_net_conv_update(s, L.conv_w, L.conv_b, m->in_proj, L.conv_state, L.d.dn_kernel_size, conv_dim, L.d.dn_kernel_size - 1));
+            } else {
+                next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, nullptr, true);
+                // DeltaNetConvUpdate rides in the in-proj epilogue: the lane that finishes a conv channel's row convolves it
+                p.conv_w = L.conv_w, p.conv_b = L.conv_b, p.conv_state = L.conv_state, p.conv_dim = conv_dim, p.conv_ks = L.d.dn_kernel_size;
+                dec_gemv(e, p, "gemv_dec[norm+in_proj+conv]");
+            }
+            if (linear_rht(L.out_proj)) {
+                // the norm-gate prologue has no Hadamard instance: the delta rule with its RMSNorm * SiLU(z) tail as one kernel, InputRht, a plain-row GEMV
+                RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(s, m->in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, Hk * Dk,
+                                                                                      Hv * Dv, L.d.dn_norm_epsilon));
+                dec_gemv_row_parallel(e, dec_gemv_base(L.out_proj, in_transform(L.out_proj, m->delta_out), m->mixed), "gemv_dec[out_proj]");
+                pending = &L.out_proj, pending_row = m->mixed;
+            } else {
+                k::DeltaDecParams q{};
+                q.in_proj = m->in_proj, q.a_log = L.a_log, q.dt_bias = L.dt_bias, q.state = L.ssm_state, q.o = m->dn_o, q.sz = m->dn_sz;
+                q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv;
+                RUN("delta_dec", (size_t)2 * Hv * Dv * Dk * 4, k::delta_dec(s, q));
+                // ... and the RMSNorm * SiLU(z) gate in the out-proj prologue (it needs all Dv outputs of a head)
+                k::DecGemvParams op = dec_gemv_base(L.out_proj, m->delta_out, m->mixed);
+                op.dg_o = m->dn_o, op.dg_sz = m->dn_sz, op.dg_w = L.dn_norm, op.dg_dv = Dv, op.dg_eps = L.d.dn_norm_epsilon;
+                dec_gemv_row_parallel(e, op, "gemv_dec[gate+out_proj]");
+            }
         }
-        k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
-        next_norm(up, L.pre_mlp, 2);
-        up.act_mul = 1, up.act_type = L.d.activation;
-        dec_gemv(e, up, "gemv_dec[norm+up+act]");
-        dec_gemv_row_parallel(e, dec_gemv_base(L.down, m->gated, hidden), "gemv_dec[down]");
+        if (linear_rht(L.up)) { // GatedActMul needs the OutputRht of both halves: projection, the transform (+ bias), then the product kernel
+            k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->up);
+            next_norm(up, L.pre_mlp, 2, &L.up);
+            dec_gemv(e, up, "gemv_dec[norm+up]");
+            out_transform(L.up, m->up);
+            RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, 1, 0, 0, L.d.activation, 1));
+        } else {
+            k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
+            next_norm(up, L.pre_mlp, 2, nullptr, true);
+            up.act_mul = 1, up.act_type = L.d.activation;
+            dec_gemv(e, up, "gemv_dec[norm+up+act]");
+        }
+        dec_gemv_row_parallel(e, dec_gemv_base(L.down, in_transform(L.down, m->gated), hidden), "gemv_dec[down]");
+        if (L.down.out_signs) pending = &L.down, pending_row = hidden;
+        if (m->taps) flush_pending(); // (debug taps hold finished rows)
         if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, d));
     }
     m->tap_rows = 1;
     const DLinear& ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
     k::DecGemvParams r = dec_gemv_base(ro, hidden, m->logits);
-    next_norm(r, m->output_norm, 2);
+    next_norm(r, m->output_norm, 2); // (an RHT read-out is not fused: model_fusable)
     r.normed_out = m->last_normed;
     r.part_val = m->amax_val, r.part_idx = m->amax_idx, r.part_capacity = kArgmaxPartials;
     uint32_t grid = 0;

@@ -63,6 +63,45 @@ namespace k {
 //     the prologue ends after 6-8 us of a 19 us kernel (Llama-3-8B up-projection, tools/timeline.py).  With 12-16 waves per
 //     workgroup (one workgroup per CU) waves 0-3 run the same 256-thread prologue (same element mapping, same reduction
 //     order: bit-identical) and the other waves only keep their weight loads in flight: a quarter of the traffic.
+// One 32-element stripe of the prologue's LDS row through a randomised Hadamard transform, exactly as activation_transform_kernel does it
+// across 32 lanes (k_activation_transform.hip::hadamard32: strides 1, 2, 4, 8, 16, the lower element keeps a + b, the upper gets a - b, then
+// 1/sqrt(32); sign factors before the butterfly for InputRht, after it for OutputRht; the result rounded to bf16, then -- OutputRht only -- the
+// linear's bias added and rounded again: MatmulDOps::rht_factors, kernel.rs:296-303).  `bits`: bit i = the factor of element i is -1.
+template <bool INPUT>
+__device__ __forceinline__ void rht_stripe(float* slot, uint32_t bits, const uint16_t* bias) {
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = ((const float4*)slot)[i];
+        a[4 * i] = t.x, a[4 * i + 1] = t.y, a[4 * i + 2] = t.z, a[4 * i + 3] = t.w;
+    }
+    if (INPUT) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a[i] = (bits >> i) & 1u ? -a[i] : a[i];
+    }
+#pragma unroll
+    for (int stride = 1; stride < 32; stride <<= 1) {
+#pragma unroll
+        for (int l = 0; l < 32; ++l) {
+            if (l & stride) continue;
+            const float lo = a[l], hi = a[l | stride];
+            a[l] = lo + hi, a[l | stride] = lo - hi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        float v = a[i] * (1.0f / sqrtf(32.0f));
+        if (!INPUT) v = (bits >> i) & 1u ? -v : v;
+        a[i] = round_bf16(v);
+    }
+    if (!INPUT && bias) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a[i] = round_bf16(a[i] + bf16_to_f32(bias[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ((float4*)slot)[i] = make_float4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+}
+
 template <int BITS, int CPLT, int R, bool ACT, int KIND, int PRO, bool CONV, int NW>
 __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const void* a1, const void* a2, uint32_t k_arg, int lpr_log2, const uint8_t* w0,
                                                        const uint16_t* s0, const uint16_t* o0, DecGemvParams p) {
@@ -84,7 +123,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
     constexpr int NT = 64 * NW;
-    static_assert(NW == 4 || (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))), "wide workgroups: prologue kernels of the bandwidth regime only");
+    static_assert(NW == 4 || (!CONV && PRO != 2 && (PRO == 1 || PRO == 3 || (CPLT == 0 && BITS == 4))), "wide workgroups: prologue kernels of the bandwidth regime only");
+    static_assert(PRO != 3 || (!ACT && !CONV), "an RHT linear's outputs go through OutputRht before any epilogue could use them");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     UZU_TL_DECL;
     UZU_TL_STAMP(0);
@@ -196,7 +236,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     u32x2_v x_pre[NPRE], s_pre[NPRE];
     f32x4_v n_pre[NPRE];
     const bool pro_wave = NW == 4 || wave < 4; // the prologue is a 256-thread affair (wave-uniform)
-    if (PRO == 1 && pro_wave) {
+    if ((PRO == 1 || PRO == 3) && pro_wave) {
         const uint32_t E = K / 256;
 #pragma unroll
         for (int qi = 0; qi < NPRE; ++qi) {
@@ -206,6 +246,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             s_pre[qi] = *(const u32x2_v*)((p.residual_add ? p.shortcut_in : p.x) + e);
             n_pre[qi] = *(const f32x4_v*)(p.norm_scales ? p.norm_scales + e : (const float*)p.x);
         }
+    }
+    uint32_t x_bits = 0, in_bits = 0; // PRO == 3: the sign words of the stripe this thread transforms (unconditional loads: an absent table reads the row)
+    if constexpr (PRO == 3) {
+        const uint32_t st = min((uint32_t)tid, C - 1);
+        x_bits = (p.x_rht_bits ? p.x_rht_bits : (const uint32_t*)p.x)[st];
+        in_bits = (p.in_rht_bits ? p.in_rht_bits : (const uint32_t*)p.x)[st];
     }
     f32x4_v dg_pre[6]; // norm-gate prologue: chunk 0 of this thread (o, z, w: two vectors each); further chunks load in place
     if (PRO == 2) {
@@ -346,6 +392,26 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             float* red = smem + (size_t)C * 36;     // [4]
             const uint32_t E = K / 256;
             float ss = 0.f;
+            bool x_in_lds = false;
+            if constexpr (PRO == 3) {
+                if (p.x_rht_bits) { // the row is the raw output of an RHT linear: its OutputRht (+ bias) first, stripe by stripe through the slots
+                    if (pro_wave) {
+#pragma unroll
+                        for (int qi = 0; qi < 2 * CPL; ++qi) {
+                            const uint32_t q = (uint32_t)qi * 4;
+                            if (q >= E) break;
+                            const uint32_t e = tid * E + q;
+                            const u32x2_v xr = qi < NPRE ? x_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.x + e);
+                            *(float4*)(xs + (size_t)(e / 32) * 36 + e % 32) =
+                                make_float4(bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u));
+                        }
+                    }
+                    lds_barrier();
+                    if ((uint32_t)tid < C) rht_stripe<false>(xs + (size_t)tid * 36, x_bits, p.x_rht_bias ? p.x_rht_bias + (size_t)tid * 32 : nullptr);
+                    lds_barrier();
+                    x_in_lds = true;
+                }
+            }
             if (pro_wave) {
 #pragma unroll
             for (int qi = 0; qi < 2 * CPL; ++qi) {
@@ -354,6 +420,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                 const uint32_t e = tid * E + q;
                 const u32x2_v xr = qi < NPRE ? x_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.x + e);
                 float v[4] = {bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u)};
+                if (PRO == 3 && x_in_lds) {
+                    const float4 t = *(const float4*)(xs + (size_t)(e / 32) * 36 + e % 32);
+                    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+                }
                 if (p.residual_add) {
                     const u32x2_v sr = qi < NPRE ? s_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.shortcut_in + e);
                     const float sc[4] = {bits_to_f32(sr.x << 16), bits_to_f32(sr.x & 0xFFFF0000u), bits_to_f32(sr.y << 16), bits_to_f32(sr.y & 0xFFFF0000u)};
@@ -404,6 +474,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                     *(uint2*)(p.normed_out + e) = o;
                 }
             }
+            }
+            if constexpr (PRO == 3) {
+                if (p.in_rht_bits) { // this linear's InputRht on the normalised row
+                    lds_barrier();
+                    if ((uint32_t)tid < C) rht_stripe<true>(xs + (size_t)tid * 36, in_bits, nullptr);
+                }
             }
             if ((ACT || CONV) && tid < 32) s_exp_tab[tid] = exp_entry; // rides on the barrier below (requested with the first loads)
             lds_barrier();
@@ -776,7 +852,7 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
         const void* a2 = PRO == 2 ? (const void*)p.dg_w : (const void*)p.norm_scales;                                               \
         return launch_check([&] { hipLaunchKernelGGL((gemv_dec_kernel<BITS, CPLT, RR, ACT, KIND, PRO, CONV, NWV>), dim3(grid), dim3(64 * NWV), lds, s, a0, a1, a2, p.k, lpr_log2, p.w[0], p.scales[0], p.biases[0], pl); }, "gemv_dec"); \
     } while (0)
-    if constexpr (!CONV && PRO != 2 && (PRO == 1 || (CPLT == 0 && BITS == 4))) {
+    if constexpr (!CONV && PRO != 2 && (PRO == 1 || PRO == 3 || (CPLT == 0 && BITS == 4))) {
         if (wide) { // bandwidth regime (gemv_dec_plan: R <= 2): one wide workgroup per CU shares the prologue
             // 150-190 registers on the 4-step path: 3 waves per SIMD; int8 rows need 100-170 registers: 8 waves (two workgroups per CU)
             constexpr int NWV = BITS == 8 ? 8 : (CPLT == 4 ? 12 : 16);
@@ -792,7 +868,7 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
 }
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO>
 static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
-    if constexpr (!ACT && PRO != 2) {
+    if constexpr (!ACT && PRO != 2 && PRO != 3) {
         if (p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
             if (R > 2) {
                 want *= (uint32_t)(R / 2);
@@ -809,6 +885,13 @@ static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint3
     if constexpr (CPLT != 0) { // prologues keep the row in registers (checked by the caller)
         if constexpr (!ACT)
             if (p.dg_o) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 2>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+        if (normed && (p.x_rht_bits || p.in_rht_bits)) { // Hadamard transforms around the normalisation (RHT linears)
+            if constexpr (!ACT) {
+                if (!p.conv_w) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 3>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+            }
+            set_error("gemv_dec: the Hadamard prologue is instantiated without the act-mul / conv epilogues (an RHT linear's outputs need their OutputRht first)");
+            return UZU_ERR_UNSUPPORTED;
+        }
         if (normed) return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 1>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
     }
     if constexpr (CPLT == 4) {

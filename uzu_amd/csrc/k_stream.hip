@@ -1086,7 +1086,7 @@ static int stream_cpl(const DecGemvParams& p) {
 }
 
 bool gemv_stream_supported(const DecGemvParams& p) {
-    if (p.bits != 4 || p.b_kind != UZU_MATMUL_B_SCALE_BIAS || p.conv_w || p.dg_o) return false;
+    if (p.bits != 4 || p.b_kind != UZU_MATMUL_B_SCALE_BIAS || p.conv_w || p.dg_o || p.x_rht_bits || p.in_rht_bits) return false;
     if (p.k % 32 || p.group_size % 32 || (p.group_size & (p.group_size - 1))) return false;
     const uint32_t G = (p.k + p.group_size - 1) / p.group_size;
     if (p.k % p.group_size || (G & 1)) return false; // scale rows are fetched in 4-byte units

@@ -95,6 +95,14 @@ struct DecGemvParams {
     const float* dg_w;            // [dv] norm weight
     uint32_t dg_dv;
     float dg_eps;
+    // Randomised Hadamard transforms around the Normalization prologue (RHTLinearWrapper, linear/rht_wrapper.rs:215-298; the PRO == 3
+    // instances).  Sign factors as ONE BIT per element (bit i of word s: the factor of element 32 s + i is -1), packed at load.
+    //   x_rht_bits / x_rht_bias: the row in `x` is the RAW output of an RHT linear -- its OutputRht (butterfly, 1/sqrt(32), factors, rounded
+    //     to bf16) and then its bias (rounded again) are applied before anything else (MatmulDOps::rht_factors, kernel.rs:296-303)
+    //   in_rht_bits: InputRht of the normalised row (factors, butterfly, 1/sqrt(32), rounded to bf16) = this linear's own input transform
+    const uint32_t* x_rht_bits;   // [k / 32] or null
+    const uint16_t* x_rht_bias;   // bf16 [k] or null
+    const uint32_t* in_rht_bits;  // [k / 32] or null
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);

@@ -70,6 +70,7 @@ class ModelConfig:
     qlora_rank: int = 0            # every layer linear carries a bf16 low-rank adapter of this rank (QLoRALinearWrapper); with `rht` also the signs
     sliding_windows: Optional[List[int]] = None  # per attention layer (in layer order): window size, 0 = full attention (Gemma / gpt-oss pattern)
     sinks: bool = False            # every attention layer carries per-head sink logits (mixer.sinks)
+    linear_biases: bool = False    # every layer linear carries an output bias (with `rht`: added behind the OutputRht, kernel.rs:296-303)
 
     @property
     def num_layers(self) -> int:
@@ -183,7 +184,7 @@ def make_linear(cfg: ModelConfig, name: str, n: int, k: int, gain: float = 1.0,
         else:
             zero_points = rng.integers(120, 136, size=(n, groups), dtype=np.uint8)
     ob = None
-    if out_bias:
+    if out_bias or (cfg.linear_biases and name.startswith("layers.")):
         ob = f32_to_bf16_bits(rng.uniform(-0.1, 0.1, size=(n,)).astype(np.float32))
     lw = D.LinearWeights(n, k, bits, g, method, codes, scales_b, biases_b, zero_points, ob)
     if cfg.rht and name.startswith("layers.") and n % 32 == 0 and k % 32 == 0:  # whole 32-wide Hadamard blocks on both sides
