@@ -440,6 +440,9 @@ TP_CASES = [
     # HybridSpec (RHT) linears under TP: the Hadamard factors are cut with their rows / k slices (tp.py::take_rows / take_k), OutputRht of a
     # row-parallel linear runs behind the all-reduce (rht_wrapper.rs:215-298)
     ("tiny-llama", {"rht": True}, 40, 8, 0.25, 0.05),
+    # ... and at a width the FUSED decode step covers (model_dim % 1024 == 0): the transforms ride in the GEMV prologues, the OutputRht of the
+    # row-parallel projections behind the one-hop exchange
+    ("tiny-llama", {"rht": True, "model_dim": 1024}, 40, 8, 0.25, 0.05),
 ]
 
 

@@ -1097,8 +1097,13 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 g.in_rht_bits = L.gate.in_bits;
                 dec_gemv(e, g, "gemv_dec[norm+gate]");
             }
-            out_transform(L.qkv, m->qkv);
-            if (L.d.has_gate) out_transform(L.gate, m->gate);
+            if (L.qkv.out_bits && L.d.has_gate && L.gate.out_bits) // both rows in one launch
+                RUN("rht_out_rows", 0, k::rht_out_rows(s, m->qkv, L.qkv.out_bits, (const uint16_t*)L.qkv.out_biases, L.qkv.n, m->gate, L.gate.out_bits,
+                                                        (const uint16_t*)L.gate.out_biases, L.gate.n, nullptr, nullptr, nullptr, 0, 0));
+            else {
+                out_transform(L.qkv, m->qkv);
+                if (L.d.has_gate) out_transform(L.gate, m->gate);
+            }
             k::AttnDecParams a{};
             a.qkv = m->qkv, a.keys = L.keys, a.values = L.values, a.cosines = m->rope_cos, a.sines = m->rope_sin, a.ctx_len = m->d_ctx_len;
             a.q_norm = {L.qn.present, L.qn.full_layer, L.qn.eps, L.qn.offset, L.qn.scales};
@@ -1119,8 +1124,8 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 // the conv needs the OutputRht of the row it convolves: projection, the transform, then DeltaNetConvUpdate as a launch of its own
                 next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, &L.in_proj);
                 dec_gemv(e, p, "gemv_dec[norm+in_proj]");
-                out_transform(L.in_proj, m->in_proj);
-                RUN("delta_net_conv_update", 0, k::delta_net_conv_update(s, L.conv_w, L.conv_b, m->in_proj, L.conv_state, L.d.dn_kernel_size, conv_dim, L.d.dn_kernel_size - 1));
+                RUN("rht_out_rows", 0, k::rht_out_rows(s, m->in_proj, L.in_proj.out_bits, (const uint16_t*)L.in_proj.out_biases, L.in_proj.n, nullptr, nullptr, nullptr, 0, L.conv_w,
+                                                        L.conv_b, L.conv_state, L.d.dn_kernel_size, conv_dim));
             } else {
                 next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, nullptr, true);
                 // DeltaNetConvUpdate rides in the in-proj epilogue: the lane that finishes a conv channel's row convolves it
@@ -1144,19 +1149,22 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 dec_gemv_row_parallel(e, op, "gemv_dec[gate+out_proj]");
             }
         }
-        if (linear_rht(L.up)) { // GatedActMul needs the OutputRht of both halves: projection, the transform (+ bias), then the product kernel
+        const uint16_t* down_in = nullptr; // the down projection's input row once its InputRht has been applied
+        if (linear_rht(L.up)) { // GatedActMul needs the OutputRht of both halves: projection, then the transform (+ bias) and the product
             k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->up);
             next_norm(up, L.pre_mlp, 2, &L.up);
             dec_gemv(e, up, "gemv_dec[norm+up]");
-            out_transform(L.up, m->up);
-            RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, 1, 0, 0, L.d.activation, 1));
+            // ... as ONE launch with the down projection's InputRht (a thread per stripe; the reference's four kernels on one row)
+            RUN("rht_mlp_join", 0, k::rht_mlp_join(s, m->up, L.up.out_bits, (const uint16_t*)L.up.out_biases, L.down.in_bits, L.down.in_bits ? m->rht_scratch : m->gated,
+                                                    L.d.hidden_dim, L.d.activation));
+            down_in = L.down.in_bits ? m->rht_scratch : m->gated;
         } else {
             k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
             next_norm(up, L.pre_mlp, 2, nullptr, true);
             up.act_mul = 1, up.act_type = L.d.activation;
             dec_gemv(e, up, "gemv_dec[norm+up+act]");
         }
-        dec_gemv_row_parallel(e, dec_gemv_base(L.down, in_transform(L.down, m->gated), hidden), "gemv_dec[down]");
+        dec_gemv_row_parallel(e, dec_gemv_base(L.down, down_in ? down_in : in_transform(L.down, m->gated), hidden), "gemv_dec[down]");
         if (L.down.out_signs) pending = &L.down, pending_row = hidden;
         if (m->taps) flush_pending(); // (debug taps hold finished rows)
         if (m->taps) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, d));

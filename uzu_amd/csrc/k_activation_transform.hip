@@ -16,21 +16,14 @@
 #include "device_utils.h"
 #include "gemm_tile_map.h"
 #include "kernels.h"
+#include "rht_stripe.h"
 
 namespace uzu {
 namespace k {
 
 namespace {
 
-// 32-lane Hadamard butterfly (mod.rs:27-47); `half` lanes l = 0..31 hold element l of the stripe
-__device__ __forceinline__ float hadamard32(float v, int l) {
-#pragma unroll
-    for (int stride = 1; stride < 32; stride <<= 1) {
-        const float other = __shfl_xor(v, stride, 64);
-        v = (l & stride) ? other - v : v + other; // lower lane keeps a + b, upper lane gets a - b (a = the lower lane's value)
-    }
-    return v * (1.0f / sqrtf(32.0f));
-}
+// (the 32-lane Hadamard butterfly, mod.rs:27-47: rht_stripe.h::hadamard32)
 
 // grid (ceil(columns / 256), rows); 256 threads = 8 stripes of one row
 template <class T>

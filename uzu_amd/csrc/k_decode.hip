@@ -29,6 +29,7 @@
 #include "gemv_core.h"
 #include "kernels.h"
 #include "kernels_decode.h"
+#include "rht_stripe.h"
 
 #ifndef UZU_GEMV_PRELOAD2
 #ifndef UZU_GEMV_RAWX
@@ -63,10 +64,8 @@ namespace k {
 //     the prologue ends after 6-8 us of a 19 us kernel (Llama-3-8B up-projection, tools/timeline.py).  With 12-16 waves per
 //     workgroup (one workgroup per CU) waves 0-3 run the same 256-thread prologue (same element mapping, same reduction
 //     order: bit-identical) and the other waves only keep their weight loads in flight: a quarter of the traffic.
-// One 32-element stripe of the prologue's LDS row through a randomised Hadamard transform, exactly as activation_transform_kernel does it
-// across 32 lanes (k_activation_transform.hip::hadamard32: strides 1, 2, 4, 8, 16, the lower element keeps a + b, the upper gets a - b, then
-// 1/sqrt(32); sign factors before the butterfly for InputRht, after it for OutputRht; the result rounded to bf16, then -- OutputRht only -- the
-// linear's bias added and rounded again: MatmulDOps::rht_factors, kernel.rs:296-303).  `bits`: bit i = the factor of element i is -1.
+// One 32-element stripe of the prologue's LDS row through a randomised Hadamard transform (rht_stripe.h); OutputRht is followed by the linear's
+// bias, rounded again (MatmulDOps::rht_factors, kernel.rs:296-303).
 template <bool INPUT>
 __device__ __forceinline__ void rht_stripe(float* slot, uint32_t bits, const uint16_t* bias) {
     float a[32];
@@ -75,25 +74,7 @@ __device__ __forceinline__ void rht_stripe(float* slot, uint32_t bits, const uin
         const float4 t = ((const float4*)slot)[i];
         a[4 * i] = t.x, a[4 * i + 1] = t.y, a[4 * i + 2] = t.z, a[4 * i + 3] = t.w;
     }
-    if (INPUT) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) a[i] = (bits >> i) & 1u ? -a[i] : a[i];
-    }
-#pragma unroll
-    for (int stride = 1; stride < 32; stride <<= 1) {
-#pragma unroll
-        for (int l = 0; l < 32; ++l) {
-            if (l & stride) continue;
-            const float lo = a[l], hi = a[l | stride];
-            a[l] = lo + hi, a[l | stride] = lo - hi;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        float v = a[i] * (1.0f / sqrtf(32.0f));
-        if (!INPUT) v = (bits >> i) & 1u ? -v : v;
-        a[i] = round_bf16(v);
-    }
+    rht_stripe_regs<INPUT>(a, bits);
     if (!INPUT && bias) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) a[i] = round_bf16(a[i] + bf16_to_f32(bias[i]));

@@ -6,6 +6,7 @@
 #include "device_utils.h"
 #include "gemv_core.h"
 #include "kernels.h"
+#include "rht_stripe.h"
 
 namespace uzu {
 namespace k {
@@ -458,6 +459,78 @@ uzu_status gated_act_mul(hipStream_t s, const void* act_operand, const void* val
                                (T*)fp_out, gated_dim, batch_dim, value_offset, value_row_stride, act_type, interleaved);
         }, "gated_act_mul");
     });
+}
+
+// =============================================================== RHT rows of the fused decode step (engine.hip::encode_decode_fused)
+// A lane per element, 32 lanes per stripe (activation_transform_kernel's own mapping and butterfly: rht_stripe.h::hadamard32): the composition of
+// the reference's kernels on ONE row, with their rounding points -- OutputRht of the up projection's two halves (+ its bias), GatedActMul,
+// InputRht for the down projection (activation_transform OUTPUT_RHT -> tensor_add_bias -> gated_act_mul -> activation_transform INPUT_RHT;
+// gated_act_mul.rs:36-70).  One launch instead of four: the activation (a glibc-exact expf) stays one per lane.
+__global__ void __launch_bounds__(256) rht_mlp_join_kernel(const uint16_t* up_row, const uint32_t* up_out_bits, const uint16_t* up_bias, const uint32_t* down_in_bits,
+                                                           uint16_t* out, uint32_t hidden, uint32_t act_type) {
+    const uint32_t index = blockIdx.x * 256 + threadIdx.x, l = threadIdx.x & 31;
+    const bool live = index < hidden; // hidden % 32 == 0: a stripe is live or dead as a whole
+    const uint32_t at = live ? index : 0, stripes = hidden / 32;
+    auto sign = [&](const uint32_t* bits, uint32_t word, float v) { return (bits[word] >> l) & 1u ? -v : v; };
+    float up = bf16_to_f32(up_row[at]), gate = bf16_to_f32(up_row[hidden + at]);
+    up = round_bf16(sign(up_out_bits, at / 32, hadamard32(up, (int)l)));
+    gate = round_bf16(sign(up_out_bits, stripes + at / 32, hadamard32(gate, (int)l)));
+    if (up_bias) up = round_bf16(up + bf16_to_f32(up_bias[at])), gate = round_bf16(gate + bf16_to_f32(up_bias[hidden + at]));
+    float v = rnd<bf16_t>(up * activate<bf16_t>(act_type, gate));
+    if (down_in_bits) v = round_bf16(hadamard32(sign(down_in_bits, at / 32, v), (int)l));
+    if (live) out[index] = f32_to_bf16(v);
+}
+uzu_status rht_mlp_join(hipStream_t s, const uint16_t* up_row, const uint32_t* up_out_bits, const uint16_t* up_bias, const uint32_t* down_in_bits, uint16_t* out,
+                        uint32_t hidden, uint32_t act_type) {
+    if (!hidden || hidden % 32 || !up_out_bits) {
+        set_error("rht_mlp_join: hidden %u is not a whole number of Hadamard blocks / no factors", hidden);
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    return launch_check([&] { hipLaunchKernelGGL(rht_mlp_join_kernel, dim3((hidden + 255) / 256), dim3(256), 0, s, up_row, up_out_bits, up_bias, down_in_bits, out, hidden, act_type); },
+                        "rht_mlp_join");
+}
+
+// OutputRht (+ bias) of up to two raw output rows in place (query / key / value row and the gate row of a gated attention layer: one launch), and
+// for row 0 the DeltaNetConvUpdate of its first conv_dim channels right behind it (conv_update.rs:17-55 on the value the transform has just
+// produced; the channel's taps are read, shifted and written by that lane only) -- activation_transform OUTPUT_RHT -> tensor_add_bias
+// [-> delta_net_conv_update] as one launch, same arithmetic per element.
+__global__ void __launch_bounds__(256) rht_out_rows_kernel(uint16_t* row0, const uint32_t* bits0, const uint16_t* bias0, uint32_t n0, uint16_t* row1, const uint32_t* bits1,
+                                                           const uint16_t* bias1, uint32_t n1, const float* conv_w, const float* conv_b, float* conv_state, uint32_t kernel_size,
+                                                           uint32_t conv_dim) {
+    const uint32_t blocks0 = (n0 + 255) / 256;
+    const bool second = blockIdx.x >= blocks0;
+    uint16_t* row = second ? row1 : row0;
+    const uint32_t* bits = second ? bits1 : bits0;
+    const uint16_t* bias = second ? bias1 : bias0;
+    const uint32_t n = second ? n1 : n0, index = (second ? blockIdx.x - blocks0 : blockIdx.x) * 256 + threadIdx.x, l = threadIdx.x & 31;
+    const bool live = index < n;
+    const uint32_t at = live ? index : 0;
+    float v = hadamard32(bf16_to_f32(row[at]), (int)l);
+    v = round_bf16((bits[at / 32] >> l) & 1u ? -v : v);
+    if (bias) v = round_bf16(v + bf16_to_f32(bias[at]));
+    if (!live) return;
+    if (!second && conv_w && index < conv_dim) {
+        const uint32_t tap_count = kernel_size - 1;
+        float* st_row = conv_state + (size_t)index * tap_count;
+        const float* w = conv_w + (size_t)index * kernel_size;
+        float acc = conv_b ? conv_b[index] : 0.0f;
+        for (uint32_t tap = 0; tap < tap_count; ++tap) acc += st_row[tap] * w[tap];
+        acc += v * w[tap_count];
+        for (uint32_t tap = 1; tap < tap_count; ++tap) st_row[tap - 1] = st_row[tap];
+        st_row[tap_count - 1] = v;
+        v = silu_f32(acc);
+    }
+    row[index] = f32_to_bf16(v);
+}
+uzu_status rht_out_rows(hipStream_t s, uint16_t* row0, const uint32_t* bits0, const uint16_t* bias0, uint32_t n0, uint16_t* row1, const uint32_t* bits1, const uint16_t* bias1,
+                        uint32_t n1, const float* conv_w, const float* conv_b, float* conv_state, uint32_t kernel_size, uint32_t conv_dim) {
+    if (!n0 || n0 % 32 || n1 % 32 || !bits0 || (n1 && !bits1) || (conv_w && (!conv_state || kernel_size < 2 || conv_dim > n0))) {
+        set_error("rht_out_rows: rows of %u / %u elements are not whole Hadamard blocks, or factors / conv operands are missing", n0, n1);
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    const uint32_t blocks = (n0 + 255) / 256 + (n1 + 255) / 256;
+    return launch_check([&] { hipLaunchKernelGGL(rht_out_rows_kernel, dim3(blocks), dim3(256), 0, s, row0, bits0, bias0, n0, row1, bits1, bias1, n1, conv_w, conv_b, conv_state,
+                                                  kernel_size, conv_dim); }, "rht_out_rows");
 }
 
 // =============================================================== embedding lookups (quant_embedding.rs:36-116)

@@ -159,6 +159,12 @@ uzu_status sigmoid_gate(hipStream_t s, const void* gate, void* output, uint32_t 
 uzu_status gated_act_mul(hipStream_t s, const void* act_operand, const void* value_operand, void* fp_out, uint32_t dt,
                          uint32_t gated_dim, uint32_t batch_dim, uint32_t value_offset, uint32_t value_row_stride,
                          uint32_t act_type, uint32_t interleaved);
+// one decode row of an RHT MLP: OutputRht of the up projection's halves (+ bias), GatedActMul, InputRht for the down projection (engine.hip)
+uzu_status rht_mlp_join(hipStream_t s, const uint16_t* up_row, const uint32_t* up_out_bits, const uint16_t* up_bias, const uint32_t* down_in_bits, uint16_t* out,
+                        uint32_t hidden, uint32_t act_type);
+// OutputRht (+ bias) of one or two raw output rows in place; row 0's first conv_dim channels go on through DeltaNetConvUpdate (conv_w non-null)
+uzu_status rht_out_rows(hipStream_t s, uint16_t* row0, const uint32_t* bits0, const uint16_t* bias0, uint32_t n0, uint16_t* row1, const uint32_t* bits1, const uint16_t* bias1,
+                        uint32_t n1, const float* conv_w, const float* conv_b, float* conv_state, uint32_t kernel_size, uint32_t conv_dim);
 uzu_status quantized_embedding_lookup(hipStream_t s, const uint32_t* token_ids, const uint8_t* weights,
                                       const void* scales, const uint8_t* zero_points, const void* biases, void* output,
                                       uint32_t dt, uint32_t batch_size, uint32_t vocab_size, uint32_t model_dim,
