@@ -37,7 +37,7 @@ def main():
     decode_us = (time.perf_counter() - t0) / 64 * 1e6
     tok = int(toks[-1])
     out = {"model": "qwen3.5-0.8b int4 g128 (synthetic weights)", "context": hm.context_length, "decode_us_per_token": round(decode_us, 1), "verify": []}
-    for m in (1, 2, 4, 8, 16):
+    for m in ([int(v) for v in os.environ["VERIFY_NODES"].split(",")] if os.environ.get("VERIFY_NODES") else (1, 2, 4, 8, 16)):  # VERIFY_NODES=16: one size (profiling runs)
         t_verify = t_accept = t_gpu = 0.0
         launches = 0
         for rep in range(reps + 1):  # rep 0 builds the pass's hipGraph: not timed
