@@ -165,6 +165,23 @@ def test_gated_act_mul_in_the_gemm_epilogue_is_bit_identical(hip_ctx):
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("rows", [2, 7, 16])
+def test_gated_act_mul_in_the_few_rows_kernel_is_bit_identical(hip_ctx, rows):
+    """A handful of rows (a speculative verify pass, a short prompt): the matrix-core few-rows kernel (k_gemv_rows.hip) owns the up AND the gate
+    rows of its output columns and applies GatedActMul in its epilogue; with UZU_MODEL_NO_FUSION the engine runs the same kernel without it
+    and gated_act_mul.rs's kernel behind it.  Same rounding points: bit-identical logits (groups of 128: the shapes the kernel takes)."""
+    cfg = S.tiny_qwen(group_size=128)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(rows, cfg.vocab_size)
+    outs = []
+    for flags in (0, MODEL_NO_FUSION):
+        hm = HipModel(hip_ctx, bundle, flags)
+        outs.append((hm.prefill(prompt), hm.read_logits(), hm.decode_launch_count))
+        hm.close()
+    assert outs[0][2] < outs[1][2], f"the fused epilogue was not taken ({outs[0][2]} vs {outs[1][2]} launches)"
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("heads,groups,context", [(10, 2, 2200), (6, 1, 1300)])
 def test_long_context_decode_and_odd_gqa_factors(hip_ctx, heads, groups, context):
     """A model whose context capacity is >= 4096: attn_dec takes its doubled key splits and serves 5 or 6 query heads of a KV head

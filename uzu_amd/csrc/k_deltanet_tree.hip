@@ -109,7 +109,7 @@ struct TreeSolveLds {
     float a_inv[kDnTreeMaxNodes / kBlock][kBlock][kBlock + 1];
     float kh0[kDnTreeMaxNodes][17], qh0[kDnTreeMaxNodes][17], u[kDnTreeMaxNodes][17];
     float acc[kBlock][17];
-    float prefix[kDnTreeMaxNodes], beta[kDnTreeMaxNodes];
+    float prefix[kDnTreeMaxNodes], beta[kDnTreeMaxNodes], log_decay[kDnTreeMaxNodes];
     uint32_t t_start[kDnTreeMaxNodes], t_end[kDnTreeMaxNodes];
 };
 __global__ void __launch_bounds__(256) dn_tree_solve_kernel(const uint16_t* __restrict__ q_in, const uint16_t* __restrict__ k_in, const uint16_t* __restrict__ v_in,
@@ -120,9 +120,19 @@ __global__ void __launch_bounds__(256) dn_tree_solve_kernel(const uint16_t* __re
     const uint32_t tid = threadIdx.x;
     const uint32_t tiles = D / 16, hv = blockIdx.x / tiles, c0 = (blockIdx.x % tiles) * 16, hk = hv / (Hv / Hk);
     const uint32_t key_dim = Hk * D, value_dim = Hv * D;
+    // every global operand is requested up front (round 4: the phases below used to start with a dependent global load each -- log decays inside
+    // the prefix loop, v inside the solve -- one exposed L2 / HBM round trip per phase of a 20 us kernel)
     if (tid < n) {
         L.t_start[tid] = trie[3 * tid], L.t_end[tid] = trie[3 * tid + 1];
         L.beta[tid] = beta_in[(size_t)tid * Hv + hv];
+        L.log_decay[tid] = log_decay[(size_t)tid * Hv + hv];
+    }
+    static_assert(kDnTreeMaxNodes / kBlock == 2, "v_pre is selected by hand below");
+    float v_pre[kDnTreeMaxNodes / kBlock]; // v of (token blk * kBlock + tid / 16, value column tid % 16), one per block of the solve
+#pragma unroll
+    for (uint32_t blk = 0; blk < kDnTreeMaxNodes / kBlock; ++blk) {
+        const uint32_t token = min(blk * kBlock + tid / 16, n - 1); // clamped: never consumed past n
+        v_pre[blk] = bf16_to_f32(v_in[(size_t)token * value_dim + hv * D + c0 + tid % 16]);
     }
     for (uint32_t idx = tid; idx < n * D; idx += 256) {
         const uint32_t row = idx / D, d = idx % D;
@@ -134,7 +144,7 @@ __global__ void __launch_bounds__(256) dn_tree_solve_kernel(const uint16_t* __re
     if (tid < n) { // prefix.rs:20-36: log decays of the ancestors-or-self, in column order
         float sum = 0.0f;
         for (uint32_t col = 0; col < n; ++col)
-            if (tid >= L.t_start[col] && tid <= L.t_end[col]) sum += log_decay[(size_t)col * Hv + hv];
+            if (tid >= L.t_start[col] && tid <= L.t_end[col]) sum += L.log_decay[col];
         L.prefix[tid] = sum;
     }
     __syncthreads();
@@ -164,19 +174,28 @@ __global__ void __launch_bounds__(256) dn_tree_solve_kernel(const uint16_t* __re
     const uint32_t nb = (n + kBlock - 1) / kBlock;
     if (tid < nb * kBlock) { // tree_gram.rs:98-128: (I + A_diag)^-1 by forward substitution; a thread owns one column of one block
         const uint32_t blk = tid / kBlock, col = tid % kBlock, bs = min(kBlock, n - blk * kBlock);
-        for (uint32_t row = 0; row < kBlock; ++row) L.a_inv[blk][row][col] = row == col ? 1.0f : 0.0f;
-        for (uint32_t row = col + 1; row < bs; ++row) {
-            float sum = 0.0f;
-            for (uint32_t prev = col; prev < row; ++prev) sum += L.a[blk * kBlock + row][blk * kBlock + prev] * L.a_inv[blk][prev][col];
-            L.a_inv[blk][row][col] = -sum;
+        float inv[kBlock]; // the thread's column stays in registers (the LDS copy made every row wait for the previous row's store)
+#pragma unroll
+        for (uint32_t row = 0; row < kBlock; ++row) inv[row] = row == col ? 1.0f : 0.0f;
+#pragma unroll
+        for (uint32_t row = 1; row < kBlock; ++row) {
+            if (row > col && row < bs) {
+                float sum = 0.0f;
+#pragma unroll
+                for (uint32_t prev = 0; prev < row; ++prev)
+                    if (prev >= col) sum += L.a[blk * kBlock + row][blk * kBlock + prev] * inv[prev];
+                inv[row] = -sum;
+            }
         }
+#pragma unroll
+        for (uint32_t row = 0; row < kBlock; ++row) L.a_inv[blk][row][col] = inv[row];
     }
     __syncthreads();
     const uint32_t lt = tid / 16, j = tid % 16; // (token of the block, value column)
     for (uint32_t blk = 0; blk < nb; ++blk) { // tree_update_solve.rs:58-127
         const uint32_t token = blk * kBlock + lt;
         if (token < n) {
-            const float v_val = bf16_to_f32(v_in[(size_t)token * value_dim + hv * D + c0 + j]);
+            const float v_val = blk == 0 ? v_pre[0] : v_pre[1]; // (kDnTreeMaxNodes / kBlock == 2 blocks; no dynamic register index)
             float acc = L.beta[token] * (v_val - expf_glibc(L.prefix[token]) * L.kh0[token][j]);
             for (uint32_t prev = 0; prev < blk * kBlock; ++prev) acc -= L.a[token][prev] * L.u[prev][j];
             L.acc[lt][j] = acc;

@@ -19,6 +19,7 @@
 //   * the workgroup's waves split K (steps w, w + NW, ...) and add their tiles through LDS in wave order.
 // Per 1 KiB of codes: 32 conversions + ~24 fold / broadcast VALU + 8 MFMAs for ALL 16 rows -- the M = 1 GEMV's instruction budget.
 // Results are tolerance-class against the scalar reference like every reduction kernel (f32 accumulation in another order).
+#include "decode_epilogue.h"
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -44,38 +45,51 @@ struct RowsParams {
     const uint16_t* out_bias; // [n] or null
     void* d;                  // [m, n] bf16 or f32
     uint32_t m, n, k, group_size, kind, d_f32;
+    uint32_t act_type; // ACT instances: n = 2 h weight rows [up | gate]; d = [m, h] = up * act(gate) (GatedActMul, gated_act_mul.rs:36-70)
 };
 
-template <int NW>
+// ACT: the workgroup owns the 16 up rows row0 .. and the 16 gate rows h + row0 .. (two accumulators, one activation stream), and its epilogue is
+// GatedActMul on the rounded pair -- the decode GEMV's act-mul epilogue (k_decode.hip) for a handful of rows: no [m, 2 h] round trip, no launch.
+template <int NW, bool ACT>
 __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
+    constexpr int NB = ACT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t gr_smem[];
     const uint32_t K = p.k, pitch = K * 2 + 16; // bytes per activation row in LDS (+16: rows start 4 banks apart)
     uint8_t* xs = gr_smem;                      // [16][pitch]
-    float* s_part = (float*)(gr_smem + 16 * pitch); // [NW][16 rows][16 tokens]
+    float* s_part = (float*)(gr_smem + 16 * pitch); // [NW][NB][16 rows][16 tokens]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t r = lane & 15, g = lane >> 4;
     const uint32_t row0 = blockIdx.x * 16;
     const uint32_t steps = K / 128, G = K / p.group_size, gshift = 31 - __builtin_clz(p.group_size);
     const uint32_t zp_stride = (G + 1) / 2;
-    // ---- weight row of this lane: clamped into range (a clamped row is computed and never stored)
-    const uint32_t wrow = min(row0 + r, p.n - 1);
+    // ---- weight row of this lane: clamped into range (a clamped row is computed and never stored); block 1 (ACT) = the gate rows, h further down
+    const uint32_t out_n = ACT ? p.n / 2 : p.n;
+    const uint32_t wrow = min(row0 + r, out_n - 1);
     const uint8_t* wp = p.w + (size_t)wrow * (K / 2) + 16 * g;
     // rows whose scale / offset this lane-group folds: 4 g + (lane % 4) (lanes 0..3 of the row carry them, the rest duplicate)
-    const uint32_t frow = min(row0 + 4 * g + (r & 3), p.n - 1);
-    auto load_step = [&](uint32_t s, uint4& codes, uint16_t& sc, uint16_t& of) {
-        const uint32_t sc_ = min(s, steps - 1); // past the end: a reload that is never consumed (keeps the loads countable)
-        codes = load16_stream(wp + (size_t)sc_ * 64);
-        const uint32_t grp = (sc_ * 128) >> gshift;
-        sc = p.scales[(size_t)frow * G + grp];
-        if (p.kind == UZU_MATMUL_B_SCALE_BIAS) of = p.biases[(size_t)frow * G + grp];
-        else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
-            const uint8_t z = p.zp[(size_t)frow * zp_stride + (grp >> 1)];
-            of = (grp & 1) ? (z >> 4) : (z & 0x0F);
-        } else of = 0;
+    const uint32_t frow = min(row0 + 4 * g + (r & 3), out_n - 1);
+    struct Step {
+        uint4 codes[NB];
+        uint16_t sc[NB], of[NB];
     };
-    uint4 cA, cB;
-    uint16_t scA, ofA, scB, ofB;
-    load_step(wave, cA, scA, ofA); // in flight while the activations are staged
+    auto load_step = [&](uint32_t s, Step& st) {
+        const uint32_t sc_ = min(s, steps - 1); // past the end: a reload that is never consumed (keeps the loads countable)
+        const uint32_t grp = (sc_ * 128) >> gshift;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const size_t wr = (size_t)wrow + (b ? out_n : 0), fr = (size_t)frow + (b ? out_n : 0);
+            st.codes[b] = load16_stream(p.w + wr * (K / 2) + 16 * g + (size_t)sc_ * 64);
+            st.sc[b] = p.scales[fr * G + grp];
+            if (p.kind == UZU_MATMUL_B_SCALE_BIAS) st.of[b] = p.biases[fr * G + grp];
+            else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+                const uint8_t z = p.zp[fr * zp_stride + (grp >> 1)];
+                st.of[b] = (grp & 1) ? (z >> 4) : (z & 0x0F);
+            } else st.of[b] = 0;
+        }
+    };
+    (void)wp;
+    Step stA, stB;
+    load_step(wave, stA); // in flight while the activations are staged
     // ---- stage the activation rows: 16-byte chunks (8 consecutive k) in the conversion's k order; rows >= m are zero
     {
         const uint32_t chunks_per_row = K / 8, total = 16 * chunks_per_row;
@@ -98,53 +112,75 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
     asm("" : "+v"(magic));
     asm("" : "+v"(ones));
     const gr_u32x4 ones4 = {ones, ones, ones, ones};
-    gr_f32x4 acc = {0.f, 0.f, 0.f, 0.f}; // rows 4 g + v of token r
+    gr_f32x4 acc[NB]; // rows 4 g + v of token r
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = gr_f32x4{0.f, 0.f, 0.f, 0.f};
     const uint8_t* xlane = xs + (size_t)r * pitch + 64 * g; // this lane's B chunks: token r, k0 + 32 g + 8 i
-    auto compute = [&](uint32_t s, const uint4& codes, uint16_t sc_bits, uint16_t of_bits) {
-        const uint32_t ws[4] = {codes.x, codes.y, codes.z, codes.w};
-        gr_f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](uint32_t s, const Step& st) {
+        gr_f32x4 dq[NB], dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dq[b] = gr_f32x4{0.f, 0.f, 0.f, 0.f};
         const uint8_t* xb = xlane + (size_t)s * 256;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            gr_u32x4 av;
-            av.x = ((ws[i] << 3) & mask) | magic, av.y = ((ws[i] >> 1) & mask) | magic, av.z = ((ws[i] >> 5) & mask) | magic, av.w = ((ws[i] >> 9) & mask) | magic;
             const gr_u32x4 bv = *(const gr_u32x4*)(xb + 16 * i);
-            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gr_bf16x8, av), __builtin_bit_cast(gr_bf16x8, bv), dq, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const uint32_t w = i == 0 ? st.codes[b].x : i == 1 ? st.codes[b].y : i == 2 ? st.codes[b].z : st.codes[b].w;
+                gr_u32x4 av;
+                av.x = ((w << 3) & mask) | magic, av.y = ((w >> 1) & mask) | magic, av.z = ((w >> 5) & mask) | magic, av.w = ((w >> 9) & mask) | magic;
+                dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gr_bf16x8, av), __builtin_bit_cast(gr_bf16x8, bv), dq[b], 0, 0, 0);
+            }
             dx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gr_bf16x8, ones4), __builtin_bit_cast(gr_bf16x8, bv), dx, 0, 0, 0);
         }
         // group fold: acc[v] += scale_v * dq[v] + (offset_v - 16 scale_v) * sum_x   (dx[v] = sum_k x of token r, the same in every v)
-        const float sc = bf16_to_f32(sc_bits);
-        float of;
-        if (p.kind == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(of_bits);
-        else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) of = -sc * (float)of_bits;
-        else of = -sc * 8.0f;
-        of = fmaf(-kQ4Offset, sc, of);
-        const float s0 = row_share<0>(sc), s1 = row_share<1>(sc), s2 = row_share<2>(sc), s3 = row_share<3>(sc);
-        const float o0 = row_share<0>(of), o1 = row_share<1>(of), o2 = row_share<2>(of), o3 = row_share<3>(of);
-        acc.x = fmaf(s0, dq.x, fmaf(o0, dx.x, acc.x));
-        acc.y = fmaf(s1, dq.y, fmaf(o1, dx.x, acc.y));
-        acc.z = fmaf(s2, dq.z, fmaf(o2, dx.x, acc.z));
-        acc.w = fmaf(s3, dq.w, fmaf(o3, dx.x, acc.w));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float sc = bf16_to_f32(st.sc[b]);
+            float of;
+            if (p.kind == UZU_MATMUL_B_SCALE_BIAS) of = bf16_to_f32(st.of[b]);
+            else if (p.kind == UZU_MATMUL_B_SCALE_ZERO_POINT) of = -sc * (float)st.of[b];
+            else of = -sc * 8.0f;
+            of = fmaf(-kQ4Offset, sc, of);
+            const float s0 = row_share<0>(sc), s1 = row_share<1>(sc), s2 = row_share<2>(sc), s3 = row_share<3>(sc);
+            const float o0 = row_share<0>(of), o1 = row_share<1>(of), o2 = row_share<2>(of), o3 = row_share<3>(of);
+            acc[b].x = fmaf(s0, dq[b].x, fmaf(o0, dx.x, acc[b].x));
+            acc[b].y = fmaf(s1, dq[b].y, fmaf(o1, dx.x, acc[b].y));
+            acc[b].z = fmaf(s2, dq[b].z, fmaf(o2, dx.x, acc[b].z));
+            acc[b].w = fmaf(s3, dq[b].w, fmaf(o3, dx.x, acc[b].w));
+        }
     };
     for (uint32_t s = wave; s < steps; s += 2 * NW) {
-        load_step(s + NW, cB, scB, ofB);
-        compute(s, cA, scA, ofA);
-        load_step(s + 2 * NW, cA, scA, ofA);
-        if (s + NW < steps) compute(s + NW, cB, scB, ofB);
+        load_step(s + NW, stB);
+        compute(s, stA);
+        load_step(s + 2 * NW, stA);
+        if (s + NW < steps) compute(s + NW, stB);
     }
     // ---- add the waves' tiles in wave order, bias, store: thread t = (row t / 16, token t % 16)
-    float* mine = s_part + (size_t)wave * 256;
-    mine[(4 * g + 0) * 16 + r] = acc.x, mine[(4 * g + 1) * 16 + r] = acc.y, mine[(4 * g + 2) * 16 + r] = acc.z, mine[(4 * g + 3) * 16 + r] = acc.w;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float* mine = s_part + ((size_t)wave * NB + b) * 256;
+        mine[(4 * g + 0) * 16 + r] = acc[b].x, mine[(4 * g + 1) * 16 + r] = acc[b].y, mine[(4 * g + 2) * 16 + r] = acc[b].z, mine[(4 * g + 3) * 16 + r] = acc[b].w;
+    }
     lds_barrier();
     if (tid < 256) {
         const uint32_t row = tid >> 4, j = tid & 15;
-        float v = s_part[tid];
+        float v[NB];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += s_part[w * 256 + tid];
-        if (j < p.m && row0 + row < p.n) {
-            float value = 1.0f * v; // MatmulKernel epilogue with ab_scale = 1 (kernel.rs:281-292)
+        for (int b = 0; b < NB; ++b) {
+            v[b] = s_part[b * 256 + tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v[b] += s_part[((size_t)w * NB + b) * 256 + tid];
+        }
+        if (j < p.m && row0 + row < out_n) {
+            float value = 1.0f * v[0]; // MatmulKernel epilogue with ab_scale = 1 (kernel.rs:281-292)
             if (p.out_bias) value += bf16_to_f32(p.out_bias[row0 + row]);
-            if (p.d_f32) ((float*)p.d)[(size_t)j * p.n + row0 + row] = value;
+            if constexpr (ACT) {
+                float gate = 1.0f * v[1];
+                if (p.out_bias) gate += bf16_to_f32(p.out_bias[out_n + row0 + row]);
+                const float up_b = round_bf16(value), gate_b = round_bf16(gate); // the rounded outputs the unfused pair of kernels would have stored
+                ((uint16_t*)p.d)[(size_t)j * out_n + row0 + row] = f32_to_bf16(round_bf16(up_b * act_bf16(p.act_type, gate_b, kExp2fTab))); // gated_act_mul/mod.rs:5-12
+            } else if (p.d_f32) ((float*)p.d)[(size_t)j * p.n + row0 + row] = value;
             else ((uint16_t*)p.d)[(size_t)j * p.n + row0 + row] = f32_to_bf16(value);
         }
     }
@@ -159,7 +195,8 @@ bool gemv_rows_mfma_supported(const MatmulParams& p) {
     if (!on || exact_mode()) return false;
     if (p.m < 2 || p.m > 16 || p.bits != 4 || p.b_kind == UZU_MATMUL_B_FULL_PRECISION) return false;
     if (p.w_dt != UZU_BF16 || p.a_dt != UZU_BF16 || (p.d_dt != UZU_BF16 && p.d_dt != UZU_F32)) return false;
-    if (p.signed_codes || p.ab_scale != 1.0f || p.accumulate || p.has_soft_cap || p.gather || p.act_mul) return false;
+    if (p.signed_codes || p.ab_scale != 1.0f || p.accumulate || p.has_soft_cap || p.gather) return false;
+    if (p.act_mul && ((p.n & 1) || p.d_dt != UZU_BF16)) return false; // GatedActMul epilogue: [up | gate] halves, bf16 out
     if (p.k % 128 || p.group_size % 128 || (p.group_size & (p.group_size - 1)) || p.k % p.group_size) return false;
     if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16) return false;
     if ((size_t)16 * (p.k * 2 + 16) + 8 * 256 * 4 > 150 * 1024) return false; // the staged activations must fit the CU's LDS
@@ -170,19 +207,23 @@ uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p) {
     RowsParams q{};
     q.a = (const uint16_t*)p.a, q.w = (const uint8_t*)p.b, q.scales = (const uint16_t*)p.scales, q.biases = (const uint16_t*)p.biases, q.zp = p.zero_points;
     q.out_bias = (const uint16_t*)p.bias, q.d = p.d, q.m = p.m, q.n = p.n, q.k = p.k, q.group_size = p.group_size, q.kind = p.b_kind, q.d_f32 = p.d_dt == UZU_F32;
-    const uint32_t blocks = (p.n + 15) / 16, steps = p.k / 128;
+    q.act_type = p.act_type;
+    const bool act = p.act_mul != 0;
+    const uint32_t blocks = ((act ? p.n / 2 : p.n) + 15) / 16, steps = p.k / 128;
     // eight waves split K where the row blocks alone leave most of the chip idle and there are steps to share
-    const bool wide = blocks < 256 && steps >= 16;
+    const bool wide = !act && blocks < 256 && steps >= 16;
     const int nw = wide ? 8 : 4;
-    const size_t lds = (size_t)16 * (p.k * 2 + 16) + (size_t)nw * 256 * 4;
-    static LdsLimit lim4, lim8;
-    if (!raise_lds_limit(wide ? lim8 : lim4, wide ? (const void*)gemv_rows_mfma_kernel<8> : (const void*)gemv_rows_mfma_kernel<4>, lds)) {
+    const size_t lds = (size_t)16 * (p.k * 2 + 16) + (size_t)nw * (act ? 2 : 1) * 256 * 4;
+    static LdsLimit lim4, lim8, lim_act;
+    const void* fn = act ? (const void*)gemv_rows_mfma_kernel<4, true> : wide ? (const void*)gemv_rows_mfma_kernel<8, false> : (const void*)gemv_rows_mfma_kernel<4, false>;
+    if (!raise_lds_limit(act ? lim_act : wide ? lim8 : lim4, fn, lds)) {
         set_error("gemv_rows: %zu bytes of LDS are not available", lds);
         return UZU_ERR_UNSUPPORTED;
     }
     return launch_check([&] {
-        if (wide) hipLaunchKernelGGL(gemv_rows_mfma_kernel<8>, dim3(blocks), dim3(512), lds, s, q);
-        else hipLaunchKernelGGL(gemv_rows_mfma_kernel<4>, dim3(blocks), dim3(256), lds, s, q);
+        if (act) hipLaunchKernelGGL((gemv_rows_mfma_kernel<4, true>), dim3(blocks), dim3(256), lds, s, q);
+        else if (wide) hipLaunchKernelGGL((gemv_rows_mfma_kernel<8, false>), dim3(blocks), dim3(512), lds, s, q);
+        else hipLaunchKernelGGL((gemv_rows_mfma_kernel<4, false>), dim3(blocks), dim3(256), lds, s, q);
     }, "gemv_rows_mfma");
 }
 

@@ -292,6 +292,7 @@ bool matmul_act_mul_supported(hipStream_t s, const MatmulParams& p, int num_cus)
     MatmulParams q = p;
     q.act_mul = 1;
     if (exact_mode() || q.b_kind == UZU_MATMUL_B_FULL_PRECISION || (uintptr_t)q.b % 16 || (uintptr_t)q.a % 16) return false;
+    if (gemv_rows_mfma_supported(q)) return true; // a handful of rows: the few-rows kernel carries the epilogue too (no workspace: fine under capture)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false; // no workspace during capture
     return gemm_q_mfma_supported(q) && gemm_q_mfma128_supported(q, num_cus);
