@@ -915,10 +915,11 @@ def test_delta_net_update(hip_ctx):
     assert ulp_diff_bf16(want, got).max() <= 2.0
 
 
-@pytest.mark.parametrize("T", [37, 64, 200, 1000])
+@pytest.mark.parametrize("T", [37, 64, 200, 513, 1000, 2043])
 def test_delta_net_prefill_path(hip_ctx, T):
     """conv_pack -> conv_scan -> prefill_prep -> prefill -> norm_gate against the oracle (GQA-style Hv = 2 Hk).
-    T = 37 runs the one/two-token recurrence, T >= 64 the chunked form (32-token chunks, ragged last chunk)."""
+    T = 37 runs the one/two-token recurrence, T >= 64 the chunked form (32-token chunks, ragged last chunk), from 16 chunks (T = 513, 1000, 2043) as
+    two concurrent segments + the S_mid fix-up (k_deltanet_chunk.hip: ScanSplit; T = 513: 9 + 8 chunks, the second segment ends on a 1-token chunk)."""
     rng = np.random.default_rng(15)
     Hv, Hk, Dk, Dv, ks = 4, 2, 128, 128, 4
     key_dim, value_dim = Hk * Dk, Hv * Dv

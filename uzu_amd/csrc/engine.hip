@@ -572,7 +572,13 @@ static void offset_tables(uzu_hip_model* m, const DLinear& L, const uint16_t* in
     if (input == m->normed && m->rs_rows == batch && m->rs_k == L.k && m->rs_group == L.group) p->pre_rowsum = m->rowsum;
 }
 
-void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false) {
+// `post`: the Normalization that reads `output` next (PostNorm below): a split-K prefill GEMM then ends with one reduction + epilogue + normalisation
+// launch and sets post->done; on every other path the caller runs the normalisation itself.
+struct PostNorm {
+    k::NormParams p{};
+    uint32_t done = 0;
+};
+void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false, PostNorm* post = nullptr) {
     if (L.lora_rank) return linear_qlora(e, L, input, output, batch); // (tensor-parallel shards of QLoRA linears are refused by the planner)
     const bool exchange = row_parallel && e.m->tp != nullptr;
     if (L.in_signs) {
@@ -591,10 +597,11 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
     p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f;
     p.m = batch, p.n = L.n, p.k = L.k;
     offset_tables(e.m, L, input, batch, &p);
+    if (post && !exchange && !L.out_signs && batch >= 128) p.post_norm = &post->p, p.post_norm_done = &post->done;
     const char* variant = "matmul";
     e.begin();
     const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
-    e.run(r, variant, k::matmul_algorithmic_bytes(p));
+    e.run(r, post && post->done ? "gemm_q_mfma128+norm" : variant, k::matmul_algorithmic_bytes(p));
     if (exchange) {
         const size_t count = (size_t)batch * L.n;
         RUN("all_reduce", count * 4, tp::all_reduce_sum_f32(e.m->tp, e.s, e.m->tp_buf, count, output)); // sums rounded to bf16 into `output`
@@ -633,7 +640,7 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
 
 // mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
 // `consumer`: the quantised linear that reads `output` next as a prefill GEMM: the kernel then files the group row sums of the rows it writes
-void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr) {
+k::NormParams norm_params(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr) {
     k::NormParams p{};
     p.input = input, p.scales = N.scales, p.biases = N.biases, p.output = output, p.shortcut = mode ? shortcut : nullptr;
     p.io_dt = UZU_BF16, p.affine_dt = UZU_F32;
@@ -642,12 +649,20 @@ void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint1
     p.subtract_mean = N.subtract_mean, p.full_layer = N.full_layer;
     p.copy_to_shortcut = mode != 0, p.residual_add = mode == 2;
     uzu_hip_model* m = e.m;
-    if (output == m->normed) m->rs_rows = 0; // whatever was filed for the old rows is stale
     if (consumer && consumer->coef && !consumer->in_signs && !consumer->lora_rank && output == m->normed && rows >= 128 && consumer->k == dim && !k::exact_mode() &&
-        k::normalization_rowsum_supported(dim, consumer->group) && (size_t)(dim / consumer->group) * ((rows + 3) & ~3u) <= m->rowsum_floats) {
+        k::normalization_rowsum_supported(dim, consumer->group) && (size_t)(dim / consumer->group) * ((rows + 3) & ~3u) <= m->rowsum_floats)
         p.rowsum_out = m->rowsum, p.rowsum_group = consumer->group;
-        m->rs_rows = rows, m->rs_k = dim, m->rs_group = consumer->group;
-    }
+    return p;
+}
+// book-keeping of the filed row sums, at the point where the normalisation `p` is ISSUED (its parameters may have been drawn up earlier: PostNorm)
+void norm_issued(uzu_hip_model* m, const k::NormParams& p) {
+    if (p.output != m->normed) return;
+    m->rs_rows = 0; // whatever was filed for the old rows is stale
+    if (p.rowsum_out) m->rs_rows = p.batch_size, m->rs_k = p.element_count, m->rs_group = p.rowsum_group;
+}
+void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr) {
+    const k::NormParams p = norm_params(e, N, input, output, shortcut, mode, rows, dim, consumer);
+    norm_issued(e.m, p);
     RUN("normalization", 0, k::normalization(e.s, p));
 }
 
@@ -681,7 +696,7 @@ struct Seqs {
 
 void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
 
-void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q) {
+void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr) {
     uzu_hip_model* m = e.m;
     const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
     const uint32_t rows = q.rows();
@@ -700,7 +715,7 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
         }
     }
     if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, rows * nq * hd));
-    linear(e, L.out, m->attn_out, out, rows, true);
+    linear(e, L.out, m->attn_out, out, rows, true, post);
 }
 
 // AttentionPrepare + attention of `batch` rows of the bound sequence, which start at row `row0` of qkv / queries / attn_out
@@ -760,7 +775,7 @@ void delta_net_tree_core(Enc& e, DLayer& L, uint32_t layer, uint32_t n) {
     RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, n));
 }
 
-void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q) {
+void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr) {
     uzu_hip_model* m = e.m;
     const uint32_t rows = q.rows();
     linear(e, L.in_proj, hidden, m->in_proj, rows);
@@ -774,7 +789,7 @@ void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
             delta_net_core(e, L, q.count, (size_t)i * q.count);
         }
     }
-    linear(e, L.out_proj, m->delta_out, out, rows, true);
+    linear(e, L.out_proj, m->delta_out, out, rows, true, post);
 }
 
 // conv + delta rule + norm-gate over `batch` rows of the bound sequence, starting at row `row0` of in_proj / delta_out
@@ -840,30 +855,54 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     if (m->embedding.out_signs)
         RUN("activation_transform", 0, k::activation_transform(s, nullptr, hidden, nullptr, nullptr, nullptr, m->embedding.out_signs, UZU_BF16, rows, d,
                                                                 UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
+    // Prefill-sized passes: a row-parallel projection whose rows go straight into the next Normalization hands that normalisation to its GEMM
+    // (PostNorm: the split-K reduction, the epilogue and the normalisation of a row are one launch).  `hidden_normed`: the pre-mixer normalisation of
+    // the layer about to run has been done that way by the previous layer's down projection.
+    bool hidden_normed = false;
     for (uint32_t l = 0; l < m->d.num_layers; ++l) {
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
         if (L.pre_mixer.present) {
-            norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d, L.d.mixer_kind == UZU_MIXER_ATTENTION ? &L.qkv : &L.in_proj);
+            if (!hidden_normed) norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d, L.d.mixer_kind == UZU_MIXER_ATTENTION ? &L.qkv : &L.in_proj);
             h = m->normed;
         } else {
             RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, rows * d));
         }
+        hidden_normed = false;
+        PostNorm mlp_norm; // the pre-MLP normalisation, offered to the mixer's out projection when nothing sits between them
+        const bool offer_mlp = !L.post_mixer.present && rows >= 128;
+        if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
-            attention_mixer(e, L, h, m->mixed, q);
+            attention_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr);
         else
-            delta_net_mixer(e, L, h, m->mixed, q);
+            delta_net_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr);
         const uint16_t* mixed = m->mixed;
         if (L.post_mixer.present) {
             norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, rows * d));
         }
-        norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
+        if (offer_mlp) {
+            norm_issued(m, mlp_norm.p);
+            if (!mlp_norm.done) RUN("normalization", 0, k::normalization(e.s, mlp_norm.p));
+        } else {
+            norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
+        }
         if (!linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
             linear(e, L.up, m->normed, m->up, rows);
             RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
         }
-        linear(e, L.down, m->gated, hidden, rows, true);
+        // the next layer's pre-mixer normalisation rides on this layer's down projection (not past the last layer: the output norm takes one row)
+        PostNorm next_norm;
+        const bool offer_next = rows >= 128 && !L.post_mlp.present && l + 1 < m->d.num_layers && m->layers[l + 1].pre_mixer.present;
+        if (offer_next) {
+            const DLayer& Nx = m->layers[l + 1];
+            next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, m->shortcut, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
+        }
+        linear(e, L.down, m->gated, hidden, rows, true, offer_next ? &next_norm : nullptr);
+        if (offer_next && next_norm.done) {
+            norm_issued(m, next_norm.p);
+            hidden_normed = true;
+        }
         if (L.post_mlp.present) {
             norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, rows * d));
@@ -1391,7 +1430,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     if (max_proj) {
         ALLOC(in_proj, uint16_t, CB * max_proj);
         ALLOC(delta_out, uint16_t, CB * max_value);
-        ALLOC(dn_ws, float, k::delta_net_chunk_workspace_bytes(max_hv, (uint32_t)C) / sizeof(float));
+        ALLOC(dn_ws, float, k::delta_net_chunk_workspace_bytes(max_hv, max_value, (uint32_t)C) / sizeof(float));
         ALLOC(dn_o, float, max_value);
         ALLOC(dn_sz, float, max_value);
         ALLOC(padded, float, (C + 8) * max_proj);

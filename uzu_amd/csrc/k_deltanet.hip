@@ -264,6 +264,68 @@ __global__ void __launch_bounds__(256) conv_apply_kernel(uint16_t* in_proj, cons
             for (uint32_t tap = 0; tap < taps; ++tap) state[(size_t)c * taps + tap] = halo[((size_t)nblocks * taps + tap) * conv_dim + c];
     }
 }
+// The same per-channel arithmetic for four neighbouring channels per thread (kernel size 4): the block's 16 rows are requested up front with 8-byte
+// accesses (the scalar kernel's 2-byte load -> SiLU -> 2-byte store chain in place cannot be reordered by the compiler: one exposed round trip per token),
+// weights / halo / bias as 16-byte vectors.
+__global__ void __launch_bounds__(256) conv_apply4_kernel(uint16_t* in_proj, const float* conv_weight, const float* bias, const float* halo, float* state,
+                                                          uint32_t suffix_len, uint32_t conv_dim, uint32_t out_stride, uint32_t nblocks) {
+    __shared__ uint64_t s_exp_tab[32];
+    if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
+    constexpr uint32_t KS = 4, taps = KS - 1;
+    const uint32_t cq = conv_dim / 4;
+    const size_t total = (size_t)nblocks * cq;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(idx % cq) * 4, b = (uint32_t)(idx / cq);
+        const uint32_t t_begin = b * CONV_TBLK, t_end = (b + 1) * CONV_TBLK < suffix_len ? (b + 1) * CONV_TBLK : suffix_len;
+        u32x2_v raw[CONV_TBLK];
+#pragma unroll
+        for (int i = 0; i < CONV_TBLK; ++i) {
+            const uint32_t t = t_begin + i < suffix_len ? t_begin + i : suffix_len - 1; // clamped rows are loaded and never consumed
+            raw[i] = *(const u32x2_v*)(in_proj + (size_t)t * out_stride + c);
+        }
+        float w[4][KS], win[4][taps], b0[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const f32x4_v wv = *(const f32x4_v*)(conv_weight + (size_t)(c + ch) * KS);
+            w[ch][0] = wv.x, w[ch][1] = wv.y, w[ch][2] = wv.z, w[ch][3] = wv.w;
+        }
+#pragma unroll
+        for (uint32_t tap = 0; tap < taps; ++tap) {
+            const f32x4_v hv = *(const f32x4_v*)(halo + ((size_t)b * taps + tap) * conv_dim + c);
+            win[0][tap] = hv.x, win[1][tap] = hv.y, win[2][tap] = hv.z, win[3][tap] = hv.w;
+        }
+        {
+            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_v bv = bias ? *(const f32x4_v*)(bias + c) : zero;
+            b0[0] = bv.x, b0[1] = bv.y, b0[2] = bv.z, b0[3] = bv.w;
+        }
+#pragma unroll
+        for (int i = 0; i < CONV_TBLK; ++i) {
+            if (t_begin + i >= t_end) break;
+            const float x[4] = {bits_to_f32(raw[i].x << 16), bits_to_f32(raw[i].x & 0xFFFF0000u), bits_to_f32(raw[i].y << 16), bits_to_f32(raw[i].y & 0xFFFF0000u)};
+            uint32_t y[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float acc = b0[ch]; // the reference's order: taps oldest first, the new token last (conv_scan.rs:44-52)
+#pragma unroll
+                for (uint32_t tap = 0; tap < taps; ++tap) acc += w[ch][tap] * win[ch][tap];
+                acc += w[ch][taps] * x[ch];
+                y[ch] = f32_to_bf16(silu_f32_tab(acc, s_exp_tab));
+#pragma unroll
+                for (uint32_t tap = 0; tap + 1 < taps; ++tap) win[ch][tap] = win[ch][tap + 1];
+                win[ch][taps - 1] = x[ch];
+            }
+            u32x2_v o;
+            o.x = y[0] | (y[1] << 16), o.y = y[2] | (y[3] << 16);
+            *(u32x2_v*)(in_proj + (size_t)(t_begin + i) * out_stride + c) = o;
+        }
+        if (b + 1 == nblocks) // these channels' carried state for the next pass
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+                for (uint32_t tap = 0; tap < taps; ++tap) state[(size_t)(c + ch) * taps + tap] = halo[((size_t)nblocks * taps + tap) * conv_dim + c + ch];
+    }
+}
 size_t delta_net_conv_fused_workspace_floats(uint32_t suffix_len, uint32_t kernel_size, uint32_t conv_dim) {
     return (size_t)((suffix_len + CONV_TBLK - 1) / CONV_TBLK + 1) * (kernel_size - 1) * conv_dim;
 }
@@ -279,6 +341,17 @@ uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* c
     const uint32_t gh = (uint32_t)((h_total + 255) / 256 > 4096 ? 4096 : (h_total + 255) / 256), ga = (uint32_t)((a_total + 255) / 256 > 8192 ? 8192 : (a_total + 255) / 256);
     UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(conv_halo_kernel, dim3(gh), dim3(256), 0, s, in_proj, state, halo, suffix_len, kernel_size, conv_dim, out_stride, nblocks); },
                                "conv_halo"));
+    static const bool wide = [] { // UZU_CONV_APPLY4=0: one channel per thread everywhere (A/B runs)
+        const char* e = getenv("UZU_CONV_APPLY4");
+        return !e || atoi(e) != 0;
+    }();
+    if (wide && kernel_size == 4 && conv_dim % 4 == 0 && out_stride % 4 == 0 && (((uintptr_t)in_proj | (uintptr_t)halo) & 15) == 0 &&
+        (((uintptr_t)conv_weight | (uintptr_t)bias) & 15) == 0) {
+        const size_t a4 = (size_t)nblocks * (conv_dim / 4);
+        const uint32_t g4 = (uint32_t)((a4 + 255) / 256 > 8192 ? 8192 : (a4 + 255) / 256);
+        return launch_check([&] { hipLaunchKernelGGL(conv_apply4_kernel, dim3(g4), dim3(256), 0, s, in_proj, conv_weight, bias, halo, state, suffix_len, conv_dim, out_stride,
+                                                     nblocks); }, "conv_apply4");
+    }
     return launch_check([&] { hipLaunchKernelGGL(conv_apply_kernel, dim3(ga), dim3(256), 0, s, in_proj, conv_weight, bias, halo, state, suffix_len, kernel_size, conv_dim,
                                                  out_stride, nblocks); }, "conv_apply");
 }
@@ -519,7 +592,7 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
     if (!rows || !suffix_len) return UZU_OK;
     if (delta_net_prefill_chunked_supported(num_v_heads, num_k_heads, head_k_dim, head_v_dim, suffix_len)) {
         // long suffix: chunked form; scratch = the stream's workspace block (not while the stream is being captured)
-        if (void* ws = stream_workspace(s, delta_net_chunk_workspace_bytes(num_v_heads, suffix_len)))
+        if (void* ws = stream_workspace(s, delta_net_chunk_workspace_bytes(num_v_heads, value_dim, suffix_len)))
             return delta_net_prefill_chunked(s, q_norm, k_norm, beta, decay, in_proj, state, out, (float*)ws, num_v_heads, num_k_heads, head_v_dim, key_dim,
                                              value_dim, suffix_len);
     }

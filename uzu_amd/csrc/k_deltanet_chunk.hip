@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "device_utils.h"
+#include "internal.h"
 #include "kernels.h"
 
 namespace uzu {
@@ -31,8 +32,43 @@ constexpr int TP = CC + 1;    // LDS row pitch of the 32 x 32 matrices
 constexpr int WS_FLOATS = 2 * CC * CC + 2 * CC; // per (chunk, value head): T, P, A, W
 } // namespace
 
-size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t suffix_len) {
-    return (size_t)((suffix_len + CC - 1) / CC) * num_v_heads * WS_FLOATS * sizeof(float);
+// Sequence split (round 4).  The chain of n chunk steps is the scan's whole cost (2.5 us per chunk with half of the CUs idle: 159 us per 2043-token pass
+// of the 0.8B model), and the recurrence is AFFINE in the state, row by row -- S_t[i,:] = S_{t-1}[i,:] a_t (I - b_t k_t k_t^T) + b_t v_t[i] k_t^T -- with the
+// same linear part for every row.  So the chunks [mid, n) do not have to wait for the chunks [0, mid): they run at the same time from a ZERO state with the
+// real values (Z_t, outputs Z_t q_t) and, as Dk more "value columns" per head, from the IDENTITY with zero values (H_t, outputs u_t = H_t q_t); then
+//     S_t = S_mid H_t + Z_t        o_t = Z_t q_t + S_mid u_t        (S_mid = the state after chunk mid - 1)
+// and `dn_chunk_fixup_kernel` adds the S_mid terms (one [tokens, Dk] x [Dk, Dv] product per head on the f32 matrix cores) before the outputs are rounded.
+// Twice the scan work for segment 1, on the CUs the single chain leaves idle.  Placement decides what that buys: as three 4-wave workgroups per tile
+// (first form, 384 workgroups) the pairs that happen to share a CU share its matrix pipes and run 3.6 us per chunk -- 116 us for 32 + 32 chunks.  Here a
+// segment-1 workgroup is EIGHT waves: group 0 the real tile, group 1 the homogeneous tile of the same head (same K / Q / T / P operands, staged once, each
+// group fetching half of them), one workgroup per CU, and segment 0 -- alone on its CUs at 2.5 us per chunk -- takes the larger share of the chunks.
+struct ScanSplit {
+    uint32_t mid_chunk; // 0: one segment (the plain scan)
+    float* mid_state;   // [Hv][Dv][Dk]  final state of segment 0
+    float* z_end;       // [Hv][Dv][Dk]  final state of segment 1 started from zero
+    float* h_end;       // [Hv][Dk][Dk]  final homogeneous rows of segment 1 (started from the identity)
+    float* o32;         // [T][Hv Dv] f32: the real tiles' own outputs (rows of segment 1: Z_t q_t; segment 0's rows are not read again)
+    float* u;           // [T - 32 mid][Hv Dk] f32: H_t q_t
+};
+static uint32_t split_mid_chunk(uint32_t n_chunks, uint32_t head_v_dim) {
+    static const uint32_t min_chunks = [] { // UZU_DN_SPLIT: chunks from which the scan is split (0 = never; A/B runs).  Below ~12 chunks the fix-up launch costs more than the shorter chain saves
+        const char* e = getenv("UZU_DN_SPLIT");
+        return e ? (uint32_t)atoi(e) : 16u;
+    }();
+    static const uint32_t pct = [] { // UZU_DN_SPLIT_PCT: segment 0's share of the chunks (its workgroups run ~2.5 us per chunk, segment 1's double groups ~3.4)
+        const char* e = getenv("UZU_DN_SPLIT_PCT");
+        const int v = e ? atoi(e) : 58;
+        return (uint32_t)(v < 10 ? 10 : v > 90 ? 90 : v);
+    }();
+    if (!min_chunks || n_chunks < min_chunks || head_v_dim != (uint32_t)DKC) return 0u; // (a segment-1 workgroup pairs value tile i with homogeneous tile i: Dv = Dk)
+    const uint32_t mid = (n_chunks * pct + 50) / 100;
+    return mid < 1 ? 1u : mid > n_chunks - 1 ? n_chunks - 1 : mid;
+}
+static size_t split_floats(uint32_t num_v_heads, uint32_t value_dim, uint32_t suffix_len) {
+    return (size_t)2 * value_dim * DKC + (size_t)num_v_heads * DKC * DKC + (size_t)suffix_len * value_dim + (size_t)suffix_len * num_v_heads * DKC;
+}
+size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim, uint32_t suffix_len) {
+    return ((size_t)((suffix_len + CC - 1) / CC) * num_v_heads * WS_FLOATS + split_floats(num_v_heads, value_dim, suffix_len)) * sizeof(float);
 }
 
 // grid (chunks, Hv), 256 threads
@@ -285,6 +321,288 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_
         for (int r = 0; r < 4; ++r) sbase[(size_t)r * DKC + 16 * t] = creg[t][r];
 }
 
+// The split scan (ScanSplit).  grid (2 Dv / 16, Hv), 512 threads = two groups of the plain kernel's four waves; the stage code is the plain kernel's.
+//   workgroups [0, Dv / 16) of a head: segment 0, chunks [0, mid): group 0 = the value tile from the carried state, group 1 only stages operands;
+//   the others:                        segment 1, chunks [mid, n): group 0 = the value tile from a zero state, group 1 = the homogeneous tile (identity, v = 0).
+// Shared LDS operands K, Q, T, P, A, W: group 0's threads fetch and publish K and T, group 1's Q and P (pointer selects, no branch: a role-dependent branch
+// around global loads or stores makes the compiler wait for every outstanding load at the join -- the next chunk's operands fetched ahead: 2.5 -> 3.8 us per
+// chunk in the first form).  Every output goes to an f32 row of its role's buffer AND, rounded, to the output row, through one store path.
+__global__ void __launch_bounds__(512) dn_chunk_scan_dual_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, const float* state,
+                                                                 uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
+                                                                 uint32_t suffix_len, ScanSplit sp) {
+    constexpr int DVT = 16, TPP = 36, RPP = 18;
+    extern __shared__ __attribute__((aligned(16))) float dual_smem[];
+    float* sK = dual_smem;                 // [CC][KP]
+    float* sQ = sK + CC * KP;              // [CC][KP]
+    float* sT = sQ + CC * KP;              // [CC][TPP]
+    float* sP = sT + CC * TPP;             // [CC][TPP]
+    float* sA = sP + CC * TPP;             // [CC]
+    float* sW = sA + CC;                   // [CC]
+    float* grp_base = sW + CC;             // per group: sS [DVT][KP], sR / sD / sDw [CC][RPP]
+    constexpr int GRP_FLOATS = DVT * KP + 3 * CC * RPP;
+    const int tid = threadIdx.x, grp = tid >> 8, ltid = tid & 255, lane = ltid & 63, wave = ltid >> 6, i16 = lane & 15, kq = lane >> 4;
+    float* sS = grp_base + grp * GRP_FLOATS;
+    float* sR = sS + DVT * KP;
+    float* sD = sR + CC * RPP;
+    float* sDw = sD + CC * RPP;
+    uint32_t hv = blockIdx.y, tile = blockIdx.x;
+    { // XCD-aware numbering as in the plain kernel: a head's workgroups share one L2
+        const uint32_t nx = gridDim.x, total = nx * gridDim.y, lin = blockIdx.x + nx * blockIdx.y;
+        if (total % 8 == 0) {
+            const uint32_t pair = (lin % 8) * (total / 8) + lin / 8;
+            hv = pair / nx, tile = pair % nx;
+        }
+    }
+    const uint32_t tiles_v = head_v_dim / DVT;
+    const bool seg1 = tile >= tiles_v;
+    if (seg1) tile -= tiles_v;
+    const bool active = seg1 || grp == 0;   // group 1 of a segment-0 workgroup only stages operands
+    const bool homog = seg1 && grp == 1;
+    const uint32_t dv_base = tile * DVT, hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t conv_dim = 2 * key_dim + value_dim;
+    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
+    const uint32_t c_begin = seg1 ? sp.mid_chunk : 0u, c_end = seg1 ? n_chunks : sp.mid_chunk;
+    // f32 output row of token t = o32[t * o_stride] (real tiles: the shared [T][Hv Dv] buffer; homogeneous tile: u, whose row 0 is token 32 mid)
+    const size_t o_stride = homog ? (size_t)num_v_heads * DKC : (size_t)value_dim;
+    float* o32 = homog ? sp.u + (size_t)hv * DKC + dv_base + i16 - (size_t)sp.mid_chunk * CC * o_stride : sp.o32 + (size_t)hv * head_v_dim + dv_base + i16;
+    // ... and, rounded, to the bf16 output row as well: final for segment 0 (its outputs need nothing more), overwritten by the fix-up for segment 1 (whose two
+    // groups write the same cells: Dv = Dk) -- one store path for every role, and the fix-up has no conversion pass over segment 0
+    uint16_t* out16 = out + (size_t)hv * head_v_dim + dv_base + i16;
+    const uint32_t store_end = active ? suffix_len : 0u;
+    const uint32_t v_keep = (active && !homog) ? 0xFFFFFFFFu : 0u; // the homogeneous rows have zero values
+
+    // state in accumulator layout (plain kernel): creg[t][r] = S[dv = 4 kq + r][dk = 16 (2 wave + t) + i16]
+    f32x4_v creg[2];
+    {
+        const float* sinit = state + ((size_t)hv * head_v_dim + dv_base + 4 * kq) * DKC + 32 * wave + i16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                creg[t][r] = (!seg1 && grp == 0) ? sinit[(size_t)r * DKC + 16 * t] : (homog && dv_base + 4 * kq + r == (uint32_t)(32 * wave + 16 * t + i16)) ? 1.0f : 0.0f;
+    }
+
+    // ---- operand staging: this group's half of the shared operands (K + T | Q + P), A / W, its value rows
+    const float* kq_src = grp ? q_norm : k_norm;
+    float* kq_dst = grp ? sQ : sK;
+    float* tp_dst = grp ? sP : sT;
+    const uint32_t tp_off = grp ? CC * CC : 0;
+    f32x4_v st_kq[4];
+    float st_tp[4], st_a = 0.f, st_w = 0.f, st_v[4];
+    const int v_row = 16 * (wave & 1) + 4 * kq;
+    auto fetch = [&](uint32_t c) {
+        const uint32_t t0 = c * CC;
+        const float* w_t = ws + ((size_t)c * num_v_heads + hv) * WS_FLOATS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = ltid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            const bool live = t0 + t < suffix_len;
+            const size_t tok = live ? t0 + t : suffix_len - 1; // clamped + zeroed: unconditional loads stay countable
+            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_v xv = *(const f32x4_v*)(kq_src + tok * key_dim + hk * DKC + c4 * 4);
+            st_kq[r] = live ? xv : zero;
+            st_tp[r] = w_t[tp_off + idx];
+        }
+        st_a = w_t[2 * CC * CC + (ltid & (CC - 1))], st_w = w_t[2 * CC * CC + CC + (ltid & (CC - 1))];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = t0 + v_row + r < suffix_len;
+            const float vv = bf16_to_f32(in_proj[(size_t)(live ? t0 + v_row + r : suffix_len - 1) * total_proj_dim + 2 * key_dim + hv * head_v_dim + dv_base + i16]);
+            st_v[r] = live ? vv : 0.f;
+        }
+    };
+    float vreg[4] = {0.f, 0.f, 0.f, 0.f};
+    auto publish = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = ltid + 256 * r, t = idx / (DKC / 4), c4 = idx % (DKC / 4);
+            *(f32x4_v*)(kq_dst + t * KP + c4 * 4) = st_kq[r];
+            tp_dst[(idx / CC) * TPP + idx % CC] = st_tp[r];
+        }
+        if (tid < CC) sA[tid] = st_a, sW[tid] = st_w;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sS[(4 * kq + r) * KP + 32 * wave + 16 * t + i16] = creg[t][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vreg[r] = bits_to_f32(f32_to_bits(st_v[r]) & v_keep); // (masked here, not at the load: a role condition in `fetch` puts the loads behind branches)
+    };
+    auto mfma4 = [](float a, float b, f32x4_v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
+
+    fetch(c_begin);
+    publish();
+    __syncthreads();
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+        const uint32_t t0 = c * CC;
+        fetch(c + 1 < c_end ? c + 1 : c); // unconditional (the last chunk refetches itself)
+        // ---- stage 1: rows 16 (wave & 1) .. + 16 of K (waves 0, 1) or Q (waves 2, 3) against S^T
+        f32x4_v acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            const float* xr = (wave < 2 ? sK : sQ) + (16 * (wave & 1) + i16) * KP + 32 * kq;
+            const float* sr = sS + i16 * KP + 32 * kq;
+            f32x4_v xa[8], sb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xa[q] = *(const f32x4_v*)(xr + 4 * q), sb[q] = *(const f32x4_v*)(sr + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1 = mfma4(xa[q][e], sb[q][e], acc1);
+            if (wave < 2) { // R = V - A (K S^T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sR[(v_row + r) * RPP + i16] = vreg[r] - sA[v_row + r] * acc1[r];
+            }
+        }
+        lds_barrier();
+        // ---- stage 2 (waves 0, 1): D = T R
+        if (active && wave < 2) {
+            const float* tr = sT + (16 * wave + i16) * TPP + 8 * kq;
+            const f32x4_v ta0 = *(const f32x4_v*)tr, ta1 = *(const f32x4_v*)(tr + 4);
+            f32x4_v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) d = mfma4(s2 < 4 ? ta0[s2 & 3] : ta1[s2 & 3], sR[(8 * kq + s2) * RPP + i16], d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * wave + 4 * kq + r;
+                sD[t * RPP + i16] = d[r];
+                sDw[t * RPP + i16] = d[r] * sW[t];
+            }
+        }
+        lds_barrier();
+        // ---- stage 3 (waves 2, 3): O = A (Q S^T) + P D
+        if (active && wave >= 2) {
+            const int tb = 16 * (wave - 2);
+            const float* pr = sP + (tb + i16) * TPP + 8 * kq;
+            const f32x4_v pa0 = *(const f32x4_v*)pr, pa1 = *(const f32x4_v*)(pr + 4);
+            f32x4_v o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = sA[tb + 4 * kq + r] * acc1[r];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) o = mfma4(s2 < 4 ? pa0[s2 & 3] : pa1[s2 & 3], sD[(8 * kq + s2) * RPP + i16], o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t t = t0 + tb + 4 * kq + r;
+                if (t < store_end) {
+                    o32[(size_t)t * o_stride] = o[r];
+                    out16[(size_t)t * value_dim] = f32_to_bf16(o[r]);
+                }
+            }
+        }
+        // ---- stage 4: S = A_C S + (D W)^T K
+        if (active) {
+            const float a_c = sA[CC - 1];
+            float dw[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) dw[s2] = sDw[(8 * kq + s2) * RPP + i16];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) creg[t][r] *= a_c;
+                const float* kc = sK + (8 * kq) * KP + 32 * wave + 16 * t + i16;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) creg[t] = mfma4(dw[s2], kc[s2 * KP], creg[t]);
+            }
+        }
+        lds_barrier();
+        if (c + 1 < c_end) publish();
+        lds_barrier();
+    }
+    if (active) {
+        float* sfin = homog  ? sp.h_end + ((size_t)hv * DKC + dv_base + 4 * kq) * DKC + 32 * wave + i16
+                      : seg1 ? sp.z_end + ((size_t)hv * head_v_dim + dv_base + 4 * kq) * DKC + 32 * wave + i16
+                             : sp.mid_state + ((size_t)hv * head_v_dim + dv_base + 4 * kq) * DKC + 32 * wave + i16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sfin[(size_t)r * DKC + 16 * t] = creg[t][r];
+    }
+}
+constexpr size_t kDualLdsBytes = (size_t)(2 * CC * KP + 2 * CC * 36 + 2 * CC + 2 * (16 * KP + 3 * CC * 18)) * sizeof(float);
+
+// The S_mid terms of a split scan (see ScanSplit).  grid (tok_blocks + Dk / 16, Hv), 4 waves;
+// v_mfma_f32_16x16x4_f32 with the operand layout of the scan (lane l: row / column l % 16, contraction indices 32 (l / 16) + s over 32 steps: a lane's
+// 32 operand values are consecutive in memory).  Dv = Dk = 128 (split_mid_chunk).
+//   the first tok_blocks:    64 tokens of segment 1:   out[t, dv] = bf16(o32[t, dv] + sum_dk u[t, dk] S_mid[dv, dk])    wave w = tokens 16 w ..: A = its u rows,
+//                                                      B = S_mid rows from LDS (the head's state staged once per workgroup: one global round trip in all)
+//   the last Dk / 16 blocks: 16 state columns:         S[dv, dk] = z_end[dv, dk] + sum_j S_mid[dv, j] h_end[j, dk]       A = S_mid rows, B = h_end columns
+constexpr int FIX_TOK = 64;
+constexpr size_t kFixLdsBytes = (size_t)DKC * KP * sizeof(float); // S_mid of one head, rows 4 banks apart
+__global__ void __launch_bounds__(256) dn_chunk_fixup_kernel(ScanSplit sp, float* state, uint16_t* out, uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim,
+                                                             uint32_t suffix_len) {
+    constexpr uint32_t DV_TILES = DKC / 16;
+    extern __shared__ __attribute__((aligned(16))) float fix_smem[]; // [Dv][KP]: S_mid of the head (token blocks)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kq = lane >> 4;
+    const uint32_t hv = blockIdx.y, t_mid = sp.mid_chunk * CC, T2 = suffix_len - t_mid;
+    const uint32_t tok_blocks = (T2 + FIX_TOK - 1) / FIX_TOK;
+    const float* smid = sp.mid_state + (size_t)hv * head_v_dim * DKC;
+    auto mfma4 = [](float a, float b, f32x4_v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
+    // the token blocks come first in the grid: they are the long ones (one global round trip + 256 matrix instructions per wave)
+    if (blockIdx.x < tok_blocks) {
+        // every global operand is requested before anything is consumed: S_mid (16 x 16 bytes per thread, through LDS), this wave's u rows, its o32 values
+        f32x4_v sm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm[r] = *(const f32x4_v*)(smid + (size_t)(tid + 256 * r) * 4);
+        const uint32_t tok = blockIdx.x * FIX_TOK + 16 * wave; // this wave's 16 tokens, relative to segment 1 (past the end: computed on clamped rows, never stored)
+        const size_t u_stride = (size_t)num_v_heads * DKC;
+        const uint32_t row = min(tok + (uint32_t)i16, T2 - 1); // A: row = token
+        const float* ur = sp.u + (size_t)row * u_stride + hv * DKC + 32 * kq;
+        f32x4_v ua[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ua[q] = *(const f32x4_v*)(ur + 4 * q);
+        float prev[DV_TILES][4]; // this lane's o32 values: rows 4 kq + r, column 16 vt + i16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t t = min(tok + 4 * kq + r, T2 - 1);
+            const float* pr = sp.o32 + (size_t)(t_mid + t) * value_dim + (size_t)hv * head_v_dim + i16;
+#pragma unroll
+            for (uint32_t vt = 0; vt < DV_TILES; ++vt) prev[vt][r] = pr[vt * 16];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t e = (tid + 256 * r) * 4; // element of the [Dv][Dk] state
+            *(f32x4_v*)(fix_smem + (e / DKC) * KP + e % DKC) = sm[r];
+        }
+        lds_barrier();
+#pragma unroll
+        for (uint32_t vt = 0; vt < DV_TILES; ++vt) {
+            const float* br = fix_smem + (vt * 16 + i16) * KP + 32 * kq; // B: column dv = 16 vt + i16
+            f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4_v b = *(const f32x4_v*)(br + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma4(ua[q][e], b[e], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // rows = tokens 4 kq + r of the tile, column = dv
+                const uint32_t t = tok + 4 * kq + r;
+                if (t < T2) out[(size_t)(t_mid + t) * value_dim + (size_t)hv * head_v_dim + vt * 16 + i16] = f32_to_bf16(prev[vt][r] + acc[r]);
+            }
+        }
+    } else {
+        const uint32_t dk0 = (blockIdx.x - tok_blocks) * 16;
+        const float* hend = sp.h_end + (size_t)hv * DKC * DKC;
+        float hb[32]; // B: column dk = dk0 + i16, contraction index j = 32 kq + s
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) hb[s2] = hend[(size_t)(32 * kq + s2) * DKC + dk0 + i16];
+        for (uint32_t vt = wave; vt < DV_TILES; vt += 4) {
+            const float* ar = smid + (size_t)(vt * 16 + i16) * DKC + 32 * kq; // A: row dv = 16 vt + i16
+            f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4_v a = *(const f32x4_v*)(ar + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma4(a[e], hb[4 * q + e], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // rows dv = 16 vt + 4 kq + r, column dk
+                const size_t idx = ((size_t)hv * head_v_dim + vt * 16 + 4 * kq + r) * DKC + dk0 + i16;
+                state[idx] = sp.z_end[idx] + acc[r];
+            }
+        }
+    }
+}
+
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
     if (exact_mode()) return false; // reference-order mode: the token-by-token recurrence in the reference's own loop order (k_exact.hip)
     static const uint32_t min_t = [] {
@@ -302,10 +620,34 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         hipLaunchKernelGGL(dn_chunk_prep_kernel, dim3(n_chunks, num_v_heads), dim3(256), 0, s, q_norm, k_norm, beta, decay, workspace, num_v_heads, num_k_heads,
                            key_dim, suffix_len);
     }, "delta_net_chunk_prep"));
+    ScanSplit sp{};
+    sp.mid_chunk = value_dim == num_v_heads * head_v_dim ? split_mid_chunk(n_chunks, head_v_dim) : 0u;
+    static LdsLimit dual_lds;
+    static LdsLimit fix_lds;
+    if (sp.mid_chunk && !(raise_lds_limit(dual_lds, (const void*)dn_chunk_scan_dual_kernel, kDualLdsBytes) && raise_lds_limit(fix_lds, (const void*)dn_chunk_fixup_kernel, kFixLdsBytes)))
+        sp.mid_chunk = 0; // (74 KB / 68 KB of LDS per workgroup)
+    if (!sp.mid_chunk)
+        return launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
+                               num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+        }, "delta_net_chunk_scan");
+    { // the split's pieces live behind the T / P matrices (delta_net_chunk_workspace_bytes)
+        float* w = workspace + (size_t)n_chunks * num_v_heads * WS_FLOATS;
+        sp.mid_state = w, w += (size_t)value_dim * DKC;
+        sp.z_end = w, w += (size_t)value_dim * DKC;
+        sp.h_end = w, w += (size_t)num_v_heads * DKC * DKC;
+        sp.o32 = w, w += (size_t)suffix_len * value_dim;
+        sp.u = w;
+    }
+    UZU_PROPAGATE(launch_check([&] {
+        hipLaunchKernelGGL(dn_chunk_scan_dual_kernel, dim3(2 * (head_v_dim / 16), num_v_heads), dim3(512), kDualLdsBytes, s, q_norm, k_norm, in_proj, workspace,
+                           (const float*)state, out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, sp);
+    }, "delta_net_chunk_scan_dual"));
+    const uint32_t t_mid = sp.mid_chunk * CC, t2 = suffix_len - t_mid;
     return launch_check([&] {
-        hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
-                           num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
-    }, "delta_net_chunk_scan");
+        hipLaunchKernelGGL(dn_chunk_fixup_kernel, dim3((t2 + FIX_TOK - 1) / FIX_TOK + DKC / 16, num_v_heads), dim3(256), kFixLdsBytes, s, sp, state, out,
+                           num_v_heads, head_v_dim, value_dim, suffix_len);
+    }, "delta_net_chunk_fixup");
 }
 
 } // namespace k

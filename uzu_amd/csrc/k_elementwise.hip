@@ -82,8 +82,11 @@ __global__ void __launch_bounds__(256) normalization_kernel(NormParams p) {
 // bf16 rows of 1024 NV elements: the same arithmetic in the same order (thread t owns elements [4 NV t, 4 NV (t + 1)), one chain, block_sum4)
 // with the row in registers between the two passes and 8-byte loads / stores -- the general kernel re-reads what it has just written to the
 // shortcut (a store -> load round trip through the L2) with 2-byte accesses: 6.9 -> ~4.5 us per 1024 x 1024 prefill chunk.
-template <int NV, class TA>
-__global__ void __launch_bounds__(256) normalization_rows_kernel(NormParams p) {
+// PART: the input rows are still the split-K partial tiles of the GEMM that produces them (k_gemm128.hip): the thread adds its elements' partials in
+// split order, applies the GEMM's epilogue (bias), rounds and stores the GEMM's output -- gemm_split_reduce_kernel's arithmetic and result -- and goes
+// on with the rounded values: one launch and one round trip of the rows instead of two.
+template <int NV, class TA, bool PART>
+__global__ void __launch_bounds__(256) normalization_rows_kernel(NormParams p, NormPartials sp) {
     __shared__ float red[8];
     constexpr uint32_t E = 4 * NV;
     const uint32_t n = p.element_count;
@@ -95,9 +98,26 @@ __global__ void __launch_bounds__(256) normalization_rows_kernel(NormParams p) {
     u32x2_v sraw[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const u32x2_v raw = *(const u32x2_v*)(input + off + e0 + 4 * j);
-        v[4 * j] = bits_to_f32(raw.x << 16), v[4 * j + 1] = bits_to_f32(raw.x & 0xFFFF0000u);
-        v[4 * j + 2] = bits_to_f32(raw.y << 16), v[4 * j + 3] = bits_to_f32(raw.y & 0xFFFF0000u);
+        if constexpr (PART) {
+            const size_t idx = off + e0 + 4 * j;
+            f32x4_v acc = *(const f32x4_v*)(sp.partials + idx);
+            for (uint32_t z = 1; z < sp.splits; ++z) acc += *(const f32x4_v*)(sp.partials + (size_t)z * sp.total + idx);
+            float val[4] = {1.0f * acc.x, 1.0f * acc.y, 1.0f * acc.z, 1.0f * acc.w}; // ab_scale = 1 (checked by the caller)
+            if (sp.bias) {
+                const u32x2_v braw = *(const u32x2_v*)(sp.bias + e0 + 4 * j);
+                val[0] += bits_to_f32(braw.x << 16), val[1] += bits_to_f32(braw.x & 0xFFFF0000u), val[2] += bits_to_f32(braw.y << 16), val[3] += bits_to_f32(braw.y & 0xFFFF0000u);
+            }
+            u32x2_v o;
+            o.x = (uint32_t)f32_to_bf16(val[0]) | ((uint32_t)f32_to_bf16(val[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(val[2]) | ((uint32_t)f32_to_bf16(val[3]) << 16);
+            *(u32x2_v*)(sp.d + idx) = o; // the GEMM's output rows, as the separate reduction writes them
+            v[4 * j] = bits_to_f32(o.x << 16), v[4 * j + 1] = bits_to_f32(o.x & 0xFFFF0000u);
+            v[4 * j + 2] = bits_to_f32(o.y << 16), v[4 * j + 3] = bits_to_f32(o.y & 0xFFFF0000u);
+        } else {
+            const u32x2_v raw = *(const u32x2_v*)(input + off + e0 + 4 * j);
+            v[4 * j] = bits_to_f32(raw.x << 16), v[4 * j + 1] = bits_to_f32(raw.x & 0xFFFF0000u);
+            v[4 * j + 2] = bits_to_f32(raw.y << 16), v[4 * j + 3] = bits_to_f32(raw.y & 0xFFFF0000u);
+        }
         if (p.copy_to_shortcut && p.residual_add) sraw[j] = *(const u32x2_v*)(shortcut + off + e0 + 4 * j);
     }
     float sum = 0.f, sum_sq = 0.f;
@@ -191,11 +211,12 @@ uzu_status normalization(hipStream_t s, const NormParams& p) {
     if (fast_rows && p.io_dt == UZU_BF16 && p.batch_size >= 16 && p.element_count % 1024 == 0 && (p.affine_dt == UZU_F32 || p.affine_dt == UZU_BF16) &&
         (((uintptr_t)p.input | (uintptr_t)p.output | (uintptr_t)p.shortcut) & 7) == 0) {
         const uint32_t nv = p.element_count / 1024;
+        const NormPartials none{};
 #define UZU_ROWS(NVV)                                                                                                                            \
     case NVV:                                                                                                                                    \
         if (p.affine_dt == UZU_F32)                                                                                                              \
-            return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, float>), dim3(p.batch_size), dim3(256), 0, s, p); }, "normalization"); \
-        return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, bf16_t>), dim3(p.batch_size), dim3(256), 0, s, p); }, "normalization");
+            return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, float, false>), dim3(p.batch_size), dim3(256), 0, s, p, none); }, "normalization"); \
+        return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, bf16_t, false>), dim3(p.batch_size), dim3(256), 0, s, p, none); }, "normalization");
         switch (nv) {
             UZU_ROWS(1)
             UZU_ROWS(2)
@@ -214,6 +235,39 @@ uzu_status normalization(hipStream_t s, const NormParams& p) {
         set_error("normalization: unsupported affine dtype %u", p.affine_dt);
         return UZU_ERR_UNSUPPORTED;
     });
+}
+
+// Split-K reduction + the GEMM's epilogue + the Normalization of the rows it produces, one launch (normalization_rows_kernel<.., true>).
+bool normalization_from_partials_supported(const NormParams& p, const NormPartials& sp) {
+    static const bool on = [] { // UZU_NORM_PARTIALS=0: the reduction and the normalisation as two launches (A/B runs)
+        const char* e = getenv("UZU_NORM_PARTIALS");
+        return !e || atoi(e) != 0;
+    }();
+    if (!on || exact_mode() || p.io_dt != UZU_BF16 || p.batch_size < 16 || p.element_count % 1024 || (p.affine_dt != UZU_F32 && p.affine_dt != UZU_BF16)) return false;
+    const uint32_t nv = p.element_count / 1024;
+    if (nv != 1 && nv != 2 && nv != 4 && nv != 5 && nv != 8) return false;
+    if (!sp.partials || sp.splits < 2 || !sp.d || sp.total != (size_t)p.batch_size * p.element_count) return false;
+    if (p.rowsum_out && !normalization_rowsum_supported(p.element_count, p.rowsum_group)) return false;
+    return ((((uintptr_t)p.output | (uintptr_t)p.shortcut | (uintptr_t)sp.d | (uintptr_t)sp.bias) & 7) == 0) && ((uintptr_t)sp.partials & 15) == 0;
+}
+uzu_status normalization_from_partials(hipStream_t s, const NormParams& p, const NormPartials& sp) {
+    const uint32_t nv = p.element_count / 1024;
+#define UZU_ROWS(NVV)                                                                                                                            \
+    case NVV:                                                                                                                                    \
+        if (p.affine_dt == UZU_F32)                                                                                                              \
+            return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, float, true>), dim3(p.batch_size), dim3(256), 0, s, p, sp); }, "normalization_partials"); \
+        return launch_check([&] { hipLaunchKernelGGL((normalization_rows_kernel<NVV, bf16_t, true>), dim3(p.batch_size), dim3(256), 0, s, p, sp); }, "normalization_partials");
+    switch (nv) {
+        UZU_ROWS(1)
+        UZU_ROWS(2)
+        UZU_ROWS(4)
+        UZU_ROWS(5)
+        UZU_ROWS(8)
+    default: break;
+    }
+#undef UZU_ROWS
+    set_error("normalization_from_partials: %u elements per row", p.element_count);
+    return UZU_ERR_UNSUPPORTED;
 }
 
 // =============================================================== QKVNorm

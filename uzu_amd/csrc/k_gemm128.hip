@@ -512,6 +512,14 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
 #undef UZU_LAUNCH
     if (st != UZU_OK || splits == 1) return st;
     const size_t total = (size_t)p.m * p.n;
+    if (p.post_norm && p.post_norm_done) { // the rows go straight into a Normalization: reduction + epilogue + normalisation as one launch
+        const NormPartials sp{partials, splits, total, (const uint16_t*)p.bias, (uint16_t*)p.d};
+        if (p.ab_scale == 1.0f && !p.accumulate && !p.has_soft_cap && p.d_dt == UZU_BF16 && p.w_dt == UZU_BF16 && p.post_norm->batch_size == p.m &&
+            p.post_norm->element_count == p.n && normalization_from_partials_supported(*p.post_norm, sp)) {
+            *p.post_norm_done = 1;
+            return normalization_from_partials(s, *p.post_norm, sp);
+        }
+    }
     return launch_check([&] { hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, p, partials, splits); }, "gemm_split_reduce");
 }
 

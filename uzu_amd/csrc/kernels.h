@@ -17,6 +17,7 @@ namespace k {
 
 enum DT : uint32_t { BF16 = UZU_BF16, F32 = UZU_F32 };
 
+struct NormParams;
 // ---------------------------------------------------------------- matmul (quantised / full-precision B)
 struct MatmulParams {
     const void* a;      // [m,k] input dtype
@@ -45,6 +46,11 @@ struct MatmulParams {
     // to 4, pad rows zero = the group row sums of A, written by the kernel that produced A (NormParams::rowsum_out).  Both given: no pre-pass.
     const float* pre_rowsum;
     const float* pre_coef;
+    // The Normalization that reads D next (engine prefill: out-projection -> pre-MLP norm, down-projection -> the next layer's pre-mixer norm; its
+    // `input` is D).  A split-K GEMM then finishes with ONE launch that adds the partial tiles, applies the epilogue, stores D and normalises the rows
+    // (normalization_from_partials) and sets *post_norm_done; every other kernel choice ignores it and the caller runs the normalisation itself.
+    const NormParams* post_norm;
+    uint32_t* post_norm_done;
 };
 bool gemm_coef_table_supported(const MatmulParams& p);                          // the large-tile kernel's quantisation family
 uzu_status gemm_coef_table(hipStream_t s, const MatmulParams& p, float* coef); // coef[g][n]; p needs b / scales / biases / zero_points, n, k, bits, group_size, b_kind
@@ -86,6 +92,16 @@ struct NormParams {
 };
 uzu_status normalization(hipStream_t s, const NormParams& p);
 bool normalization_rowsum_supported(uint32_t element_count, uint32_t group);
+// rows that are still split-K partial tiles [splits][total] f32 of the GEMM producing them (`d` = that GEMM's bf16 output, `bias` its bf16 epilogue bias or null)
+struct NormPartials {
+    const float* partials;
+    uint32_t splits;
+    size_t total;
+    const uint16_t* bias;
+    uint16_t* d;
+};
+bool normalization_from_partials_supported(const NormParams& p, const NormPartials& sp);
+uzu_status normalization_from_partials(hipStream_t s, const NormParams& p, const NormPartials& sp);
 
 uzu_status qkv_norm(hipStream_t s, void* qkv, uint32_t dt, const float* scales, uint32_t batch_size,
                     uint32_t total_heads, uint32_t head_dim, float epsilon, float scale_offset, uint32_t head_offset,
@@ -237,7 +253,7 @@ uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* c
                                 uint32_t kernel_size, uint32_t conv_dim, uint32_t out_stride);
 // chunked form (k_deltanet_chunk.hip): 32-token chunks, T / P matrices built in parallel, four dense products per chunk
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len);
-size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t suffix_len);
+size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim, uint32_t suffix_len); // T / P matrices + the pieces of a split scan
 uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
                                      float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
                                      uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
