@@ -307,6 +307,57 @@ def test_delta_net_prefill_path_equals_repeated_decode_steps():
     assert np.abs(f32(np.stack(outs)) - f32(out2)).max() <= 3e-2  # prefill rounds o to bf16 before the norm; decode does not
 
 
+def test_delta_net_prefill_splits_into_concurrent_segments():
+    """The identity behind the split scan of the HIP prefill (k_deltanet_chunk.hip: ScanSplit), on the reference's own recurrence (orc_delta_net_prefill =
+    gdn/prefill.rs): the state update is affine in the state with the same linear part for every row, so tokens [mid, T) can run before S_mid is known --
+    once from a zero state with the real values (Z, outputs Z_t q_t) and once, as Dk more value rows per head, from the identity with zero values
+    (H, outputs u_t = H_t q_t) -- and  S_T = S_mid H_T + Z_T,  o_t = Z_t q_t + S_mid u_t.  The state pieces come from the oracle kernel (f32 states); the
+    output identity is checked in float64 (the kernel rounds its outputs to bf16)."""
+    rng = np.random.default_rng(21)
+    Hv, Hk, Dk, Dv, T, mid = 4, 2, 128, 128, 96, 56
+    key_dim, value_dim = Hk * Dk, Hv * Dv
+    total = 2 * key_dim + 2 * value_dim + 2 * Hv
+    in_proj = bf16(rng.normal(0, 1, (T, total)))
+    kn = rng.normal(0, 1, (T, key_dim)).astype(np.float32)
+    kn /= np.linalg.norm(kn.reshape(T, Hk, Dk), axis=2).repeat(Dk, axis=1).reshape(T, key_dim)
+    qn = (rng.normal(0, 1, (T, key_dim)) / np.sqrt(Dk)).astype(np.float32)
+    beta, decay = rng.uniform(0.05, 0.95, (T, Hv)).astype(np.float32), rng.uniform(0.6, 1.0, (T, Hv)).astype(np.float32)
+    s0 = rng.normal(0, 0.3, (Hv, Dv, Dk)).astype(np.float32)
+
+    def run(state, rows, ip, dv, vdim):
+        st, out = state.copy(), np.zeros((rows.stop - rows.start, vdim), np.uint16)
+        O.call("orc_delta_net_prefill", qn[rows].copy(), kn[rows].copy(), beta[rows].copy(), decay[rows].copy(), ip[rows].copy(), st, out, Hv, Hk, Dk, dv, key_dim, vdim,
+               rows.stop - rows.start)
+        return st
+
+    s_full = run(s0, slice(0, T), in_proj, Dv, value_dim)
+    s_mid = run(s0, slice(0, mid), in_proj, Dv, value_dim)
+    z_end = run(np.zeros_like(s0), slice(mid, T), in_proj, Dv, value_dim)
+    zero_v = np.zeros((T, 2 * key_dim + 2 * Hv * Dk + 2 * Hv), np.uint16)  # the homogeneous rows: Dk "value columns" per head, all values zero
+    h_end = run(np.broadcast_to(np.eye(Dk, dtype=np.float32), (Hv, Dk, Dk)).copy(), slice(mid, T), zero_v, Dk, Hv * Dk)
+    recombined = np.einsum("hij,hjk->hik", s_mid.astype(np.float64), h_end.astype(np.float64)) + z_end
+    assert np.abs(recombined - s_full).max() <= 2e-5 * max(1.0, np.abs(s_full).max())
+
+    # outputs, float64, one head: o_t = Z_t q_t + S_mid (H_t q_t)
+    hv, hk = 1, 0
+    v = f32(in_proj[:, 2 * key_dim + hv * Dv:2 * key_dim + (hv + 1) * Dv]).astype(np.float64)
+    k, q = kn[:, hk * Dk:(hk + 1) * Dk].astype(np.float64), qn[:, hk * Dk:(hk + 1) * Dk].astype(np.float64)
+
+    def scan(state, vals, t0, t1):
+        st, outs = state.copy(), []
+        for t in range(t0, t1):
+            d = beta[t, hv] * (vals[t] - decay[t, hv] * (st @ k[t]))
+            st = decay[t, hv] * st + np.outer(d, k[t])
+            outs.append(st @ q[t])
+        return st, np.array(outs)
+
+    sm, _ = scan(s0[hv].astype(np.float64), v, 0, mid)
+    _, o_full = scan(s0[hv].astype(np.float64), v, 0, T)
+    _, o_zero = scan(np.zeros((Dv, Dk)), v, mid, T)
+    _, u = scan(np.eye(Dk), np.zeros((T, Dk)), mid, T)
+    assert np.abs(o_zero + u @ sm.T - o_full[mid:]).max() <= 1e-10
+
+
 def test_embedding_lookup_and_argmax_rules():
     rng = np.random.default_rng(7)
     vocab, dim = 50, 128
