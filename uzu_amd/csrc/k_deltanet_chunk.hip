@@ -557,6 +557,7 @@ __global__ void __launch_bounds__(256) dn_chunk_fixup_kernel(ScanSplit sp, float
 #pragma unroll
             for (uint32_t vt = 0; vt < DV_TILES; ++vt) prev[vt][r] = pr[vt * 16];
         }
+        __builtin_amdgcn_sched_barrier(0); // (every request is out before the first wait)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t e = (tid + 256 * r) * 4; // element of the [Dv][Dk] state
@@ -585,20 +586,31 @@ __global__ void __launch_bounds__(256) dn_chunk_fixup_kernel(ScanSplit sp, float
         float hb[32]; // B: column dk = dk0 + i16, contraction index j = 32 kq + s
 #pragma unroll
         for (int s2 = 0; s2 < 32; ++s2) hb[s2] = hend[(size_t)(32 * kq + s2) * DKC + dk0 + i16];
-        for (uint32_t vt = wave; vt < DV_TILES; vt += 4) {
+        // this wave's two value tiles (wave, wave + 4): all of their S_mid rows and z_end values are requested before the first product (read in place, every
+        // 16-byte operand was a round trip of its own in front of four matrix instructions)
+        f32x4_v sa[2][8];
+        float zv[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t vt = wave + 4 * h;
             const float* ar = smid + (size_t)(vt * 16 + i16) * DKC + 32 * kq; // A: row dv = 16 vt + i16
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sa[h][q] = *(const f32x4_v*)(ar + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zv[h][r] = sp.z_end[((size_t)hv * head_v_dim + vt * 16 + 4 * kq + r) * DKC + dk0 + i16];
+        }
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the loads back to their uses)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t vt = wave + 4 * h;
             f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4_v a = *(const f32x4_v*)(ar + 4 * q);
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma4(a[e], hb[4 * q + e], acc);
-            }
+                for (int e = 0; e < 4; ++e) acc = mfma4(sa[h][q][e], hb[4 * q + e], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { // rows dv = 16 vt + 4 kq + r, column dk
-                const size_t idx = ((size_t)hv * head_v_dim + vt * 16 + 4 * kq + r) * DKC + dk0 + i16;
-                state[idx] = sp.z_end[idx] + acc[r];
-            }
+            for (int r = 0; r < 4; ++r) // rows dv = 16 vt + 4 kq + r, column dk
+                state[((size_t)hv * head_v_dim + vt * 16 + 4 * kq + r) * DKC + dk0 + i16] = zv[h][r] + acc[r];
         }
     }
 }
