@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--context", type=int, default=2048)
     ap.add_argument("--model", default="qwen3.5-0.8b")
     ap.add_argument("--detail", type=float, default=0.0, help="for launches whose span is at least this many us: exit-time distribution by XCD / grid position")
+    ap.add_argument("--dump", type=int, nargs="*", default=[], help="launch indices: the phase stamps of the 20 workgroups that finish last, next to the medians")
     args = ap.parse_args()
     from uzu_amd import _ffi
     from uzu_amd import synthetic as S
@@ -106,6 +107,17 @@ def main():
             late = rel > q[3]
             print(f"      the slowest 10 %: XCD histogram {np.bincount(wg[late] % 8, minlength=8).tolist()}, first-wave CU-slot histogram "
                   f"{np.bincount(cu[late], minlength=32).tolist()}")
+        if i in args.dump:
+            wg = np.nonzero(live)[0]
+            base = int(t0.min())
+            fin_t = np.maximum(e[:, 7], t_end) if has_last else t_end
+            order = np.argsort(-fin_t)[:20]
+            cols = lambda r: (f"{(r[0] - base) * 0.01:6.2f} " + " ".join(f"{(r[k] - r[0]) * 0.01:6.2f}" if r[k] > 0 else "   nan" for k in (1, 2, 5, 6, 4, 7)))
+            print("      workgroups finishing last:   wg xcd |  entry      x    pro   dots    fin   exit   last   (entry: after the first entry; the others: after the workgroup's own entry)")
+            for j in order:
+                print(f"                                 {wg[j]:4d}  {wg[j] % 8}  | {cols(e[j])}")
+            medr = np.median(e, axis=0)
+            print(f"                                 median   | {cols(medr.astype(np.int64))}")
         if gap == gap:
             tot["gap"] += gap
         if gap2 == gap2:
