@@ -732,7 +732,10 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         const char* e = getenv("UZU_DEC_R");
         force_r = e ? atoi(e) : 0;
         const char* t = getenv("UZU_DEC_TW");
-        tw = t ? atoi(t) : 8;
+        // waves per CU a small matrix is cut into before rows per lane group are given up.  16 since round 4 (was 8): the one kernel of the headline model
+        // it changes is the DeltaNet in-projection (2056 two-row batches sat just above 8 x 256): one row per lane group, 1028 workgroups, 1672 -> 1689-1692
+        // tok/s in three same-box A/B pairs, token streams identical (which wave computes a row does not change the row's arithmetic)
+        tw = t ? atoi(t) : 16;
     }
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
