@@ -732,10 +732,7 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         const char* e = getenv("UZU_DEC_R");
         force_r = e ? atoi(e) : 0;
         const char* t = getenv("UZU_DEC_TW");
-        // waves per CU a small matrix is cut into before rows per lane group are given up.  16 since round 4 (was 8): the one kernel of the headline model
-        // it changes is the DeltaNet in-projection (2056 two-row batches sat just above 8 x 256): one row per lane group, 1028 workgroups, 1672 -> 1689-1692
-        // tok/s in three same-box A/B pairs, token streams identical (which wave computes a row does not change the row's arithmetic)
-        tw = t ? atoi(t) : 16;
+        tw = t ? atoi(t) : 0; // 0 = the rule below
     }
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
     const uint64_t weight_bytes = ((uint64_t)p.n[0] + p.n[1]) * p.k * p.bits / 8;
@@ -782,7 +779,11 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         }
     } else {
         R = p.act_mul ? 2 : 4;
-        const uint32_t target_waves = (uint32_t)num_cus * tw;
+        // Waves per CU a small matrix is cut into before rows per lane group are given up: 8, and 16 where a lane owns ONE step of the row (K <= 2048).  Round 4:
+        // the one kernel of the headline model this changes is the DeltaNet in-projection (2056 two-row batches sat just above 8 x 256): one row per lane
+        // group, 1028 workgroups, 1672 -> 1689-1692 tok/s in three same-box A/B pairs, token streams identical (which wave computes a row does not change the
+        // row's arithmetic).  Not at K = 4096: Llama-3-8B's 8 MB out-projection with one row per lane group instead of two 160 -> 170 us per step (572 -> 566 tok/s).
+        const uint32_t target_waves = (uint32_t)num_cus * (uint32_t)(tw > 0 ? tw : (cpl == 1 ? 16 : 8));
         while (R > 1 && nb(R) < target_waves) R >>= 1;
         if (cpl > 2 && R > 2 && (p.norm_scales || p.norm_plain)) R = 2; // the 4-step register path is instantiated for R <= 2
     }
