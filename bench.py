@@ -184,27 +184,76 @@ def pmc_traffic(kernel_name, bundle, bits):
 
 
 def committed_kernel_avg(traffic_source, launches_per_step=None):
-    """rocprofv3 begin->end average of the kernel instance the counter pass matched (profiles/<round>_kernel_stats.csv of the same
-    round): the cross-check for the live HIP-event duration, which carries ~2 us of event bracketing per launch."""
+    """rocprofv3 begin->end average of the kernel instance the counter pass matched, from the NEWEST committed
+    profiles/*_kernel_stats.csv that holds this instance with the right call count (the stats file is chosen on its own -- by
+    modification order of the rounds' files, newest first -- not by the name of the counter pass: a round may refresh one without the
+    other): the cross-check for the live HIP-event duration, which carries ~2 us of event bracketing per launch."""
     import csv
+    import glob
     if not traffic_source or ":" not in traffic_source:
         return None
-    fname, key = traffic_source.split(":", 1)
+    _, key = traffic_source.split(":", 1)
     instance = key.rsplit("|", 1)[0]
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname.replace("_pmc_fetch.json", "_kernel_stats.csv"))
-    try:
-        rows = list(csv.DictReader(open(path)))
-        steps = next((int(r["calls"]) for r in rows if r.get("kernel") == "argmax_commit_kernel"), None)  # one per decode step
-        for row in rows:
-            if row.get("kernel") != instance:
-                continue
-            # the stats are keyed by kernel instance: only usable when this instance is launched by this label alone
-            # (the read-out shares its instance with the qkv projection, for example)
-            if launches_per_step and steps and int(row["calls"]) != launches_per_step * steps:
-                return None
-            return {"avg_launch_us": float(row["avg_us"]), "calls": int(row["calls"]), "source": f"{os.path.basename(path)}:{instance}"}
-    except (OSError, ValueError, KeyError):
-        pass
+    prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+
+    def round_key(path):  # r5b > r5 > r4b > r4 ...: round number, then suffix
+        import re
+        mt = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(mt.group(1)), mt.group(2)) if mt else (-1, "")
+    for path in sorted(glob.glob(os.path.join(prof_dir, "r*_kernel_stats.csv")), key=round_key, reverse=True):
+        try:
+            rows = list(csv.DictReader(open(path)))
+            steps = next((int(r["calls"]) for r in rows if r.get("kernel") == "argmax_commit_kernel"), None)  # one per decode step
+            for row in rows:
+                if row.get("kernel") != instance:
+                    continue
+                # the stats are keyed by kernel instance: only usable when this instance is launched by this label alone
+                # (the read-out shares its instance with the qkv projection, for example)
+                if launches_per_step and steps and int(row["calls"]) != launches_per_step * steps:
+                    break
+                return {"avg_launch_us": float(row["avg_us"]), "calls": int(row["calls"]), "source": f"{os.path.basename(path)}:{instance}"}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def latency_floor(ctx, bundle, per_kernel, tokens_per_s):
+    """The batch-1 decode step is a chain of dependent launches: every linear needs the WHOLE activation row its predecessor's workgroups
+    wrote (an all-to-all edge).  A layer has five such edges whatever the kernels do (mixer in-projection <- residual row, out-projection <-
+    mixer output, up <- residual row, down <- hidden row, next layer <- down's row), the read-out and the commit are two more.  The price of
+    one edge as a kernel boundary in a replayed graph is measured live (uzu_hip_probe_edge_floor: 256 workgroups, every one reading the whole
+    model_dim bf16 row the previous launch wrote, nothing else); the floor of a launch-per-dependency step = edges x that + the read-out's own
+    stream time (the one kernel that is in the bandwidth regime).  `frac_of_floor` says how close the measured step is to what this structure
+    allows; `roofline.frac` beside it stays the fraction of the HBM peak."""
+    import ctypes as C
+    from uzu_amd import _ffi
+    fn = _ffi.lib().uzu_hip_probe_edge_floor
+    fn.restype = C.c_int32
+    us = C.c_float()
+    row_bytes = max(bundle.model_dim * 2, 8)
+    if fn(ctx._h, C.c_uint32(256), C.c_uint32(row_bytes), C.c_uint32(128), C.c_uint32(20), C.byref(us)) != 0:
+        return None
+    edges = 5 * len(bundle.layers) + 2
+    readout = next((v["us"] for k, v in per_kernel.items() if "readout" in k), 0.0)
+    floor_us = edges * us.value + readout
+    return {"edges_per_token": edges, "edge_us": round(us.value, 3), "readout_stream_us": round(readout, 1), "floor_us_per_token": round(floor_us, 1),
+            "floor_tok_s": round(1e6 / floor_us, 1), "frac_of_floor": round(tokens_per_s * floor_us / 1e6, 4),
+            "method": "uzu_hip_probe_edge_floor (csrc/k_probe.hip): 128 dependent launches of 256 workgroups in one hipGraph, each reading the whole "
+                      f"{row_bytes}-byte row the previous launch wrote; wall time per launch over 20 replays.  edges = 5 per layer + read-out + commit"}
+
+
+def committed_census():
+    """Headline fields of the newest committed parity census (tools/parity_census.py -> profiles/r*_parity_census.json): production kernels
+    against reference-order mode over a pre-registered, unfiltered prompt set, teacher-forced."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_census.json")), reverse=True):
+        try:
+            c = json.load(open(path))
+            return {"steps": c["steps"], "argmax_mismatches": c["argmax_mismatches"], "max_flipped_margin": c["max_flipped_margin"], "variants": c["variants"],
+                    "top8_logit_error_max": c["top8_logit_error"]["max"], "chained_identical_streams": c["chained"]["identical_streams"],
+                    "selection": c["selection"], "source": "profiles/" + os.path.basename(path)}
+        except (OSError, ValueError, KeyError):
+            continue
     return None
 
 
@@ -519,6 +568,11 @@ def main():
         committed["frac"] = round(committed["achieved"] / HBM_PEAK_GBPS, 4)
         roofline["rocprofv3"] = committed
     per_kernel = {k: {"calls": v[0], "us": round(v[2] * 1e3, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+    if mode == "single":
+        try:
+            roofline["latency_floor"] = latency_floor(ctx, bundle, per_kernel, tokens_per_s)
+        except Exception as exc:  # noqa: BLE001 -- a probe must never take the headline down
+            roofline["latency_floor"] = {"error": str(exc)[:160]}
     parallelism = {"single": "1 GPU", "tp": f"tp{world}: one sequence, column/row-parallel shards, RCCL all-reduce after out-proj and down-proj "
                    f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]
 
@@ -555,6 +609,9 @@ def main():
             "untimed_tokens_equal": sum(int(a == b) for a, b in w_cmp), "of_untimed": len(w_cmp),
             "tokens_equal": sum(int(a == b) for a, b in t_cmp), "of": len(t_cmp), "timed_steps": args.steps,
             "distinct_tokens_compared": len({b for _, b in w_cmp + t_cmp}),
+            "selection": "the fixture's prompt variant was picked by OUTCOME (tools/stream_search.py: production and reference-order streams identical); the unfiltered "
+                         "figure is `census`",
+            "census": committed_census(),
             "note": "token ids of the prefill + warm-up steps (untimed) and of the timed steps against the committed oracle stream; `of` < timed_steps "
                     "when the run is longer than the fixture" + ("; tensor parallel: sums are taken in another order than on one GPU (tolerance class)" if mode == "tp" else "")}
     elif args.config == "c2" and args.model == "qwen3.5-0.8b":
@@ -569,6 +626,11 @@ def main():
         ar = agg.get("all_reduce", [0, 0, 0.0])
         result["tp"] = {"exchange": "one-shot peer-to-peer (hipIpc mailboxes) for decode rows, RCCL for prefill" if p2p else "RCCL", "all_reduces_per_token": ar[0], "all_reduce_us_per_token": round(ar[2] * 1e3, 1),
                         "share_of_kernel_time": round(ar[2] / max(sum(p[2] for p in prof), 1e-9), 3)}
+        try:  # what the group really used: ranks the RCCL communicator reports (0 = none: --share-gpu), collectives by route
+            rccl_ranks, rccl_calls, p2p_calls = group.stats()
+            result["tp"].update({"rccl_ranks_seen": rccl_ranks, "rccl_collectives_enqueued": rccl_calls, "p2p_exchanges_enqueued": p2p_calls})
+        except Exception as exc:  # noqa: BLE001
+            result["tp"]["stats_error"] = str(exc)[:120]
         # the serving-throughput view of the same N GPUs: N independent sequences, one whole model per GPU
         if args.share_gpu:
             raise_replicas = False

@@ -450,6 +450,13 @@ uzu_status uzu_hip_weaver_top_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
                                               uzu_buf depth_seeds, uzu_buf node_metadata, uzu_buf output_token_ids, uzu_buf output_model_logprobs, uint32_t rows,
                                               uint32_t candidates, uint32_t expand_width, uint32_t vocab_size);
 
+/* ---- measurement probe (bench.py; not part of the forward path) ----
+ * The price of one all-to-all dependency edge kept as a kernel boundary inside a replayed hipGraph -- the structure of the batch-1 decode
+ * step: `launches` dependent launches of `workgroups` workgroups, each reading the whole `row_bytes` row the previous launch wrote and
+ * writing its share of the next one, captured once and replayed `replays` times; *us_per_launch = wall time per launch between two events
+ * on the context's stream.  bench.py's roofline.latency_floor = edges per token x this + the read-out's stream time (csrc/k_probe.hip). */
+uzu_status uzu_hip_probe_edge_floor(uzu_hip_context* ctx, uint32_t workgroups, uint32_t row_bytes, uint32_t launches, uint32_t replays, float* us_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,10 @@ uzu_status uzu_hip_tp_p2p_export(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, ui
 uzu_status uzu_hip_tp_p2p_connect(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, const uint8_t* handles /* [size][64] */);
 void uzu_hip_tp_p2p_disable(uzu_hip_tp_comm* comm); /* back to RCCL for every size (all ranks must agree on the path) */
 uzu_status uzu_hip_tp_p2p_error(uzu_hip_tp_comm* comm, uint32_t* out);
+/* What the group has actually used: ranks the RCCL communicator itself reports (ncclCommCount; 0 for a local group), collectives enqueued
+ * through RCCL, exchanges enqueued through the mailboxes (host-side counts: a captured graph counts once, not per replay).  bench.py puts
+ * them into the line's `tp` object.  Test hook: UZU_TP_INJECT_TIMEOUT_AT=<n> makes mailbox exchange number n fail as a timed-out wait does. */
+uzu_status uzu_hip_tp_comm_stats(uzu_hip_tp_comm* comm, uint32_t* rccl_ranks, uint64_t* rccl_collectives, uint64_t* p2p_exchanges);
 uzu_status uzu_hip_tp_all_reduce_sum_f32(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count);
 uzu_status uzu_hip_tp_all_reduce_max_u64(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count);
 /* `comm` may be NULL (single GPU; identical to uzu_hip_model_create).  The communicator must outlive the model. */
@@ -78,6 +82,9 @@ uzu_status uzu_hip_state_create(uzu_hip_model* m, uzu_hip_state** out);
 void uzu_hip_state_destroy(uzu_hip_state* st);
 uzu_status uzu_hip_state_reset(uzu_hip_state* st);
 uint32_t uzu_hip_state_context_length(const uzu_hip_state* st);
+/* dst <- src (two states of one model): caches, recurrent states, token history, context length -- a prefilled prompt prefix can be
+ * continued any number of times.  Synchronises the context's stream. */
+uzu_status uzu_hip_state_copy(uzu_hip_state* dst, const uzu_hip_state* src);
 uzu_status uzu_hip_model_bind_state(uzu_hip_model* m, uzu_hip_state* st);
 /* Prefill `nseq` (<= UZU_MODEL_BATCH at creation) independent sequences with `count` prompt tokens each (token_ids is
  * row-major [nseq, count]): the linear layers see one matrix of nseq * chunk rows -- weights are streamed once for all
@@ -131,13 +138,18 @@ uzu_status uzu_hip_model_set_next_token(uzu_hip_model* m, uint32_t token);
  * cpu/kernel/gdn/tree_verify/*.rs) with their Tree suffix status kept for the accept, output norm + read-out + greedy sampling of EVERY
  * node (sampled_out[tree_size]; greedy, or with uzu_hip_model_set_sampling the node's own seed PRng::derive(context + height),
  * speculators/dflash_tfm.rs:267,304).  At most 32 nodes per pass (the reference speculates <= 16).  Full and ring (sliding-window) KV
- * states; single GPU (not on a tensor-parallel shard).
+ * states.  On a tensor-parallel shard (uzu_hip_model_create_tp) the nodes' tokens come out of one all-reduce(max) of per-node (logit,
+ * index) keys; stochastic sampling there draws from whole logit rows gathered on every rank (same seeds => the same tokens everywhere).
  *
  * uzu_hip_model_accept: TransformerState::encode_accept with the accepted root path (FlatTrie::accept, trie.rs:271-305; the host mirror
  * is uzu_amd/trie.py): KV rows of the accepted nodes compacted to context .. context + count - 1 (mixer/attention/state.rs:174-198),
  * DeltaNet conv state of the last accepted node + StateAdvance along the path (delta_net.rs:65-120); the context grows by `count` and
  * the token sampled at the last accepted node is the next input token (decode / the next verify_tree's root). */
 uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, uint32_t tree_size, uint32_t* sampled_out);
+/* ... with the trie's own per-node sampling seeds (FlatTrie::token_seeds, stream.rs:694); `seeds` NULL = PRng::derive(context + height) per
+ * node on the device (the reference speculators' convention).  Ignored under greedy sampling. */
+uzu_status uzu_hip_model_verify_tree_seeded(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, const uint64_t* seeds, uint32_t tree_size,
+                                            uint32_t* sampled_out);
 uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indices, uint32_t count);
 /* Device time of the last verify_tree pass, ms (HIP events around the pass; the call itself adds three small uploads, one download and a sync). */
 uzu_status uzu_hip_model_verify_gpu_ms(uzu_hip_model* m, float* out_ms);
@@ -146,7 +158,11 @@ uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out
 
 /* bf16 logits [vocab] of the last sampled row. */
 uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out);
-/* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass. */
+/* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass.
+ * rows the last pass left in the taps, and the rows one layer's tap can hold (= rows of one prefill pass): `out` of read_layer_output must
+ * hold rows * model_dim bf16 values -- size it from `capacity`. */
+uzu_status uzu_hip_model_layer_output_rows(uzu_hip_model* m, uint32_t* rows, uint32_t* capacity);
+/* bf16 [rows, model_dim] output of `layer` in the last forward pass (rows <= capacity above). */
 uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uint16_t* out, uint32_t* rows);
 /* Runs ONE decode step with plain launches and a HIP event pair around every kernel on the context stream;
  * returns per launch: kernel label (static string), algorithmic bytes (0 where not meaningful), duration in ms.

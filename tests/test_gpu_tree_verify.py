@@ -353,3 +353,70 @@ def test_engine_verify_guards(hip_ctx):
     hm.accept([0, 1])
     assert hm.context_length == 11
     hm.close()
+
+
+def test_engine_tree_pass_takes_the_tries_own_seeds(hip_ctx):
+    """stream.rs:690-695: under stochastic sampling the reference uploads the trie's token_seeds -- whatever the speculator put into its
+    nodes -- as the per-node seeds of UnifiedSampling.  verify_tree(..., seeds) does the same; each node must draw exactly what the CPU
+    restatement draws from the pass's own logits of that node with THAT seed, eagerly and in the captured graph of the second pass (a pass
+    with host seeds and one with derived seeds are different graphs); without seeds the position-derived ones are back."""
+    from test_gpu_model import prng_derive
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(21, cfg.vocab_size)
+    hm = HipModel(hip_ctx, bundle)
+    seed = 0x7654321
+    hm.set_sampling(seed=seed, temperature=25.0, top_k=40)
+    tok = hm.prefill(prompt)
+
+    def draw(row, s_):
+        want = np.zeros(1, np.uint32)
+        seeds = np.array([s_], np.uint64)
+        O.lib().orc_unified_sampling(O.p(np.ascontiguousarray(row)), O.BF16, O.p(want), O.p(seeds), None, 1, C.c_float(25.0), 1, 40, 0, C.c_float(0.0), 0, C.c_float(0.0),
+                                     cfg.vocab_size, 1)
+        return int(want[0])
+
+    for rnd in range(3):
+        root = TrieNode(tok, seed=0xA000 + rnd)
+        a, b = TrieNode(5, seed=0xB111 * (rnd + 1)), TrieNode(9, seed=0xC222 + 7 * rnd)
+        root.add(a), root.add(b)
+        a.add(TrieNode(11, seed=0xD333 ^ rnd)), b.add(TrieNode(13, seed=(1 << 63) + rnd))
+        flat = root.linearize()
+        use_trie = rnd != 1
+        sampled = hm.verify_tree(flat.token_ids(), flat.nodes(), flat.token_seeds() if use_trie else None)
+        logits = hm.read_tree_logits()
+        ctx_len = hm.context_length
+        for i, node in enumerate(flat.nodes()):
+            s_ = int(flat.token_seeds()[i]) if use_trie else prng_derive(seed, ctx_len + int(node[2]))
+            assert int(sampled[i]) == draw(logits[i], s_), f"round {rnd} node {i}"
+        hm.accept([0])
+        tok = int(sampled[0])
+    hm.close()
+
+
+def test_a_pending_tree_is_void_once_the_sequence_moves_on_another_way(hip_ctx):
+    """A verified tree that is never accepted must not survive a prefill / decode of the same sequence (advisor finding, round 4: a later
+    accept would compact KV rows at the new context offsets and advance the DeltaNet states a second time from stale tree buffers)."""
+    from uzu_amd._ffi import UzuHipError
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(15, cfg.vocab_size)
+    hm = HipModel(hip_ctx, bundle)
+    tok = hm.prefill(prompt)
+    ref, _ = hm.decode(5)
+    for mover in ("decode", "prefill"):
+        hm.reset()
+        assert hm.prefill(prompt) == tok
+        flat = TrieNode.flat([tok, 5, 6]).linearize()
+        hm.verify_tree(flat.token_ids(), flat.nodes())
+        if mover == "decode":
+            got, _ = hm.decode(5)  # the tree is dropped; the stream is the plain one
+            assert np.array_equal(got, ref)
+        else:
+            hm.prefill(np.array([int(ref[0])], np.uint32))
+        with pytest.raises(UzuHipError):  # nothing is pending any more
+            hm.accept([0, 1])
+        flat2 = TrieNode.flat([int(ref[-1]), 5]).linearize()
+        hm.verify_tree(flat2.token_ids(), flat2.nodes())  # and a new tree can be verified (it was refused as "already pending" before)
+        hm.accept([0])
+    hm.close()

@@ -123,6 +123,13 @@ def test_planner_refuses_what_it_would_get_wrong():
     TP.shard_bundle(S.build_model(S.tiny_qwen(rht=True)), 0, 2)  # (the synthetic in-proj, n % 32 != 0, carries no factors)
     with pytest.raises(NotImplementedError, match="RHT embeddings"):
         TP.shard_bundle(S.build_model(S.tiny_llama(rht_embeddings=True)), 0, 2)
+    # hidden padding of an RHT MLP: the zero rows between the up and gate halves must be whole 32-row Hadamard blocks (advisor finding, round 4:
+    # with an unquantised down projection, group 1, the gate half could shift against its OutputRht blocks and still pass take_rows' check)
+    assert TP.padded_hidden(224, 1, 4) == 224 and TP.padded_hidden(224, 1, 4, rht=True) == 256
+    assert TP.padded_hidden(224, 16, 2, rht=True) == 256 and (TP.padded_hidden(224, 16, 2, rht=True) - 224) % 32 == 0
+    assert TP.padded_hidden(3584, 128, 8, rht=True) == 4096
+    with pytest.raises(NotImplementedError, match="Hadamard block"):
+        TP.padded_hidden(240, 16, 4, rht=True)
 
 
 @pytest.mark.parametrize("size", [2, 4])
@@ -517,3 +524,89 @@ def test_tp_sharded_forward_n_ranks_one_gpu(tmp_path, case, size):
         assert top2_gap(o_logits[common]) < tie or any(top2_gap(o_logits[i]) < tie for i in range(common + 1)), \
             f"{preset} tp{size}: chained stream leaves the oracle's at step {common} without a near-tie\noracle {o_tokens}\ntp     {chained}"
     print(f"{preset} tp{size}: worst logit error {worst:.3f} sigma, chained stream identical for {common}/{len(o_tokens)} tokens, {int(res[0]['launches'])} launches per decode step")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["tiny-qwen", "tiny-llama"])
+def test_tp_stochastic_sampling_and_tree_verify_n_ranks_one_gpu(tmp_path, preset):
+    """The two engine features BASELINE configs[3] / [4] (tensor-parallel configurations) could not use before round 5, on 2 ranks sharing
+    GPU 0: (a) SamplingMethod::Stochastic over the vocab-sharded read-out -- every rank gathers the whole logit row (tp::gather_logits: its
+    shard filed into a zeroed f32 row, all-reduce(sum): exact) and draws with the same derived seed: every token must be EXACTLY what the CPU
+    restatement of UnifiedSampling draws from the concatenation of the ranks' own logit shards of that step (unified_sampling.rs:13-99,
+    stream.rs:248-258, 598-600), identical on all ranks, in the eager steps and the graph replays; (b) uzu_hip_model_verify_tree /
+    _accept on a shard (stream.rs:556-628, 380-470): the token of every node = arg-max (ties -> lowest index) of the gathered per-node
+    logits through one all-reduce(max) of per-node keys, under stochastic sampling the node's own seed PRng::derive(context + height);
+    the accept compacts each shard's KV rows / advances its DeltaNet heads, and the ranks keep committing identical tokens afterwards."""
+    import ctypes as C
+    from helpers import f32
+    from oracle import oracle as O
+    from test_gpu_model import prng_derive
+    size, prompt_len, steps = 2, 33, 6
+    cfg = S.PRESETS[preset]()
+    settings = dict(temperature=25.0, top_k=40)
+    seed = 0x0BADC0FFEE123
+    spec = tmp_path / "spec.json"
+    spec.write_text(json.dumps({"preset": preset, "kwargs": {}, "prompt_len": prompt_len, "steps": steps, "teacher": [1] * (steps + 1),
+                                "stochastic": {"seed": seed, "settings": settings}, "tree": True}))
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="4")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tp_worker.py"), str(r), str(size), str(tmp_path), str(spec)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(size)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("tp workers timed out")
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    res = [np.load(tmp_path / f"out_{r}.npz") for r in range(size)]
+    assert all(int(r["p2p_error"]) == 0 for r in res)
+    for key in ("st_tokens", "st_many", "st_tree_sampled", "tree_sampled", "tree_accepted", "tree_after"):
+        for r in res[1:]:
+            assert np.array_equal(r[key], res[0][key]), f"ranks disagree on {key}: {[list(x[key]) for x in res]}"
+
+    def draw(row, position):
+        out = np.zeros(1, np.uint32)
+        seeds = np.array([prng_derive(seed, position)], np.uint64)
+        O.lib().orc_unified_sampling(O.p(np.ascontiguousarray(row)), O.BF16, O.p(out), O.p(seeds), None, 1, C.c_float(settings["temperature"]), 1, settings["top_k"],
+                                     0, C.c_float(0.0), 0, C.c_float(0.0), cfg.vocab_size, 1)
+        return int(out[0])
+
+    # (a) stochastic stream: position of the sampled row = prompt_len - 1 + step
+    st = [int(t) for t in res[0]["st_tokens"]]
+    for step in range(steps + 1):
+        full = np.concatenate([r["st_logits"][step] for r in res])
+        assert st[step] == draw(full, prompt_len - 1 + step), f"{preset}: stochastic step {step}"
+    assert len(set(st)) > 2, f"a stochastic stream that never moves: {st}"
+    # ... and a stochastic tree pass: node i draws with derive(context + height_i) from ITS gathered row
+    ctx_len = int(res[0]["st_tree_ctx"])
+    for i, h in enumerate(res[0]["st_tree_heights"]):
+        full = np.concatenate([r["st_tree_logits"][i] for r in res])
+        assert int(res[0]["st_tree_sampled"][i]) == draw(full, ctx_len + int(h)), f"{preset}: stochastic tree node {i}"
+    # (b) greedy tree pass: every node's token is the arg-max of the gathered row, lowest index on ties
+    for i in range(len(res[0]["tree_sampled"])):
+        full = f32(np.concatenate([r["tree_logits"][i] for r in res]))
+        assert int(res[0]["tree_sampled"][i]) == int(np.argmax(full)), f"{preset}: tree node {i}"
+    assert len(res[0]["tree_accepted"]) >= 1 and res[0]["tree_accepted"][0] == 0
+    print(f"{preset} tp{size}: stochastic stream {st}, tree sampled {list(res[0]['tree_sampled'])}, accepted {list(res[0]['tree_accepted'])}, then {list(res[0]['tree_after'])}")
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_rccl_when_a_p2p_exchange_fails():
+    """bench.py's recovery branch for first contact with a multi-GPU node (p2p + graph TP decode fails -> every all-reduce on RCCL, eager
+    launches, the line says so) executed for real: one rank through the N > 1 code path (--force-dist: nccl process group, RCCL
+    communicator, mailbox of its own), with mailbox exchange number 30 failing the way a timed-out wait does (UZU_TP_INJECT_TIMEOUT_AT, the
+    sticky group-wide error of csrc/tp.hip).  The line must carry the note, report RCCL as the exchange, the rank count the RCCL communicator
+    itself returns (ncclCommCount) and a non-zero number of RCCL collectives, and still hold a positive value."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "4", "--warmup", "1", "--context", "96", "--no-cpu-baseline"]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), UZU_TP_INJECT_TIMEOUT_AT="30",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "rerun on RCCL, eager" in line["config"].get("note", ""), line["config"]
+    assert line["tp"]["exchange"] == "RCCL" and line["config"]["graph"] is False
+    assert line["tp"]["rccl_ranks_seen"] == 1 and line["tp"]["rccl_collectives_enqueued"] > 0 and line["tp"]["p2p_exchanges_enqueued"] >= 30
+    assert line["value"] > 0 and line["steps"] == 4

@@ -75,9 +75,59 @@ def main():
     exchange("ready3", b"x")
     toks, _ = model.decode(steps)
     chained += [int(t) for t in toks]
+    extra = {}
+    if spec.get("stochastic"):
+        # pass 3: SamplingMethod::Stochastic on the shards -- every rank gathers the whole logit row (tp::gather_logits) and draws with the same seed
+        st = spec["stochastic"]
+        model.reset()
+        model.set_sampling(seed=st["seed"], **st["settings"])
+        exchange("ready4", b"x")
+        st_tokens = [model.prefill(prompt)]
+        st_logits = [model.read_logits()]
+        for i in range(steps):
+            exchange(f"st{i}", b"x")
+            toks, _ = model.decode(1)
+            st_tokens.append(int(toks[0]))
+            st_logits.append(model.read_logits())
+        exchange("ready5", b"x")
+        many, _ = model.decode(3)  # several replays of the captured graph in one call
+        extra.update(st_tokens=np.array(st_tokens, np.int64), st_logits=np.stack(st_logits), st_many=np.array(many, np.int64))
+        if spec.get("tree"):  # a stochastic tree pass on top: per-node seeds
+            from uzu_amd.trie import TrieNode
+            root = TrieNode(int(many[-1]))
+            a, b = TrieNode(5), TrieNode(9)
+            root.add(a), root.add(b)
+            a.add(TrieNode(11)), b.add(TrieNode(13))
+            flat = root.linearize()
+            exchange("ready6", b"x")
+            sampled = model.verify_tree(flat.token_ids(), flat.nodes())
+            extra.update(st_tree_sampled=np.array(sampled, np.int64), st_tree_logits=model.read_tree_logits(), st_tree_ctx=model.context_length,
+                         st_tree_heights=flat.nodes()[:, 2].astype(np.int64))
+            model.accept([0])
+        model.set_sampling(None)
+    if spec.get("tree"):
+        # pass 4: greedy verify -> accept on the shards: a chain along the chained stream with one wrong branch
+        from uzu_amd.trie import TrieNode
+        model.reset()
+        exchange("ready7", b"x")
+        first = model.prefill(prompt)
+        root = TrieNode(first)
+        n1, n2, wrong = TrieNode(chained[1]), TrieNode(chained[2]), TrieNode((chained[1] + 1) % cfg.vocab_size)
+        root.add(n1), root.add(wrong)
+        n1.add(n2)
+        flat = root.linearize()
+        exchange("ready8", b"x")
+        sampled = model.verify_tree(flat.token_ids(), flat.nodes())
+        tree_logits = model.read_tree_logits()
+        accepted = flat.accept(sampled)
+        model.accept([index for index, _, _ in accepted])
+        exchange("ready9", b"x")
+        after, _ = model.decode(2)
+        extra.update(tree_sampled=np.array(sampled, np.int64), tree_logits=tree_logits, tree_accepted=np.array([i for i, _, _ in accepted], np.int64),
+                     tree_after=np.array(after, np.int64), tree_tokens=flat.token_ids().astype(np.int64))
     err = group.p2p_error()
     np.savez(os.path.join(workdir, f"out_{rank}.npz"), tf_tokens=np.array(tf_tokens, np.int64), tf_logits=np.stack(tf_logits), chained=np.array(chained, np.int64),
-             vocab_offset=off, p2p_error=err, launches=model.decode_launch_count)
+             vocab_offset=off, p2p_error=err, launches=model.decode_launch_count, **extra)
     exchange("done", b"x")  # nobody tears its mailbox down while a peer may still write into it
     model.close()
     group.close()

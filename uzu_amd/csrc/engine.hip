@@ -92,6 +92,7 @@ struct uzu_hip_state {
     hipGraphExec_t graph_single = nullptr, graph_two = nullptr;
     uint32_t graph_epoch = 0; // sampling_epoch of the model when the graphs were captured (they bake the sampling kernels in)
     std::vector<void*> allocations;
+    std::vector<size_t> allocation_bytes; // parallel to `allocations` (uzu_hip_state_copy)
     size_t bytes = 0;
 };
 
@@ -140,7 +141,7 @@ struct uzu_hip_model {
     uint64_t* d_seed = nullptr;
     void* sampling_scratch = nullptr;
     uint32_t sampling_epoch = 0;
-    uint16_t* taps = nullptr; // [layers][1024][d]
+    uint16_t* taps = nullptr; // [layers][chunk][d] (chunk = rows of one prefill pass)
     uint32_t tap_rows = 0;
 
     // fused decode path
@@ -166,7 +167,11 @@ struct uzu_hip_model {
     uzu::tp::Comm* tp = nullptr; // borrowed; null => single GPU
     uint32_t vocab_offset = 0;   // first vocabulary row of this rank's read-out shard
     float* tp_buf = nullptr;     // [1024 rows][model_dim] f32 partial sums
-    unsigned long long* tp_key = nullptr;
+    unsigned long long* tp_key = nullptr; // [kDnTreeMaxNodes] packed (logit, index) keys: one per sampled row
+    // stochastic sampling over the vocab-sharded read-out: the ranks' logit shards gathered into whole rows (tp::gather_logits)
+    float* tp_gather_f32 = nullptr;   // [tp_gather_rows][vocab]
+    uint16_t* tp_gather_bf16 = nullptr;
+    uint32_t tp_gather_rows = 0;
 
     // A speculated tree between uzu_hip_model_verify_tree and uzu_hip_model_accept (stream.rs:556-628, 380-470): the attention layers
     // keep the suffix rows behind the caches' logical end, a DeltaNet layer keeps its DeltaNetSuffixStatus::Tree (delta_net.rs:39-46).
@@ -186,6 +191,7 @@ struct uzu_hip_model {
         uint16_t* logits = nullptr;     // bf16 [nodes, vocab rows of this rank]
         void* argmax_scratch = nullptr;
         uint64_t* d_seeds = nullptr;    // [kDnTreeMaxNodes] per-node sampling seeds (stochastic sampling)
+        bool host_seeds = false;        // d_seeds was uploaded by the caller (the trie's token_seeds, stream.rs:694) instead of derived on the device
         void* sampling_scratch = nullptr;
         bool allocated = false;
         bool active = false;            // the forward pass being encoded is a tree pass
@@ -200,6 +206,7 @@ struct uzu_hip_model {
             uzu_hip_state* state;
             uint32_t nodes;
             bool two_pass;
+            bool host_seeds; // the pass takes the caller's per-node seeds (no derive_tree_seeds launch in it)
             hipGraphExec_t exec;
             uint32_t launches;
         };
@@ -257,6 +264,7 @@ uzu_status state_alloc(uzu_hip_state* st, size_t bytes, void** out) {
         return e == hipErrorOutOfMemory ? UZU_ERR_OUT_OF_MEMORY : UZU_ERR_HIP;
     }
     st->allocations.push_back(p);
+    st->allocation_bytes.push_back(alloc);
     st->bytes += alloc;
     uzu_hip_context* ctx = st->m->ctx;
     ctx->current_bytes += alloc;
@@ -274,6 +282,7 @@ void state_release(uzu_hip_state* st) {
     st->graph_single = st->graph_two = nullptr;
     for (void* p : st->allocations) (void)hipFree(p);
     st->allocations.clear();
+    st->allocation_bytes.clear();
     uzu_hip_context* ctx = st->m->ctx;
     ctx->current_bytes -= st->bytes < ctx->current_bytes ? st->bytes : ctx->current_bytes;
     st->bytes = 0;
@@ -666,6 +675,20 @@ void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint1
     RUN("normalization", 0, k::normalization(e.s, p));
 }
 
+// whole logit rows for stochastic sampling on a vocab shard (allocated on first use: set_sampling / a stochastic tree pass under TP)
+uzu_status ensure_tp_gather(uzu_hip_model* m, uint32_t rows) {
+    if (!m->tp || m->tp_gather_rows >= rows) return UZU_OK;
+    void* p = nullptr;
+    if (m->tp_gather_f32) dev_free(m, m->tp_gather_f32), dev_free(m, m->tp_gather_bf16);
+    m->tp_gather_f32 = nullptr, m->tp_gather_bf16 = nullptr, m->tp_gather_rows = 0;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)rows * m->d.vocab_size * 4, &p));
+    m->tp_gather_f32 = (float*)p;
+    UZU_PROPAGATE(dev_alloc(m, (size_t)rows * m->d.vocab_size * 2, &p));
+    m->tp_gather_bf16 = (uint16_t*)p;
+    m->tp_gather_rows = rows;
+    return UZU_OK;
+}
+
 uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
     if (rows <= m->partial_rows) return UZU_OK;
     // regrow: the old blocks stay allocated until the model is destroyed -- captured decode graphs (this state's and every
@@ -919,13 +942,24 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         linear(e, ro, m->tree.normed, m->tree.logits, count);
         if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f)
             RUN("logit_transform", 0, k::logit_transform(s, m->tree.logits, UZU_BF16, ro.n * count, m->d.logit_scale, m->d.logit_soft_cap, m->d.logit_soft_cap != 0.0f));
-        if (m->sampling.on) { // every node draws with the seed of ITS position: PRng::derive(context + height) (dflash_tfm.rs:267,304)
-            RUN("derive_tree_seeds", 0, k::derive_tree_seeds(s, m->sampling.seed, m->d_ctx_len, m->tree.d_trie, count, m->tree.d_seeds));
+        if (m->sampling.on) {
+            // every node draws with ITS seed: the trie's token_seeds when the caller passed them (stream.rs:694), else the seed of its position,
+            // PRng::derive(context + height) (dflash_tfm.rs:267,304)
+            if (!m->tree.host_seeds) RUN("derive_tree_seeds", 0, k::derive_tree_seeds(s, m->sampling.seed, m->d_ctx_len, m->tree.d_trie, count, m->tree.d_seeds));
             k::UnifiedSamplingParams sp = m->sampling.p;
             sp.logits = m->tree.logits, sp.dt = UZU_BF16, sp.output = m->tree.d_sampled, sp.seeds = m->tree.d_seeds, sp.vocab_size = ro.n, sp.batch_size = count;
-            RUN("unified_sampling", (size_t)ro.n * 2 * count, k::unified_sampling(s, sp, m->tree.sampling_scratch));
+            if (m->tp) { // the whole rows on every rank: same seeds, same distribution => the same token everywhere
+                RUN("tp_gather_logits", (size_t)m->d.vocab_size * 4 * count, tp::gather_logits(m->tp, s, m->tree.logits, ro.n, m->vocab_offset, m->d.vocab_size, count, m->tp_gather_f32, m->tp_gather_bf16));
+                sp.logits = m->tp_gather_bf16, sp.vocab_size = m->d.vocab_size;
+            }
+            RUN("unified_sampling", (size_t)sp.vocab_size * 2 * count, k::unified_sampling(s, sp, m->tree.sampling_scratch));
         } else {
             RUN("argmax", (size_t)ro.n * 2 * count, k::argmax(s, m->tree.logits, UZU_BF16, m->tree.d_sampled, ro.n, count, m->tree.argmax_scratch));
+            if (m->tp) { // vocab-sharded read-out: one (logit, global index) key per node, reduced with max
+                RUN("tp_keys", 0, tp::keys_from_tokens(s, m->tree.logits, ro.n, m->tree.d_sampled, m->vocab_offset, m->tp_key, count));
+                RUN("all_reduce", 8 * count, tp::all_reduce_max_u64(m->tp, s, m->tp_key, count));
+                RUN("tp_tokens", 0, tp::tokens_from_keys(s, m->tp_key, m->tree.d_sampled, count));
+            }
         }
         if (e.st != UZU_OK) return e.st;
         hipError_t terr = hipGetLastError();
@@ -952,11 +986,15 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
                 RUN("derive_seed", 0, k::derive_seed(s, m->sampling.seed, m->d_ctx_len, count - 1, m->d_seed));
                 k::UnifiedSamplingParams sp = m->sampling.p;
                 sp.logits = m->logits, sp.dt = UZU_BF16, sp.output = m->d_out_token, sp.seeds = m->d_seed, sp.vocab_size = ro.n, sp.batch_size = 1;
-                RUN("unified_sampling", (size_t)ro.n * 2, k::unified_sampling(s, sp, m->sampling_scratch));
+                if (m->tp) { // the whole row on every rank (tp::gather_logits): same seed, same distribution => the same token everywhere
+                    RUN("tp_gather_logits", (size_t)m->d.vocab_size * 4, tp::gather_logits(m->tp, s, m->logits, ro.n, m->vocab_offset, m->d.vocab_size, 1, m->tp_gather_f32, m->tp_gather_bf16));
+                    sp.logits = m->tp_gather_bf16, sp.vocab_size = m->d.vocab_size;
+                }
+                RUN("unified_sampling", (size_t)sp.vocab_size * 2, k::unified_sampling(s, sp, m->sampling_scratch));
             } else {
                 RUN("argmax", (size_t)ro.n * 2, k::argmax(s, m->logits, UZU_BF16, m->d_out_token, ro.n, 1, m->argmax_scratch));
             }
-            if (m->tp) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
+            if (m->tp && !m->sampling.on) { // vocab-sharded read-out: every rank contributes (logit, global index) of its local winner
                 RUN("tp_key", 0, tp::key_from_token(s, m->logits, m->d_out_token, m->vocab_offset, m->tp_key));
                 RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
                 RUN("tp_token", 0, tp::token_from_key(s, m->tp_key, m->d_out_token));
@@ -1216,7 +1254,16 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
     r.part_val = m->amax_val, r.part_idx = m->amax_idx, r.part_capacity = kArgmaxPartials;
     uint32_t grid = 0;
     dec_gemv(e, r, "gemv_dec[norm+readout+argmax]", &grid);
-    if (m->tp) {
+    if (m->tp && m->sampling.on) { // stochastic sampling over the gathered row (stream.rs:598-600 seed), then the plain commit with that token
+        RUN("derive_seed", 0, k::derive_seed(s, m->sampling.seed, m->d_ctx_len, 0, m->d_seed));
+        RUN("tp_gather_logits", (size_t)m->d.vocab_size * 4, tp::gather_logits(m->tp, s, m->logits, ro.n, m->vocab_offset, m->d.vocab_size, 1, m->tp_gather_f32, m->tp_gather_bf16));
+        k::UnifiedSamplingParams sp = m->sampling.p;
+        sp.logits = m->tp_gather_bf16, sp.dt = UZU_BF16, sp.output = m->d_out_token, sp.seeds = m->d_seed, sp.vocab_size = m->d.vocab_size, sp.batch_size = 1;
+        RUN("unified_sampling", (size_t)m->d.vocab_size * 2, k::unified_sampling(s, sp, m->sampling_scratch));
+        k::CommitEmbed eb{};
+        eb.token_in = m->d_out_token;
+        RUN("argmax_commit", 0, k::argmax_commit(s, m->amax_val, m->amax_idx, grid, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled, &eb));
+    } else if (m->tp) {
         RUN("tp_argmax_key", 0, tp::argmax_key(s, m->amax_val, m->amax_idx, grid, m->vocab_offset, m->tp_key));
         RUN("all_reduce", 8, tp::all_reduce_max_u64(m->tp, s, m->tp_key, 1));
         RUN("tp_commit_key", 0, tp::commit_key(s, m->tp_key, m->d_ctx_len, m->d_tokens, m->d_out_token, m->d_sampled));
@@ -1466,7 +1513,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     ALLOC(logits, uint16_t, desc->vocab_size);
     if (m->tp) {
         ALLOC(tp_buf, float, CB * d);
-        ALLOC(tp_key, unsigned long long, 1);
+        ALLOC(tp_key, unsigned long long, k::kDnTreeMaxNodes);
     }
     TRY(dev_alloc(m, k::argmax_scratch_bytes(1), &m->argmax_scratch));
     TRY(dev_alloc(m, k::unified_sampling_scratch_bytes(1), &m->sampling_scratch));
@@ -1577,10 +1624,30 @@ uzu_status uzu_hip_state_reset(uzu_hip_state* st) {
     bind_state(m, prev);
     return r;
 }
+// dst <- src: KV caches, DeltaNet conv / SSM states, token history, context length (both states of ONE model: the same buffers in the same
+// order).  A prompt prefix prefilled once can so be continued many times (tools/parity_census.py: prompts that share all but their tail).
+uzu_status uzu_hip_state_copy(uzu_hip_state* dst, const uzu_hip_state* src) {
+    UZU_REQUIRE(dst && src && dst->m && dst->m == src->m, "state_copy: null state, or states of different models");
+    if (dst == src) return UZU_OK;
+    uzu_hip_model* m = dst->m;
+    UZU_REQUIRE(dst->allocations.size() == src->allocations.size() && dst->allocation_bytes == src->allocation_bytes, "state_copy: the states differ in layout");
+    (void)hipSetDevice(m->ctx->device);
+    hipStream_t s = m->ctx->stream;
+    for (size_t i = 0; i < dst->allocations.size(); ++i) HIPCHK(hipMemcpyAsync(dst->allocations[i], src->allocations[i], dst->allocation_bytes[i], hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint32_t len = m->bound == src ? m->context_length : src->context_length;
+    dst->context_length = len;
+    if (m->bound == dst) m->context_length = len, m->hidden_ready = false, m->tree.size = 0, m->tree.state = nullptr;
+    return UZU_OK;
+}
 uint32_t uzu_hip_state_context_length(const uzu_hip_state* st) {
     if (!st || !st->m) return 0;
     return st->m->bound == st ? st->m->context_length : st->context_length;
 }
+
+// A speculated tree that was verified but never accepted is void once the sequence moves on by any other route (prefill / decode advance
+// the context: a later accept would compact KV rows at the new offsets and advance the DeltaNet states from stale tree buffers).
+static void drop_pending_tree(uzu_hip_model* m) { m->tree.size = 0, m->tree.state = nullptr; }
 
 // LanguageModelStream::new for `nseq` independent sequences at once: `count` prompt tokens each (token_ids row-major
 // [nseq, count]), chunks of <= 1024 tokens per sequence, every chunk pass carrying all sequences (struct Seqs).
@@ -1596,6 +1663,7 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
     hipStream_t s = m->ctx->stream;
     uzu_hip_state* prev = m->bound;
     m->hidden_ready = false;
+    drop_pending_tree(m);
     uint32_t max_heads = 0, max_hd = 0;
     for (auto& L : m->layers)
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
@@ -1651,6 +1719,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
                 m->context_length, count, m->d.max_context_length);
     hipStream_t s = m->ctx->stream;
     m->hidden_ready = false; // the prefill pass uses `hidden` for its own rows
+    drop_pending_tree(m);
     const uint32_t pass_rows = k::exact_mode() ? kSuffixCapacity : m->chunk; // reference-order mode: the reference's own passes (bit-identical logits)
     for (uint32_t start = 0; start < count; start += pass_rows) {
         const uint32_t n = count - start < pass_rows ? count - start : pass_rows;
@@ -1682,6 +1751,7 @@ uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps) {
     UZU_REQUIRE(m, "model_decode: null model");
     UZU_REQUIRE(m->context_length > 0, "model_decode: prefill first (no input token)");
     drop_stale_graphs(m);
+    drop_pending_tree(m);
     return enqueue_decode(m, steps);
 }
 
@@ -1761,7 +1831,8 @@ uzu_status uzu_hip_model_set_sampling(uzu_hip_model* m, const uzu_sampling_confi
         m->sampling.on = false;
         return UZU_OK;
     }
-    UZU_UNSUPPORTED(m->tp != nullptr, "model_set_sampling: stochastic sampling over a vocab-sharded read-out is not implemented");
+    // a vocab-sharded read-out gathers the whole row on every rank first (tp::gather_logits): every rank then draws the same token
+    UZU_PROPAGATE(ensure_tp_gather(m, k::kDnTreeMaxNodes)); // (tree passes sample every node; one size: captured graphs hold the pointers)
     UZU_REQUIRE(!cfg->has_temperature || cfg->temperature > 0.0f, "model_set_sampling: temperature must be positive");
     UZU_REQUIRE(!cfg->has_top_k || cfg->top_k > 0, "model_set_sampling: top_k must be positive");
     m->sampling.on = true;
@@ -1845,10 +1916,16 @@ static uzu_status ensure_tree(uzu_hip_model* m) {
 // attention under the trie mask, DeltaNet layers through tree-verify, greedy token of EVERY node into sampled_out.  Nothing is accepted:
 // follow with uzu_hip_model_accept.
 uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, uint32_t tree_size, uint32_t* sampled_out) {
+    return uzu_hip_model_verify_tree_seeded(m, token_ids, trie_nodes, nullptr, tree_size, sampled_out);
+}
+
+// ... with the trie's own per-node sampling seeds (FlatTrie::token_seeds, stream.rs:694: the speculator sets them); null = every node draws with
+// PRng::derive(context + height), the convention of the reference's own speculators (dflash_tfm.rs:267,304).  Ignored under greedy sampling.
+uzu_status uzu_hip_model_verify_tree_seeded(uzu_hip_model* m, const uint32_t* token_ids, const uint32_t* trie_nodes, const uint64_t* seeds, uint32_t tree_size,
+                                            uint32_t* sampled_out) {
     UZU_REQUIRE(m && token_ids && trie_nodes && tree_size > 0, "model_verify_tree: null / empty input");
     (void)hipSetDevice(m->ctx->device);
     UZU_UNSUPPORTED(tree_size > k::kDnTreeMaxNodes, "model_verify_tree: %u nodes (at most %u per pass)", tree_size, k::kDnTreeMaxNodes);
-    UZU_UNSUPPORTED(m->tp != nullptr, "model_verify_tree: speculative verification on a tensor-parallel shard is not implemented");
     UZU_REQUIRE(m->tree.size == 0, "model_verify_tree: a speculated tree is already pending (accept it first)");
     UZU_REQUIRE(m->context_length > 0, "model_verify_tree: prefill first");
     UZU_REQUIRE(m->context_length + tree_size <= m->d.max_context_length, "model_verify_tree: %u + %u tokens exceed max_context_length %u", m->context_length, tree_size,
@@ -1873,6 +1950,8 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
     HIPCHK(hipMemcpyAsync(m->d_tokens, token_ids, (size_t)tree_size * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m->tree.d_trie, trie_nodes, (size_t)tree_size * 12, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m->tree.d_parents, parents.data(), (size_t)tree_size * 4, hipMemcpyHostToDevice, s));
+    m->tree.host_seeds = seeds != nullptr && m->sampling.on;
+    if (m->tree.host_seeds) HIPCHK(hipMemcpyAsync(m->tree.d_seeds, seeds, (size_t)tree_size * 8, hipMemcpyHostToDevice, s));
     {
         uint32_t max_heads = 0, max_hd = 0;
         bool two_pass = false;
@@ -1898,7 +1977,7 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
             m->tree.graph_epoch = m->sampling_epoch;
         }
         for (auto& g : m->tree.graphs)
-            if (g.state == m->bound && g.nodes == tree_size && g.two_pass == two_pass_regime) exec = g.exec, m->launches = g.launches;
+            if (g.state == m->bound && g.nodes == tree_size && g.two_pass == two_pass_regime && g.host_seeds == m->tree.host_seeds) exec = g.exec, m->launches = g.launches;
         if (!exec) {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             m->regime_override = two_pass_regime ? 1 : 0;
@@ -1915,7 +1994,7 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
             }
             HIPCHK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(g));
-            m->tree.graphs.push_back({m->bound, tree_size, two_pass_regime, exec, m->launches});
+            m->tree.graphs.push_back({m->bound, tree_size, two_pass_regime, m->tree.host_seeds, exec, m->launches});
         }
         HIPCHK(hipGraphLaunch(exec, s));
     }
@@ -1924,6 +2003,7 @@ uzu_status uzu_hip_model_verify_tree(uzu_hip_model* m, const uint32_t* token_ids
     HIPCHK(hipMemcpyAsync(m->tree.sampled.data(), m->tree.d_sampled, (size_t)tree_size * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&m->tree.last_gpu_ms, m->ev0, m->ev1);
+    if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     UZU_PROPAGATE(k::gemv_stream_check());
     if (sampled_out) memcpy(sampled_out, m->tree.sampled.data(), (size_t)tree_size * 4);
     m->tree.size = tree_size, m->tree.state = m->bound, m->tree.parents = parents;
@@ -1998,6 +2078,14 @@ uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out
     return UZU_OK;
 }
 
+// rows the last pass left in the taps / rows one layer's tap can hold: size the buffer of read_layer_output from `capacity`
+uzu_status uzu_hip_model_layer_output_rows(uzu_hip_model* m, uint32_t* rows, uint32_t* capacity) {
+    UZU_REQUIRE(m, "model_layer_output_rows: null model");
+    if (rows) *rows = m->tap_rows;
+    if (capacity) *capacity = m->chunk;
+    return UZU_OK;
+}
+
 uzu_status uzu_hip_model_read_layer_output(uzu_hip_model* m, uint32_t layer, uint16_t* out, uint32_t* rows) {
     UZU_REQUIRE(m && out && layer < m->d.num_layers, "model_read_layer_output: bad argument");
     UZU_REQUIRE(m->taps, "model_read_layer_output: model was not created with UZU_MODEL_DEBUG_TAPS");
@@ -2041,6 +2129,13 @@ uzu_status uzu_hip_tp_p2p_connect(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, c
 }
 void uzu_hip_tp_p2p_disable(uzu_hip_tp_comm* comm) { uzu::tp::p2p_disable((uzu::tp::Comm*)comm); }
 uzu_status uzu_hip_tp_p2p_error(uzu_hip_tp_comm* comm, uint32_t* out) { return uzu::tp::p2p_error((uzu::tp::Comm*)comm, out); }
+uzu_status uzu_hip_tp_comm_stats(uzu_hip_tp_comm* comm, uint32_t* rccl_ranks, uint64_t* rccl_collectives, uint64_t* p2p_exchanges) {
+    unsigned long long r = 0, p = 0;
+    UZU_PROPAGATE(uzu::tp::comm_stats((uzu::tp::Comm*)comm, rccl_ranks, &r, &p));
+    if (rccl_collectives) *rccl_collectives = r;
+    if (p2p_exchanges) *p2p_exchanges = p;
+    return UZU_OK;
+}
 // stand-alone collective entry points (tests, tools): in place on device buffers of the context's stream
 uzu_status uzu_hip_tp_all_reduce_sum_f32(uzu_hip_context* ctx, uzu_hip_tp_comm* comm, uzu_hip_buffer* buf, size_t offset_bytes, size_t count) {
     UZU_REQUIRE(ctx && comm && buf && offset_bytes + count * 4 <= buf->size, "tp_all_reduce_sum_f32: bad argument");

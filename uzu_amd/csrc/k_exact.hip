@@ -66,8 +66,83 @@ __global__ void __launch_bounds__(64) normalization_exact_kernel(NormParams p) {
         st(output, off + i, result);
     }
 }
+// The same loops with a workgroup per row (round 5: one thread walking a 4096-element row through global memory took 1.9 ms per decode
+// launch).  Everything that is element-wise runs on 256 threads -- the residual add, the rounding to T, the shortcut store, the output
+// formula: each element's arithmetic is the scalar kernel's, so the values are bit-identical -- and only the two running sums, whose ORDER
+// is the point of this mode, stay sequential: thread 0 adds the staged values in index order (normalization.rs:56-78).
+template <class T, class AffineT>
+__global__ void __launch_bounds__(256) normalization_exact_row_kernel(NormParams p) {
+    extern __shared__ float s_val[]; // element_count values + {mean, rms_inv}
+    const size_t batch = blockIdx.x;
+    const T* input = (const T*)(p.input ? p.input : p.output);
+    T* output = (T*)p.output;
+    T* shortcut = (T*)p.shortcut;
+    const AffineT* scales = (const AffineT*)p.scales;
+    const AffineT* biases = (const AffineT*)p.biases;
+    const size_t element_count = p.element_count, off = batch * element_count;
+    const float element_count_accum = (float)element_count;
+    for (size_t i = threadIdx.x; i < element_count; i += 256) {
+        float val = ld(input, off + i);
+        if (p.copy_to_shortcut) {
+            if (p.residual_add) {
+                val = rnd<T>(val + ld(shortcut, off + i));
+                if (p.scale_residual_sum) val = rnd<T>(val * p.post_layer_scalar);
+            }
+            st(shortcut, off + i, val);
+        }
+        s_val[i] = val;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sum = 0.0f, sum_sq = 0.0f;
+        for (size_t i = 0; i < element_count; ++i) {
+            const float accum_val = s_val[i];
+            if (p.subtract_mean) sum = sum + accum_val;
+            sum_sq = sum_sq + accum_val * accum_val;
+        }
+        const float mean = p.subtract_mean ? sum / element_count_accum : 0.0f;
+        const float variance = sum_sq / element_count_accum - mean * mean;
+        s_val[element_count] = mean;
+        s_val[element_count + 1] = 1.0f / sqrtf(variance + p.epsilon);
+    }
+    __syncthreads();
+    const float mean = s_val[element_count], rms_inv = s_val[element_count + 1];
+    for (size_t i = threadIdx.x; i < element_count; i += 256) {
+        // (the scalar kernel re-reads the shortcut it has just stored / the input: the same value as the staged one, T-rounded where it was stored)
+        const float input_val = p.residual_add ? (p.copy_to_shortcut ? s_val[i] : ld(shortcut, off + i)) : ld(input, off + i);
+        const float normalized = (input_val - mean) * rms_inv;
+        float result;
+        if (scales) {
+            const float scale_val = ld(scales, i);
+            if (p.full_layer) {
+                result = rnd<T>(normalized * (scale_val + p.scale_offset));
+            } else {
+                const float normalized_out = rnd<T>(normalized);
+                const float scale_out = rnd<T>(scale_val + p.scale_offset);
+                result = rnd<T>(normalized_out * scale_out);
+            }
+        } else {
+            result = rnd<T>(normalized);
+        }
+        if (biases) result = rnd<T>(result + ld(biases, i));
+        if (p.scale_output) result = rnd<T>(result * rnd<T>(p.post_layer_scalar));
+        st(output, off + i, result);
+    }
+}
+
 uzu_status normalization_exact(hipStream_t s, const NormParams& p) {
     if (p.batch_size == 0) return UZU_OK;
+    // in-place rows whose input IS the output and is not restaged through the shortcut would read elements another thread has already
+    // overwritten only if an element depended on its neighbours -- it does not: element i reads and writes index i alone
+    if (p.element_count <= 12288 && getenv("UZU_EXACT_SCALAR") == nullptr) {
+        const size_t lds = ((size_t)p.element_count + 2) * 4;
+        return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
+            if (p.affine_dt == UZU_F32) return launch_check([&] { hipLaunchKernelGGL((normalization_exact_row_kernel<T, float>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization_exact");
+            if (p.affine_dt == UZU_BF16) return launch_check([&] { hipLaunchKernelGGL((normalization_exact_row_kernel<T, bf16_t>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization_exact");
+            set_error("normalization: unsupported affine dtype %u", p.affine_dt);
+            return UZU_ERR_UNSUPPORTED;
+        });
+    }
     const uint32_t grid = (p.batch_size + 63) / 64;
     return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
         if (p.affine_dt == UZU_F32) return launch_check([&] { hipLaunchKernelGGL((normalization_exact_kernel<T, float>), dim3(grid), dim3(64), 0, s, p); }, "normalization_exact");
@@ -172,6 +247,105 @@ __global__ void __launch_bounds__(64) attention_exact_kernel(AttentionParams a_i
         for (uint32_t j = 0; j < HD; ++j) st(out, o_offset * HD + j, o[j] / sum_exp_score);
     }
 }
+// The same reduction orders with a WORKGROUP per (head, query, block) instead of a thread (round 5: a decode step has heads x blocks = 8 .. 1280
+// of them; one thread each, with q / o in private memory, took 3.5 ms per launch).  Per tile of 256 of the block's keys:
+//   1. thread t owns key t: score_t = sum_j q_j k_tj, j ascending, one accumulator (the scalar kernel's inner loop);
+//   2. the running maximum is a prefix maximum (max is exact and associative): every thread scans the tile's scores up to its own key, then
+//      factor_t = exp(max_before_t - max_t) and exp_score_t = exp(score_t - max_t) -- the scalar kernel's values, computed in parallel;
+//      thread 0 runs the one chain that is order-dependent, sum = sum * factor_t + exp_score_t, over the tile in key order;
+//   3. thread j owns output element j (and j + 256): o_j = o_j * factor_t + exp_score_t * v_tj for the tile's keys in order.
+// Masked keys are skipped exactly as the scalar kernel's `continue` does.  Bit-identical to attention_exact_kernel (GPU test).
+template <class T>
+__global__ void __launch_bounds__(256) attention_exact_coop_kernel(AttentionParams a_in, uint32_t num_blocks, float init_max, T* out, float* partials, float* sums, float* maxs) {
+    __shared__ float q_s[kExactMaxHeadDim];
+    __shared__ float score_s[256], fac_s[256], exp_s[256];
+    __shared__ uint32_t use_s[256];
+    __shared__ float s_state[2]; // running max, running sum
+    AttentionParams a = a_in;
+    attention_resolve_dyn(a);
+    const uint32_t HD = a.head_dim, tid = threadIdx.x;
+    const uint32_t sequence_length = a.sequence_length;
+    const uint32_t prefix_length = sequence_length - a.suffix_length;
+    const uint32_t suffix_position = a.is_kv_cache_ring ? a.ring_length : prefix_length;
+    const size_t idx = blockIdx.x;
+    const uint32_t block_idx = (uint32_t)(idx % num_blocks);
+    const size_t hq = idx / num_blocks;
+    const uint32_t head_idx = (uint32_t)(hq / a.suffix_length), q_seq_idx = (uint32_t)(hq % a.suffix_length);
+    const uint32_t kv_head_idx = head_idx / a.gqa_factor;
+    const size_t o_offset = (size_t)q_seq_idx * a.num_heads + head_idx;
+    const size_t q_offset = (size_t)head_idx * a.suffix_length + q_seq_idx;
+    const uint32_t query_position = attention_query_position(a, suffix_position, q_seq_idx);
+    const T* queries = (const T*)a.queries;
+    const T* keys = (const T*)a.keys;
+    const T* values = (const T*)a.values;
+    for (uint32_t j = tid; j < HD; j += 256) q_s[j] = a.scale * ld(queries, q_offset * HD + j);
+    float o0 = 0.0f, o1 = 0.0f;
+    if (tid == 0) {
+        float max_score = init_max, sum_exp_score = 0.0f;
+        if (a.sinks && block_idx == 0) {
+            max_score = ld((const T*)a.sinks, num_blocks == 1 ? head_idx % a.num_heads : head_idx);
+            sum_exp_score = 1.0f;
+        }
+        s_state[0] = max_score, s_state[1] = sum_exp_score;
+    }
+    __syncthreads();
+    const uint32_t keys_of_block = sequence_length > block_idx ? (sequence_length - block_idx + num_blocks - 1) / num_blocks : 0;
+    for (uint32_t base = 0; base < keys_of_block; base += 256) {
+        // 1. scores
+        const uint32_t n = base + tid;
+        const uint32_t i = block_idx + n * num_blocks;
+        const bool use = n < keys_of_block && should_use_key(a, q_seq_idx, prefix_length, suffix_position, query_position, i);
+        float score = 0.0f;
+        if (use) {
+            const size_t kb = (size_t)kv_head_idx * a.k_head_stride + (size_t)i * a.k_seq_stride;
+            for (uint32_t j = 0; j < HD; ++j) score += q_s[j] * ld(keys, kb + j);
+        }
+        score_s[tid] = score, use_s[tid] = use ? 1u : 0u;
+        __syncthreads();
+        // 2. prefix maxima -> factors, exponentials; the sum chain on thread 0
+        {
+            float before = s_state[0];
+            for (uint32_t t = 0; t < tid; ++t)
+                if (use_s[t]) before = fmaxf(before, score_s[t]);
+            if (use) {
+                const float new_max = fmaxf(before, score);
+                fac_s[tid] = expf_glibc(before - new_max);
+                exp_s[tid] = expf_glibc(score - new_max);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float max_score = s_state[0], sum_exp_score = s_state[1];
+            for (uint32_t t = 0; t < 256; ++t)
+                if (use_s[t]) {
+                    max_score = fmaxf(max_score, score_s[t]);
+                    sum_exp_score = sum_exp_score * fac_s[t] + exp_s[t];
+                }
+            s_state[0] = max_score, s_state[1] = sum_exp_score;
+        }
+        // 3. outputs
+        const uint32_t tile = keys_of_block - base < 256 ? keys_of_block - base : 256;
+        for (uint32_t t = 0; t < tile; ++t) {
+            if (!use_s[t]) continue;
+            const uint32_t it = block_idx + (base + t) * num_blocks;
+            const size_t vb = (size_t)kv_head_idx * a.v_head_stride + (size_t)it * a.v_seq_stride;
+            const float factor = fac_s[t], exp_score = exp_s[t];
+            if (tid < HD) o0 = o0 * factor + exp_score * ld(values, vb + tid);
+            if (tid + 256 < HD) o1 = o1 * factor + exp_score * ld(values, vb + tid + 256);
+        }
+        __syncthreads();
+    }
+    const float max_score = s_state[0], sum_exp_score = s_state[1];
+    if (partials) {
+        float* out_base = partials + (o_offset * num_blocks + block_idx) * HD;
+        if (tid < HD) out_base[tid] = o0;
+        if (tid + 256 < HD) out_base[tid + 256] = o1;
+        if (tid == 0) sums[o_offset * num_blocks + block_idx] = sum_exp_score, maxs[o_offset * num_blocks + block_idx] = max_score;
+    } else {
+        if (tid < HD) st(out, o_offset * HD + tid, o0 / sum_exp_score);
+        if (tid + 256 < HD) st(out, o_offset * HD + tid + 256, o1 / sum_exp_score);
+    }
+}
 static uzu_status attention_exact_launch(hipStream_t s, const AttentionParams& a, uint32_t num_blocks, float init_max, void* out, float* partials, float* sums, float* maxs) {
     if (!a.suffix_length || !a.num_heads) return UZU_OK;
     if (a.head_dim > kExactMaxHeadDim) {
@@ -179,6 +353,12 @@ static uzu_status attention_exact_launch(hipStream_t s, const AttentionParams& a
         return UZU_ERR_UNSUPPORTED;
     }
     const size_t total = (size_t)a.num_heads * a.suffix_length * num_blocks;
+    if (total <= 16384 && getenv("UZU_EXACT_SCALAR") == nullptr) // decode steps, tree passes, short suffixes: a workgroup per reduction
+        return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status {
+            return launch_check([&] {
+                hipLaunchKernelGGL((attention_exact_coop_kernel<T>), dim3((uint32_t)total), dim3(256), 0, s, a, num_blocks, init_max, (T*)out, partials, sums, maxs);
+            }, "attention_exact");
+        });
     return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status {
         return launch_check([&] {
             hipLaunchKernelGGL((attention_exact_kernel<T>), dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, s, a, num_blocks, init_max, (T*)out, partials, sums, maxs);
@@ -207,10 +387,41 @@ __global__ void __launch_bounds__(64) attention_two_pass2_exact_kernel(const flo
         st(out, o_offset * HD + j, val / global_sum);
     }
 }
+// a workgroup per output row: thread j owns output element j (its 32-term sum in block order, as above); the weights exp(max_b - global_max)
+// are the same values for every j and are computed once per block by thread b
+template <class T>
+__global__ void __launch_bounds__(256) attention_two_pass2_exact_row_kernel(const float* partials, const float* sums, const float* maxs, T* out, uint32_t HD) {
+    __shared__ float w_s[32];
+    __shared__ float s_sum;
+    const size_t o_offset = blockIdx.x;
+    const float* mx = maxs + o_offset * 32;
+    const float* sm = sums + o_offset * 32;
+    float global_max = -INFINITY;
+    for (uint32_t b = 0; b < 32; ++b) global_max = fmaxf(global_max, mx[b]);
+    if (threadIdx.x < 32) w_s[threadIdx.x] = expf_glibc(mx[threadIdx.x] - global_max);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float global_sum = 0.0f;
+        for (uint32_t b = 0; b < 32; ++b) global_sum += sm[b] * w_s[b];
+        s_sum = global_sum;
+    }
+    __syncthreads();
+    const float global_sum = s_sum;
+    for (uint32_t j = threadIdx.x; j < HD; j += 256) {
+        float val = 0.0f;
+        for (uint32_t b = 0; b < 32; ++b) val += partials[(o_offset * 32 + b) * HD + j] * w_s[b];
+        st(out, o_offset * HD + j, val / global_sum);
+    }
+}
 uzu_status attention_two_pass2_exact(hipStream_t s, const float* partials, const float* sums, const float* maxs, void* out, uint32_t dt, uint32_t head_dim, uint32_t num_heads,
                                      uint32_t suffix_length) {
     const uint32_t rows = num_heads * suffix_length;
     if (!rows) return UZU_OK;
+    if (rows <= 16384 && getenv("UZU_EXACT_SCALAR") == nullptr)
+        return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
+            return launch_check([&] { hipLaunchKernelGGL((attention_two_pass2_exact_row_kernel<T>), dim3(rows), dim3(256), 0, s, partials, sums, maxs, (T*)out, head_dim); },
+                                "attention_two_pass2_exact");
+        });
     return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
         return launch_check([&] { hipLaunchKernelGGL((attention_two_pass2_exact_kernel<T>), dim3((rows + 63) / 64), dim3(64), 0, s, partials, sums, maxs, (T*)out, head_dim, rows); },
                             "attention_two_pass2_exact");

@@ -92,6 +92,78 @@ __global__ void __launch_bounds__(256) matmul_ref_kernel(MatmulParams p, uint32_
     epilogue_store(p, row, col, accumulator);
 }
 
+// Reference-order kernel, vectorised: the SAME arithmetic per element in the SAME order as matmul_ref_kernel (one thread per output,
+// `b_value = scale * code + bias_term; accumulator += a_value * b_value` for inner = 0 .. k - 1, no contraction) -- so bit-identical
+// results -- but the memory side is a 16-byte vector of codes per 32 (int4) / 16 (int8) elements, the group's scale / bias once per
+// vector, and a wave-uniform activation row (a wave = 64 consecutive columns of ONE row: the activation loads are broadcasts).  Round 5:
+// matmul_ref_kernel issued ~6 dependent byte / halfword loads per element; a reference-order 4096-token Llama-3-8B prefill took 257 s
+// and a decode step 0.8 s, which priced the reference-order proxy oracle out of configuration-scale parity tests and of a parity census.
+// Covers quantised B, bf16 / f32 activations and scales, no gather; everything else stays on matmul_ref_kernel.
+template <int BITS, class TA, class TW>
+__global__ void __launch_bounds__(256) matmul_ref_vec_kernel(MatmulParams p) {
+    constexpr uint32_t EPV = 128 / BITS; // elements per 16-byte vector of codes
+    const uint32_t col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (row >= p.m) return;
+    const bool live = col < p.n;
+    const uint32_t b_col = live ? col : p.n - 1; // clamped: computed, never stored
+    const uint32_t k = p.k, group_size = p.group_size;
+    const size_t num_groups_k = (k + group_size - 1) / group_size;
+    const size_t zero_point_stride = BITS == 4 ? (num_groups_k + 1) / 2 : num_groups_k;
+    const uint4* codes = (const uint4*)((const uint8_t*)p.b + (size_t)b_col * k * BITS / 8);
+    const TA* a = (const TA*)p.a + (size_t)row * k;
+    const TW* scales = (const TW*)p.scales + (size_t)b_col * num_groups_k;
+    const TW* biases = p.biases ? (const TW*)p.biases + (size_t)b_col * num_groups_k : nullptr;
+    const uint32_t flip = p.signed_codes ? 1u << (BITS - 1) : 0u;
+    float accumulator = 0.0f;
+    for (uint32_t k0 = 0; k0 < k; k0 += EPV) {
+        const uint4 cv = codes[k0 / EPV];
+        const uint32_t words[4] = {cv.x, cv.y, cv.z, cv.w};
+        const size_t group_index = k0 / group_size; // group_size % EPV == 0: one group per vector
+        const float scale = ld<TW>(scales, group_index);
+        float bias_term;
+        if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
+            float zp;
+            if (BITS == 4) {
+                const uint8_t byte_value = p.zero_points[(size_t)b_col * zero_point_stride + (group_index >> 1)];
+                zp = (group_index & 1) == 0 ? (float)(byte_value & 0x0F) : (float)((byte_value >> 4) & 0x0F);
+            } else {
+                zp = (float)p.zero_points[(size_t)b_col * zero_point_stride + group_index];
+            }
+            bias_term = -scale * zp;
+        } else if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) {
+            bias_term = ld<TW>(biases, group_index);
+        } else {
+            bias_term = -scale * (float)(1u << (BITS - 1));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < EPV; ++j) {
+            const float a_value = ld<TA>(a, k0 + j);
+            const uint32_t weight_code = ((words[j * BITS / 32] >> ((j * BITS) % 32)) & ((1u << BITS) - 1u)) ^ flip;
+            const float quantized_value = (float)weight_code;
+            const float b_value = scale * quantized_value + bias_term;
+            accumulator += a_value * b_value;
+        }
+    }
+    if (live) epilogue_store(p, row, col, accumulator);
+}
+static bool matmul_ref_vec_supported(const MatmulParams& p) {
+    if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || p.gather || (p.bits != 4 && p.bits != 8)) return false;
+    const uint32_t epv = 128 / p.bits;
+    if (p.k % epv || p.group_size % epv || (uintptr_t)p.b % 16 || ((size_t)p.k * p.bits / 8) % 16) return false;
+    if (!(p.a_dt == UZU_BF16 || p.a_dt == UZU_F32) || !(p.w_dt == UZU_BF16 || p.w_dt == UZU_F32)) return false;
+    return getenv("UZU_EXACT_SCALAR") == nullptr; // UZU_EXACT_SCALAR=1: the element-by-element kernel (A/B of the two: tests)
+}
+template <int BITS> static uzu_status launch_ref_vec(hipStream_t s, const MatmulParams& p) {
+    const dim3 grid((p.n + 63) / 64, (p.m + 3) / 4);
+    return launch_check([&] {
+        if (p.a_dt == UZU_BF16 && p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
+        else if (p.a_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, float>), grid, dim3(256), 0, s, p);
+        else if (p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, bf16_t>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, float>), grid, dim3(256), 0, s, p);
+    }, "matmul_ref_vec");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fast quantised GEMV (lane mapping and arithmetic: gemv_core.h).
 template <class TA> __device__ __forceinline__ void load_x32(const TA* a, size_t e, float (&xf)[32]);
@@ -256,6 +328,7 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
     const bool fast = quant && !exact_mode() && aligned && p.k % wpc == 0 && p.group_size % wpc == 0 &&
                       (p.w_dt == p.a_dt) && (p.w_dt == UZU_BF16 || p.w_dt == UZU_F32);
     if (!fast) {
+        if (matmul_ref_vec_supported(p)) return p.bits == 4 ? launch_ref_vec<4>(s, p) : launch_ref_vec<8>(s, p);
         const size_t total = (size_t)p.m * p.n;
         return launch_check([&] {
             hipLaunchKernelGGL(matmul_ref_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, p, 1u, p.k);

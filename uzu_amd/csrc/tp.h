@@ -14,6 +14,7 @@ struct Comm;
 uzu_status unique_id(uint8_t out[128]);                                  // rank 0: ncclGetUniqueId
 uzu_status comm_create(const uint8_t id[128], int rank, int size, Comm** out); // collective over the group
 void comm_destroy(Comm* c);
+uzu_status comm_stats(Comm* c, uint32_t* rccl_ranks, unsigned long long* rccl_calls, unsigned long long* p2p_calls);
 int comm_rank(const Comm* c);
 int comm_size(const Comm* c);
 
@@ -34,6 +35,12 @@ uzu_status cast_f32_bf16(hipStream_t s, const float* in, uint16_t* out, size_t n
 uzu_status argmax_key(hipStream_t s, const float* part_val, const uint32_t* part_idx, uint32_t parts, uint32_t vocab_offset, unsigned long long* key);
 uzu_status key_from_token(hipStream_t s, const uint16_t* logits, const uint32_t* local_token, uint32_t vocab_offset, unsigned long long* key);
 uzu_status token_from_key(hipStream_t s, const unsigned long long* key, uint32_t* out_token);
+// `rows` sampled rows at once (the nodes of a speculated tree): keys[r] from the local arg-max of row r, and back
+uzu_status keys_from_tokens(hipStream_t s, const uint16_t* logits, size_t row_stride, const uint32_t* local_tokens, uint32_t vocab_offset, unsigned long long* keys, uint32_t rows);
+uzu_status tokens_from_keys(hipStream_t s, const unsigned long long* keys, uint32_t* out_tokens, uint32_t rows);
+// full bf16 logit rows [rows, vocab] on every rank from the ranks' shards [rows, local_n] (stochastic sampling needs the whole distribution):
+// scatter into a zeroed f32 row at vocab_offset, all-reduce(sum) -- exact, one non-zero term per element
+uzu_status gather_logits(Comm* c, hipStream_t s, const uint16_t* local, uint32_t local_n, uint32_t vocab_offset, uint32_t vocab, uint32_t rows, float* full_f32, uint16_t* full_bf16);
 uzu_status commit_key(hipStream_t s, const unsigned long long* key, uint32_t* ctx_len, uint32_t* tokens, uint32_t* out_token, uint32_t* sampled);
 
 } // namespace tp

@@ -27,6 +27,7 @@ struct Api {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr; // optional
 };
 Api g_api;
 
@@ -47,6 +48,7 @@ uzu_status load_api() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         set_error("tp: librccl lacks a required entry point");
         return UZU_ERR_UNSUPPORTED;
@@ -119,6 +121,29 @@ __global__ void token_from_key_kernel(const unsigned long long* key, uint32_t* o
     const uint32_t t = 0xFFFFFFFFu - inv;
     *out_token = t == 0xFFFFFFFFu ? 0u : t;
 }
+// the same for `rows` sampled rows at once (a speculated tree's nodes): logits [rows, row_stride] of this rank's shard
+__global__ void keys_from_tokens_kernel(const uint16_t* logits, size_t row_stride, const uint32_t* local_tokens, uint32_t vocab_offset, unsigned long long* keys, uint32_t rows) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t t = local_tokens[r];
+    keys[r] = ((unsigned long long)orderable(bf16_to_f32(logits[(size_t)r * row_stride + t])) << 32) | (unsigned long long)(0xFFFFFFFFu - (t + vocab_offset));
+}
+__global__ void tokens_from_keys_kernel(const unsigned long long* keys, uint32_t* out_tokens, uint32_t rows) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t t = 0xFFFFFFFFu - (uint32_t)(keys[r] & 0xFFFFFFFFull);
+    out_tokens[r] = t == 0xFFFFFFFFu ? 0u : t;
+}
+// Stochastic sampling needs the WHOLE distribution of a row (top-k / top-p / min-p, unified_sampling.rs:13-99): every rank files its shard of
+// the bf16 logits at its vocabulary offset of a zeroed f32 row; the sum over the ranks is then the full row, exactly (one non-zero term per
+// element), and its bf16 rounding gives back the shard's own bits.
+__global__ void __launch_bounds__(256) scatter_shard_kernel(const uint16_t* local, uint32_t local_n, uint32_t vocab_offset, uint32_t vocab, float* full) {
+    const uint32_t row = blockIdx.y;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) {
+        const uint32_t j = i - vocab_offset; // wraps for i < vocab_offset
+        full[(size_t)row * vocab + i] = j < local_n ? bf16_to_f32(local[(size_t)row * local_n + j]) : 0.0f;
+    }
+}
 // the fused decode step's commit (k_decode.hip::argmax_commit_kernel) with the token taken from the reduced key
 __global__ void commit_key_kernel(const unsigned long long* key, uint32_t* ctx_len, uint32_t* tokens, uint32_t* out_token, uint32_t* sampled) {
     const uint32_t inv = (uint32_t)(*key & 0xFFFFFFFFull);
@@ -163,6 +188,7 @@ struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
     P2P p2p;
+    unsigned long long rccl_calls = 0, p2p_calls = 0; // collectives enqueued on either route (host counters: a captured graph counts once)
 };
 
 namespace {
@@ -170,6 +196,7 @@ struct P2PArgs {
     Mailbox* box[kMaxRanks];
     int rank, size;
     unsigned long long timeout_ticks; // bounded wait, in ticks of the 100 MHz s_memrealtime clock
+    uint32_t inject_seq;              // test hook (UZU_TP_INJECT_TIMEOUT_AT): the exchange with this sequence number behaves as if its wait had given up
 };
 // OP 0: f32 sum over `count` floats (in place on buf; `bf16_out` (optional) also receives the sums rounded to bf16: the cast the
 // engine would otherwise launch as its own kernel); OP 1: u64 max over `count` keys (buf = unsigned long long*).
@@ -218,6 +245,8 @@ __global__ void __launch_bounds__(256) p2p_all_reduce_kernel(P2PArgs a, void* bu
             }
         }
     }
+    __syncthreads();
+    if (tid == 0 && a.inject_seq && seq == a.inject_seq) s_ok = 0u; // injected failure: same path as a real time-out from here on
     __syncthreads();
     if (!s_ok) {
         // gave up (or an earlier exchange did): record the first failing sequence number, poison the result, and still advance the
@@ -394,7 +423,23 @@ template <int OP> static uzu_status p2p_launch(Comm* c, hipStream_t s, void* buf
     for (int r = 0; r < c->size; ++r) a.box[r] = c->p2p.peer[r];
     a.rank = c->rank, a.size = c->size;
     a.timeout_ticks = p2p_timeout_ticks();
+    static const uint32_t inject = [] {
+        const char* e = getenv("UZU_TP_INJECT_TIMEOUT_AT");
+        return e && atol(e) > 0 ? (uint32_t)atol(e) : 0u;
+    }();
+    a.inject_seq = inject;
+    ++c->p2p_calls;
     return launch_check([&] { hipLaunchKernelGGL(p2p_all_reduce_kernel<OP>, dim3(1), dim3(256), 0, s, a, buf, count, bf16_out); }, "tp_p2p_all_reduce");
+}
+// ranks the RCCL communicator itself reports (ncclCommCount; 0 = no communicator), collectives enqueued through RCCL / the mailboxes
+uzu_status comm_stats(Comm* c, uint32_t* rccl_ranks, unsigned long long* rccl_calls, unsigned long long* p2p_calls) {
+    UZU_REQUIRE(c, "tp_comm_stats: null communicator");
+    int n = 0;
+    if (c->comm && g_api.CommCount) UZU_PROPAGATE(check(g_api.CommCount(c->comm, &n), "ncclCommCount"));
+    if (rccl_ranks) *rccl_ranks = (uint32_t)n;
+    if (rccl_calls) *rccl_calls = c->rccl_calls;
+    if (p2p_calls) *p2p_calls = c->p2p_calls;
+    return UZU_OK;
 }
 int comm_rank(const Comm* c) { return c->rank; }
 int comm_size(const Comm* c) { return c->size; }
@@ -412,12 +457,14 @@ uzu_status all_reduce_sum_f32(Comm* c, hipStream_t s, float* buf, size_t count, 
         return UZU_OK;
     }
     UZU_REQUIRE(c->comm, "tp: no RCCL communicator for a %zu-float all-reduce", count);
+    ++c->rccl_calls;
     UZU_PROPAGATE(check(g_api.AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->comm, s), "ncclAllReduce(sum,f32)"));
     return bf16_out ? cast_f32_bf16(s, buf, bf16_out, count) : UZU_OK;
 }
 uzu_status all_reduce_max_u64(Comm* c, hipStream_t s, unsigned long long* buf, size_t count) {
     if (c->p2p.connected && count * 2 <= kMailboxFloats) return p2p_launch<1>(c, s, buf, (uint32_t)count);
     UZU_REQUIRE(c->comm, "tp: no RCCL communicator");
+    ++c->rccl_calls;
     return check(g_api.AllReduce(buf, buf, count, ncclUint64, ncclMax, c->comm, s), "ncclAllReduce(max,u64)");
 }
 
@@ -433,6 +480,16 @@ uzu_status key_from_token(hipStream_t s, const uint16_t* logits, const uint32_t*
 }
 uzu_status token_from_key(hipStream_t s, const unsigned long long* key, uint32_t* out_token) {
     return launch_check([&] { hipLaunchKernelGGL(token_from_key_kernel, dim3(1), dim3(1), 0, s, key, out_token); }, "tp_token_from_key");
+}
+uzu_status keys_from_tokens(hipStream_t s, const uint16_t* logits, size_t row_stride, const uint32_t* local_tokens, uint32_t vocab_offset, unsigned long long* keys, uint32_t rows) {
+    return launch_check([&] { hipLaunchKernelGGL(keys_from_tokens_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, logits, row_stride, local_tokens, vocab_offset, keys, rows); }, "tp_keys_from_tokens");
+}
+uzu_status tokens_from_keys(hipStream_t s, const unsigned long long* keys, uint32_t* out_tokens, uint32_t rows) {
+    return launch_check([&] { hipLaunchKernelGGL(tokens_from_keys_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, keys, out_tokens, rows); }, "tp_tokens_from_keys");
+}
+uzu_status gather_logits(Comm* c, hipStream_t s, const uint16_t* local, uint32_t local_n, uint32_t vocab_offset, uint32_t vocab, uint32_t rows, float* full_f32, uint16_t* full_bf16) {
+    UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(scatter_shard_kernel, dim3(64, rows), dim3(256), 0, s, local, local_n, vocab_offset, vocab, full_f32); }, "tp_scatter_shard"));
+    return all_reduce_sum_f32(c, s, full_f32, (size_t)rows * vocab, full_bf16);
 }
 uzu_status commit_key(hipStream_t s, const unsigned long long* key, uint32_t* ctx_len, uint32_t* tokens, uint32_t* out_token, uint32_t* sampled) {
     return launch_check([&] { hipLaunchKernelGGL(commit_key_kernel, dim3(1), dim3(1), 0, s, key, ctx_len, tokens, out_token, sampled); }, "tp_commit_key");

@@ -49,6 +49,10 @@ class HipState:
     def reset(self):
         call("uzu_hip_state_reset", self._h)
 
+    def copy_from(self, other: "HipState"):
+        """self <- other (uzu_hip_state_copy): caches, recurrent states, token history, context length."""
+        call("uzu_hip_state_copy", self._h, other._h)
+
     @property
     def context_length(self) -> int:
         fn = _ffi.lib().uzu_hip_state_context_length
@@ -162,14 +166,19 @@ class HipModel:
         return out
 
     # ---- speculative decoding (stream.rs:380-470, 556-628; host trie: uzu_amd/trie.py) ----
-    def verify_tree(self, token_ids, trie_nodes) -> np.ndarray:
+    def verify_tree(self, token_ids, trie_nodes, seeds=None) -> np.ndarray:
         """One forward pass over a speculated tree (DFS order; trie_nodes uint32 [n, 3] = {start, end, height}) hanging off the
-        sequence; nothing is accepted.  -> the greedy token sampled at every node."""
+        sequence; nothing is accepted.  -> the token sampled at every node (greedy, or with set_sampling the node's own draw).
+        `seeds` (uint64 [n], FlatTrie.token_seeds(): the seeds the speculator gave its nodes, stream.rs:694) replace the default
+        PRng::derive(context + height) per node under stochastic sampling."""
         token_ids = np.ascontiguousarray(token_ids, dtype=np.uint32)
         trie_nodes = np.ascontiguousarray(trie_nodes, dtype=np.uint32).reshape(token_ids.size, 3)
         sampled = np.empty(token_ids.size, dtype=np.uint32)
-        call("uzu_hip_model_verify_tree", self._h, C.c_void_p(token_ids.ctypes.data), C.c_void_p(trie_nodes.ctypes.data), C.c_uint32(token_ids.size),
-             C.c_void_p(sampled.ctypes.data))
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert seeds.size == token_ids.size
+        call("uzu_hip_model_verify_tree_seeded", self._h, C.c_void_p(token_ids.ctypes.data), C.c_void_p(trie_nodes.ctypes.data),
+             C.c_void_p(seeds.ctypes.data) if seeds is not None else None, C.c_uint32(token_ids.size), C.c_void_p(sampled.ctypes.data))
         self._tree_size = int(token_ids.size)
         return sampled
 
@@ -189,19 +198,21 @@ class HipModel:
         call("uzu_hip_model_read_tree_logits", self._h, C.c_void_p(out.ctypes.data))
         return out
 
-    def speculative_step(self, root_token: int, propose):
+    def speculative_step(self, root_token: int, propose, trie_seeds: bool = False):
         """One round of LanguageModelStream's speculative loop: `propose(root_token)` returns a uzu_amd.trie.TrieNode whose root carries
         `root_token` (the last sampled token); the tree is verified in one pass, the accepted path taken.  -> the tokens gained (the
-        tokens sampled along the accepted path: at least one, whatever the proposal)."""
+        tokens sampled along the accepted path: at least one, whatever the proposal).  `trie_seeds`: under stochastic sampling every node
+        draws with the seed its TrieNode carries (what the reference stream uploads, stream.rs:690-695) instead of the position-derived one."""
         flat = propose(root_token).linearize()
-        sampled = self.verify_tree(flat.token_ids(), flat.nodes())
+        sampled = self.verify_tree(flat.token_ids(), flat.nodes(), flat.token_seeds() if trie_seeds else None)
         accepted = flat.accept(sampled)
         self.accept([index for index, _, _ in accepted])
         return [int(out) for _, _, out in accepted]
 
     def read_layer_output(self, layer: int) -> np.ndarray:
-        out = np.empty(1024 * self.model_dim, dtype=np.uint16)
-        rows = C.c_uint32()
+        rows, capacity = C.c_uint32(), C.c_uint32()
+        call("uzu_hip_model_layer_output_rows", self._h, C.byref(rows), C.byref(capacity))  # a prefill pass holds up to `chunk` rows (2048 by default, UZU_PREFILL_CHUNK)
+        out = np.empty(max(capacity.value, rows.value, 1) * self.model_dim, dtype=np.uint16)
         call("uzu_hip_model_read_layer_output", self._h, C.c_uint32(layer), C.c_void_p(out.ctypes.data), C.byref(rows))
         return out[: rows.value * self.model_dim].reshape(rows.value, self.model_dim).copy()
 

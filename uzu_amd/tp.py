@@ -156,8 +156,15 @@ def _head_range(total: int, rank: int, size: int) -> Tuple[int, int]:
     return h, h + 1
 
 
-def padded_hidden(hidden: int, group: int, size: int) -> int:
+def padded_hidden(hidden: int, group: int, size: int, rht: bool = False) -> int:
+    """Hidden width every rank can take an equal, whole-quant-group slice of.  `rht`: the MLP linears carry Hadamard factors -- the padding
+    between the up and gate halves of the fused matrix must then be whole 32-row blocks too (otherwise the gate half shifts against its
+    OutputRht blocks while still passing take_rows' alignment check on the REBUILT matrix) and every rank's slice a multiple of 32."""
     unit = max(group, 1) * size
+    if rht:
+        unit = int(np.lcm(unit, RHT_BLOCK * size))
+        if hidden % RHT_BLOCK:
+            raise NotImplementedError("tensor-parallel MLP shard of a HybridSpec linear whose hidden width is not a multiple of the 32-element Hadamard block")
     return (hidden + unit - 1) // unit * unit
 
 
@@ -167,7 +174,8 @@ def shard_layer(l: D.LayerWeights, rank: int, size: int) -> D.LayerWeights:
     # ---- MLP: up || gate column-parallel, down row-parallel
     h = l.hidden_dim
     group = l.down_projection.group_size if l.down_projection.method != D.QUANT_NONE else 1
-    hp = padded_hidden(h, group, size)
+    rht = any(x is not None for x in (l.up_projection.output_signs, l.up_projection.input_signs, l.down_projection.input_signs, l.down_projection.output_signs))
+    hp = padded_hidden(h, group, size, rht)
     per = hp // size
     lo, hi = rank * per, (rank + 1) * per
     up_full, down_full = l.up_projection, l.down_projection
@@ -292,6 +300,12 @@ class TpGroup:
         out = C.c_uint32()
         call("uzu_hip_tp_p2p_error", self._h, C.byref(out))
         return out.value
+
+    def stats(self) -> Tuple[int, int, int]:
+        """(ranks the RCCL communicator reports -- 0 for a local group --, collectives enqueued through RCCL, exchanges through the mailboxes)"""
+        ranks, rccl, p2p = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        call("uzu_hip_tp_comm_stats", self._h, C.byref(ranks), C.byref(rccl), C.byref(p2p))
+        return ranks.value, rccl.value, p2p.value
 
     def all_reduce_sum_f32(self, buf, count: int, offset_bytes: int = 0):
         call("uzu_hip_tp_all_reduce_sum_f32", self.ctx._h, self._h, buf._h, C.c_size_t(offset_bytes), C.c_size_t(count))
