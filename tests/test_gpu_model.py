@@ -946,3 +946,136 @@ def test_state_copy_continues_a_prefilled_prefix(hip_ctx, preset):
     hm.bind(None)
     snap.close(), work.close()
     hm.close()
+
+
+# ------------------------------------------------------------------------------------------ parity at the sizes the BASELINE configs name
+# The CPU oracle cannot reach a 4096-token Llama-3-8B prefill or a 14B-class decode at context 8192 (hours); reference-order mode can
+# (round 5: ~20 s / ~0.1 s per step) and is the proxy oracle there -- its logits are bit-identical to the CPU oracle's wherever the oracle
+# runs (test_exact_mode_*: tiny models, the full-size 0.8B model, the bench fixture's whole stream).  UZU_SKIP_SCALE_TESTS=1 skips them
+# (about three GPU-minutes together, most of it building 4 + 8 GB of synthetic weights on the host).
+scale = pytest.mark.skipif(os.environ.get("UZU_SKIP_SCALE_TESTS") == "1", reason="UZU_SKIP_SCALE_TESTS=1")
+
+
+def _band_check(label, ref_bits, got_bits, row_mult, tol=0.25):
+    """Production logits `got` against reference-order logits `ref` of the same row: the reference's top-8 matched within `tol` sigma
+    (row-normalised), the production arg-max = the reference's token or a token the reference itself places within the band of its top."""
+    ref, got = f32(ref_bits).astype(np.float64), f32(got_bits).astype(np.float64)
+    sigma = (ref / row_mult).std()
+    top8 = np.argsort(ref)[-8:]
+    err = float((np.abs(got[top8] - ref[top8]) / row_mult[top8]).max() / sigma)
+    assert err <= tol, f"{label}: a top-8 logit is off by {err:.3f} sigma (row-normalised; tolerance {tol})"
+    best, amax = int(np.argmax(ref)), int(np.argmax(got))
+    margin = 0.0 if amax == best else float((ref[best] - ref[amax]) / (sigma * (row_mult[best] + row_mult[amax])))
+    assert margin <= tol, f"{label}: production arg-max {amax} != reference {best}, and the reference separates them by {margin:.3f} sigma (band {tol})"
+    return err, margin
+
+
+@scale
+def test_config3_scale_llama3_8b_4096_token_prefill_production_vs_reference_order(hip_ctx):
+    """BASELINE configs[2] at its own size: Llama-3-8B int4, all 32 layers, 4096-token prompts.  (a) sequence 0 prefilled by the production
+    kernels (matrix-core GEMMs at M = 2048 per pass, flash-attention tiles) against the same prefill in reference-order mode: the reference's
+    top-8 logits within 0.25 sigma, arg-max equal or inside the band; (b) bench.py --config c3's batched prefill (8 sequences per pass,
+    M = 8 x 2048) against the same 8 prompts prefilled one at a time: every first token equal, or decided inside the band by the single run's
+    own logits (a batched pass may split K of a GEMM differently: tolerance class, stream.rs:194 chunking is per sequence either way)."""
+    nseq, plen = 8, 4096
+    cfg = S.llama3_8b(max_context_length=plen + 8)
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg).astype(np.float64)
+    base = S.synthetic_prompt(plen, cfg.vocab_size).astype(np.int64)
+    prompts = np.stack([(base * (2 * i + 1) + 17 * i) % cfg.vocab_size for i in range(nseq)]).astype(np.uint32)  # bench.py::bench_c3's prompts
+    hm = HipModel(hip_ctx, bundle, MODEL_BATCH(nseq))
+    states = [hm.new_state() for _ in range(nseq)]
+    batched = [int(t) for t in hm.prefill_batch(states, prompts)]
+    single_tokens, single_logits = [], []
+    for i, st in enumerate(states):
+        st.reset()
+        hm.bind(st)
+        single_tokens.append(int(hm.prefill(prompts[i])))
+        single_logits.append(hm.read_logits())
+    hm.bind(None)
+    for i in range(nseq):
+        ref = f32(single_logits[i]).astype(np.float64)
+        sigma = (ref / row_mult).std()
+        a, b = single_tokens[i], batched[i]
+        margin = 0.0 if a == b else float((ref[a] - ref[b]) / (sigma * (row_mult[a] + row_mult[b])))
+        assert margin <= 0.25, f"sequence {i}: batched first token {b} != single {a}, separated by {margin:.3f} sigma in the single run's logits"
+    for st in states:
+        st.close()
+    hm.close()
+    _set_exact(True)
+    try:
+        ex = HipModel(hip_ctx, bundle)
+        ex.prefill(prompts[0])
+        ref_logits = ex.read_logits()
+        ex.close()
+    finally:
+        _set_exact(False)
+    err, margin = _band_check("llama-3-8b 4096-token prefill", ref_logits, single_logits[0], row_mult)
+    print(f"config 3 scale: production vs reference-order after a 4096-token prefill: worst top-8 logit error {err:.3f} sigma, arg-max margin {margin:.3f}; "
+          f"batched vs single first tokens equal in {sum(int(a == b) for a, b in zip(single_tokens, batched))}/{nseq}")
+
+
+@scale
+def test_config5_scale_14b_class_decode_and_prefill_chunk_at_context_8192(hip_ctx):
+    """BASELINE configs[4] at its own size: the 14B-class model (d 5120, ffn 17408, 40 q / 8 kv heads, vocab 151 936), all 40 layers, context
+    8192.  The context is prefilled ONCE by the production kernels and copied (uzu_hip_state_copy), so that both sides start from the same
+    caches; then (a) 3 decode steps at context 8192+ -- fused decode GEMVs at K = 5120 / 17408 with the LDS-resident row, attn_dec over 8192
+    keys, the 151 936-row read-out -- against the same steps in reference-order mode, teacher-forced with the reference's tokens; (b) the
+    `mixed prefill + decode` leg: a 256-token prompt chunk appended at context 8192 (matrix-core GEMMs, two-pass attention over the long
+    prefix) against the same chunk in reference-order mode.  Bars as everywhere: the reference's top-8 logits within 0.25 sigma
+    (row-normalised), arg-max equal or inside the band."""
+    ctx_len, chunk = 8192, 256
+    cfg = S.qwen3_14b_class(max_context_length=ctx_len + chunk + 16)
+    bundle = S.build_model(cfg)
+    row_mult = S.readout_row_multipliers(cfg).astype(np.float64)
+    prompt = S.synthetic_prompt(ctx_len, cfg.vocab_size)
+    extra = ((S.synthetic_prompt(chunk, cfg.vocab_size).astype(np.int64) * 3 + 11) % cfg.vocab_size).astype(np.uint32)
+    hm = HipModel(hip_ctx, bundle)
+    base, work = hm.new_state(), hm.new_state()
+    hm.bind(base)
+    first = hm.prefill(prompt)
+
+    def run(exact, what):
+        work.copy_from(base)
+        hm.bind(work)
+        _set_exact(exact)
+        try:
+            if what == "chunk":
+                hm.prefill(extra)
+                return [hm.read_logits()]
+            rows, toks = [], list(what)
+            for t in toks:
+                hm.set_next_token(t)
+                hm.decode(1)
+                rows.append(hm.read_logits())
+            return rows
+        finally:
+            _set_exact(False)
+
+    # (a) decode: the reference-order side chains on its own tokens; production is teacher-forced with them
+    work.copy_from(base)
+    hm.bind(work)
+    _set_exact(True)
+    try:
+        forced, ref_rows, tok = [], [], first
+        for _ in range(3):
+            forced.append(tok)
+            hm.set_next_token(tok)
+            t, _ms = hm.decode(1)
+            ref_rows.append(hm.read_logits())
+            tok = int(t[0])
+    finally:
+        _set_exact(False)
+    got_rows = run(False, forced)
+    worst = 0.0
+    for i, (r, g) in enumerate(zip(ref_rows, got_rows)):
+        err, _ = _band_check(f"14B-class decode step {i} at context {ctx_len + i}", r, g, row_mult)
+        worst = max(worst, err)
+    # (b) a prompt chunk at the long context
+    ref_chunk = run(True, "chunk")[0]
+    got_chunk = run(False, "chunk")[0]
+    err_c, _ = _band_check(f"14B-class {chunk}-token prefill chunk at context {ctx_len}", ref_chunk, got_chunk, row_mult)
+    print(f"config 5 scale: decode at context {ctx_len}: worst top-8 logit error {worst:.3f} sigma over 3 steps; {chunk}-token chunk at that context: {err_c:.3f} sigma")
+    hm.bind(None)
+    base.close(), work.close()
+    hm.close()

@@ -99,23 +99,28 @@ __global__ void __launch_bounds__(256) matmul_ref_kernel(MatmulParams p, uint32_
 // matmul_ref_kernel issued ~6 dependent byte / halfword loads per element; a reference-order 4096-token Llama-3-8B prefill took 257 s
 // and a decode step 0.8 s, which priced the reference-order proxy oracle out of configuration-scale parity tests and of a parity census.
 // Covers quantised B, bf16 / f32 activations and scales, no gather; everything else stays on matmul_ref_kernel.
-template <int BITS, class TA, class TW>
+template <int BITS, class TA, class TW, int MR>
 __global__ void __launch_bounds__(256) matmul_ref_vec_kernel(MatmulParams p) {
+    // a thread owns column `col` of MR consecutive rows (MR = 4 for prefill-sized M: the dequantised b_value of an element is computed once
+    // and used by four accumulators; the rows' activation values are wave-uniform -- the row index comes from blockIdx alone)
     constexpr uint32_t EPV = 128 / BITS; // elements per 16-byte vector of codes
-    const uint32_t col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t row = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (row >= p.m) return;
+    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t row0 = blockIdx.y * MR;
     const bool live = col < p.n;
     const uint32_t b_col = live ? col : p.n - 1; // clamped: computed, never stored
     const uint32_t k = p.k, group_size = p.group_size;
     const size_t num_groups_k = (k + group_size - 1) / group_size;
     const size_t zero_point_stride = BITS == 4 ? (num_groups_k + 1) / 2 : num_groups_k;
     const uint4* codes = (const uint4*)((const uint8_t*)p.b + (size_t)b_col * k * BITS / 8);
-    const TA* a = (const TA*)p.a + (size_t)row * k;
+    const TA* a[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) a[r] = (const TA*)p.a + (size_t)(row0 + r < p.m ? row0 + r : p.m - 1) * k; // clamped rows: computed, never stored
     const TW* scales = (const TW*)p.scales + (size_t)b_col * num_groups_k;
     const TW* biases = p.biases ? (const TW*)p.biases + (size_t)b_col * num_groups_k : nullptr;
     const uint32_t flip = p.signed_codes ? 1u << (BITS - 1) : 0u;
-    float accumulator = 0.0f;
+    float accumulator[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) accumulator[r] = 0.0f;
     for (uint32_t k0 = 0; k0 < k; k0 += EPV) {
         const uint4 cv = codes[k0 / EPV];
         const uint32_t words[4] = {cv.x, cv.y, cv.z, cv.w};
@@ -138,14 +143,20 @@ __global__ void __launch_bounds__(256) matmul_ref_vec_kernel(MatmulParams p) {
         }
 #pragma unroll
         for (uint32_t j = 0; j < EPV; ++j) {
-            const float a_value = ld<TA>(a, k0 + j);
             const uint32_t weight_code = ((words[j * BITS / 32] >> ((j * BITS) % 32)) & ((1u << BITS) - 1u)) ^ flip;
             const float quantized_value = (float)weight_code;
             const float b_value = scale * quantized_value + bias_term;
-            accumulator += a_value * b_value;
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const float a_value = ld<TA>(a[r], k0 + j);
+                accumulator[r] += a_value * b_value;
+            }
         }
     }
-    if (live) epilogue_store(p, row, col, accumulator);
+    if (live)
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+            if (row0 + r < p.m) epilogue_store(p, row0 + r, col, accumulator[r]);
 }
 static bool matmul_ref_vec_supported(const MatmulParams& p) {
     if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || p.gather || (p.bits != 4 && p.bits != 8)) return false;
@@ -154,14 +165,17 @@ static bool matmul_ref_vec_supported(const MatmulParams& p) {
     if (!(p.a_dt == UZU_BF16 || p.a_dt == UZU_F32) || !(p.w_dt == UZU_BF16 || p.w_dt == UZU_F32)) return false;
     return getenv("UZU_EXACT_SCALAR") == nullptr; // UZU_EXACT_SCALAR=1: the element-by-element kernel (A/B of the two: tests)
 }
-template <int BITS> static uzu_status launch_ref_vec(hipStream_t s, const MatmulParams& p) {
-    const dim3 grid((p.n + 63) / 64, (p.m + 3) / 4);
+template <int BITS, int MR> static uzu_status launch_ref_vec_r(hipStream_t s, const MatmulParams& p) {
+    const dim3 grid((p.n + 255) / 256, (p.m + MR - 1) / MR);
     return launch_check([&] {
-        if (p.a_dt == UZU_BF16 && p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
-        else if (p.a_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, float>), grid, dim3(256), 0, s, p);
-        else if (p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, bf16_t>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, float>), grid, dim3(256), 0, s, p);
+        if (p.a_dt == UZU_BF16 && p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, bf16_t, MR>), grid, dim3(256), 0, s, p);
+        else if (p.a_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, bf16_t, float, MR>), grid, dim3(256), 0, s, p);
+        else if (p.w_dt == UZU_BF16) hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, bf16_t, MR>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((matmul_ref_vec_kernel<BITS, float, float, MR>), grid, dim3(256), 0, s, p);
     }, "matmul_ref_vec");
+}
+template <int BITS> static uzu_status launch_ref_vec(hipStream_t s, const MatmulParams& p) {
+    return p.m >= 4 ? launch_ref_vec_r<BITS, 4>(s, p) : launch_ref_vec_r<BITS, 1>(s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
