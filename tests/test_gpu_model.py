@@ -1079,3 +1079,51 @@ def test_config5_scale_14b_class_decode_and_prefill_chunk_at_context_8192(hip_ct
     hm.bind(None)
     base.close(), work.close()
     hm.close()
+
+
+@pytest.mark.parametrize("preset,kw,context,splits", [("tiny-qwen", {"model_dim": 1024}, 200, 0), ("tiny-llama", {"model_dim": 1024}, 1500, 0),
+                                                      ("tiny-llama", {"model_dim": 1024, "num_heads": 10, "num_groups": 2}, 300, 64)])
+def test_one_launch_sdpa_decode_is_bit_identical_to_the_two_launch_form(hip_ctx, preset, kw, context, splits, monkeypatch):
+    """north_star's "fused SDPA decode kernel": attn_dec runs pass 2 (AttentionTwoPass2 + SigmoidGate) inside its own launch -- every
+    workgroup publishes its split's partials with write-through stores, draws a ticket of its KV-head group, waits for the group and merges
+    its slice of the group's rows, in attn_merge_kernel's arithmetic order.  Tokens and logits must be BIT-IDENTICAL to the two-launch form,
+    one launch per attention layer fewer, graph replays and eager steps alike, over many consecutive steps (the ticket counters are
+    monotonic: nothing is reset between launches), with a GQA factor of 5 (slices straddle heads) and contexts on both sides of 1024."""
+    if splits:  # gqa 5, head_dim 64: 320 outputs per KV-head group do not split over the default 128 workgroups; over 64 they do (5 each)
+        monkeypatch.setenv("UZU_DEC_SPLITS", str(splits))
+    cfg = S.PRESETS[preset](max_context_length=context + 80, **kw)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(context, cfg.vocab_size)
+    n_att = sum(1 for l in bundle.layers if l.qkv_projection is not None)
+    fn = _ffi.lib().uzu_hip_debug_set_attn_fused
+    fn.restype, fn.argtypes = None, [C.c_int32]
+    fn(1)
+    probe = HipModel(hip_ctx, bundle)
+    probe.prefill(prompt[:8])
+    probe.decode(1)
+    fused_built = probe.decode_launch_count
+    fn(0)
+    probe.reset()
+    probe.prefill(prompt[:8])
+    probe.decode(1)
+    fused_built = fused_built != probe.decode_launch_count
+    probe.close()
+    fn(-1)
+    if not fused_built:
+        pytest.skip("the library was built without the in-launch pass 2 (make FUSED_ATTN=1): measured slower than two launches, profiles/r5_sdpa_fused_ab.txt")
+    runs = {}
+    try:
+        for mode in (0, 1):
+            fn(mode)
+            for flags in (0, MODEL_NO_GRAPH):
+                hm = HipModel(hip_ctx, bundle, flags)
+                first = hm.prefill(prompt)
+                toks, _ = hm.decode(40)
+                runs[(mode, flags)] = ([first] + [int(t) for t in toks], hm.read_logits(), hm.decode_launch_count)
+                hm.close()
+    finally:
+        fn(-1)
+    for flags in (0, MODEL_NO_GRAPH):
+        a, b = runs[(0, flags)], runs[(1, flags)]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), f"fused SDPA decode differs from attn_dec + attn_merge (flags {flags})"
+        assert a[2] - b[2] == n_att, f"launches per step: {a[2]} -> {b[2]} with {n_att} attention layers"

@@ -157,6 +157,7 @@ struct uzu_hip_model {
     uint16_t* lora_scratch = nullptr; // [rows][widest adapter rank]: x down^T of a QLoRA linear
     uint32_t lora_max_rank = 0;
     float *dec_partials = nullptr, *dec_sums = nullptr, *dec_maxs = nullptr;
+    uint32_t* dec_tickets = nullptr; // one monotonic arrival counter per (kv head, head sub-group): attn_dec's in-launch pass 2
     float* dn_ws = nullptr; // chunked DeltaNet prefill: T / P matrices of one 1024-token pass (k_deltanet_chunk.hip)
     float *dn_o = nullptr, *dn_sz = nullptr; // raw DeltaNet outputs and SiLU(z) of the decode token (f32 [value_dim])
     uint32_t dec_splits = 0;
@@ -1189,8 +1190,14 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
             a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
             a.partials = m->dec_partials, a.sums = m->dec_sums, a.maxs = m->dec_maxs, a.cache_rows = m->max_positions;
             const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
-            RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
-            RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
+            if (k::attn_dec_fused_supported(nq, nq / nkv, hd, m->dec_splits, m->ctx->num_cus)) {
+                // "a fused SDPA decode kernel": pass 2 + SigmoidGate inside the launch (every workgroup merges its slice of its KV-head group's rows)
+                a.tickets = m->dec_tickets, a.gate = L.d.has_gate ? m->gate : nullptr, a.out = m->attn_out;
+                RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
+            } else {
+                RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
+                RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
+            }
             dec_gemv_row_parallel(e, dec_gemv_base(L.out, in_transform(L.out, m->attn_out), m->mixed), "gemv_dec[out_proj]");
             if (L.out.out_signs) pending = &L.out, pending_row = m->mixed;
         } else {
@@ -1508,6 +1515,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         ALLOC(dec_partials, float, (size_t)max_heads * m->dec_splits * max_hd);
         ALLOC(dec_sums, float, (size_t)max_heads * m->dec_splits);
         ALLOC(dec_maxs, float, (size_t)max_heads * m->dec_splits);
+        ALLOC(dec_tickets, uint32_t, (size_t)max_heads); // (zeroed by dev_alloc; groups <= heads)
     }
     ALLOC(last_normed, uint16_t, d);
     ALLOC(logits, uint16_t, desc->vocab_size);
@@ -1682,6 +1690,7 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
         HIPCHK(hipStreamSynchronize(s)); // the staging buffer is reused; also surfaces kernel faults per chunk
         if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
         UZU_PROPAGATE(k::gemv_stream_check());
+    UZU_PROPAGATE(k::attn_dec_check());
         for (uint32_t i = 0; i < nseq; ++i) {
             bind_state(m, states[i]);
             m->context_length += n;
@@ -1740,6 +1749,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
         HIPCHK(hipStreamSynchronize(s)); // token_ids is caller memory; also surfaces kernel faults per chunk
         if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
         UZU_PROPAGATE(k::gemv_stream_check());
+    UZU_PROPAGATE(k::attn_dec_check());
         m->context_length += n;
     }
     if (first_token) HIPCHK(hipMemcpy(first_token, m->d_out_token, 4, hipMemcpyDeviceToHost));
@@ -1761,6 +1771,7 @@ uzu_status uzu_hip_model_read_tokens(uzu_hip_model* m, uint32_t first_position, 
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     UZU_PROPAGATE(k::gemv_stream_check());
+    UZU_PROPAGATE(k::attn_dec_check());
     HIPCHK(hipMemcpy(out_tokens, m->d_sampled + first_position, (size_t)count * 4, hipMemcpyDeviceToHost));
     return UZU_OK;
 }
@@ -1781,6 +1792,7 @@ uzu_status uzu_hip_model_decode(uzu_hip_model* m, uint32_t steps, uint32_t* out_
     HIPCHK(hipEventSynchronize(m->ev1));
     if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     UZU_PROPAGATE(k::gemv_stream_check());
+    UZU_PROPAGATE(k::attn_dec_check());
     if (gpu_ms) HIPCHK(hipEventElapsedTime(gpu_ms, m->ev0, m->ev1));
     if (out_tokens) UZU_PROPAGATE(uzu_hip_model_read_tokens(m, first, steps, out_tokens));
     return UZU_OK;
@@ -2005,6 +2017,7 @@ uzu_status uzu_hip_model_verify_tree_seeded(uzu_hip_model* m, const uint32_t* to
     (void)hipEventElapsedTime(&m->tree.last_gpu_ms, m->ev0, m->ev1);
     if (m->tp) UZU_PROPAGATE(tp::p2p_check(m->tp));
     UZU_PROPAGATE(k::gemv_stream_check());
+    UZU_PROPAGATE(k::attn_dec_check());
     if (sampled_out) memcpy(sampled_out, m->tree.sampled.data(), (size_t)tree_size * 4);
     m->tree.size = tree_size, m->tree.state = m->bound, m->tree.parents = parents;
     return UZU_OK;

@@ -1169,7 +1169,9 @@ uzu_status delta_dec(hipStream_t s, const DeltaDecParams& p_in) {
 // grid (kv_head * subs + sub, split); 256 threads.  Keys of split s: i = s, s + S, s + 2S, ...
 // Latency design: the context length is the only thing the kernel has to wait for before it can issue every
 // other load (qkv row, norm scales, RoPE row, and the first batch of K/V rows of each key group).
-template <int HD, int GS>
+__device__ uint32_t g_attn_err_dev; // set when a fused attn_dec's bounded wait for its group gave up (host: attn_dec_check)
+
+template <int HD, int GS, bool FUSED>
 __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
     constexpr int LPK = HD / 8, KG = 64 / LPK, NGRP = 4 * KG;
     constexpr int TB = 4; // keys per group per batch (all K/V loads of a batch are in flight together)
@@ -1388,10 +1390,129 @@ __global__ void __launch_bounds__(256) attn_dec_kernel(AttnDecParams p) {
             acc += s_o[w][g][e] * f;
         }
         const size_t row = (size_t)(head0 + g) * S + split;
-        p.partials[row * HD + e] = acc;
-        if (e == 0) p.sums[row] = l, p.maxs[row] = m;
+        if constexpr (FUSED) {
+            // write-through (sc1) stores: the merging workgroups read them with sc1 loads, no cache maintenance on either side
+            // (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> flag; sc1 loads may replace the acquire when the producer stored sc1);
+            // two elements per store: even lanes take their odd neighbour's value (8-byte sc1 stores cost half the fabric writes of 4-byte ones)
+            const float hi = __shfl_down(acc, 1, 64);
+            if ((e & 1) == 0) {
+                const unsigned long long v = (unsigned long long)f32_to_bits(acc) | ((unsigned long long)f32_to_bits(hi) << 32);
+                __hip_atomic_store((unsigned long long*)(p.partials + row * HD + e), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (e == 0) {
+                __hip_atomic_store(p.sums + row, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.maxs + row, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            p.partials[row * HD + e] = acc;
+            if (e == 0) p.sums[row] = l, p.maxs[row] = m;
+        }
     }
     UZU_TL_STAMP(6);
+    if constexpr (FUSED) {
+        // ---- pass 2 inside the launch: AttentionTwoPass2 (attention_two_pass.rs:143-190) over the S splits + SigmoidGate, in
+        // attn_merge_kernel's arithmetic order (same weights, same 16 x 16 fma chains, same sums): bit-identical rows.
+        // Publish: every store of the workgroup acknowledged, then ONE ticket per workgroup.  The ticket counter is monotonic: launches on
+        // one stream are serialised and every launch adds exactly S per group, so ticket / S numbers the launch and (ticket / S + 1) S is the
+        // value the counter reaches when the group of THIS launch is complete -- nothing to reset between launches or graph replays.
+        __shared__ float s_gsum[GS];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (the key groups' merge state is dead from here on: its LDS holds the merge weights [GS][256] and the 16 x 16 slice sums)
+        float (*s_w)[256] = (float (*)[256]) & s_o[0][0][0];
+        float (*s_acc2)[16] = (float (*)[16])(&s_o[0][0][0] + GS * 256);
+        static_assert((size_t)NGRP * GS * HD >= (size_t)GS * 256 + 256, "merge scratch does not fit the key-group state");
+        uint32_t* ticket = p.tickets + blockIdx.x;
+        if (tid == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = (t / S + 1u) * S;
+            uint32_t spins = 0;
+            while ((int32_t)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) { // ~0.3 s: a workgroup of the group never arrived (it cannot be resident?) -- give up loudly, never hang
+                    atomicOr(&g_attn_err_dev, 1u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        UZU_TL_STAMP(3); // the group is complete
+        // ONE memory round trip: the partials of this workgroup's slice (first 16 outputs: thread = (element e of 16, split-slice of 16)) are
+        // requested before the merge weights are derived from the maxima / sums
+        constexpr uint32_t kOut = GS * HD;
+        const uint32_t el = kOut / S, first = split * el; // el * S == kOut (host-checked)
+        const uint32_t e16 = tid & 15, slice = tid >> 4;
+        auto load_slice = [&](uint32_t base, float (&pv)[16], uint32_t& g, uint32_t& j, bool& live, float& gt) {
+            const uint32_t oi = first + base + e16;
+            live = base + e16 < el;
+            g = live ? oi / HD : 0, j = live ? oi % HD : 0;
+            const float* pp = p.partials + (size_t)(head0 + g) * S * HD + j;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t b = slice + 16 * t;
+                pv[t] = (live && b < S) ? __hip_atomic_load(pp + (size_t)b * HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            }
+            gt = (p.gate && live && slice == 0) ? bf16_to_f32(p.gate[(size_t)(head0 + g) * HD + j]) : 0.f;
+        };
+        float pv0[16], gt0;
+        uint32_t g0, j0;
+        bool live0;
+        load_slice(0, pv0, g0, j0, live0, gt0);
+        // merge weights of the heads this workgroup's slice touches (el <= HD: at most two): wave w takes head g_lo + w; lane L owns
+        // splits L + 64 t (attn_merge_kernel, wave 0)
+        const uint32_t g_lo = first / HD, g_hi = (first + el - 1) / HD;
+        for (uint32_t g = g_lo + wave; g <= g_hi; g += 4) {
+            const size_t hrow = (size_t)(head0 + g) * S;
+            float mv[4], sv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t b = lane + 64 * t;
+                mv[t] = b < S ? __hip_atomic_load(p.maxs + hrow + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+                sv[t] = b < S ? __hip_atomic_load(p.sums + hrow + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            }
+            const float gmax = wave_max(fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3])));
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t b = lane + 64 * t;
+                if (b < S) {
+                    const float w = fast_exp(mv[t] - gmax);
+                    s_w[g][b] = w;
+                    part += sv[t] * w;
+                }
+            }
+            part = wave_sum(part);
+            if (lane == 0) s_gsum[g] = part;
+        }
+        __syncthreads();
+        auto finish = [&](const float (&pv)[16], uint32_t g, uint32_t j, bool live, float gt) {
+            float val = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t b = slice + 16 * t;
+                if (b < S) val = fmaf(pv[t], s_w[g][b], val);
+            }
+            s_acc2[slice][e16] = val;
+            __syncthreads();
+            if (slice == 0 && live) {
+                float total = 0.f;
+#pragma unroll
+                for (int q2 = 0; q2 < 16; ++q2) total += s_acc2[q2][e16];
+                float r = round_bf16(total / s_gsum[g]);
+                if (p.gate) r = round_bf16(r * (1.0f / (1.0f + expf_glibc(-gt)))); // SigmoidGate (sigmoid_gate.rs:9-22)
+                p.out[(size_t)(head0 + g) * HD + j] = f32_to_bf16(r);
+            }
+            __syncthreads();
+        };
+        finish(pv0, g0, j0, live0, gt0);
+        for (uint32_t base = 16; base < el; base += 16) { // slices of more than 16 outputs (few splits): further round trips
+            float pv[16], gt;
+            uint32_t g, j;
+            bool live;
+            load_slice(base, pv, g, j, live, gt);
+            finish(pv, g, j, live, gt);
+        }
+    }
     UZU_TL_STAMP(4);
     UZU_TL_FLUSH(p);
 }
@@ -1400,7 +1521,17 @@ template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDec
     const uint32_t kv_heads = p.num_heads / p.gqa_factor;
     const uint32_t gs = attn_dec_group_size(p.gqa_factor);
     const dim3 grid(kv_heads * (p.gqa_factor / gs), splits);
-#define UZU_LAUNCH(G) return launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G>), grid, dim3(256), 0, s, p); }, "attn_dec")
+// The in-launch pass 2 (FUSED) is compiled only with -DUZU_ATTN_FUSED_BUILD (make FUSED_ATTN=1): measured SLOWER than attn_dec + attn_merge on
+// this chip (profiles/r5_sdpa_fused_ab.txt: 15.2 us against 6.9 + 4.4 us per layer on Qwen3.5-0.8B, 15.3 against 7.3 + 4.3 on Llama-3-8B,
+// bit-identical rows): store acknowledgement -> ticket -> poll -> sc1 reads are four dependent fabric round trips where a kernel boundary
+// costs 1.5 us.  The default library carries no instance of it.
+#ifdef UZU_ATTN_FUSED_BUILD
+#define UZU_LAUNCH(G)                                                                                                                           \
+    return p.out ? launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G, true>), grid, dim3(256), 0, s, p); }, "attn_dec")              \
+                 : launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G, false>), grid, dim3(256), 0, s, p); }, "attn_dec")
+#else
+#define UZU_LAUNCH(G) return launch_check([&] { hipLaunchKernelGGL((attn_dec_kernel<HD, G, false>), grid, dim3(256), 0, s, p); }, "attn_dec")
+#endif
     switch (gs) {
     case 6: UZU_LAUNCH(6);
     case 5: UZU_LAUNCH(5);
@@ -1411,8 +1542,49 @@ template <int HD> static uzu_status launch_attn_dec(hipStream_t s, const AttnDec
     }
 #undef UZU_LAUNCH
 }
+int g_attn_fused_override = -1; // uzu_hip_debug_set_attn_fused: -1 = environment / default, 0 = two launches, 1 = fused
+bool attn_dec_fused_supported(uint32_t num_heads, uint32_t gqa_factor, uint32_t head_dim, uint32_t splits, int num_cus) {
+#ifndef UZU_ATTN_FUSED_BUILD
+    return false; // not compiled in (see UZU_LAUNCH above)
+#endif
+    static const bool env_on = [] { // UZU_ATTN_FUSED=1 selects it (a FUSED_ATTN=1 build; A/B runs; same arithmetic): off by default -- measured slower
+        const char* e = getenv("UZU_ATTN_FUSED");
+        return e && e[0] == '1';
+    }();
+    const bool off = g_attn_fused_override >= 0 ? g_attn_fused_override == 0 : !env_on;
+    if (off || !gqa_factor || num_heads % gqa_factor || !splits || splits > 256) return false;
+    const uint32_t gs = attn_dec_group_size(gqa_factor), groups = (num_heads / gqa_factor) * (gqa_factor / gs);
+    if ((gs * head_dim) % splits) return false;              // every workgroup merges gs * hd / splits outputs of its group
+    return (uint64_t)groups * splits <= (uint64_t)num_cus * 2; // the group's workgroups wait for each other: all must be resident (<= 4 fit a CU)
+}
+static uint32_t g_attn_fused_launched = 0; // devices (bit d) that have run a fused attn_dec
+uzu_status attn_dec_check() {
+    if (!g_attn_fused_launched) return UZU_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(g_attn_fused_launched >> (dev & 31) & 1u)) return UZU_OK;
+    uint32_t v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_err_dev), 4) != hipSuccess) {
+        (void)hipGetLastError();
+        return UZU_OK;
+    }
+    if (!v) return UZU_OK;
+    const uint32_t zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_err_dev), &zero, 4);
+    set_error("attn_dec: a workgroup gave up waiting for its KV-head group (fused pass 2): the attention rows since the last check are garbage");
+    return UZU_ERR_HIP;
+}
 uzu_status attn_dec(hipStream_t s, const AttnDecParams& p_in, uint32_t splits) {
     AttnDecParams p = p_in;
+    if (p.out) {
+        if (!p.tickets) {
+            set_error("attn_dec: the fused pass 2 needs the ticket words");
+            return UZU_ERR_INVALID_ARGUMENT;
+        }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        g_attn_fused_launched |= 1u << (dev & 31);
+    }
 #ifdef UZU_TIMELINE
     p.tl = timeline_next_slot();
 #endif
@@ -1507,3 +1679,6 @@ uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, c
 
 } // namespace k
 } // namespace uzu
+
+// tests / A-B runs: -1 = environment / default, 0 = attn_dec + attn_merge, 1 = fused (decided when a step is encoded or captured)
+extern "C" void uzu_hip_debug_set_attn_fused(int mode) { uzu::k::g_attn_fused_override = mode; }

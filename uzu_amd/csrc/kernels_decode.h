@@ -166,8 +166,20 @@ struct AttnDecParams {
     float* sums;           // [heads, splits]
     float* maxs;
     uint32_t cache_rows;   // rows the K / V caches are allocated for (> context length): the first loads are clamped to it, not to the context
+    // One-launch SDPA decode (round 5): pass 2 (attn_merge_kernel's arithmetic, bit for bit) + SigmoidGate inside the same launch.  Every
+    // workgroup publishes its split's partials with write-through stores, draws a ticket of its KV-head group, waits until the group's
+    // `splits` workgroups have all drawn theirs, and then merges ITS slice -- gqa-group x head_dim / splits output elements -- of the
+    // group's attention rows.  tickets: one monotonic u32 per (kv head, head sub-group), zeroed once at allocation; out != null selects it.
+    uint32_t* tickets;
+    const uint16_t* gate;  // [heads, hd] or null (SigmoidGate)
+    uint16_t* out;         // bf16 [heads, hd]: the attention rows
 };
 uzu_status attn_dec(hipStream_t s, const AttnDecParams& p, uint32_t splits);
+// can attn_dec run pass 2 inside the launch for this geometry?  (every workgroup of a KV-head group must be resident at once: grid <= 2 x CUs;
+// the group's gqa x head_dim outputs must split evenly over the workgroups)
+bool attn_dec_fused_supported(uint32_t num_heads, uint32_t gqa_factor, uint32_t head_dim, uint32_t splits, int num_cus);
+// host sync points: UZU_ERR_HIP if a bounded wait of a fused attn_dec gave up since the last check (its rows are then garbage)
+uzu_status attn_dec_check();
 // query heads of one KV head a workgroup of attn_dec serves together (the K / V rows are read once for all of them):
 // the largest divisor of the GQA factor <= 6 (LDS: 8 KB of merge state per head)
 inline uint32_t attn_dec_group_size(uint32_t gqa_factor) {
