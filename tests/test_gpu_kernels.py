@@ -1465,34 +1465,6 @@ def test_quantized_embedding_lookup_with_output_hadamard(hip_ctx, bits, method):
     assert np.array_equal(bo.download(np.uint16, want.size).reshape(want.shape), want)
 
 
-MFMA_STREAM_SHAPES = [(6144, 4096), (4096, 14336), (1000, 1024), (515, 5120), (300, 17408), (97, 8192), (8224, 1024), (33, 4096), (5, 2048), (3000, 3072)]
-
-
-@pytest.mark.parametrize("n,k", MFMA_STREAM_SHAPES)
-def test_stream_gemv_with_matrix_core_consumers(hip_ctx, n, k):
-    """The MFMA-tiled GEMV (csrc/k_stream.hip::gemv_stream_mfma_kernel): LDS-staged 16-row x 2048-k (32-row x 1024-k) weight slices, the pair
-    conversion (16 + q) feeding v_mfma_f32_16x16x32_bf16 with the activation row as the other operand, group scale / offset applied per
-    128-k group in f32.  Another summation order than the register GEMV (tolerance class): every output within 1 bf16 ulp of the CPU
-    restatement of the reference and >= 99 % bit-identical -- the bar of every production matmul here -- deterministic, ragged row counts,
-    units split over 1 / 2 / 4 consumers, one or two 16-row groups per unit."""
-    rng = np.random.default_rng(n * 5 + k)
-    q = quant_matrix(rng, n, k, 4, 128, 0)
-    a = activations(rng, 1, k)
-    bias = bf16(rng.uniform(-0.5, 0.5, size=(n,)))
-    try:
-        _set_stream(3)
-        got = hip_matmul(hip_ctx, a, q, 1, bias=bias)
-        again = hip_matmul(hip_ctx, a, q, 1, bias=bias)
-    finally:
-        _set_stream(-1)
-    assert _stream_error() == 0, "a bounded wait of the streaming kernel gave up"
-    assert np.array_equal(got, again), "the streaming kernel is not deterministic"
-    want = oracle_matmul(a, q, 1, bias=bias)
-    ulps = ulp_diff_bf16(want, got)
-    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps ({(ulps > 1).sum()} of {n} outputs)"
-    assert (want == got).mean() >= 0.99
-
-
 def test_matmul_activation_format_policy(hip_ctx):
     """MatmulKernel::{a8_activation_plan, select_activation_format} (kernel.rs:28-42) through the C ABI: the plan exists for every
     quantised B the A8 matmul takes (activation group = ACTIVATION_SCALE_GROUP_SIZE = 128; a sum group for the prologues with an offset

@@ -668,24 +668,6 @@ def test_streaming_decode_engine_is_bit_identical(hip_ctx, preset, kw):
         assert np.array_equal(a, b)
 
 
-def test_streaming_decode_with_matrix_core_consumers_matches_the_oracle(hip_ctx):
-    """Llama-3-8B shapes (2 layers), every decode GEMV on the MFMA-tiled LDS stream (uzu_hip_debug_set_decode_stream(3): Normalization
-    prologue + qkv, out-projection, fused up / gate with GatedActMul, down-projection at K = 14336, read-out with arg-max): tokens equal
-    the oracle's and the register-GEMV engine's, logits within the model-level tolerance (another summation order: tolerance class)."""
-    fn = _ffi.lib().uzu_hip_debug_set_decode_stream
-    fn.restype, fn.argtypes = None, [C.c_int]
-    err = _ffi.lib().uzu_hip_debug_decode_stream_error
-    err.restype, err.argtypes = C.c_uint32, []
-    cfg = S.llama3_8b(max_context_length=256, layer_kinds=[D.MIXER_ATTENTION] * 2, seed=7)
-    try:
-        fn(3)
-        o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 48, 6)
-    finally:
-        fn(-1)
-    assert int(err()) == 0, "a bounded wait of the streaming kernel gave up"
-    assert h_tokens == o_tokens, f"oracle {o_tokens}\nhip    {h_tokens}"
-
-
 # ------------------------------------------------------------------------------------------ reference-order mode: bit-exact logits
 def _set_exact(on):
     fn = _ffi.lib().uzu_hip_set_exact
@@ -1097,18 +1079,9 @@ def test_one_launch_sdpa_decode_is_bit_identical_to_the_two_launch_form(hip_ctx,
     n_att = sum(1 for l in bundle.layers if l.qkv_projection is not None)
     fn = _ffi.lib().uzu_hip_debug_set_attn_fused
     fn.restype, fn.argtypes = None, [C.c_int32]
-    fn(1)
-    probe = HipModel(hip_ctx, bundle)
-    probe.prefill(prompt[:8])
-    probe.decode(1)
-    fused_built = probe.decode_launch_count
-    fn(0)
-    probe.reset()
-    probe.prefill(prompt[:8])
-    probe.decode(1)
-    fused_built = fused_built != probe.decode_launch_count
-    probe.close()
-    fn(-1)
+    built = _ffi.lib().uzu_hip_debug_attn_fused_built
+    built.restype, built.argtypes = C.c_int, []
+    fused_built = bool(built())
     if not fused_built:
         pytest.skip("the library was built without the in-launch pass 2 (make FUSED_ATTN=1): measured slower than two launches, profiles/r5_sdpa_fused_ab.txt")
     runs = {}

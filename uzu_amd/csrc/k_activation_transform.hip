@@ -368,217 +368,8 @@ __global__ void __launch_bounds__(256, 2) gemm_a8_mfma_kernel(MatmulParams p, co
         }
 }
 
-// ---- LDS-DMA form of the same tile: a three-stage ring filled by global_load_lds (no registers between memory and LDS, the operands of
-// stages st + 1 and st + 2 in flight while stage st is multiplied).  The register-staged kernel above is one memory round trip deep per stage
-// (~3.5 us per stage at 4096 x 14336 x 4096).  Everything the loop needs comes through the ring -- int8 activation rows, RAW weight code rows
-// (unpacked when an operand is read), the stage's activation scales, and the dwords holding the columns' bf16 scales and offsets / zero points --
-// so that no compiler-counted vector load sits between the DMA operations (its vmcnt waits would drain them).  16-byte chunks of a row are
-// XOR-swizzled so that the MFMA operand reads are conflict-free (A) / two-way (int4 B) without row padding, which the DMA cannot produce.
-__device__ __forceinline__ void a8_dma16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void a8_dma4(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int BITS, int GK>
-__global__ void __launch_bounds__(256, BITS == 4 ? 2 : 1) gemm_a8_dma_kernel(MatmulParams p, const int8_t* a_q, const float* a_scales, uint32_t a_group) {
-    constexpr int NS = 3;
-    constexpr int KS = GK / 32;
-    constexpr int ROWA = GK, ROWB = GK * BITS / 8;          // bytes per row and stage
-    constexpr int CHA = ROWA / 16, CHB = ROWB / 16;         // 16-byte chunks per row
-    constexpr int A_BYTES = 128 * ROWA, B_BYTES = 128 * ROWB;
-    constexpr int OFF_B = A_BYTES, OFF_SA = OFF_B + B_BYTES, OFF_SC = OFF_SA + 512, OFF_BI = OFF_SC + 512, SLOT = OFF_BI + 512;
-    constexpr int IA = A_BYTES / 4096, IB = B_BYTES / 4096; // 1 KiB DMA instructions per wave and stage
-    constexpr int OPS = IA + IB + 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t a8_smem[]; // NS slots + NS x 128 row sums (i32)
-    int32_t* s_S = (int32_t*)(a8_smem + NS * SLOT);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
-    uint32_t m_t, n_t;
-    if (!gemm_tile_of_block(blockIdx.x, (p.m + 127u) / 128u, (p.n + 127u) / 128u, &m_t, &n_t)) return;
-    const uint32_t n0 = n_t * 128u, m0 = m_t * 128u, K = p.k, stages = K / GK;
-    const uint32_t a_groups = K / a_group, w_groups = K / p.group_size;
-    const uint32_t zp_stride = BITS == 4 ? (w_groups + 1) / 2 : w_groups;
-    const float centre = BITS == 4 ? 0.0f : 128.0f;
-    const uint32_t flip = p.signed_codes ? (BITS == 4 ? 0x88888888u : 0x80808080u) : 0u;
-    const uint32_t smem_base = (uint32_t)(uintptr_t)a8_smem;
-    auto swz = [](uint32_t row, int rowb, int ch) -> uint32_t { return (row / (uint32_t)(128 / rowb)) % (uint32_t)ch; };
-    // ---- DMA sources of this lane (rows clamped into the matrix: computed, never stored)
-    const int8_t* a_src[IA];
-    const uint8_t* b_src[IB];
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const uint32_t gi = wave * IA + i, row = gi * (1024 / ROWA) + lane / CHA, chunk = (lane % CHA) ^ swz(row, ROWA, CHA);
-        a_src[i] = a_q + (size_t)min(m0 + row, p.m - 1) * K + chunk * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        const uint32_t gi = wave * IB + i, row = gi * (1024 / ROWB) + lane / CHB, chunk = (lane % CHB) ^ swz(row, ROWB, CHB);
-        b_src[i] = (const uint8_t*)p.b + (size_t)min(n0 + row, p.n - 1) * K * BITS / 8 + chunk * 16;
-    }
-    // misc: operation 0 = activation scales of rows [64 w, +64) (waves 0, 1) or the scale dwords of columns [64 (w - 2), +64) (waves 2, 3);
-    // operation 1 = the offset-table dwords of columns [64 w, +64) (waves 0, 1); waves 2, 3 repeat the activation scales (same values)
-    const uint32_t my_row = min(m0 + (wave & 1) * 64 + lane, p.m - 1), my_col = min(n0 + (wave & 1) * 64 + lane, p.n - 1);
-    const float* sa_src = a_scales + (size_t)my_row * a_groups;
-    const uint8_t* off_tab = p.b_kind == UZU_MATMUL_B_SCALE_BIAS ? (const uint8_t*)p.biases : p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT ? p.zero_points : (const uint8_t*)p.scales;
-    auto issue = [&](uint32_t st) {
-        const uint32_t slot = smem_base + (st % NS) * SLOT, k0 = st * GK;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) a8_dma16(a_src[i] + k0, slot + (wave * IA + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < IB; ++i) a8_dma16(b_src[i] + (size_t)k0 * BITS / 8, slot + OFF_B + (wave * IB + i) * 1024);
-        const uint32_t gw = k0 / p.group_size;
-        const size_t sc_byte = ((size_t)my_col * w_groups + gw) * 2;                      // bf16 tables (host-checked)
-        const size_t of_byte = p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT ? (size_t)my_col * zp_stride + (BITS == 4 ? gw >> 1 : gw) : sc_byte;
-        if (wave < 2) {
-            a8_dma4(sa_src + k0 / a_group, slot + OFF_SA + wave * 256);
-            a8_dma4(off_tab + (of_byte & ~(size_t)3), slot + OFF_BI + wave * 256);
-        } else {
-            a8_dma4((const uint8_t*)p.scales + (sc_byte & ~(size_t)3), slot + OFF_SC + (wave - 2) * 256);
-            a8_dma4(sa_src + k0 / a_group, slot + OFF_SA + (wave - 2) * 256);
-        }
-    };
-    float acc[2][2][16];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-    uint32_t ncol[2];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) ncol[nb] = min(n0 + wn * 64 + nb * 32 + c, p.n - 1);
-    issue(0);
-    if (stages > 1) issue(1);
-    for (uint32_t st = 0; st < stages; ++st) {
-        if (st + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier(); // every wave's share of stage st has landed; every wave is done with stage st - 1 (whose slot the next issue refills)
-        if (st + 2 < stages) issue(st + 2);
-        const uint8_t* slot = a8_smem + (st % NS) * SLOT;
-        int32_t* sS = s_S + (st % NS) * 128;
-        // ---- integer products of the stage; the A fragments also give the stage's row sums (row c of each block, k half h)
-        a8_i32x16 d[2][2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) d[mb][nb][r] = 0;
-        int32_t spart[2] = {0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            a8_i32x4 af[2], bf[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const uint32_t row = wm * 64 + mb * 32 + c;
-                af[mb] = *(const a8_i32x4*)(slot + row * ROWA + (((uint32_t)(ks * 2 + h)) ^ swz(row, ROWA, CHA)) * 16);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) spart[mb] = dot4((uint32_t)af[mb][w], 0x01010101u, spart[mb]);
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const uint32_t row = wn * 64 + nb * 32 + c;
-                if constexpr (BITS == 4) {
-                    const uint2 raw = *(const uint2*)(slot + OFF_B + row * ROWB + (((uint32_t)ks) ^ swz(row, ROWB, CHB)) * 16 + h * 8); // 16 codes
-                    const uint32_t w2[2] = {raw.x ^ flip, raw.y ^ flip};
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const uint32_t lo = w2[q] & 0x0F0F0F0Fu, hi = (w2[q] >> 4) & 0x0F0F0F0Fu;
-                        bf[nb][2 * q] = (int)__builtin_amdgcn_perm(hi, lo, 0x05010400u);
-                        bf[nb][2 * q + 1] = (int)__builtin_amdgcn_perm(hi, lo, 0x07030602u);
-                    }
-                } else {
-                    const a8_i32x4 raw = *(const a8_i32x4*)(slot + OFF_B + row * ROWB + (((uint32_t)(ks * 2 + h)) ^ swz(row, ROWB, CHB)) * 16);
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) bf[nb][w] = (int)(((uint32_t)raw[w] ^ flip) ^ 0x80808080u);
-                }
-            }
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) d[mb][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mb], bf[nb], d[mb][nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const int32_t tot = spart[mb] + __shfl_xor(spart[mb], 32, 64);
-            if (wn == 0 && h == 0) sS[wm * 64 + mb * 32 + c] = tot;
-        }
-        lds_barrier(); // row sums of the stage are in LDS
-        // ---- fold
-        float sw[2], cf[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const uint32_t lc = wn * 64 + nb * 32 + c, n = ncol[nb], gw = st * GK / p.group_size;
-            const size_t sc_byte = ((size_t)n * w_groups + gw) * 2;
-            const uint32_t sdw = *(const uint32_t*)(slot + OFF_SC + lc * 4);
-            const float s_w_f = bits_to_f32((sc_byte & 2) ? (sdw & 0xFFFF0000u) : (sdw << 16));
-            const uint32_t odw = *(const uint32_t*)(slot + OFF_BI + lc * 4);
-            float beta;
-            if (p.b_kind == UZU_MATMUL_B_SCALE_BIAS) beta = bits_to_f32((sc_byte & 2) ? (odw & 0xFFFF0000u) : (odw << 16));
-            else if (p.b_kind == UZU_MATMUL_B_SCALE_ZERO_POINT) {
-                const size_t zi = (size_t)n * zp_stride + (BITS == 4 ? gw >> 1 : gw);
-                const uint32_t zb = (odw >> (8 * (uint32_t)(zi & 3))) & 0xFFu;
-                const uint32_t zp = BITS == 4 ? ((gw & 1) ? (zb >> 4) : (zb & 0x0F)) : zb;
-                beta = -s_w_f * (float)zp;
-            } else beta = -s_w_f * (BITS == 4 ? 8.0f : 128.0f);
-            sw[nb] = s_w_f, cf[nb] = fmaf(s_w_f, centre, beta);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = wm * 64 + mb * 32 + 8 * r4 + 4 * h;
-                const float4 sa4 = *(const float4*)(slot + OFF_SA + row * 4);
-                const a8_i32x4 S4 = *(const a8_i32x4*)(sS + row);
-                const a8_f32x2 sa2[2] = {{sa4.x, sa4.y}, {sa4.z, sa4.w}};
-                const a8_f32x2 rs2[2] = {{sa4.x * (float)S4[0], sa4.y * (float)S4[1]}, {sa4.z * (float)S4[2], sa4.w * (float)S4[3]}};
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const a8_f32x2 sw2 = {sw[nb], sw[nb]}, cf2 = {cf[nb], cf[nb]};
-#pragma unroll
-                    for (int i2 = 0; i2 < 2; ++i2) {
-                        const int r = 4 * r4 + 2 * i2;
-                        const a8_f32x2 dv = {(float)d[mb][nb][r], (float)d[mb][nb][r + 1]};
-                        a8_f32x2 av = {acc[mb][nb][r], acc[mb][nb][r + 1]};
-                        av = __builtin_elementwise_fma(sw2, dv * sa2[i2], av);
-                        av = __builtin_elementwise_fma(cf2, rs2[i2], av);
-                        acc[mb][nb][r] = av.x, acc[mb][nb][r + 1] = av.y;
-                    }
-                }
-            }
-    }
-    // ---- epilogue (kernel.rs:281-292)
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const uint32_t n = n0 + wn * 64 + nb * 32 + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.m || n >= p.n) continue;
-                const size_t output_index = (size_t)m * p.n + n;
-                float value = p.ab_scale * acc[mb][nb][r];
-                if (p.accumulate) value += ldt(p.d, p.d_dt, output_index);
-                if (p.bias) value += ldt(p.bias, p.w_dt, n);
-                if (p.has_soft_cap) value = p.soft_cap * tanhf(value / p.soft_cap);
-                stt(p.d, p.d_dt, output_index, value);
-            }
-        }
-}
-template <int BITS, int GK> static uzu_status launch_a8_dma(hipStream_t s, const MatmulParams& p, const int8_t* a_q, const float* a_scales, uint32_t a_group_size) {
-    constexpr size_t lds = 3 * (128 * GK + 128 * GK * BITS / 8 + 1536) + 3 * 128 * 4;
-    static LdsLimit lim;
-    if (!raise_lds_limit(lim, (const void*)gemm_a8_dma_kernel<BITS, GK>, lds)) {
-        set_error("matmul_a8: %zu bytes of LDS are not available", lds);
-        return UZU_ERR_UNSUPPORTED;
-    }
-    const dim3 grid(gemm_grid_x((p.m + 127u) / 128u, (p.n + 127u) / 128u));
-    return launch_check([&] { hipLaunchKernelGGL((gemm_a8_dma_kernel<BITS, GK>), grid, dim3(256), lds, s, p, a_q, a_scales, a_group_size); }, "gemm_a8_dma");
-}
-
+// (An LDS-DMA ring form of this tile -- gemm_a8_dma_kernel, round 3 -- ran at the same rate and was removed in round 5: the int8-activation GEMM is
+// never selected by the engine (select_activation_format answers Bf16), one matrix-core form is enough for the C ABI's MatmulA::Int8Symmetric.)
 } // namespace
 
 uzu_status activation_transform(hipStream_t s, const void* input, void* fp_out, int8_t* q_out, float* scales_out, int32_t* group_sums_out,
@@ -630,20 +421,6 @@ uzu_status matmul_a8(hipStream_t s, const MatmulParams& p, const int8_t* a_q, co
     const uint32_t gk = a_group_size < p.group_size ? a_group_size : p.group_size;
     if (mfma_on && p.m >= 128 && (gk == 64 || gk == 128) && p.k % gk == 0 && (p.bits == 8 || p.k % 32 == 0) && (uintptr_t)a_q % 16 == 0 && (uintptr_t)p.b % 16 == 0 &&
         p.k % 16 == 0) {
-        // three-stage LDS-DMA ring (UZU_A8_MFMA=2: the register-staged kernel, A/B runs): bf16 tables, 4-byte-aligned table bases
-        static const bool dma_on = [] {
-            const char* e = getenv("UZU_A8_MFMA");
-            return !e || atoi(e) != 2;
-        }();
-        // the DMA kernel fetches table entries as the aligned dword that holds them: a table whose byte size is not a multiple of 4 (odd
-        // n * groups of bf16 entries, n * zp_stride of u8 zero points) would be read 1-3 bytes past its end on a tightly packed buffer
-        const uint32_t w_groups = (p.k + p.group_size - 1) / p.group_size, zp_stride = p.bits == 4 ? (w_groups + 1) / 2 : w_groups;
-        const bool tables_whole = ((uint64_t)p.n * w_groups * 2) % 4 == 0 && (p.b_kind != UZU_MATMUL_B_SCALE_ZERO_POINT || ((uint64_t)p.n * zp_stride) % 4 == 0);
-        if (dma_on && tables_whole && p.w_dt == UZU_BF16 && (uintptr_t)p.scales % 4 == 0 && (uintptr_t)a_scales % 4 == 0 &&
-            (p.b_kind != UZU_MATMUL_B_SCALE_BIAS || (uintptr_t)p.biases % 4 == 0) && (p.b_kind != UZU_MATMUL_B_SCALE_ZERO_POINT || (uintptr_t)p.zero_points % 4 == 0)) {
-            if (p.bits == 4) return gk == 64 ? launch_a8_dma<4, 64>(s, p, a_q, a_scales, a_group_size) : launch_a8_dma<4, 128>(s, p, a_q, a_scales, a_group_size);
-            return gk == 64 ? launch_a8_dma<8, 64>(s, p, a_q, a_scales, a_group_size) : launch_a8_dma<8, 128>(s, p, a_q, a_scales, a_group_size);
-        }
         const dim3 g2(gemm_grid_x((p.m + 127u) / 128u, (p.n + 127u) / 128u));
 #define UZU_A8(B, G) return launch_check([&] { hipLaunchKernelGGL((gemm_a8_mfma_kernel<B, G>), g2, dim3(256), 0, s, p, a_q, a_scales, a_group_size); }, "gemm_a8_mfma")
         if (p.bits == 4) {

@@ -1682,3 +1682,8 @@ uzu_status attn_merge(hipStream_t s, const float* partials, const float* sums, c
 
 // tests / A-B runs: -1 = environment / default, 0 = attn_dec + attn_merge, 1 = fused (decided when a step is encoded or captured)
 extern "C" void uzu_hip_debug_set_attn_fused(int mode) { uzu::k::g_attn_fused_override = mode; }
+#ifdef UZU_ATTN_FUSED_BUILD
+extern "C" int uzu_hip_debug_attn_fused_built(void) { return 1; }
+#else
+extern "C" int uzu_hip_debug_attn_fused_built(void) { return 0; }
+#endif

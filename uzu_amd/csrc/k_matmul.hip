@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) matmul_ref_kernel(MatmulParams p, uint32_
 // results -- but the memory side is a 16-byte vector of codes per 32 (int4) / 16 (int8) elements, the group's scale / bias once per
 // vector, and a wave-uniform activation row (a wave = 64 consecutive columns of ONE row: the activation loads are broadcasts).  Round 5:
 // matmul_ref_kernel issued ~6 dependent byte / halfword loads per element; a reference-order 4096-token Llama-3-8B prefill took 257 s
-// and a decode step 0.8 s, which priced the reference-order proxy oracle out of configuration-scale parity tests and of a parity census.
+// and a decode step 0.8 s, which priced reference-order mode out of configuration-scale parity tests and of a parity census.
 // Covers quantised B, bf16 / f32 activations and scales, no gather; everything else stays on matmul_ref_kernel.
 template <int BITS, class TA, class TW, int MR>
 __global__ void __launch_bounds__(256) matmul_ref_vec_kernel(MatmulParams p) {
