@@ -420,3 +420,40 @@ def test_a_pending_tree_is_void_once_the_sequence_moves_on_another_way(hip_ctx):
         hm.verify_tree(flat2.token_ids(), flat2.nodes())  # and a new tree can be verified (it was refused as "already pending" before)
         hm.accept([0])
     hm.close()
+
+
+@pytest.mark.parametrize("preset,kw", [("tiny-qwen", {"model_dim": 1024, "group_size": 128}), ("tiny-llama", {"model_dim": 1024, "group_size": 128, "method": 1}),
+                                       ("tiny-qwen", {"model_dim": 1024, "group_size": 128, "norm_full_layer": False, "norm_scale_offset": 0.0})])
+def test_few_rows_passes_run_the_normalization_in_the_linears_prologue(hip_ctx, preset, kw, monkeypatch):
+    """Speculative verify passes and prefill tails of 2 or 3 rows: the pre-mixer Normalization rides in the prologue of the qkv / DeltaNet
+    in-projection launch, the pre-MLP Normalization in the fused up | gate + GatedActMul launch (k_gemv_rows.hip, RowsNorm: every workgroup
+    normalises the rows it stages, normalization_kernel's element mapping and reduction order; the residual rows ping-pong between two
+    buffers).  Logits of every tree node, of a 3-row prefill tail and of the decode steps behind an accept must be BIT-IDENTICAL to the
+    passes with separate Normalization launches (UZU_ROWS_NORM=0), with two launches per layer fewer.  (From four rows on the prologue
+    costs more than the launch it saves -- every workgroup redoes every row -- and the engine keeps the separate kernel: engine.hip::linear_normed.)"""
+    cfg = S.PRESETS[preset](max_context_length=256, **kw)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(50, cfg.vocab_size)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("UZU_ROWS_NORM", mode)
+        hm = HipModel(hip_ctx, bundle)
+        hm.prefill(prompt[:47])
+        tok = hm.prefill(prompt[47:])  # a 3-row tail
+        tail_logits = hm.read_logits()
+        root = TrieNode(tok)
+        root.add(TrieNode(5)), root.add(TrieNode(9))
+        flat = root.linearize()
+        sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+        tree_logits = hm.read_tree_logits()
+        launches = hm.decode_launch_count
+        acc = [i for i, _, _ in flat.accept(sampled)]
+        hm.accept(acc)
+        toks, _ = hm.decode(3)
+        runs[mode] = (tok, tail_logits, [int(t) for t in sampled], tree_logits, [int(t) for t in toks], hm.read_logits(), launches)
+        hm.close()
+    a, b = runs["0"], runs["1"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]), "the 3-row prefill tail differs"
+    assert a[2] == b[2] and np.array_equal(a[3], b[3]), "the tree pass differs"
+    assert a[4] == b[4] and np.array_equal(a[5], b[5]), "the decode steps behind the accept differ"
+    assert a[6] - b[6] == 2 * len(bundle.layers), f"launches of the tree pass: {a[6]} -> {b[6]} ({len(bundle.layers)} layers)"

@@ -648,6 +648,40 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
     return true;
 }
 
+bool norm_fusable(const DNorm& N);
+// Two or three rows (small speculative verify passes, prefill tails): the Normalization as the PROLOGUE of the linear that reads its rows
+// (k_gemv_rows.hip, RowsNorm) -- one launch instead of two, the rows bit-identical to the separate kernel's.  mode 1 copy / 2 add; the residual rows go
+// from `sc_in` to `sc_out` (two buffers: the other workgroups still read sc_in); `normed_out` (optional) receives the normalised rows for a second
+// linear.  gated: L is the fused up | gate matrix and `output` = GatedActMul of its halves.  false = not available: the caller runs the separate kernels.
+bool linear_normed(Enc& e, const DNorm& N, int mode, const DLinear& L, const uint16_t* x, const uint16_t* sc_in, uint16_t* sc_out, uint16_t* normed_out, uint16_t* output,
+                   uint32_t rows, bool gated, uint32_t act_type) {
+    const char* env = getenv("UZU_ROWS_NORM"); // =0: the separate Normalization launch (A/B runs, tests; read when a pass is encoded or captured)
+    const bool enabled = !env || atoi(env) != 0;
+    uzu_hip_model* m = e.m;
+    // rows <= 3 only: EVERY workgroup of the linear normalises all the rows it stages (hundreds of workgroups x rows x two passes through the L2), which
+    // costs more than the launch it saves from 4 rows on -- measured on Qwen3.5-0.8B (profiles/r5_verify_cost.json, `rows_norm_ab`): 2 nodes 1560 -> 1492 us,
+    // 4 nodes 1603 -> 1656, 8 nodes 1711 -> 1996, 16 nodes 1959 -> 2794 with the prologue at every size
+    static const uint32_t max_rows = [] {
+        const char* v = getenv("UZU_ROWS_NORM_MAX");
+        return (uint32_t)(v && atoi(v) > 0 ? atoi(v) : 3);
+    }();
+    if (!enabled || rows < 2 || rows > max_rows || rows > 16 || k::exact_mode() || (m->flags & UZU_MODEL_NO_FUSION) || !norm_fusable(N) || mode == 0) return false;
+    if (L.in_signs || L.out_signs || L.lora_rank || L.method == UZU_QUANT_NONE || L.bits != 4 || (gated && L.out_biases)) return false;
+    k::MatmulParams p{};
+    p.a = x, p.b = L.w, p.scales = L.scales, p.biases = L.biases, p.zero_points = L.zp, p.d = output, p.bias = L.out_biases;
+    p.w_dt = p.a_dt = p.d_dt = UZU_BF16;
+    p.b_kind = L.method == UZU_QUANT_SCALE_BIAS ? UZU_MATMUL_B_SCALE_BIAS : L.method == UZU_QUANT_SCALE_ZERO_POINT ? UZU_MATMUL_B_SCALE_ZERO_POINT : UZU_MATMUL_B_SCALE_SYMMETRIC;
+    p.bits = L.bits, p.group_size = L.group, p.ab_scale = 1.0f, p.m = rows, p.n = L.n, p.k = L.k;
+    if (gated) p.act_mul = 1, p.act_type = act_type;
+    if (!k::gemv_rows_norm_supported(p)) return false;
+    k::RowsNorm rn{};
+    rn.scales = N.scales, rn.eps = N.eps, rn.offset = N.offset, rn.full_layer = N.full_layer, rn.residual_add = mode == 2;
+    rn.shortcut_in = mode == 2 ? sc_in : nullptr, rn.shortcut_out = sc_out, rn.normed_out = normed_out;
+    e.begin();
+    e.run(k::gemv_rows_mfma(e.s, p, &rn), gated ? "gemv_rows[norm+up+act]" : "gemv_rows[norm+linear]", k::matmul_algorithmic_bytes(p));
+    return true;
+}
+
 // mode: 0 none, 1 copy, 2 add (ShortcutMode, encodable_block/normalization.rs:22-27)
 // `consumer`: the quantised linear that reads `output` next as a prefill GEMM: the kernel then files the group row sums of the rows it writes
 k::NormParams norm_params(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr) {
@@ -720,12 +754,13 @@ struct Seqs {
 
 void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
 
-void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr) {
+// `first_done`: the layer's first projection (qkv; the DeltaNet in-projection) has been run with its Normalization prologue already (linear_normed)
+void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr, bool first_done = false) {
     uzu_hip_model* m = e.m;
     const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
     const uint32_t rows = q.rows();
     if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, rows);
-    linear(e, L.qkv, hidden, m->qkv, rows);
+    if (!first_done) linear(e, L.qkv, hidden, m->qkv, rows);
     if (L.qn.present)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, rows, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
     if (L.kn.present)
@@ -799,10 +834,10 @@ void delta_net_tree_core(Enc& e, DLayer& L, uint32_t layer, uint32_t n) {
     RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, m->delta_out, m->in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, n));
 }
 
-void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr) {
+void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr, bool first_done = false) {
     uzu_hip_model* m = e.m;
     const uint32_t rows = q.rows();
-    linear(e, L.in_proj, hidden, m->in_proj, rows);
+    if (!first_done) linear(e, L.in_proj, hidden, m->in_proj, rows);
     if (m->tree.active) { // !batch_dim.full_accept() (delta_net.rs:496-502)
         delta_net_tree_core(e, L, (uint32_t)(&L - m->layers.data()), q.count);
     } else if (q.n == 0) {
@@ -883,35 +918,53 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     // (PostNorm: the split-K reduction, the epilogue and the normalisation of a row are one launch).  `hidden_normed`: the pre-mixer normalisation of
     // the layer about to run has been done that way by the previous layer's down projection.
     bool hidden_normed = false;
+    // the residual rows: in place in m->shortcut, except where a Normalization rides in a few-rows linear's prologue (linear_normed: 2 .. 16 rows, one
+    // sequence) -- those read sc_cur and write the other buffer of the pair
+    uint16_t* sc_cur = m->shortcut;
+    auto sc_other = [&]() { return sc_cur == m->shortcut ? m->shortcut_b : m->shortcut; };
+    const bool few_rows = !seqs && m->shortcut_b != nullptr;
     for (uint32_t l = 0; l < m->d.num_layers; ++l) {
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
+        bool first_done = false;
         if (L.pre_mixer.present) {
-            if (!hidden_normed) norm(e, L.pre_mixer, hidden, m->normed, m->shortcut, l > 0 ? 2 : 1, rows, d, L.d.mixer_kind == UZU_MIXER_ATTENTION ? &L.qkv : &L.in_proj);
+            if (!hidden_normed) {
+                const bool att = L.d.mixer_kind == UZU_MIXER_ATTENTION;
+                // (a gated attention layer's gate projection reads the same normalised rows: the prologue files them in m->normed)
+                if (few_rows && linear_normed(e, L.pre_mixer, l > 0 ? 2 : 1, att ? L.qkv : L.in_proj, hidden, sc_cur, sc_other(), att && L.d.has_gate ? m->normed : nullptr,
+                                              att ? m->qkv : m->in_proj, rows, false, 0)) {
+                    first_done = true, sc_cur = sc_other();
+                } else {
+                    norm(e, L.pre_mixer, hidden, m->normed, sc_cur, l > 0 ? 2 : 1, rows, d, att ? &L.qkv : &L.in_proj);
+                }
+            }
             h = m->normed;
         } else {
-            RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->shortcut, UZU_BF16, rows * d));
+            RUN("tensor_copy", 0, k::tensor_copy(s, hidden, sc_cur, UZU_BF16, rows * d));
         }
         hidden_normed = false;
         PostNorm mlp_norm; // the pre-MLP normalisation, offered to the mixer's out projection when nothing sits between them
         const bool offer_mlp = !L.post_mixer.present && rows >= 128;
-        if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
+        if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, sc_cur, 2, rows, d, &L.up);
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
-            attention_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr);
+            attention_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr, first_done);
         else
-            delta_net_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr);
+            delta_net_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr, first_done);
         const uint16_t* mixed = m->mixed;
         if (L.post_mixer.present) {
             norm(e, L.post_mixer, m->mixed, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, m->mixed, UZU_BF16, rows * d));
         }
+        bool mlp_done = false; // pre-MLP Normalization + up | gate + GatedActMul as ONE few-rows launch
         if (offer_mlp) {
             norm_issued(m, mlp_norm.p);
             if (!mlp_norm.done) RUN("normalization", 0, k::normalization(e.s, mlp_norm.p));
+        } else if (few_rows && !L.post_mixer.present && linear_normed(e, L.pre_mlp, 2, L.up, mixed, sc_cur, sc_other(), nullptr, m->gated, rows, true, L.d.activation)) {
+            mlp_done = true, sc_cur = sc_other();
         } else {
-            norm(e, L.pre_mlp, mixed, m->normed, m->shortcut, 2, rows, d, &L.up);
+            norm(e, L.pre_mlp, mixed, m->normed, sc_cur, 2, rows, d, &L.up);
         }
-        if (!linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
+        if (!mlp_done && !linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
             linear(e, L.up, m->normed, m->up, rows);
             RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
         }
@@ -920,7 +973,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         const bool offer_next = rows >= 128 && !L.post_mlp.present && l + 1 < m->d.num_layers && m->layers[l + 1].pre_mixer.present;
         if (offer_next) {
             const DLayer& Nx = m->layers[l + 1];
-            next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, m->shortcut, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
+            next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, sc_cur, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
         }
         linear(e, L.down, m->gated, hidden, rows, true, offer_next ? &next_norm : nullptr);
         if (offer_next && next_norm.done) {
@@ -936,7 +989,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     m->tap_rows = count;
     if (m->tree.active) {
         // a tree pass: output norm, read-out and greedy sampling of EVERY node (output_range 0..size, stream.rs:618-628), no commit
-        norm(e, m->output_norm, hidden, m->tree.normed, m->shortcut, 2, count, d);
+        norm(e, m->output_norm, hidden, m->tree.normed, sc_cur, 2, count, d);
         DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
         ro.in_signs = m->d.tied_embeddings ? m->embedding.out_signs : m->output_embedding.in_signs;
         ro.out_signs = nullptr;
@@ -974,7 +1027,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         if (seqs) bind_state(m, seqs[i]);
         if (sample) {
             const size_t last = ((size_t)i * count + count - 1) * d;
-            norm(e, m->output_norm, hidden + last, m->last_normed, m->shortcut + last, 2, 1, d);
+            norm(e, m->output_norm, hidden + last, m->last_normed, sc_cur + last, 2, 1, d);
             // Embedding::encode_readout (embedding.rs:374-456): the read-out's private InputRht -- a tied table's output signs
             // (embedding.rs:167-173) or the untied output embedding's input signs (embedding.rs:255-274) -- then the plain matmul
             DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;

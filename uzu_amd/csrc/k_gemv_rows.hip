@@ -46,11 +46,12 @@ struct RowsParams {
     void* d;                  // [m, n] bf16 or f32
     uint32_t m, n, k, group_size, kind, d_f32;
     uint32_t act_type; // ACT instances: n = 2 h weight rows [up | gate]; d = [m, h] = up * act(gate) (GatedActMul, gated_act_mul.rs:36-70)
+    RowsNorm norm;     // NORM instances: `a` holds the raw rows
 };
 
 // ACT: the workgroup owns the 16 up rows row0 .. and the 16 gate rows h + row0 .. (two accumulators, one activation stream), and its epilogue is
 // GatedActMul on the rounded pair -- the decode GEMV's act-mul epilogue (k_decode.hip) for a handful of rows: no [m, 2 h] round trip, no launch.
-template <int NW, bool ACT>
+template <int NW, bool ACT, bool NORM>
 __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
     constexpr int NB = ACT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t gr_smem[];
@@ -91,7 +92,83 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
     Step stA, stB;
     load_step(wave, stA); // in flight while the activations are staged
     // ---- stage the activation rows: 16-byte chunks (8 consecutive k) in the conversion's k order; rows >= m are zero
-    {
+    if constexpr (NORM) {
+        // Normalization prologue (normalization.rs:56-125 with AccumT = f32, no mean / biases): normalization_kernel's arithmetic per row -- thread t of
+        // 256 owns the E = K / 256 elements [t E, t E + E), one fma chain, the wave butterfly, ((w0 + w1) + w2) + w3 -- so the staged rows are the rows
+        // the separate kernel would have written.  256 threads per row (a 512-thread workgroup takes two rows at a time); two passes over the rows
+        // (sums, then values: the second read comes from the L2), element e of a row lands at chunk e / 8, pair e % 4, half e / 4 % 2.
+        const uint32_t E = K / 256, t = tid & 255u, rg = tid >> 8;
+        constexpr uint32_t RG = NW / 4;
+        float* red = s_part; // [16 rows][4 waves]: free until the tiles are parked
+        auto load4 = [&](uint32_t row, uint32_t e, float (&v)[4]) {
+            const uint2 xr = *(const uint2*)(p.a + (size_t)row * K + e);
+            v[0] = __builtin_bit_cast(float, xr.x << 16), v[1] = __builtin_bit_cast(float, xr.x & 0xFFFF0000u);
+            v[2] = __builtin_bit_cast(float, xr.y << 16), v[3] = __builtin_bit_cast(float, xr.y & 0xFFFF0000u);
+            if (p.norm.residual_add) {
+                const uint2 sr = *(const uint2*)(p.norm.shortcut_in + (size_t)row * K + e);
+                const float sc[4] = {__builtin_bit_cast(float, sr.x << 16), __builtin_bit_cast(float, sr.x & 0xFFFF0000u), __builtin_bit_cast(float, sr.y << 16),
+                                     __builtin_bit_cast(float, sr.y & 0xFFFF0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = round_bf16(v[i] + sc[i]);
+            }
+        };
+        for (uint32_t row = rg; row < p.m; row += RG) {
+            float ss = 0.f;
+            for (uint32_t q = 0; q < E; q += 4) {
+                float v[4];
+                load4(row, t * E + q, v);
+                if (p.norm.shortcut_out && blockIdx.x == 0) {
+                    uint2 o;
+                    o.x = (__builtin_bit_cast(uint32_t, v[0]) >> 16) | (__builtin_bit_cast(uint32_t, v[1]) & 0xFFFF0000u);
+                    o.y = (__builtin_bit_cast(uint32_t, v[2]) >> 16) | (__builtin_bit_cast(uint32_t, v[3]) & 0xFFFF0000u);
+                    *(uint2*)(p.norm.shortcut_out + (size_t)row * K + t * E + q) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss = fmaf(v[i], v[i], ss);
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[row * 4 + (t >> 6)] = ss;
+        }
+        lds_barrier();
+        for (uint32_t row = rg; row < p.m; row += RG) {
+            const float total = ((red[row * 4] + red[row * 4 + 1]) + red[row * 4 + 2]) + red[row * 4 + 3];
+            const float variance = total / (float)K - 0.0f * 0.0f;
+            const float rms_inv = 1.0f / sqrtf(variance + p.norm.eps);
+            for (uint32_t q = 0; q < E; q += 4) {
+                const uint32_t e = t * E + q;
+                float v[4];
+                load4(row, e, v);
+                float scl[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.norm.scales) {
+                    const float4 s4 = *(const float4*)(p.norm.scales + e);
+                    scl[0] = s4.x, scl[1] = s4.y, scl[2] = s4.z, scl[3] = s4.w;
+                }
+                uint16_t* dst = (uint16_t*)(xs + (size_t)row * pitch + (size_t)(e / 8) * 16) + (e % 8) / 4; // pair i of the chunk at +2 i halfwords; half e / 4 % 2
+                uint16_t ob[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float normalized = (v[i] - 0.0f) * rms_inv;
+                    float r_;
+                    if (!p.norm.scales) r_ = round_bf16(normalized);
+                    else if (p.norm.full_layer) r_ = round_bf16(normalized * (scl[i] + p.norm.offset));
+                    else r_ = round_bf16(round_bf16(normalized) * round_bf16(scl[i] + p.norm.offset));
+                    ob[i] = f32_to_bf16(r_);
+                    dst[2 * i] = ob[i];
+                }
+                if (p.norm.normed_out && blockIdx.x == 0) {
+                    uint2 o;
+                    o.x = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16), o.y = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+                    *(uint2*)(p.norm.normed_out + (size_t)row * K + e) = o;
+                }
+            }
+        }
+        // rows >= m: zero
+        const uint32_t chunks_per_row = K / 8, total = (16 - p.m) * chunks_per_row;
+        for (uint32_t idx = tid; idx < total; idx += 64 * NW) {
+            const uint32_t j = p.m + idx / chunks_per_row, c = idx % chunks_per_row;
+            *(gr_u32x4*)(xs + (size_t)j * pitch + (size_t)c * 16) = gr_u32x4{0u, 0u, 0u, 0u};
+        }
+    } else {
         const uint32_t chunks_per_row = K / 8, total = 16 * chunks_per_row;
         for (uint32_t idx = tid; idx < total; idx += 64 * NW) {
             const uint32_t j = idx / chunks_per_row, c = idx % chunks_per_row;
@@ -203,28 +280,38 @@ bool gemv_rows_mfma_supported(const MatmulParams& p) {
     return true;
 }
 
-uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p) {
+// the Normalization prologue needs whole 4-element vectors per thread of the 256-thread mapping (k % 1024 == 0) on top of the kernel's own conditions
+bool gemv_rows_norm_supported(const MatmulParams& p) { return gemv_rows_mfma_supported(p) && p.k % 1024 == 0 && p.k <= 16384; }
+
+template <int NW, bool ACT, bool NORM> static uzu_status launch_rows(hipStream_t s, const RowsParams& q, uint32_t blocks, size_t lds) {
+    static LdsLimit lim;
+    if (!raise_lds_limit(lim, (const void*)gemv_rows_mfma_kernel<NW, ACT, NORM>, lds)) {
+        set_error("gemv_rows: %zu bytes of LDS are not available", lds);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    return launch_check([&] { hipLaunchKernelGGL((gemv_rows_mfma_kernel<NW, ACT, NORM>), dim3(blocks), dim3(64 * NW), lds, s, q); }, "gemv_rows_mfma");
+}
+
+uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p, const RowsNorm* norm) {
     RowsParams q{};
     q.a = (const uint16_t*)p.a, q.w = (const uint8_t*)p.b, q.scales = (const uint16_t*)p.scales, q.biases = (const uint16_t*)p.biases, q.zp = p.zero_points;
     q.out_bias = (const uint16_t*)p.bias, q.d = p.d, q.m = p.m, q.n = p.n, q.k = p.k, q.group_size = p.group_size, q.kind = p.b_kind, q.d_f32 = p.d_dt == UZU_F32;
     q.act_type = p.act_type;
+    if (norm) {
+        if (!gemv_rows_norm_supported(p) || (norm->residual_add && !norm->shortcut_in) || (norm->shortcut_out && norm->shortcut_out == norm->shortcut_in)) {
+            set_error("gemv_rows: the Normalization prologue does not cover this shape (k %u), or its residual rows alias", p.k);
+            return UZU_ERR_UNSUPPORTED;
+        }
+        q.norm = *norm;
+    }
     const bool act = p.act_mul != 0;
     const uint32_t blocks = ((act ? p.n / 2 : p.n) + 15) / 16, steps = p.k / 128;
     // eight waves split K where the row blocks alone leave most of the chip idle and there are steps to share
     const bool wide = !act && blocks < 256 && steps >= 16;
     const int nw = wide ? 8 : 4;
     const size_t lds = (size_t)16 * (p.k * 2 + 16) + (size_t)nw * (act ? 2 : 1) * 256 * 4;
-    static LdsLimit lim4, lim8, lim_act;
-    const void* fn = act ? (const void*)gemv_rows_mfma_kernel<4, true> : wide ? (const void*)gemv_rows_mfma_kernel<8, false> : (const void*)gemv_rows_mfma_kernel<4, false>;
-    if (!raise_lds_limit(act ? lim_act : wide ? lim8 : lim4, fn, lds)) {
-        set_error("gemv_rows: %zu bytes of LDS are not available", lds);
-        return UZU_ERR_UNSUPPORTED;
-    }
-    return launch_check([&] {
-        if (act) hipLaunchKernelGGL((gemv_rows_mfma_kernel<4, true>), dim3(blocks), dim3(256), lds, s, q);
-        else if (wide) hipLaunchKernelGGL((gemv_rows_mfma_kernel<8, false>), dim3(blocks), dim3(512), lds, s, q);
-        else hipLaunchKernelGGL((gemv_rows_mfma_kernel<4, false>), dim3(blocks), dim3(256), lds, s, q);
-    }, "gemv_rows_mfma");
+    if (norm) return act ? launch_rows<4, true, true>(s, q, blocks, lds) : wide ? launch_rows<8, false, true>(s, q, blocks, lds) : launch_rows<4, false, true>(s, q, blocks, lds);
+    return act ? launch_rows<4, true, false>(s, q, blocks, lds) : wide ? launch_rows<8, false, false>(s, q, blocks, lds) : launch_rows<4, false, false>(s, q, blocks, lds);
 }
 
 } // namespace k

@@ -64,7 +64,19 @@ uzu_status matmul(hipStream_t s, const MatmulParams& p, int num_cus, const char*
 bool matmul_act_mul_supported(hipStream_t s, const MatmulParams& p, int num_cus);
 // k_gemv_rows.hip: 2 <= M <= 16 activation rows against int4 codes (group % 128 == 0) as ONE pass over the weights on the matrix cores
 bool gemv_rows_mfma_supported(const MatmulParams& p);
-uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p);
+// Normalization (RMS; ShortcutMode Copy / Add; normalization.rs:56-125) of the m <= 16 activation rows as the PROLOGUE of the few-rows kernel
+// (speculative verify passes, prefill tails: round 5): every workgroup normalises the rows while it stages them, with the element mapping and
+// reduction order of normalization_kernel (bit-identical rows); workgroup 0 also writes the residual rows and, if asked, the normalised rows.
+struct RowsNorm {
+    const float* scales;         // f32 [k] or null (plain RMS norm)
+    float eps, offset;
+    uint32_t full_layer, residual_add;
+    const uint16_t* shortcut_in; // residual_add: bf16 [m, k], added to the rows first
+    uint16_t* shortcut_out;      // bf16 [m, k] or null: the (summed) rows, i.e. the new residual -- must not alias shortcut_in (other workgroups still read it)
+    uint16_t* normed_out;        // bf16 [m, k] or null: the normalised rows (for a second linear that reads the same rows)
+};
+bool gemv_rows_norm_supported(const MatmulParams& p);
+uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p, const RowsNorm* norm = nullptr);
 bool gemm_q_mfma_supported(const MatmulParams& p);   // k_gemm.hip: M >= 20, bf16 activations, int4/int8 codes, group % 64 == 0
 uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus);
 // k_gemm128.hip: 128 x 128 tiles, M >= 128, group 64 / 128 / 256; `workspace` holds the activation row-sum pieces (+ split-K partials)
