@@ -4,7 +4,7 @@ the transforms in the GEMV prologues / as the reference's own kernels around the
 one-kernel-per-reference-kernel path (UZU_MODEL_NO_FUSION: what these models took before), next to the same model without the transforms.
 Synthetic weights.  Prints one JSON object.
 
-  python tools/rht_decode_cost.py > profiles/r4_rht_decode.json
+  python tools/rht_decode_cost.py > profiles/r5_rht_decode.json
 """
 import json
 import os
@@ -34,6 +34,13 @@ def main():
             ctx.synchronize()
             dt = time.perf_counter() - t0
             row[label] = {"tokens_per_s": round(steps / dt, 1), "us_per_token": round(dt / steps * 1e6, 1), "launches_per_token": hm.decode_launch_count}
+            if label == "rht_fused":  # where the step goes: one eager step with events around every launch (an upper bound on the in-graph times)
+                agg = {}
+                for name, _, ms in hm.profile_decode_step():
+                    a = agg.setdefault(name, [0, 0.0])
+                    a[0] += 1
+                    a[1] += ms * 1e3
+                row[label]["kernel_us_per_step"] = {k: {"calls": v[0], "us": round(v[1], 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             hm.close()
         row["rht_fused_over_unfused"] = round(row["rht_fused"]["tokens_per_s"] / row["rht_unfused"]["tokens_per_s"], 2)
         out["models"].append(row)

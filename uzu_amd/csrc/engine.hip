@@ -1251,7 +1251,13 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 RUN("attn_dec", kv_bytes, k::attn_dec(s, a, m->dec_splits));
                 RUN("attn_merge", 0, k::attn_merge(s, m->dec_partials, m->dec_sums, m->dec_maxs, L.d.has_gate ? m->gate : nullptr, m->attn_out, nq, hd, m->dec_splits));
             }
-            dec_gemv_row_parallel(e, dec_gemv_base(L.out, in_transform(L.out, m->attn_out), m->mixed), "gemv_dec[out_proj]");
+            if (L.out.in_bits && k::gemv_dec_plain_in_rht_supported(L.out.k, L.out.bits)) { // the out-projection's InputRht in the GEMV's registers (round 5)
+                k::DecGemvParams op = dec_gemv_base(L.out, m->attn_out, m->mixed);
+                op.in_rht_bits = L.out.in_bits;
+                dec_gemv_row_parallel(e, op, "gemv_dec[out_proj]");
+            } else {
+                dec_gemv_row_parallel(e, dec_gemv_base(L.out, in_transform(L.out, m->attn_out), m->mixed), "gemv_dec[out_proj]");
+            }
             if (L.out.out_signs) pending = &L.out, pending_row = m->mixed;
         } else {
             const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
@@ -1269,13 +1275,7 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 p.conv_w = L.conv_w, p.conv_b = L.conv_b, p.conv_state = L.conv_state, p.conv_dim = conv_dim, p.conv_ks = L.d.dn_kernel_size;
                 dec_gemv(e, p, "gemv_dec[norm+in_proj+conv]");
             }
-            if (linear_rht(L.out_proj)) {
-                // the norm-gate prologue has no Hadamard instance: the delta rule with its RMSNorm * SiLU(z) tail as one kernel, InputRht, a plain-row GEMV
-                RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(s, m->in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, m->delta_out, Hv, Hk, Dk, Dv, Hk * Dk,
-                                                                                      Hv * Dv, L.d.dn_norm_epsilon));
-                dec_gemv_row_parallel(e, dec_gemv_base(L.out_proj, in_transform(L.out_proj, m->delta_out), m->mixed), "gemv_dec[out_proj]");
-                pending = &L.out_proj, pending_row = m->mixed;
-            } else {
+            {
                 k::DeltaDecParams q{};
                 q.in_proj = m->in_proj, q.a_log = L.a_log, q.dt_bias = L.dt_bias, q.state = L.ssm_state, q.o = m->dn_o, q.sz = m->dn_sz;
                 q.num_v_heads = Hv, q.num_k_heads = Hk, q.head_v_dim = Dv, q.key_dim = Hk * Dk, q.value_dim = Hv * Dv;
@@ -1283,7 +1283,11 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 // ... and the RMSNorm * SiLU(z) gate in the out-proj prologue (it needs all Dv outputs of a head)
                 k::DecGemvParams op = dec_gemv_base(L.out_proj, m->delta_out, m->mixed);
                 op.dg_o = m->dn_o, op.dg_sz = m->dn_sz, op.dg_w = L.dn_norm, op.dg_dv = Dv, op.dg_eps = L.d.dn_norm_epsilon;
+                // an RHT out-projection (round 5: until then delta_net_update on 16 workgroups + an InputRht launch + a plain-row GEMV): its InputRht is
+                // applied to the gated row inside the norm-gate prologue; its OutputRht (+ bias) rides in the next normalised GEMV's prologue as before
+                op.in_rht_bits = L.out_proj.in_bits;
                 dec_gemv_row_parallel(e, op, "gemv_dec[gate+out_proj]");
+                if (L.out_proj.out_signs) pending = &L.out_proj, pending_row = m->mixed;
             }
         }
         const uint16_t* down_in = nullptr; // the down projection's input row once its InputRht has been applied

@@ -234,6 +234,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         x_bits = (p.x_rht_bits ? p.x_rht_bits : (const uint32_t*)p.x)[st];
         in_bits = (p.in_rht_bits ? p.in_rht_bits : (const uint32_t*)p.x)[st];
     }
+    if constexpr (PRO == 2) { // the norm-gate prologue of an RHT out-projection: its InputRht on the gated row (round 5)
+        if (p.in_rht_bits) in_bits = p.in_rht_bits[min((uint32_t)tid, C - 1)];
+    }
     f32x4_v dg_pre[6]; // norm-gate prologue: chunk 0 of this thread (o, z, w: two vectors each); further chunks load in place
     if (PRO == 2) {
         const uint32_t nchunks = K / 8, per = nchunks > 256 ? nchunks / 256 : 1;
@@ -324,6 +327,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                     *(float4*)(slot + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
+            if (p.in_rht_bits) { // RHTLinearWrapper (rht_wrapper.rs:215-298): this linear's InputRht on the gated row, stripe by stripe through the slots --
+                lds_barrier();   // activation_transform INPUT_RHT's arithmetic on the bf16 values delta_net_update would have stored (bit-identical)
+                if ((uint32_t)tid < C) rht_stripe<true>(xs + (size_t)tid * 36, in_bits, nullptr);
+            }
             if ((ACT || CONV) && tid < 32) s_exp_tab[tid] = exp_entry; // rides on the barrier below
             lds_barrier();
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                     for (int i = 0; i < 32; ++i) xf[RAWX ? 0 : j][i] = 0.f;
                 }
             }
-        } else if (PRO == 0) { // plain activation row: every lane fetches its own steps
+        } else if (PRO == 0 || PRO == 4) { // plain activation row: every lane fetches its own steps
             if constexpr (RAWX) { // int4: bf16 pairs straight into packed-dot order, step sums through the dot unit (as for K > 8192)
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -358,8 +365,13 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const uint32_t c = sl + lpr * j;
-                if (c < C) load32_bf16(p.x + (size_t)c * 32, xf[RAWX ? 0 : j]);
-                else {
+                if (c < C) {
+                    load32_bf16(p.x + (size_t)c * 32, xf[RAWX ? 0 : j]);
+                    // PRO == 4: the InputRht of an RHT linear on its plain input row (attention rows in front of the out-projection): a lane's step IS
+                    // one 32-element stripe, so the transform runs in its registers -- activation_transform INPUT_RHT's arithmetic (rht_stripe.h),
+                    // redone by every lane group instead of a launch of its own in front of the GEMV (round 5)
+                    if constexpr (PRO == 4) rht_stripe_regs<true>(xf[RAWX ? 0 : j], p.in_rht_bits[c]);
+                } else {
 #pragma unroll
                     for (int i = 0; i < 32; ++i) xf[RAWX ? 0 : j][i] = 0.f;
                 }
@@ -518,7 +530,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         for (int j = 0; j < CPL; ++j) xpack_from_f32(xq[BITS == 4 ? j : 0], xf[j]);
     }
 
-    if ((ACT || CONV) && (PRO == 0 || CPLT == 0)) { // no prologue barrier to ride on
+    if ((ACT || CONV) && (PRO == 0 || PRO == 4 || CPLT == 0)) { // no prologue barrier to ride on
         if (tid < 32) s_exp_tab[tid] = exp_entry;
         lds_barrier();
     }
@@ -853,7 +865,7 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
 }
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO>
 static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
-    if constexpr (!ACT && PRO != 2 && PRO != 3) {
+    if constexpr (!ACT && PRO != 2 && PRO != 3 && PRO != 4) {
         if (p.conv_w) { // conv epilogue with prefetched operands (kernel size 4, instantiated for R <= 2)
             if (R > 2) {
                 want *= (uint32_t)(R / 2);
@@ -878,6 +890,9 @@ static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint3
             return UZU_ERR_UNSUPPORTED;
         }
         if (normed) return launch_gemv_dec_p<BITS, CPLT, ACT, KIND, 1>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+        if constexpr (!ACT && CPLT != 4) {
+            if (p.in_rht_bits && !p.conv_w) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 4>(s, p, want, lpr_log2, R, num_cus, grid_out, wide); // plain row + InputRht
+        }
     }
     if constexpr (CPLT == 4) {
         set_error("gemv_dec: the 4-step register path is instantiated for the prologue variants only");
@@ -917,6 +932,12 @@ unsigned long long* timeline_next_slot() {
 extern "C" void uzu_hip_debug_set_timeline(unsigned long long* base, uint32_t max_launches) { g_tl_base = base, g_tl_max = max_launches, g_tl_next = 0; }
 #endif
 
+// a plain-row GEMV takes its linear's InputRht in registers (PRO == 4) when a lane holds its steps of the row there: <= 2 steps per lane
+bool gemv_dec_plain_in_rht_supported(uint32_t k, uint32_t bits) {
+    if (k % 32 || (bits != 4 && bits != 8)) return false;
+    const uint32_t C = k / 32, lpr = 1u << gemv_lpr_log2(k);
+    return (C + lpr - 1) / lpr <= 2;
+}
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint32_t* grid_out) {
     DecGemvParams p = p_in;
 #ifdef UZU_TIMELINE
@@ -934,6 +955,10 @@ uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p_in, int num_cus, uint3
             set_error("gemv_dec: unsupported norm-gate prologue (k %u, dv %u)", p.k, dv);
             return UZU_ERR_UNSUPPORTED;
         }
+    }
+    if (p.in_rht_bits && !p.norm_scales && !p.norm_plain && !p.dg_o && !gemv_dec_plain_in_rht_supported(p.k, p.bits)) {
+        set_error("gemv_dec: the InputRht of a plain input row runs on register-resident rows only (k %u: more than two steps per lane)", p.k);
+        return UZU_ERR_UNSUPPORTED;
     }
     if (p.conv_w && (p.conv_ks != 4 || p.act_mul || p.out_f32)) {
         set_error("gemv_dec: the conv epilogue is instantiated for kernel size 4 (got %u)", p.conv_ks);

@@ -106,6 +106,7 @@ struct DecGemvParams {
 };
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
+bool gemv_dec_plain_in_rht_supported(uint32_t k, uint32_t bits); // in_rht_bits on a plain (not normalised, not norm-gated) input row
 // The weight-streaming engine (k_stream.hip): LDS-DMA loader wave + consumer waves per CU; same arithmetic as gemv_dec.  gemv_dec
 // routes to it when gemv_stream_wanted (bandwidth regime, int4 ScaleBias, UZU_DEC_STREAM / uzu_hip_debug_set_decode_stream).
 bool gemv_stream_supported(const DecGemvParams& p);
