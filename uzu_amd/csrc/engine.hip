@@ -1264,11 +1264,19 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
             k::DecGemvParams p = dec_gemv_base(L.in_proj, hidden, m->in_proj);
             const uint32_t conv_dim = 2 * Hk * Dk + Hv * Dv;
             if (linear_rht(L.in_proj)) {
-                // the conv needs the OutputRht of the row it convolves: projection, the transform, then DeltaNetConvUpdate as a launch of its own
+                // the conv needs the OutputRht of the row it convolves
                 next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, &L.in_proj);
-                dec_gemv(e, p, "gemv_dec[norm+in_proj]");
-                RUN("rht_out_rows", 0, k::rht_out_rows(s, m->in_proj, L.in_proj.out_bits, (const uint16_t*)L.in_proj.out_biases, L.in_proj.n, nullptr, nullptr, nullptr, 0, L.conv_w,
-                                                        L.conv_b, L.conv_state, L.d.dn_kernel_size, conv_dim));
+                k::DecGemvParams ps = p;
+                ps.ep_out_bits = L.in_proj.out_bits, ps.ep_bias = (const uint16_t*)L.in_proj.out_biases;
+                ps.conv_w = L.conv_w, ps.conv_b = L.conv_b, ps.conv_state = L.conv_state, ps.conv_dim = conv_dim, ps.conv_ks = L.d.dn_kernel_size;
+                if (L.in_proj.out_bits && k::gemv_dec_stripe_supported(ps, m->ctx->num_cus)) {
+                    // round 5: the projection's workgroups own whole 32-row Hadamard blocks and finish them themselves (k_decode.hip, PRO == 5)
+                    dec_gemv(e, ps, "gemv_dec[norm+in_proj+rht+conv]");
+                } else { // projection, the transform, then DeltaNetConvUpdate as a launch of its own
+                    dec_gemv(e, p, "gemv_dec[norm+in_proj]");
+                    RUN("rht_out_rows", 0, k::rht_out_rows(s, m->in_proj, L.in_proj.out_bits, (const uint16_t*)L.in_proj.out_biases, L.in_proj.n, nullptr, nullptr, nullptr, 0, L.conv_w,
+                                                            L.conv_b, L.conv_state, L.d.dn_kernel_size, conv_dim));
+                }
             } else {
                 next_norm(p, L.pre_mixer, l > 0 ? 2 : 1, nullptr, true);
                 // DeltaNetConvUpdate rides in the in-proj epilogue: the lane that finishes a conv channel's row convolves it
@@ -1294,11 +1302,18 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
         if (linear_rht(L.up)) { // GatedActMul needs the OutputRht of both halves: projection, then the transform (+ bias) and the product
             k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->up);
             next_norm(up, L.pre_mlp, 2, &L.up);
-            dec_gemv(e, up, "gemv_dec[norm+up]");
-            // ... as ONE launch with the down projection's InputRht (a thread per stripe; the reference's four kernels on one row)
-            RUN("rht_mlp_join", 0, k::rht_mlp_join(s, m->up, L.up.out_bits, (const uint16_t*)L.up.out_biases, L.down.in_bits, L.down.in_bits ? m->rht_scratch : m->gated,
-                                                    L.d.hidden_dim, L.d.activation));
             down_in = L.down.in_bits ? m->rht_scratch : m->gated;
+            k::DecGemvParams us = up;
+            us.act_mul = 1, us.act_type = L.d.activation, us.out[0] = (uint16_t*)down_in;
+            us.ep_out_bits = L.up.out_bits, us.ep_bias = (const uint16_t*)L.up.out_biases, us.ep_next_in_bits = L.down.in_bits;
+            if (L.up.out_bits && k::gemv_dec_stripe_supported(us, m->ctx->num_cus)) {
+                // round 5: up | gate rows, their OutputRht (+ bias), GatedActMul and the down projection's InputRht in ONE launch (k_decode.hip, PRO == 5)
+                dec_gemv(e, us, "gemv_dec[norm+up+rht+act]");
+            } else {
+                dec_gemv(e, up, "gemv_dec[norm+up]");
+                // ... as ONE launch with the down projection's InputRht (a thread per stripe; the reference's four kernels on one row)
+                RUN("rht_mlp_join", 0, k::rht_mlp_join(s, m->up, L.up.out_bits, (const uint16_t*)L.up.out_biases, L.down.in_bits, (uint16_t*)down_in, L.d.hidden_dim, L.d.activation));
+            }
         } else {
             k::DecGemvParams up = dec_gemv_base(L.up, m->mixed, m->gated);
             next_norm(up, L.pre_mlp, 2, nullptr, true);

@@ -104,8 +104,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     constexpr int NPHYS = ACT ? 2 : 1;
     constexpr int CPL = CPLT == 0 ? 1 : CPLT; // register-resident steps (CPLT == 0: streaming over j)
     constexpr int NT = 64 * NW;
-    static_assert(NW == 4 || (!CONV && PRO != 2 && (PRO == 1 || PRO == 3 || (CPLT == 0 && BITS == 4))), "wide workgroups: prologue kernels of the bandwidth regime only");
+    static_assert(NW == 4 || (!CONV && PRO != 2 && (PRO == 1 || PRO == 3 || PRO == 5 || (CPLT == 0 && BITS == 4))), "wide workgroups: prologue kernels of the bandwidth regime only");
     static_assert(PRO != 3 || (!ACT && !CONV), "an RHT linear's outputs go through OutputRht before any epilogue could use them");
+    // PRO == 5 (round 5): PRO == 3's prologue + the STRIPE epilogue -- a workgroup owns whole 32-row Hadamard blocks of the output, parks the raw rows of a
+    // block in LDS and one wave runs the linear's OutputRht (+ bias) on it and what follows (the GatedActMul + the next linear's InputRht of
+    // rht_mlp_join, or the DeltaNet conv of rht_out_rows) before anything is stored: the join launches behind the up / in-projection disappear
+    static_assert(PRO != 5 || ((NW == 4 || NW == 8) && R == 1 && !CONV), "the stripe epilogue: 4- or 8-wave workgroups, one row per lane group");
+    constexpr bool RHTP = PRO == 3 || PRO == 5;
+    constexpr bool STRIPE = PRO == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     UZU_TL_DECL;
     UZU_TL_STAMP(0);
@@ -134,7 +140,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     };
     // Loads of one (batch, step) item.  Batches [0, batches0) belong to matrix 0, the rest to matrix 1 (wave-uniform:
     // the base pointers stay in SGPRs and the per-lane part of every address is a 32-bit byte offset -- host-checked).
-    const uint32_t b_own = min((uint32_t)(blockIdx.x * bpw + min((uint32_t)wave, bpw - 1)), num_batches - 1);
+    // STRIPE: batches per 32-row block (a multiple of the NW waves: rows_per_batch = rpw is 1, 2 or 4 -- host-checked), blocks of the matrix; workgroup w owns
+    // blocks w, w + grid, ...: wave v takes batches v, v + NW, ... of a block
+    const uint32_t nbs = STRIPE ? 32u / rows_per_batch : 1u;
+    const uint32_t b_own = STRIPE ? min(blockIdx.x * nbs + (uint32_t)wave, num_batches - 1) : min((uint32_t)(blockIdx.x * bpw + min((uint32_t)wave, bpw - 1)), num_batches - 1);
     auto load_item = [&](uint32_t b, uint32_t j, Item& it) {
         // Unconditional: batch and step are clamped into range and a clamped reload is never consumed.  VMEM returns in
         // issue order and the compiler only emits counted waits (vmcnt(N)) across loads that are always issued; even a
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             c4.bias = p.conv_b ? bias : 0.0f;
         }
     };
-    const uint32_t b0 = (uint32_t)wave < bpw ? blockIdx.x * bpw + wave : num_batches;
+    const uint32_t b0 = STRIPE ? blockIdx.x * nbs + (uint32_t)wave : ((uint32_t)wave < bpw ? blockIdx.x * bpw + wave : num_batches);
     // Wide workgroups hand their batches out dynamically.  On a CU the oldest waves win the issue arbitration: with a static
     // assignment the first-dispatched quarter of a 1024-workgroup grid finishes after 10.4 us, the last after 17.2 us
     // (Llama-3-8B up-projection, tools/timeline.py --detail; no difference between XCDs), and the CU idles towards the end with
@@ -196,7 +205,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     __shared__ uint32_t s_next_slot;
     if (NW > 4 && tid == 0) s_next_slot = bpw; // published by the prologue's barrier, first drawn after it
     auto next_batch = [&](uint32_t b) -> uint32_t {
-        if constexpr (NW > 4) {
+        if constexpr (STRIPE) {
+            const uint32_t pos = b % nbs;
+            return pos + NW < nbs ? b + NW : b - pos + gridDim.x * nbs + (uint32_t)wave; // the next batch of this block, or this wave's first of the workgroup's next block
+        } else if constexpr (NW > 4) {
             uint32_t n = 0;
             if (lane == 0) n = atomicAdd(&s_next_slot, 1u);
             n = __builtin_amdgcn_readfirstlane(n);
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
     u32x2_v x_pre[NPRE], s_pre[NPRE];
     f32x4_v n_pre[NPRE];
     const bool pro_wave = NW == 4 || wave < 4; // the prologue is a 256-thread affair (wave-uniform)
-    if ((PRO == 1 || PRO == 3) && pro_wave) {
+    if ((PRO == 1 || RHTP) && pro_wave) {
         const uint32_t E = K / 256;
 #pragma unroll
         for (int qi = 0; qi < NPRE; ++qi) {
@@ -229,10 +241,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         }
     }
     uint32_t x_bits = 0, in_bits = 0; // PRO == 3: the sign words of the stripe this thread transforms (unconditional loads: an absent table reads the row)
-    if constexpr (PRO == 3) {
+    uint32_t x_bits_s = 0, in_bits_s = 0; // ... and of the stripe this thread's OWN elements [tid E, tid E + E) lie in (the spread form below)
+    if constexpr (RHTP) {
         const uint32_t st = min((uint32_t)tid, C - 1);
         x_bits = (p.x_rht_bits ? p.x_rht_bits : (const uint32_t*)p.x)[st];
         in_bits = (p.in_rht_bits ? p.in_rht_bits : (const uint32_t*)p.x)[st];
+        const uint32_t sw = min((uint32_t)tid * (K / 256) / 32, C - 1);
+        x_bits_s = (p.x_rht_bits ? p.x_rht_bits : (const uint32_t*)p.x)[sw];
+        in_bits_s = (p.in_rht_bits ? p.in_rht_bits : (const uint32_t*)p.x)[sw];
     }
     if constexpr (PRO == 2) { // the norm-gate prologue of an RHT out-projection: its InputRht on the gated row (round 5)
         if (p.in_rht_bits) in_bits = p.in_rht_bits[min((uint32_t)tid, C - 1)];
@@ -386,8 +402,52 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             const uint32_t E = K / 256;
             float ss = 0.f;
             bool x_in_lds = false;
-            if constexpr (PRO == 3) {
-                if (p.x_rht_bits) { // the row is the raw output of an RHT linear: its OutputRht (+ bias) first, stripe by stripe through the slots
+            // PRO == 3, spread form (rht_stripe.h::rht_spread): with E a power of two in [4, 32] a stripe is 32 / E neighbouring threads of the
+            // prologue, and both transforms run on the elements where they already are -- in the owning threads' registers
+            constexpr int EMAX = RHTP ? 8 * CPL : 1;
+            float er[EMAX];
+            const bool spread = RHTP && (E == 4 || E == 8 || E == 16 || E == 32) && E <= (uint32_t)EMAX;
+            bool x_in_regs = false;
+            auto spread_transform = [&](bool input, uint32_t bits) {
+                const uint32_t fb = ((uint32_t)tid * E) % 32;
+                if constexpr (RHTP) {
+                    if (E == 4) input ? rht_spread<4, true>(*(float(*)[4])er, bits, fb, lane) : rht_spread<4, false>(*(float(*)[4])er, bits, fb, lane);
+                    if constexpr (EMAX >= 8) {
+                        if (E == 8) input ? rht_spread<8, true>(*(float(*)[8])er, bits, fb, lane) : rht_spread<8, false>(*(float(*)[8])er, bits, fb, lane);
+                    }
+                    if constexpr (EMAX >= 16) {
+                        if (E == 16) input ? rht_spread<16, true>(*(float(*)[16])er, bits, fb, lane) : rht_spread<16, false>(*(float(*)[16])er, bits, fb, lane);
+                    }
+                    if constexpr (EMAX >= 32) {
+                        if (E == 32) input ? rht_spread<32, true>(*(float(*)[32])er, bits, fb, lane) : rht_spread<32, false>(*(float(*)[32])er, bits, fb, lane);
+                    }
+                }
+            };
+            if constexpr (RHTP) {
+                if (p.x_rht_bits && spread) { // the row is the raw output of an RHT linear: its OutputRht (+ bias) first
+                    if (pro_wave) {
+#pragma unroll
+                        for (int qi = 0; qi < 2 * CPL; ++qi) {
+                            const uint32_t q = (uint32_t)qi * 4;
+                            if (q >= E) break;
+                            const u32x2_v xr = qi < NPRE ? x_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.x + tid * E + q);
+                            er[4 * qi] = bits_to_f32(xr.x << 16), er[4 * qi + 1] = bits_to_f32(xr.x & 0xFFFF0000u);
+                            er[4 * qi + 2] = bits_to_f32(xr.y << 16), er[4 * qi + 3] = bits_to_f32(xr.y & 0xFFFF0000u);
+                        }
+                        spread_transform(false, x_bits_s);
+                        if (p.x_rht_bias) {
+#pragma unroll
+                            for (int qi = 0; qi < 2 * CPL; ++qi) {
+                                const uint32_t q = (uint32_t)qi * 4;
+                                if (q >= E) break;
+                                const u32x2_v br = *(const u32x2_v*)(p.x_rht_bias + tid * E + q);
+                                er[4 * qi] = round_bf16(er[4 * qi] + bits_to_f32(br.x << 16)), er[4 * qi + 1] = round_bf16(er[4 * qi + 1] + bits_to_f32(br.x & 0xFFFF0000u));
+                                er[4 * qi + 2] = round_bf16(er[4 * qi + 2] + bits_to_f32(br.y << 16)), er[4 * qi + 3] = round_bf16(er[4 * qi + 3] + bits_to_f32(br.y & 0xFFFF0000u));
+                            }
+                        }
+                    }
+                    x_in_regs = true;
+                } else if (p.x_rht_bits) { // (E not a power of two: stripe by stripe through the slots, one thread per stripe)
                     if (pro_wave) {
 #pragma unroll
                         for (int qi = 0; qi < 2 * CPL; ++qi) {
@@ -413,9 +473,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                 const uint32_t e = tid * E + q;
                 const u32x2_v xr = qi < NPRE ? x_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.x + e);
                 float v[4] = {bits_to_f32(xr.x << 16), bits_to_f32(xr.x & 0xFFFF0000u), bits_to_f32(xr.y << 16), bits_to_f32(xr.y & 0xFFFF0000u)};
-                if (PRO == 3 && x_in_lds) {
+                if (RHTP && x_in_lds) {
                     const float4 t = *(const float4*)(xs + (size_t)(e / 32) * 36 + e % 32);
                     v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+                }
+                if constexpr (RHTP) {
+                    if (x_in_regs) v[0] = er[4 * qi], v[1] = er[4 * qi + 1], v[2] = er[4 * qi + 2], v[3] = er[4 * qi + 3];
                 }
                 if (p.residual_add) {
                     const u32x2_v sr = qi < NPRE ? s_pre[qi < NPRE ? qi : 0] : *(const u32x2_v*)(p.shortcut_in + e);
@@ -459,6 +522,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                     else if (p.norm_full_layer) v[i] = round_bf16(normalized * (scl[i] + p.norm_offset));
                     else v[i] = round_bf16(round_bf16(normalized) * round_bf16(scl[i] + p.norm_offset));
                 }
+                if constexpr (RHTP) {
+                    if (spread && p.in_rht_bits) er[4 * qi] = v[0], er[4 * qi + 1] = v[1], er[4 * qi + 2] = v[2], er[4 * qi + 3] = v[3]; // (transformed below, then stored)
+                }
                 *(float4*)slot = make_float4(v[0], v[1], v[2], v[3]);
                 if (p.normed_out && blockIdx.x == 0) {
                     uint2 o;
@@ -468,8 +534,19 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
                 }
             }
             }
-            if constexpr (PRO == 3) {
-                if (p.in_rht_bits) { // this linear's InputRht on the normalised row
+            if constexpr (RHTP) {
+                if (p.in_rht_bits && spread) { // this linear's InputRht on the normalised row, in the owning threads' registers
+                    if (pro_wave) {
+                        spread_transform(true, in_bits_s);
+#pragma unroll
+                        for (int qi = 0; qi < 2 * CPL; ++qi) {
+                            const uint32_t q = (uint32_t)qi * 4;
+                            if (q >= E) break;
+                            const uint32_t e = tid * E + q;
+                            *(float4*)(xs + (size_t)(e / 32) * 36 + e % 32) = make_float4(er[4 * qi], er[4 * qi + 1], er[4 * qi + 2], er[4 * qi + 3]);
+                        }
+                    }
+                } else if (p.in_rht_bits) { // this linear's InputRht on the normalised row
                     lds_barrier();
                     if ((uint32_t)tid < C) rht_stripe<true>(xs + (size_t)tid * 36, in_bits, nullptr);
                 }
@@ -594,6 +671,52 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             keep_row = 0xFFFFFFFFu, act_cnt = 0;
         }
     };
+    __shared__ float s_stripe[STRIPE ? 2 : 1][STRIPE ? 32 : 1];
+    // One complete 32-row block: wave 0 runs rht_mlp_join_kernel's (ACT) / rht_out_rows_kernel's arithmetic on it -- hadamard32 across the lanes of a
+    // half-wave, the sign factors, the roundings, the bias, then GatedActMul + the next linear's InputRht, or the DeltaNet conv of a channel --
+    // and stores the finished rows.  ACT: lanes 0-31 carry the block's up rows, lanes 32-63 its gate rows.
+    auto stripe_epilogue = [&](uint32_t st) {
+        if constexpr (STRIPE) {
+            lds_barrier();
+            if (wave == 0) {
+                const int l = lane & 31, half = lane >> 5;
+                const uint32_t stripes = n_log0 / 32, row = st * 32 + (uint32_t)l;
+                if constexpr (ACT) {
+                    float v = hadamard32(s_stripe[half][l], l);
+                    const uint32_t word = p.ep_out_bits[half ? stripes + st : st];
+                    v = round_bf16((word >> l) & 1u ? -v : v);
+                    if (p.ep_bias) v = round_bf16(v + bf16_to_f32(p.ep_bias[(half ? n_log0 : 0u) + row]));
+                    const float gate = __shfl(v, l + 32, 64);
+                    float r_ = round_bf16(v * act_bf16(p.act_type, gate, s_exp_tab)); // gated_act_mul/mod.rs:5-12 (lanes 32-63 compute on, unused)
+                    if (p.ep_next_in_bits) {
+                        const uint32_t iw = p.ep_next_in_bits[st];
+                        r_ = round_bf16(hadamard32((iw >> l) & 1u ? -r_ : r_, l));
+                    }
+                    if (half == 0) p.out[0][row] = f32_to_bf16(r_);
+                } else {
+                    float v = hadamard32(s_stripe[0][l], l);
+                    const uint32_t word = p.ep_out_bits[st];
+                    v = round_bf16((word >> l) & 1u ? -v : v);
+                    if (p.ep_bias) v = round_bf16(v + bf16_to_f32(p.ep_bias[row]));
+                    if (half == 0) {
+                        if (p.conv_w && row < p.conv_dim) { // DeltaNetConvUpdate of this channel (conv_update.rs:17-55), as rht_out_rows_kernel does it
+                            const uint32_t tap_count = p.conv_ks - 1;
+                            float* st_row = p.conv_state + (size_t)row * tap_count;
+                            const float* w = p.conv_w + (size_t)row * p.conv_ks;
+                            float cacc = p.conv_b ? p.conv_b[row] : 0.0f;
+                            for (uint32_t tap = 0; tap < tap_count; ++tap) cacc += st_row[tap] * w[tap];
+                            cacc += v * w[tap_count];
+                            for (uint32_t tap = 1; tap < tap_count; ++tap) st_row[tap - 1] = st_row[tap];
+                            st_row[tap_count - 1] = v;
+                            v = silu_f32(cacc);
+                        }
+                        p.out[0][row] = f32_to_bf16(v);
+                    }
+                }
+            }
+            lds_barrier(); // the block's slots are free again
+        }
+    };
     auto finish = [&](uint32_t b, float (&acc)[R][NPHYS], const ConvPre (&cp)[CONV ? R : 1]) {
         const int mat = __builtin_amdgcn_readfirstlane(b >= batches0 ? 1 : 0);
         const uint32_t lb = mat ? b - batches0 : b;
@@ -603,7 +726,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
             const float v0 = row_sum_rt(acc[r][0], lpr);
             const float v1 = ACT ? row_sum_rt(acc[r][NPHYS - 1], lpr) : 0.f;
             const uint32_t lrow = lb * rows_per_batch + r * rpw + rsub;
-            if constexpr (ACT) {
+            if constexpr (STRIPE) {
+                // the raw rows of the workgroup's current 32-row block, rounded to bf16 as the separate launch would have stored them (the linear's
+                // own bias comes behind its OutputRht: bias_after_rht) -- stripe_epilogue takes over when the block is complete
+                if (sl == 0) {
+                    s_stripe[0][lrow & 31u] = round_bf16(1.0f * v0);
+                    if (ACT) s_stripe[1][lrow & 31u] = round_bf16(1.0f * v1);
+                }
+            } else if constexpr (ACT) {
                 // every lane of a row's group holds the row sums; MatmulKernel epilogue with ab_scale = 1 (kernel.rs:281-292), rounded to bf16
                 float value = 1.0f * v0, gate = 1.0f * v1;
                 if (p.out_bias[0] && lrow < nl) value += bf16_to_f32(p.out_bias[0][lrow]), gate += bf16_to_f32(p.out_bias[0][lrow + p.n[0] / 2]);
@@ -692,6 +822,9 @@ __global__ void __launch_bounds__(64 * NW) gemv_dec_kernel(const void* a0, const
         }
         UZU_TL_STAMP(5); // dot products of the (last) batch done
         finish(b, acc, cp_cur);
+        if constexpr (STRIPE) {
+            if (b % nbs + NW >= nbs) stripe_epilogue(b / nbs); // this wave's last batch of the block: all waves meet here
+        }
         UZU_TL_STAMP(6);
         if (CONV) conv_prefetch(bn, cp_cur); // operands of this wave's next batch
         return bn;
@@ -863,6 +996,47 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
 #undef UZU_LAUNCH
 #undef UZU_LAUNCH_N
 }
+// an RHT linear whose epilogue (GatedActMul / DeltaNet conv) needs its OutputRht first: whole 32-row blocks per workgroup (PRO == 5)
+bool gemv_dec_stripe_supported(const DecGemvParams& p, int num_cus) {
+    static const bool on = [] { // UZU_DEC_STRIPE=0: the join launches behind the GEMV (A/B runs)
+        const char* e = getenv("UZU_DEC_STRIPE");
+        return !e || atoi(e) != 0;
+    }();
+    if (!on || p.bits != 4 || p.n[1] || !(p.norm_scales || p.norm_plain) || p.k % 1024 || p.out_f32 || p.part_val || p.dg_o) return false;
+    const uint32_t n_log0 = p.act_mul ? p.n[0] / 2 : p.n[0];
+    if (!n_log0 || n_log0 % 32) return false;
+    const uint32_t C = p.k / 32, lpr = 1u << gemv_lpr_log2(p.k), cpl = (C + lpr - 1) / lpr;
+    if (cpl > 2 || (32u / (64u / lpr)) % 4) return false; // (a block's batches split evenly over four waves)
+    const uint64_t weight_bytes = (uint64_t)p.n[0] * p.k / 2;
+    if (weight_bytes >= (10u << 20)) return false; // the bandwidth regime keeps its wide workgroups (one block per workgroup would idle most of their waves)
+    (void)num_cus;
+    return true;
+}
+template <int CPLT, bool ACT, int KIND>
+static uzu_status launch_gemv_dec_stripe(hipStream_t s, const DecGemvParams& p, int lpr_log2, int num_cus, uint32_t* grid_out) {
+    if (!gemv_dec_stripe_supported(p, num_cus)) {
+        set_error("gemv_dec: the stripe epilogue does not cover this shape (n %u, k %u)", p.n[0], p.k);
+        return UZU_ERR_UNSUPPORTED;
+    }
+    const size_t lds = ((size_t)(p.k / 32) * 36 + 16) * sizeof(float);
+    const uint32_t stripes = (p.act_mul ? p.n[0] / 2 : p.n[0]) / 32, cap = (uint32_t)num_cus * 4;
+    const uint32_t grid = stripes < cap ? stripes : cap;
+    if (grid_out) *grid_out = grid;
+    return launch_check([&] {
+        // eight waves where a block has at least eight batches (one or two rows per wave pass): two batches per wave instead of four
+        const uint32_t nbs = 32u / (64u >> lpr_log2);
+        static const int nw_env = [] { // UZU_DEC_STRIPE_NW=4: four-wave workgroups (A/B runs)
+            const char* e = getenv("UZU_DEC_STRIPE_NW");
+            return e ? atoi(e) : 8;
+        }();
+        if (nbs >= 8 && nbs % 8 == 0 && nw_env == 8)
+            hipLaunchKernelGGL((gemv_dec_kernel<4, CPLT, 1, ACT, KIND, 5, false, 8>), dim3(grid), dim3(512), lds, s, (const void*)p.x, (const void*)p.shortcut_in, (const void*)p.norm_scales, p.k,
+                               lpr_log2, p.w[0], p.scales[0], p.biases[0], p);
+        else
+            hipLaunchKernelGGL((gemv_dec_kernel<4, CPLT, 1, ACT, KIND, 5, false, 4>), dim3(grid), dim3(256), lds, s, (const void*)p.x, (const void*)p.shortcut_in, (const void*)p.norm_scales, p.k,
+                               lpr_log2, p.w[0], p.scales[0], p.biases[0], p);
+    }, "gemv_dec");
+}
 template <int BITS, int CPLT, bool ACT, int KIND, int PRO>
 static uzu_status launch_gemv_dec_p(hipStream_t s, const DecGemvParams& p, uint32_t want, int lpr_log2, int R, int num_cus, uint32_t* grid_out, bool wide) {
     if constexpr (!ACT && PRO != 2 && PRO != 3 && PRO != 4) {
@@ -882,6 +1056,11 @@ static uzu_status launch_gemv_dec_k(hipStream_t s, const DecGemvParams& p, uint3
     if constexpr (CPLT != 0) { // prologues keep the row in registers (checked by the caller)
         if constexpr (!ACT)
             if (p.dg_o) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 2>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);
+        if (normed && p.ep_out_bits) { // RHT linear with the stripe epilogue (gemv_dec_stripe_supported)
+            if constexpr (BITS == 4 && CPLT != 4) return launch_gemv_dec_stripe<CPLT, ACT, KIND>(s, p, lpr_log2, num_cus, grid_out);
+            set_error("gemv_dec: the stripe epilogue is instantiated for int4 rows of one or two steps per lane");
+            return UZU_ERR_UNSUPPORTED;
+        }
         if (normed && (p.x_rht_bits || p.in_rht_bits)) { // Hadamard transforms around the normalisation (RHT linears)
             if constexpr (!ACT) {
                 if (!p.conv_w) return launch_gemv_dec_p<BITS, CPLT, false, KIND, 3>(s, p, want, lpr_log2, R, num_cus, grid_out, wide);

@@ -103,7 +103,17 @@ struct DecGemvParams {
     const uint32_t* x_rht_bits;   // [k / 32] or null
     const uint16_t* x_rht_bias;   // bf16 [k] or null
     const uint32_t* in_rht_bits;  // [k / 32] or null
+    // The STRIPE epilogue (PRO == 5, round 5): THIS linear is an RHT linear whose consumer needs its OutputRht first.  A workgroup owns whole 32-row
+    // blocks, parks a block's raw rows in LDS, and one wave applies the OutputRht (ep_out_bits: one sign bit per output row, [n / 32] words;
+    // act_mul: up blocks then gate blocks) + ep_bias (bf16 [n] or null) and then
+    //   act_mul: GatedActMul of the block's (up, gate) pairs + the NEXT linear's InputRht (ep_next_in_bits: [n / 64] words or null) -> out[0][n / 2]
+    //   else   : the DeltaNet conv of rows < conv_dim (conv_w / conv_b / conv_state / conv_ks as above, any kernel size) -> out[0][n]
+    // -- rht_mlp_join's / rht_out_rows's arithmetic (k_elementwise.hip) without their launches.  gemv_dec_stripe_supported says where it applies.
+    const uint32_t* ep_out_bits;
+    const uint16_t* ep_bias;
+    const uint32_t* ep_next_in_bits;
 };
+bool gemv_dec_stripe_supported(const DecGemvParams& p, int num_cus);
 uint32_t gemv_dec_grid(const DecGemvParams& p, int num_cus, int* lpr_log2, int* R);
 uzu_status gemv_dec(hipStream_t s, const DecGemvParams& p, int num_cus, uint32_t* grid_out);
 bool gemv_dec_plain_in_rht_supported(uint32_t k, uint32_t bits); // in_rht_bits on a plain (not normalised, not norm-gated) input row

@@ -42,5 +42,49 @@ __device__ __forceinline__ void rht_stripe_regs(float (&a)[32], uint32_t bits) {
     }
 }
 
+// The same transform with a stripe SPREAD over 32 / E consecutive, aligned lanes whose threads own E consecutive elements each (E in {4, 8, 16, 32}:
+// the Normalization prologue's element mapping, thread t <-> elements [t E, t E + E)): strides below E run in the thread's registers, the others with
+// xor shuffles; the butterfly order (1, 2, 4, 8, 16; the lower element keeps a + b, the upper gets a - b), the 1 / sqrt(32) and the place of the sign
+// factors are rht_stripe_regs': the same f32 operations in the same order per element => bit-identical values, without the LDS round trip, the two
+// barriers and the 32 / E-fold under-occupation of the one-thread-per-stripe form (round 5: 2.5 us per RHT prologue).  `bits` = the stripe's sign word.
+template <int E>
+__device__ __forceinline__ void hadamard_spread(float (&v)[E], int lane) {
+#pragma unroll
+    for (int stride = 1; stride < E; stride <<= 1) {
+#pragma unroll
+        for (int l = 0; l < E; ++l) {
+            if (l & stride) continue;
+            const float lo = v[l], hi = v[l | stride];
+            v[l] = lo + hi, v[l | stride] = lo - hi;
+        }
+    }
+#pragma unroll
+    for (int stride = E; stride < 32; stride <<= 1) {
+        const int m = stride / E;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int l = 0; l < E; ++l) {
+            const float other = __shfl_xor(v[l], m, 64);
+            v[l] = upper ? other - v[l] : v[l] + other;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < E; ++l) v[l] = v[l] * (1.0f / sqrtf(32.0f));
+}
+template <int E, bool INPUT>
+__device__ __forceinline__ void rht_spread(float (&v)[E], uint32_t bits, uint32_t first_bit, int lane) { // element i of v carries sign bit first_bit + i
+    if (INPUT) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = (bits >> (first_bit + i)) & 1u ? -v[i] : v[i];
+    }
+    hadamard_spread<E>(v, lane);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        float x = v[i];
+        if (!INPUT) x = (bits >> (first_bit + i)) & 1u ? -x : x;
+        v[i] = round_bf16(x);
+    }
+}
+
 } // namespace k
 } // namespace uzu
