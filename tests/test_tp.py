@@ -121,8 +121,21 @@ def test_planner_refuses_what_it_would_get_wrong():
         TP.take_rows(up, np.arange(8, 40))
     assert np.array_equal(TP.take_rows(up, np.arange(32, 96)).output_signs, up.output_signs[32:96])
     TP.shard_bundle(S.build_model(S.tiny_qwen(rht=True)), 0, 2)  # (the synthetic in-proj, n % 32 != 0, carries no factors)
+    # RHT embeddings (round 5): the sign vectors run along model_dim, which the vocabulary split does not cut -- the shard's read-out takes them whole as
+    # its input factors (a tied table's output factors are the read-out's input factors, embedding.rs:167-173), the lookup table stays replicated
+    for cfg in (S.tiny_llama(rht_embeddings=True), S.tiny_qwen(rht_embeddings=True)):
+        full = S.build_model(cfg)
+        for r in range(2):
+            sh, off = TP.shard_bundle(full, r, 2)
+            want = full.embedding.output_signs if full.tied_embeddings else full.output_embedding.input_signs
+            assert not sh.tied_embeddings and sh.output_embedding.output_signs is None and np.array_equal(sh.output_embedding.input_signs, want)
+            assert np.array_equal(sh.embedding.output_signs, full.embedding.output_signs) and sh.output_embedding.n == cfg.vocab_size // 2 and off == r * cfg.vocab_size // 2
+            src = full.embedding if full.tied_embeddings else full.output_embedding
+            assert np.array_equal(sh.output_embedding.weights, src.weights[off:off + cfg.vocab_size // 2])
+    bad = S.build_model(S.tiny_llama(rht_embeddings=True))
+    bad.output_embedding.output_signs = np.ones(bad.output_embedding.n, np.int32)
     with pytest.raises(NotImplementedError, match="RHT embeddings"):
-        TP.shard_bundle(S.build_model(S.tiny_llama(rht_embeddings=True)), 0, 2)
+        TP.shard_bundle(bad, 0, 2)
     # hidden padding of an RHT MLP: the zero rows between the up and gate halves must be whole 32-row Hadamard blocks (advisor finding, round 4:
     # with an unquantised down projection, group 1, the gate half could shift against its OutputRht blocks and still pass take_rows' check)
     assert TP.padded_hidden(224, 1, 4) == 224 and TP.padded_hidden(224, 1, 4, rht=True) == 256
@@ -450,6 +463,10 @@ TP_CASES = [
     # ... and at a width the FUSED decode step covers (model_dim % 1024 == 0): the transforms ride in the GEMV prologues, the OutputRht of the
     # row-parallel projections behind the one-hop exchange
     ("tiny-llama", {"rht": True, "model_dim": 1024}, 40, 8, 0.25, 0.05),
+    # RHT embeddings under TP (round 5): untied (Output mode on the lookup table, Input mode on the sharded read-out) and tied (the table's output factors
+    # are the read-out's input factors)
+    ("tiny-llama", {"rht_embeddings": True}, 40, 8, 0.25, 0.05),
+    ("tiny-qwen", {"rht_embeddings": True}, 40, 8, 0.25, 0.05),
 ]
 
 

@@ -235,20 +235,27 @@ def shard_bundle(bundle: D.ModelBundle, rank: int, size: int) -> Tuple[D.ModelBu
     """-> (shard bundle, vocab_offset).  size == 1 still produces the untied-readout form the TP engine expects."""
     assert 0 <= rank < size
     # HybridSpec linears shard with their Hadamard factors (take_rows / take_k: 32-aligned cuts only, refused otherwise).  Not planned:
-    # QLoRA adapters (refused by the helpers) and RHT embeddings (the read-out is cut by vocabulary rows, its InputRht form and the
-    # lookup's OutputRht would each need the factors of the other cut).
-    if bundle.embedding.input_signs is not None or bundle.embedding.output_signs is not None or (
-            bundle.output_embedding is not None and (bundle.output_embedding.input_signs is not None or bundle.output_embedding.output_signs is not None)):
-        raise NotImplementedError("tensor-parallel shards of RHT embeddings are not planned")
-    for w in (bundle.embedding, bundle.output_embedding):
+    # QLoRA adapters (refused by the helpers).  RHT embeddings (embedding.rs:126-341; round 5): their sign vectors run along MODEL_DIM -- the
+    # lookup's OutputRht on the replicated table, the read-out's InputRht on the normalised row -- which the vocabulary split does not cut:
+    # the shard's read-out keeps them whole as its input factors (a tied table's output factors ARE the read-out's input factors,
+    # embedding.rs:167-173).  Only the combinations the reference does not have either are refused.
+    emb, out_emb = bundle.embedding, bundle.output_embedding
+    if emb.input_signs is not None or (out_emb is not None and out_emb.output_signs is not None):
+        raise NotImplementedError("tensor-parallel shards of RHT embeddings: input factors on the lookup table / output factors on the read-out are not a HybridSpec embedding form")
+    for w in (emb, out_emb):
         if w is not None:
             _refuse_adapters(w)
     V = bundle.vocab_size
     assert V % size == 0, f"vocab {V} does not split over {size} ranks"
     lo, hi = rank * V // size, (rank + 1) * V // size
-    readout = bundle.embedding if bundle.tied_embeddings else bundle.output_embedding
+    readout = emb if bundle.tied_embeddings else out_emb
+    readout_in_signs = emb.output_signs if bundle.tied_embeddings else out_emb.input_signs
+    rows = np.arange(lo, hi)
+    cp = lambda a: None if a is None else np.ascontiguousarray(a[rows])
+    readout_shard = D.LinearWeights(hi - lo, readout.k, readout.bits, readout.group_size, readout.method, cp(readout.weights), cp(readout.scales), cp(readout.biases),
+                                    cp(readout.zero_points), cp(readout.out_biases), input_signs=readout_in_signs, output_signs=None)
     shard = replace(bundle, layers=[shard_layer(l, rank, size) for l in bundle.layers], tied_embeddings=False,
-                    output_embedding=take_rows(readout, np.arange(lo, hi)), _keep=[])
+                    output_embedding=readout_shard, _keep=[])
     shard.name = f"{bundle.name}[tp {rank}/{size}]"
     return shard, lo
 
