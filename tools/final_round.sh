@@ -13,6 +13,7 @@ timeout 300 python bench.py --model llama-3-8b --steps 64 --warmup 4 --no-cpu-ba
 timeout 600 python bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
 timeout 300 python bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
 timeout 600 python bench.py --config c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 300 python tools/rht_decode_cost.py > $O/rht_decode.json 2> $O/rht_decode.err
 bash tools/refresh_profiles.sh $R > $O/refresh.log 2>&1
 cd $ROOT
 [ -f uzu_amd/lib_tl/libuzu_hip.so ] && bash tools/timeline_run.sh $O > $O/timeline.log 2>&1
