@@ -211,6 +211,27 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
     assert (want == got).mean() >= 0.97
 
 
+@pytest.mark.parametrize("bits,method,group_size,n,k,m", [(4, 0, 128, 520, 2048, 300), (4, 1, 64, 1160, 1024, 1000), (4, 2, 256, 264, 1024, 131),
+                                                          (8, 0, 128, 520, 1024, 300), (8, 1, 64, 392, 512, 257)])
+@pytest.mark.parametrize("splits", ["1", "2"])
+def test_gemm_ping_pong_form_is_bit_identical_to_the_256_thread_form(hip_ctx, bits, method, group_size, n, k, m, splits, monkeypatch):
+    """UZU_GEMM_PP=1 (k_gemm128.hip, PP instantiation): two 128 x 128 tiles per 512-thread workgroup, convert / MFMA phases half a k-step
+    apart.  A half runs the 256-thread form's arithmetic in the same order, so the outputs are equal byte for byte -- ragged M / N,
+    an odd tile count (one half idle), split-K -- and both hold the oracle tolerance."""
+    monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
+    rng = np.random.default_rng(bits * 1000 + method * 100 + group_size + m)
+    q = quant_matrix(rng, n, k, bits, group_size, method)
+    a = activations(rng, m, k)
+    monkeypatch.setenv("UZU_GEMM_PP", "0")
+    base = hip_matmul(hip_ctx, a, q, m)
+    monkeypatch.setenv("UZU_GEMM_PP", "1")
+    got = hip_matmul(hip_ctx, a, q, m)
+    assert np.array_equal(base, got)
+    want = oracle_matmul(a, q, m)
+    assert ulp_diff_bf16(want, got).max() <= 1.0
+    assert (want == got).mean() >= 0.97
+
+
 @pytest.mark.parametrize("m", [131, 203, 1023])
 def test_gemm_mfma_row_count_not_a_multiple_of_four(hip_ctx, m):
     """The offset-term tables are padded to whole quads of rows (k_gemm128.hip pre-pass); 1023 is the second chunk of the

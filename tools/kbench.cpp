@@ -54,6 +54,60 @@ int main(int argc, char** argv) {
             return gemv_dec(s, p, cus, nullptr);
         });
     };
+    if (getenv("KB_GEMM_AB")) { // 256-thread form against the ping-pong form (UZU_GEMM_PP), same box, random data: time + byte comparison of the outputs
+        struct Shape { uint32_t m, n, k, g, bits; int gated; };
+        std::vector<Shape> shapes = {{2048, 8224, 1024, 128, 4, 0}, {2048, 7168, 1024, 128, 4, 1}, {2048, 1024, 3584, 128, 4, 0}, {2048, 1024, 2048, 128, 4, 0}, {2048, 5120, 1024, 128, 4, 0},
+                                     {4096, 14336, 4096, 128, 4, 0}, {4096, 28672, 4096, 128, 4, 1}, {4096, 4096, 14336, 128, 4, 0}, {4096, 6144, 4096, 128, 4, 0}, {4096, 4096, 4096, 128, 4, 0},
+                                     {300, 520, 2048, 64, 4, 0}, {1000, 520, 2048, 256, 4, 0}, {4096, 14336, 4096, 64, 8, 0}, {2048, 7168, 1024, 128, 8, 1}};
+        if (getenv("KB_GEMM_AB_SHORT")) shapes = {{2048, 7168, 1024, 128, 4, 1}, {2048, 1024, 3584, 128, 4, 0}, {4096, 14336, 4096, 128, 4, 0}, {4096, 4096, 14336, 128, 4, 0}};
+        uint64_t rs = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 32); };
+        for (const Shape& sh : shapes) {
+            const uint32_t m = sh.m, n = sh.n, k = sh.k, g = sh.g, G = k / g;
+            const size_t wb = (size_t)n * k * sh.bits / 8;
+            std::vector<uint8_t> hw(wb); for (auto& v : hw) v = (uint8_t)rnd();
+            std::vector<uint16_t> hs((size_t)n * G), hb((size_t)n * G), hx((size_t)m * k);
+            for (auto& v : hs) v = (uint16_t)(0x3c00 + (rnd() & 0xff));             // scales ~ 0.0078 .. 0.0156
+            for (auto& v : hb) v = (uint16_t)(0xbd00 + (rnd() & 0xff) + ((rnd() & 1) << 15)); // biases ~ +-0.03 .. 0.06
+            for (auto& v : hx) v = (uint16_t)(0x3e00 + (rnd() & 0x1ff) + ((rnd() & 1) << 15)); // activations ~ +-0.125 .. 1
+            uint8_t* w = dalloc<uint8_t>(wb); uint16_t* sc = dalloc<uint16_t>(hs.size()); uint16_t* bi = dalloc<uint16_t>(hb.size()); uint16_t* x = dalloc<uint16_t>(hx.size());
+            CK(hipMemcpy(w, hw.data(), wb, hipMemcpyHostToDevice)); CK(hipMemcpy(sc, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(bi, hb.data(), hb.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+            const size_t on = (size_t)m * (sh.gated ? n / 2 : n);
+            uint16_t* out[2] = {dalloc<uint16_t>(on, 0), dalloc<uint16_t>(on, 0)};
+            MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
+            p.bits = sh.bits, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k; p.act_mul = sh.gated; p.act_type = 0;
+            if (!gemm_q_mfma128_supported(p, cus)) { printf("%ux%ux%u: not a large-tile shape\n", m, n, k); continue; }
+            void* gemm_ws = dalloc<uint8_t>(gemm_q_mfma128_workspace_bytes(p, cus) + 65536);
+            double us[2];
+            for (int pp = 0; pp < 2; ++pp) {
+                setenv("UZU_GEMM_PP", pp ? "1" : "0", 1);
+                char name[96]; snprintf(name, sizeof name, "gemm %ux%ux%u g%u int%u%s %s", m, n, k, g, sh.bits, sh.gated ? " +act" : "", pp ? "ping-pong" : "256-thread");
+                p.d = out[pp];
+                us[pp] = time_graph(name, wb + (size_t)m * k * 2 + on * 2, 8, [&](int) { return gemm_q_mfma128(s, p, cus, gemm_ws); });
+            }
+            std::vector<uint16_t> h0(on), h1(on);
+            CK(hipMemcpy(h0.data(), out[0], on * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), out[1], on * 2, hipMemcpyDeviceToHost));
+            size_t diff = 0, nz = 0; for (size_t i = 0; i < on; ++i) diff += h0[i] != h1[i], nz += (h0[i] & 0x7fff) != 0;
+            printf("    -> %.1f vs %.1f TFLOP/s (x%.3f); outputs differing: %zu of %zu (%zu non-zero)\n", 2.0 * m * n * k / us[0] / 1e6, 2.0 * m * n * k / us[1] / 1e6, us[0] / us[1], diff, on, nz);
+            if (getenv("KB_GEMM_PP_TIMING")) { // a library built with -DUZU_GEMM_PP_TIMING: mean shader cycles per k-step and wave in each phase
+                const size_t slots = 65536 * 5;
+                unsigned long long* d = dalloc<unsigned long long>(slots * 8, 0);
+                uzu::k::g_gemm128_dbg = d; p.d = out[1];
+                gemm_q_mfma128(s, p, cus, gemm_ws); CK(hipStreamSynchronize(s));
+                uzu::k::g_gemm128_dbg = nullptr;
+                std::vector<unsigned long long> h(slots * 8); CK(hipMemcpy(h.data(), d, slots * 64, hipMemcpyDeviceToHost));
+                double sum[2][8] = {}; double steps[2] = {0, 0};
+                for (size_t i = 65536; i < slots; ++i) { const unsigned long long* o = &h[i * 8]; if (!o[4]) continue; const int hf = (int)o[5] & 1; steps[hf] += (double)o[4]; for (int q = 0; q < 4; ++q) sum[hf][q] += (double)o[q]; sum[hf][4] += (double)(o[5] >> 8), sum[hf][5] += (double)o[6], sum[hf][6] += (double)(o[7] & 0xffffffffull), sum[hf][7] += (double)(o[7] >> 32); }
+                for (int hf = 0; hf < 2; ++hf) if (steps[hf] > 0)
+                    printf("    timing half %d: per k-step cycles  convert %.0f  barrier %.0f  mfma %.0f  barrier %.0f\n", hf, sum[hf][0] / steps[hf], sum[hf][1] / steps[hf], sum[hf][2] / steps[hf], sum[hf][3] / steps[hf]),
+                    printf("        convert phase: fold: entry + hazard wait %.0f  FMAs %.0f  scales %.0f;  weight loads %.0f  convert %.0f\n", sum[hf][6] / steps[hf], sum[hf][7] / steps[hf], sum[hf][4] / steps[hf], sum[hf][5] / steps[hf], sum[hf][0] / steps[hf]);
+                CK(hipFree(d));
+            }
+            for (void* q : {(void*)w, (void*)sc, (void*)bi, (void*)x, (void*)out[0], (void*)out[1], gemm_ws}) CK(hipFree(q));
+        }
+        return 0;
+    }
     if (getenv("KB_GEMM")) { // prefill GEMM on the matrix cores (k_gemm.hip)
         for (auto sh : std::vector<std::array<uint32_t, 3>>{{1024, 8224, 1024}, {1024, 7168, 1024}, {1024, 1024, 3584}, {1024, 1024, 2048}, {1024, 3072, 1024}, {4096, 14336, 4096}}) {
             const uint32_t m = sh[0], n = sh[1], k = sh[2], g = 128;

@@ -37,6 +37,18 @@ namespace {
 constexpr int BK = 64, BM = 128, BN = 128;
 constexpr int A_PITCH = 144;
 constexpr bool kPairs = UZU_GEMM_PAIR_DEQUANT != 0;
+#ifndef UZU_GEMM_PP_DEFAULT
+#define UZU_GEMM_PP_DEFAULT 0
+#endif
+#ifndef UZU_GEMM_PP_DB
+#define UZU_GEMM_PP_DB 4 // ping-pong form: weight ring depth
+#endif
+#ifndef UZU_GEMM_PP_DA
+#define UZU_GEMM_PP_DA 2 // ping-pong form: activation register stages
+#endif
+#ifndef UZU_GEMM_FOLD_PK
+#define UZU_GEMM_FOLD_PK 0 // group fold with v_pk_fma_f32 (1) or pairs of v_fma_f32 (0)
+#endif
 #ifndef UZU_GEMM_PIPE
 #define UZU_GEMM_PIPE 1 // software-pipelined k16 steps (operands one step ahead of the MFMAs); 0 = operands right in front of them
 #endif
@@ -99,16 +111,28 @@ __global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float
 
 // ---------------------------------------------------------------------------------------------- main kernel
 // grid (8 S ceil(Q / 8), splits), see tile_map().  GS = k-steps per quant group (1, 2, 4 <=> group 64, 128, 256).
-template <int BITS, int GS>
-__global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, const float* rowsum, const float* coef, float* partials, unsigned long long* dbg) {
+//
+// PP ("ping-pong", round 5): ONE 512-thread workgroup per CU works on a 128 x 256 tile: two halves of four waves, each half the 128 x 128
+// tile of the 256-thread form (same k order, same fold -> bit-identical results) over ONE activation tile in LDS that all eight waves
+// stage (half the L2 -> L1 activation traffic of two independent workgroups).  Wave w and wave w + 4 share a SIMD.  A k-step is cut into
+// a CONVERT phase (weight codes of the step -> bf16 fragments in registers, the group fold, the weight prefetch: VALU / VMEM only) and an
+// MFMA phase (8 ds_read_b128 + 16 back-to-back v_mfma_f32_32x32x16_bf16, with the staging of the next activation tile -- 2 global loads,
+// 8 v_perm, 2 ds_write per thread -- in their shadow); an s_barrier over all eight waves after every phase keeps the halves half a step
+// apart, so a SIMD always holds one wave that wants the matrix pipe and one that wants the vector ALU.
+template <int BITS, int GS, bool PP>
+__global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_kernel(MatmulParams p, const float* rowsum, const float* coef, float* partials, unsigned long long* dbg) {
     constexpr int WV = BITS / 4;           // 16-byte code vectors per lane per 32-column block per k-step
-    constexpr int DB = BITS == 4 ? 4 : 2;  // weight ring depth (k-steps in flight + 1)
-    constexpr int DA = 2;                  // activation register stages
+    constexpr int DB = BITS == 8 ? 2 : PP ? UZU_GEMM_PP_DB : 4;  // weight ring depth (k-steps in flight + 1)
+    constexpr int DA = PP ? UZU_GEMM_PP_DA : 2;                  // activation register stages
     constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
-    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][BM * A_PITCH];
+    constexpr int NH = PP ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_a_all[NH][2][BM * A_PITCH];
     __shared__ uint64_t s_exp_tab[32]; // gated epilogue only
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    uint8_t(*const s_a)[BM * A_PITCH] = s_a_all[0];                       // activation tiles of the main loop (PP: shared by the halves)
+    uint8_t* const s_ep = &s_a_all[PP ? half ^ 1 : 0][0][0];                // epilogue staging (PP: half 0 finishes first and must not touch the tiles half 1 still reads)
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
     const uint32_t M = p.m, N = p.n, K = p.k;
     // GatedActMul fused into the epilogue (p.act_mul; the up projection's rows [0, N/2) = up, [N/2, N) = gate, gated_act_mul.rs:52-58):
@@ -121,7 +145,19 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     // what each 4 MB L2 sees: XCD x works through super-tiles x, x + 8, ... of TM x TN tiles (8 x 8 when the matrix is
     // large enough) -- the 64 resident workgroups then share 8 activation row blocks and 8 weight column blocks.
     uint32_t m_t, n_t;
-    if (!gemm_tile_of_block(blockIdx.x, m_tiles, n_tiles, &m_t, &n_t)) return;
+    bool live;
+    if (PP) { // the tile map runs over PAIRS of column tiles; half h takes column tile 2 pair + h of the same row block
+        uint32_t pr;
+        if (!gemm_tile_of_block(blockIdx.x, m_tiles, (n_tiles + 1) / 2, &m_t, &pr)) return;
+        n_t = 2 * pr + half;
+        live = n_t < n_tiles;
+        if (!live) n_t = n_tiles - 1; // odd tile count: the idle half walks its neighbour's tile for the barriers' sake and stores nothing
+    } else {
+        live = gemm_tile_of_block(blockIdx.x, m_tiles, n_tiles, &m_t, &n_t);
+        if (!live) return;
+    }
+    const uint32_t vblock = PP ? blockIdx.x * 2 + half : blockIdx.x;
+    const uint32_t Mst = live ? M : 0u; // row bound of every store
     const uint32_t xcd = blockIdx.x & 7;
     unsigned long long ts[4];
     ts[0] = wall_clock64();
@@ -137,37 +173,40 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
     // ---- activation staging role: 8 lanes fetch one row's 128 bytes (one cache line per row per instruction), four
     // passes of 32 rows.  (One thread per (row, 64-byte half) costs 45 L1 accesses per wave instruction -- rocprofv3
     // TCP_TOTAL_CACHE_ACCESSES / TA_FLAT_READ_WAVEFRONTS -- and saturates the texture addresser at 4096^2-sized shapes.)
-    const int chunk = tid & 7, rpass = tid >> 3;
-    uint32_t a_off[4]; // element offsets of the thread's four rows
+    // PP: all 512 threads stage the one tile, two passes of 64 rows.
+    constexpr int NR = PP ? 2 : 4, RSTEP = PP ? 64 : 32;
+    const int stid = PP ? (int)threadIdx.x : tid;
+    const int chunk = stid & 7, rpass = stid >> 3;
+    uint32_t a_off[NR]; // element offsets of the thread's rows
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_off[j] = min(m0 + 32 * j + (uint32_t)rpass, M - 1) * K + kt_lo * BK + 8 * chunk;
+    for (int j = 0; j < NR; ++j) a_off[j] = min(m0 + RSTEP * j + (uint32_t)rpass, M - 1) * K + kt_lo * BK + 8 * chunk;
     const uint16_t* a_base = (const uint16_t*)p.a;
-    u32x4_v a_st[DA][4];
-    auto load_a = [&](uint32_t kt, u32x4_v (&st)[4]) {
+    u32x4_v a_st[DA][NR];
+    auto load_a = [&](uint32_t kt, u32x4_v (&st)[NR]) {
         kt = min(kt, KTz - 1); // past the end: re-read the last tile (never staged into a buffer that is read)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st[j] = *(const u32x4_v*)(a_base + (size_t)a_off[j] + kt * BK);
+        for (int j = 0; j < NR; ++j) st[j] = *(const u32x4_v*)((a_base + (size_t)kt * BK) + a_off[j]); // uniform base + 32-bit lane offset: no 64-bit vector address arithmetic
     };
-    auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[4]) {
+    auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[NR]) {
         uint8_t* dst = &s_a[kt & 1][rpass * A_PITCH + chunk * 16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(u32x4_v*)(dst + j * 32 * A_PITCH) = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
+        for (int j = 0; j < NR; ++j) *(u32x4_v*)(dst + j * RSTEP * A_PITCH) = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
     };
 
     // ---- weight role: lane -> column c of each of the wave's two 32-column blocks, k half h
     uint32_t ncol[2];
-    const uint8_t* w_src[2];
+    uint32_t w_off[2]; // byte offsets (< 2^32, host-checked) from a uniform base
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         ncol[nb] = gated ? (wn ? H : 0u) + min(n_t * 64 + nb * 32 + c, H - 1) : min(n0 + wn * 64 + nb * 32 + c, N - 1);
-        w_src[nb] = (const uint8_t*)p.b + (size_t)ncol[nb] * row_bytes + (size_t)kt_lo * BK * BITS / 8 + (size_t)(32 * h) * BITS / 8;
+        w_off[nb] = ncol[nb] * row_bytes + (32 * h) * BITS / 8;
     }
     u32x4_v ring[DB][2][WV];
     auto load_w = [&](uint32_t kt, u32x4_v (&r)[2][WV]) {
         kt = min(kt, KTz - 1);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            const u32x4_v* src = (const u32x4_v*)(w_src[nb] + (size_t)kt * BK * BITS / 8);
+            const u32x4_v* src = (const u32x4_v*)(((const uint8_t*)p.b + (size_t)(kt_lo + kt) * BK * BITS / 8) + w_off[nb]);
 #pragma unroll
             for (int v = 0; v < WV; ++v) r[nb][v] = src[v];
         }
@@ -183,11 +222,13 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
             for (int r = 0; r < 16; ++r) acc_g[mb][nb][r] = 0.f, acc_t[mb][nb][r] = 0.f;
 
     // group scales: sc_cur = group being accumulated, sc_nxt = the next one (requested one group ahead)
-    uint16_t sc_cur[2], sc_nxt[2];
-    auto load_scale = [&](uint32_t g, uint16_t (&dst)[2]) {
+    // (32-bit registers: as uint16_t pairs the compiler packs the two halves into one VGPR with a v_perm right behind the loads, i.e. an
+    // s_waitcnt vmcnt(0) -- a full memory round trip, ~1000 cycles -- in every group fold: the ping-pong form's phase stamps, round 5)
+    uint32_t sc_cur[2], sc_nxt[2];
+    auto load_scale = [&](uint32_t g, uint32_t (&dst)[2]) {
         g = min(g_lo + g, G - 1);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) dst[nb] = scales[(size_t)ncol[nb] * G + g];
+        for (int nb = 0; nb < 2; ++nb) dst[nb] = (scales + g)[ncol[nb] * G];
     };
 
     const uint8_t* a_frag_base = &s_a[0][(wm * 64 + c) * A_PITCH + h * 64];
@@ -239,58 +280,198 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
 #endif
     };
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#if defined(UZU_GEMM_PP_TIMING)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = 0; // shader cycles per phase (ping-pong form)
+#define UZU_PP_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn = clock64(); tsum[i] += tn - tmark; tmark = tn; __builtin_amdgcn_sched_barrier(0); }
+#define UZU_FOLD_MARK(i) UZU_PP_MARK(i)
+#else
+#define UZU_PP_MARK(i)
+#define UZU_FOLD_MARK(i)
+#endif
     auto fold = [&]() { // acc_t += scale * acc_g at a group boundary
         f32x2_t sc[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = ((BITS == 4 && !kPairs) ? 16.0f : 1.0f) * bf16_to_f32(sc_cur[nb]);
+        for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = ((BITS == 4 && !kPairs) ? 16.0f : 1.0f) * bits_to_f32(sc_cur[nb] << 16);
         // In place on acc_t through inline asm: left to itself the register allocator writes the result over acc_g and
         // permutes the 16-register accumulator tuples around the loop (60-180 VGPRs of spills at the 256 budget).  The
         // hazard recogniser cannot see an MFMA -> VALU read through inline asm, so the wait for the last MFMA of the
         // group (at most 16 passes: 18 wait states) is spelled out.
         asm volatile("s_nop 15\n\ts_nop 3");
+        UZU_FOLD_MARK(6)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
+#if UZU_GEMM_FOLD_PK == 1
                     f32x2_t t = {acc_t[mb][nb][r], acc_t[mb][nb][r + 1]};
                     const f32x2_t g = {acc_g[mb][nb][r], acc_g[mb][nb][r + 1]};
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(sc[nb]), "v"(g));
                     acc_t[mb][nb][r] = t.x, acc_t[mb][nb][r + 1] = t.y;
+#else
+                    float t0 = acc_t[mb][nb][r], t1 = acc_t[mb][nb][r + 1];
+#if UZU_GEMM_FOLD_PK == 2
+                    asm volatile("v_fmac_f32_e32 %0, %2, %3\n\tv_fmac_f32_e32 %1, %2, %4" : "+v"(t0), "+v"(t1) : "v"(sc[nb].x), "v"(acc_g[mb][nb][r]), "v"(acc_g[mb][nb][r + 1]));
+#else
+                    asm volatile("v_fma_f32 %0, %2, %3, %0\n\tv_fma_f32 %1, %2, %4, %1" : "+v"(t0), "+v"(t1) : "v"(sc[nb].x), "v"(acc_g[mb][nb][r]), "v"(acc_g[mb][nb][r + 1]));
+#endif
+                    acc_t[mb][nb][r] = t0, acc_t[mb][nb][r + 1] = t1;
+#endif
                 }
         __builtin_amdgcn_sched_barrier(0); // the next group's first MFMA must not be hoisted above the fold (it would need a second acc_g)
+        UZU_FOLD_MARK(7)
     };
 
-    // ---- prologue: activation tile 0 -> LDS, tiles 1 .. DA -> registers, ring slots 0 .. DB-2, scales of groups 0 and 1
-    {
-        u32x4_v first[4];
-        load_a(0, first);
+    if constexpr (PP) {
+        // ---- ping-pong main loop.  Per half: C(kt) | barrier | M(kt) | barrier | C(kt + 1) ...; half 1 starts one phase late.
+        // B fragments: k16 steps 0 and 1 are converted in C(kt) and held across the barrier, steps 2 and 3 in the shadow of the MFMAs of steps
+        // 0 and 1 (a 32-cycle MFMA hides ~5 vector instructions of its own wave)
+        u32x4_t bfr[4][2];
+        auto convert = [&](const u32x4_v (&raw)[2][WV], int s) {
 #pragma unroll
-        for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
-#pragma unroll
-        for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
-        load_scale(0, sc_cur);
-        load_scale(1, sc_nxt);
-        stage_a(0, first);
-    }
-    lds_barrier();
-    ts[1] = wall_clock64();
-
-    for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t kt = kt0 + u;
-            load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
-            mfma_codes(kt, ring[u % DB], u % GS == 0);
-            stage_a(kt + 1, a_st[(u + 1) % DA]); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
-            load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
-            if ((u + 1) % GS == 0) {
-                fold();
-                sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
-                load_scale((kt + 1) / GS + 1, sc_nxt);
+            for (int nb = 0; nb < 2; ++nb) {
+                if (BITS == 4) bfr[s][nb] = kPairs ? dequant4_pairs(raw[nb][0][s] ^ flip) : dequant4(raw[nb][0][s] ^ flip);
+                else bfr[s][nb] = dequant8(raw[nb][s >> 1][(s & 1) * 2] ^ flip, raw[nb][s >> 1][(s & 1) * 2 + 1] ^ flip);
             }
+        };
+        auto mfma_phase = [&](uint32_t kt, bool first, const u32x4_v (&raw)[2][WV], u32x4_v (&ast)[NR]) {
+            const uint8_t* ab = a_frag_base + (kt & 1) * (BM * A_PITCH);
+            u32x4_t af[4][2];
+            auto reads = [&](int s) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) af[s][mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+            };
+            auto mfmas = [&](int s) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const f32x16_t zero = {};
+                        acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s][mb]), __builtin_bit_cast(bf16x8_t, bfr[s][nb]),
+                                                                               (first && s == 0) ? zero : acc_g[mb][nb], 0, 0, 0);
+                    }
+            };
+            // program order = the intended issue order; the sched_group_barriers below pin it (MFMA k16 step s | what runs in its shadow):
+            //   0 | convert step 2      1 | convert step 3      2 | this thread's part of tile kt + 1 -> the other LDS buffer      3 | request tile kt + 1 + DA
+            reads(0), reads(1);
+            mfmas(0);
+            convert(raw, 2);
+            reads(2);
+            mfmas(1);
+            convert(raw, 3);
+            reads(3);
+            mfmas(2);
+            stage_a(kt + 1, ast);
+            mfmas(3);
+            load_a(kt + 1 + DA, ast);
+            constexpr int CV = BITS == 4 ? (kPairs ? 5 : 8) : 6; // vector instructions of one step's conversion per MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, CV, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NR, 0); // v_perm
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, NR, 0); // ds_write
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NR, 0); // global loads
+        };
+        auto phase_barrier = [&]() { // nothing of a phase moves into the other half's turn on the pipe
+            __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        {
+            u32x4_v first[NR];
+            load_a(0, first);
+#pragma unroll
+            for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
+#pragma unroll
+            for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
+            load_scale(0, sc_cur);
+            load_scale(1, sc_nxt);
+            stage_a(0, first); // both halves, before the first barrier either of them passes
+        }
+        ts[1] = wall_clock64();
+        if (half) phase_barrier();
+#ifdef UZU_GEMM_PP_TIMING
+        tmark = clock64();
+#endif
+        for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t kt = kt0 + u;
+                // ---- C(kt)
+                if (u % GS == 0 && kt) { // the group that M(kt - 1) completed
+                    fold();
+                    sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
+                    load_scale(kt / GS + 1, sc_nxt);
+                }
+                UZU_PP_MARK(4)
+                load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
+                UZU_PP_MARK(5)
+                convert(ring[u % DB], 0);
+                convert(ring[u % DB], 1);
+                __builtin_amdgcn_sched_barrier(0);
+                UZU_PP_MARK(0)
+                phase_barrier();
+                UZU_PP_MARK(1)
+                // ---- M(kt)
+                mfma_phase(kt, u % GS == 0, ring[u % DB], a_st[(u + 1) % DA]);
+                __builtin_amdgcn_sched_barrier(0);
+                UZU_PP_MARK(2)
+                phase_barrier();
+                UZU_PP_MARK(3)
+            }
+        }
+#ifdef UZU_GEMM_PP_TIMING
+        if (dbg && lane == 0 && live) {
+            unsigned long long* o = dbg + ((size_t)65536 + (size_t)vblock * 4 + wave) * 8;
+            for (int i = 0; i < 4; ++i) o[i] = tsum[i];
+            o[4] = KTz, o[5] = half | tsum[4] << 8, o[6] = tsum[5], o[7] = tsum[6] | tsum[7] << 32;
+        }
+#endif
+        fold();
+    } else {
+        // ---- prologue: activation tile 0 -> LDS, tiles 1 .. DA -> registers, ring slots 0 .. DB-2, scales of groups 0 and 1
+        {
+            u32x4_v first[NR];
+            load_a(0, first);
+    #pragma unroll
+            for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
+    #pragma unroll
+            for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
+            load_scale(0, sc_cur);
+            load_scale(1, sc_nxt);
+            stage_a(0, first);
+        }
+        lds_barrier();
+        ts[1] = wall_clock64();
+
+        for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t kt = kt0 + u;
+                load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
+                mfma_codes(kt, ring[u % DB], u % GS == 0);
+                stage_a(kt + 1, a_st[(u + 1) % DA]); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
+                load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
+                if ((u + 1) % GS == 0) {
+                    fold();
+                    sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
+                    load_scale((kt + 1) / GS + 1, sc_nxt);
+                }
+                lds_barrier();
+            }
         }
     }
     ts[2] = wall_clock64();
@@ -329,7 +510,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
         // Common case, branch-free: bf16(ab_scale * acc + bias) goes to a wave-private LDS tile (64 rows x 64 columns,
         // 144-byte pitch; the activation buffers are free after the last barrier) and leaves as 16-byte row segments,
         // 8 lanes per 128-byte row -- instead of 64 two-byte stores per lane.
-        uint16_t* s_d = (uint16_t*)&s_a[0][0] + wave * (64 * 72);
+        uint16_t* s_d = (uint16_t*)s_ep + wave * (64 * 72);
         const float ab = p.ab_scale;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -352,7 +533,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
             // element is a dependent round trip with two waves to hide it)
             if (tid < 32) s_exp_tab[tid] = kExp2fTab[tid];
             __syncthreads();
-            const uint16_t* s_u = (const uint16_t*)&s_a[0][0] + (wm * 2) * (64 * 72);
+            const uint16_t* s_u = (const uint16_t*)s_ep + (wm * 2) * (64 * 72);
             const uint16_t* s_g = s_u + 64 * 72;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -365,7 +546,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
                     const float g0 = bits_to_f32(gv[w] << 16), g1 = bits_to_f32(gv[w] & 0xFFFF0000u);
                     ov[w] = pack_bf16(u0 * activate_bf16_tab(p.act_type, g0, s_exp_tab), u1 * activate_bf16_tab(p.act_type, g1, s_exp_tab));
                 }
-                if (m < M && n < H) *(u32x4_v*)(d + (size_t)m * H + n) = ov;
+                if (m < Mst && n < H) *(u32x4_v*)(d + (size_t)m * H + n) = ov;
             }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no workgroup barrier needed
@@ -373,7 +554,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
             for (int pass = 0; pass < 8; ++pass) {
                 const uint32_t lr = pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n0 + wn * 64 + seg * 8;
                 const u32x4_v v = *(const u32x4_v*)(s_d + lr * 72 + seg * 8);
-                if (m < M && n < N) *(u32x4_v*)(d + (size_t)m * N + n) = v;
+                if (m < Mst && n < N) *(u32x4_v*)(d + (size_t)m * N + n) = v;
             }
         }
     } else if (partials) { // split-K: raw f32 partial tile (32 lanes = one 128-byte row segment per store)
@@ -386,7 +567,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < M && n < N) pz[(size_t)m * N + n] = acc_t[mb][nb][r];
+                    if (m < Mst && n < N) pz[(size_t)m * N + n] = acc_t[mb][nb][r];
                 }
         }
     } else {
@@ -399,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m >= M || n >= N) continue;
+                    if (m >= Mst || n >= N) continue;
                     const size_t idx = (size_t)m * N + n;
                     const float acc = nb ? acc_t[mb][1][r] : acc_t[mb][0][r];
                     float value = p.ab_scale * acc;
@@ -411,9 +592,10 @@ __global__ void __launch_bounds__(256, 2) gemm_q_mfma128_kernel(MatmulParams p, 
                 }
         }
     }
-    if (dbg && tid == 0) {
+    if (PP && !half) lds_barrier(); // the partner half's last phase barrier (it runs one phase behind)
+    if (dbg && tid == 0 && live) {
         ts[3] = wall_clock64();
-        unsigned long long* o = dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        unsigned long long* o = dbg + (size_t)(blockIdx.y * gridDim.x * NH + vblock) * 8;
         for (int i = 0; i < 4; ++i) o[i] = ts[i];
         o[6] = (unsigned long long)m_t << 32 | n_t;
         o[7] = xcd;
@@ -452,6 +634,11 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
     for (uint32_t s = 2; s <= 4; ++s) // each split adds an f32 tile round trip: stop once the chip has a workgroup per CU
         if (ok(s) && tiles * best < (uint32_t)num_cus * 3 / 4 && tiles * s <= (uint32_t)num_cus * 2) best = s;
     return best;
+}
+// UZU_GEMM_PP=0 / 1: the 256-thread form / the ping-pong form (read per call: A/B runs and the bit-identity test flip it)
+static bool gemm128_ping_pong() {
+    const char* e = getenv("UZU_GEMM_PP");
+    return e ? atoi(e) != 0 : UZU_GEMM_PP_DEFAULT != 0;
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;
@@ -497,8 +684,11 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     const float* rowsum_in = p.pre_rowsum ? p.pre_rowsum : rowsum;
     const float* coef_in = p.pre_coef ? p.pre_coef : coef;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
-    const dim3 grid(gemm_grid_x(m_tiles, n_tiles), splits);
-#define UZU_LAUNCH(B, GSV) st = launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV>), grid, dim3(256), 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
+    const bool pp = gemm128_ping_pong();
+    const dim3 grid(pp ? gemm_grid_x(m_tiles, (n_tiles + 1) / 2) : gemm_grid_x(m_tiles, n_tiles), splits), block(pp ? 512 : 256);
+#define UZU_LAUNCH(B, GSV)                                                                                                                                            \
+    st = pp ? launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, true>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128pp") \
+            : launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, false>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
     const uint32_t gs = p.group_size / BK;
     if (p.bits == 4) {
         if (gs == 1) UZU_LAUNCH(4, 1);
