@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
                                      {4096, 14336, 4096, 128, 4, 0}, {4096, 28672, 4096, 128, 4, 1}, {4096, 4096, 14336, 128, 4, 0}, {4096, 6144, 4096, 128, 4, 0}, {4096, 4096, 4096, 128, 4, 0},
                                      {300, 520, 2048, 64, 4, 0}, {1000, 520, 2048, 256, 4, 0}, {4096, 14336, 4096, 64, 8, 0}, {2048, 7168, 1024, 128, 8, 1}};
         if (getenv("KB_GEMM_AB_SHORT")) shapes = {{2048, 7168, 1024, 128, 4, 1}, {2048, 1024, 3584, 128, 4, 0}, {4096, 14336, 4096, 128, 4, 0}, {4096, 4096, 14336, 128, 4, 0}};
+        if (getenv("KB_GEMM_AB_ONE")) shapes = {{4096, 14336, 4096, 128, 4, 0}};
         uint64_t rs = 0x9E3779B97F4A7C15ull;
         auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 32); };
         for (const Shape& sh : shapes) {

@@ -37,9 +37,6 @@ namespace {
 constexpr int BK = 64, BM = 128, BN = 128;
 constexpr int A_PITCH = 144;
 constexpr bool kPairs = UZU_GEMM_PAIR_DEQUANT != 0;
-#ifndef UZU_GEMM_PP_DEFAULT
-#define UZU_GEMM_PP_DEFAULT 0
-#endif
 #ifndef UZU_GEMM_PP_DB
 #define UZU_GEMM_PP_DB 4 // ping-pong form: weight ring depth
 #endif
@@ -48,6 +45,9 @@ constexpr bool kPairs = UZU_GEMM_PAIR_DEQUANT != 0;
 #endif
 #ifndef UZU_GEMM_FOLD_PK
 #define UZU_GEMM_FOLD_PK 0 // group fold with v_pk_fma_f32 (1) or pairs of v_fma_f32 (0)
+#endif
+#ifndef UZU_GEMM_PP_MSCHED
+#define UZU_GEMM_PP_MSCHED 2 // ping-pong form, MFMA phase: 0 = operands | 16 MFMAs | staging; 1 = staging interleaved with the MFMAs; 2 = staging first
 #endif
 #ifndef UZU_GEMM_PIPE
 #define UZU_GEMM_PIPE 1 // software-pipelined k16 steps (operands one step ahead of the MFMAs); 0 = operands right in front of them
@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float
 // PP ("ping-pong", round 5): ONE 512-thread workgroup per CU works on a 128 x 256 tile: two halves of four waves, each half the 128 x 128
 // tile of the 256-thread form (same k order, same fold -> bit-identical results) over ONE activation tile in LDS that all eight waves
 // stage (half the L2 -> L1 activation traffic of two independent workgroups).  Wave w and wave w + 4 share a SIMD.  A k-step is cut into
-// a CONVERT phase (weight codes of the step -> bf16 fragments in registers, the group fold, the weight prefetch: VALU / VMEM only) and an
-// MFMA phase (8 ds_read_b128 + 16 back-to-back v_mfma_f32_32x32x16_bf16, with the staging of the next activation tile -- 2 global loads,
+// a CONVERT phase (weight codes of the step -> bf16 fragments, ONCE per half: the two waves of a column pair split the work and share the
+// fragments through LDS; the group fold; the weight prefetch: VALU / VMEM / 4 ds_write only) and an
+// MFMA phase (16 ds_read_b128 + 16 back-to-back v_mfma_f32_32x32x16_bf16, with the staging of the next activation tile -- 2 global loads,
 // 8 v_perm, 2 ds_write per thread -- in their shadow); an s_barrier over all eight waves after every phase keeps the halves half a step
 // apart, so a SIMD always holds one wave that wants the matrix pipe and one that wants the vector ALU.
 template <int BITS, int GS, bool PP>
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
     constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
     constexpr int NH = PP ? 2 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_a_all[NH][2][BM * A_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[PP ? 2 : 1][PP ? 16384 : 16]; // PP: a half's converted weight fragments of one k-step
     __shared__ uint64_t s_exp_tab[32]; // gated epilogue only
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,12 +285,19 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
 #if defined(UZU_GEMM_PP_TIMING)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = 0; // shader cycles per phase (ping-pong form)
 #define UZU_PP_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn = clock64(); tsum[i] += tn - tmark; tmark = tn; __builtin_amdgcn_sched_barrier(0); }
+#if UZU_GEMM_PP_TIMING >= 2
 #define UZU_FOLD_MARK(i) UZU_PP_MARK(i)
+#define UZU_PP_MARK2(i) UZU_PP_MARK(i)
 #else
+#define UZU_FOLD_MARK(i)
+#define UZU_PP_MARK2(i)
+#endif
+#else
+#define UZU_PP_MARK2(i)
 #define UZU_PP_MARK(i)
 #define UZU_FOLD_MARK(i)
 #endif
-    auto fold = [&]() { // acc_t += scale * acc_g at a group boundary
+    auto fold = [&](bool hazard_wait = true) { // acc_t += scale * acc_g at a group boundary
         f32x2_t sc[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) sc[nb].x = sc[nb].y = ((BITS == 4 && !kPairs) ? 16.0f : 1.0f) * bits_to_f32(sc_cur[nb] << 16);
@@ -296,7 +305,7 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
         // permutes the 16-register accumulator tuples around the loop (60-180 VGPRs of spills at the 256 budget).  The
         // hazard recogniser cannot see an MFMA -> VALU read through inline asm, so the wait for the last MFMA of the
         // group (at most 16 passes: 18 wait states) is spelled out.
-        asm volatile("s_nop 15\n\ts_nop 3");
+        if (hazard_wait) asm volatile("s_nop 15\n\ts_nop 3");
         UZU_FOLD_MARK(6)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -325,22 +334,37 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
 
     if constexpr (PP) {
         // ---- ping-pong main loop.  Per half: C(kt) | barrier | M(kt) | barrier | C(kt + 1) ...; half 1 starts one phase late.
-        // B fragments: k16 steps 0 and 1 are converted in C(kt) and held across the barrier, steps 2 and 3 in the shadow of the MFMAs of steps
-        // 0 and 1 (a 32-cycle MFMA hides ~5 vector instructions of its own wave)
-        u32x4_t bfr[4][2];
-        auto convert = [&](const u32x4_v (&raw)[2][WV], int s) {
+        // Weight fragments through LDS, converted ONCE per half: the two waves that share 64 columns (wm = 0 / 1) each convert one of the two
+        // 32-column blocks (block wm: one 16-byte code vector per lane per k-step, 36 vector instructions instead of 72) and write the four
+        // bf16 fragments lane-aligned -- [wn][block][k16 step][lane] x 16 bytes, reader lane = writer lane, conflict-free both ways; the
+        // barrier that ends the phase publishes them, and every wave of the half reads the eight fragments of its columns in M(kt).
+        uint8_t* const s_bw = &s_b[half][((wn * 2 + wm) * 4) * 1024 + lane * 16];
+        const uint8_t* const s_br = &s_b[half][(wn * 2 * 4) * 1024 + lane * 16];
+        const uint32_t w_own = wm ? w_off[1] : w_off[0];
+        u32x4_v ringp[DB][WV];
+        auto load_w1 = [&](uint32_t kt, u32x4_v (&r)[WV]) {
+            kt = min(kt, KTz - 1);
+            const u32x4_v* src = (const u32x4_v*)(((const uint8_t*)p.b + (size_t)(kt_lo + kt) * BK * BITS / 8) + w_own);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                if (BITS == 4) bfr[s][nb] = kPairs ? dequant4_pairs(raw[nb][0][s] ^ flip) : dequant4(raw[nb][0][s] ^ flip);
-                else bfr[s][nb] = dequant8(raw[nb][s >> 1][(s & 1) * 2] ^ flip, raw[nb][s >> 1][(s & 1) * 2 + 1] ^ flip);
+            for (int v = 0; v < WV; ++v) r[v] = src[v];
+        };
+        auto convert_own = [&](const u32x4_v (&raw)[WV]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u32x4_t f;
+                if (BITS == 4) f = kPairs ? dequant4_pairs(raw[0][s] ^ flip) : dequant4(raw[0][s] ^ flip);
+                else f = dequant8(raw[s >> 1][(s & 1) * 2] ^ flip, raw[s >> 1][(s & 1) * 2 + 1] ^ flip);
+                *(u32x4_t*)(s_bw + s * 1024) = f;
             }
         };
-        auto mfma_phase = [&](uint32_t kt, bool first, const u32x4_v (&raw)[2][WV], u32x4_v (&ast)[NR]) {
+        auto mfma_phase = [&](uint32_t kt, bool first, u32x4_v (&ast)[NR]) {
             const uint8_t* ab = a_frag_base + (kt & 1) * (BM * A_PITCH);
-            u32x4_t af[4][2];
+            u32x4_t af[4][2], bf[4][2];
             auto reads = [&](int s) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) af[s][mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) bf[s][nb] = *(const u32x4_t*)(s_br + (nb * 4 + s) * 1024);
             };
             auto mfmas = [&](int s) {
 #pragma unroll
@@ -348,33 +372,60 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const f32x16_t zero = {};
-                        acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s][mb]), __builtin_bit_cast(bf16x8_t, bfr[s][nb]),
+                        acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s][mb]), __builtin_bit_cast(bf16x8_t, bf[s][nb]),
                                                                                (first && s == 0) ? zero : acc_g[mb][nb], 0, 0, 0);
                     }
             };
-            // program order = the intended issue order; the sched_group_barriers below pin it (MFMA k16 step s | what runs in its shadow):
-            //   0 | convert step 2      1 | convert step 3      2 | this thread's part of tile kt + 1 -> the other LDS buffer      3 | request tile kt + 1 + DA
+            // every operand request up front, sixteen MFMAs back to back (an instruction issued between two MFMAs delays the second by more than
+            // its own slot), then this thread's part of tile kt + 1 -> the other LDS buffer and the request for tile kt + 1 + DA while the pipe drains
+#if UZU_GEMM_PP_MSCHED == 2
+            // staging FIRST (its registers arrived k-steps ago): the LDS stores and the new requests are under way while the MFMAs run, and the
+            // lgkmcnt(0) that ends the phase finds them done -- behind the last MFMA their ~130-cycle drain is exposed
+            stage_a(kt + 1, ast);
+            load_a(kt + 1 + DA, ast);
             reads(0), reads(1);
             mfmas(0);
-            convert(raw, 2);
             reads(2);
             mfmas(1);
-            convert(raw, 3);
+            reads(3);
+            mfmas(2);
+            mfmas(3);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * NR, 0); // v_perm
+            __builtin_amdgcn_sched_group_barrier(0x200, NR, 0);     // ds_write
+            __builtin_amdgcn_sched_group_barrier(0x020, NR, 0);     // global loads
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#elif UZU_GEMM_PP_MSCHED == 0
+            reads(0), reads(1), reads(2), reads(3);
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(0), mfmas(1), mfmas(2), mfmas(3);
+            __builtin_amdgcn_s_setprio(0);
+            stage_a(kt + 1, ast);
+            load_a(kt + 1 + DA, ast);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * NR, 0); // v_perm
+            __builtin_amdgcn_sched_group_barrier(0x200, NR, 0);     // ds_write
+            __builtin_amdgcn_sched_group_barrier(0x020, NR, 0);     // global loads
+#else
+            reads(0), reads(1);
+            mfmas(0);
+            reads(2);
+            mfmas(1);
             reads(3);
             mfmas(2);
             stage_a(kt + 1, ast);
             mfmas(3);
             load_a(kt + 1 + DA, ast);
-            constexpr int CV = BITS == 4 ? (kPairs ? 5 : 8) : 6; // vector instructions of one step's conversion per MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, CV, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -384,6 +435,7 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
             __builtin_amdgcn_sched_group_barrier(0x200, NR, 0); // ds_write
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, NR, 0); // global loads
+#endif
         };
         auto phase_barrier = [&]() { // nothing of a phase moves into the other half's turn on the pipe
             __builtin_amdgcn_sched_barrier(0);
@@ -396,7 +448,7 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
 #pragma unroll
             for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
 #pragma unroll
-            for (int u = 0; u < DB - 1; ++u) load_w(u, ring[u]);
+            for (int u = 0; u < DB - 1; ++u) load_w1(u, ringp[u]);
             load_scale(0, sc_cur);
             load_scale(1, sc_nxt);
             stage_a(0, first); // both halves, before the first barrier either of them passes
@@ -411,22 +463,24 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
             for (int u = 0; u < U; ++u) {
                 const uint32_t kt = kt0 + u;
                 // ---- C(kt)
+                // fragments first, fold last: the four LDS stores drain under the fold's FMAs instead of in front of the barrier, and the
+                // conversion's ~40 instructions are the MFMA -> VALU hazard distance the fold would otherwise idle through
+                load_w1(kt + DB - 1, ringp[(u + DB - 1) % DB]);
+                UZU_PP_MARK2(5)
+                convert_own(ringp[u % DB]);
+                __builtin_amdgcn_sched_barrier(0);
                 if (u % GS == 0 && kt) { // the group that M(kt - 1) completed
-                    fold();
+                    fold(false);
                     sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
                     load_scale(kt / GS + 1, sc_nxt);
                 }
-                UZU_PP_MARK(4)
-                load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
-                UZU_PP_MARK(5)
-                convert(ring[u % DB], 0);
-                convert(ring[u % DB], 1);
+                UZU_PP_MARK2(4)
                 __builtin_amdgcn_sched_barrier(0);
                 UZU_PP_MARK(0)
                 phase_barrier();
                 UZU_PP_MARK(1)
                 // ---- M(kt)
-                mfma_phase(kt, u % GS == 0, ring[u % DB], a_st[(u + 1) % DA]);
+                mfma_phase(kt, u % GS == 0, a_st[(u + 1) % DA]);
                 __builtin_amdgcn_sched_barrier(0);
                 UZU_PP_MARK(2)
                 phase_barrier();
@@ -635,10 +689,14 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
         if (ok(s) && tiles * best < (uint32_t)num_cus * 3 / 4 && tiles * s <= (uint32_t)num_cus * 2) best = s;
     return best;
 }
-// UZU_GEMM_PP=0 / 1: the 256-thread form / the ping-pong form (read per call: A/B runs and the bit-identity test flip it)
-static bool gemm128_ping_pong() {
-    const char* e = getenv("UZU_GEMM_PP");
-    return e ? atoi(e) != 0 : UZU_GEMM_PP_DEFAULT != 0;
+// The ping-pong form where it measured faster than the 256-thread form (tools/kbench KB_GEMM_AB, same box, profiles/r5_gemm_pp_ab.txt: x1.05-1.16):
+// long reductions (>= 48 k-steps: its one workgroup per CU has no second workgroup whose main loop would cover its prologue / epilogue),
+// at least one 128 x 256 tile per CU, no split-K, no gated epilogue (x0.95: both halves reach the heavy act-mul epilogue at the same time).
+// UZU_GEMM_PP=0 / 1 forces the choice (read per call: A/B runs and the bit-identity test flip it).
+static bool gemm128_ping_pong(const MatmulParams& p, int num_cus, uint32_t splits) {
+    if (const char* e = getenv("UZU_GEMM_PP")) return atoi(e) != 0;
+    const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
+    return !p.act_mul && splits == 1 && p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus;
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;
@@ -684,7 +742,7 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     const float* rowsum_in = p.pre_rowsum ? p.pre_rowsum : rowsum;
     const float* coef_in = p.pre_coef ? p.pre_coef : coef;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
-    const bool pp = gemm128_ping_pong();
+    const bool pp = gemm128_ping_pong(p, num_cus, splits);
     const dim3 grid(pp ? gemm_grid_x(m_tiles, (n_tiles + 1) / 2) : gemm_grid_x(m_tiles, n_tiles), splits), block(pp ? 512 : 256);
 #define UZU_LAUNCH(B, GSV)                                                                                                                                            \
     st = pp ? launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, true>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128pp") \
