@@ -214,17 +214,19 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
 @pytest.mark.parametrize("bits,method,group_size,n,k,m", [(4, 0, 128, 520, 2048, 300), (4, 1, 64, 1160, 1024, 1000), (4, 2, 256, 264, 1024, 131),
                                                           (8, 0, 128, 520, 1024, 300), (8, 1, 64, 392, 512, 257)])
 @pytest.mark.parametrize("splits", ["1", "2"])
-def test_gemm_ping_pong_form_is_bit_identical_to_the_256_thread_form(hip_ctx, bits, method, group_size, n, k, m, splits, monkeypatch):
-    """UZU_GEMM_PP=1 (k_gemm128.hip, PP instantiation): two 128 x 128 tiles per 512-thread workgroup, convert / MFMA phases half a k-step
-    apart.  A half runs the 256-thread form's arithmetic in the same order, so the outputs are equal byte for byte -- ragged M / N,
-    an odd tile count (one half idle), split-K -- and both hold the oracle tolerance."""
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_gemm_512_thread_forms_are_bit_identical_to_the_256_thread_form(hip_ctx, bits, method, group_size, n, k, m, splits, form, monkeypatch):
+    """UZU_GEMM_FORM=1 (k_gemm128.hip, ping-pong: a 128 x 256 tile per 512-thread workgroup, convert / MFMA phases half a k-step apart) and
+    UZU_GEMM_FORM=2 (wave-specialised: four consumer waves on the matrix cores, four producer waves converting / staging).  Both run the
+    256-thread form's arithmetic in the same order, so the outputs are equal byte for byte -- ragged M / N, an odd tile count (one half
+    idle), split-K -- and hold the oracle tolerance."""
     monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
     rng = np.random.default_rng(bits * 1000 + method * 100 + group_size + m)
     q = quant_matrix(rng, n, k, bits, group_size, method)
     a = activations(rng, m, k)
-    monkeypatch.setenv("UZU_GEMM_PP", "0")
+    monkeypatch.setenv("UZU_GEMM_FORM", "0")
     base = hip_matmul(hip_ctx, a, q, m)
-    monkeypatch.setenv("UZU_GEMM_PP", "1")
+    monkeypatch.setenv("UZU_GEMM_FORM", form)
     got = hip_matmul(hip_ctx, a, q, m)
     assert np.array_equal(base, got)
     want = oracle_matmul(a, q, m)

@@ -75,6 +75,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(w, hw.data(), wb, hipMemcpyHostToDevice)); CK(hipMemcpy(sc, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
             CK(hipMemcpy(bi, hb.data(), hb.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
             const size_t on = (size_t)m * (sh.gated ? n / 2 : n);
+            const int alt = getenv("KB_GEMM_FORM") ? atoi(getenv("KB_GEMM_FORM")) : 1; // the form compared with the 256-thread one
             uint16_t* out[2] = {dalloc<uint16_t>(on, 0), dalloc<uint16_t>(on, 0)};
             MatmulParams p{}; p.a = x, p.b = w, p.scales = sc, p.biases = bi; p.w_dt = p.a_dt = p.d_dt = UZU_BF16; p.b_kind = UZU_MATMUL_B_SCALE_BIAS;
             p.bits = sh.bits, p.group_size = g, p.ab_scale = 1.f, p.m = m, p.n = n, p.k = k; p.act_mul = sh.gated; p.act_type = 0;
@@ -82,8 +83,8 @@ int main(int argc, char** argv) {
             void* gemm_ws = dalloc<uint8_t>(gemm_q_mfma128_workspace_bytes(p, cus) + 65536);
             double us[2];
             for (int pp = 0; pp < 2; ++pp) {
-                setenv("UZU_GEMM_PP", pp ? "1" : "0", 1);
-                char name[96]; snprintf(name, sizeof name, "gemm %ux%ux%u g%u int%u%s %s", m, n, k, g, sh.bits, sh.gated ? " +act" : "", pp ? "ping-pong" : "256-thread");
+                setenv("UZU_GEMM_FORM", pp ? (alt == 2 ? "2" : "1") : "0", 1);
+                char name[96]; snprintf(name, sizeof name, "gemm %ux%ux%u g%u int%u%s %s", m, n, k, g, sh.bits, sh.gated ? " +act" : "", pp ? (alt == 2 ? "wave-spec" : "ping-pong") : "256-thread");
                 p.d = out[pp];
                 us[pp] = time_graph(name, wb + (size_t)m * k * 2 + on * 2, 8, [&](int) { return gemm_q_mfma128(s, p, cus, gemm_ws); });
             }
@@ -92,7 +93,7 @@ int main(int argc, char** argv) {
             size_t diff = 0, nz = 0; for (size_t i = 0; i < on; ++i) diff += h0[i] != h1[i], nz += (h0[i] & 0x7fff) != 0;
             printf("    -> %.1f vs %.1f TFLOP/s (x%.3f); outputs differing: %zu of %zu (%zu non-zero)\n", 2.0 * m * n * k / us[0] / 1e6, 2.0 * m * n * k / us[1] / 1e6, us[0] / us[1], diff, on, nz);
             if (getenv("KB_GEMM_PP_TIMING")) { // a library built with -DUZU_GEMM_PP_TIMING: mean shader cycles per k-step and wave in each phase
-                const size_t slots = 65536 * 5;
+                const size_t slots = 65536 * 9;
                 unsigned long long* d = dalloc<unsigned long long>(slots * 8, 0);
                 uzu::k::g_gemm128_dbg = d; p.d = out[1];
                 gemm_q_mfma128(s, p, cus, gemm_ws); CK(hipStreamSynchronize(s));
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
                 double sum[2][8] = {}; double steps[2] = {0, 0};
                 for (size_t i = 65536; i < slots; ++i) { const unsigned long long* o = &h[i * 8]; if (!o[4]) continue; const int hf = (int)o[5] & 1; steps[hf] += (double)o[4]; for (int q = 0; q < 4; ++q) sum[hf][q] += (double)o[q]; sum[hf][4] += (double)(o[5] >> 8), sum[hf][5] += (double)o[6], sum[hf][6] += (double)(o[7] & 0xffffffffull), sum[hf][7] += (double)(o[7] >> 32); }
                 for (int hf = 0; hf < 2; ++hf) if (steps[hf] > 0)
-                    printf("    timing half %d: per k-step cycles  convert %.0f  barrier %.0f  mfma %.0f  barrier %.0f\n", hf, sum[hf][0] / steps[hf], sum[hf][1] / steps[hf], sum[hf][2] / steps[hf], sum[hf][3] / steps[hf]),
+                    printf(alt == 2 ? "    timing %d (0 = consumers: [2] work [3] barrier; 1 = producers: [0] work [1] barrier): per k-step cycles  %.0f  %.0f  %.0f  %.0f\n" : "    timing half %d: per k-step cycles  convert %.0f  barrier %.0f  mfma %.0f  barrier %.0f\n", hf, sum[hf][0] / steps[hf], sum[hf][1] / steps[hf], sum[hf][2] / steps[hf], sum[hf][3] / steps[hf]),
                     printf("        convert phase: fold: entry + hazard wait %.0f  FMAs %.0f  scales %.0f;  weight loads %.0f  convert %.0f\n", sum[hf][6] / steps[hf], sum[hf][7] / steps[hf], sum[hf][4] / steps[hf], sum[hf][5] / steps[hf], sum[hf][0] / steps[hf]);
                 CK(hipFree(d));
             }

@@ -120,21 +120,30 @@ __global__ void __launch_bounds__(256) gemm_prepass_kernel(MatmulParams p, float
 // MFMA phase (16 ds_read_b128 + 16 back-to-back v_mfma_f32_32x32x16_bf16, with the staging of the next activation tile -- 2 global loads,
 // 8 v_perm, 2 ds_write per thread -- in their shadow); an s_barrier over all eight waves after every phase keeps the halves half a step
 // apart, so a SIMD always holds one wave that wants the matrix pipe and one that wants the vector ALU.
-template <int BITS, int GS, bool PP>
-__global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_kernel(MatmulParams p, const float* rowsum, const float* coef, float* partials, unsigned long long* dbg) {
+//
+// WS ("wave-specialised", MODE 2): ONE 512-thread workgroup per CU on a 128 x 128 tile.  Waves 0-3 are CONSUMERS (the 2 x 2 wave tiles of the
+// 256-thread form: nothing but ds_read_b128 + MFMA + the group fold; every operand, weights included, comes out of LDS), waves 4-7 -- the
+// second wave of each SIMD -- are PRODUCERS: they stage the activation tile of the NEXT k-step and convert its weight codes (one 32-column
+// block per wave, once per workgroup) into the other LDS stage while the consumers work on this one; one s_barrier per k-step swaps the
+// stages.  The matrix pipe of a SIMD belongs to one wave that never converts; the vector ALU work runs beside it in a wave that never
+// multiplies.  Same k order and fold as the other forms -> bit-identical results.
+template <int BITS, int GS, int MODE>
+__global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128_kernel(MatmulParams p, const float* rowsum, const float* coef, float* partials, unsigned long long* dbg) {
+    constexpr bool PP = MODE == 1, WS = MODE == 2;
     constexpr int WV = BITS / 4;           // 16-byte code vectors per lane per 32-column block per k-step
     constexpr int DB = BITS == 8 ? 2 : PP ? UZU_GEMM_PP_DB : 4;  // weight ring depth (k-steps in flight + 1)
     constexpr int DA = PP ? UZU_GEMM_PP_DA : 2;                  // activation register stages
     constexpr int U = 4;                   // unroll: a multiple of DB, DA, 2 (LDS buffers) and GS
-    constexpr int NH = PP ? 2 : 1;
+    constexpr int NH = MODE ? 2 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_a_all[NH][2][BM * A_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[PP ? 2 : 1][PP ? 16384 : 16]; // PP: a half's converted weight fragments of one k-step
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[MODE ? 2 : 1][MODE ? 16384 : 16]; // PP: a half's converted weight fragments of one k-step; WS: the two stages
     __shared__ uint64_t s_exp_tab[32]; // gated epilogue only
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
     uint8_t(*const s_a)[BM * A_PITCH] = s_a_all[0];                       // activation tiles of the main loop (PP: shared by the halves)
-    uint8_t* const s_ep = &s_a_all[PP ? half ^ 1 : 0][0][0];                // epilogue staging (PP: half 0 finishes first and must not touch the tiles half 1 still reads)
+    const bool producer = WS && threadIdx.x >= 256;
+    uint8_t* const s_ep = &s_a_all[PP ? half ^ 1 : WS ? 1 : 0][0][0];                // epilogue staging (PP: half 0 finishes first and must not touch the tiles half 1 still reads)
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, c = lane & 31;
     const uint32_t M = p.m, N = p.n, K = p.k;
     // GatedActMul fused into the epilogue (p.act_mul; the up projection's rows [0, N/2) = up, [N/2, N) = gate, gated_act_mul.rs:52-58):
@@ -332,7 +341,127 @@ __global__ void __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) gemm_q_mfma128_ker
         UZU_FOLD_MARK(7)
     };
 
-    if constexpr (PP) {
+    if constexpr (WS) {
+        auto step_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (producer) {
+            // ---- producers: wave pw owns the 32-column block pw of the tile (block = wn * 2 + nb of the consumers' numbering)
+            const int pw = wave, pwn = pw >> 1, pnb = pw & 1;
+            const uint32_t pcol = gated ? (pwn ? H : 0u) + min(n_t * 64 + pnb * 32 + c, H - 1) : min(n0 + pwn * 64 + pnb * 32 + c, N - 1);
+            const uint32_t w_own = pcol * row_bytes + (32 * h) * BITS / 8;
+            u32x4_v ringp[DB][WV];
+            auto load_w1 = [&](uint32_t kt, u32x4_v (&r)[WV]) {
+                kt = min(kt, KTz - 1);
+                const u32x4_v* src = (const u32x4_v*)(((const uint8_t*)p.b + (size_t)(kt_lo + kt) * BK * BITS / 8) + w_own);
+#pragma unroll
+                for (int v = 0; v < WV; ++v) r[v] = src[v];
+            };
+            auto convert_to = [&](uint32_t kt, const u32x4_v (&raw)[WV]) { // fragments of k-step kt -> stage kt & 1, [block][k16 step][lane]
+                uint8_t* dst = &s_b[kt & 1][(pw * 4) * 1024 + lane * 16];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    u32x4_t f;
+                    if (BITS == 4) f = kPairs ? dequant4_pairs(raw[0][s] ^ flip) : dequant4(raw[0][s] ^ flip);
+                    else f = dequant8(raw[s >> 1][(s & 1) * 2] ^ flip, raw[s >> 1][(s & 1) * 2 + 1] ^ flip);
+                    *(u32x4_t*)(dst + s * 1024) = f;
+                }
+            };
+            {
+                u32x4_v first[NR];
+                load_a(0, first);
+#pragma unroll
+                for (int u = 1; u <= DA; ++u) load_a(u, a_st[u % DA]); // slot (kt + 1) % DA holds tile kt + 1
+#pragma unroll
+                for (int u = 0; u < DB; ++u) load_w1(u, ringp[u]);
+                stage_a(0, first);
+                convert_to(0, ringp[0]);
+                load_w1(DB, ringp[0]);
+            }
+            step_barrier(); // stage 0 is complete
+#ifdef UZU_GEMM_PP_TIMING
+            tmark = clock64();
+#endif
+            for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { // while the consumers run k-step kt out of stage kt & 1: k-step kt + 1 -> the other stage
+                    const uint32_t kt = kt0 + u;
+                    stage_a(kt + 1, a_st[(u + 1) % DA]);
+                    load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
+                    convert_to(kt + 1, ringp[(u + 1) % DB]);
+                    load_w1(kt + 1 + DB, ringp[(u + 1) % DB]);
+                    UZU_PP_MARK(0)
+                    step_barrier();
+                    UZU_PP_MARK(1)
+                }
+            }
+#ifdef UZU_GEMM_PP_TIMING
+            if (dbg && lane == 0 && live) {
+                unsigned long long* o = dbg + ((size_t)65536 + (size_t)vblock * 8 + 4 + wave) * 8;
+                for (int i = 0; i < 4; ++i) o[i] = tsum[i];
+                o[4] = KTz, o[5] = 1, o[6] = 0, o[7] = 0;
+            }
+#endif
+            if (gated) __syncthreads(); // the consumers' act-mul epilogue has one workgroup barrier
+            return;
+        }
+        // ---- consumers
+        const uint8_t* const s_br = &s_b[0][(wn * 2 * 4) * 1024 + lane * 16];
+        load_scale(0, sc_cur);
+        load_scale(1, sc_nxt);
+        ts[1] = wall_clock64();
+        step_barrier();
+#ifdef UZU_GEMM_PP_TIMING
+        tmark = clock64();
+#endif
+        for (uint32_t kt0 = 0; kt0 < KTz; kt0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t kt = kt0 + u;
+                const uint8_t* ab = a_frag_base + (kt & 1) * (BM * A_PITCH);
+                const uint8_t* bb = s_br + (kt & 1) * 16384;
+                u32x4_t af[4][2], bf[4][2];
+                auto reads = [&](int s) {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) af[s][mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) bf[s][nb] = *(const u32x4_t*)(bb + (nb * 4 + s) * 1024);
+                };
+                auto mfmas = [&](int s) {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const f32x16_t zero = {};
+                            acc_g[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s][mb]), __builtin_bit_cast(bf16x8_t, bf[s][nb]),
+                                                                                   (u % GS == 0 && s == 0) ? zero : acc_g[mb][nb], 0, 0, 0);
+                        }
+                };
+                reads(0), reads(1), reads(2), reads(3);
+                mfmas(0), mfmas(1), mfmas(2), mfmas(3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_barrier(0); // the fold's inline-asm FMAs must not be scheduled between the MFMAs (the hazard wait sits at its head)
+                if ((u + 1) % GS == 0) {
+                    fold();
+                    sc_cur[0] = sc_nxt[0], sc_cur[1] = sc_nxt[1];
+                    load_scale((kt + 1) / GS + 1, sc_nxt);
+                }
+                UZU_PP_MARK(2)
+                step_barrier();
+                UZU_PP_MARK(3)
+            }
+        }
+#ifdef UZU_GEMM_PP_TIMING
+        if (dbg && lane == 0 && live) {
+            unsigned long long* o = dbg + ((size_t)65536 + (size_t)vblock * 8 + wave) * 8;
+            for (int i = 0; i < 4; ++i) o[i] = tsum[i];
+            o[4] = KTz, o[5] = 0, o[6] = 0, o[7] = 0;
+        }
+#endif
+    } else if constexpr (PP) {
         // ---- ping-pong main loop.  Per half: C(kt) | barrier | M(kt) | barrier | C(kt + 1) ...; half 1 starts one phase late.
         // Weight fragments through LDS, converted ONCE per half: the two waves that share 64 columns (wm = 0 / 1) each convert one of the two
         // 32-column blocks (block wm: one 16-byte code vector per lane per k-step, 36 vector instructions instead of 72) and write the four
@@ -689,14 +818,14 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
         if (ok(s) && tiles * best < (uint32_t)num_cus * 3 / 4 && tiles * s <= (uint32_t)num_cus * 2) best = s;
     return best;
 }
-// The ping-pong form where it measured faster than the 256-thread form (tools/kbench KB_GEMM_AB, same box, profiles/r5_gemm_pp_ab.txt: x1.05-1.16):
-// long reductions (>= 48 k-steps: its one workgroup per CU has no second workgroup whose main loop would cover its prologue / epilogue),
-// at least one 128 x 256 tile per CU, no split-K, no gated epilogue (x0.95: both halves reach the heavy act-mul epilogue at the same time).
-// UZU_GEMM_PP=0 / 1 forces the choice (read per call: A/B runs and the bit-identity test flip it).
-static bool gemm128_ping_pong(const MatmulParams& p, int num_cus, uint32_t splits) {
-    if (const char* e = getenv("UZU_GEMM_PP")) return atoi(e) != 0;
+// Which form runs (0 = 256-thread, 1 = ping-pong, 2 = wave-specialised).  UZU_GEMM_FORM forces one (read per call: A/B runs and the bit-identity
+// test flip it); otherwise the plan: the ping-pong form where it measured faster than the 256-thread form (tools/kbench KB_GEMM_AB, same box,
+// profiles/r5_gemm_pp_ab.txt: x1.05-1.16) -- long reductions (>= 48 k-steps: its one workgroup per CU has no second workgroup whose main loop
+// would cover its prologue / epilogue), at least one 128 x 256 tile per CU, no split-K, no gated epilogue.
+static int gemm128_form(const MatmulParams& p, int num_cus, uint32_t splits) {
+    if (const char* e = getenv("UZU_GEMM_FORM")) return atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
-    return !p.act_mul && splits == 1 && p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus;
+    return (!p.act_mul && splits == 1 && p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus) ? 1 : 0;
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;
@@ -742,11 +871,12 @@ uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, voi
     const float* rowsum_in = p.pre_rowsum ? p.pre_rowsum : rowsum;
     const float* coef_in = p.pre_coef ? p.pre_coef : coef;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
-    const bool pp = gemm128_ping_pong(p, num_cus, splits);
-    const dim3 grid(pp ? gemm_grid_x(m_tiles, (n_tiles + 1) / 2) : gemm_grid_x(m_tiles, n_tiles), splits), block(pp ? 512 : 256);
+    const int form = gemm128_form(p, num_cus, splits);
+    const dim3 grid(form == 1 ? gemm_grid_x(m_tiles, (n_tiles + 1) / 2) : gemm_grid_x(m_tiles, n_tiles), splits), block(form ? 512 : 256);
 #define UZU_LAUNCH(B, GSV)                                                                                                                                            \
-    st = pp ? launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, true>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128pp") \
-            : launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, false>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
+    st = form == 2 ? launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, 2>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128ws") \
+       : form == 1 ? launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, 1>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128pp") \
+                   : launch_check([&] { hipLaunchKernelGGL((gemm_q_mfma128_kernel<B, GSV, 0>), grid, block, 0, s, p, rowsum_in, coef_in, partials, g_gemm128_dbg); }, "gemm_q_mfma128")
     const uint32_t gs = p.group_size / BK;
     if (p.bits == 4) {
         if (gs == 1) UZU_LAUNCH(4, 1);
