@@ -819,13 +819,17 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
     return best;
 }
 // Which form runs (0 = 256-thread, 1 = ping-pong, 2 = wave-specialised).  UZU_GEMM_FORM forces one (read per call: A/B runs and the bit-identity
-// test flip it); otherwise the plan: the ping-pong form where it measured faster than the 256-thread form (tools/kbench KB_GEMM_AB, same box,
-// profiles/r5_gemm_pp_ab.txt: x1.05-1.16) -- long reductions (>= 48 k-steps: its one workgroup per CU has no second workgroup whose main loop
-// would cover its prologue / epilogue), at least one 128 x 256 tile per CU, no split-K, no gated epilogue.
+// test flip it); otherwise the plan, from same-box A/B runs of all three (tools/kbench KB_GEMM_AB, profiles/r5_gemm_pp_ab.txt):
+//   * ping-pong (x1.05-1.16): long reductions (>= 48 k-steps: its one workgroup per CU has no second workgroup whose main loop would cover its
+//     prologue / epilogue), at least one 128 x 256 tile per CU, no split-K, no gated epilogue;
+//   * wave-specialised (x1.02-1.05): the few-tile split-K shapes (N = 1024 projections of the 0.8B model);
+//   * the 256-thread form everywhere else (gated epilogues, short reductions with many tiles: x0.6-0.9 for the other two).
 static int gemm128_form(const MatmulParams& p, int num_cus, uint32_t splits) {
     if (const char* e = getenv("UZU_GEMM_FORM")) return atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
+    if (p.act_mul) return 0;
+    if (splits > 1) return 2;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
-    return (!p.act_mul && splits == 1 && p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus) ? 1 : 0;
+    return (p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus) ? 1 : 0;
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;
