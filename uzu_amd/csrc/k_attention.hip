@@ -249,9 +249,12 @@ __global__ void __launch_bounds__(256) attention_two_pass2_kernel(const float* p
     for (int b = 0; b < 32; ++b) global_max = fmaxf(global_max, mx[b]);
     float global_sum = 0.f;
     float w[32];
+    // lane b evaluates the weight of block b ONCE (the libm-exact exp is ~150 double-precision operations; every lane used to evaluate all 32) and the
+    // wave reads it from there: same values, same summation order
+    const float w_mine = expf_glibc(mx[lane & 31] - global_max);
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
-        w[b] = expf_glibc(mx[b] - global_max);
+        w[b] = __shfl(w_mine, b, 64);
         global_sum += sm[b] * w[b];
     }
     for (uint32_t j = lane; j < HD; j += 64) {

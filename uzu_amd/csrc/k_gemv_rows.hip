@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t gr_smem[];
     const uint32_t K = p.k, pitch = K * 2 + 16; // bytes per activation row in LDS (+16: rows start 4 banks apart)
     uint8_t* xs = gr_smem;                      // [16][pitch]
-    float* s_part = (float*)(gr_smem + 16 * pitch); // [NW][NB][16 rows][16 tokens]
+    float* s_part = (float*)(gr_smem + (NORM ? 16 * pitch : 0)); // [NW][NB][16 rows][16 tokens]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t r = lane & 15, g = lane >> 4;
     const uint32_t row0 = blockIdx.x * 16;
@@ -69,10 +69,16 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
     const uint8_t* wp = p.w + (size_t)wrow * (K / 2) + 16 * g;
     // rows whose scale / offset this lane-group folds: 4 g + (lane % 4) (lanes 0..3 of the row carry them, the rest duplicate)
     const uint32_t frow = min(row0 + 4 * g + (r & 3), out_n - 1);
+    // !NORM: the activation chunks go straight from the L2 into the lanes that feed them to the matrix core (lane (r, g): token r, k0 + 32 g + 8 i,
+    // four 16-byte loads per step riding in the same prefetch slot as the codes).  The waves of a workgroup split K, so a staged copy in LDS has no
+    // second reader inside the workgroup -- staging it first cost every one of the hundreds of workgroups a 32-112 KB copy and a barrier in front of
+    // its first MFMA.  Same chunks, same k order, same MFMAs: bit-identical to the staged form (which the Normalization prologue keeps).
     struct Step {
         uint4 codes[NB];
         uint16_t sc[NB], of[NB];
+        gr_u32x4 xv[NORM ? 1 : 4];
     };
+    const uint16_t* xrow = p.a + (size_t)min(r, p.m - 1) * K + 32 * g; // rows >= m: a clamped row, zeroed before use
     auto load_step = [&](uint32_t s, Step& st) {
         const uint32_t sc_ = min(s, steps - 1); // past the end: a reload that is never consumed (keeps the loads countable)
         const uint32_t grp = (sc_ * 128) >> gshift;
@@ -86,6 +92,10 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
                 const uint8_t z = p.zp[fr * zp_stride + (grp >> 1)];
                 st.of[b] = (grp & 1) ? (z >> 4) : (z & 0x0F);
             } else st.of[b] = 0;
+        }
+        if constexpr (!NORM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.xv[i] = *(const gr_u32x4*)(xrow + (size_t)sc_ * 128 + 8 * i);
         }
     };
     (void)wp;
@@ -168,22 +178,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
             const uint32_t j = p.m + idx / chunks_per_row, c = idx % chunks_per_row;
             *(gr_u32x4*)(xs + (size_t)j * pitch + (size_t)c * 16) = gr_u32x4{0u, 0u, 0u, 0u};
         }
-    } else {
-        const uint32_t chunks_per_row = K / 8, total = 16 * chunks_per_row;
-        for (uint32_t idx = tid; idx < total; idx += 64 * NW) {
-            const uint32_t j = idx / chunks_per_row, c = idx % chunks_per_row;
-            gr_u32x4 o = {0u, 0u, 0u, 0u};
-            if (j < p.m) {
-                const gr_u32x4 u = *(const gr_u32x4*)(p.a + (size_t)j * K + (size_t)c * 8); // (x0,x1) (x2,x3) (x4,x5) (x6,x7)
-                o.x = __builtin_amdgcn_perm(u.z, u.x, 0x05040100u); // (x0, x4)
-                o.y = __builtin_amdgcn_perm(u.z, u.x, 0x07060302u); // (x1, x5)
-                o.z = __builtin_amdgcn_perm(u.w, u.y, 0x05040100u); // (x2, x6)
-                o.w = __builtin_amdgcn_perm(u.w, u.y, 0x07060302u); // (x3, x7)
-            }
-            *(gr_u32x4*)(xs + (size_t)j * pitch + (size_t)c * 16) = o;
-        }
+        lds_barrier();
     }
-    lds_barrier();
     uint32_t mask = 0x00780078u, magic = 0x41804180u, ones = 0x3F803F80u;
     asm("" : "+s"(mask));
     asm("" : "+v"(magic));
@@ -200,7 +196,15 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
         const uint8_t* xb = xlane + (size_t)s * 256;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const gr_u32x4 bv = *(const gr_u32x4*)(xb + 16 * i);
+            gr_u32x4 bv;
+            if constexpr (NORM) {
+                bv = *(const gr_u32x4*)(xb + 16 * i);
+            } else { // (x0,x1) (x2,x3) (x4,x5) (x6,x7) -> the conversion's k order (x0,x4) (x1,x5) (x2,x6) (x3,x7); rows >= m are zero
+                const gr_u32x4 u = st.xv[i];
+                bv.x = __builtin_amdgcn_perm(u.z, u.x, 0x05040100u), bv.y = __builtin_amdgcn_perm(u.z, u.x, 0x07060302u);
+                bv.z = __builtin_amdgcn_perm(u.w, u.y, 0x05040100u), bv.w = __builtin_amdgcn_perm(u.w, u.y, 0x07060302u);
+                if (r >= p.m) bv = gr_u32x4{0u, 0u, 0u, 0u};
+            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const uint32_t w = i == 0 ? st.codes[b].x : i == 1 ? st.codes[b].y : i == 2 ? st.codes[b].z : st.codes[b].w;
@@ -276,12 +280,14 @@ bool gemv_rows_mfma_supported(const MatmulParams& p) {
     if (p.act_mul && ((p.n & 1) || p.d_dt != UZU_BF16)) return false; // GatedActMul epilogue: [up | gate] halves, bf16 out
     if (p.k % 128 || p.group_size % 128 || (p.group_size & (p.group_size - 1)) || p.k % p.group_size) return false;
     if ((uintptr_t)p.a % 16 || (uintptr_t)p.b % 16) return false;
-    if ((size_t)16 * (p.k * 2 + 16) + 8 * 256 * 4 > 150 * 1024) return false; // the staged activations must fit the CU's LDS
     return true;
 }
 
 // the Normalization prologue needs whole 4-element vectors per thread of the 256-thread mapping (k % 1024 == 0) on top of the kernel's own conditions
-bool gemv_rows_norm_supported(const MatmulParams& p) { return gemv_rows_mfma_supported(p) && p.k % 1024 == 0 && p.k <= 16384; }
+// and the rows it stages must fit the CU's LDS
+bool gemv_rows_norm_supported(const MatmulParams& p) {
+    return gemv_rows_mfma_supported(p) && p.k % 1024 == 0 && (size_t)16 * (p.k * 2 + 16) + 8 * 256 * 4 <= 150 * 1024;
+}
 
 template <int NW, bool ACT, bool NORM> static uzu_status launch_rows(hipStream_t s, const RowsParams& q, uint32_t blocks, size_t lds) {
     static LdsLimit lim;
@@ -309,7 +315,7 @@ uzu_status gemv_rows_mfma(hipStream_t s, const MatmulParams& p, const RowsNorm* 
     // eight waves split K where the row blocks alone leave most of the chip idle and there are steps to share
     const bool wide = !act && blocks < 256 && steps >= 16;
     const int nw = wide ? 8 : 4;
-    const size_t lds = (size_t)16 * (p.k * 2 + 16) + (size_t)nw * (act ? 2 : 1) * 256 * 4;
+    const size_t lds = (norm ? (size_t)16 * (p.k * 2 + 16) : 0) + (size_t)nw * (act ? 2 : 1) * 256 * 4; // the staged rows only where the prologue writes them
     if (norm) return act ? launch_rows<4, true, true>(s, q, blocks, lds) : wide ? launch_rows<8, false, true>(s, q, blocks, lds) : launch_rows<4, false, true>(s, q, blocks, lds);
     return act ? launch_rows<4, true, false>(s, q, blocks, lds) : wide ? launch_rows<8, false, false>(s, q, blocks, lds) : launch_rows<4, false, false>(s, q, blocks, lds);
 }
