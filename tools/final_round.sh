@@ -29,3 +29,4 @@ for f in sorted(glob.glob('gpurun_out/final/bench_*.json')):
     except Exception as e:
         print(f, 'ERR', e)
 PY
+timeout 300 python tools/verify_cost.py > $O/verify_cost.json 2> $O/verify_cost.err
