@@ -191,6 +191,18 @@ typedef struct {
 uzu_status uzu_hip_decode_gemv_plan(uint32_t n0, uint32_t n1, uint32_t k, uint32_t bits, uint32_t normed, uint32_t gated_act, uint32_t num_cus,
                                     uzu_decode_gemv_plan* out);
 
+/* The plan of the prefill GEMM (csrc/k_gemm128.hip) for a quantized linear of n rows over k columns at m activation rows on a device with
+ * `num_cus` compute units -- host arithmetic only, no GPU needed.  large_tile = 0: the shape goes to the 64 x 64-tile kernel / the few-rows
+ * kernel / the GEMV.  form: 0 = 256-thread workgroups (128 x 128 tile, weights straight into the MFMA operand), 1 = ping-pong (128 x 256 tile
+ * per 512-thread workgroup, weight fragments converted once per half into LDS), 2 = wave-specialised (consumer waves fed from LDS + producer
+ * waves); the three are bit-identical, the choice follows the same-box measurements in profiles/r5_gemm_pp_ab.txt.  workgroups = tiles with
+ * work x splits. */
+typedef struct {
+    uint32_t large_tile, form, splits, workgroups;
+} uzu_prefill_gemm_plan;
+uzu_status uzu_hip_prefill_gemm_plan(uint32_t m, uint32_t n, uint32_t k, uint32_t bits, uint32_t group_size, uint32_t gated_act, uint32_t num_cus,
+                                     uzu_prefill_gemm_plan* out);
+
 #ifdef __cplusplus
 }
 #endif

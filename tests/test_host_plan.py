@@ -87,3 +87,57 @@ def test_bad_arguments_are_rejected():
     assert lib.uzu_hip_decode_gemv_plan(4096, 0, 4096, 5, 0, 0, CUS, C.byref(p)) != 0
     assert lib.uzu_hip_decode_gemv_plan(4097, 0, 4096, 4, 0, 1, CUS, C.byref(p)) != 0
     assert lib.uzu_hip_decode_gemv_plan(4096, 0, 4096, 4, 0, 0, CUS, None) != 0
+
+
+# ---------------------------------------------------------------------------------------------- prefill GEMM plan
+class GemmPlan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("large_tile", "form", "splits", "workgroups")]
+
+
+def gemm_plan(m, n, k, bits=4, group=128, gated=False, cus=CUS):
+    lib = _ffi.lib()
+    lib.uzu_hip_prefill_gemm_plan.argtypes = [C.c_uint32] * 7 + [C.POINTER(GemmPlan)]
+    lib.uzu_hip_prefill_gemm_plan.restype = C.c_int32
+    p = GemmPlan()
+    assert lib.uzu_hip_prefill_gemm_plan(m, n, k, bits, group, int(gated), cus, C.byref(p)) == 0
+    return p
+
+
+def test_prefill_gemm_plan_follows_the_measured_ab(monkeypatch):
+    """csrc/k_gemm128.hip::gemm128_form through uzu_hip_prefill_gemm_plan (host arithmetic).  The three forms are bit-identical
+    (tests/test_gpu_kernels.py); which one runs is the same-box A/B of profiles/r5_gemm_pp_ab.txt: ping-pong on long reductions with at
+    least one 128 x 256 tile per CU and a plain epilogue, wave-specialised on the few-tile split-K shapes, the 256-thread form elsewhere."""
+    monkeypatch.delenv("UZU_GEMM_FORM", raising=False)
+    monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+    # Llama-3-8B at 4096 rows: qkv / out / down on the ping-pong form (x1.05-1.16), the gated up projection on the 256-thread form (x0.95)
+    for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):
+        p = gemm_plan(4096, n, k)
+        assert (p.large_tile, p.form, p.splits) == (1, 1, 1), (n, k)
+    assert gemm_plan(4096, 28672, 4096, gated=True).form == 0
+    # a 1024-row pass of the same model leaves CUs without a tile pair: 256-thread form
+    assert gemm_plan(1024, 4096, 4096).form == 0
+    # Qwen3.5-0.8B at 2048 rows: short reductions with many tiles stay on the 256-thread form, the N = 1024 projections split K and take
+    # the wave-specialised form (x1.02-1.05)
+    assert gemm_plan(2048, 8224, 1024).form == 0 and gemm_plan(2048, 8224, 1024).workgroups == 16 * 65
+    assert gemm_plan(2048, 7168, 1024, gated=True).form == 0
+    for n, k in ((1024, 3584), (1024, 2048)):
+        p = gemm_plan(2048, n, k)
+        assert p.form == 2 and p.splits > 1, (n, k)
+    # below 128 rows the large-tile kernel is not used at all
+    assert gemm_plan(64, 4096, 4096).large_tile == 0
+    # the switch forces a form
+    monkeypatch.setenv("UZU_GEMM_FORM", "0")
+    assert gemm_plan(4096, 4096, 4096).form == 0
+    monkeypatch.setenv("UZU_GEMM_FORM", "2")
+    assert gemm_plan(4096, 4096, 4096).form == 2
+
+
+def test_prefill_gemm_plan_bad_arguments():
+    lib = _ffi.lib()
+    lib.uzu_hip_prefill_gemm_plan.argtypes = [C.c_uint32] * 7 + [C.POINTER(GemmPlan)]
+    lib.uzu_hip_prefill_gemm_plan.restype = C.c_int32
+    p = GemmPlan()
+    assert lib.uzu_hip_prefill_gemm_plan(0, 4096, 4096, 4, 128, 0, CUS, C.byref(p)) != 0
+    assert lib.uzu_hip_prefill_gemm_plan(4096, 4096, 4096, 5, 128, 0, CUS, C.byref(p)) != 0
+    assert lib.uzu_hip_prefill_gemm_plan(4096, 4096, 4000, 4, 128, 0, CUS, C.byref(p)) != 0
+    assert lib.uzu_hip_prefill_gemm_plan(4096, 4097, 4096, 4, 128, 1, CUS, C.byref(p)) != 0

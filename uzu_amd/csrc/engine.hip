@@ -1777,6 +1777,20 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
 uint32_t uzu_hip_model_context_length(const uzu_hip_model* m) { return m ? m->context_length : 0; }
 size_t uzu_hip_model_weight_bytes(const uzu_hip_model* m) { return m ? m->weight_bytes : 0; }
 uint32_t uzu_hip_model_decode_launch_count(const uzu_hip_model* m) { return m ? m->launches : 0; }
+uzu_status uzu_hip_prefill_gemm_plan(uint32_t m, uint32_t n, uint32_t k, uint32_t bits, uint32_t group_size, uint32_t gated_act, uint32_t num_cus,
+                                     uzu_prefill_gemm_plan* out) {
+    if (!out || !m || !n || !k || (bits != 4 && bits != 8) || !group_size || k % group_size || !num_cus || (gated_act && (n & 1))) {
+        set_error("prefill_gemm_plan: bad arguments");
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    k::MatmulParams p{};
+    static __attribute__((aligned(16))) uint16_t dummy[8] = {0};
+    p.a = p.b = p.scales = p.biases = dummy, p.d = dummy; // only tested for presence / alignment
+    p.m = m, p.n = n, p.k = k, p.bits = bits, p.group_size = group_size, p.b_kind = UZU_MATMUL_B_SCALE_BIAS, p.ab_scale = 1.0f;
+    p.w_dt = p.a_dt = p.d_dt = UZU_BF16, p.act_mul = gated_act ? 1 : 0;
+    k::gemm_q_mfma128_plan_query(p, (int)num_cus, &out->large_tile, &out->form, &out->splits, &out->workgroups);
+    return UZU_OK;
+}
 uzu_status uzu_hip_decode_gemv_plan(uint32_t n0, uint32_t n1, uint32_t k, uint32_t bits, uint32_t normed, uint32_t gated_act, uint32_t num_cus,
                                     uzu_decode_gemv_plan* out) {
     if (!out || !n0 || !k || k % 32 || (bits != 4 && bits != 8) || !num_cus || (gated_act && (n0 & 1))) {

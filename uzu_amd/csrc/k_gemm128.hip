@@ -803,6 +803,7 @@ __global__ void __launch_bounds__(256) gemm_split_reduce_kernel(MatmulParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus);
 unsigned long long* g_gemm128_dbg = nullptr; // tools/kbench KB_GEMM_DBG: per-workgroup phase timestamps (100 MHz wall clock)
 static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
     const char* e = getenv("UZU_GEMM_SPLITS"); // read per call: tests/test_gpu_kernels.py pins it to cover both paths
@@ -830,6 +831,16 @@ static int gemm128_form(const MatmulParams& p, int num_cus, uint32_t splits) {
     if (splits > 1) return 2;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;
     return (p.k / BK >= 48 && m_tiles * ((n_tiles + 1) / 2) >= (uint32_t)num_cus) ? 1 : 0;
+}
+// host arithmetic only (uzu_hip_prefill_gemm_plan): which kernel / form / split-K a shape gets; UZU_GEMM_FORM / UZU_GEMM_SPLITS apply as at launch
+void gemm_q_mfma128_plan_query(const MatmulParams& p, int num_cus, uint32_t* large_tile, uint32_t* form, uint32_t* splits, uint32_t* workgroups) {
+    *large_tile = gemm_q_mfma128_supported(p, num_cus) ? 1u : 0u;
+    *form = *splits = *workgroups = 0;
+    if (!*large_tile) return;
+    *splits = gemm128_splits(p, num_cus);
+    *form = (uint32_t)gemm128_form(p, num_cus, *splits);
+    const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = p.act_mul ? (p.n / 2 + 63) / 64 : (p.n + BN - 1) / BN;
+    *workgroups = (*form == 1 ? m_tiles * ((n_tiles + 1) / 2) : m_tiles * n_tiles) * *splits; // tiles with work (the launch grid pads them to whole super-tiles)
 }
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus) {
     if (p.m < 128 || p.n < 64) return false;

@@ -83,6 +83,7 @@ uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus);
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus);
 size_t gemm_q_mfma128_workspace_bytes(const MatmulParams& p, int num_cus);
 uzu_status gemm_q_mfma128(hipStream_t s, const MatmulParams& p, int num_cus, void* workspace);
+void gemm_q_mfma128_plan_query(const MatmulParams& p, int num_cus, uint32_t* large_tile, uint32_t* form, uint32_t* splits, uint32_t* workgroups);
 extern unsigned long long* g_gemm128_dbg; // profiling aid (tools/kbench KB_GEMM_DBG)
 size_t matmul_algorithmic_bytes(const MatmulParams& p); // codes + scales + correction + A + D, SURVEY.md §8d
 
