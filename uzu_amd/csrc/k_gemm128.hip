@@ -201,7 +201,13 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
     auto stage_a = [&](uint32_t kt, const u32x4_v (&st)[NR]) {
         uint8_t* dst = &s_a[kt & 1][rpass * A_PITCH + chunk * 16];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) *(u32x4_v*)(dst + j * RSTEP * A_PITCH) = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
+        for (int j = 0; j < NR; ++j) {
+            u32x4_v v = (kPairs && BITS == 4) ? permute_pairs(st[j]) : st[j];
+#ifdef UZU_GEMM_LAB_SWAP // LAB: the wave-specialised form with two k slots of every operand exchanged -- is the MFMA's sum independent of the slot order?
+            if (WS) { const uint32_t t = v.x; v.x = v.w, v.w = t; }
+#endif
+            *(u32x4_v*)(dst + j * RSTEP * A_PITCH) = v;
+        }
     };
 
     // ---- weight role: lane -> column c of each of the wave's two 32-column blocks, k half h
@@ -374,6 +380,9 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
                     u32x4_t f;
                     if (BITS == 4) f = kPairs ? dequant4_pairs(raw[0][s] ^ flip) : dequant4(raw[0][s] ^ flip);
                     else f = dequant8(raw[s >> 1][(s & 1) * 2] ^ flip, raw[s >> 1][(s & 1) * 2 + 1] ^ flip);
+#ifdef UZU_GEMM_LAB_SWAP
+                    { const uint32_t t = f.x; f.x = f.w, f.w = t; }
+#endif
                     *(u32x4_t*)(dst + s * 1024) = f;
                 }
             };
