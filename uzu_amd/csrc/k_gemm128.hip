@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
             for (int mb = 0; mb < 2; ++mb) af[mb] = *(const u32x4_t*)(ab + mb * 32 * A_PITCH + s * 16);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-#ifdef UZU_GEMM_LAB_NOCONV // LAB (wrong results): the code word fed to the matrix core as it is -- the loop without its conversion instructions
+#ifdef UZU_GEMM_LAB_NOCONV // LAB (wrong results): one and-or per fragment instead of nine instructions -- the loop without its conversion work (finite operands: arbitrary bit patterns cost clock)
                 { const uint32_t one = (raw[nb][0][s] & 0x00010001u) | 0x3f803f80u; bf[nb] = u32x4_t{one, one, one, one}; } // bf16 1.0 / 1.0078: finite, benign
 #else
                 if (BITS == 4) bf[nb] = kPairs ? dequant4_pairs(raw[nb][0][s] ^ flip) : dequant4(raw[nb][0][s] ^ flip);
@@ -662,12 +662,8 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
             for (int u = 0; u < U; ++u) {
                 const uint32_t kt = kt0 + u;
                 // (UZU_GEMM_LAB_*: ablation builds for tools/kbench -- wrong results, one ingredient of the k-step removed at a time)
-#ifndef UZU_GEMM_LAB_NOWLOAD
                 load_w(kt + DB - 1, ring[(u + DB - 1) % DB]);
-#endif
-#ifndef UZU_GEMM_LAB_NOMFMA
                 mfma_codes(kt, ring[u % DB], u % GS == 0);
-#endif
 #ifndef UZU_GEMM_LAB_NOSTAGE
                 stage_a(kt + 1, a_st[(u + 1) % DA]); // tile kt + 1 (requested DA k-steps ago) -> the other LDS buffer
                 load_a(kt + 1 + DA, a_st[(u + 1) % DA]);
