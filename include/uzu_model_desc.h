@@ -156,6 +156,26 @@ typedef struct {
     /* --- dense MLP (encodable_block/mlp/dense.rs) --- */
     uzu_linear_desc up_projection;   /* n = 2*hidden: rows [0,h) = up, [h,2h) = gate */
     uzu_linear_desc down_projection; /* k = hidden */
+
+    /* --- layer options of the Gemma families (config/transformer_layer.rs:16-20, config/token_mixer/attention.rs:26-28);
+     *     all zero = none of them (a layer description that stops at down_projection keeps its meaning) --- */
+    uint32_t rope_index;            /* use_rope != 0: which entry of uzu_model_desc.ropes rotates this layer (transformer.rs:101-118);
+                                       ignored when num_ropes == 0 (the single `rope`) */
+    uint32_t has_post_layer_scalar; /* transformer_layer.rs:61-84: pre_mlp_norm scales the residual sum, post_mlp_norm (required) its
+                                       output -- unless the layer has a PLE projection, which then owns the scalar */
+    float post_layer_scalar;        /* tensor `post_layer_scalar` [1] */
+    uint32_t is_kv_sharing;         /* AttentionConfig::is_kv_sharing == TransformerLayerConfig::kv_source_layer_index.is_some(): the packed
+                                       projection yields queries only (n = heads*head_dim), no key / value norm, no KV append; the
+                                       attention reads the source layer's state (mixer/attention/mode.rs:79-84, transformer.rs:264-275) */
+    uint32_t kv_source_layer_index; /* an earlier attention layer that owns its state (is_kv_sharing != 0) */
+    uint32_t normalize_values;      /* AttentionConfig::value_norm_config(): scale-free RMS norm (eps 1e-6, FullLayer) of the value heads */
+    uint32_t has_ple;               /* ple_config.is_some(): PerLayerEmbeddingProjection (per_layer_embedding.rs:150-271) ends the layer */
+    uint32_t ple_dim;
+    uint32_t ple_activation;        /* uzu_activation_type */
+    uint32_t reserved3;
+    uzu_linear_desc ple_gate;       /* ple.gate: n = ple_dim, k = model_dim */
+    uzu_linear_desc ple_projection; /* ple.projection: n = model_dim, k = ple_dim */
+    uzu_norm_desc ple_norm;         /* ple.norm: [model_dim] */
 } uzu_layer_desc;
 
 typedef struct {
@@ -174,6 +194,24 @@ typedef struct {
     uzu_linear_desc output_embedding; /* untied readout; ignored when tied */
     uzu_norm_desc output_norm;
     const uzu_layer_desc* layers;
+
+    /* --- decoder options of the Gemma families; all zero = none --- */
+    uint32_t num_ropes;          /* 0: every rotating layer uses `rope` above.  Else the distinct AnyRoPEConfig values of the layers in
+                                    order of first use (Transformer::new, transformer.rs:101-118): layer l rotates with ropes[rope_index] */
+    uint32_t has_ple;            /* DecoderConfig::ple_model_config.is_some() (decoder.rs:85-99) */
+    const uzu_rope_desc* ropes;
+    uzu_norm_desc embedding_norm; /* DecoderConfig::embedding_norm_config: a Normalization of the looked-up rows (decoder.rs:68-83,149-154) */
+    /* PLEModelConfig (config/per_layer_embedding.rs:5-15), PerLayerEmbedding (per_layer_embedding.rs:36-148); num_layers == the layer count */
+    uint32_t ple_dim;
+    uint32_t ple_vocab_size;
+    float ple_embed_scale;
+    float ple_model_projection_scale;
+    float ple_input_scale;
+    uint32_t reserved;
+    uzu_linear_desc ple_token_embedding;  /* per_layer_embedding.token_embedding: n = ple_vocab_size, k = num_layers*ple_dim (an embedding table) */
+    uzu_linear_desc ple_model_projection; /* per_layer_embedding.model_projection: n = num_layers*ple_dim, k = model_dim */
+    uzu_norm_desc ple_projection_norm;    /* per_layer_embedding.projection_norm: [ple_dim]; epsilon as configured (the engine divides it by
+                                             model_projection_scale^2, per_layer_embedding.rs:75-80) */
 } uzu_model_desc;
 
 #ifdef __cplusplus

@@ -14,6 +14,10 @@
  *   Sampling (greedy)          BU/src/backends/cpu/kernel/sampling/unified_sampling.rs:90-98
  *   encode_accept              BU/src/encodable_block/mixer/attention/state.rs:174-236 (Full cache, flat
  *                              full accept => no copies, length += n)
+ *   PerLayerEmbedding          BU/src/encodable_block/per_layer_embedding.rs:36-148 (model side), :150-271 (layer side)
+ * and the Gemma-family layer options: per-layer RoPE configurations (transformer.rs:101-118,249-257), post-layer scalar
+ * (transformer_layer.rs:61-84), embedding norm (decoder.rs:68-83,149-154), KV sharing (transformer.rs:264-275,
+ * mixer/attention/mode.rs:79-84), value normalisation (mixer/attention/qkv_norm.rs:70-72,149-175)
  * on top of the kernels in uzu_oracle_kernels.c.  Activations are bf16 (LanguageModel hard-codes
  * BF16, BU/src/engine/language_model/mod.rs:74).
  */
@@ -67,12 +71,30 @@ orc_model* orc_model_create(const uzu_model_desc* desc) {
     m->layers = (uzu_layer_desc*)xcalloc(desc->num_layers, sizeof(uzu_layer_desc));
     memcpy(m->layers, desc->layers, sizeof(uzu_layer_desc) * desc->num_layers);
     m->desc.layers = m->layers;
+    if (desc->num_ropes) { /* own copy of the table of RoPE configurations (their factor arrays stay the caller's, like every tensor) */
+        uzu_rope_desc* ropes = (uzu_rope_desc*)xcalloc(desc->num_ropes, sizeof(uzu_rope_desc));
+        memcpy(ropes, desc->ropes, sizeof(uzu_rope_desc) * desc->num_ropes);
+        m->desc.ropes = ropes;
+    }
     m->states = (layer_state*)xcalloc(desc->num_layers, sizeof(layer_state));
     m->layer_outputs = (uint16_t**)xcalloc(desc->num_layers, sizeof(uint16_t*));
     m->final_hidden = (uint16_t*)xcalloc(desc->model_dim, 2);
     for (uint32_t l = 0; l < desc->num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
-        if (L->mixer_kind == UZU_MIXER_ATTENTION) {
+        if (L->mixer_kind == UZU_MIXER_ATTENTION && L->is_kv_sharing) {
+            /* TransformerLayerStateType::Shared(kv_source_layer_index) (transformer.rs:205-216): no state of its own */
+            const uint32_t src = L->kv_source_layer_index;
+            if (src >= l || m->layers[src].mixer_kind != UZU_MIXER_ATTENTION || m->layers[src].is_kv_sharing) {
+                fprintf(stderr, "oracle: layer %u shares the KV state of layer %u, which is not an earlier attention layer owning its state\n", l, src);
+                abort();
+            }
+            /* the core's ring / window specialisation comes from the layer's own config, the ring parameters from the state it reads
+             * (mod.rs:166-198, core/single_pass.rs:60-70): only equal geometry is a meaningful configuration */
+            if (m->layers[src].sliding_window_size != L->sliding_window_size || m->layers[src].num_groups != L->num_groups || m->layers[src].head_dim != L->head_dim) {
+                fprintf(stderr, "oracle: layer %u and its KV source %u differ in window / kv heads / head_dim\n", l, src);
+                abort();
+            }
+        } else if (L->mixer_kind == UZU_MIXER_ATTENTION) {
             /* AttentionState::create_empty (state.rs:69-136): causal + sliding window => Ring with max_length = the window */
             const size_t max_prefix = L->sliding_window_size ? L->sliding_window_size : desc->max_context_length;
             const size_t max_elements = max_prefix + ATTENTION_SUFFIX_CAPACITY;
@@ -127,6 +149,7 @@ void orc_model_destroy(orc_model* m) {
     free(m->final_hidden);
     free(m->states);
     free(m->layers);
+    if (m->desc.num_ropes) free((void*)m->desc.ropes);
     free(m);
 }
 
@@ -137,7 +160,7 @@ void orc_model_fill_synthetic_context(orc_model* m, uint32_t n) {
     if (n > m->desc.max_context_length) n = m->desc.max_context_length;
     for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
-        if (L->mixer_kind != UZU_MIXER_ATTENTION) continue;
+        if (L->mixer_kind != UZU_MIXER_ATTENTION || L->is_kv_sharing) continue;
         const size_t element_size = (size_t)L->num_groups * L->head_dim;
         const uint32_t rows = m->states[l].ring_max && n > m->states[l].ring_max ? m->states[l].ring_max : n; /* a ring holds its window */
         for (size_t i = 0; i < (size_t)rows * element_size; ++i) {
@@ -232,8 +255,15 @@ static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint3
 }
 
 /* Normalization::encode (encodable_block/normalization.rs:114-146); mode: 0 none, 1 copy, 2 add */
+/* scalar_mode: PostLayerScalar (normalization.rs:17-21,76-80): 0 None, 1 ScaleResidualSum(scalar), 2 ScaleOutput(scalar) */
+static uint16_t* norm_scaled(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim,
+                             int scalar_mode, float scalar, float epsilon);
 static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows,
                       uint32_t dim) {
+    return norm_scaled(nd, input, shortcut, mode, rows, dim, 0, 1.0f, nd->epsilon);
+}
+static uint16_t* norm_scaled(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim,
+                             int scalar_mode, float scalar, float epsilon) {
     uint16_t* out = (uint16_t*)xcalloc((size_t)rows * dim, 2);
     orc_norm_args g;
     memset(&g, 0, sizeof(g));
@@ -246,9 +276,11 @@ static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* 
     g.affine_dtype = ORC_F32;
     g.batch_size = rows;
     g.element_count = dim;
-    g.epsilon = nd->epsilon;
+    g.epsilon = epsilon;
     g.scale_offset = nd->scale_offset;
-    g.post_layer_scalar = 1.0f;
+    g.post_layer_scalar = scalar_mode ? scalar : 1.0f;
+    g.scale_residual_sum = scalar_mode == 1;
+    g.scale_output = scalar_mode == 2;
     g.subtract_mean = nd->subtract_mean;
     g.full_layer = nd->full_layer;
     g.copy_to_shortcut = mode != 0;
@@ -257,29 +289,39 @@ static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* 
     return out;
 }
 
+/* the RoPE configuration of layer l: uzu_model_desc.ropes[rope_index] when the model carries several (transformer.rs:101-118) */
+static const uzu_rope_desc* layer_rope(const uzu_model_desc* D, const uzu_layer_desc* L) {
+    return D->num_ropes ? &D->ropes[L->rope_index] : &D->rope;
+}
+
 static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uint32_t batch, const float* cosines,
                                  const float* sines, const uint32_t* trie) {
     const uzu_layer_desc* L = &m->layers[l];
-    layer_state* st = &m->states[l];
+    /* MaybeMut::Const(owned layer's state) for a sharing layer (transformer.rs:264-275) */
+    layer_state* st = &m->states[L->is_kv_sharing ? L->kv_source_layer_index : l];
     const uint32_t hd = L->head_dim, nq = L->num_heads, nkv = L->num_groups;
+    const uint32_t nkv_proj = L->is_kv_sharing ? 0 : nkv; /* num_kv_heads = (!is_kv_sharing).then_some(num_groups) (mod.rs:80) */
     /* gate projection first, from a copy of hidden (mode.rs:54-61) */
     uint16_t* gate = NULL;
     if (L->has_gate) gate = linear(&L->gate_projection, hidden, batch);
     uint16_t* qkv = linear(&L->qkv_projection, hidden, batch);
-    const uint32_t total_heads = nq + 2 * nkv;
-    /* QKVNorm::encode_packed (qkv_norm.rs:137-175) */
+    const uint32_t total_heads = nq + 2 * nkv_proj;
+    /* QKVNorm::encode_packed (qkv_norm.rs:137-175): query, key, value heads; key / value norms are dropped with KV sharing (mod.rs:135-137),
+     * head_count == 0 skips a head group */
     if (L->query_norm.present)
         orc_qkv_norm(qkv, ORC_BF16, L->query_norm.scales, batch, total_heads, hd, L->query_norm.epsilon,
                      L->query_norm.scale_offset, 0, nq, L->query_norm.full_layer);
-    if (L->key_norm.present)
+    if (L->key_norm.present && nkv_proj)
         orc_qkv_norm(qkv, ORC_BF16, L->key_norm.scales, batch, total_heads, hd, L->key_norm.epsilon,
                      L->key_norm.scale_offset, nq, nkv, L->key_norm.full_layer);
-    /* prepare_kv_and_queries (mode.rs:200-232): kv_token_offset = physical_prefix_length */
+    if (L->normalize_values && nkv_proj) /* AttentionConfig::value_norm_config (config/token_mixer/attention.rs:32-42): eps 1e-6, FullLayer, no scales */
+        orc_qkv_norm(qkv, ORC_BF16, NULL, batch, total_heads, hd, 1e-6f, 0.0f, nq + nkv, nkv, 1);
+    /* prepare_kv_and_queries (mode.rs:200-232): kv_token_offset = physical_prefix_length; prepare_queries (mode.rs:234-259) with KV sharing */
     uint16_t* queries = (uint16_t*)xcalloc((size_t)nq * batch * hd, 2);
-    const uint32_t rope_dim = L->use_rope ? m->desc.rope.head_dim : 0;
+    const uint32_t rope_dim = L->use_rope ? layer_rope(&m->desc, L)->head_dim : 0;
     /* kv_token_offset = state_type.physical_prefix_length(): the length of a Full cache, max_length of a Ring (state.rs:26-37) */
     const uint32_t physical_prefix = st->ring_max ? st->ring_max : st->length;
-    orc_attention_prepare(qkv, queries, st->keys, st->values, cosines, sines, nq, nkv, hd, rope_dim, physical_prefix, batch, 1);
+    orc_attention_prepare(qkv, queries, st->keys, st->values, cosines, sines, nq, nkv, hd, rope_dim, physical_prefix, batch, nkv_proj != 0);
     free(qkv);
     /* AttentionCores::encode (core/mod.rs:81-93) */
     orc_attention_args a;
@@ -293,7 +335,7 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     a.sequence_length = physical_prefix + batch; /* core/single_pass.rs:60 */
     if (st->ring_max) { /* ring_params (state.rs:39-54), sliding window (core/mod.rs:17-28) */
         a.is_kv_cache_ring = 1, a.ring_offset = st->ring_offset, a.ring_length = st->length;
-        a.is_sliding_window = 1, a.sliding_window_size = L->sliding_window_size;
+        a.is_sliding_window = 1, a.sliding_window_size = L->sliding_window_size; /* the layer's own core arguments (mod.rs:166-198) */
     }
     if (L->has_sinks) a.sinks = L->sinks;
     a.k_head_stride = hd;
@@ -462,15 +504,50 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
     /* EmbeddingTable with output Hadamard factors (embedding_table.rs:34-125, quant_embedding.metal use_hadamard): OutputRht of the row */
     if (D->embedding.output_signs)
         orc_activation_transform(NULL, hidden, NULL, NULL, NULL, D->embedding.output_signs, ORC_BF16, count, d, 1, 0, 0);
+    /* Decoder::encode (decoder.rs:149-154): the embedding norm, no shortcut */
+    if (D->embedding_norm.present) {
+        uint16_t* t = norm(&D->embedding_norm, hidden, NULL, 0, count, d);
+        free(hidden);
+        hidden = t;
+    }
+    /* PerLayerEmbedding::encode (per_layer_embedding.rs:108-147): per_layer_inputs [count, layers, ple_dim] =
+     * token table row * (ple_embed_scale * input_scale) + projection_norm(model_projection(embedded)) [ScaleOutput(input_scale),
+     * epsilon / model_projection_scale^2] */
+    uint16_t* per_layer_inputs = NULL;
+    if (D->has_ple) {
+        const uint32_t total = D->num_layers * D->ple_dim;
+        uint16_t* token_ple = (uint16_t*)xcalloc((size_t)count * total, 2);
+        const float fused_token_scale = D->ple_embed_scale * D->ple_input_scale; /* per_layer_embedding.rs:103 */
+        const uzu_linear_desc* T = &D->ple_token_embedding;
+        if (T->method == UZU_QUANT_NONE)
+            orc_full_precision_embedding_lookup(token_ids, T->weights, token_ple, ORC_BF16, count, D->ple_vocab_size, total, fused_token_scale);
+        else
+            orc_quantized_embedding_lookup(token_ids, (const uint8_t*)T->weights, T->scales, T->zero_points, T->biases, token_ple, ORC_BF16, count,
+                                           D->ple_vocab_size, total, fused_token_scale, T->group_size, T->bits, T->method);
+        uint16_t* projected = linear(&D->ple_model_projection, hidden, count); /* on a copy of the rows (:125-128): `hidden` stays as it is */
+        const float s2 = D->ple_model_projection_scale * D->ple_model_projection_scale;
+        uint16_t* normed = norm_scaled(&D->ple_projection_norm, projected, NULL, 0, count * D->num_layers, D->ple_dim, 2, D->ple_input_scale,
+                                       D->ple_projection_norm.epsilon / s2);
+        free(projected);
+        per_layer_inputs = (uint16_t*)xcalloc((size_t)count * total, 2);
+        orc_tensor_add_scale(token_ple, normed, per_layer_inputs, ORC_BF16, count * total, count * total, 1.0f);
+        free(token_ple);
+        free(normed);
+    }
     uint16_t* shortcut = (uint16_t*)xcalloc((size_t)count * d, 2);
-    /* host RoPE tables for this pass (transformer.rs:247-254) */
-    float *cosines = NULL, *sines = NULL;
-    if (D->rope.kind != UZU_ROPE_NONE) {
+    /* host RoPE tables for this pass, one pair per distinct configuration (transformer.rs:247-257) */
+    const uint32_t n_ropes = D->num_ropes ? D->num_ropes : (D->rope.kind != UZU_ROPE_NONE ? 1u : 0u);
+    float** cos_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
+    float** sin_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
+    if (n_ropes) {
         uint32_t* pos = (uint32_t*)xcalloc(count, 4);
         for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + (trie ? trie[3 * i + 2] : i); /* transformer.rs:247: context + height */
-        cosines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
-        sines = (float*)xcalloc((size_t)count * D->rope.head_dim, 4);
-        orc_rope_tables(&D->rope, pos, count, cosines, sines);
+        for (uint32_t r = 0; r < n_ropes; ++r) {
+            const uzu_rope_desc* R = D->num_ropes ? &D->ropes[r] : &D->rope;
+            cos_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
+            sin_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
+            orc_rope_tables(R, pos, count, cos_tabs[r], sin_tabs[r]);
+        }
         free(pos);
     }
     m->last_rows = count;
@@ -484,6 +561,11 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
             memcpy(shortcut, hidden, (size_t)count * d * 2);
             h = hidden;
         }
+        const uint32_t ri = D->num_ropes ? L->rope_index : 0;
+        const float* cosines = L->use_rope && n_ropes ? cos_tabs[ri] : NULL;
+        const float* sines = L->use_rope && n_ropes ? sin_tabs[ri] : NULL;
+        /* transformer_layer.rs:61-84: the scalar belongs to the two norms unless a PLE projection owns it */
+        const int norms_scale = L->has_post_layer_scalar && !L->has_ple;
         uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines, trie)
                                                                : delta_net_mixer(m, l, h, count, trie, parents);
         free(h);
@@ -492,7 +574,7 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
             free(mixed);
             mixed = t;
         }
-        uint16_t* mlp_in = norm(&L->pre_mlp_norm, mixed, shortcut, 2, count, d);
+        uint16_t* mlp_in = norm_scaled(&L->pre_mlp_norm, mixed, shortcut, 2, count, d, norms_scale ? 1 : 0, L->post_layer_scalar, L->pre_mlp_norm.epsilon);
         free(mixed);
         /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
         uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
@@ -503,17 +585,36 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
         uint16_t* down = linear(&L->down_projection, gated, count);
         free(gated);
         if (L->post_mlp_norm.present) {
-            uint16_t* t = norm(&L->post_mlp_norm, down, NULL, 0, count, d);
+            uint16_t* t = norm_scaled(&L->post_mlp_norm, down, NULL, 0, count, d, norms_scale ? 2 : 0, L->post_layer_scalar, L->post_mlp_norm.epsilon);
             free(down);
             down = t;
+        }
+        if (L->has_ple) {
+            /* PerLayerEmbeddingProjection::encode (per_layer_embedding.rs:217-270): shortcut += hidden; gate(shortcut) -> act(gate) * the
+             * layer's slice of per_layer_inputs -> projection -> norm; shortcut = (shortcut + normed) * post_layer_scalar; hidden = 0 */
+            const uint32_t length = count * d;
+            orc_tensor_add_bias(NULL, down, shortcut, ORC_BF16, ORC_BF16, length, length);
+            uint16_t* gate_out = linear(&L->ple_gate, shortcut, count);
+            uint16_t* activated = (uint16_t*)xcalloc((size_t)count * L->ple_dim, 2);
+            orc_gated_act_mul(gate_out, per_layer_inputs, activated, ORC_BF16, L->ple_dim, count, l * L->ple_dim, D->num_layers * L->ple_dim, L->ple_activation, 0);
+            free(gate_out);
+            uint16_t* projected = linear(&L->ple_projection, activated, count);
+            free(activated);
+            uint16_t* normed = norm(&L->ple_norm, projected, NULL, 0, count, d);
+            free(projected);
+            orc_tensor_add_scale(NULL, normed, shortcut, ORC_BF16, length, length, L->has_post_layer_scalar ? L->post_layer_scalar : 1.0f);
+            free(normed);
+            memset(down, 0, (size_t)length * 2); /* encoder.encode_fill(&mut hidden, 0) (transformer_layer.rs:231) */
         }
         hidden = down;
         free(m->layer_outputs[l]);
         m->layer_outputs[l] = (uint16_t*)xcalloc((size_t)count * d, 2);
         memcpy(m->layer_outputs[l], hidden, (size_t)count * d * 2);
     }
-    free(cosines);
-    free(sines);
+    for (uint32_t r = 0; r < n_ropes; ++r) free(cos_tabs[r]), free(sin_tabs[r]);
+    free(cos_tabs);
+    free(sin_tabs);
+    free(per_layer_inputs);
     /* output_norm over the output range, shortcut add (transformer.rs:317-323): the last row of a flat pass, every row of a tree */
     const uint32_t out_rows = trie ? count : 1;
     const size_t first = (size_t)(count - out_rows) * d;
@@ -544,7 +645,7 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
     }
     /* encode_accept (state.rs:174-236), flat full accept: nothing to copy on a Full cache; a Ring takes the suffix rows in order */
     for (uint32_t l = 0; l < D->num_layers; ++l) {
-        if (m->layers[l].mixer_kind != UZU_MIXER_ATTENTION) continue;
+        if (m->layers[l].mixer_kind != UZU_MIXER_ATTENTION || m->layers[l].is_kv_sharing) continue; /* Shared layer states are skipped (transformer.rs:63-69) */
         layer_state* st = &m->states[l];
         if (!st->ring_max) {
             st->length += count;
@@ -590,6 +691,7 @@ void orc_model_accept(orc_model* m, const uint32_t* accepted, uint32_t n) {
     for (uint32_t l = 0; l < m->desc.num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
         layer_state* st = &m->states[l];
+        if (L->mixer_kind == UZU_MIXER_ATTENTION && L->is_kv_sharing) continue; /* TransformerLayerStateType::Shared (transformer.rs:63-69) */
         if (L->mixer_kind == UZU_MIXER_ATTENTION) {
             orc_copy* copies = (orc_copy*)xcalloc(n, sizeof(orc_copy));
             uint32_t nc = 0;

@@ -68,6 +68,11 @@ class LayerDesc(C.Structure):
         ("dn_conv_weights", C.c_void_p), ("dn_conv_biases", C.c_void_p), ("dn_a_log", C.c_void_p),
         ("dn_dt_bias", C.c_void_p), ("dn_norm_scales", C.c_void_p),
         ("up_projection", LinearDesc), ("down_projection", LinearDesc),
+        # layer options of the Gemma families (all zero = none)
+        ("rope_index", C.c_uint32), ("has_post_layer_scalar", C.c_uint32), ("post_layer_scalar", C.c_float),
+        ("is_kv_sharing", C.c_uint32), ("kv_source_layer_index", C.c_uint32), ("normalize_values", C.c_uint32),
+        ("has_ple", C.c_uint32), ("ple_dim", C.c_uint32), ("ple_activation", C.c_uint32), ("reserved3", C.c_uint32),
+        ("ple_gate", LinearDesc), ("ple_projection", LinearDesc), ("ple_norm", NormDesc),
     ]
 
 
@@ -81,6 +86,12 @@ class ModelDesc(C.Structure):
         ("embedding", LinearDesc), ("output_embedding", LinearDesc),
         ("output_norm", NormDesc),
         ("layers", C.POINTER(LayerDesc)),
+        # decoder options of the Gemma families (all zero = none)
+        ("num_ropes", C.c_uint32), ("has_ple", C.c_uint32), ("ropes", C.POINTER(RopeDesc)),
+        ("embedding_norm", NormDesc),
+        ("ple_dim", C.c_uint32), ("ple_vocab_size", C.c_uint32), ("ple_embed_scale", C.c_float),
+        ("ple_model_projection_scale", C.c_float), ("ple_input_scale", C.c_float), ("reserved", C.c_uint32),
+        ("ple_token_embedding", LinearDesc), ("ple_model_projection", LinearDesc), ("ple_projection_norm", NormDesc),
     ]
 
 
@@ -151,6 +162,29 @@ ABSENT_NORM = NormWeights(present=False)
 
 
 @dataclass
+class PleLayerWeights:
+    """PLELayerConfig + the `ple` subtree of a layer (PerLayerEmbeddingProjection, per_layer_embedding.rs:150-271)."""
+    ple_dim: int
+    activation: int
+    gate: "LinearWeights"        # [ple_dim, model_dim]
+    projection: "LinearWeights"  # [model_dim, ple_dim]
+    norm: "NormWeights"          # [model_dim]
+
+
+@dataclass
+class PleModelWeights:
+    """PLEModelConfig + the `per_layer_embedding` subtree (PerLayerEmbedding, per_layer_embedding.rs:36-148)."""
+    ple_dim: int
+    ple_vocab_size: int
+    ple_embed_scale: float
+    model_projection_scale: float
+    input_scale: float
+    token_embedding: "LinearWeights"   # table [ple_vocab, num_layers * ple_dim]
+    model_projection: "LinearWeights"  # [num_layers * ple_dim, model_dim]
+    projection_norm: "NormWeights"     # [ple_dim], epsilon as configured
+
+
+@dataclass
 class LayerWeights:
     mixer_kind: int
     hidden_dim: int
@@ -189,6 +223,12 @@ class LayerWeights:
     dn_a_log: Optional[np.ndarray] = None
     dn_dt_bias: Optional[np.ndarray] = None
     dn_norm_scales: Optional[np.ndarray] = None
+    # layer options of the Gemma families (config/transformer_layer.rs:16-20, config/token_mixer/attention.rs:26-28)
+    rope_index: int = 0                          # which of ModelBundle.ropes rotates this layer (use_rope)
+    post_layer_scalar: Optional[float] = None    # has_post_layer_scalar + tensor `post_layer_scalar` [1]
+    kv_source_layer_index: Optional[int] = None  # is_kv_sharing: queries only, the KV state of that earlier layer is read
+    normalize_values: bool = False
+    ple: Optional["PleLayerWeights"] = None      # ple_config: PerLayerEmbeddingProjection at the end of the layer
 
     def desc(self) -> LayerDesc:
         empty = LinearDesc()
@@ -208,12 +248,20 @@ class LayerWeights:
             _ptr(self.dn_conv_weights), _ptr(self.dn_conv_biases), _ptr(self.dn_a_log), _ptr(self.dn_dt_bias),
             _ptr(self.dn_norm_scales),
             ld(self.up_projection), ld(self.down_projection),
+            int(self.rope_index), int(self.post_layer_scalar is not None), float(self.post_layer_scalar or 0.0),
+            int(self.kv_source_layer_index is not None), int(self.kv_source_layer_index or 0), int(self.normalize_values),
+            int(self.ple is not None), self.ple.ple_dim if self.ple else 0, self.ple.activation if self.ple else 0, 0,
+            ld(self.ple.gate if self.ple else None), ld(self.ple.projection if self.ple else None),
+            (self.ple.norm if self.ple else ABSENT_NORM).desc(),
         )
 
     def linears(self):
         names = ("qkv_projection", "gate_projection", "out_projection", "dn_in_proj", "dn_out_proj", "up_projection",
                  "down_projection")
-        return [(n, getattr(self, n)) for n in names if getattr(self, n) is not None]
+        out = [(n, getattr(self, n)) for n in names if getattr(self, n) is not None]
+        if self.ple is not None:
+            out += [("ple.gate", self.ple.gate), ("ple.projection", self.ple.projection)]
+        return out
 
 
 @dataclass
@@ -259,16 +307,32 @@ class ModelBundle:
     input_scale: float = 1.0
     logit_scale: float = 1.0
     logit_soft_cap: float = 0.0
+    ropes: Optional[List[RopeConfig]] = None     # distinct per-layer RoPE configurations (LayerWeights.rope_index); None: `rope` for all
+    embedding_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
+    ple: Optional[PleModelWeights] = None
     _keep: list = field(default_factory=list, repr=False)
 
     def desc(self) -> ModelDesc:
         arr = (LayerDesc * len(self.layers))(*[l.desc() for l in self.layers])
         self._keep.append(arr)
         out_emb = self.output_embedding.desc() if self.output_embedding is not None else LinearDesc()
+        ropes = None
+        if self.ropes:
+            ropes = (RopeDesc * len(self.ropes))(*[r.desc() for r in self.ropes])
+            self._keep.append(ropes)
+        e = LinearDesc()
+        p = self.ple
         return ModelDesc(self.vocab_size, self.model_dim, len(self.layers), int(self.tied_embeddings),
                          self.input_scale, self.logit_scale, self.logit_soft_cap, self.max_context_length,
                          self.rope.desc(), self.embedding.desc(), out_emb, self.output_norm.desc(),
-                         C.cast(arr, C.POINTER(LayerDesc)))
+                         C.cast(arr, C.POINTER(LayerDesc)),
+                         len(self.ropes) if self.ropes else 0, int(p is not None),
+                         C.cast(ropes, C.POINTER(RopeDesc)) if ropes is not None else None,
+                         self.embedding_norm.desc(),
+                         p.ple_dim if p else 0, p.ple_vocab_size if p else 0, p.ple_embed_scale if p else 0.0,
+                         p.model_projection_scale if p else 0.0, p.input_scale if p else 0.0, 0,
+                         p.token_embedding.desc() if p else e, p.model_projection.desc() if p else e,
+                         (p.projection_norm if p else ABSENT_NORM).desc())
 
     # ---- algorithmic bytes per decoded token (SURVEY.md §8d formula) ----
     def weight_stream_bytes(self) -> int:
@@ -278,13 +342,16 @@ class ModelBundle:
                 total += w.nbytes()
         readout = self.embedding if self.tied_embeddings else self.output_embedding
         total += readout.nbytes()
+        if self.ple is not None:
+            total += self.ple.model_projection.nbytes()
         return total
 
     def state_bytes_per_token(self, context: int) -> int:
         total = 0
         for l in self.layers:
             if l.mixer_kind == MIXER_ATTENTION:
-                total += 2 * context * l.num_groups * l.head_dim * 2          # K and V rows, bf16
+                rows = min(context, l.sliding_window_size) if l.sliding_window_size else context
+                total += 2 * rows * l.num_groups * l.head_dim * 2             # K and V rows, bf16 (a sharing layer reads its source's)
             else:
                 total += 2 * l.dn_num_heads * l.dn_value_head_dim * l.dn_head_dim * 4  # f32 state read + write
                 conv_dim = 2 * l.dn_num_groups * l.dn_head_dim + l.dn_num_heads * l.dn_value_head_dim

@@ -71,6 +71,17 @@ class ModelConfig:
     sliding_windows: Optional[List[int]] = None  # per attention layer (in layer order): window size, 0 = full attention (Gemma / gpt-oss pattern)
     sinks: bool = False            # every attention layer carries per-head sink logits (mixer.sinks)
     linear_biases: bool = False    # every layer linear carries an output bias (with `rht`: added behind the OutputRht, kernel.rs:296-303)
+    # layer / decoder options of the Gemma families (transformer_layer.rs:61-184, decoder.rs:68-99)
+    post_norms: bool = False       # post_mixer_norm + post_mlp_norm on every layer (the Gemma sandwich)
+    post_layer_scalars: bool = False  # has_post_layer_scalar on every layer (needs post_norms)
+    embedding_norm: bool = False
+    normalize_values: bool = False
+    layer_ropes: Optional[List[D.RopeConfig]] = None  # distinct RoPE configurations; rope_pattern picks one per attention layer (cyclic)
+    rope_pattern: Optional[List[int]] = None
+    kv_sharing: Optional[dict] = None  # {layer index: source layer index}: the layer's projection yields queries only, it reads the source's KV state
+    ple_dim: int = 0               # > 0: per-layer embeddings (PLEModelConfig + a PLELayerConfig on every layer)
+    ple_vocab_size: int = 0        # 0 = vocab_size
+    first_layer_without_pre_mixer_norm: bool = False
 
     @property
     def num_layers(self) -> int:
@@ -145,7 +156,23 @@ def tiny_llama(**kw) -> ModelConfig:
     return replace(cfg, **kw)
 
 
-PRESETS = {"qwen3.5-0.8b": qwen35_0p8b, "llama-3-8b": llama3_8b, "qwen3-14b-class": qwen3_14b_class, "tiny-qwen": tiny_qwen, "tiny-llama": tiny_llama}
+def tiny_gemma(**kw) -> ModelConfig:
+    """The layer / decoder options of the Gemma 3 / 3n families at toy size: local (sliding window, its own RoPE base) and global attention
+    layers, sandwich norms, post-layer scalars, value normalisation, two trailing layers that share the KV state of an earlier layer of
+    their kind, per-layer embeddings."""
+    local = D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=64, max_sequence_length=8192, base=10000.0)
+    glob = D.RopeConfig(kind=D.ROPE_LINEAR, head_dim=64, max_sequence_length=8192, base=1000000.0, scaling_factor=8.0)
+    cfg = ModelConfig(
+        name="tiny-gemma", vocab_size=1024, model_dim=256, hidden_dim=512,
+        layer_kinds=[D.MIXER_ATTENTION] * 5, num_heads=4, num_groups=2, head_dim=64, qk_norm=True,
+        rope=local, layer_ropes=[local, glob], rope_pattern=[0, 1, 0, 0, 1], sliding_windows=[48, 0, 48, 48, 0],
+        kv_sharing={3: 0, 4: 1}, post_norms=True, post_layer_scalars=True, normalize_values=True, ple_dim=32,
+        norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
+        bits=4, group_size=32, method=D.QUANT_SCALE_BIAS, tied_embeddings=True, max_context_length=2048, seed=77)
+    return replace(cfg, **kw)
+
+
+PRESETS = {"tiny-gemma": tiny_gemma, "qwen3.5-0.8b": qwen35_0p8b, "llama-3-8b": llama3_8b, "qwen3-14b-class": qwen3_14b_class, "tiny-qwen": tiny_qwen, "tiny-llama": tiny_llama}
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -229,24 +256,42 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
         p = f"layers.{li}."
         lw = D.LayerWeights(
             mixer_kind=kind, hidden_dim=cfg.hidden_dim, activation=D.ACT_SILU,
-            pre_mixer_norm=make_norm(cfg, p + "pre_mixer_norm", d),
+            pre_mixer_norm=D.ABSENT_NORM if (li == 0 and cfg.first_layer_without_pre_mixer_norm) else make_norm(cfg, p + "pre_mixer_norm", d),
             pre_mlp_norm=make_norm(cfg, p + "pre_mlp_norm", d),
             up_projection=make_linear(cfg, p + "mlp.up_projection", 2 * cfg.hidden_dim, d, gain=1.0),
             down_projection=make_linear(cfg, p + "mlp.down_projection", d, cfg.hidden_dim, gain=1.5),
         )
+        if cfg.post_norms:
+            lw.post_mixer_norm, lw.post_mlp_norm = make_norm(cfg, p + "post_mixer_norm", d), make_norm(cfg, p + "post_mlp_norm", d)
+        if cfg.post_layer_scalars:
+            assert cfg.post_norms, "a post-layer scalar needs the post-MLP norm (transformer_layer.rs:61-66)"
+            lw.post_layer_scalar = float(bf16_bits_to_f32(f32_to_bf16_bits(_rng(cfg.seed, p + "post_layer_scalar").uniform(0.5, 1.5, 1)))[0])
+        if cfg.ple_dim:
+            lw.ple = D.PleLayerWeights(
+                ple_dim=cfg.ple_dim, activation=D.ACT_GELU_APPROX,
+                gate=make_linear(cfg, p + "ple.gate", cfg.ple_dim, d, gain=1.0),
+                projection=make_linear(cfg, p + "ple.projection", d, cfg.ple_dim, gain=1.0),
+                norm=make_norm(cfg, p + "ple.norm", d))
         if kind == D.MIXER_ATTENTION:
             q_dim = cfg.num_heads * cfg.head_dim
             kv_dim = cfg.num_groups * cfg.head_dim
             lw.num_heads, lw.num_groups, lw.head_dim = cfg.num_heads, cfg.num_groups, cfg.head_dim
             lw.has_gate = cfg.has_gate
             lw.use_rope = cfg.rope.kind != D.ROPE_NONE
+            if cfg.layer_ropes:
+                lw.rope_index = int(cfg.rope_pattern[attn_index % len(cfg.rope_pattern)]) if cfg.rope_pattern else 0
+            lw.normalize_values = cfg.normalize_values
+            if cfg.kv_sharing and li in cfg.kv_sharing:
+                lw.kv_source_layer_index = int(cfg.kv_sharing[li])
+                kv_dim = 0  # the packed projection yields queries only (mixer/attention/mod.rs:89-95)
             lw.qkv_projection = make_linear(cfg, p + "mixer.qkv_projection", q_dim + 2 * kv_dim, d, gain=1.0)
             if cfg.has_gate:
                 lw.gate_projection = make_linear(cfg, p + "mixer.gate_projection", q_dim, d, gain=1.0)
             lw.out_projection = make_linear(cfg, p + "mixer.out_projection", d, q_dim, gain=1.0)
             if cfg.qk_norm:
                 lw.query_norm = make_norm(cfg, p + "mixer.query_norm", cfg.head_dim)
-                lw.key_norm = make_norm(cfg, p + "mixer.key_norm", cfg.head_dim)
+                if lw.kv_source_layer_index is None:
+                    lw.key_norm = make_norm(cfg, p + "mixer.key_norm", cfg.head_dim)
             if cfg.sliding_windows is not None:
                 lw.sliding_window_size = int(cfg.sliding_windows[attn_index % len(cfg.sliding_windows)])
             if cfg.sinks:
@@ -268,10 +313,22 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
             lw.dn_dt_bias = r.uniform(-1.0, 1.0, size=(Hv,)).astype(np.float32)
             lw.dn_norm_scales = (1.0 + r.uniform(-0.1, 0.1, size=(Dv,))).astype(np.float32)
         layers.append(lw)
+    ple = None
+    if cfg.ple_dim:
+        total = cfg.num_layers * cfg.ple_dim
+        pv = cfg.ple_vocab_size or cfg.vocab_size
+        ple = D.PleModelWeights(
+            ple_dim=cfg.ple_dim, ple_vocab_size=pv, ple_embed_scale=float(np.sqrt(cfg.ple_dim)), model_projection_scale=float(1.0 / np.sqrt(d)),
+            input_scale=float(1.0 / np.sqrt(2.0)),
+            token_embedding=make_linear(cfg, "per_layer_embedding.token_embedding", pv, total, gain=1.0),
+            model_projection=make_linear(cfg, "per_layer_embedding.model_projection", total, d, gain=1.0),
+            projection_norm=make_norm(cfg, "per_layer_embedding.projection_norm", cfg.ple_dim))
     return D.ModelBundle(
         name=cfg.name, vocab_size=cfg.vocab_size, model_dim=d, max_context_length=cfg.max_context_length,
         rope=cfg.rope, embedding=embedding, output_norm=make_norm(cfg, "output_norm", d), layers=layers,
-        tied_embeddings=cfg.tied_embeddings, output_embedding=output_embedding)
+        tied_embeddings=cfg.tied_embeddings, output_embedding=output_embedding,
+        ropes=list(cfg.layer_ropes) if cfg.layer_ropes else None,
+        embedding_norm=make_norm(cfg, "embedding_norm", d) if cfg.embedding_norm else D.ABSENT_NORM, ple=ple)
 
 
 def synthetic_prompt(length: int, vocab_size: int, variant: int = 0, suffix: int = 16) -> np.ndarray:
