@@ -48,6 +48,10 @@ def variants():
     yield "longrope", S.tiny_llama(rope=D.RopeConfig(kind=D.ROPE_LONGROPE, head_dim=64, max_sequence_length=8192, base=10000.0, scaling_factor=8.0,
                                                      original_context_length=1024, short_factor=rng.uniform(1.0, 1.2, 32).astype(np.float32),
                                                      long_factor=rng.uniform(1.0, 6.0, 32).astype(np.float32)))
+    # the Gemma-family layer / decoder options (transformer_layer.rs:61-184, decoder.rs:68-99): two RoPE configurations, sandwich norms with
+    # post-layer scalars, value normalisation, two layers sharing an earlier layer's KV state, per-layer embeddings; + embedding norm, no first pre-mixer norm
+    yield "tiny-gemma", S.tiny_gemma(ple_dim=32)
+    yield "tiny-gemma-embedding-norm", S.tiny_gemma(ple_dim=0, embedding_norm=True, first_layer_without_pre_mixer_norm=True, kv_sharing={4: 1})
 
 
 @pytest.mark.parametrize("name,cfg", list(variants()), ids=[n for n, _ in variants()])
@@ -222,3 +226,41 @@ def test_tensor_validation_matches_the_reference(tmp_path):
         f.write((10 ** 12).to_bytes(8, "little"))
     with pytest.raises(L.ModelFormatError, match="header length"):
         L.load_model_dir(d)
+
+
+def test_gemma_family_options_reach_the_config_and_inconsistent_ones_are_refused(tmp_path):
+    """What save_model_dir writes for the options is what the reference's config structs name (TransformerLayerConfig::{ple_config,
+    has_post_layer_scalar, kv_source_layer_index, rope_config}, AttentionConfig::{normalize_values, is_kv_sharing}, DecoderConfig::
+    {ple_model_config, embedding_norm_config}); the reference's construction errors are load errors here."""
+    bundle = S.build_model(S.tiny_gemma(ple_dim=32, embedding_norm=True))
+    L.save_model_dir(bundle, str(tmp_path))
+    cfg_path = os.path.join(str(tmp_path), "config.json")
+    cfg = json.load(open(cfg_path))
+    dec = cfg["decoder_config"]
+    layers = dec["transformer_config"]["layer_configs"]
+    assert dec["ple_model_config"]["num_layers"] == 5 and dec["ple_model_config"]["ple_dim"] == 32 and dec["embedding_norm_config"] is not None
+    assert [l["kv_source_layer_index"] for l in layers] == [None, None, None, 0, 1]
+    assert [l["mixer_config"]["is_kv_sharing"] for l in layers] == [False, False, False, True, True]
+    assert all(l["has_post_layer_scalar"] and l["ple_config"]["ple_dim"] == 32 for l in layers)
+    assert layers[0]["rope_config"]["type"] == "UnscaledRoPEConfig" and layers[1]["rope_config"]["type"] == "LinearScalingRoPEConfig"
+    assert layers[0]["mixer_config"]["normalize_values"] is True
+    loaded = L.load_model_dir(str(tmp_path))
+    assert loaded.ropes is not None and [l.rope_index for l in loaded.layers] == [0, 1, 0, 0, 1]
+    assert loaded.layers[3].qkv_projection.n == 4 * 64 and loaded.layers[3].kv_source_layer_index == 0
+
+    def broken(mutate, match, exc=L.ModelFormatError):
+        c = json.loads(json.dumps(cfg))
+        mutate(c["decoder_config"])
+        json.dump(c, open(cfg_path, "w"))
+        with pytest.raises(exc, match=match):
+            L.load_model_dir(str(tmp_path))
+    lc = lambda d, i: d["transformer_config"]["layer_configs"][i]
+    broken(lambda d: lc(d, 3)["mixer_config"].update(is_kv_sharing=False), "is_kv_sharing")
+    broken(lambda d: lc(d, 3).update(kv_source_layer_index=4), "not an earlier attention layer")
+    broken(lambda d: lc(d, 4).update(kv_source_layer_index=3), "not an earlier attention layer")
+    broken(lambda d: lc(d, 4).update(kv_source_layer_index=0), "differ in sliding window")
+    broken(lambda d: lc(d, 1).update(post_mlp_norm_config=None), "post-layer scalar")
+    broken(lambda d: lc(d, 1).update(pre_mixer_norm_config=None), "pre_mixer_norm_config")
+    broken(lambda d: d["ple_model_config"].update(num_layers=4), "num_layers")
+    broken(lambda d: d.update(ple_model_config=None), "without decoder_config.ple_model_config")
+    broken(lambda d: lc(d, 2)["ple_config"].update(ple_dim=16), "ple_dim")

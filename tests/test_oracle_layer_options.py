@@ -194,7 +194,7 @@ def test_speculated_tree_on_the_gemma_options_equals_linear_decoding():
     first = om.prefill(PROMPT)
     assert first == lin[0][0]
     chain = [lin[0][0], lin[0][1], lin[0][2]]
-    trie = np.array([[i, len(chain), i] for i in range(len(chain))], np.uint32)  # {trie_start, trie_end, height}: a path
+    trie = np.array([[i, len(chain) - 1, i] for i in range(len(chain))], np.uint32)  # {trie_start, trie_end, height} (subtree range, inclusive): a path
     sampled = om.verify_tree(chain, trie)
     assert list(sampled) == lin[0][1:4]
     om.accept(np.arange(len(chain), dtype=np.uint32))

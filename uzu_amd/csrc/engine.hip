@@ -62,6 +62,9 @@ struct DNorm {
     float eps = 0.f, offset = 0.f;
     float* scales = nullptr;
     float* biases = nullptr;
+    // PostLayerScalar (encodable_block/normalization.rs:17-21,76-80): 0 None, 1 ScaleResidualSum(scalar), 2 ScaleOutput(scalar)
+    int scalar_mode = 0;
+    float scalar = 1.0f;
 };
 struct DLayer {
     uzu_layer_desc d; // scalars only (pointers are host pointers: never dereferenced after create)
@@ -69,7 +72,16 @@ struct DLayer {
     DLinear qkv, gate, out, in_proj, out_proj, up, down;
     float *conv_w = nullptr, *conv_b = nullptr, *a_log = nullptr, *dt_bias = nullptr, *dn_norm = nullptr;
     uint16_t* sinks = nullptr; // bf16 [heads] (has_sinks)
-    uint16_t *keys = nullptr, *values = nullptr;
+    // the layer's RoPE configuration (uzu_model_desc::ropes[rope_index], or the model's single `rope`): tables [max positions][rope_dim]
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    uint32_t rope_dim = 0;
+    // PerLayerEmbeddingProjection (per_layer_embedding.rs:150-271) at the end of the layer (d.has_ple)
+    DLinear ple_gate, ple_projection;
+    DNorm ple_norm;
+    uint16_t *keys = nullptr, *values = nullptr; // a KV-sharing layer (d.is_kv_sharing): its source layer's rows (bind_state)
+    // the last layer that reads this layer's KV state in a pass (itself, or the last layer sharing it): a ring takes the pass's suffix rows
+    // (encode_accept, after the WHOLE pass in the reference: stream.rs:441-444) only once that layer has run
+    uint32_t last_reader = 0;
     float *conv_state = nullptr, *ssm_state = nullptr;
     size_t conv_state_bytes = 0, ssm_state_bytes = 0;
 };
@@ -110,7 +122,18 @@ struct uzu_hip_model {
     std::vector<size_t> allocation_bytes; // parallel to `allocations` (context memory accounting)
     size_t weight_bytes = 0;
 
-    float *rope_cos = nullptr, *rope_sin = nullptr;
+    struct RopeTable {
+        float *cos = nullptr, *sin = nullptr;
+        uint32_t dim = 0;
+    };
+    std::vector<RopeTable> ropes; // one per distinct RoPE configuration (transformer.rs:101-118)
+    DNorm embedding_norm;         // decoder.rs:68-83
+    // PerLayerEmbedding (per_layer_embedding.rs:36-148): token table + projection of the embedded rows -> per_layer_inputs [rows][layers][ple_dim]
+    DLinear ple_token_embedding, ple_model_projection;
+    DNorm ple_projection_norm;
+    uint16_t *ple_inputs = nullptr, *ple_token = nullptr, *ple_projected = nullptr; // [rows][layers * ple_dim]
+    uint16_t *ple_gate_out = nullptr, *ple_activated = nullptr;                      // [rows][ple_dim]
+    bool gemma_options = false; // any option that only the one-kernel-per-reference-kernel pass implements (no fused decode step, no tensor parallelism)
     // device-resident sequence state
     uint32_t* d_ctx_len = nullptr;  // current context length
     uint32_t* d_tokens = nullptr;   // [1024] input token ids of the pass
@@ -306,7 +329,9 @@ uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
     for (size_t l = 0; l < m->layers.size(); ++l) {
         const uzu_layer_desc& h = m->layers[l].d;
         void* p = nullptr;
-        if (h.mixer_kind == UZU_MIXER_ATTENTION) {
+        if (h.mixer_kind == UZU_MIXER_ATTENTION && h.is_kv_sharing) {
+            // TransformerLayerStateType::Shared(kv_source_layer_index) (transformer.rs:205-216): no state of its own
+        } else if (h.mixer_kind == UZU_MIXER_ATTENTION) {
             // AttentionState::create_empty (state.rs:69-136): a causal sliding-window layer keeps a RING of `window` rows + the suffix region
             const size_t kv_rows = h.sliding_window_size ? (size_t)h.sliding_window_size + m->chunk : (size_t)m->max_positions;
             const size_t kv_bytes = kv_rows * h.num_groups * h.head_dim * 2;
@@ -339,7 +364,9 @@ void bind_state(uzu_hip_model* m, uzu_hip_state* st) {
         m->bound->graph_single = m->graph_single, m->bound->graph_two = m->graph_two, m->bound->graph_epoch = m->graph_epoch;
     }
     for (size_t l = 0; l < m->layers.size(); ++l) {
-        m->layers[l].keys = st->layers[l].keys, m->layers[l].values = st->layers[l].values;
+        // a KV-sharing layer reads the rows of the layer that owns them (MaybeMut::Const(owned layer state), transformer.rs:264-275)
+        const size_t src = m->layers[l].d.mixer_kind == UZU_MIXER_ATTENTION && m->layers[l].d.is_kv_sharing ? m->layers[l].d.kv_source_layer_index : l;
+        m->layers[l].keys = st->layers[src].keys, m->layers[l].values = st->layers[src].values;
         m->layers[l].conv_state = st->layers[l].conv_state, m->layers[l].ssm_state = st->layers[l].ssm_state;
     }
     m->d_ctx_len = st->d_ctx_len, m->d_tokens = st->d_tokens, m->d_out_token = st->d_out_token, m->d_sampled = st->d_sampled;
@@ -689,7 +716,8 @@ k::NormParams norm_params(Enc& e, const DNorm& N, const uint16_t* input, uint16_
     p.input = input, p.scales = N.scales, p.biases = N.biases, p.output = output, p.shortcut = mode ? shortcut : nullptr;
     p.io_dt = UZU_BF16, p.affine_dt = UZU_F32;
     p.batch_size = rows, p.element_count = dim;
-    p.epsilon = N.eps, p.scale_offset = N.offset, p.post_layer_scalar = 1.0f;
+    p.epsilon = N.eps, p.scale_offset = N.offset, p.post_layer_scalar = N.scalar_mode ? N.scalar : 1.0f;
+    p.scale_residual_sum = N.scalar_mode == 1, p.scale_output = N.scalar_mode == 2;
     p.subtract_mean = N.subtract_mean, p.full_layer = N.full_layer;
     p.copy_to_shortcut = mode != 0, p.residual_add = mode == 2;
     uzu_hip_model* m = e.m;
@@ -757,14 +785,17 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
 // `first_done`: the layer's first projection (qkv; the DeltaNet in-projection) has been run with its Normalization prologue already (linear_normed)
 void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post = nullptr, bool first_done = false) {
     uzu_hip_model* m = e.m;
-    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
+    // KV sharing: the packed projection yields queries only, key / value norms are dropped (mixer/attention/mod.rs:80-95,135-137)
+    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.is_kv_sharing ? 0u : L.d.num_groups, total_heads = nq + 2 * nkv;
     const uint32_t rows = q.rows();
     if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, rows);
     if (!first_done) linear(e, L.qkv, hidden, m->qkv, rows);
     if (L.qn.present)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, rows, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
-    if (L.kn.present)
+    if (L.kn.present && nkv)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.kn.scales, rows, total_heads, hd, L.kn.eps, L.kn.offset, nq, nkv, L.kn.full_layer));
+    if (L.d.normalize_values && nkv) // AttentionConfig::value_norm_config (config/token_mixer/attention.rs:32-42): eps 1e-6, FullLayer, no scales
+        RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, nullptr, rows, total_heads, hd, 1e-6f, 0.0f, nq + nkv, nkv, 1));
     if (q.n == 0) {
         attention_core(e, L, q.count, 0);
     } else {
@@ -780,17 +811,18 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
 // AttentionPrepare + attention of `batch` rows of the bound sequence, which start at row `row0` of qkv / queries / attn_out
 void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     uzu_hip_model* m = e.m;
-    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + 2 * nkv;
+    const bool has_kv = !L.d.is_kv_sharing; // prepare_queries (mode.rs:234-259): no KV rows are written; the source layer wrote this pass's already
+    const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + (has_kv ? 2 * nkv : 0);
     const uint16_t* qkv = m->qkv + row0 * total_heads * hd;
     uint16_t* queries = m->queries + row0 * nq * hd;
     uint16_t* attn_out = m->attn_out + row0 * nq * hd;
-    const uint32_t rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
+    const uint32_t rope_dim = L.d.use_rope ? L.rope_dim : 0;
     // Ring state (causal sliding window; state.rs:16-55, mode.rs:66-78): the new rows go to the suffix region behind the ring
     // (kv_token_offset = physical_prefix_length = window), the attention sees window + batch rows with ring parameters derived on the
     // device from the accepted-token count, and the rows enter the ring afterwards (encode_accept, state.rs:200-219).
     const uint32_t W = L.d.sliding_window_size;
     const uint32_t* trie = m->tree.active ? m->tree.d_trie : nullptr; // a speculated tree: RoPE positions = context + height, trie mask (mode.rs:178-192)
-    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, m->rope_cos, m->rope_sin, nq, nkv, hd, rope_dim, W, batch, 1,
+    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, L.rope_cos, L.rope_sin, nq, nkv, hd, rope_dim, W, batch, has_kv ? 1u : 0u,
                                m->d_ctx_len, W ? 1u : 0u, trie));
     k::AttentionParams a{};
     a.queries = queries, a.keys = L.keys, a.values = L.values;
@@ -814,7 +846,8 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     } else {
         RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, attn_out));
     }
-    if (W && !trie) RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
+    if (W && !trie && has_kv && L.last_reader == (uint32_t)(&L - m->layers.data()))
+        RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
 }
 
 void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
@@ -914,6 +947,26 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     if (m->embedding.out_signs)
         RUN("activation_transform", 0, k::activation_transform(s, nullptr, hidden, nullptr, nullptr, nullptr, m->embedding.out_signs, UZU_BF16, rows, d,
                                                                 UZU_ACTIVATION_TRANSFORM_OUTPUT_RHT, 0, 0));
+    // Decoder::encode (decoder.rs:149-154): the embedding norm, no shortcut
+    if (m->embedding_norm.present) {
+        norm(e, m->embedding_norm, hidden, m->normed, nullptr, 0, rows, d);
+        RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, rows * d));
+    }
+    // PerLayerEmbedding::encode (per_layer_embedding.rs:108-147): per_layer_inputs [rows][layers][ple_dim] = token table row * (ple_embed_scale *
+    // input_scale) + projection_norm(model_projection(embedded rows)) [ScaleOutput(input_scale); epsilon / model_projection_scale^2 at load]
+    if (m->d.has_ple) {
+        const uint32_t total = m->d.num_layers * m->d.ple_dim;
+        const DLinear& T = m->ple_token_embedding;
+        const float fused_token_scale = m->d.ple_embed_scale * m->d.ple_input_scale; // per_layer_embedding.rs:103
+        if (T.method == UZU_QUANT_NONE)
+            RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, token_ids, T.w, m->ple_token, UZU_BF16, rows, m->d.ple_vocab_size, total, fused_token_scale));
+        else
+            RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, token_ids, (const uint8_t*)T.w, T.scales, T.zp, T.biases, m->ple_token, UZU_BF16, rows,
+                                                m->d.ple_vocab_size, total, fused_token_scale, T.group, T.bits, T.method));
+        linear(e, m->ple_model_projection, hidden, m->ple_projected, rows);
+        norm(e, m->ple_projection_norm, m->ple_projected, m->ple_inputs, nullptr, 0, rows * m->d.num_layers, m->d.ple_dim);
+        RUN("tensor_add_scale", 0, k::tensor_add_scale(s, m->ple_token, m->ple_inputs, m->ple_inputs, UZU_BF16, rows * total, rows * total, 1.0f));
+    }
     // Prefill-sized passes: a row-parallel projection whose rows go straight into the next Normalization hands that normalisation to its GEMM
     // (PostNorm: the split-K reduction, the epilogue and the normalisation of a row are one launch).  `hidden_normed`: the pre-mixer normalisation of
     // the layer about to run has been done that way by the previous layer's down projection.
@@ -944,7 +997,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         }
         hidden_normed = false;
         PostNorm mlp_norm; // the pre-MLP normalisation, offered to the mixer's out projection when nothing sits between them
-        const bool offer_mlp = !L.post_mixer.present && rows >= 128;
+        const bool offer_mlp = !L.post_mixer.present && rows >= 128 && !L.pre_mlp.scalar_mode;
         if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, sc_cur, 2, rows, d, &L.up);
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
             attention_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr, first_done);
@@ -970,7 +1023,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         }
         // the next layer's pre-mixer normalisation rides on this layer's down projection (not past the last layer: the output norm takes one row)
         PostNorm next_norm;
-        const bool offer_next = rows >= 128 && !L.post_mlp.present && l + 1 < m->d.num_layers && m->layers[l + 1].pre_mixer.present;
+        const bool offer_next = rows >= 128 && !L.post_mlp.present && !L.d.has_ple && l + 1 < m->d.num_layers && m->layers[l + 1].pre_mixer.present;
         if (offer_next) {
             const DLayer& Nx = m->layers[l + 1];
             next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, sc_cur, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
@@ -984,6 +1037,28 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             norm(e, L.post_mlp, hidden, m->normed, nullptr, 0, rows, d);
             RUN("tensor_copy", 0, k::tensor_copy(s, m->normed, hidden, UZU_BF16, rows * d));
         }
+        if (L.d.has_ple) {
+            // PerLayerEmbeddingProjection::encode (per_layer_embedding.rs:217-270): shortcut += hidden; gate(shortcut) -> act(gate) * this layer's slice
+            // of per_layer_inputs -> projection -> norm; shortcut = (shortcut + normed) * post_layer_scalar; hidden = 0 (transformer_layer.rs:231)
+            const uint32_t length = rows * d, pd = L.d.ple_dim;
+            RUN("tensor_add_bias", 0, k::tensor_add_bias(s, nullptr, hidden, sc_cur, UZU_BF16, UZU_BF16, length, length));
+            linear(e, L.ple_gate, sc_cur, m->ple_gate_out, rows);
+            RUN("gated_act_mul", 0, k::gated_act_mul(s, m->ple_gate_out, m->ple_inputs, m->ple_activated, UZU_BF16, pd, rows, l * pd, m->d.num_layers * pd, L.d.ple_activation, 0));
+            linear(e, L.ple_projection, m->ple_activated, m->mixed, rows);
+            norm(e, L.ple_norm, m->mixed, m->normed, nullptr, 0, rows, d);
+            RUN("tensor_add_scale", 0, k::tensor_add_scale(s, nullptr, m->normed, sc_cur, UZU_BF16, length, length, L.d.has_post_layer_scalar ? L.d.post_layer_scalar : 1.0f));
+            HIPCHK(hipMemsetAsync(hidden, 0, (size_t)length * 2, s));
+        }
+        // a ring whose rows later layers of this pass still had to read takes the pass's suffix rows now (DLayer::last_reader)
+        if (!m->tree.active)
+            for (uint32_t o = 0; o < l; ++o) {
+                DLayer& Lo = m->layers[o];
+                if (Lo.d.mixer_kind != UZU_MIXER_ATTENTION || Lo.d.is_kv_sharing || !Lo.d.sliding_window_size || Lo.last_reader != l) continue;
+                for (uint32_t i = 0; i < (q.n ? q.n : 1u); ++i) {
+                    if (q.n) bind_state(m, q.st[i]);
+                    RUN("kv_ring_insert", 0, k::kv_ring_insert(s, Lo.keys, Lo.values, UZU_BF16, m->d_ctx_len, count, Lo.d.sliding_window_size, Lo.d.num_groups * Lo.d.head_dim));
+                }
+            }
         if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, count * d));
     }
     m->tap_rows = count;
@@ -1128,11 +1203,12 @@ bool linear_fusable(const DLinear& L) {
     if (L.method == UZU_QUANT_NONE || (L.bits != 4 && L.bits != 8)) return false;
     return L.k % 32 == 0 && L.group % 32 == 0 && (L.group & (L.group - 1)) == 0 && L.k <= 32768;
 }
-bool norm_fusable(const DNorm& N) { return N.present && !N.subtract_mean && !N.biases; }
+bool norm_fusable(const DNorm& N) { return N.present && !N.subtract_mean && !N.biases && !N.scalar_mode; }
 // the fused Normalization prologue needs model_dim % 1024 == 0 and <= 8192 (k_decode.hip)
 bool dim_fusable(uint32_t d) { return d % 1024 == 0 && d <= 8192; }
 
 bool model_fusable(const uzu_hip_model* m) {
+    if (m->gemma_options) return false; // post-layer scalars, embedding norm, KV sharing, value normalisation, per-layer embeddings: the one-kernel-per-reference-kernel pass
     if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f) return false;
     if (!dim_fusable(m->d.model_dim)) return false;
     if (!norm_fusable(m->output_norm)) return false;
@@ -1236,10 +1312,10 @@ uzu_status encode_decode_fused(uzu_hip_model* m, hipStream_t s, bool with_embed)
                 if (L.d.has_gate) out_transform(L.gate, m->gate);
             }
             k::AttnDecParams a{};
-            a.qkv = m->qkv, a.keys = L.keys, a.values = L.values, a.cosines = m->rope_cos, a.sines = m->rope_sin, a.ctx_len = m->d_ctx_len;
+            a.qkv = m->qkv, a.keys = L.keys, a.values = L.values, a.cosines = L.rope_cos, a.sines = L.rope_sin, a.ctx_len = m->d_ctx_len;
             a.q_norm = {L.qn.present, L.qn.full_layer, L.qn.eps, L.qn.offset, L.qn.scales};
             a.k_norm = {L.kn.present, L.kn.full_layer, L.kn.eps, L.kn.offset, L.kn.scales};
-            a.num_heads = nq, a.gqa_factor = nq / nkv, a.head_dim = hd, a.rope_dim = L.d.use_rope ? m->d.rope.head_dim : 0;
+            a.num_heads = nq, a.gqa_factor = nq / nkv, a.head_dim = hd, a.rope_dim = L.d.use_rope ? L.rope_dim : 0;
             a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
             a.partials = m->dec_partials, a.sums = m->dec_sums, a.maxs = m->dec_maxs, a.cache_rows = m->max_positions;
             const size_t kv_bytes = (size_t)2 * (m->context_length + 1) * nkv * hd * 2;
@@ -1465,6 +1541,24 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     TRY(upload_linear(m, desc->embedding, &m->embedding, true));
     if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding, true));
     TRY(upload_norm(m, desc->output_norm, d, &m->output_norm));
+    TRY(upload_norm(m, desc->embedding_norm, d, &m->embedding_norm));
+    m->gemma_options = desc->embedding_norm.present || desc->has_ple;
+    if (desc->has_ple) { // PerLayerEmbedding::new (per_layer_embedding.rs:47-106)
+        const uint32_t total = desc->num_layers * desc->ple_dim;
+        if (!desc->ple_dim || desc->ple_token_embedding.k != total || desc->ple_token_embedding.n != desc->ple_vocab_size || desc->ple_model_projection.n != total ||
+            desc->ple_model_projection.k != d || !desc->ple_projection_norm.present || desc->ple_model_projection_scale == 0.0f) {
+            set_error("model_create: per-layer embedding shapes inconsistent (token table [%u, %u], projection [%u, %u], %u layers x ple_dim %u)", desc->ple_token_embedding.n,
+                      desc->ple_token_embedding.k, desc->ple_model_projection.n, desc->ple_model_projection.k, desc->num_layers, desc->ple_dim);
+            return fail(UZU_ERR_INVALID_ARGUMENT);
+        }
+        TRY(upload_linear(m, desc->ple_token_embedding, &m->ple_token_embedding, true));
+        TRY(upload_linear(m, desc->ple_model_projection, &m->ple_model_projection));
+        TRY(upload_norm(m, desc->ple_projection_norm, desc->ple_dim, &m->ple_projection_norm));
+        // per_layer_embedding.rs:75-90: epsilon / model_projection_scale^2, PostLayerScalar::ScaleOutput(input_scale)
+        m->ple_projection_norm.eps = desc->ple_projection_norm.epsilon / (desc->ple_model_projection_scale * desc->ple_model_projection_scale);
+        m->ple_projection_norm.scalar_mode = 2, m->ple_projection_norm.scalar = desc->ple_input_scale;
+    }
+    if (desc->num_ropes && !desc->ropes) return fail((set_error("model_create: num_ropes without a ropes table"), UZU_ERR_INVALID_ARGUMENT));
     m->chunk = prefill_chunk_rows();
     m->max_positions = desc->max_context_length + m->chunk;
     m->layers.resize(desc->num_layers);
@@ -1481,6 +1575,30 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             set_error("model_create: layer %u has no pre_mlp_norm", l);
             return fail(UZU_ERR_INVALID_ARGUMENT);
         }
+        if (!L.pre_mixer.present && l != 0) { // TransformerLayerError::MissingPreMixerNormConfig (transformer_layer.rs:110-114)
+            set_error("model_create: layer %u has no pre_mixer_norm (only the first layer may omit it)", l);
+            return fail(UZU_ERR_INVALID_ARGUMENT);
+        }
+        L.last_reader = l;
+        if (h.has_post_layer_scalar) {
+            if (!L.post_mlp.present) { // TransformerLayerError::PostLayerScalarWithoutPostMlpNorm (transformer_layer.rs:61-66)
+                set_error("model_create: layer %u has a post-layer scalar but no post_mlp_norm", l);
+                return fail(UZU_ERR_INVALID_ARGUMENT);
+            }
+            if (!h.has_ple) // with a PLE projection the projection owns the scalar (transformer_layer.rs:78-84)
+                L.pre_mlp.scalar_mode = 1, L.pre_mlp.scalar = h.post_layer_scalar, L.post_mlp.scalar_mode = 2, L.post_mlp.scalar = h.post_layer_scalar;
+            m->gemma_options = true;
+        }
+        if (h.has_ple) { // PerLayerEmbeddingProjection::new (per_layer_embedding.rs:166-215)
+            if (!desc->has_ple || h.ple_dim != desc->ple_dim || h.ple_gate.n != h.ple_dim || h.ple_gate.k != d || h.ple_projection.n != d || h.ple_projection.k != h.ple_dim ||
+                !h.ple_norm.present) {
+                set_error("model_create: layer %u per-layer embedding projection inconsistent with the model's per-layer embedding", l);
+                return fail(UZU_ERR_INVALID_ARGUMENT);
+            }
+            TRY(upload_linear(m, h.ple_gate, &L.ple_gate));
+            TRY(upload_linear(m, h.ple_projection, &L.ple_projection));
+            TRY(upload_norm(m, h.ple_norm, d, &L.ple_norm));
+        }
         TRY(upload_linear(m, h.up_projection, &L.up));
         TRY(upload_linear(m, h.down_projection, &L.down));
         if (h.up_projection.n != 2 * h.hidden_dim || h.down_projection.k != h.hidden_dim) {
@@ -1489,6 +1607,33 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         }
         max_hidden = max_hidden > h.hidden_dim ? max_hidden : h.hidden_dim;
         if (h.mixer_kind == UZU_MIXER_ATTENTION) {
+            if (h.is_kv_sharing) { // TransformerLayerStateType::Shared (transformer.rs:205-216, 264-275)
+                const uint32_t src = h.kv_source_layer_index;
+                if (src >= l || desc->layers[src].mixer_kind != UZU_MIXER_ATTENTION || desc->layers[src].is_kv_sharing) {
+                    set_error("model_create: layer %u shares the KV state of layer %u, which is not an earlier attention layer that owns its state", l, src);
+                    return fail(UZU_ERR_INVALID_ARGUMENT);
+                }
+                // the core's ring / window specialisation comes from the layer's own config, the ring parameters from the state it reads
+                // (mixer/attention/mod.rs:166-198, core/single_pass.rs:60-70): only equal geometry is a meaningful configuration
+                const uzu_layer_desc& S = desc->layers[src];
+                if (S.sliding_window_size != h.sliding_window_size || S.num_groups != h.num_groups || S.head_dim != h.head_dim) {
+                    set_error("model_create: layer %u and its KV source %u differ in window / kv heads / head_dim", l, src);
+                    return fail(UZU_ERR_INVALID_ARGUMENT);
+                }
+                m->layers[src].last_reader = l;
+                m->gemma_options = true;
+            }
+            if (h.normalize_values) m->gemma_options = true;
+            if (h.is_kv_sharing && h.qkv_projection.n != h.num_heads * h.head_dim) { // queries only (mixer/attention/mod.rs:89-95)
+                set_error("model_create: KV-sharing layer %u: the packed projection has %u rows, expected heads * head_dim = %u", l, h.qkv_projection.n, h.num_heads * h.head_dim);
+                return fail(UZU_ERR_INVALID_ARGUMENT);
+            }
+            if (h.use_rope) { // (tables are uploaded below; here only the index check)
+                if (desc->num_ropes ? h.rope_index >= desc->num_ropes : desc->rope.kind == UZU_ROPE_NONE) {
+                    set_error("model_create: layer %u rotates with a RoPE configuration the model does not carry", l);
+                    return fail(UZU_ERR_INVALID_ARGUMENT);
+                }
+            }
             TRY(upload_linear(m, h.qkv_projection, &L.qkv));
             if (h.has_gate) TRY(upload_linear(m, h.gate_projection, &L.gate));
             TRY(upload_linear(m, h.out_projection, &L.out));
@@ -1522,13 +1667,29 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             max_hv = max_hv > h.dn_num_heads ? max_hv : h.dn_num_heads;
         }
     }
-    if (desc->rope.kind != UZU_ROPE_NONE) {
-        std::vector<float> c, sn;
-        rope_tables(desc->rope, m->max_positions, c, sn);
-        size_t saved = m->weight_bytes;
-        TRY(upload(m, c.data(), c.size() * 4, &m->rope_cos));
-        TRY(upload(m, sn.data(), sn.size() * 4, &m->rope_sin));
+    {   // one table pair per distinct RoPE configuration (Transformer::new dedups them, transformer.rs:101-118); a layer points at its own
+        const uint32_t n_ropes = desc->num_ropes ? desc->num_ropes : (desc->rope.kind != UZU_ROPE_NONE ? 1u : 0u);
+        m->ropes.resize(n_ropes);
+        const size_t saved = m->weight_bytes;
+        for (uint32_t r = 0; r < n_ropes; ++r) {
+            const uzu_rope_desc& R = desc->num_ropes ? desc->ropes[r] : desc->rope;
+            if (R.kind == UZU_ROPE_NONE || !R.head_dim) return fail((set_error("model_create: RoPE configuration %u is empty", r), UZU_ERR_INVALID_ARGUMENT));
+            std::vector<float> c, sn;
+            rope_tables(R, m->max_positions, c, sn);
+            TRY(upload(m, c.data(), c.size() * 4, &m->ropes[r].cos));
+            TRY(upload(m, sn.data(), sn.size() * 4, &m->ropes[r].sin));
+            m->ropes[r].dim = R.head_dim;
+        }
         m->weight_bytes = saved;
+        for (DLayer& L : m->layers)
+            if (L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.use_rope) {
+                const uzu_hip_model::RopeTable& T = m->ropes[desc->num_ropes ? L.d.rope_index : 0];
+                L.rope_cos = T.cos, L.rope_sin = T.sin, L.rope_dim = T.dim;
+            }
+    }
+    if (m->tp && m->gemma_options) {
+        set_error("model_create: post-layer scalars, embedding norm, KV sharing, value normalisation and per-layer embeddings are not sharded (single GPU only)");
+        return fail(UZU_ERR_UNSUPPORTED);
     }
     void* p;
     const size_t C = m->chunk;
@@ -1566,6 +1727,14 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         ALLOC(decay, float, C * max_hv);
     }
     ALLOC(shortcut_b, uint16_t, C * d);
+    if (desc->has_ple) {
+        const size_t total = (size_t)desc->num_layers * desc->ple_dim;
+        ALLOC(ple_inputs, uint16_t, CB * total);
+        ALLOC(ple_token, uint16_t, CB * total);
+        ALLOC(ple_projected, uint16_t, CB * total);
+        ALLOC(ple_gate_out, uint16_t, CB * desc->ple_dim);
+        ALLOC(ple_activated, uint16_t, CB * desc->ple_dim);
+    }
     if (m->rht_max_k) ALLOC(rht_scratch, uint16_t, CB * m->rht_max_k);
     if (m->lora_max_rank) ALLOC(lora_scratch, uint16_t, CB * m->lora_max_rank);
     ALLOC(amax_val, float, kArgmaxPartials);
@@ -2128,6 +2297,7 @@ uzu_status uzu_hip_model_accept(uzu_hip_model* m, const uint32_t* accepted_indic
         if (accepted_indices[i] != i) copies.push_back({m->context_length + accepted_indices[i], m->context_length + i});
     for (size_t l = 0; l < m->layers.size(); ++l) {
         DLayer& L = m->layers[l];
+        if (L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.is_kv_sharing) continue; // TransformerLayerStateType::Shared: nothing of its own to accept (transformer.rs:63-69)
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION && L.d.sliding_window_size) {
             // AttentionStateType::Ring (state.rs:200-219): the accepted suffix rows (behind the ring, at window + index) enter the ring one by
             // one; with n tokens accepted so far the next slot is n mod window (what the offset / length bookkeeping amounts to)

@@ -166,7 +166,7 @@ def tiny_gemma(**kw) -> ModelConfig:
         name="tiny-gemma", vocab_size=1024, model_dim=256, hidden_dim=512,
         layer_kinds=[D.MIXER_ATTENTION] * 5, num_heads=4, num_groups=2, head_dim=64, qk_norm=True,
         rope=local, layer_ropes=[local, glob], rope_pattern=[0, 1, 0, 0, 1], sliding_windows=[48, 0, 48, 48, 0],
-        kv_sharing={3: 0, 4: 1}, post_norms=True, post_layer_scalars=True, normalize_values=True, ple_dim=32,
+        kv_sharing={3: 0, 4: 1}, post_norms=True, post_layer_scalars=True, normalize_values=True, ple_dim=256,
         norm_epsilon=1e-6, norm_scale_offset=1.0, norm_full_layer=True,
         bits=4, group_size=32, method=D.QUANT_SCALE_BIAS, tied_embeddings=True, max_context_length=2048, seed=77)
     return replace(cfg, **kw)

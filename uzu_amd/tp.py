@@ -239,6 +239,10 @@ def shard_bundle(bundle: D.ModelBundle, rank: int, size: int) -> Tuple[D.ModelBu
     # lookup's OutputRht on the replicated table, the read-out's InputRht on the normalised row -- which the vocabulary split does not cut:
     # the shard's read-out keeps them whole as its input factors (a tied table's output factors ARE the read-out's input factors,
     # embedding.rs:167-173).  Only the combinations the reference does not have either are refused.
+    # Not planned either: the Gemma-family options that only the one-kernel-per-reference-kernel pass implements (the engine refuses them on a shard too)
+    if bundle.embedding_norm.present or bundle.ple is not None or any(
+            l.post_layer_scalar is not None or l.kv_source_layer_index is not None or l.normalize_values or l.ple is not None for l in bundle.layers):
+        raise NotImplementedError("tensor-parallel shards of models with post-layer scalars, an embedding norm, KV sharing, value normalisation or per-layer embeddings")
     emb, out_emb = bundle.embedding, bundle.output_embedding
     if emb.input_signs is not None or (out_emb is not None and out_emb.output_signs is not None):
         raise NotImplementedError("tensor-parallel shards of RHT embeddings: input factors on the lookup table / output factors on the read-out are not a HybridSpec embedding form")
