@@ -12,7 +12,8 @@ from dataclasses import replace
 import numpy as np
 import pytest
 
-from helpers import bf16, f32, ulp_diff_bf16
+from helpers import bf16, f32, quant_matrix, ulp_diff_bf16
+from test_gpu_kernels import activations, hip_matmul, oracle_matmul
 from oracle import oracle as O
 from uzu_amd import _ffi
 from uzu_amd import backend as B
@@ -130,6 +131,41 @@ def test_long_prompt_takes_the_prefill_gemm_paths_with_every_option(hip_ctx):
     assert worst <= 0.25, f"logits {worst:.3f} sigma off the oracle's"
     hm.close()
     om.close()
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_prompt_fed_in_two_passes_stops_the_first_behind_the_last_owning_layer(hip_ctx, exact, monkeypatch):
+    """Transformer::prefill_cache_layer_count (transformer.rs:186-199,239-243): a pass without output runs only up to the last layer that owns a
+    state -- here layers 3 and 4 (KV sharing) are skipped in the first pass of a 1100-token prompt (1024 + 76 rows: the reference's own passes in
+    reference-order mode, UZU_PREFILL_CHUNK=1024 in production mode), and the ring of layer 0, whose last reader was skipped, takes its rows behind
+    layer 2.  The oracle runs every layer in both passes: same logits (bit-identical / within tolerance), same tokens."""
+    monkeypatch.setenv("UZU_PREFILL_CHUNK", "1024")
+    cfg = S.tiny_gemma(embedding_norm=True, max_context_length=1200)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(1100, cfg.vocab_size)
+    om = O.OracleModel(bundle)
+    _set_exact(bool(exact))
+    try:
+        hm = HipModel(hip_ctx, bundle)
+        o_tok, o_logits = om.prefill(prompt, True)
+        h_tok = hm.prefill(prompt)
+        worst = 0.0
+        for step in range(4):
+            got = hm.read_logits()
+            if exact:
+                assert np.array_equal(o_logits, got), f"step {step}: {(o_logits != got).sum()} of {got.size} logits differ"
+                assert h_tok == o_tok
+            else:
+                worst = max(worst, sigma_error(o_logits, got))
+                assert h_tok == o_tok or top2_gap(o_logits) < 0.05
+                hm.set_next_token(o_tok)
+            o_tok, o_logits = om.forward([o_tok], True)
+            h_tok = int(hm.decode(1)[0][0])
+        assert worst <= 0.25
+        hm.close()
+    finally:
+        _set_exact(False)
+        om.close()
 
 
 def test_layer_taps_with_every_option_in_reference_order_mode(hip_ctx):
@@ -287,3 +323,45 @@ def test_normalization_post_layer_scalar_specialisations(hip_ctx, which, full_la
     assert np.array_equal(bsc.download(np.uint16, rows * dim).reshape(rows, dim), want_sc)
     assert ulp_diff_bf16(want, got).max() <= (1.0 if full_layer else 2.0)
     assert (want == got).mean() >= 0.98
+
+
+@pytest.mark.parametrize("bits,method", [(4, 0), (4, 1), (8, 2)])
+@pytest.mark.parametrize("m", [1, 3, 16, 130])
+@pytest.mark.parametrize("n,k", [(256, 32), (32, 256), (40, 64), (256, 96), (1280, 160)])
+def test_matmul_with_the_short_reductions_of_a_per_layer_embedding(hip_ctx, bits, method, m, n, k):
+    """A PLE projection reduces over ple_dim and a PLE gate has ple_dim outputs: K and N far below the layer shapes of the other matmul tests
+    (K = 32: one 32-weight lane step; N = 32 / 40: a fraction of a tile) through every kernel the row count selects (decode GEMV, few-rows,
+    64-tile and 128-tile GEMMs or their fall-backs).  Same bar as test_gemv_quant_variants / test_gemm_mfma_variants."""
+    rng = np.random.default_rng(bits * 1000 + method * 100 + m + n + k)
+    q = quant_matrix(rng, n, k, bits, 32, method)
+    a = activations(rng, m, k)
+    want, got = oracle_matmul(a, q, m), hip_matmul(hip_ctx, a, q, m)
+    ulps = ulp_diff_bf16(want, got)
+    assert ulps.max() <= 1.0, f"max {ulps.max()} bf16 ulps"
+    assert (want == got).mean() >= 0.97
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_per_layer_embedding_of_32_dimensions(hip_ctx, exact):
+    cfg = S.tiny_gemma(ple_dim=32)
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(150, cfg.vocab_size)
+    om = O.OracleModel(bundle)
+    _set_exact(bool(exact))
+    try:
+        hm = HipModel(hip_ctx, bundle)
+        o_tok, o_logits = om.prefill(prompt, True)
+        hm.prefill(prompt)
+        for step in range(4):
+            got = hm.read_logits()
+            if exact:
+                assert np.array_equal(o_logits, got), f"step {step}: {(o_logits != got).sum()} of {got.size} logits differ"
+            else:
+                assert sigma_error(o_logits, got) <= 0.25
+            hm.set_next_token(o_tok)
+            o_tok, o_logits = om.forward([o_tok], True)
+            hm.decode(1)
+        hm.close()
+    finally:
+        _set_exact(False)
+        om.close()

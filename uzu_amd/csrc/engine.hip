@@ -976,7 +976,12 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     uint16_t* sc_cur = m->shortcut;
     auto sc_other = [&]() { return sc_cur == m->shortcut ? m->shortcut_b : m->shortcut; };
     const bool few_rows = !seqs && m->shortcut_b != nullptr;
-    for (uint32_t l = 0; l < m->d.num_layers; ++l) {
+    // Transformer::prefill_cache_layer_count (transformer.rs:186-199,239-243): a pass that produces no output (a prefill chunk that is not the
+    // prompt's last) only has to fill the caches -- it stops behind the last layer that owns a state; trailing KV-sharing layers write nothing
+    uint32_t layer_count = m->d.num_layers;
+    if (!sample && !m->tree.active && !m->taps)
+        while (layer_count > 1 && m->layers[layer_count - 1].d.mixer_kind == UZU_MIXER_ATTENTION && m->layers[layer_count - 1].d.is_kv_sharing) --layer_count;
+    for (uint32_t l = 0; l < layer_count; ++l) {
         DLayer& L = m->layers[l];
         const uint16_t* h = hidden;
         bool first_done = false;
@@ -1023,7 +1028,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         }
         // the next layer's pre-mixer normalisation rides on this layer's down projection (not past the last layer: the output norm takes one row)
         PostNorm next_norm;
-        const bool offer_next = rows >= 128 && !L.post_mlp.present && !L.d.has_ple && l + 1 < m->d.num_layers && m->layers[l + 1].pre_mixer.present;
+        const bool offer_next = rows >= 128 && !L.post_mlp.present && !L.d.has_ple && l + 1 < layer_count && m->layers[l + 1].pre_mixer.present;
         if (offer_next) {
             const DLayer& Nx = m->layers[l + 1];
             next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, sc_cur, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
@@ -1049,11 +1054,13 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
             RUN("tensor_add_scale", 0, k::tensor_add_scale(s, nullptr, m->normed, sc_cur, UZU_BF16, length, length, L.d.has_post_layer_scalar ? L.d.post_layer_scalar : 1.0f));
             HIPCHK(hipMemsetAsync(hidden, 0, (size_t)length * 2, s));
         }
-        // a ring whose rows later layers of this pass still had to read takes the pass's suffix rows now (DLayer::last_reader)
+        // a ring whose rows later layers of this pass still had to read takes the pass's suffix rows now (DLayer::last_reader; at the latest
+        // behind the last layer this pass runs)
         if (!m->tree.active)
-            for (uint32_t o = 0; o < l; ++o) {
+            for (uint32_t o = 0; o <= l; ++o) {
                 DLayer& Lo = m->layers[o];
-                if (Lo.d.mixer_kind != UZU_MIXER_ATTENTION || Lo.d.is_kv_sharing || !Lo.d.sliding_window_size || Lo.last_reader != l) continue;
+                if (Lo.d.mixer_kind != UZU_MIXER_ATTENTION || Lo.d.is_kv_sharing || !Lo.d.sliding_window_size || Lo.last_reader == o) continue; // (== o: inserted by its own launch sequence)
+                if (!(Lo.last_reader == l || (l + 1 == layer_count && Lo.last_reader > l))) continue;
                 for (uint32_t i = 0; i < (q.n ? q.n : 1u); ++i) {
                     if (q.n) bind_state(m, q.st[i]);
                     RUN("kv_ring_insert", 0, k::kv_ring_insert(s, Lo.keys, Lo.values, UZU_BF16, m->d_ctx_len, count, Lo.d.sliding_window_size, Lo.d.num_groups * Lo.d.head_dim));
