@@ -10,10 +10,13 @@
  * PARITY STATUS: the reference is Rust 1.94 (no toolchain in this environment, no network) and
  * ships no golden vectors for this path, so this oracle cannot be checked against outputs of the
  * reference itself: **parity unpinned** except for (a) the literal known answers the reference tree
- * holds (gated_act_mul_test.rs:139-160; gumbel_test.rs: the uniform mapping of the sampler), (b) the
- * published Random123 known-answer vectors of Philox4x32-10, the sampler's generator, and
- * (c) independent float64 NumPy references of the same math, mirroring the reference's own
- * `reference_attention` style checks (tests/test_oracle_*.py).
+ * holds (gated_act_mul_test.rs:139-160; gumbel_test.rs: the uniform mapping of the sampler) and the
+ * expectations its tests compute in-test, independently of any kernel, and hold the CPU backend to
+ * (tensor_add_bias / add_swap / copy, full-precision embedding, the KV-cache copy patterns, gather == dense,
+ * DeltaNet prep's compact V, tree prefix sums: tests/test_reference_vectors.py replays each on the
+ * reference's own procedural inputs), (b) the published Random123 known-answer vectors of Philox4x32-10,
+ * the sampler's generator, and (c) independent float64 NumPy references of the same math, mirroring the
+ * reference's own `reference_attention` style checks (tests/test_oracle_*.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
  * The product (uzu_amd/) never does.

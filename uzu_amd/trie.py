@@ -5,6 +5,8 @@ through tree-verify), ``FlatTrie.accept`` walks the sampled tokens from the root
 sequence state takes exactly that path (``HipModel.accept``).  Same names and meaning as the reference:
 
   TrieNode(token, seed, logprob).add / get / linearize   trie.rs:25-170
+  TrieNode.prune_to_budget / flat                       trie.rs:93-156
+  PRng(seed).derive(index)                              encodable_block/sampling/prng.rs (the per-position sampling seeds of the nodes)
   FlatTrie.token_ids / nodes / accept                   trie.rs:186-305  (nodes = token_subtrie_ranges: {start, end, height})
   parents(nodes)                                        batch_topology.rs:11-37
 """
@@ -13,6 +15,26 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
+
+
+_M64 = (1 << 64) - 1
+
+
+class PRng:
+    """encodable_block/sampling/prng.rs: the 64-bit finaliser (MurmurHash3's fmix64) of seed + index -- the seed of the draw at a position
+    (stream.rs:248-258) and of a trie node (trie.rs:147-151).  The device derives the same numbers (csrc/k_sampling.hip::derive_seed)."""
+
+    def __init__(self, seed: int):
+        self.seed = int(seed) & _M64
+
+    def derive(self, index: int) -> int:
+        h = (self.seed + int(index)) & _M64
+        h ^= h >> 33
+        h = (h * 0xff51afd7ed558ccd) & _M64
+        h ^= h >> 33
+        h = (h * 0xc4ceb9fe1a85ec53) & _M64
+        h ^= h >> 33
+        return h
 
 
 class DuplicateTokenId(ValueError):
@@ -39,14 +61,49 @@ class TrieNode:
     def node_count(self) -> int:
         return 1 + sum(n.node_count() for n in self.next)
 
+    def prune_to_budget(self, budget: int):
+        """Keep the `budget` nodes with the largest cumulative log-probabilities (trie.rs:93-138): a stable descending sort of the DFS order
+        (ties keep the earlier node, i.e. a parent before its child), then every dropped node goes with its whole subtree."""
+        assert budget > 0, "budget must keep at least the root"
+        logprobs: List[float] = []
+
+        def collect(node: "TrieNode", parent: np.float32):
+            lp = np.float32(parent + np.float32(node.logprob))
+            logprobs.append(lp)
+            for child in node.next:
+                collect(child, lp)
+
+        collect(self, np.float32(0.0))
+        if budget >= len(logprobs):
+            return
+        order = sorted(range(len(logprobs)), key=lambda i: -float(logprobs[i]))  # (stable, like slice::sort_by; total_cmp: no NaNs here)
+        kept = [False] * len(logprobs)
+        for i in order[:budget]:
+            kept[i] = True
+        cursor = [0]
+
+        def prune(node: "TrieNode"):
+            cursor[0] += 1
+            children = []
+            for child in node.next:
+                index = cursor[0]
+                prune(child)
+                if kept[index]:
+                    children.append(child)
+            node.next = children
+
+        prune(self)
+
     @classmethod
-    def flat(cls, tokens: Sequence[int]) -> "TrieNode":
-        """A chain (trie.rs:137-152, seeds left at 0: greedy verification draws none)."""
+    def flat(cls, tokens: Sequence[int], prefix_length: int = 0, prng: Optional[PRng] = None) -> "TrieNode":
+        """A chain (trie.rs:140-156): node i carries prng.derive(prefix_length + i); without a prng the seeds stay 0 (greedy verification
+        draws none)."""
         assert len(tokens) > 0, "need seed node"
-        root = cls(tokens[0])
+        seed = (lambda i: prng.derive(prefix_length + i)) if prng is not None else (lambda i: 0)
+        root = cls(tokens[0], seed(0))
         leaf = root
-        for t in tokens[1:]:
-            leaf.add(cls(t))
+        for i, t in enumerate(tokens[1:], start=1):
+            leaf.add(cls(t, seed(i)))
             leaf = leaf.next[0]
         return root
 
@@ -75,6 +132,10 @@ class FlatTrie:
 
     def __len__(self) -> int:
         return len(self._nodes)
+
+    def index(self, node: TrieNode) -> Optional[int]:
+        """Position of THIS node object in the DFS order (trie.rs:262-267: pointer identity, not equality of the fields)."""
+        return next((i for i, n in enumerate(self._nodes) if n is node), None)
 
     def token_ids(self) -> np.ndarray:
         return np.array([n.token for n in self._nodes], dtype=np.uint32)
