@@ -7,6 +7,7 @@ import ctypes as C
 from dataclasses import replace
 
 import numpy as np
+import pytest
 
 from oracle import oracle as O
 from uzu_amd import desc as D
@@ -212,3 +213,14 @@ def test_all_options_together_feed_in_chunks_equals_feed_at_once():
     one, cut = run(b, PROMPT, 5), run(b, PROMPT, 5, chunks=[0, 13, 41, 60])
     assert one[0] == cut[0] and spread(one, cut) <= 0.25
     assert len(set(one[0])) >= 1
+
+
+def test_tensor_parallel_planner_refuses_the_options_by_name():
+    """uzu_amd/tp.py plans column / row splits of plain decoder layers; the options above run on one GPU only (the engine refuses such a shard too)."""
+    from uzu_amd import tp
+    for kw in (dict(), dict(BASE, embedding_norm=True), dict(BASE, normalize_values=True), dict(BASE, post_layer_scalars=True), dict(BASE, kv_sharing={4: 1}),
+               dict(BASE, ple_dim=32)):
+        with pytest.raises(NotImplementedError, match="post-layer scalars, an embedding norm, KV sharing"):
+            tp.shard_bundle(S.build_model(S.tiny_gemma(**kw)), 0, 2)
+    shard, _ = tp.shard_bundle(S.build_model(S.tiny_gemma(**dict(BASE, layer_ropes=S.tiny_gemma().layer_ropes, rope_pattern=[0, 1, 0, 0, 1]))), 0, 2)
+    assert shard.ropes is not None and [l.rope_index for l in shard.layers] == [0, 1, 0, 0, 1], "per-layer RoPE configurations are replicated with the layers"
