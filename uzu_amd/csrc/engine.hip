@@ -263,7 +263,10 @@ uzu_status dev_alloc(uzu_hip_model* m, size_t bytes, void** out, bool zero = fal
     m->allocation_bytes.push_back(alloc);
     m->ctx->current_bytes += alloc;
     if (m->ctx->current_bytes > m->ctx->peak_bytes) m->ctx->peak_bytes = m->ctx->current_bytes;
-    if (zero) HIPCHK(hipMemset(p, 0, alloc));
+    // on the engine's OWN stream: hipMemset runs on the null stream and returns before the fill has happened, and the engine's stream is
+    // hipStreamNonBlocking -- a pass started right after model creation raced the zeroing of its scratch (first model of a process, wide
+    // layers, a short prompt: the tail of the fills -- `logits` -- landed after the pass had written them: token 0)
+    if (zero) HIPCHK(hipMemsetAsync(p, 0, alloc, m->ctx->stream));
     *out = p;
     return UZU_OK;
 }
@@ -293,7 +296,7 @@ uzu_status state_alloc(uzu_hip_state* st, size_t bytes, void** out) {
     uzu_hip_context* ctx = st->m->ctx;
     ctx->current_bytes += alloc;
     if (ctx->current_bytes > ctx->peak_bytes) ctx->peak_bytes = ctx->current_bytes;
-    HIPCHK(hipMemset(p, 0, alloc));
+    HIPCHK(hipMemsetAsync(p, 0, alloc, ctx->stream)); // stream-ordered with every pass that will use the state (see dev_alloc)
     *out = p;
     return UZU_OK;
 }
@@ -1783,6 +1786,12 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         set_error("model_create: hipEventCreate failed");
         return fail(UZU_ERR_HIP);
     }
+    // the fills of the state and scratch blocks and the load-time tables are done before the model is handed out (host-side readers
+    // -- hipMemcpy on the null stream -- are not ordered behind the engine's stream)
+    if (hipStreamSynchronize(m->ctx->stream) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        set_error("model_create: synchronisation after load failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(UZU_ERR_HIP);
+    }
     *out = m;
     return UZU_OK;
 }
@@ -1840,6 +1849,7 @@ uzu_status uzu_hip_state_create(uzu_hip_model* m, uzu_hip_state** out) {
     (void)hipSetDevice(m->ctx->device);
     UZU_PROPAGATE(state_build(m, out));
     m->user_states.push_back(*out);
+    HIPCHK(hipStreamSynchronize(m->ctx->stream)); // the zero fills of the new caches (state_alloc)
     return UZU_OK;
 }
 void uzu_hip_state_destroy(uzu_hip_state* st) {
