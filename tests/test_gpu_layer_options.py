@@ -402,3 +402,45 @@ def test_gemma_shaped_layers_production_against_reference_order(hip_ctx):
         assert got_tok == want_tok or top2_gap(want) < 0.05
     assert worst <= 0.25, f"production logits {worst:.3f} sigma off reference-order mode"
     print(f"gemma-shaped layers: production within {worst:.3f} sigma of reference-order mode")
+
+
+def test_first_model_of_a_fresh_process_with_a_short_prompt():
+    """Regression test of the fill race: `hipMemset` on the null stream returns before the fill has happened and the engine's
+    stream is non-blocking, so the zero fills of a new model's scratch used to land on buffers a SHORT first pass had already written (all-zero logits,
+    token 0) -- only for the first model of a process, which no in-process test can be.  A subprocess creates a 2048-wide model (~200 MB of fills), runs
+    a 70-token prompt at once, production mode first, then reference-order mode: same token, logits within tolerance, no logit exactly 0."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, 'tests')
+from helpers import f32
+from uzu_amd import _ffi, synthetic as S, desc as D
+from uzu_amd.backend import Context
+from uzu_amd.engine import HipModel
+rope = D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=256, max_sequence_length=8192, base=10000.0)
+cfg = S.tiny_llama(name='wide', vocab_size=4096, model_dim=2048, hidden_dim=8192, layer_kinds=[D.MIXER_ATTENTION] * 3, num_heads=8, num_groups=2, head_dim=256,
+                   rope=rope, group_size=128, method=D.QUANT_SCALE_BIAS, max_context_length=1024, seed=91)
+bundle = S.build_model(cfg)
+prompt = S.synthetic_prompt(70, cfg.vocab_size)
+ctx = Context.new(0)
+fn = _ffi.lib().uzu_hip_set_exact
+fn.restype, fn.argtypes = None, [C.c_int32]
+out = []
+for exact in (0, 1):
+    fn(exact)
+    hm = HipModel(ctx, bundle)
+    out.append((hm.prefill(prompt), f32(hm.read_logits()).astype(np.float64)))
+    hm.close()
+fn(0)
+(pt, pl), (et, el) = out
+print('RESULT', pt, et, float(np.abs(pl - el).max() / el.std()), int((pl == 0).sum()))
+"""
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    line = [l for l in res.stdout.splitlines() if l.startswith("RESULT")]
+    assert res.returncode == 0 and line, res.stdout + res.stderr
+    prod_tok, exact_tok, err, zeros = line[0].split()[1:]
+    assert int(zeros) == 0 and float(err) <= 0.25 and prod_tok == exact_tok, line[0]
