@@ -264,3 +264,42 @@ def test_gemma_family_options_reach_the_config_and_inconsistent_ones_are_refused
     broken(lambda d: d["ple_model_config"].update(num_layers=4), "num_layers")
     broken(lambda d: d.update(ple_model_config=None), "without decoder_config.ple_model_config")
     broken(lambda d: lc(d, 2)["ple_config"].update(ple_dim=16), "ple_dim")
+
+
+def test_kv_sharing_layer_with_a_key_norm_config_loads_like_the_reference(tmp_path):
+    """lalamo still writes `key_norm_config` on KV-sharing layers (the TODO at mixer/attention/mod.rs:134): the reference drops the key / value norms of such a
+    layer and never opens `key_norm.scales`.  A config that carries the entry therefore loads -- and, exactly as in the reference, a checkpoint that ALSO holds the
+    tensor is refused, because LanguageModel::load ends with assert_all_tensors_validated (engine/language_model/mod.rs:98, parameters/loader.rs:230-250: every key
+    of the index must have been validated), which lists the unread `...mixer.key_norm.scales`."""
+    import numpy as np
+    bundle = S.build_model(S.tiny_gemma(ple_dim=0))
+    d = str(tmp_path)
+    L.save_model_dir(bundle, d)
+    cfg_path = os.path.join(d, "config.json")
+    cfg = json.load(open(cfg_path))
+    layers = cfg["decoder_config"]["transformer_config"]["layer_configs"]
+    sharing = [i for i, l in enumerate(layers) if l["mixer_config"]["is_kv_sharing"]]
+    assert sharing and all(layers[i]["mixer_config"]["key_norm_config"] is None for i in sharing)
+    donor = next(l["mixer_config"]["key_norm_config"] or l["mixer_config"]["query_norm_config"] for l in layers if not l["mixer_config"]["is_kv_sharing"])
+    assert donor is not None
+    for i in sharing:
+        layers[i]["mixer_config"]["key_norm_config"] = donor
+    json.dump(cfg, open(cfg_path, "w"))
+    loaded = L.load_model_dir(d)  # the config entry alone is ignored (key norm dropped under sharing)
+    assert all(not loaded.layers[i].key_norm.present for i in sharing)
+    bundles_equal(bundle, loaded)
+    # ... with the tensor in the file as well: the reference's load fails with UnvalidatedTensors; so does this one
+    st_path = os.path.join(d, "model.safetensors")
+    raw = open(st_path, "rb").read()
+    hlen = int.from_bytes(raw[:8], "little")
+    header = json.loads(raw[8:8 + hlen])
+    data = raw[8 + hlen:]
+    hd = loaded.layers[sharing[0]].head_dim
+    key = f"decoder.transformer.layers.{sharing[0]}.mixer.key_norm.scales"
+    header[key] = {"dtype": "F32", "shape": [hd], "data_offsets": [len(data), len(data) + 4 * hd]}
+    data += np.ones(hd, dtype="<f4").tobytes()
+    hj = json.dumps(header).encode()
+    hj += b" " * (-len(hj) % 8)
+    open(st_path, "wb").write(len(hj).to_bytes(8, "little") + hj + data)
+    with pytest.raises(L.ModelFormatError, match="never read"):
+        L.load_model_dir(d)
