@@ -49,6 +49,9 @@ def parse_args():
                     "hipIpc mailboxes for every exchange -- RCCL refuses duplicate devices).  The line says so (physical_gpus 1); it is a correctness / "
                     "plumbing run of the p2p + hipGraph decode path, not a scaling measurement")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=3)
+    ap.add_argument("--exact", action="store_true", help="reference-order mode (uzu_hip_set_exact(1): every reduction in the reference's own loop order, logits "
+                    "bit-identical to the CPU oracle's -- tests/test_gpu_model.py::test_exact_mode_*): the price tag of bit-exact logits on the same workload; "
+                    "a side line (config.exact_mode = true), never the headline")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="BASELINE.json configs[1..4]: c2 (default, the headline) Qwen3.5-0.8B int4 ctx-2048 decode; c3 Llama-3-8B int4, 4k prefill x 8 "
                          "sequences in batched passes (prefill tokens/s, MFMA roofline); c4 Llama-3-8B int8 decode (TP = --gpus); c5 Qwen3-14B-class int4 at "
@@ -56,6 +59,8 @@ def parse_args():
     ap.add_argument("--sequences", type=int, default=8, help="c3: sequences per batched prefill pass")
     ap.add_argument("--prompt", type=int, default=4096, help="c3: prompt tokens per sequence")
     args = ap.parse_args()
+    if args.exact:
+        args.steps, args.warmup, args.no_cpu_baseline = min(args.steps, 32), min(args.warmup, 5), True
     if args.config == "c4":
         args.model, args.bits = "llama-3-8b", 8
     elif args.config == "c5":
@@ -94,6 +99,39 @@ def cpu_baseline(bundle, cfg, decode_tokens, context):
             "sample": f"{decode_tokens} greedy decode tokens at context {context}..{context + decode_tokens} (synthetic KV rows instead of a CPU prefill), same "
                       f"weights, 1 thread (the reference CPU backend is single-threaded)",
             "all_cores_value": round(allc, 4), "all_cores": cores}
+
+
+def cpu_baseline_prefill_extrapolated(cfg, prompt_tokens):
+    """c3: prompt tokens/s of the CPU oracle, EXTRAPOLATED per layer (the whole 32-layer 4096-token prefill is hours of single-threaded CPU work): one layer of the
+    same shapes is timed on `sample` prompt tokens starting at an empty context and again behind `mid` synthetic KV rows (the attention term grows with the context,
+    the linears do not); the two points give the per-token cost of a layer at context c as a + b c, integrated over the prompt and multiplied by the layer count.
+    The read-out runs on one row per sequence and is ignored."""
+    from oracle import oracle as O
+    from uzu_amd import desc as D
+    from uzu_amd import synthetic as S
+    one = dataclasses.replace(cfg, layer_kinds=[D.MIXER_ATTENTION], max_context_length=prompt_tokens + 64)
+    bundle1 = S.build_model(one)
+    O.set_threads(1)
+    sample, mid = 8, min(2048, prompt_tokens)
+    toks = [int(t) for t in S.synthetic_prompt(sample + 1, cfg.vocab_size)]
+    om = O.OracleModel(bundle1)
+
+    def per_token():  # a pass of 1 + `sample` rows minus a pass of 1 row: the read-out of the last row (one per pass) cancels
+        t0 = time.perf_counter()
+        om.forward(toks[:1])
+        t1 = time.perf_counter()
+        om.forward(toks)
+        return ((time.perf_counter() - t1) - (t1 - t0)) / sample
+    t_empty = per_token()                                   # per token of ONE layer at context ~ 0
+    om.fill_synthetic_context(mid)
+    t_mid = per_token()                                     # ... at context ~ mid
+    om.close()
+    b = max(t_mid - t_empty, 0.0) / mid
+    layers = len(cfg.layer_kinds)
+    per_prompt = layers * (t_empty * prompt_tokens + b * prompt_tokens * prompt_tokens / 2.0)
+    return {"value": round(prompt_tokens / per_prompt, 4), "unit": "tokens/s", "cores": 1, "kind": "port", "extrapolated": True,
+            "sample": f"ONE layer of the same shapes, {sample} prompt tokens at context 0 ({t_empty * 1e3:.0f} ms per token) and behind {mid} synthetic KV rows ({t_mid * 1e3:.0f} ms per token), "
+                      f"1 thread; cost of a token at context c = a + b c, summed over a {prompt_tokens}-token prompt, x {layers} layers (read-out of the last row ignored)"}
 
 
 def dominant_gemv_shape(kernel_name, bundle):
@@ -242,11 +280,28 @@ def latency_floor(ctx, bundle, per_kernel, tokens_per_s):
                       f"{row_bytes}-byte row the previous launch wrote; wall time per launch over 20 replays.  edges = 5 per layer + read-out + commit"}
 
 
-def committed_census():
-    """Headline fields of the newest committed parity census (tools/parity_census.py -> profiles/r*_parity_census.json): production kernels
-    against reference-order mode over a pre-registered, unfiltered prompt set, teacher-forced."""
+def committed_exact_mode():
+    """tokens/s of reference-order mode on the headline workload from the newest committed `bench.py --exact` line (profiles/r*_bench_exact.json): what
+    bit-identical logits cost.  The bit-identity itself is asserted by tests/test_gpu_model.py::test_exact_mode_* (tiny models, the full-size 0.8B, the bench
+    fixture's whole chained stream against the CPU oracle)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_census.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_exact.json")), reverse=True):
+        try:
+            c = json.load(open(path))
+            return {"tokens_per_s": c["value"], "prefill_tokens_per_s": c["prefill_tokens_per_s"], "logits_bit_identical": True,
+                    "tokens_equal_to_oracle_stream": f'{c["parity"]["untimed_tokens_equal"] + c["parity"]["tokens_equal"]} / {c["parity"]["of_untimed"] + c["parity"]["of"]}',
+                    "proof": "tests/test_gpu_model.py::test_exact_mode_* (logits of every vocabulary entry equal the CPU oracle's, bit for bit)", "source": "profiles/" + os.path.basename(path)}
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    return None
+
+
+def committed_census(config="c2"):
+    """Headline fields of the newest committed parity census (tools/parity_census.py -> profiles/r*_parity_census[_cN].json): production kernels
+    against reference-order mode over a pre-registered, unfiltered prompt set, teacher-forced.  `config`: the BASELINE configuration the census ran on."""
+    import glob
+    pattern = "r*_parity_census.json" if config == "c2" else f"r*_parity_census_{config}.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             c = json.load(open(path))
             return {"steps": c["steps"], "argmax_mismatches": c["argmax_mismatches"], "max_flipped_margin": c["max_flipped_margin"], "variants": c["variants"],
@@ -348,7 +403,12 @@ def bench_c3(args):
         # a batched pass may split K of a GEMM differently from the single-sequence pass (tolerance-class logits): reported, not asserted
         "first_tokens": [int(t) for t in first], "single_sequence_first_tokens": single_firsts,
         "first_tokens_agree": sum(int(a) == b for a, b in zip(first, single_firsts)), "device": ctx.device_name(),
+        # production kernels against reference-order mode on this configuration's model and prompt length, pre-registered prompts (tools/parity_census.py --config c3)
+        "parity": {"census": committed_census("c3"), "oracle": "reference-order mode (bit-identical to the CPU oracle where the oracle runs: tests/test_gpu_model.py::test_exact_mode_*); "
+                   "the CPU oracle itself needs ~4 CPU-hours per 4096-token Llama-3-8B prompt"},
     }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_prefill_extrapolated(cfg, args.prompt)
     for st in states:
         st.close()
     model.close()
@@ -442,6 +502,12 @@ def main():
     else:
         bundle = S.build_model(cfg)
     ctx = Context.new(local_rank)
+    if args.exact:  # reference-order kernels, eager, the reference's own 1024-row prefill passes (read when a model is created / a pass is encoded)
+        import ctypes as C
+        from uzu_amd import _ffi
+        fn = _ffi.lib().uzu_hip_set_exact
+        fn.restype, fn.argtypes = None, [C.c_int32]
+        fn(1)
     flags = MODEL_NO_GRAPH if args.no_graph else MODEL_DEFAULT
     # fill the context: prompt = context - warmup tokens, then `warmup` untimed decode steps reach `context`
     prompt_len = max(args.context - args.warmup, 1)
@@ -568,7 +634,7 @@ def main():
         committed["frac"] = round(committed["achieved"] / HBM_PEAK_GBPS, 4)
         roofline["rocprofv3"] = committed
     per_kernel = {k: {"calls": v[0], "us": round(v[2] * 1e3, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
-    if mode == "single" and os.environ.get("UZU_BENCH_NO_FLOOR_PROBE", "0") != "1":  # the counter passes of tools/refresh_profiles.sh skip the probe's 2.7k launches
+    if mode == "single" and not args.exact and os.environ.get("UZU_BENCH_NO_FLOOR_PROBE", "0") != "1":  # the counter passes of tools/refresh_profiles.sh skip the probe's 2.7k launches
         try:
             roofline["latency_floor"] = latency_floor(ctx, bundle, per_kernel, tokens_per_s)
         except Exception as exc:  # noqa: BLE001 -- a probe must never take the headline down
@@ -577,13 +643,17 @@ def main():
                    f"({2 * len(bundle.layers)} + 1 per token)", "replicas": f"{world} independent sequences (one per GPU), no collective"}[mode]
 
     result = {
-        "metric": "decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)" if (args.model, cfg.bits) == ("qwen3.5-0.8b", 4) and not args.model_dir else f"decode tokens/s ({cfg.name} int{cfg.bits}, batch 1, greedy)",
+        "metric": ("decode tokens/s (Qwen3.5-0.8B int4, batch 1, greedy)" if (args.model, cfg.bits) == ("qwen3.5-0.8b", 4) and not args.model_dir else f"decode tokens/s ({cfg.name} int{cfg.bits}, batch 1, greedy)")
+                  + (" [reference-order mode: not the headline]" if args.exact else ""),
         "value": round(tokens_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+        **({"exact_mode": True} if args.exact else {}),
         "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": f"int{cfg.bits} weights x bf16 activations, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int{cfg.bits} ScaleBias g{cfg.group_size}, batch=1 greedy decode, context {start_ctx}->{end_ctx}",
-                   "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or use_graph), "parallelism": parallelism},
+                   "prompt_tokens": prompt_len, "graph": (not args.no_graph) and (mode != "tp" or use_graph) and not args.exact, "parallelism": parallelism,
+                   **({"exact_mode": "reference-order kernels (uzu_hip_set_exact(1)): one thread per reduction in the reference's loop order, eager launches, prefill in the "
+                                     "reference's 1024-row passes; logits bit-identical to the CPU oracle's"} if args.exact else {})},
         "gpu_ms_per_step_events": round(gpu_ms / args.steps, 5),
         # the timed steps' token ids: two builds / plan switches that only move rows between waves must agree on it (same-box A/B runs)
         "timed_tokens_crc32": zlib.crc32(np.asarray(timed_tokens, dtype="<u4").tobytes()),
@@ -612,10 +682,14 @@ def main():
             "selection": "the fixture's prompt variant was picked by OUTCOME (tools/stream_search.py: production and reference-order streams identical); the unfiltered "
                          "figure is `census`",
             "census": committed_census(),
+            **({} if args.exact else {"exact_mode": committed_exact_mode()}),
             "note": "token ids of the prefill + warm-up steps (untimed) and of the timed steps against the committed oracle stream; `of` < timed_steps "
                     "when the run is longer than the fixture" + ("; tensor parallel: sums are taken in another order than on one GPU (tolerance class)" if mode == "tp" else "")}
     elif args.config == "c2" and args.model == "qwen3.5-0.8b":
         result["parity"] = None
+    elif args.config in ("c4", "c5"):  # production kernels against reference-order mode on this configuration (tools/parity_census.py --config c4|c5)
+        result["parity"] = {"census": committed_census(args.config), "oracle": "reference-order mode (bit-identical to the CPU oracle where the oracle runs: "
+                            "tests/test_gpu_model.py::test_exact_mode_*)"}
     if args.share_gpu:
         result["physical_gpus"] = 1
         note = (note + "; " if note else "") + f"DRY RUN: {world} ranks share ONE physical GPU (bench.py --share-gpu): plumbing of the p2p + hipGraph TP decode path, not a scaling point"

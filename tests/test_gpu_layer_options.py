@@ -1,4 +1,4 @@
-"""GPU parity tests of the Gemma-family layer / decoder options in the HIP engine (csrc/engine.hip::encode_forward) against the CPU oracle:
+"""GPU parity tests of the Gemma-family layer / decoder options in the HIP engine (csrc/engine_forward.hip::encode_forward) against the CPU oracle:
 per-layer RoPE configurations (transformer.rs:101-118,249-257), post-layer scalars (transformer_layer.rs:61-84), embedding norm
 (decoder.rs:68-83,149-154), KV sharing between layers (transformer.rs:264-275, mixer/attention/mode.rs:79-84), value normalisation
 (qkv_norm.rs:70-72), per-layer embeddings (per_layer_embedding.rs), a first layer without pre-mixer norm (transformer_layer.rs:217-220).

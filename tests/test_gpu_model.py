@@ -274,7 +274,7 @@ def test_fused_decode_matches_unfused(hip_ctx):
     same arithmetic as the one-kernel-per-reference-kernel path: on a DeltaNet-only model tokens AND logits are
     bit-identical; with attention layers (own KV split) tokens are identical and logits within tolerance."""
     for kinds, exact in (([D.MIXER_DELTA_NET] * 3, True), (None, False)):
-        # model_dim 1024: the fused step's Normalization prologue covers rows that are multiples of 1024 (engine.hip::dim_fusable); the
+        # model_dim 1024: the fused step's Normalization prologue covers rows that are multiples of 1024 (engine_forward.hip::dim_fusable); the
         # launch counts prove which path each run took (round 4: at the presets' 256 both runs took the unfused one)
         cfg = S.tiny_qwen(model_dim=1024) if kinds is None else S.tiny_qwen(model_dim=1024, layer_kinds=kinds)
         bundle = S.build_model(cfg)
@@ -828,7 +828,7 @@ def test_qlora_adapters_and_rht_embeddings_end_to_end(hip_ctx, preset, kw):
 @pytest.mark.parametrize("preset,kw", [("tiny-llama", {"qlora_rank": 8, "group_size": 64}), ("tiny-qwen", {"qlora_rank": 4})])
 def test_qlora_without_signs_keeps_its_adapter_in_a_prefill_of_128_rows_or_more(hip_ctx, preset, kw):
     """A QLoRA linear WITHOUT incoherence signs and a prefill chunk of >= 128 rows at group 64: the shape for which the up projection
-    would take the fused matrix-core GEMM + GatedActMul path (engine.hip::linear_gated), which knows nothing of the adapter term
+    would take the fused matrix-core GEMM + GatedActMul path (engine_forward.hip::linear_gated), which knows nothing of the adapter term
     (x down^T) up^T (qlora_wrapper.rs:177-251).  Teacher-forced against the oracle: prefill logits and six decode steps."""
     cfg = S.PRESETS[preset](seed=51, **kw)
     o_tokens, h_tokens, worst, om, hm = run_pair(hip_ctx, cfg, 200, 6, teacher_forced=True)

@@ -49,7 +49,8 @@ def summarise(records, args, seconds):
             hist[str(r["chained_common"])] = hist.get(str(r["chained_common"]), 0) + 1
     q = lambda a, p: float(np.quantile(a, p)) if a.size else None
     return {
-        "config": f"BASELINE configs[1]: {args.model} int4 g128, {args.prompt}-token prompts, reference-order prefill + {args.steps} chained greedy steps; production teacher-forced on the reference's tokens",
+        "config": f"BASELINE configs[{'c2 c3 c4 c5'.split().index(args.config) + 1}]: {args.model} int{args.bits or 4} g128, {args.prompt}-token prompts, reference-order prefill + {args.steps} chained greedy steps; production teacher-forced on the reference's tokens",
+        "baseline_config": args.config,
         "selection": f"pre-registered: synthetic_prompt variants {args.first}..{args.first + len(records) - 1}, in order, none filtered or skipped",
         "reference": "reference-order mode (uzu_hip_set_exact(1)): bit-identical to the CPU oracle where the oracle runs (tests/test_gpu_model.py::test_exact_mode_*)",
         "variants": len(records), "steps_per_variant": args.steps + 1, "steps": steps,
@@ -72,7 +73,10 @@ def summarise(records, args, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3.5-0.8b")
-    ap.add_argument("--prompt", type=int, default=2043)
+    ap.add_argument("--bits", type=int, default=0)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2", help="BASELINE configs[1..4]: c3 Llama-3-8B int4, 4096-token prompts (prefill decisions + a few steps); "
+                    "c4 Llama-3-8B int8 decode at context 2048; c5 Qwen3-14B-class int4 at context 8192 (round 6: the side lines of bench.py carry their own census)")
+    ap.add_argument("--prompt", type=int, default=0)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--variants", type=int, default=200)
     ap.add_argument("--first", type=int, default=0)
@@ -80,6 +84,11 @@ def main():
     ap.add_argument("--out", default="gpurun_out/parity_census.json")
     ap.add_argument("--resume", default="")
     args = ap.parse_args()
+    preset = {"c2": ("qwen3.5-0.8b", 0, 2043), "c3": ("llama-3-8b", 4, 4096), "c4": ("llama-3-8b", 8, 2043), "c5": ("qwen3-14b-class", 4, 8187)}[args.config]
+    if args.config != "c2":
+        args.model, args.bits = preset[0], preset[1]
+    if not args.prompt:
+        args.prompt = preset[2]
     from helpers import f32
     from uzu_amd import _ffi
     from uzu_amd import synthetic as S
@@ -93,7 +102,7 @@ def main():
 
     t_start = time.time()
     ctx = Context.new(0)
-    cfg = S.PRESETS[args.model](max_context_length=args.prompt + args.steps + 8)
+    cfg = S.PRESETS[args.model](max_context_length=args.prompt + args.steps + 8, **({"bits": args.bits} if args.bits else {}))
     bundle = S.build_model(cfg)
     m = S.readout_row_multipliers(cfg).astype(np.float64)
     prod = HipModel(ctx, bundle)

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -63,6 +64,25 @@ inline bool raise_lds_limit(LdsLimit& st, const void* fn, size_t lds) {
     have = lds;
     return true;
 }
+
+// Environment switches.  The shipped library reads nine (UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK, UZU_TP_TIMEOUT_MS,
+// UZU_TP_INJECT_TIMEOUT_AT, UZU_GEMM_FORM, UZU_GEMM_SPLITS, UZU_EXACT_SCALAR, UZU_ROWS_NORM -- each crossed by a test); every other knob is a LAB switch
+// of the A/B scripts under tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
+inline const char* lab_env(const char* name) {
+#ifdef UZU_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// UZU_HIP_POISON (CI mode, runtime.hip): 1 = every fresh device allocation that is not zero-filled by contract, every user buffer and every hand-out of a
+// recycled per-stream workspace block is filled with 0xFF bytes first (bf16 / f32 NaN, out-of-range indices) on the stream that will use it -- a kernel that
+// reads what nothing wrote, or a pass that starts before its fills have landed, shows up as NaN logits instead of passing on zeros; 2 = the engine's scratch
+// blocks as well (they are zero-filled otherwise).  No extra synchronisation of kernels; allocation-time fills are followed by a stream synchronisation.
+int poison_level();
+uzu_status poison_fill(void* p, size_t bytes, hipStream_t s, bool synchronise);
 
 #define UZU_PROPAGATE(expr)            \
     do {                               \

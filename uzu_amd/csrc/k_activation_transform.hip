@@ -415,7 +415,7 @@ uzu_status matmul_a8(hipStream_t s, const MatmulParams& p, const int8_t* a_q, co
     }
     // prefill-sized M: the int8 matrix cores (stages of min(activation group, weight group) = 64 or 128 elements)
     static const bool mfma_on = [] { // UZU_A8_MFMA=0: the VALU kernel everywhere (A/B runs)
-        const char* e = getenv("UZU_A8_MFMA");
+        const char* e = lab_env("UZU_A8_MFMA");
         return !e || atoi(e) != 0;
     }();
     const uint32_t gk = a_group_size < p.group_size ? a_group_size : p.group_size;

@@ -274,11 +274,11 @@ __global__ void __launch_bounds__(256) attention_prefill_mfma_kernel(AttentionPa
 bool attention_prefill_mfma_supported(const AttentionParams& a) {
     if (exact_mode()) return false; // reference-order mode: the scalar-order kernels of k_exact.hip
     static const uint32_t min_m = [] {
-        const char* e = getenv("UZU_ATTN_MFMA_MIN_M");
+        const char* e = lab_env("UZU_ATTN_MFMA_MIN_M");
         return e ? (uint32_t)atoi(e) : 16u;
     }();
     static const bool general_on = [] { // UZU_ATTN_MFMA_GENERAL=0: sliding-window / ring / sink layers back on the VALU kernels (A/B runs)
-        const char* e = getenv("UZU_ATTN_MFMA_GENERAL");
+        const char* e = lab_env("UZU_ATTN_MFMA_GENERAL");
         return !e || atoi(e) != 0;
     }();
     if (a.dt != UZU_BF16 || !a.is_causal || a.trie) return false;
@@ -326,11 +326,11 @@ uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void*
     const uint32_t kv_heads = a.num_heads / a.gqa_factor;
     const uint32_t n_tasks = a.gqa_factor * ((a.suffix_length + TQ - 1) / TQ);
     static const uint32_t force_tpw = [] {
-        const char* e = getenv("UZU_ATTN_TPW");
+        const char* e = lab_env("UZU_ATTN_TPW");
         return e ? (uint32_t)atoi(e) : 0u;
     }();
     static const int force_split = [] { // UZU_ATTN_KSPLIT: 1 = never split the keys (A/B runs), n = that many splits
-        const char* e = getenv("UZU_ATTN_KSPLIT");
+        const char* e = lab_env("UZU_ATTN_KSPLIT");
         return e ? atoi(e) : 0;
     }();
     // Few task groups (few kv heads x short chunks): keep four tasks per workgroup -- they share every staged K / V tile -- and split the KEYS

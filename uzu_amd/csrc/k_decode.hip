@@ -874,9 +874,9 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     const uint32_t n_log0 = p.act_mul ? p.n[0] / 2 : p.n[0];
     static int force_r = -1, tw = -1;
     if (force_r < 0) {
-        const char* e = getenv("UZU_DEC_R");
+        const char* e = lab_env("UZU_DEC_R");
         force_r = e ? atoi(e) : 0;
-        const char* t = getenv("UZU_DEC_TW");
+        const char* t = lab_env("UZU_DEC_TW");
         tw = t ? atoi(t) : 0; // 0 = the rule below
     }
     const uint32_t C = p.k / 32, lpr = 1u << lpr_log2, cpl = (C + lpr - 1) / lpr;
@@ -884,11 +884,11 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
     int R;
     auto nb = [&](int rr) { return (n_log0 + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw) + (p.n[1] + (uint32_t)(rr * rpw) - 1) / (uint32_t)(rr * rpw); };
     static const int wide_on = [] { // UZU_DEC_WIDE=0: 4-wave workgroups everywhere; 2: every bandwidth-regime kernel (A/B runs)
-        const char* e = getenv("UZU_DEC_WIDE");
+        const char* e = lab_env("UZU_DEC_WIDE");
         return e ? atoi(e) : 1;
     }();
     static const uint64_t big_bytes = [] { // UZU_DEC_BIG_MB: where the bandwidth regime (persistent grid) starts
-        const char* e = getenv("UZU_DEC_BIG_MB");
+        const char* e = lab_env("UZU_DEC_BIG_MB");
         return (uint64_t)(e && atoi(e) > 0 ? atoi(e) : 16) << 20;
     }();
     *wide_out = false;
@@ -906,7 +906,7 @@ static uint32_t gemv_dec_plan(const DecGemvParams& p, int num_cus, int* lpr_log2
         // waves (up 27.0 -> 26.3 us but qkv 11.8 -> 13.5): int8 stays on 4-wave workgroups
         *wide_out = wide_on && force_r <= 0 && (wide_on == 2 || (p.bits == 4 && cpl >= 2));
         static const int wide_r = [] { // UZU_DEC_WIDE_R: rows per lane group of the wide workgroups (A/B runs; 0 = the rule above)
-            const char* e = getenv("UZU_DEC_WIDE_R");
+            const char* e = lab_env("UZU_DEC_WIDE_R");
             return e ? atoi(e) : 0;
         }();
         if (*wide_out && wide_r > 0 && !(p.act_mul && cpl > 2)) R = wide_r > 2 ? 2 : wide_r;
@@ -944,11 +944,11 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
                        : (CPLT == 0 && BITS == 4)                  ? ((size_t)(p.k / 32) * 21 + 16) * sizeof(float) // packed row + per-step sums
                                                                    : 0;
     static const int spread_on = [] { // UZU_DEC_SPREAD=0: a partial round keeps 16 busy waves per workgroup on fewer CUs (A/B runs)
-        const char* c = getenv("UZU_DEC_SPREAD");
+        const char* c = lab_env("UZU_DEC_SPREAD");
         return c ? atoi(c) : 1;
     }();
     static const int cap_override = [] {
-        const char* c = getenv("UZU_DEC_CAP");
+        const char* c = lab_env("UZU_DEC_CAP");
         return c ? atoi(c) : 0;
     }();
 #define UZU_LAUNCH(RR) UZU_LAUNCH_N(RR, 4)
@@ -999,7 +999,7 @@ static uzu_status launch_gemv_dec_c(hipStream_t s, const DecGemvParams& p, uint3
 // an RHT linear whose epilogue (GatedActMul / DeltaNet conv) needs its OutputRht first: whole 32-row blocks per workgroup (PRO == 5)
 bool gemv_dec_stripe_supported(const DecGemvParams& p, int num_cus) {
     static const bool on = [] { // UZU_DEC_STRIPE=0: the join launches behind the GEMV (A/B runs)
-        const char* e = getenv("UZU_DEC_STRIPE");
+        const char* e = lab_env("UZU_DEC_STRIPE");
         return !e || atoi(e) != 0;
     }();
     if (!on || p.bits != 4 || p.n[1] || !(p.norm_scales || p.norm_plain) || p.k % 1024 || p.out_f32 || p.part_val || p.dg_o) return false;
@@ -1026,7 +1026,7 @@ static uzu_status launch_gemv_dec_stripe(hipStream_t s, const DecGemvParams& p, 
         // eight waves where a block has at least eight batches (one or two rows per wave pass): two batches per wave instead of four
         const uint32_t nbs = 32u / (64u >> lpr_log2);
         static const int nw_env = [] { // UZU_DEC_STRIPE_NW=4: four-wave workgroups (A/B runs)
-            const char* e = getenv("UZU_DEC_STRIPE_NW");
+            const char* e = lab_env("UZU_DEC_STRIPE_NW");
             return e ? atoi(e) : 8;
         }();
         if (nbs >= 8 && nbs % 8 == 0 && nw_env == 8)
@@ -1752,7 +1752,7 @@ bool attn_dec_fused_supported(uint32_t num_heads, uint32_t gqa_factor, uint32_t 
     return false; // not compiled in (see UZU_LAUNCH above)
 #endif
     static const bool env_on = [] { // UZU_ATTN_FUSED=1 selects it (a FUSED_ATTN=1 build; A/B runs; same arithmetic): off by default -- measured slower
-        const char* e = getenv("UZU_ATTN_FUSED");
+        const char* e = lab_env("UZU_ATTN_FUSED");
         return e && e[0] == '1';
     }();
     const bool off = g_attn_fused_override >= 0 ? g_attn_fused_override == 0 : !env_on;

@@ -52,11 +52,11 @@ struct ScanSplit {
 };
 static uint32_t split_mid_chunk(uint32_t n_chunks, uint32_t head_v_dim) {
     static const uint32_t min_chunks = [] { // UZU_DN_SPLIT: chunks from which the scan is split (0 = never; A/B runs).  Below ~12 chunks the fix-up launch costs more than the shorter chain saves
-        const char* e = getenv("UZU_DN_SPLIT");
+        const char* e = lab_env("UZU_DN_SPLIT");
         return e ? (uint32_t)atoi(e) : 16u;
     }();
     static const uint32_t pct = [] { // UZU_DN_SPLIT_PCT: segment 0's share of the chunks (its workgroups run ~2.5 us per chunk, segment 1's double groups ~3.4)
-        const char* e = getenv("UZU_DN_SPLIT_PCT");
+        const char* e = lab_env("UZU_DN_SPLIT_PCT");
         const int v = e ? atoi(e) : 58;
         return (uint32_t)(v < 10 ? 10 : v > 90 ? 90 : v);
     }();
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256) dn_chunk_fixup_kernel(ScanSplit sp, float
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len) {
     if (exact_mode()) return false; // reference-order mode: the token-by-token recurrence in the reference's own loop order (k_exact.hip)
     static const uint32_t min_t = [] {
-        const char* e = getenv("UZU_DN_CHUNK_MIN_T");
+        const char* e = lab_env("UZU_DN_CHUNK_MIN_T");
         return e ? (uint32_t)atoi(e) : 64u;
     }();
     return head_k_dim == DKC && num_k_heads && num_v_heads % num_k_heads == 0 && head_v_dim % 16 == 0 && suffix_len >= min_t;

@@ -205,7 +205,7 @@ uzu_status normalization(hipStream_t s, const NormParams& p) {
     }
     if (exact_mode()) return normalization_exact(s, p);
     static const bool fast_rows = [] { // UZU_NORM_ROWS=0: the general kernel everywhere (A/B runs)
-        const char* e = getenv("UZU_NORM_ROWS");
+        const char* e = lab_env("UZU_NORM_ROWS");
         return !e || atoi(e) != 0;
     }();
     if (fast_rows && p.io_dt == UZU_BF16 && p.batch_size >= 16 && p.element_count % 1024 == 0 && (p.affine_dt == UZU_F32 || p.affine_dt == UZU_BF16) &&
@@ -240,7 +240,7 @@ uzu_status normalization(hipStream_t s, const NormParams& p) {
 // Split-K reduction + the GEMM's epilogue + the Normalization of the rows it produces, one launch (normalization_rows_kernel<.., true>).
 bool normalization_from_partials_supported(const NormParams& p, const NormPartials& sp) {
     static const bool on = [] { // UZU_NORM_PARTIALS=0: the reduction and the normalisation as two launches (A/B runs)
-        const char* e = getenv("UZU_NORM_PARTIALS");
+        const char* e = lab_env("UZU_NORM_PARTIALS");
         return !e || atoi(e) != 0;
     }();
     if (!on || exact_mode() || p.io_dt != UZU_BF16 || p.batch_size < 16 || p.element_count % 1024 || (p.affine_dt != UZU_F32 && p.affine_dt != UZU_BF16)) return false;

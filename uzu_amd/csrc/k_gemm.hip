@@ -286,7 +286,7 @@ bool gemm_q_mfma_supported(const MatmulParams& p) {
     static const uint32_t min_m = [] {
         // below ~20 rows the GEMV in passes of four rows is faster than a 64-row tile a quarter full: a 16-node speculative tree pass of
         // Qwen3.5-0.8B takes 2.93 ms with the GEMVs against 3.64 ms with the tiles (tools/verify_cost.py, profiles/r4_verify_cost.json)
-        const char* e = getenv("UZU_GEMM_MIN_M");
+        const char* e = lab_env("UZU_GEMM_MIN_M");
         return e ? (uint32_t)atoi(e) : 20u;
     }();
     if (p.b_kind == UZU_MATMUL_B_FULL_PRECISION || (p.bits != 4 && p.bits != 8)) return false;
@@ -310,7 +310,7 @@ template <int MB, int NB> static uzu_status launch_gemm(hipStream_t s, const Mat
 // 64 x 64 runs four waves per SIMD and is 1.4-1.7x faster from 1024 x 1024 x 2048 up to 4096 x 14336 x 4096.
 uzu_status gemm_q_mfma(hipStream_t s, const MatmulParams& p, int num_cus) {
     static const int force = [] {
-        const char* e = getenv("UZU_GEMM_TILE");
+        const char* e = lab_env("UZU_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
     // M >= 128: the 128 x 128 tile kernel (k_gemm128.hip).  Its scratch (row-sum pieces of A, split-K partials) is the

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_rows_mfma_kernel(RowsParams p) {
 
 bool gemv_rows_mfma_supported(const MatmulParams& p) {
     static const bool on = [] { // UZU_GEMV_ROWS=0: small M back on the GEMV passes / GEMM tiles (A/B runs)
-        const char* e = getenv("UZU_GEMV_ROWS");
+        const char* e = lab_env("UZU_GEMV_ROWS");
         return !e || atoi(e) != 0;
     }();
     if (!on || exact_mode()) return false;

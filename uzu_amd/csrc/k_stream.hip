@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(DecGemvParams p, S
 // ---------------------------------------------------------------------------------------------------------------- host side
 static int stream_mode() { // UZU_DEC_STREAM: 0 = never, 1 (default) = the bandwidth regime, 2 = every supported shape (tests / A-B runs)
     static const int env = [] {
-        const char* e = getenv("UZU_DEC_STREAM");
+        const char* e = lab_env("UZU_DEC_STREAM");
         return e ? atoi(e) : 1;
     }();
     return env;
@@ -623,7 +623,7 @@ template <int CPL, int NW> static uzu_status launch_stream_c(hipStream_t s, cons
 // waves per workgroup: 16 (15 consumers; 128 registers per wave) where the activation row is short (K <= 4096), 8 (256 registers) beyond
 static int stream_waves(int cpl) {
     static const int env = [] { // UZU_STREAM_WAVES=8: 8-wave workgroups everywhere (A/B runs)
-        const char* e = getenv("UZU_STREAM_WAVES");
+        const char* e = lab_env("UZU_STREAM_WAVES");
         return e ? atoi(e) : 16;
     }();
     return (cpl <= 2 && env >= 16) ? 16 : 8;
@@ -653,7 +653,7 @@ uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, ui
     const uint32_t item_rows = rr * rpw;
     const uint32_t row_bytes = p.k / 2, G = p.k / p.group_size;
     static const uint32_t slot_target = [] { // UZU_STREAM_SLOT_KB: bytes of codes per slot (A/B runs)
-        const char* e = getenv("UZU_STREAM_SLOT_KB");
+        const char* e = lab_env("UZU_STREAM_SLOT_KB");
         return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 16) << 10;
     }();
     uint32_t items = slot_target / (nphys * item_rows * row_bytes);
@@ -674,7 +674,7 @@ uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, ui
     g.off_biases = g.off_scales + nphys * g.sb_stride;
     g.slot_bytes = g.off_biases + nphys * g.sb_stride;
     static const int depth_env = [] { // UZU_STREAM_DEPTH=1: one slot (instead of two) may be in flight behind the one being issued (A/B runs)
-        const char* e = getenv("UZU_STREAM_DEPTH");
+        const char* e = lab_env("UZU_STREAM_DEPTH");
         return e ? atoi(e) : 2;
     }();
     g.depth = depth_env >= 2 ? 2 : 1;
@@ -682,7 +682,7 @@ uzu_status gemv_stream(hipStream_t s, const DecGemvParams& p_in, int num_cus, ui
     const size_t lds_budget = 160u * 1024 - 2048 - 256; // static LDS of the kernel (flags, tables), the padding dump, margin
     uint32_t ring = (uint32_t)((lds_budget - xs_bytes) / g.slot_bytes);
     static const uint32_t ring_cap = [] {
-        const char* e = getenv("UZU_STREAM_RING");
+        const char* e = lab_env("UZU_STREAM_RING");
         return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : (int)kMaxRing);
     }();
     if (ring > ring_cap) ring = ring_cap;

@@ -41,6 +41,24 @@ uzu_status cmdbuf_check_encoding(uzu_hip_cmdbuf* cb) {
 } // namespace uzu
 
 namespace uzu {
+static int g_poison = -1;
+int poison_level() {
+    if (g_poison < 0) {
+        const char* e = getenv("UZU_HIP_POISON");
+        g_poison = e ? atoi(e) : 0;
+        if (g_poison < 0 || g_poison > 2) g_poison = 0;
+    }
+    return g_poison;
+}
+uzu_status poison_fill(void* p, size_t bytes, hipStream_t s, bool synchronise) {
+    if (!p || !bytes) return UZU_OK;
+    UZU_HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, s));
+    if (synchronise) UZU_HIP_TRY(hipStreamSynchronize(s));
+    return UZU_OK;
+}
+} // namespace uzu
+
+namespace uzu {
 namespace k {
 // Per-stream scratch for kernels that need a transient device buffer (split-K partials, DeltaNet chunk tables, arg-max
 // partials).  One grow-only hipMalloc block per stream: consecutive users on a stream are ordered by the stream itself.
@@ -59,7 +77,11 @@ void* stream_workspace(hipStream_t s, size_t bytes) {
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr; // a graph would pin a block that may be regrown
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     WsEntry& e = g_ws[s];
-    if (e.bytes >= bytes) return e.ptr;
+    if (e.bytes >= bytes) {
+        // poison mode: a recycled block comes back full of NaNs, stream-ordered behind its previous user and in front of the next
+        if (poison_level() && bytes) (void)poison_fill(e.ptr, bytes, s, false);
+        return e.ptr;
+    }
     if (e.ptr) { // earlier users may still be running: drain the stream before the block goes away
         (void)hipStreamSynchronize(s);
         (void)hipFree(e.ptr);
@@ -72,6 +94,7 @@ void* stream_workspace(hipStream_t s, size_t bytes) {
         return nullptr;
     }
     e.ptr = p, e.bytes = want;
+    if (poison_level()) (void)poison_fill(p, want, s, false);
     return p;
 }
 void stream_workspace_release(hipStream_t s) {
@@ -205,6 +228,7 @@ uzu_status uzu_hip_buffer_create(uzu_hip_context* ctx, size_t size, uzu_hip_buff
     }
     ctx->current_bytes += alloc;
     if (ctx->current_bytes > ctx->peak_bytes) ctx->peak_bytes = ctx->current_bytes;
+    if (poison_level()) (void)poison_fill(b->dptr, alloc, ctx->stream, true); // Buffer contents are undefined until written (as in the reference): make that visible
     *out = b;
     return UZU_OK;
 }
