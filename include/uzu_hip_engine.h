@@ -156,6 +156,37 @@ uzu_status uzu_hip_model_verify_gpu_ms(uzu_hip_model* m, float* out_ms);
 /* bf16 logits [tree_size, vocab] of the pending tree's nodes (between verify_tree and accept). */
 uzu_status uzu_hip_model_read_tree_logits(uzu_hip_model* m, uint16_t* logits_out);
 
+/* ---- the tree speculator's draft model: DFlash (encodable_block/dflash.rs:41-346, speculators/dflash_tfm.rs) ----
+ * The reference's LanguageModelStream asks its speculator for a tree in front of every verify pass (stream.rs:551-576): the DFlash draft model -- a few
+ * TransformerLayers with block attention whose KV state is fed with projections of the TARGET's hidden features -- drafts a block of tokens in one pass;
+ * tree shaping (the Argmax chain, trie, pruning) is host code (uzu_amd/speculator.py <- dflash_tfm.rs:133-343, uzu_amd/trie.py <- trie.rs).
+ *
+ * uzu_hip_model_set_feature_layers: the target's hidden-feature taps (DFlashTfmSpeculator::hidden_feature_layer_indices, stream.rs:213-214,632-633):
+ *   every later pass (prefill chunk, decode step, tree pass) files Transformer::capture_residual(shortcut, hidden) = bf16(shortcut + hidden) of every row after
+ *   each listed layer (transformer.rs:160-171,285-293).  Production outputs, independent of UZU_MODEL_DEBUG_TAPS; count 0 removes the taps.  A model with taps
+ *   decodes through the one-kernel-per-reference-kernel pass.  Not on tensor-parallel shards (UZU_ERR_UNSUPPORTED).
+ * uzu_hip_model_read_features: bf16 [rows, model_dim] of tap `index` (position in the list) for the rows of the last pass; `out` NULL = only `rows`.
+ * uzu_hip_drafter_create: uploads the draft model (DFlash::new); it keeps a borrowed pointer to `target` (embedding lookup / read-out / taps), which must
+ *   outlive it, and owns an AttentionState per layer for desc->context_capacity rows (DFlash::empty_state).
+ * uzu_hip_drafter_accept: DFlash::encode_accept over rows `accepted_indices` of the target's LAST pass -- call it after every prefill chunk (indices 0..n) and,
+ *   after a verify pass, BEFORE or AFTER uzu_hip_model_accept with the same indices (the taps are not touched by accept); the target's taps must be exactly
+ *   desc->target_layer_ids in order.
+ * uzu_hip_drafter_draft: DFlash::encode_draft for [target_output_token, mask, ...] (batch_size rows, 2..block_size) + the greedy token of every lookahead row
+ *   (the Argmax construction, dflash_tfm.rs:167-217): tokens_out [batch_size - 1].  Nothing is accepted; the drafter's context does not move.
+ * uzu_hip_drafter_read_draft: DFlashOutput of the last draft: draft_hidden bf16 [rows, model_dim], logits f32 [rows - 1, vocab]. */
+typedef struct uzu_hip_drafter uzu_hip_drafter;
+uzu_status uzu_hip_model_set_feature_layers(uzu_hip_model* m, const uint32_t* layer_ids, uint32_t count);
+uzu_status uzu_hip_model_read_features(uzu_hip_model* m, uint32_t index, uint16_t* out, uint32_t* rows);
+uzu_status uzu_hip_drafter_create(uzu_hip_context* ctx, uzu_hip_model* target, const uzu_dflash_desc* desc, uzu_hip_drafter** out);
+void uzu_hip_drafter_destroy(uzu_hip_drafter* f);
+uzu_status uzu_hip_drafter_reset(uzu_hip_drafter* f);
+uint32_t uzu_hip_drafter_context_length(const uzu_hip_drafter* f);
+uzu_status uzu_hip_drafter_accept(uzu_hip_drafter* f, const uint32_t* accepted_indices, uint32_t count);
+uzu_status uzu_hip_drafter_draft(uzu_hip_drafter* f, uint32_t target_output_token, uint32_t batch_size, uint32_t* tokens_out);
+uzu_status uzu_hip_drafter_read_draft(uzu_hip_drafter* f, uint16_t* draft_hidden_out, float* logits_out, uint32_t* rows);
+/* device time of the last accept / draft, ms (HIP events on the engine's stream) */
+uzu_status uzu_hip_drafter_gpu_ms(uzu_hip_drafter* f, float* accept_ms, float* draft_ms);
+
 /* bf16 logits [vocab] of the last sampled row. */
 uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out);
 /* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass.

@@ -172,7 +172,8 @@ typedef struct {
     uint32_t has_ple;               /* ple_config.is_some(): PerLayerEmbeddingProjection (per_layer_embedding.rs:150-271) ends the layer */
     uint32_t ple_dim;
     uint32_t ple_activation;        /* uzu_activation_type */
-    uint32_t reserved3;
+    uint32_t is_non_causal;         /* AttentionConfig::is_causal == false (mixer/attention/mod.rs:166-198, mask.rs:3-61): every suffix row sees every suffix row --
+                                       the block attention of a DFlash draft model (encodable_block/dflash.rs).  0 = causal (the field was `reserved3`: same layout) */
     uzu_linear_desc ple_gate;       /* ple.gate: n = ple_dim, k = model_dim */
     uzu_linear_desc ple_projection; /* ple.projection: n = model_dim, k = ple_dim */
     uzu_norm_desc ple_norm;         /* ple.norm: [model_dim] */
@@ -213,6 +214,34 @@ typedef struct {
     uzu_norm_desc ple_projection_norm;    /* per_layer_embedding.projection_norm: [ple_dim]; epsilon as configured (the engine divides it by
                                              model_projection_scale^2, per_layer_embedding.rs:75-80) */
 } uzu_model_desc;
+
+/*
+ * The DFlash draft model of the tree speculator: DFlashDraftConfig (config/dflash.rs:9-23) + the tensors of the subtree
+ * `speculator.draft_model` (speculators/dflash_tfm.rs:86-107, encodable_block/dflash.rs:86-172):
+ *   context_projection.*   Linear  [model_dim, model_dim * num_target_layers]   the accepted tokens' target features, side by side
+ *   context_norm.scales    Normalization of the projected features (no shortcut)
+ *   state_kv_projection.*  Linear  [num_layers * 2 * groups * head_dim, model_dim]   keys | values of every draft layer from one projected row
+ *   layers.{i}.*           TransformerLayers with attention mixers (block attention: is_non_causal as configured) and a full KV state
+ *   output_norm.scales     Normalization with the shortcut added
+ * The draft model has no embedding of its own: rows are looked up in, and read out through, the TARGET model's table (dflash.rs:285,335).
+ */
+typedef struct {
+    uint32_t model_dim;
+    uint32_t hidden_dim;
+    uint32_t block_size;           /* rows of one draft pass (<= ATTENTION_SUFFIX_CAPACITY = 1024) */
+    uint32_t mask_token_id;
+    uint32_t num_target_layers;    /* target_layer_ids.len(): the target's hidden-feature taps (stream.rs:213-214,632-633) */
+    uint32_t num_layers;
+    uint32_t vocab_size;
+    uint32_t context_capacity;     /* DFlash::empty_state(context_capacity) (dflash.rs:174-188; language_model/state.rs:46-51: the target's max context) */
+    const uint32_t* target_layer_ids;
+    uzu_linear_desc context_projection;
+    uzu_norm_desc context_norm;
+    uzu_linear_desc state_kv_projection;
+    uzu_rope_desc rope;            /* rope_config: positions context .. context + rows; max_sequence_length bounds the state */
+    const uzu_layer_desc* layers;
+    uzu_norm_desc output_norm;
+} uzu_dflash_desc;
 
 #ifdef __cplusplus
 }

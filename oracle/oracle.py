@@ -206,6 +206,80 @@ class OracleModel:
         n = rows.value * self.model_dim
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(n,)).copy().reshape(rows.value, -1)
 
+    # ---- speculator taps (stream.rs:213-214,632-633)
+    def capture_features(self, on: bool = True):
+        lib().orc_model_capture_features.argtypes = [C.c_void_p, C.c_uint32]
+        lib().orc_model_capture_features(self._h, C.c_uint32(1 if on else 0))
+
+    def hidden_feature(self, layer: int) -> np.ndarray:
+        """capture_residual(shortcut, hidden) of `layer` for every row of the last forward: bf16 bits [rows, model_dim]"""
+        fn = lib().orc_model_hidden_feature
+        fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p, C.c_uint32, C.c_void_p]
+        rows = C.c_uint32(0)
+        ptr = fn(self._h, C.c_uint32(layer), C.byref(rows))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(rows.value * self.model_dim,)).copy().reshape(rows.value, -1)
+
+    def final_hidden_rows(self) -> np.ndarray:
+        """output norm of every output row of the last forward (DecoderEncodeOutput::final_hidden): bf16 bits [rows, model_dim]"""
+        fn = lib().orc_model_final_hidden_rows
+        fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p]
+        rows = C.c_uint32(0)
+        ptr = fn(self._h, C.byref(rows))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(rows.value * self.model_dim,)).copy().reshape(rows.value, -1)
+
     def final_hidden(self) -> np.ndarray:
         ptr = lib().orc_model_final_hidden(self._h)
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(self.model_dim,)).copy()
+
+
+class OracleDFlash:
+    """orc_dflash_*: the DFlash draft model (encodable_block/dflash.rs:41-346) next to an OracleModel target."""
+
+    def __init__(self, bundle):
+        self.bundle = bundle
+        self._desc = bundle.desc()
+        fn = lib().orc_dflash_create
+        fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p]
+        self._h = fn(C.byref(self._desc))
+        self.block_size, self.model_dim, self.vocab_size = bundle.block_size, bundle.model_dim, bundle.vocab_size
+        self.target_layer_ids = list(bundle.target_layer_ids)
+
+    def close(self):
+        if self._h:
+            lib().orc_dflash_destroy.argtypes = [C.c_void_p]
+            lib().orc_dflash_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        lib().orc_dflash_reset.argtypes = [C.c_void_p]
+        lib().orc_dflash_reset(self._h)
+
+    @property
+    def context_length(self) -> int:
+        fn = lib().orc_dflash_context_length
+        fn.restype, fn.argtypes = C.c_uint32, [C.c_void_p]
+        return int(fn(self._h))
+
+    def accept(self, target_features, accepted_indices):
+        """DFlash::encode_accept: target_features = one bf16-bits array [rows, model_dim] per tapped target layer (in target_layer_ids order)"""
+        feats = [np.ascontiguousarray(f, dtype=np.uint16) for f in target_features]
+        assert len(feats) == len(self.target_layer_ids)
+        idx = np.ascontiguousarray(accepted_indices, dtype=np.uint32)
+        assert all(f.ndim == 2 and f.shape[1] == self.model_dim and (idx.size == 0 or int(idx.max()) < f.shape[0]) for f in feats)
+        ptrs = (C.c_void_p * len(feats))(*[f.ctypes.data for f in feats])
+        fn = lib().orc_dflash_accept
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        fn(self._h, ptrs, p(idx), C.c_uint32(idx.size))
+
+    def draft(self, target: "OracleModel", target_output_token: int, batch_size: int):
+        """DFlash::encode_draft + greedy tokens of the lookahead rows -> (draft_hidden bf16 bits [batch, d], logits f32 [batch - 1, vocab], tokens [batch - 1])"""
+        hidden = np.empty((batch_size, self.model_dim), dtype=np.uint16)
+        logits = np.empty((batch_size - 1, self.vocab_size), dtype=np.float32)
+        tokens = np.empty(batch_size - 1, dtype=np.uint32)
+        fn = lib().orc_dflash_draft
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn(self._h, target._h, C.c_uint32(int(target_output_token)), C.c_uint32(batch_size), p(hidden), p(logits), p(tokens))
+        return hidden, logits, tokens

@@ -273,6 +273,24 @@ void orc_model_accept(orc_model* m, const uint32_t* accepted, uint32_t n);
 /* Debug taps: copy the last forward's per-layer outputs (bf16 [count, model_dim]) */
 const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint32_t* rows);
 const uint16_t* orc_model_final_hidden(const orc_model* m); /* output_norm of last row, bf16 [model_dim] */
+/* speculator taps (stream.rs:213-214,632-633): with capture on, every forward keeps capture_residual(shortcut, hidden) of every layer (bf16 [rows, d],
+ * transformer.rs:160-171,285-293) and the output norm of every output row (DecoderEncodeOutput::final_hidden, decoder.rs:190-194) */
+void orc_model_capture_features(orc_model* m, uint32_t on);
+const uint16_t* orc_model_hidden_feature(const orc_model* m, uint32_t layer, uint32_t* rows);
+const uint16_t* orc_model_final_hidden_rows(const orc_model* m, uint32_t* rows);
+const uzu_model_desc* orc_model_desc(const orc_model* m);
+
+/* ---- DFlash draft model (encodable_block/dflash.rs:41-346; uzu_oracle_dflash.c) ---- */
+typedef struct orc_dflash orc_dflash;
+orc_dflash* orc_dflash_create(const uzu_dflash_desc* desc); /* keeps the desc's tensor pointers */
+void orc_dflash_destroy(orc_dflash* f);
+void orc_dflash_reset(orc_dflash* f);
+uint32_t orc_dflash_context_length(const orc_dflash* f);
+/* encode_accept: target_features[i] = bf16 [rows, model_dim] of target layer target_layer_ids[i] */
+void orc_dflash_accept(orc_dflash* f, const uint16_t* const* target_features, const uint32_t* accepted_indices, uint32_t num_tokens);
+/* encode_draft + the greedy tokens of the Argmax construction: draft_hidden bf16 [batch, d], logits f32 [batch - 1, vocab], tokens [batch - 1] (each optional) */
+void orc_dflash_draft(orc_dflash* f, const orc_model* target, uint32_t target_output_token, uint32_t batch_size, uint16_t* draft_hidden_out, float* logits_out,
+                      uint32_t* tokens_out);
 
 #ifdef __cplusplus
 }

@@ -28,35 +28,11 @@
 
 #include "uzu_oracle.h"
 
-#define ATTENTION_SUFFIX_CAPACITY 1024u /* mixer/attention/state.rs:14 */
+#include "uzu_oracle_model_internal.h"
 
-typedef struct {
-    uint16_t* keys;   /* bf16 [max_ctx + 1024, kv_heads*hd] */
-    uint16_t* values;
-    uint32_t length;  /* AttentionStateType::Full { length } | Ring { length } */
-    uint32_t ring_offset, ring_max; /* AttentionStateType::Ring { offset, .., max_length } (ring_max == 0: Full), state.rs:16-55 */
-    float* conv_state; /* f32 [conv_dim, k-1] */
-    float* ssm_state;  /* f32 [Hv, Dv, Dk] */
-    /* DeltaNetSuffixStatus::Tree (delta_net.rs:39-46): what an unaccepted tree pass leaves behind for encode_accept */
-    float* tree_conv_states; /* f32 [tree, conv_dim, k-1] */
-    uint16_t *tree_k, *tree_v; /* bf16 [tree, key_dim] / [tree, value_dim] */
-    float *tree_log_decay, *tree_beta; /* f32 [tree, Hv] */
-} layer_state;
-
-struct orc_model {
-    uzu_model_desc desc;
-    uzu_layer_desc* layers;
-    layer_state* states;
-    uint32_t context_length;
-    uint16_t** layer_outputs; /* debug taps: per layer [rows, d] of the last forward */
-    uint32_t last_rows;
-    uint16_t* final_hidden;
-    /* an unaccepted speculated tree (orc_model_verify_tree ... orc_model_accept) */
-    uint32_t tree_size;
-    int32_t* tree_parents;
-};
-
-static void* xcalloc(size_t n, size_t sz) {
+void* orc_xcalloc(size_t n, size_t sz);
+#define xcalloc orc_xcalloc
+void* orc_xcalloc(size_t n, size_t sz) {
     void* p = calloc(n ? n : 1, sz);
     if (!p) {
         fprintf(stderr, "oracle: out of memory (%zu x %zu)\n", n, sz);
@@ -79,6 +55,7 @@ orc_model* orc_model_create(const uzu_model_desc* desc) {
     m->states = (layer_state*)xcalloc(desc->num_layers, sizeof(layer_state));
     m->layer_outputs = (uint16_t**)xcalloc(desc->num_layers, sizeof(uint16_t*));
     m->final_hidden = (uint16_t*)xcalloc(desc->model_dim, 2);
+    m->hidden_features = (uint16_t**)xcalloc(desc->num_layers, sizeof(uint16_t*));
     for (uint32_t l = 0; l < desc->num_layers; ++l) {
         const uzu_layer_desc* L = &m->layers[l];
         if (L->mixer_kind == UZU_MIXER_ATTENTION && L->is_kv_sharing) {
@@ -143,7 +120,10 @@ void orc_model_destroy(orc_model* m) {
         free(m->states[l].tree_log_decay);
         free(m->states[l].tree_beta);
         free(m->layer_outputs[l]);
+        free(m->hidden_features[l]);
     }
+    free(m->hidden_features);
+    free(m->final_hidden_rows);
     free(m->tree_parents);
     free(m->layer_outputs);
     free(m->final_hidden);
@@ -180,6 +160,16 @@ const uint16_t* orc_model_layer_output(const orc_model* m, uint32_t layer, uint3
     return m->layer_outputs[layer];
 }
 const uint16_t* orc_model_final_hidden(const orc_model* m) { return m->final_hidden; }
+void orc_model_capture_features(orc_model* m, uint32_t on) { m->capture_features = on; }
+const uint16_t* orc_model_hidden_feature(const orc_model* m, uint32_t layer, uint32_t* rows) {
+    if (rows) *rows = m->last_rows;
+    return m->hidden_features[layer];
+}
+const uint16_t* orc_model_final_hidden_rows(const orc_model* m, uint32_t* rows) {
+    if (rows) *rows = m->final_hidden_row_count;
+    return m->final_hidden_rows;
+}
+const uzu_model_desc* orc_model_desc(const orc_model* m) { return &m->desc; }
 
 /* Linear::encode -> MatmulKernel::encode with b_transpose = true (linear/matmul.rs:122-148) */
 static void fp_matmul(const uint16_t* a, const uint16_t* b, uint16_t* d, uint32_t m, uint32_t n, uint32_t k, int accumulate) {
@@ -217,9 +207,15 @@ static uint16_t* linear_qlora(const uzu_linear_desc* lin, const uint16_t* input,
     return out;
 }
 
-static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) {
-    if (lin->lora_rank) return linear_qlora(lin, input, batch);
-    uint16_t* out = (uint16_t*)xcalloc((size_t)batch * lin->n, 2);
+void* orc_linear_typed(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch, uint32_t d_dtype) {
+    if (lin->lora_rank) {
+        if (d_dtype != ORC_BF16) {
+            fprintf(stderr, "oracle: a QLoRA linear with a non-bf16 output\n");
+            abort();
+        }
+        return linear_qlora(lin, input, batch);
+    }
+    void* out = xcalloc((size_t)batch * lin->n, d_dtype == ORC_F32 ? 4 : 2);
     /* RHTLinearWrapper::encode_input (linear/rht_wrapper.rs:215-298), full-precision activation format: InputRht of the rows
      * (encode_fp_in_place on the wrapper's own allocation), the inner LinearMatmul with MatmulDOps::rht_factors = output signs */
     uint16_t* transformed = NULL;
@@ -243,7 +239,7 @@ static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint3
     g.group_size = lin->group_size;
     g.b_transpose = 1;
     g.d = out;
-    g.d_dtype = ORC_BF16;
+    g.d_dtype = d_dtype;
     g.ab_scale = 1.0f;
     g.bias = lin->out_biases;
     g.m = batch;
@@ -253,15 +249,17 @@ static uint16_t* linear(const uzu_linear_desc* lin, const uint16_t* input, uint3
     free(transformed);
     return out;
 }
+uint16_t* orc_linear(const uzu_linear_desc* lin, const uint16_t* input, uint32_t batch) { return (uint16_t*)orc_linear_typed(lin, input, batch, ORC_BF16); }
+#define linear orc_linear
 
 /* Normalization::encode (encodable_block/normalization.rs:114-146); mode: 0 none, 1 copy, 2 add */
 /* scalar_mode: PostLayerScalar (normalization.rs:17-21,76-80): 0 None, 1 ScaleResidualSum(scalar), 2 ScaleOutput(scalar) */
 static uint16_t* norm_scaled(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim,
                              int scalar_mode, float scalar, float epsilon);
-static uint16_t* norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows,
-                      uint32_t dim) {
+uint16_t* orc_norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim) {
     return norm_scaled(nd, input, shortcut, mode, rows, dim, 0, 1.0f, nd->epsilon);
 }
+#define norm orc_norm
 static uint16_t* norm_scaled(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim,
                              int scalar_mode, float scalar, float epsilon) {
     uint16_t* out = (uint16_t*)xcalloc((size_t)rows * dim, 2);
@@ -345,7 +343,7 @@ static uint16_t* attention_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     a.scale = L->attention_scale != 0.0f ? L->attention_scale : 1.0f / sqrtf((float)hd);
     a.num_heads = nq;
     a.suffix_length = batch;
-    a.is_causal = 1;
+    a.is_causal = L->is_non_causal ? 0 : 1; /* AttentionConfig::is_causal (mod.rs:166-198): a DFlash draft block attends to all of its rows */
     a.trie = trie; /* mode.rs:178-192: a non-flat batch runs the is_trie cores with the nodes as the mask's suffix topology */
     uint16_t* out = (uint16_t*)xcalloc((size_t)batch * nq * hd, 2);
     if (physical_prefix + batch > 1024) { /* core/mod.rs:89-92 */
@@ -460,6 +458,100 @@ static uint16_t* delta_net_mixer(orc_model* m, uint32_t l, uint16_t* hidden, uin
     return projected;
 }
 
+uint16_t* orc_layers_forward(orc_model* m, uint16_t* hidden, uint32_t count, const uint32_t* trie, const int32_t* parents, const uint16_t* per_layer_inputs,
+                             uint16_t** shortcut_out) {
+    const uzu_model_desc* D = &m->desc;
+    const uint32_t d = D->model_dim;
+    uint16_t* shortcut = (uint16_t*)xcalloc((size_t)count * d, 2);
+    /* host RoPE tables for this pass, one pair per distinct configuration (transformer.rs:247-257) */
+    const uint32_t n_ropes = D->num_ropes ? D->num_ropes : (D->rope.kind != UZU_ROPE_NONE ? 1u : 0u);
+    float** cos_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
+    float** sin_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
+    if (n_ropes) {
+        uint32_t* pos = (uint32_t*)xcalloc(count, 4);
+        for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + (trie ? trie[3 * i + 2] : i); /* transformer.rs:247: context + height */
+        for (uint32_t r = 0; r < n_ropes; ++r) {
+            const uzu_rope_desc* R = D->num_ropes ? &D->ropes[r] : &D->rope;
+            cos_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
+            sin_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
+            orc_rope_tables(R, pos, count, cos_tabs[r], sin_tabs[r]);
+        }
+        free(pos);
+    }
+    m->last_rows = count;
+    for (uint32_t l = 0; l < D->num_layers; ++l) {
+        const uzu_layer_desc* L = &m->layers[l];
+        uint16_t* h;
+        if (L->pre_mixer_norm.present) {
+            h = norm(&L->pre_mixer_norm, hidden, shortcut, l > 0 ? 2 : 1, count, d);
+            free(hidden);
+        } else {
+            memcpy(shortcut, hidden, (size_t)count * d * 2);
+            h = hidden;
+        }
+        const uint32_t ri = D->num_ropes ? L->rope_index : 0;
+        const float* cosines = L->use_rope && n_ropes ? cos_tabs[ri] : NULL;
+        const float* sines = L->use_rope && n_ropes ? sin_tabs[ri] : NULL;
+        /* transformer_layer.rs:61-84: the scalar belongs to the two norms unless a PLE projection owns it */
+        const int norms_scale = L->has_post_layer_scalar && !L->has_ple;
+        uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines, trie)
+                                                               : delta_net_mixer(m, l, h, count, trie, parents);
+        free(h);
+        if (L->post_mixer_norm.present) {
+            uint16_t* t = norm(&L->post_mixer_norm, mixed, NULL, 0, count, d);
+            free(mixed);
+            mixed = t;
+        }
+        uint16_t* mlp_in = norm_scaled(&L->pre_mlp_norm, mixed, shortcut, 2, count, d, norms_scale ? 1 : 0, L->post_layer_scalar, L->pre_mlp_norm.epsilon);
+        free(mixed);
+        /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
+        uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
+        free(mlp_in);
+        uint16_t* gated = (uint16_t*)xcalloc((size_t)count * L->hidden_dim, 2);
+        orc_gated_act_mul(fused_up, NULL, gated, ORC_BF16, L->hidden_dim, count, 0, 0, L->activation, 1);
+        free(fused_up);
+        uint16_t* down = linear(&L->down_projection, gated, count);
+        free(gated);
+        if (L->post_mlp_norm.present) {
+            uint16_t* t = norm_scaled(&L->post_mlp_norm, down, NULL, 0, count, d, norms_scale ? 2 : 0, L->post_layer_scalar, L->post_mlp_norm.epsilon);
+            free(down);
+            down = t;
+        }
+        if (L->has_ple) {
+            /* PerLayerEmbeddingProjection::encode (per_layer_embedding.rs:217-270): shortcut += hidden; gate(shortcut) -> act(gate) * the
+             * layer's slice of per_layer_inputs -> projection -> norm; shortcut = (shortcut + normed) * post_layer_scalar; hidden = 0 */
+            const uint32_t length = count * d;
+            orc_tensor_add_bias(NULL, down, shortcut, ORC_BF16, ORC_BF16, length, length);
+            uint16_t* gate_out = linear(&L->ple_gate, shortcut, count);
+            uint16_t* activated = (uint16_t*)xcalloc((size_t)count * L->ple_dim, 2);
+            orc_gated_act_mul(gate_out, per_layer_inputs, activated, ORC_BF16, L->ple_dim, count, l * L->ple_dim, D->num_layers * L->ple_dim, L->ple_activation, 0);
+            free(gate_out);
+            uint16_t* projected = linear(&L->ple_projection, activated, count);
+            free(activated);
+            uint16_t* normed = norm(&L->ple_norm, projected, NULL, 0, count, d);
+            free(projected);
+            orc_tensor_add_scale(NULL, normed, shortcut, ORC_BF16, length, length, L->has_post_layer_scalar ? L->post_layer_scalar : 1.0f);
+            free(normed);
+            memset(down, 0, (size_t)length * 2); /* encoder.encode_fill(&mut hidden, 0) (transformer_layer.rs:231) */
+        }
+        hidden = down;
+        if (m->capture_features) { /* Transformer::capture_residual (transformer.rs:160-171): TensorAddScale(shortcut, hidden, 1.0) */
+            free(m->hidden_features[l]);
+            m->hidden_features[l] = (uint16_t*)xcalloc((size_t)count * d, 2);
+            orc_tensor_add_scale(shortcut, hidden, m->hidden_features[l], ORC_BF16, count * d, count * d, 1.0f);
+        }
+        free(m->layer_outputs[l]);
+        m->layer_outputs[l] = (uint16_t*)xcalloc((size_t)count * d, 2);
+        /* (a PLE layer has folded its output into the shortcut and zeroed `hidden`: its tap is the residual row, what capture_residual would file) */
+        memcpy(m->layer_outputs[l], L->has_ple ? shortcut : hidden, (size_t)count * d * 2);
+    }
+    for (uint32_t r = 0; r < n_ropes; ++r) free(cos_tabs[r]), free(sin_tabs[r]);
+    free(cos_tabs);
+    free(sin_tabs);
+    *shortcut_out = shortcut;
+    return hidden;
+}
+
 /* `trie` == NULL: a flat, fully accepted pass (prefill chunk / decode step): logits + greedy token of the LAST row, then encode_accept.
  * `trie` != NULL (3 u32 per node): a speculated tree, not accepted (stream.rs:556-566,618-628): token positions = context + height, logits
  * and greedy tokens of EVERY row (output_range 0..size), the states keep the unaccepted suffix for orc_model_accept. */
@@ -534,92 +626,20 @@ static uint32_t forward_core(orc_model* m, const uint32_t* token_ids, uint32_t c
         free(token_ple);
         free(normed);
     }
-    uint16_t* shortcut = (uint16_t*)xcalloc((size_t)count * d, 2);
-    /* host RoPE tables for this pass, one pair per distinct configuration (transformer.rs:247-257) */
-    const uint32_t n_ropes = D->num_ropes ? D->num_ropes : (D->rope.kind != UZU_ROPE_NONE ? 1u : 0u);
-    float** cos_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
-    float** sin_tabs = (float**)xcalloc(n_ropes, sizeof(float*));
-    if (n_ropes) {
-        uint32_t* pos = (uint32_t*)xcalloc(count, 4);
-        for (uint32_t i = 0; i < count; ++i) pos[i] = m->context_length + (trie ? trie[3 * i + 2] : i); /* transformer.rs:247: context + height */
-        for (uint32_t r = 0; r < n_ropes; ++r) {
-            const uzu_rope_desc* R = D->num_ropes ? &D->ropes[r] : &D->rope;
-            cos_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
-            sin_tabs[r] = (float*)xcalloc((size_t)count * R->head_dim, 4);
-            orc_rope_tables(R, pos, count, cos_tabs[r], sin_tabs[r]);
-        }
-        free(pos);
-    }
-    m->last_rows = count;
-    for (uint32_t l = 0; l < D->num_layers; ++l) {
-        const uzu_layer_desc* L = &m->layers[l];
-        uint16_t* h;
-        if (L->pre_mixer_norm.present) {
-            h = norm(&L->pre_mixer_norm, hidden, shortcut, l > 0 ? 2 : 1, count, d);
-            free(hidden);
-        } else {
-            memcpy(shortcut, hidden, (size_t)count * d * 2);
-            h = hidden;
-        }
-        const uint32_t ri = D->num_ropes ? L->rope_index : 0;
-        const float* cosines = L->use_rope && n_ropes ? cos_tabs[ri] : NULL;
-        const float* sines = L->use_rope && n_ropes ? sin_tabs[ri] : NULL;
-        /* transformer_layer.rs:61-84: the scalar belongs to the two norms unless a PLE projection owns it */
-        const int norms_scale = L->has_post_layer_scalar && !L->has_ple;
-        uint16_t* mixed = L->mixer_kind == UZU_MIXER_ATTENTION ? attention_mixer(m, l, h, count, cosines, sines, trie)
-                                                               : delta_net_mixer(m, l, h, count, trie, parents);
-        free(h);
-        if (L->post_mixer_norm.present) {
-            uint16_t* t = norm(&L->post_mixer_norm, mixed, NULL, 0, count, d);
-            free(mixed);
-            mixed = t;
-        }
-        uint16_t* mlp_in = norm_scaled(&L->pre_mlp_norm, mixed, shortcut, 2, count, d, norms_scale ? 1 : 0, L->post_layer_scalar, L->pre_mlp_norm.epsilon);
-        free(mixed);
-        /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
-        uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
-        free(mlp_in);
-        uint16_t* gated = (uint16_t*)xcalloc((size_t)count * L->hidden_dim, 2);
-        orc_gated_act_mul(fused_up, NULL, gated, ORC_BF16, L->hidden_dim, count, 0, 0, L->activation, 1);
-        free(fused_up);
-        uint16_t* down = linear(&L->down_projection, gated, count);
-        free(gated);
-        if (L->post_mlp_norm.present) {
-            uint16_t* t = norm_scaled(&L->post_mlp_norm, down, NULL, 0, count, d, norms_scale ? 2 : 0, L->post_layer_scalar, L->post_mlp_norm.epsilon);
-            free(down);
-            down = t;
-        }
-        if (L->has_ple) {
-            /* PerLayerEmbeddingProjection::encode (per_layer_embedding.rs:217-270): shortcut += hidden; gate(shortcut) -> act(gate) * the
-             * layer's slice of per_layer_inputs -> projection -> norm; shortcut = (shortcut + normed) * post_layer_scalar; hidden = 0 */
-            const uint32_t length = count * d;
-            orc_tensor_add_bias(NULL, down, shortcut, ORC_BF16, ORC_BF16, length, length);
-            uint16_t* gate_out = linear(&L->ple_gate, shortcut, count);
-            uint16_t* activated = (uint16_t*)xcalloc((size_t)count * L->ple_dim, 2);
-            orc_gated_act_mul(gate_out, per_layer_inputs, activated, ORC_BF16, L->ple_dim, count, l * L->ple_dim, D->num_layers * L->ple_dim, L->ple_activation, 0);
-            free(gate_out);
-            uint16_t* projected = linear(&L->ple_projection, activated, count);
-            free(activated);
-            uint16_t* normed = norm(&L->ple_norm, projected, NULL, 0, count, d);
-            free(projected);
-            orc_tensor_add_scale(NULL, normed, shortcut, ORC_BF16, length, length, L->has_post_layer_scalar ? L->post_layer_scalar : 1.0f);
-            free(normed);
-            memset(down, 0, (size_t)length * 2); /* encoder.encode_fill(&mut hidden, 0) (transformer_layer.rs:231) */
-        }
-        hidden = down;
-        free(m->layer_outputs[l]);
-        m->layer_outputs[l] = (uint16_t*)xcalloc((size_t)count * d, 2);
-        memcpy(m->layer_outputs[l], hidden, (size_t)count * d * 2);
-    }
-    for (uint32_t r = 0; r < n_ropes; ++r) free(cos_tabs[r]), free(sin_tabs[r]);
-    free(cos_tabs);
-    free(sin_tabs);
+    uint16_t* shortcut = NULL;
+    hidden = orc_layers_forward(m, hidden, count, trie, parents, per_layer_inputs, &shortcut);
     free(per_layer_inputs);
     /* output_norm over the output range, shortcut add (transformer.rs:317-323): the last row of a flat pass, every row of a tree */
     const uint32_t out_rows = trie ? count : 1;
     const size_t first = (size_t)(count - out_rows) * d;
     uint16_t* normed = norm(&D->output_norm, hidden + first, shortcut + first, 2, out_rows, d);
     memcpy(m->final_hidden, normed + (size_t)(out_rows - 1) * d, (size_t)d * 2);
+    if (m->capture_features) {
+        free(m->final_hidden_rows);
+        m->final_hidden_rows = (uint16_t*)xcalloc((size_t)out_rows * d, 2);
+        memcpy(m->final_hidden_rows, normed, (size_t)out_rows * d * 2);
+        m->final_hidden_row_count = out_rows;
+    }
     free(hidden);
     free(shortcut);
     /* Embedding::encode_readout (embedding.rs:374-456): readout_input_hadamard = the tied table's output signs (embedding.rs:167-173) or

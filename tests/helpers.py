@@ -195,3 +195,34 @@ def attention_float64(q, k, v, heads, kv_heads, hd, seq, suffix, k_head_stride, 
             denom = p.sum() + (np.exp(sink - m) if sink is not None else 0.0)
             out[qi, h] = (p @ np.array(vals)) / denom if scores else 0.0
     return out
+
+
+class OracleTarget:
+    """The `target` duck type of uzu_amd.speculator over the CPU oracle (the GPU tests pair it with HipModel + HipDrafter)."""
+
+    def __init__(self, om, layer_ids):
+        self.om, self.layer_ids = om, list(layer_ids)
+        om.capture_features(True)
+
+    @property
+    def context_length(self):
+        return self.om.context_length
+
+    def prefill(self, tokens):
+        return self.om.prefill(tokens)
+
+    def hidden_features(self):
+        return [self.om.hidden_feature(l) for l in self.layer_ids]
+
+    def verify_tree(self, token_ids, nodes, seeds=None):
+        return self.om.verify_tree(token_ids, nodes)
+
+    def accept(self, indices):
+        self.om.accept(indices)
+
+    # OracleDFlash.draft wants the OracleModel
+    @property
+    def _h(self):
+        return self.om._h
+
+

@@ -285,7 +285,7 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     a.sequence_length = batch; // + *d_ctx_len on the device
     a.k_head_stride = hd, a.k_seq_stride = nkv * hd, a.v_head_stride = hd, a.v_seq_stride = nkv * hd;
     a.scale = L.d.attention_scale != 0.0f ? L.d.attention_scale : 1.0f / sqrtf((float)hd);
-    a.num_heads = nq, a.suffix_length = batch, a.is_causal = 1;
+    a.num_heads = nq, a.suffix_length = batch, a.is_causal = L.d.is_non_causal ? 0 : 1; // AttentionConfig::is_causal (mod.rs:166-198; mask.rs:3-61)
     a.dyn = m->d_ctx_len;
     a.trie = trie;
     if (W) a.ring_window = W, a.is_kv_cache_ring = 1, a.is_sliding_window = 1, a.sliding_window_size = W;
@@ -392,7 +392,8 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     const uint32_t rows = q.rows();
     const uint32_t* token_ids = seqs ? m->batch_tokens : m->d_tokens;
     uint16_t* hidden = m->hidden;
-    if (m->embedding.method == UZU_QUANT_NONE)
+    if (m->headless) { // the rows are in `hidden` already (a draft model embeds through its target: engine_drafter.hip)
+    } else if (m->embedding.method == UZU_QUANT_NONE)
         RUN("full_precision_embedding_lookup", 0, k::full_precision_embedding_lookup(s, token_ids, m->embedding.w, hidden, UZU_BF16, rows, m->d.vocab_size, d, m->d.input_scale));
     else
         RUN("quantized_embedding_lookup", 0, k::quantized_embedding_lookup(s, token_ids, (const uint8_t*)m->embedding.w, m->embedding.scales, m->embedding.zp, m->embedding.biases,
@@ -434,7 +435,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     // Transformer::prefill_cache_layer_count (transformer.rs:186-199,239-243): a pass that produces no output (a prefill chunk that is not the
     // prompt's last) only has to fill the caches -- it stops behind the last layer that owns a state; trailing KV-sharing layers write nothing
     uint32_t layer_count = m->d.num_layers;
-    if (!sample && !m->tree.active && !m->taps)
+    if (!sample && !m->tree.active && !m->taps && m->feature_layers.empty())
         while (layer_count > 1 && m->layers[layer_count - 1].d.mixer_kind == UZU_MIXER_ATTENTION && m->layers[layer_count - 1].d.is_kv_sharing) --layer_count;
     for (uint32_t l = 0; l < layer_count; ++l) {
         DLayer& L = m->layers[l];
@@ -521,9 +522,26 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
                     RUN("kv_ring_insert", 0, k::kv_ring_insert(s, Lo.keys, Lo.values, UZU_BF16, m->d_ctx_len, count, Lo.d.sliding_window_size, Lo.d.num_groups * Lo.d.head_dim));
                 }
             }
-        if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, count * d));
+        // (a PLE layer has folded its output into the shortcut and zeroed `hidden`: its tap is the residual row, what capture_residual would file)
+        if (m->taps && !seqs) RUN("tensor_copy", 0, k::tensor_copy(s, L.d.has_ple ? sc_cur : hidden, m->taps + ((size_t)l * m->chunk) * d, UZU_BF16, count * d));
+        // Transformer::capture_residual (transformer.rs:160-171,285-293): TensorAddScale(shortcut, hidden, 1.0) of the rows, per tapped layer
+        if (!seqs)
+            for (size_t fi = 0; fi < m->feature_layers.size(); ++fi)
+                if (m->feature_layers[fi] == l)
+                    RUN("tensor_add_scale", 0, k::tensor_add_scale(s, sc_cur, hidden, m->features + (fi * m->chunk) * d, UZU_BF16, count * d, count * d, 1.0f));
     }
     m->tap_rows = count;
+    m->feature_rows = seqs ? 0 : count;
+    m->last_shortcut = sc_cur;
+    if (m->headless) { // a draft pass: no output norm / read-out / commit of its own (engine_drafter.hip does what follows)
+        if (e.st != UZU_OK) return e.st;
+        const hipError_t herr = hipGetLastError();
+        if (herr != hipSuccess) {
+            set_error("engine: draft pass launch failed: %s", hipGetErrorString(herr));
+            return UZU_ERR_HIP;
+        }
+        return UZU_OK;
+    }
     if (m->tree.active) {
         // a tree pass: output norm, read-out and greedy sampling of EVERY node (output_range 0..size, stream.rs:618-628), no commit
         norm(e, m->output_norm, hidden, m->tree.normed, sc_cur, 2, count, d);
@@ -670,6 +688,7 @@ bool norm_fusable(const DNorm& N) { return N.present && !N.subtract_mean && !N.b
 bool dim_fusable(uint32_t d) { return d % 1024 == 0 && d <= 8192; }
 
 bool model_fusable(const uzu_hip_model* m) {
+    if (m->headless || !m->feature_layers.empty()) return false; // draft cores; a target whose passes file hidden features: the one-kernel-per-reference-kernel pass
     if (m->gemma_options) return false; // post-layer scalars, embedding norm, KV sharing, value normalisation, per-layer embeddings: the one-kernel-per-reference-kernel pass
     if (m->d.logit_scale != 1.0f || m->d.logit_soft_cap != 0.0f) return false;
     if (!dim_fusable(m->d.model_dim)) return false;
@@ -684,7 +703,7 @@ bool model_fusable(const uzu_hip_model* m) {
             if (L.d.has_gate && (!linear_fusable(L.gate) || L.gate.bits != L.qkv.bits || L.gate.group != L.qkv.group || L.gate.method != L.qkv.method)) return false;
             // (the two matrices of the fused launch share one prologue: with different input transforms the gate gets a launch of its own)
             if (!(L.d.head_dim == 64 || L.d.head_dim == 128 || L.d.head_dim == 256)) return false;
-            if (L.d.sliding_window_size || L.d.has_sinks) return false; // ring KV state / sinks: the one-kernel-per-reference-kernel path (attn_dec has neither)
+            if (L.d.sliding_window_size || L.d.has_sinks || L.d.is_non_causal) return false; // ring KV state / sinks / block attention: the one-kernel-per-reference-kernel path (attn_dec has neither)
             if ((L.qn.present && (L.qn.subtract_mean || L.qn.biases)) || (L.kn.present && (L.kn.subtract_mean || L.kn.biases))) return false;
         } else {
             if (!linear_fusable(L.in_proj) || !linear_fusable(L.out_proj)) return false;

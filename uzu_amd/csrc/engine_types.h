@@ -166,6 +166,15 @@ struct uzu_hip_model {
     uint32_t sampling_epoch = 0;
     uint16_t* taps = nullptr; // [layers][chunk][d] (chunk = rows of one prefill pass)
     uint32_t tap_rows = 0;
+    // The hidden-feature taps of a speculator (stream.rs:213-214,632-633; Transformer::capture_residual, transformer.rs:160-171,285-293): after each tapped
+    // layer the residual-stream row shortcut + hidden of every row of the pass.  Production outputs (not UZU_MODEL_DEBUG_TAPS): uzu_hip_model_set_feature_layers
+    std::vector<uint32_t> feature_layers; // tapped layer indices, in the caller's order
+    uint16_t* features = nullptr;         // [feature_layers.size()][chunk][d]
+    uint32_t feature_rows = 0;            // rows of the last pass
+    // A DFlash draft model's layer stack runs on a uzu_hip_model of its own (engine_drafter.hip) without an embedding: the caller fills `hidden` with the rows,
+    // the pass neither samples nor commits (its block is never accepted: dflash.rs:273-345), and leaves where the residual rows ended up
+    bool headless = false;
+    uint16_t* last_shortcut = nullptr;
 
     // fused decode path
     bool fusable = false;

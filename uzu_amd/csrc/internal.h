@@ -65,9 +65,10 @@ inline bool raise_lds_limit(LdsLimit& st, const void* fn, size_t lds) {
     return true;
 }
 
-// Environment switches.  The shipped library reads nine (UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK, UZU_TP_TIMEOUT_MS,
-// UZU_TP_INJECT_TIMEOUT_AT, UZU_GEMM_FORM, UZU_GEMM_SPLITS, UZU_EXACT_SCALAR, UZU_ROWS_NORM -- each crossed by a test); every other knob is a LAB switch
-// of the A/B scripts under tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
+// Environment switches.  The shipped library reads twelve, each crossed by a test: UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK,
+// UZU_TP_TIMEOUT_MS, UZU_TP_INJECT_TIMEOUT_AT, UZU_GEMM_FORM, UZU_GEMM_SPLITS, UZU_EXACT_SCALAR, UZU_ROWS_NORM, UZU_CONV_APPLY4, UZU_NORM_PARTIALS, UZU_DN_SPLIT
+// (the last three: tests/test_gpu_prefill_switches.py holds the fused prefill paths to the paths they replace).  Every other knob is a LAB switch of the A/B
+// scripts under tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
 inline const char* lab_env(const char* name) {
 #ifdef UZU_LAB
     return getenv(name);

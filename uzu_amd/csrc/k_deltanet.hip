@@ -342,7 +342,7 @@ uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* c
     UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(conv_halo_kernel, dim3(gh), dim3(256), 0, s, in_proj, state, halo, suffix_len, kernel_size, conv_dim, out_stride, nblocks); },
                                "conv_halo"));
     static const bool wide = [] { // UZU_CONV_APPLY4=0: one channel per thread everywhere (A/B runs)
-        const char* e = lab_env("UZU_CONV_APPLY4");
+        const char* e = getenv("UZU_CONV_APPLY4");
         return !e || atoi(e) != 0;
     }();
     if (wide && kernel_size == 4 && conv_dim % 4 == 0 && out_stride % 4 == 0 && (((uintptr_t)in_proj | (uintptr_t)halo) & 15) == 0 &&

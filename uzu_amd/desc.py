@@ -71,7 +71,7 @@ class LayerDesc(C.Structure):
         # layer options of the Gemma families (all zero = none)
         ("rope_index", C.c_uint32), ("has_post_layer_scalar", C.c_uint32), ("post_layer_scalar", C.c_float),
         ("is_kv_sharing", C.c_uint32), ("kv_source_layer_index", C.c_uint32), ("normalize_values", C.c_uint32),
-        ("has_ple", C.c_uint32), ("ple_dim", C.c_uint32), ("ple_activation", C.c_uint32), ("reserved3", C.c_uint32),
+        ("has_ple", C.c_uint32), ("ple_dim", C.c_uint32), ("ple_activation", C.c_uint32), ("is_non_causal", C.c_uint32),
         ("ple_gate", LinearDesc), ("ple_projection", LinearDesc), ("ple_norm", NormDesc),
     ]
 
@@ -229,6 +229,7 @@ class LayerWeights:
     kv_source_layer_index: Optional[int] = None  # is_kv_sharing: queries only, the KV state of that earlier layer is read
     normalize_values: bool = False
     ple: Optional["PleLayerWeights"] = None      # ple_config: PerLayerEmbeddingProjection at the end of the layer
+    is_non_causal: bool = False                  # AttentionConfig::is_causal == false (the block attention of a DFlash draft layer)
 
     def desc(self) -> LayerDesc:
         empty = LinearDesc()
@@ -250,7 +251,7 @@ class LayerWeights:
             ld(self.up_projection), ld(self.down_projection),
             int(self.rope_index), int(self.post_layer_scalar is not None), float(self.post_layer_scalar or 0.0),
             int(self.kv_source_layer_index is not None), int(self.kv_source_layer_index or 0), int(self.normalize_values),
-            int(self.ple is not None), self.ple.ple_dim if self.ple else 0, self.ple.activation if self.ple else 0, 0,
+            int(self.ple is not None), self.ple.ple_dim if self.ple else 0, self.ple.activation if self.ple else 0, int(self.is_non_causal),
             ld(self.ple.gate if self.ple else None), ld(self.ple.projection if self.ple else None),
             (self.ple.norm if self.ple else ABSENT_NORM).desc(),
         )
@@ -289,6 +290,45 @@ class RopeConfig:
         return RopeDesc(self.kind, self.head_dim, self.max_sequence_length, self.original_context_length, self.base,
                         self.scaling_factor, self.low_frequency_factor, self.high_frequency_factor, self.beta_fast, self.beta_slow,
                         int(self.truncate), 0, ptr(self.short_factor), ptr(self.long_factor))
+
+
+class DFlashDesc(C.Structure):
+    """include/uzu_model_desc.h::uzu_dflash_desc"""
+    _fields_ = [
+        ("model_dim", C.c_uint32), ("hidden_dim", C.c_uint32), ("block_size", C.c_uint32), ("mask_token_id", C.c_uint32),
+        ("num_target_layers", C.c_uint32), ("num_layers", C.c_uint32), ("vocab_size", C.c_uint32), ("context_capacity", C.c_uint32),
+        ("target_layer_ids", C.POINTER(C.c_uint32)),
+        ("context_projection", LinearDesc), ("context_norm", NormDesc), ("state_kv_projection", LinearDesc), ("rope", RopeDesc),
+        ("layers", C.POINTER(LayerDesc)), ("output_norm", NormDesc),
+    ]
+
+
+@dataclass
+class DFlashBundle:
+    """A DFlash draft model (DFlashDraftConfig, config/dflash.rs:9-23, + the tensors of `speculator.draft_model`)."""
+    name: str
+    model_dim: int
+    hidden_dim: int
+    block_size: int
+    mask_token_id: int
+    target_layer_ids: List[int]
+    vocab_size: int
+    context_capacity: int
+    context_projection: "LinearWeights"
+    context_norm: "NormWeights"
+    state_kv_projection: "LinearWeights"
+    rope: "RopeConfig"
+    layers: List["LayerWeights"]
+    output_norm: "NormWeights"
+    _keep: list = field(default_factory=list, repr=False)
+
+    def desc(self) -> DFlashDesc:
+        arr = (LayerDesc * len(self.layers))(*[l.desc() for l in self.layers])
+        ids = (C.c_uint32 * len(self.target_layer_ids))(*self.target_layer_ids)
+        self._keep += [arr, ids]
+        return DFlashDesc(self.model_dim, self.hidden_dim, self.block_size, self.mask_token_id, len(self.target_layer_ids), len(self.layers), self.vocab_size,
+                          self.context_capacity, C.cast(ids, C.POINTER(C.c_uint32)), self.context_projection.desc(), self.context_norm.desc(),
+                          self.state_kv_projection.desc(), self.rope.desc(), C.cast(arr, C.POINTER(LayerDesc)), self.output_norm.desc())
 
 
 @dataclass

@@ -209,6 +209,24 @@ class HipModel:
         self.accept([index for index, _, _ in accepted])
         return [int(out) for _, _, out in accepted]
 
+    # ---- the speculator's hidden-feature taps (stream.rs:213-214,632-633; transformer.rs:160-171,285-293) ----
+    def set_feature_layers(self, layer_ids):
+        """Every later pass files bf16(shortcut + hidden) of every row after each listed layer (production outputs; [] removes the taps)."""
+        ids = np.ascontiguousarray(layer_ids, dtype=np.uint32)
+        call("uzu_hip_model_set_feature_layers", self._h, C.c_void_p(ids.ctypes.data) if ids.size else None, C.c_uint32(ids.size))
+        self._feature_layers = [int(i) for i in ids]
+
+    def hidden_features(self):
+        """-> one bf16-bits array [rows, model_dim] per tapped layer, for the rows of the last pass"""
+        out = []
+        for i in range(len(getattr(self, "_feature_layers", []))):
+            rows = C.c_uint32()
+            call("uzu_hip_model_read_features", self._h, C.c_uint32(i), None, C.byref(rows))
+            a = np.empty((rows.value, self.model_dim), dtype=np.uint16)
+            call("uzu_hip_model_read_features", self._h, C.c_uint32(i), C.c_void_p(a.ctypes.data), C.byref(rows))
+            out.append(a)
+        return out
+
     def read_layer_output(self, layer: int) -> np.ndarray:
         rows, capacity = C.c_uint32(), C.c_uint32()
         call("uzu_hip_model_layer_output_rows", self._h, C.byref(rows), C.byref(capacity))  # a prefill pass holds up to `chunk` rows (2048 by default, UZU_PREFILL_CHUNK)
@@ -224,3 +242,64 @@ class HipModel:
         count = C.c_uint32()
         call("uzu_hip_model_profile_decode_step", self._h, C.c_uint32(capacity), names, nbytes, ms, C.byref(count))
         return [(names[i].decode(), int(nbytes[i]), float(ms[i])) for i in range(count.value)]
+
+
+class HipDrafter:
+    """The DFlash draft model next to its target (include/uzu_hip_engine.h: uzu_hip_drafter_*; encodable_block/dflash.rs:41-346).  Same duck type as
+    oracle.OracleDFlash: uzu_amd.speculator drives either."""
+
+    def __init__(self, ctx: Context, target: HipModel, bundle):
+        self.ctx, self.target, self.bundle = ctx, target, bundle
+        self.block_size, self.model_dim, self.vocab_size = bundle.block_size, bundle.model_dim, bundle.vocab_size
+        self.target_layer_ids = list(bundle.target_layer_ids)
+        desc = bundle.desc()
+        self._h = C.c_void_p()
+        call("uzu_hip_drafter_create", ctx._h, target._h, C.byref(desc), C.byref(self._h))
+        target.set_feature_layers(self.target_layer_ids)
+
+    def close(self):
+        if self._h:
+            fn = _ffi.lib().uzu_hip_drafter_destroy
+            fn.restype, fn.argtypes = None, [C.c_void_p]
+            fn(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        call("uzu_hip_drafter_reset", self._h)
+
+    @property
+    def context_length(self) -> int:
+        fn = _ffi.lib().uzu_hip_drafter_context_length
+        fn.restype, fn.argtypes = C.c_uint32, [C.c_void_p]
+        return int(fn(self._h))
+
+    def accept(self, target_features, accepted_indices):
+        """DFlash::encode_accept over rows of the target's LAST pass; `target_features` is accepted for symmetry with the oracle object and ignored:
+        the rows never leave the device (the engine reads the target's taps in place)."""
+        idx = np.ascontiguousarray(accepted_indices, dtype=np.uint32)
+        call("uzu_hip_drafter_accept", self._h, C.c_void_p(idx.ctypes.data) if idx.size else None, C.c_uint32(idx.size))
+
+    def draft(self, target, target_output_token: int, batch_size: int, want_outputs: bool = False):
+        """-> (draft_hidden bf16 bits [batch, d] | None, logits f32 [batch - 1, vocab] | None, greedy tokens [batch - 1])"""
+        tokens = np.empty(batch_size - 1, dtype=np.uint32)
+        call("uzu_hip_drafter_draft", self._h, C.c_uint32(int(target_output_token)), C.c_uint32(batch_size), C.c_void_p(tokens.ctypes.data))
+        hidden = logits = None
+        if want_outputs:
+            hidden = np.empty((batch_size, self.model_dim), dtype=np.uint16)
+            logits = np.empty((batch_size - 1, self.target.logit_count), dtype=np.float32)
+            call("uzu_hip_drafter_read_draft", self._h, C.c_void_p(hidden.ctypes.data), C.c_void_p(logits.ctypes.data), None)
+        return hidden, logits, tokens
+
+    @property
+    def gpu_ms(self):
+        """(accept_ms, draft_ms) of the last calls: device time between HIP events on the engine's stream"""
+        a, d = C.c_float(), C.c_float()
+        call("uzu_hip_drafter_gpu_ms", self._h, C.byref(a), C.byref(d))
+        return a.value, d.value

@@ -82,6 +82,7 @@ class ModelConfig:
     ple_dim: int = 0               # > 0: per-layer embeddings (PLEModelConfig + a PLELayerConfig on every layer)
     ple_vocab_size: int = 0        # 0 = vocab_size
     first_layer_without_pre_mixer_norm: bool = False
+    non_causal_attention: bool = False  # AttentionConfig::is_causal == false on every attention layer (the block attention of a DFlash draft model)
 
     @property
     def num_layers(self) -> int:
@@ -238,18 +239,9 @@ def make_norm(cfg: ModelConfig, name: str, dim: int) -> D.NormWeights:
     return D.NormWeights(True, cfg.norm_full_layer, False, cfg.norm_epsilon, cfg.norm_scale_offset, scales, None)
 
 
-def build_model(cfg: ModelConfig) -> D.ModelBundle:
+def build_layers(cfg: ModelConfig) -> List[D.LayerWeights]:
+    """The TransformerLayers of `cfg` (also the layers of a DFlash draft model: build_drafter)."""
     d = cfg.model_dim
-    row_mult = readout_row_multipliers(cfg)
-    embedding = make_linear(cfg, "embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
-    output_embedding = None
-    if not cfg.tied_embeddings:
-        output_embedding = make_linear(cfg, "output_embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
-    if cfg.rht_embeddings:  # HybridSpec Output mode on the (input) table, Input mode on an untied output embedding (embedding.rs:126-341)
-        signs = np.array([-1, 1], np.int32)
-        embedding.output_signs = np.ascontiguousarray(_rng(cfg.seed, "embedding.signs").choice(signs, d))
-        if output_embedding is not None:
-            output_embedding.input_signs = np.ascontiguousarray(_rng(cfg.seed, "output_embedding.signs").choice(signs, d))
     layers: List[D.LayerWeights] = []
     attn_index = 0
     for li, kind in enumerate(cfg.layer_kinds):
@@ -296,6 +288,7 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
                 lw.sliding_window_size = int(cfg.sliding_windows[attn_index % len(cfg.sliding_windows)])
             if cfg.sinks:
                 lw.sinks = f32_to_bf16_bits(_rng(cfg.seed, p + "mixer.sinks").normal(0.0, 1.0, cfg.num_heads).astype(np.float32))
+            lw.is_non_causal = cfg.non_causal_attention
             attn_index += 1
         else:
             Hv, Hk, Dk, Dv = cfg.dn_num_heads, cfg.dn_num_groups, cfg.dn_head_dim, cfg.dn_value_head_dim
@@ -313,6 +306,22 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
             lw.dn_dt_bias = r.uniform(-1.0, 1.0, size=(Hv,)).astype(np.float32)
             lw.dn_norm_scales = (1.0 + r.uniform(-0.1, 0.1, size=(Dv,))).astype(np.float32)
         layers.append(lw)
+    return layers
+
+
+def build_model(cfg: ModelConfig) -> D.ModelBundle:
+    d = cfg.model_dim
+    row_mult = readout_row_multipliers(cfg)
+    embedding = make_linear(cfg, "embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
+    output_embedding = None
+    if not cfg.tied_embeddings:
+        output_embedding = make_linear(cfg, "output_embedding", cfg.vocab_size, d, gain=1.0, row_mult=row_mult)
+    if cfg.rht_embeddings:  # HybridSpec Output mode on the (input) table, Input mode on an untied output embedding (embedding.rs:126-341)
+        signs = np.array([-1, 1], np.int32)
+        embedding.output_signs = np.ascontiguousarray(_rng(cfg.seed, "embedding.signs").choice(signs, d))
+        if output_embedding is not None:
+            output_embedding.input_signs = np.ascontiguousarray(_rng(cfg.seed, "output_embedding.signs").choice(signs, d))
+    layers = build_layers(cfg)
     ple = None
     if cfg.ple_dim:
         total = cfg.num_layers * cfg.ple_dim
@@ -329,6 +338,29 @@ def build_model(cfg: ModelConfig) -> D.ModelBundle:
         tied_embeddings=cfg.tied_embeddings, output_embedding=output_embedding,
         ropes=list(cfg.layer_ropes) if cfg.layer_ropes else None,
         embedding_norm=make_norm(cfg, "embedding_norm", d) if cfg.embedding_norm else D.ABSENT_NORM, ple=ple)
+
+
+def build_drafter(target: ModelConfig, num_layers: int = 2, block_size: int = 8, target_layer_ids: Optional[List[int]] = None, hidden_dim: int = 0, num_heads: int = 0,
+                  num_groups: int = 0, head_dim: int = 0, non_causal: bool = True, qk_norm: Optional[bool] = None, mask_token_id: Optional[int] = None,
+                  context_capacity: int = 0) -> "D.DFlashBundle":
+    """A DFlash draft model for `target` (DFlashDraftConfig, config/dflash.rs:9-23; tensors of `speculator.draft_model`, encodable_block/dflash.rs:86-172):
+    attention-only layers of the target's width, the context projection over the tapped target layers, the per-layer key / value projection."""
+    ids = list(target_layer_ids) if target_layer_ids is not None else sorted({max(target.num_layers // 2 - 1, 0), target.num_layers - 1})
+    assert all(0 <= i < target.num_layers for i in ids)
+    rope = target.rope if target.rope.kind != D.ROPE_NONE else D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=head_dim or target.head_dim, max_sequence_length=target.max_context_length + 1024, base=10000.0)
+    cfg = replace(target, name=target.name + "-dflash", layer_kinds=[D.MIXER_ATTENTION] * num_layers, hidden_dim=hidden_dim or target.hidden_dim,
+                  num_heads=num_heads or target.num_heads, num_groups=num_groups or target.num_groups, head_dim=head_dim or target.head_dim, has_gate=False,
+                  qk_norm=target.qk_norm if qk_norm is None else qk_norm, seed=target.seed + 7001, rope=replace(rope, head_dim=min(rope.head_dim, head_dim or target.head_dim)),
+                  non_causal_attention=non_causal, sliding_windows=None, sinks=False, post_norms=False, post_layer_scalars=False, embedding_norm=False, normalize_values=False,
+                  layer_ropes=None, rope_pattern=None, kv_sharing=None, ple_dim=0, first_layer_without_pre_mixer_norm=False, rht=False, rht_embeddings=False, qlora_rank=0)
+    d = cfg.model_dim
+    layers = build_layers(cfg)
+    kv_dim = 2 * cfg.num_groups * cfg.head_dim
+    return D.DFlashBundle(
+        name=cfg.name, model_dim=d, hidden_dim=cfg.hidden_dim, block_size=block_size, mask_token_id=(target.vocab_size - 1) if mask_token_id is None else mask_token_id,
+        target_layer_ids=ids, vocab_size=target.vocab_size, context_capacity=context_capacity or target.max_context_length,
+        context_projection=make_linear(cfg, "context_projection", d, d * len(ids), gain=1.0), context_norm=make_norm(cfg, "context_norm", d),
+        state_kv_projection=make_linear(cfg, "state_kv_projection", num_layers * kv_dim, d, gain=1.0), rope=cfg.rope, layers=layers, output_norm=make_norm(cfg, "output_norm", d))
 
 
 def synthetic_prompt(length: int, vocab_size: int, variant: int = 0, suffix: int = 16) -> np.ndarray:
