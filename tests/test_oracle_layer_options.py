@@ -142,8 +142,12 @@ def test_per_layer_embedding_owns_the_post_layer_scalar():
     half.layers[0].ple.norm = D.NormWeights(True, True, False, 1e-6, 0.0, np.zeros(cfg.model_dim, np.float32), None)
     half.layers[0].post_layer_scalar = 0.5
     oa, ob = O.OracleModel(half), O.OracleModel(S.build_model(replace(one, ple_dim=0, post_layer_scalars=False)))
+    oa.capture_features(True), ob.capture_features(True)
     oa.forward(PROMPT[:5]), ob.forward(PROMPT[:5])
-    assert np.array_equal(oa.layer_output(0), np.zeros_like(oa.layer_output(0))), "the PLE projection leaves hidden = 0 (transformer_layer.rs:231)"
+    # the PLE projection folds the layer's output into the shortcut and leaves hidden = 0 (transformer_layer.rs:231): the layer's tap is the residual row --
+    # what Transformer::capture_residual(shortcut, hidden) files for it -- here exactly half of the plain layer's residual row
+    assert np.array_equal(oa.layer_output(0), oa.hidden_feature(0))
+    assert np.array_equal(f(oa.layer_output(0)), 0.5 * f(ob.hidden_feature(0)))
     la, lb = f(oa.final_hidden()), f(ob.final_hidden())
     assert np.abs(la - lb).max() <= 2.0 ** -6 * np.abs(lb).max()
     oa.close(), ob.close()

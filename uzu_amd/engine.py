@@ -245,8 +245,8 @@ class HipModel:
 
 
 class HipDrafter:
-    """The DFlash draft model next to its target (include/uzu_hip_engine.h: uzu_hip_drafter_*; encodable_block/dflash.rs:41-346).  Same duck type as
-    oracle.OracleDFlash: uzu_amd.speculator drives either."""
+    """The DFlash draft model next to its target (include/uzu_hip_engine.h: uzu_hip_drafter_*; encodable_block/dflash.rs:41-346): the `drafter`
+    duck type of uzu_amd.speculator."""
 
     def __init__(self, ctx: Context, target: HipModel, bundle):
         self.ctx, self.target, self.bundle = ctx, target, bundle
@@ -281,7 +281,7 @@ class HipDrafter:
         return int(fn(self._h))
 
     def accept(self, target_features, accepted_indices):
-        """DFlash::encode_accept over rows of the target's LAST pass; `target_features` is accepted for symmetry with the oracle object and ignored:
+        """DFlash::encode_accept over rows of the target's LAST pass; `target_features` belongs to the duck type (a host-side drafter would need the rows) and is ignored here:
         the rows never leave the device (the engine reads the target's taps in place)."""
         idx = np.ascontiguousarray(accepted_indices, dtype=np.uint32)
         call("uzu_hip_drafter_accept", self._h, C.c_void_p(idx.ctypes.data) if idx.size else None, C.c_uint32(idx.size))

@@ -1,13 +1,13 @@
 """Host side of the DFlash tree speculator (crates/backend-uzu/src/speculators/dflash_tfm.rs) and of the speculative leg of
 ``LanguageModelStream`` (engine/language_model/stream/stream.rs:299-318 prefill taps, 380-470 accept, 551-628 propose + verify).
 
-The device work sits behind two duck-typed objects, so the SAME host code drives the CPU oracle and the HIP engine (the parity tests compare the tries
-and token streams the two produce):
+The device work sits behind two duck-typed objects (the parity tests drive a CPU checker through the same host code and compare the tries and token
+streams):
 
   target   prefill(tokens) -> token, verify_tree(token_ids, nodes[, seeds]) -> sampled tokens, accept(indices), hidden_features() -> [rows, d] per tapped
-           layer of the LAST pass, context_length                        (uzu_amd.engine.HipModel | tests' oracle adapter)
+           layer of the LAST pass, context_length                        (uzu_amd.engine.HipModel)
   drafter  accept(features, indices), draft(target, token, depth) -> (draft_hidden, logits, tokens), block_size, target_layer_ids, context_length
-                                                                         (uzu_amd.engine.HipDrafter | oracle.OracleDFlash)
+                                                                         (uzu_amd.engine.HipDrafter)
 
 Same names and meaning as the reference:
   DFlashTfmTreeShape / DFlashTfmTreeConstructionMethod     dflash_tfm.rs:57-72
