@@ -457,6 +457,32 @@ uzu_status uzu_hip_weaver_top_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
  * on the context's stream.  bench.py's roofline.latency_floor = edges per token x this + the read-out's stream time (csrc/k_probe.hip). */
 uzu_status uzu_hip_probe_edge_floor(uzu_hip_context* ctx, uint32_t workgroups, uint32_t row_bytes, uint32_t launches, uint32_t replays, float* us_per_launch);
 
+/* ---- Mixture of experts (MoeBlock::encode, encodable_block/mlp/moe/mod.rs:204-350).  BF16 tensors.  Where the reference's CPU kernel has a
+ * body the entry follows it (router_topk.rs, counts_offsets_fused.rs, gather.rs, the down pass of experts_two_pass_decode.rs:33-77, finalize.rs); where it is todo!()
+ * the Metal shader is the statement of record (scatter_buckets.metal, experts_two_pass_decode.metal pass A).  Metal's tile-map / dispatch-argument kernels
+ * (tiles_map.rs, tiles_pass_a.rs) and MoeBlockBasesFromPartials only shape its indirect dispatches and have no counterpart: the expert passes are launched for the row
+ * capacity (tokens x active experts), find a row's expert through `row_expert_map` (MoePassABuildRowMap) and stop at the routed count in `sumk_buf`. */
+uzu_status uzu_hip_moe_router_top_k_create(uzu_hip_context* ctx, uint32_t scalar_t, uint32_t has_biases, uint32_t has_router_scales, uint32_t has_per_expert_scales,
+                                           uint32_t has_router_input_scale, uint32_t normalize_router_input, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_router_top_k_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf weight, uzu_buf bias, uzu_buf topk_ids, uzu_buf topk_probs, uint32_t t, uint32_t d_model,
+                                           uint32_t e, uint32_t top_k, uint32_t renorm);
+uzu_status uzu_hip_moe_counts_offsets_fused_create(uzu_hip_context* ctx, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_counts_offsets_fused_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf topk_ids, uzu_buf offsets, uzu_buf sum_k_out, uzu_buf partials /* optional */, uint32_t t,
+                                                   uint32_t e, uint32_t top_k);
+uzu_status uzu_hip_moe_scatter_buckets_map_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_scatter_buckets_map_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf topk_ids, uzu_buf topk_probs, uzu_buf offsets, uzu_buf out_ids, uzu_buf out_probs, uint32_t t,
+                                                  uint32_t e, uint32_t top_k, uzu_buf tok2row, uzu_buf row_expert_map);
+uzu_status uzu_hip_moe_gather_x_perm_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_gather_x_perm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf x, uzu_buf bucketed_ids, uzu_buf x_perm, uzu_buf sumk_buf, uint32_t d_model, uint32_t t, uint32_t top_k);
+uzu_status uzu_hip_moe_experts_pass_a_create(uzu_hip_context* ctx, uint32_t t, uint32_t gating_sel, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_experts_pass_a_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf x_perm, uzu_buf row_expert_map, uzu_buf sumk_buf, uzu_buf w13_all, uzu_buf up_biases, uzu_buf hidden_out,
+                                             uint32_t d_model, uint32_t d_ff, float gate_clip_min, float gate_clip_max, float up_clip_min, float up_clip_max, float silu_alpha, uint32_t capacity);
+uzu_status uzu_hip_moe_experts_down_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_experts_down_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf hidden, uzu_buf row_expert_map, uzu_buf sumk_buf, uzu_buf w2_all, uzu_buf down_biases, uzu_buf y_out,
+                                           uint32_t d_model, uint32_t d_ff, uint32_t capacity);
+uzu_status uzu_hip_moe_finalize_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out);
+uzu_status uzu_hip_moe_finalize_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf tok2row, uzu_buf probs, uzu_buf y_partial, uzu_buf y, uint32_t t_count, uint32_t d_model, uint32_t top_k);
+
 #ifdef __cplusplus
 }
 #endif

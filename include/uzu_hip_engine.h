@@ -33,6 +33,11 @@ enum {
 /* bits 8..15 of `flags`: sequences one batched prefill pass may carry (scratch is sized for it); 0 = 1 */
 #define UZU_MODEL_BATCH(n) (((uint32_t)(n) & 0xFFu) << 8)
 
+/* sizeof of {uzu_linear_desc, uzu_norm_desc, uzu_rope_desc, uzu_layer_desc, uzu_model_desc, uzu_dflash_desc} in THIS library build: the description structs have grown
+ * in place over the rounds and uzu_layer_desc is an array element, so a caller built against another header must refuse to go on (uzu_amd/desc.py checks at import of the
+ * engine; there is no version negotiation: one header, one library). */
+void uzu_hip_desc_abi(uint32_t out[6]);
+
 /* Uploads every tensor of `desc` into HBM (the desc's host pointers are not retained). */
 uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out);
 void uzu_hip_model_destroy(uzu_hip_model* m);

@@ -110,12 +110,37 @@ typedef struct {
     const float* long_factor;         /* LongRoPE: used when max_sequence_length > original_context_length */
 } uzu_rope_desc;
 
-/* config/transformer_layer.rs:8-21 with AttentionConfig / DeltaNetConfig and a DenseMLPConfig */
+/* MixtureOfExpertsConfig (config/mlp/mixture_of_experts.rs:9-22) + the tensors of the `mlp` subtree of a MoE layer (encodable_block/mlp/moe/mod.rs:114-160),
+ * all in the model's data type (bf16), full precision:
+ *   router.weights.weights [E, model_dim] (FullPrecisionSpec, Layout::OutputInput), router.biases [E]
+ *   experts.up_projection.weights.weights [E, 2*d_ff, model_dim] (rows [0, d_ff) of an expert = up, [d_ff, 2 d_ff) = gate), experts.up_projection.biases [E, 2*d_ff]
+ *   experts.down_projection.weights.weights [E, model_dim, d_ff], experts.down_projection.biases [E, model_dim]
+ * What MoeBlock::new refuses is refused here as well: shared experts, an expert gate, a block without router / up / down biases, activations other than
+ * SiLU / GELUApprox, more than 512 routed or 128 active experts, model_dim % 4 != 0 (mod.rs:84-112). */
+typedef struct {
+    uint32_t num_routed_experts;
+    uint32_t num_active_experts; /* num_active_routed_experts */
+    uint32_t expert_hidden_dim;  /* d_ff */
+    uint32_t router_renorm;      /* routing_function == SoftmaxRouting: softmax over the k winners (mod.rs:110); else the raw logits */
+    uint32_t gating_sel;         /* 2 = SwiGLU (expert activation SILU), 3 = GEGLU (GELUApprox)  (mod.rs:104-108) */
+    float silu_alpha;            /* expert_config.activation.alpha() */
+    float gate_clip_min, gate_clip_max, up_clip_min, up_clip_max; /* expert_config.{gate,up}_clipping; -inf / +inf = none */
+    const uint16_t* router_weights;
+    const uint16_t* router_biases;
+    const uint16_t* w13;
+    const uint16_t* w2;
+    const uint16_t* up_biases;
+    const uint16_t* down_biases;
+} uzu_moe_desc;
+
+typedef enum { UZU_MLP_DENSE = 0, UZU_MLP_MOE = 1 } uzu_mlp_kind;
+
+/* config/transformer_layer.rs:8-21 with AttentionConfig / DeltaNetConfig and a DenseMLPConfig | MixtureOfExpertsConfig */
 typedef struct {
     uint32_t mixer_kind; /* uzu_mixer_kind */
     uint32_t hidden_dim; /* MLP hidden (up projection has 2*hidden rows: [up ; gate]) */
     uint32_t activation; /* uzu_activation_type of the gated MLP */
-    uint32_t reserved;
+    uint32_t mlp_kind;   /* uzu_mlp_kind (the field was `reserved`: 0 = the dense MLP) */
 
     uzu_norm_desc pre_mixer_norm;
     uzu_norm_desc post_mixer_norm;
@@ -158,7 +183,8 @@ typedef struct {
     uzu_linear_desc down_projection; /* k = hidden */
 
     /* --- layer options of the Gemma families (config/transformer_layer.rs:16-20, config/token_mixer/attention.rs:26-28);
-     *     all zero = none of them (a layer description that stops at down_projection keeps its meaning) --- */
+     *     all zero = none of them.  NB the struct has grown in place over the rounds (it is the element type of uzu_model_desc.layers, so its size is
+     *     part of the ABI): uzu_hip_desc_abi() reports the sizes the library was built with -- a caller checks them once (uzu_amd/desc.py does) --- */
     uint32_t rope_index;            /* use_rope != 0: which entry of uzu_model_desc.ropes rotates this layer (transformer.rs:101-118);
                                        ignored when num_ropes == 0 (the single `rope`) */
     uint32_t has_post_layer_scalar; /* transformer_layer.rs:61-84: pre_mlp_norm scales the residual sum, post_mlp_norm (required) its
@@ -177,6 +203,9 @@ typedef struct {
     uzu_linear_desc ple_gate;       /* ple.gate: n = ple_dim, k = model_dim */
     uzu_linear_desc ple_projection; /* ple.projection: n = model_dim, k = ple_dim */
     uzu_norm_desc ple_norm;         /* ple.norm: [model_dim] */
+
+    /* --- mixture of experts (mlp_kind == UZU_MLP_MOE: up_projection / down_projection / hidden_dim / activation above are unused) --- */
+    uzu_moe_desc moe;
 } uzu_layer_desc;
 
 typedef struct {

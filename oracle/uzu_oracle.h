@@ -280,6 +280,19 @@ const uint16_t* orc_model_hidden_feature(const orc_model* m, uint32_t layer, uin
 const uint16_t* orc_model_final_hidden_rows(const orc_model* m, uint32_t* rows);
 const uzu_model_desc* orc_model_desc(const orc_model* m);
 
+/* ---- Mixture of experts (encodable_block/mlp/moe/mod.rs; uzu_oracle_moe.c: which kernels follow a CPU body and which the Metal shader is said there) ---- */
+void orc_moe_router_topk(const void* input, const void* weight, const void* bias, int32_t* topk_ids, void* topk_probs, uint32_t dt, uint32_t t, uint32_t d_model, uint32_t e,
+                         uint32_t k, uint32_t renorm);
+void orc_moe_counts_offsets_fused(const int32_t* topk_ids, uint32_t* offsets, uint32_t* sum_k_out, uint32_t* partials, uint32_t t, uint32_t e, uint32_t k);
+void orc_moe_scatter_buckets(const int32_t* topk_ids, const void* topk_probs, const uint32_t* offsets, int32_t* bucketed_ids, void* bucketed_probs, int32_t* tok2row, uint32_t dt,
+                             uint32_t t, uint32_t e, uint32_t k);
+void orc_moe_gather(const void* x, const int32_t* bucketed_ids, void* x_perm, const uint32_t* sumk_buf, uint32_t dt, uint32_t d_model, uint32_t t, uint32_t k);
+void orc_moe_experts_pass_a(const void* x_perm, const uint32_t* expert_offsets, const void* w13_all, const void* up_biases, float* hidden_out, uint32_t dt, uint32_t d_model,
+                            uint32_t d_ff, uint32_t e, float gate_clip_min, float gate_clip_max, float up_clip_min, float up_clip_max, float alpha, uint32_t gating_sel);
+void orc_moe_experts_down(const float* hidden, const uint32_t* row_expert_map, const void* w2_all, const void* down_biases, void* y_out, uint32_t dt, uint32_t total_rows,
+                          uint32_t d_model, uint32_t d_ff, uint32_t e);
+void orc_moe_finalize(const int32_t* tok2row, const void* probs, const void* y_partial, void* y, uint32_t dt, uint32_t t_count, uint32_t d_model, uint32_t k);
+
 /* ---- DFlash draft model (encodable_block/dflash.rs:41-346; uzu_oracle_dflash.c) ---- */
 typedef struct orc_dflash orc_dflash;
 orc_dflash* orc_dflash_create(const uzu_dflash_desc* desc); /* keeps the desc's tensor pointers */

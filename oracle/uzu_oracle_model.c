@@ -504,14 +504,20 @@ uint16_t* orc_layers_forward(orc_model* m, uint16_t* hidden, uint32_t count, con
         }
         uint16_t* mlp_in = norm_scaled(&L->pre_mlp_norm, mixed, shortcut, 2, count, d, norms_scale ? 1 : 0, L->post_layer_scalar, L->pre_mlp_norm.epsilon);
         free(mixed);
-        /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
-        uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
-        free(mlp_in);
-        uint16_t* gated = (uint16_t*)xcalloc((size_t)count * L->hidden_dim, 2);
-        orc_gated_act_mul(fused_up, NULL, gated, ORC_BF16, L->hidden_dim, count, 0, 0, L->activation, 1);
-        free(fused_up);
-        uint16_t* down = linear(&L->down_projection, gated, count);
-        free(gated);
+        uint16_t* down;
+        if (L->mlp_kind == UZU_MLP_MOE) { /* MoeBlock::encode (mlp/moe/mod.rs:204-350): uzu_oracle_moe.c */
+            down = orc_moe_block(&L->moe, d, mlp_in, count);
+            free(mlp_in);
+        } else {
+            /* DenseMlp (mlp/dense.rs:32-48): up -> GatedActMul(interleaved) -> down */
+            uint16_t* fused_up = linear(&L->up_projection, mlp_in, count);
+            free(mlp_in);
+            uint16_t* gated = (uint16_t*)xcalloc((size_t)count * L->hidden_dim, 2);
+            orc_gated_act_mul(fused_up, NULL, gated, ORC_BF16, L->hidden_dim, count, 0, 0, L->activation, 1);
+            free(fused_up);
+            down = linear(&L->down_projection, gated, count);
+            free(gated);
+        }
         if (L->post_mlp_norm.present) {
             uint16_t* t = norm_scaled(&L->post_mlp_norm, down, NULL, 0, count, d, norms_scale ? 2 : 0, L->post_layer_scalar, L->post_mlp_norm.epsilon);
             free(down);

@@ -55,4 +55,7 @@ uint16_t* orc_norm(const uzu_norm_desc* nd, const uint16_t* input, uint16_t* sho
 uint16_t* orc_layers_forward(orc_model* m, uint16_t* hidden, uint32_t count, const uint32_t* trie, const int32_t* parents, const uint16_t* per_layer_inputs,
                              uint16_t** shortcut_out);
 
+/* MoeBlock::encode (uzu_oracle_moe.c): a fresh bf16 [batch, model_dim] buffer */
+uint16_t* orc_moe_block(const uzu_moe_desc* M, uint32_t model_dim, const uint16_t* input, uint32_t batch);
+
 #endif

@@ -97,8 +97,8 @@ def test_production_kernels_within_tolerance(hip_ctx, preset):
     prompt = _prompt(cfg, 40)
     o_tok, h_tok = om.prefill(prompt), hm.prefill(prompt)
     o_feats, h_feats = [om.hidden_feature(l) for l in db.target_layer_ids], hm.hidden_features()
-    for a, b in zip(h_feats, o_feats):  # residual-stream rows: a couple of bf16 ulps of their scale
-        assert np.abs(f32(a).astype(np.float64) - f32(b)).max() <= 0.04 * f32(b).std()
+    for a, b in zip(h_feats, o_feats):  # residual-stream rows: a few bf16 ulps at the top binade (one ulp there = 2^-7 of the largest value)
+        assert np.abs(f32(a).astype(np.float64) - f32(b)).max() <= 2.0 ** -5 * np.abs(f32(b)).max()
     od.accept(o_feats, np.arange(40))
     hd.accept(h_feats, np.arange(40))
     _, ol, ot = od.draft(om, o_tok, 8)

@@ -165,8 +165,13 @@ def test_strictness_matches_the_reference(tmp_path):
     with pytest.raises(L.ModelFormatError, match="type is 'Swish'"):
         L.load_model_dir(d)
     fresh()  # well-formed but outside the hot path: loud, not silent
+    # (mixture-of-experts MLPs load since round 6 -- tests/test_oracle_moe.py; a DenseMLPConfig's fields under that tag are a format error, and a Mamba mixer stays refused)
     edit_config(d, lambda c: layer0(c)["mlp_config"].update(type="MixtureOfExpertsConfig"))
-    with pytest.raises(L.UnsupportedModelError, match="mixture-of-experts"):
+    with pytest.raises(L.ModelFormatError, match="expert_config is missing"):
+        L.load_model_dir(d)
+    fresh()
+    edit_config(d, lambda c: layer0(c)["mixer_config"].update(type="Mamba2Config"))
+    with pytest.raises(L.UnsupportedModelError, match="Mamba2 mixer"):
         L.load_model_dir(d)
     fresh()
     # sliding windows load since round 3 (ring KV state in the engine); a non-positive window is a format error, sinks need their tensor

@@ -625,3 +625,59 @@ class WeaverTopChildrenKernel(_Kernel):
                vocab_size, encoder):
         self._enc(encoder, *[_buf(b) for b in (residual_logits, candidate_logits, candidate_ids, depth_seeds, node_metadata, output_token_ids, output_model_logprobs)],
                   *[_u(v) for v in (rows, candidates, expand_width, vocab_size)])
+
+
+# ---- Mixture of experts (include/uzu_hip.h "Mixture of experts"; MoeBlock::encode, encodable_block/mlp/moe/mod.rs:204-350); BF16 tensors
+class MoeRouterTopKKernel(_Kernel):
+    """new(context, ScalarT, has_biases, has_router_scales, has_per_expert_scales, has_router_input_scale, normalize_router_input)   (router_topk.rs:9-32)"""
+    _create, _encode = "uzu_hip_moe_router_top_k_create", "uzu_hip_moe_router_top_k_encode"
+
+    def encode(self, input, weight, bias, topk_ids, topk_probs, t, d_model, e, k, renorm, encoder):
+        self._enc(encoder, _buf(input), _buf(weight), _buf(bias), _buf(topk_ids), _buf(topk_probs), _u(t), _u(d_model), _u(e), _u(k), _u(int(renorm)))
+
+
+class MoeCountsOffsetsFusedKernel(_Kernel):
+    _create, _encode = "uzu_hip_moe_counts_offsets_fused_create", "uzu_hip_moe_counts_offsets_fused_encode"
+
+    def encode(self, topk_ids, offsets, sum_k_out, partials, t, e, k, encoder):
+        self._enc(encoder, _buf(topk_ids), _buf(offsets), _buf(sum_k_out), _buf(partials), _u(t), _u(e), _u(k))
+
+
+class MoeScatterBucketsMapKernel(_Kernel):
+    """new(context, T): MoeBlockBasesFromPartials + MoeScatterBucketsMap + MoePassABuildRowMap as one launch (rows of an expert in (token, slot) order)"""
+    _create, _encode = "uzu_hip_moe_scatter_buckets_map_create", "uzu_hip_moe_scatter_buckets_map_encode"
+
+    def encode(self, topk_ids, topk_probs, offsets, out_ids, out_probs, t, e, k, tok2row, row_expert_map, encoder):
+        self._enc(encoder, _buf(topk_ids), _buf(topk_probs), _buf(offsets), _buf(out_ids), _buf(out_probs), _u(t), _u(e), _u(k), _buf(tok2row), _buf(row_expert_map))
+
+
+class MoeGatherXPermKernel(_Kernel):
+    _create, _encode = "uzu_hip_moe_gather_x_perm_create", "uzu_hip_moe_gather_x_perm_encode"
+
+    def encode(self, x, bucketed_ids, x_perm, sumk_buf, d_model, t, k, encoder):
+        self._enc(encoder, _buf(x), _buf(bucketed_ids), _buf(x_perm), _buf(sumk_buf), _u(d_model), _u(t), _u(k))
+
+
+class MoeExpertsPassAKernel(_Kernel):
+    """new(context, T, gating_sel): MoeExperts{Decode,Prefill}PassA; rows are found through row_expert_map, `capacity` rows launched, *sumk_buf rows live"""
+    _create, _encode = "uzu_hip_moe_experts_pass_a_create", "uzu_hip_moe_experts_pass_a_encode"
+
+    def encode(self, x_perm, row_expert_map, sumk_buf, w13_all, up_biases, hidden_out, d_model, d_ff, gate_clip_min, gate_clip_max, up_clip_min, up_clip_max, silu_alpha,
+               capacity, encoder):
+        self._enc(encoder, _buf(x_perm), _buf(row_expert_map), _buf(sumk_buf), _buf(w13_all), _buf(up_biases), _buf(hidden_out), _u(d_model), _u(d_ff), _f(gate_clip_min),
+                  _f(gate_clip_max), _f(up_clip_min), _f(up_clip_max), _f(silu_alpha), _u(capacity))
+
+
+class MoeExpertsDownKernel(_Kernel):
+    """new(context, T): MoeExpertsDecodeDownFused2D / MoeExpertsPrefillPassB"""
+    _create, _encode = "uzu_hip_moe_experts_down_create", "uzu_hip_moe_experts_down_encode"
+
+    def encode(self, hidden, row_expert_map, sumk_buf, w2_all, down_biases, y_out, d_model, d_ff, capacity, encoder):
+        self._enc(encoder, _buf(hidden), _buf(row_expert_map), _buf(sumk_buf), _buf(w2_all), _buf(down_biases), _buf(y_out), _u(d_model), _u(d_ff), _u(capacity))
+
+
+class MoeFinalizeKernel(_Kernel):
+    _create, _encode = "uzu_hip_moe_finalize_create", "uzu_hip_moe_finalize_encode"
+
+    def encode(self, tok2row, probs, y_partial, y, t_count, d_model, k, encoder):
+        self._enc(encoder, _buf(tok2row), _buf(probs), _buf(y_partial), _buf(y), _u(t_count), _u(d_model), _u(k))

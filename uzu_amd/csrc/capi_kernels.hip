@@ -17,6 +17,7 @@ enum KernelKind : uint32_t {
     KK_LOGIT_TRANSFORM, KK_TENSOR_ADD_BIAS, KK_TENSOR_ADD_SCALE, KK_TENSOR_ADD_SWAP, KK_TENSOR_COPY, KK_UNIFIED_SAMPLING,
     KK_DN_CONV_UPDATE, KK_DN_UPDATE, KK_CONV1D_PACK, KK_DN_CONV_SCAN, KK_DN_PREFILL_PREP, KK_DN_PREFILL, KK_DN_NORM_GATE,
     KK_CONV_TREE_SCAN, KK_DN_TREE_VERIFY, KK_STATE_ADVANCE, KK_ANCESTOR_ATTENTION, KK_WEAVER_SELECT, KK_WEAVER_INSERT, KK_WEAVER_TOP_CHILDREN,
+    KK_MOE_ROUTER_TOPK, KK_MOE_COUNTS_OFFSETS, KK_MOE_SCATTER, KK_MOE_GATHER, KK_MOE_PASS_A, KK_MOE_DOWN, KK_MOE_FINALIZE,
 };
 
 bool is_float_dt(uint32_t dt) { return dt == UZU_BF16 || dt == UZU_F32; }
@@ -936,6 +937,99 @@ uzu_status uzu_hip_weaver_top_children_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf*
     return k::weaver_top_children(cb_stream(cb), (const uint16_t*)bptr(residual_logits), (const float*)bptr(candidate_logits), (const uint32_t*)bptr(candidate_ids),
                                   (const uint64_t*)bptr(depth_seeds), (const uint32_t*)bptr(node_metadata), (uint32_t*)bptr(output_token_ids), (float*)bptr(output_model_logprobs),
                                   rows, candidates, expand_width, vocab_size);
+}
+
+// ------------------------------------------------------------------------------------- Mixture of experts (k_moe.hip; bf16 only)
+#define REQ_BF16(dt, what) UZU_UNSUPPORTED((dt) != UZU_BF16, what ": data type %u (the MoE kernels are built for BF16, LanguageModel's data type)", (unsigned)(dt))
+uzu_status uzu_hip_moe_router_top_k_create(uzu_hip_context* ctx, uint32_t scalar_t, uint32_t has_biases, uint32_t has_router_scales, uint32_t has_per_expert_scales,
+                                           uint32_t has_router_input_scale, uint32_t normalize_router_input, uzu_hip_kernel** out) {
+    REQ_BF16(scalar_t, "moe_router_top_k");
+    // MoeBlock::new instantiates (true, false, false, false, false) (mod.rs:170-172); the Gemma-4 router inputs are not built
+    UZU_UNSUPPORTED(has_router_scales || has_per_expert_scales || has_router_input_scale || normalize_router_input, "moe_router_top_k: router scales / input normalisation");
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_MOE_ROUTER_TOPK, out, &k));
+    k->f[0] = has_biases;
+    return UZU_OK;
+}
+uzu_status uzu_hip_moe_router_top_k_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf input, uzu_buf weight, uzu_buf bias, uzu_buf topk_ids, uzu_buf topk_probs, uint32_t t, uint32_t d_model,
+                                           uint32_t e, uint32_t top_k, uint32_t renorm) {
+    UZU_PROPAGATE(check(k, KK_MOE_ROUTER_TOPK, cb));
+    UZU_REQUIRE(input.buffer && weight.buffer && topk_ids.buffer && topk_probs.buffer && (!k->f[0] || bias.buffer), "moe_router_top_k: null buffer");
+    return k::moe_router_topk(cb_stream(cb), (const uint16_t*)bptr(input), (const uint16_t*)bptr(weight), k->f[0] ? (const uint16_t*)bptr(bias) : nullptr, (int32_t*)bptr(topk_ids),
+                              (uint16_t*)bptr(topk_probs), t, d_model, e, top_k, renorm);
+}
+uzu_status uzu_hip_moe_counts_offsets_fused_create(uzu_hip_context* ctx, uzu_hip_kernel** out) {
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_MOE_COUNTS_OFFSETS, out, &k);
+}
+uzu_status uzu_hip_moe_counts_offsets_fused_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf topk_ids, uzu_buf offsets, uzu_buf sum_k_out, uzu_buf partials, uint32_t t, uint32_t e,
+                                                   uint32_t top_k) {
+    UZU_PROPAGATE(check(k, KK_MOE_COUNTS_OFFSETS, cb));
+    UZU_REQUIRE(topk_ids.buffer && offsets.buffer && sum_k_out.buffer, "moe_counts_offsets_fused: null buffer");
+    return k::moe_counts_offsets(cb_stream(cb), (const int32_t*)bptr(topk_ids), (uint32_t*)bptr(offsets), (uint32_t*)bptr(sum_k_out), (uint32_t*)bptr(partials), t, e, top_k);
+}
+// MoeBlockBasesFromPartials + MoeScatterBucketsMap (+ MoePassABuildRowMap) as ONE kernel: block bases / allocations are Metal's way of ordering its threadgroups; here the
+// bucket order is (token, slot) by construction.  Arguments = the map kernel's (scatter_buckets.rs:24-41) without the block tables, plus the row -> expert map.
+uzu_status uzu_hip_moe_scatter_buckets_map_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_BF16(t, "moe_scatter_buckets_map");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_MOE_SCATTER, out, &k);
+}
+uzu_status uzu_hip_moe_scatter_buckets_map_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf topk_ids, uzu_buf topk_probs, uzu_buf offsets, uzu_buf out_ids, uzu_buf out_probs, uint32_t t,
+                                                  uint32_t e, uint32_t top_k, uzu_buf tok2row, uzu_buf row_expert_map) {
+    UZU_PROPAGATE(check(k, KK_MOE_SCATTER, cb));
+    UZU_REQUIRE(topk_ids.buffer && topk_probs.buffer && offsets.buffer && out_ids.buffer && out_probs.buffer && tok2row.buffer && row_expert_map.buffer, "moe_scatter_buckets_map: null buffer");
+    return k::moe_scatter_buckets(cb_stream(cb), (const int32_t*)bptr(topk_ids), (const uint16_t*)bptr(topk_probs), (const uint32_t*)bptr(offsets), (int32_t*)bptr(out_ids),
+                                  (uint16_t*)bptr(out_probs), (int32_t*)bptr(tok2row), (uint32_t*)bptr(row_expert_map), t, e, top_k);
+}
+uzu_status uzu_hip_moe_gather_x_perm_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_BF16(t, "moe_gather_x_perm");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_MOE_GATHER, out, &k);
+}
+uzu_status uzu_hip_moe_gather_x_perm_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf x, uzu_buf bucketed_ids, uzu_buf x_perm, uzu_buf sumk_buf, uint32_t d_model, uint32_t t, uint32_t top_k) {
+    UZU_PROPAGATE(check(k, KK_MOE_GATHER, cb));
+    UZU_REQUIRE(x.buffer && bucketed_ids.buffer && x_perm.buffer && sumk_buf.buffer, "moe_gather_x_perm: null buffer");
+    return k::moe_gather(cb_stream(cb), (const uint16_t*)bptr(x), (const int32_t*)bptr(bucketed_ids), (uint16_t*)bptr(x_perm), (const uint32_t*)bptr(sumk_buf), d_model, t, top_k);
+}
+// MoeExperts{Decode,Prefill}PassA without Metal's tile map / indirect dispatch buffer: rows are found through the row -> expert map, `capacity` rows are launched
+uzu_status uzu_hip_moe_experts_pass_a_create(uzu_hip_context* ctx, uint32_t t, uint32_t gating_sel, uzu_hip_kernel** out) {
+    REQ_BF16(t, "moe_experts_pass_a");
+    UZU_REQUIRE(gating_sel <= 3, "moe_experts_pass_a: gating_sel %u", gating_sel);
+    uzu_hip_kernel* k;
+    UZU_PROPAGATE(make_kernel(ctx, KK_MOE_PASS_A, out, &k));
+    k->f[0] = gating_sel;
+    return UZU_OK;
+}
+uzu_status uzu_hip_moe_experts_pass_a_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf x_perm, uzu_buf row_expert_map, uzu_buf sumk_buf, uzu_buf w13_all, uzu_buf up_biases, uzu_buf hidden_out,
+                                             uint32_t d_model, uint32_t d_ff, float gate_clip_min, float gate_clip_max, float up_clip_min, float up_clip_max, float silu_alpha, uint32_t capacity) {
+    UZU_PROPAGATE(check(k, KK_MOE_PASS_A, cb));
+    UZU_REQUIRE(x_perm.buffer && row_expert_map.buffer && sumk_buf.buffer && w13_all.buffer && up_biases.buffer && hidden_out.buffer, "moe_experts_pass_a: null buffer");
+    const k::MoeExpertParams q{d_model, d_ff, k->f[0], gate_clip_min, gate_clip_max, up_clip_min, up_clip_max, silu_alpha};
+    return k::moe_experts_pass_a(cb_stream(cb), (const uint16_t*)bptr(x_perm), (const uint32_t*)bptr(row_expert_map), (const uint32_t*)bptr(sumk_buf), (const uint16_t*)bptr(w13_all),
+                                 (const uint16_t*)bptr(up_biases), (float*)bptr(hidden_out), q, capacity);
+}
+uzu_status uzu_hip_moe_experts_down_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_BF16(t, "moe_experts_down");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_MOE_DOWN, out, &k);
+}
+uzu_status uzu_hip_moe_experts_down_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf hidden, uzu_buf row_expert_map, uzu_buf sumk_buf, uzu_buf w2_all, uzu_buf down_biases, uzu_buf y_out,
+                                           uint32_t d_model, uint32_t d_ff, uint32_t capacity) {
+    UZU_PROPAGATE(check(k, KK_MOE_DOWN, cb));
+    UZU_REQUIRE(hidden.buffer && row_expert_map.buffer && sumk_buf.buffer && w2_all.buffer && down_biases.buffer && y_out.buffer, "moe_experts_down: null buffer");
+    return k::moe_experts_down(cb_stream(cb), (const float*)bptr(hidden), (const uint32_t*)bptr(row_expert_map), (const uint32_t*)bptr(sumk_buf), (const uint16_t*)bptr(w2_all),
+                               (const uint16_t*)bptr(down_biases), (uint16_t*)bptr(y_out), d_model, d_ff, capacity);
+}
+uzu_status uzu_hip_moe_finalize_create(uzu_hip_context* ctx, uint32_t t, uzu_hip_kernel** out) {
+    REQ_BF16(t, "moe_finalize");
+    uzu_hip_kernel* k;
+    return make_kernel(ctx, KK_MOE_FINALIZE, out, &k);
+}
+uzu_status uzu_hip_moe_finalize_encode(uzu_hip_kernel* k, uzu_hip_cmdbuf* cb, uzu_buf tok2row, uzu_buf probs, uzu_buf y_partial, uzu_buf y, uint32_t t_count, uint32_t d_model, uint32_t top_k) {
+    UZU_PROPAGATE(check(k, KK_MOE_FINALIZE, cb));
+    UZU_REQUIRE(tok2row.buffer && probs.buffer && y_partial.buffer && y.buffer, "moe_finalize: null buffer");
+    return k::moe_finalize(cb_stream(cb), (const int32_t*)bptr(tok2row), (const uint16_t*)bptr(probs), (const uint16_t*)bptr(y_partial), (uint16_t*)bptr(y), t_count, d_model, top_k);
 }
 
 } // extern "C"

@@ -112,8 +112,11 @@ uzu_status state_build(uzu_hip_model* m, uzu_hip_state** out) {
             // AttentionState::create_empty (state.rs:69-136): a causal sliding-window layer keeps a RING of `window` rows + the suffix region
             const size_t kv_rows = h.sliding_window_size ? (size_t)h.sliding_window_size + m->chunk : (size_t)m->max_positions;
             const size_t kv_bytes = kv_rows * h.num_groups * h.head_dim * 2;
-            if (r == UZU_OK) r = state_alloc(st, kv_bytes, &p, false), st->layers[l].keys = (uint16_t*)p;
-            if (r == UZU_OK) r = state_alloc(st, kv_bytes, &p, false), st->layers[l].values = (uint16_t*)p;
+            // a Full cache's rows are undefined until AttentionPrepare writes them; a RING's unfilled slots are read by the attention kernels and masked by weight
+            // (ring_length), so they must hold finite values: zero by contract
+            const bool zero_by_contract = h.sliding_window_size != 0;
+            if (r == UZU_OK) r = state_alloc(st, kv_bytes, &p, zero_by_contract), st->layers[l].keys = (uint16_t*)p;
+            if (r == UZU_OK) r = state_alloc(st, kv_bytes, &p, zero_by_contract), st->layers[l].values = (uint16_t*)p;
         } else {
             need(m->layers[l].conv_state_bytes, &p), st->layers[l].conv_state = (float*)p;
             need(m->layers[l].ssm_state_bytes, &p), st->layers[l].ssm_state = (float*)p;
@@ -300,6 +303,13 @@ void rope_tables(const uzu_rope_desc& r, uint32_t n_pos, std::vector<float>& cos
 
 extern "C" {
 
+// sizes of the description structs this library was built with (include/uzu_model_desc.h: they are part of the ABI -- uzu_layer_desc is an array element)
+void uzu_hip_desc_abi(uint32_t out[6]) {
+    if (!out) return;
+    out[0] = (uint32_t)sizeof(uzu_linear_desc), out[1] = (uint32_t)sizeof(uzu_norm_desc), out[2] = (uint32_t)sizeof(uzu_rope_desc), out[3] = (uint32_t)sizeof(uzu_layer_desc);
+    out[4] = (uint32_t)sizeof(uzu_model_desc), out[5] = (uint32_t)sizeof(uzu_dflash_desc);
+}
+
 uzu_status uzu_hip_model_create(uzu_hip_context* ctx, const uzu_model_desc* desc, uint32_t flags, uzu_hip_model** out) {
     return uzu_hip_model_create_tp(ctx, desc, flags, nullptr, 0, out);
 }
@@ -353,6 +363,7 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     m->max_positions = desc->max_context_length + m->chunk;
     m->layers.resize(desc->num_layers);
     uint32_t max_qkv = 0, max_qdim = 0, max_hidden = 0, max_proj = 0, max_value = 0, max_key = 0, max_hv = 0, max_hd = 0, max_heads = 0;
+    uint32_t max_moe_k = 0, max_moe_ff = 0, max_moe_e = 0;
     for (uint32_t l = 0; l < desc->num_layers; ++l) {
         const uzu_layer_desc& h = desc->layers[l];
         DLayer& L = m->layers[l];
@@ -389,13 +400,34 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
             TRY(upload_linear(m, h.ple_projection, &L.ple_projection));
             TRY(upload_norm(m, h.ple_norm, d, &L.ple_norm));
         }
-        TRY(upload_linear(m, h.up_projection, &L.up));
-        TRY(upload_linear(m, h.down_projection, &L.down));
-        if (h.up_projection.n != 2 * h.hidden_dim || h.down_projection.k != h.hidden_dim) {
-            set_error("model_create: layer %u MLP shapes inconsistent", l);
-            return fail(UZU_ERR_INVALID_ARGUMENT);
+        if (h.mlp_kind == UZU_MLP_MOE) { // MoeBlock::new (mlp/moe/mod.rs:84-200): the refusals are the reference's own
+            const uzu_moe_desc& M = h.moe;
+            if (d % 8 || M.num_routed_experts == 0 || M.num_routed_experts > 512 || M.num_active_experts == 0 || M.num_active_experts > 128 || M.num_active_experts > M.num_routed_experts ||
+                M.expert_hidden_dim == 0 || M.expert_hidden_dim % 8 || (M.gating_sel != 2 && M.gating_sel != 3) || !M.router_weights || !M.router_biases || !M.w13 || !M.w2 || !M.up_biases ||
+                !M.down_biases) {
+                set_error("model_create: layer %u MoE description refused (model_dim %% 8, 1..512 routed / 1..128 active experts, SiLU / GELUApprox experts, router + up + down biases required)", l);
+                return fail(UZU_ERR_UNSUPPORTED);
+            }
+            if (m->tp) return fail((set_error("model_create: MoE layers are not sharded (single GPU only)"), UZU_ERR_UNSUPPORTED));
+            const size_t E = M.num_routed_experts, F = M.expert_hidden_dim;
+            TRY(upload(m, M.router_weights, E * d * 2, &L.moe.router_weights));
+            TRY(upload(m, M.router_biases, E * 2, &L.moe.router_biases));
+            TRY(upload(m, M.w13, E * 2 * F * d * 2, &L.moe.w13));
+            TRY(upload(m, M.w2, E * d * F * 2, &L.moe.w2));
+            TRY(upload(m, M.up_biases, E * 2 * F * 2, &L.moe.up_biases));
+            TRY(upload(m, M.down_biases, E * d * 2, &L.moe.down_biases));
+            max_moe_k = max_moe_k > M.num_active_experts ? max_moe_k : M.num_active_experts;
+            max_moe_ff = max_moe_ff > M.expert_hidden_dim ? max_moe_ff : M.expert_hidden_dim;
+            max_moe_e = max_moe_e > M.num_routed_experts ? max_moe_e : M.num_routed_experts;
+        } else {
+            TRY(upload_linear(m, h.up_projection, &L.up));
+            TRY(upload_linear(m, h.down_projection, &L.down));
+            if (h.up_projection.n != 2 * h.hidden_dim || h.down_projection.k != h.hidden_dim) {
+                set_error("model_create: layer %u MLP shapes inconsistent", l);
+                return fail(UZU_ERR_INVALID_ARGUMENT);
+            }
+            max_hidden = max_hidden > h.hidden_dim ? max_hidden : h.hidden_dim;
         }
-        max_hidden = max_hidden > h.hidden_dim ? max_hidden : h.hidden_dim;
         if (h.mixer_kind == UZU_MIXER_ATTENTION) {
             if (h.is_kv_sharing) { // TransformerLayerStateType::Shared (transformer.rs:205-216, 264-275)
                 const uint32_t src = h.kv_source_layer_index;
@@ -507,6 +539,20 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     }
     ALLOC(up, uint16_t, CB * 2 * max_hidden);
     ALLOC(gated, uint16_t, CB * max_hidden);
+    if (max_moe_k) {
+        const size_t rows = CB * max_moe_k;
+        ALLOC(moe.topk_ids, int32_t, rows);
+        ALLOC(moe.bucketed_ids, int32_t, rows);
+        ALLOC(moe.tok2row, int32_t, rows);
+        ALLOC(moe.topk_probs, uint16_t, rows);
+        ALLOC(moe.bucketed_probs, uint16_t, rows);
+        ALLOC(moe.x_perm, uint16_t, rows * d);
+        ALLOC(moe.y_partial, uint16_t, rows * d);
+        ALLOC(moe.offsets, uint32_t, max_moe_e + 1);
+        ALLOC(moe.sumk, uint32_t, 1);
+        ALLOC(moe.row_expert_map, uint32_t, rows);
+        ALLOC(moe.hidden, float, rows * max_moe_ff);
+    }
     if (max_proj) {
         ALLOC(in_proj, uint16_t, CB * max_proj);
         ALLOC(delta_out, uint16_t, CB * max_value);

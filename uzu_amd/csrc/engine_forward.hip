@@ -369,6 +369,24 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     }
 }
 
+// MoeBlock::encode (mlp/moe/mod.rs:204-350): router top-k -> counts / offsets -> scatter (+ row map) -> gather -> experts pass A / pass B -> finalize.
+// (topk_ids / tok2row need no 0xFF fill here: the router writes every id, the scatter marks every entry -- valid ones with their row, the others with -1.)
+void moe_mlp(Enc& e, DLayer& L, const uint16_t* input, uint16_t* output, uint32_t rows) {
+    uzu_hip_model* m = e.m;
+    const uzu_moe_desc& M = L.d.moe;
+    const uint32_t d = m->d.model_dim, E = M.num_routed_experts, K = M.num_active_experts, F = M.expert_hidden_dim, capacity = rows * K;
+    auto& S = m->moe;
+    RUN("moe_router_topk", (size_t)E * d * 2, k::moe_router_topk(e.s, input, L.moe.router_weights, L.moe.router_biases, S.topk_ids, S.topk_probs, rows, d, E, K, M.router_renorm));
+    RUN("moe_counts_offsets", 0, k::moe_counts_offsets(e.s, S.topk_ids, S.offsets, S.sumk, nullptr, rows, E, K));
+    RUN("moe_scatter_buckets", 0, k::moe_scatter_buckets(e.s, S.topk_ids, S.topk_probs, S.offsets, S.bucketed_ids, S.bucketed_probs, S.tok2row, S.row_expert_map, rows, E, K));
+    RUN("moe_gather", 0, k::moe_gather(e.s, input, S.bucketed_ids, S.x_perm, S.sumk, d, rows, K));
+    const k::MoeExpertParams q{d, F, M.gating_sel, M.gate_clip_min, M.gate_clip_max, M.up_clip_min, M.up_clip_max, M.silu_alpha};
+    const size_t active = (size_t)(capacity < E ? capacity : E); // experts touched, at most
+    RUN("moe_experts_pass_a", active * 2 * F * d * 2, k::moe_experts_pass_a(e.s, S.x_perm, S.row_expert_map, S.sumk, L.moe.w13, L.moe.up_biases, S.hidden, q, capacity));
+    RUN("moe_experts_down", active * F * d * 2, k::moe_experts_down(e.s, S.hidden, S.row_expert_map, S.sumk, L.moe.w2, L.moe.down_biases, S.y_partial, d, F, capacity));
+    RUN("moe_finalize", 0, k::moe_finalize(e.s, S.tok2row, S.topk_probs, S.y_partial, output, rows, d, K));
+}
+
 __global__ void commit_kernel(uint32_t* ctx_len, uint32_t* tokens, const uint32_t* out_token, uint32_t* sampled, uint32_t count, uint32_t has_token) {
     const uint32_t len = *ctx_len;
     if (has_token) {
@@ -459,7 +477,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         hidden_normed = false;
         PostNorm mlp_norm; // the pre-MLP normalisation, offered to the mixer's out projection when nothing sits between them
         const bool offer_mlp = !L.post_mixer.present && rows >= 128 && !L.pre_mlp.scalar_mode;
-        if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, sc_cur, 2, rows, d, &L.up);
+        if (offer_mlp) mlp_norm.p = norm_params(e, L.pre_mlp, m->mixed, m->normed, sc_cur, 2, rows, d, L.d.mlp_kind == UZU_MLP_MOE ? nullptr : &L.up);
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION)
             attention_mixer(e, L, h, m->mixed, q, offer_mlp ? &mlp_norm : nullptr, first_done);
         else
@@ -473,23 +491,26 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         if (offer_mlp) {
             norm_issued(m, mlp_norm.p);
             if (!mlp_norm.done) RUN("normalization", 0, k::normalization(e.s, mlp_norm.p));
-        } else if (few_rows && !L.post_mixer.present && linear_normed(e, L.pre_mlp, 2, L.up, mixed, sc_cur, sc_other(), nullptr, m->gated, rows, true, L.d.activation)) {
+        } else if (few_rows && L.d.mlp_kind != UZU_MLP_MOE && !L.post_mixer.present && linear_normed(e, L.pre_mlp, 2, L.up, mixed, sc_cur, sc_other(), nullptr, m->gated, rows, true, L.d.activation)) {
             mlp_done = true, sc_cur = sc_other();
         } else {
-            norm(e, L.pre_mlp, mixed, m->normed, sc_cur, 2, rows, d, &L.up);
+            norm(e, L.pre_mlp, mixed, m->normed, sc_cur, 2, rows, d, L.d.mlp_kind == UZU_MLP_MOE ? nullptr : &L.up);
         }
-        if (!mlp_done && !linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
+        const bool is_moe = L.d.mlp_kind == UZU_MLP_MOE;
+        if (is_moe) {
+            moe_mlp(e, L, m->normed, hidden, rows);
+        } else if (!mlp_done && !linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
             linear(e, L.up, m->normed, m->up, rows);
             RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
         }
         // the next layer's pre-mixer normalisation rides on this layer's down projection (not past the last layer: the output norm takes one row)
         PostNorm next_norm;
-        const bool offer_next = rows >= 128 && !L.post_mlp.present && !L.d.has_ple && l + 1 < layer_count && m->layers[l + 1].pre_mixer.present;
+        const bool offer_next = !is_moe && rows >= 128 && !L.post_mlp.present && !L.d.has_ple && l + 1 < layer_count && m->layers[l + 1].pre_mixer.present;
         if (offer_next) {
             const DLayer& Nx = m->layers[l + 1];
             next_norm.p = norm_params(e, Nx.pre_mixer, hidden, m->normed, sc_cur, 2, rows, d, Nx.d.mixer_kind == UZU_MIXER_ATTENTION ? &Nx.qkv : &Nx.in_proj);
         }
-        linear(e, L.down, m->gated, hidden, rows, true, offer_next ? &next_norm : nullptr);
+        if (!is_moe) linear(e, L.down, m->gated, hidden, rows, true, offer_next ? &next_norm : nullptr);
         if (offer_next && next_norm.done) {
             norm_issued(m, next_norm.p);
             hidden_normed = true;
@@ -697,6 +718,7 @@ bool model_fusable(const uzu_hip_model* m) {
     if (m->embedding.in_signs || m->embedding.out_signs) return false; // RHT embedding rows: the commit kernel's lookup has no transform
     for (const DLayer& L : m->layers) {
         if (!norm_fusable(L.pre_mixer) || !norm_fusable(L.pre_mlp) || L.post_mixer.present || L.post_mlp.present) return false;
+        if (L.d.mlp_kind == UZU_MLP_MOE) return false; // MoE layers: the one-kernel-per-reference-kernel pass
         if (!linear_fusable(L.up) || !linear_fusable(L.down)) return false;
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
             if (!linear_fusable(L.qkv) || !linear_fusable(L.out)) return false;

@@ -77,6 +77,10 @@ struct DLayer {
     uint32_t last_reader = 0;
     float *conv_state = nullptr, *ssm_state = nullptr;
     size_t conv_state_bytes = 0, ssm_state_bytes = 0;
+    // MoeBlock (mlp/moe/mod.rs:30-60; d.mlp_kind == UZU_MLP_MOE): bf16 tensors in HBM, the scalars stay in d.moe
+    struct {
+        uint16_t *router_weights = nullptr, *router_biases = nullptr, *w13 = nullptr, *w2 = nullptr, *up_biases = nullptr, *down_biases = nullptr;
+    } moe;
 };
 
 } // namespace eng
@@ -155,6 +159,13 @@ struct uzu_hip_model {
     uint32_t partial_rows = 0;
     uint16_t *last_normed = nullptr, *logits = nullptr;
     void* argmax_scratch = nullptr;
+    // scratch of the MoE layers (sized for chunk * max_seqs tokens x the widest active-expert count): MoeBlock::encode's scratch allocations (mod.rs:214-270)
+    struct {
+        int32_t *topk_ids = nullptr, *bucketed_ids = nullptr, *tok2row = nullptr;
+        uint16_t *topk_probs = nullptr, *bucketed_probs = nullptr, *x_perm = nullptr, *y_partial = nullptr;
+        uint32_t *offsets = nullptr, *sumk = nullptr, *row_expert_map = nullptr;
+        float* hidden = nullptr;
+    } moe;
     // SamplingMethod::Stochastic for the engine's own prefill / decode loop (uzu_hip_model_set_sampling); greedy when !on
     struct {
         bool on = false;

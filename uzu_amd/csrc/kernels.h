@@ -332,5 +332,23 @@ uzu_status delta_net_norm_gate_exact(hipStream_t s, uint16_t* in_out, const uint
 uzu_status advance_u32(hipStream_t s, uint32_t* counter, uint32_t amount); // *counter += amount
 uzu_status fill_u32(hipStream_t s, uint32_t* dst, uint32_t value, uint32_t count);
 
+// ---- Mixture of experts (k_moe.hip; MoeBlock::encode, encodable_block/mlp/moe/mod.rs:204-350); bf16 tensors
+struct MoeExpertParams {
+    uint32_t d_model, d_ff, gating_sel; // 0 GELU(up), 1 SiLU(up), 2 SwiGLU, 3 GEGLU
+    float gate_clip_min, gate_clip_max, up_clip_min, up_clip_max, silu_alpha;
+};
+uzu_status moe_router_topk(hipStream_t s, const uint16_t* input, const uint16_t* weight, const uint16_t* bias, int32_t* topk_ids, uint16_t* topk_probs, uint32_t t, uint32_t d_model, uint32_t e,
+                           uint32_t k, uint32_t renorm);
+uzu_status moe_counts_offsets(hipStream_t s, const int32_t* topk_ids, uint32_t* offsets, uint32_t* sum_k_out, uint32_t* partials, uint32_t t, uint32_t e, uint32_t k);
+uzu_status moe_scatter_buckets(hipStream_t s, const int32_t* topk_ids, const uint16_t* topk_probs, const uint32_t* offsets, int32_t* bucketed_ids, uint16_t* bucketed_probs, int32_t* tok2row,
+                               uint32_t* row_expert_map, uint32_t t, uint32_t e, uint32_t k);
+uzu_status moe_gather(hipStream_t s, const uint16_t* x, const int32_t* bucketed_ids, uint16_t* x_perm, const uint32_t* sumk, uint32_t d_model, uint32_t t, uint32_t k);
+// `capacity` = rows the launch covers (tokens x active experts); rows past *sumk return at once
+uzu_status moe_experts_pass_a(hipStream_t s, const uint16_t* x_perm, const uint32_t* row_expert_map, const uint32_t* sumk, const uint16_t* w13_all, const uint16_t* up_biases, float* hidden_out,
+                              const MoeExpertParams& q, uint32_t capacity);
+uzu_status moe_experts_down(hipStream_t s, const float* hidden, const uint32_t* row_expert_map, const uint32_t* sumk, const uint16_t* w2_all, const uint16_t* down_biases, uint16_t* y_out,
+                            uint32_t d_model, uint32_t d_ff, uint32_t capacity);
+uzu_status moe_finalize(hipStream_t s, const int32_t* tok2row, const uint16_t* probs, const uint16_t* y_partial, uint16_t* y, uint32_t t_count, uint32_t d_model, uint32_t k);
+
 } // namespace k
 } // namespace uzu

@@ -52,9 +52,22 @@ class RopeDesc(C.Structure):
     ]
 
 
+class MoeDesc(C.Structure):
+    """include/uzu_model_desc.h::uzu_moe_desc"""
+    _fields_ = [
+        ("num_routed_experts", C.c_uint32), ("num_active_experts", C.c_uint32), ("expert_hidden_dim", C.c_uint32), ("router_renorm", C.c_uint32),
+        ("gating_sel", C.c_uint32), ("silu_alpha", C.c_float),
+        ("gate_clip_min", C.c_float), ("gate_clip_max", C.c_float), ("up_clip_min", C.c_float), ("up_clip_max", C.c_float),
+        ("router_weights", C.c_void_p), ("router_biases", C.c_void_p), ("w13", C.c_void_p), ("w2", C.c_void_p), ("up_biases", C.c_void_p), ("down_biases", C.c_void_p),
+    ]
+
+
+MLP_DENSE, MLP_MOE = 0, 1
+
+
 class LayerDesc(C.Structure):
     _fields_ = [
-        ("mixer_kind", C.c_uint32), ("hidden_dim", C.c_uint32), ("activation", C.c_uint32), ("reserved", C.c_uint32),
+        ("mixer_kind", C.c_uint32), ("hidden_dim", C.c_uint32), ("activation", C.c_uint32), ("mlp_kind", C.c_uint32),
         ("pre_mixer_norm", NormDesc), ("post_mixer_norm", NormDesc), ("pre_mlp_norm", NormDesc),
         ("post_mlp_norm", NormDesc),
         ("num_heads", C.c_uint32), ("num_groups", C.c_uint32), ("head_dim", C.c_uint32), ("has_gate", C.c_uint32),
@@ -73,6 +86,7 @@ class LayerDesc(C.Structure):
         ("is_kv_sharing", C.c_uint32), ("kv_source_layer_index", C.c_uint32), ("normalize_values", C.c_uint32),
         ("has_ple", C.c_uint32), ("ple_dim", C.c_uint32), ("ple_activation", C.c_uint32), ("is_non_causal", C.c_uint32),
         ("ple_gate", LinearDesc), ("ple_projection", LinearDesc), ("ple_norm", NormDesc),
+        ("moe", MoeDesc),
     ]
 
 
@@ -185,14 +199,43 @@ class PleModelWeights:
 
 
 @dataclass
+class MoeWeights:
+    """MixtureOfExpertsConfig + the `mlp` subtree of a MoE layer (encodable_block/mlp/moe/mod.rs:84-200); every tensor bf16 bits (uint16)."""
+    num_routed_experts: int
+    num_active_experts: int
+    expert_hidden_dim: int
+    router_weights: np.ndarray   # [E, model_dim]
+    router_biases: np.ndarray    # [E]
+    w13: np.ndarray              # [E, 2 * d_ff, model_dim]
+    w2: np.ndarray               # [E, model_dim, d_ff]
+    up_biases: np.ndarray        # [E, 2 * d_ff]
+    down_biases: np.ndarray      # [E, model_dim]
+    router_renorm: bool = True   # SoftmaxRouting
+    gating_sel: int = 2          # 2 SwiGLU (SiLU), 3 GEGLU (GELUApprox)
+    silu_alpha: float = 1.0
+    gate_clip: tuple = (float("-inf"), float("inf"))
+    up_clip: tuple = (float("-inf"), float("inf"))
+
+    def desc(self) -> MoeDesc:
+        return MoeDesc(self.num_routed_experts, self.num_active_experts, self.expert_hidden_dim, int(self.router_renorm), self.gating_sel, self.silu_alpha,
+                       self.gate_clip[0], self.gate_clip[1], self.up_clip[0], self.up_clip[1], _ptr(self.router_weights), _ptr(self.router_biases), _ptr(self.w13),
+                       _ptr(self.w2), _ptr(self.up_biases), _ptr(self.down_biases))
+
+    def nbytes_active(self) -> int:
+        """bytes one decoded token streams: the router + the k active experts' matrices and biases"""
+        per_expert = (self.w13.nbytes + self.w2.nbytes + self.up_biases.nbytes + self.down_biases.nbytes) // self.num_routed_experts
+        return self.router_weights.nbytes + self.router_biases.nbytes + self.num_active_experts * per_expert
+
+
+@dataclass
 class LayerWeights:
     mixer_kind: int
     hidden_dim: int
     activation: int
     pre_mixer_norm: NormWeights
     pre_mlp_norm: NormWeights
-    up_projection: LinearWeights
-    down_projection: LinearWeights
+    up_projection: Optional[LinearWeights]
+    down_projection: Optional[LinearWeights]
     post_mixer_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
     post_mlp_norm: NormWeights = field(default_factory=lambda: ABSENT_NORM)
     # attention
@@ -230,12 +273,13 @@ class LayerWeights:
     normalize_values: bool = False
     ple: Optional["PleLayerWeights"] = None      # ple_config: PerLayerEmbeddingProjection at the end of the layer
     is_non_causal: bool = False                  # AttentionConfig::is_causal == false (the block attention of a DFlash draft layer)
+    moe: Optional["MoeWeights"] = None           # mlp_config = MixtureOfExpertsConfig: replaces the dense MLP (up / down projection are then None)
 
     def desc(self) -> LayerDesc:
         empty = LinearDesc()
         ld = lambda w: w.desc() if w is not None else empty
         return LayerDesc(
-            self.mixer_kind, self.hidden_dim, self.activation, 0,
+            self.mixer_kind, self.hidden_dim, self.activation, MLP_MOE if self.moe is not None else MLP_DENSE,
             self.pre_mixer_norm.desc(), self.post_mixer_norm.desc(), self.pre_mlp_norm.desc(),
             self.post_mlp_norm.desc(),
             self.num_heads, self.num_groups, self.head_dim, int(self.has_gate), self.attention_scale,
@@ -254,6 +298,7 @@ class LayerWeights:
             int(self.ple is not None), self.ple.ple_dim if self.ple else 0, self.ple.activation if self.ple else 0, int(self.is_non_causal),
             ld(self.ple.gate if self.ple else None), ld(self.ple.projection if self.ple else None),
             (self.ple.norm if self.ple else ABSENT_NORM).desc(),
+            self.moe.desc() if self.moe is not None else MoeDesc(),
         )
 
     def linears(self):
@@ -380,6 +425,8 @@ class ModelBundle:
         for l in self.layers:
             for _, w in l.linears():
                 total += w.nbytes()
+            if l.moe is not None:
+                total += l.moe.nbytes_active()
         readout = self.embedding if self.tied_embeddings else self.output_embedding
         total += readout.nbytes()
         if self.ple is not None:
@@ -406,6 +453,9 @@ class ModelBundle:
         for l in self.layers:
             for _, w in l.linears():
                 macs += w.n * w.k
+            if l.moe is not None:  # router for every token + the k active experts' up | gate and down matrices
+                mo = l.moe
+                macs += mo.num_routed_experts * self.model_dim + mo.num_active_experts * 3 * mo.expert_hidden_dim * self.model_dim
         flops = 2.0 * tokens * macs
         readout = self.embedding if self.tied_embeddings else self.output_embedding
         flops += 2.0 * readout.n * readout.k

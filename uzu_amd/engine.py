@@ -19,6 +19,19 @@ from .desc import ModelBundle
 MODEL_DEFAULT, MODEL_NO_GRAPH, MODEL_NO_FUSION, MODEL_DEBUG_TAPS = 0, 1, 2, 4
 
 
+def check_desc_abi():
+    """The description structs are part of the ABI (uzu_layer_desc is an array element and has grown in place): the ctypes mirrors of uzu_amd/desc.py must have the
+    sizes the loaded library was built with (uzu_hip_desc_abi)."""
+    from . import desc as D
+    got = (C.c_uint32 * 6)()
+    fn = _ffi.lib().uzu_hip_desc_abi
+    fn.restype, fn.argtypes = None, [C.c_void_p]
+    fn(got)
+    want = [C.sizeof(t) for t in (D.LinearDesc, D.NormDesc, D.RopeDesc, D.LayerDesc, D.ModelDesc, D.DFlashDesc)]
+    if list(got) != want:
+        raise RuntimeError(f"libuzu_hip.so was built with description structs of {list(got)} bytes, uzu_amd/desc.py mirrors {want}: rebuild the library (one header, one library)")
+
+
 def MODEL_BATCH(n: int) -> int:
     """flags bits 8..15: sequences one batched prefill pass may carry (UZU_MODEL_BATCH)."""
     return (int(n) & 0xFF) << 8
@@ -68,6 +81,7 @@ class HipModel:
         self.model_dim = bundle.model_dim
         self.num_layers = len(bundle.layers)
         self.tp_group = tp_group
+        check_desc_abi()
         desc = bundle.desc()
         self._h = C.c_void_p()
         if tp_group is None:

@@ -82,6 +82,11 @@ class ModelConfig:
     ple_dim: int = 0               # > 0: per-layer embeddings (PLEModelConfig + a PLELayerConfig on every layer)
     ple_vocab_size: int = 0        # 0 = vocab_size
     first_layer_without_pre_mixer_norm: bool = False
+    moe_experts: int = 0           # > 0: every layer's MLP is a MixtureOfExpertsConfig with this many routed experts (full-precision bf16 experts)
+    moe_active: int = 2
+    moe_hidden: int = 0            # expert_hidden_dim (0 = hidden_dim)
+    moe_gelu: bool = False         # GEGLU experts (GELUApprox) instead of SwiGLU
+    moe_clip: Optional[float] = None  # symmetric gate / up clipping at +-moe_clip
     non_causal_attention: bool = False  # AttentionConfig::is_causal == false on every attention layer (the block attention of a DFlash draft model)
 
     @property
@@ -250,9 +255,20 @@ def build_layers(cfg: ModelConfig) -> List[D.LayerWeights]:
             mixer_kind=kind, hidden_dim=cfg.hidden_dim, activation=D.ACT_SILU,
             pre_mixer_norm=D.ABSENT_NORM if (li == 0 and cfg.first_layer_without_pre_mixer_norm) else make_norm(cfg, p + "pre_mixer_norm", d),
             pre_mlp_norm=make_norm(cfg, p + "pre_mlp_norm", d),
-            up_projection=make_linear(cfg, p + "mlp.up_projection", 2 * cfg.hidden_dim, d, gain=1.0),
-            down_projection=make_linear(cfg, p + "mlp.down_projection", d, cfg.hidden_dim, gain=1.5),
+            up_projection=None if cfg.moe_experts else make_linear(cfg, p + "mlp.up_projection", 2 * cfg.hidden_dim, d, gain=1.0),
+            down_projection=None if cfg.moe_experts else make_linear(cfg, p + "mlp.down_projection", d, cfg.hidden_dim, gain=1.5),
         )
+        if cfg.moe_experts:  # MoeBlock's tensors (mlp/moe/mod.rs:114-160): bf16, full precision; magnitudes as for the dense MLP
+            r = _rng(cfg.seed, p + "mlp.moe")
+            E, F = cfg.moe_experts, cfg.moe_hidden or cfg.hidden_dim
+            bf = lambda a: f32_to_bf16_bits(np.asarray(a, np.float32))
+            clip = (float("-inf"), float("inf")) if cfg.moe_clip is None else (-float(cfg.moe_clip), float(cfg.moe_clip))
+            lw.moe = D.MoeWeights(
+                num_routed_experts=E, num_active_experts=cfg.moe_active, expert_hidden_dim=F,
+                router_weights=bf(r.normal(0.0, 1.0 / np.sqrt(d), (E, d))), router_biases=bf(r.uniform(-0.5, 0.5, (E,))),
+                w13=bf(r.normal(0.0, 1.0 / np.sqrt(d), (E, 2 * F, d))), w2=bf(r.normal(0.0, 1.5 / np.sqrt(F), (E, d, F))),
+                up_biases=bf(r.uniform(-0.05, 0.05, (E, 2 * F))), down_biases=bf(r.uniform(-0.05, 0.05, (E, d))),
+                gating_sel=3 if cfg.moe_gelu else 2, gate_clip=clip, up_clip=clip)
         if cfg.post_norms:
             lw.post_mixer_norm, lw.post_mlp_norm = make_norm(cfg, p + "post_mixer_norm", d), make_norm(cfg, p + "post_mlp_norm", d)
         if cfg.post_layer_scalars:
