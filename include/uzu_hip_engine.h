@@ -192,6 +192,28 @@ uzu_status uzu_hip_drafter_read_draft(uzu_hip_drafter* f, uint16_t* draft_hidden
 /* device time of the last accept / draft, ms (HIP events on the engine's stream) */
 uzu_status uzu_hip_drafter_gpu_ms(uzu_hip_drafter* f, float* accept_ms, float* draft_ms);
 
+/* DecoderEncodeOutput::final_hidden (BU/../encodable_block/decoder.rs; ForwardPassChaining's output_norm, BU/../language_model/stream.rs:466-476) of the last prefill
+ * (1 row: the sampled one) or tree pass (one row per node): the output-norm rows, bf16 [rows][model_dim].  `out` may be NULL (rows only). */
+uzu_status uzu_hip_model_read_final_hidden(uzu_hip_model* m, uint16_t* out, uint32_t capacity_rows, uint32_t* rows);
+
+/* The Weaver tree constructor of a DFlash speculator (BU/../encodable_block/weaver.rs:166-676, weaver_layer.rs:150-200; DFlashTfmTreeConstructionMethod::Weaver,
+ * BU/../speculators/dflash_tfm.rs:224-292).  Built on a drafter (its last draft's hidden rows and f32 logits are the tree's inputs and stay in HBM) and that drafter's
+ * target (embedding lookup, sparse read-out).  Destroy it BEFORE the drafter.  The launches of a shape (~25 per round on <= 32 rows) are captured once into a
+ * hipGraph and replayed; in reference-order mode they run eagerly. */
+typedef struct uzu_hip_weaver uzu_hip_weaver;
+uzu_status uzu_hip_weaver_create(uzu_hip_context* ctx, uzu_hip_drafter* drafter, const uzu_weaver_desc* desc, uzu_hip_weaver** out);
+void uzu_hip_weaver_destroy(uzu_hip_weaver* w);
+uint32_t uzu_hip_weaver_max_depth(const uzu_hip_weaver* w);
+/* Weaver::encode_tree over the drafter's LAST draft (uzu_hip_drafter_draft with batch_size == shape->dflash_depth).  target_hidden_row: bf16 [target_model_dim], the
+ * target's output-norm row of the position that sampled root_token_id.  depth_seeds [depth_seed_count == desc.max_depth] = PRng::derive(root position + depth).
+ * Outputs (host): packed_tree u32 [6][slots], frontier u32 [7][slots * expand_width], slots = 1 + (rounds - 1) * expand_per_round (EncodedWeaverTree's two
+ * structure-of-arrays buffers; EncodedWeaverTree::read_nodes is host code: uzu_amd/speculator.py).  UZU_ERR_INVALID_ARGUMENT "invalid Weaver tree input" =
+ * WeaverEncodeError::InvalidTreeInput. */
+uzu_status uzu_hip_weaver_encode_tree(uzu_hip_weaver* w, const uint16_t* target_hidden_row, const uint64_t* depth_seeds, uint32_t depth_seed_count, uint32_t root_token_id,
+                                      const uzu_weaver_tree_shape* shape, uint32_t* packed_tree_out, uint32_t* frontier_out);
+/* device time (ms) and kernel launches of the last tree */
+uzu_status uzu_hip_weaver_stats(uzu_hip_weaver* w, float* gpu_ms, uint32_t* launches);
+
 /* bf16 logits [vocab] of the last sampled row. */
 uzu_status uzu_hip_model_read_logits(uzu_hip_model* m, uint16_t* logits_out);
 /* Debug taps (UZU_MODEL_DEBUG_TAPS): bf16 [rows, model_dim] output of `layer` in the last forward pass.

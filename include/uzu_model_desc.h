@@ -272,6 +272,54 @@ typedef struct {
     uzu_norm_desc output_norm;
 } uzu_dflash_desc;
 
+/*
+ * The Weaver tree constructor of the speculator: WeaverConfig (config/weaver.rs:5-17) + the tensors of the subtree `speculator.weaver`
+ * (encodable_block/weaver.rs:166-275, weaver_layer.rs:47-148).  All norms share norm_config (their own scales); the layers' MLP is a DenseMLP with SiLU and
+ * up / down biases (weaver_layer.rs:126-131); model_dim = num_heads * rope.head_dim.
+ *   embedding_norm.scales [target_embedding_dim], embedding_projection.{weights.*, biases} [model_dim, target_embedding_dim]
+ *   hidden_state_norm.scales [target_model_dim], hidden_state_projection.{weights.*, biases} [model_dim, target_model_dim]
+ *   blocks.{i}.{pre_attention_norm, qkv_projection [3 model_dim, model_dim], out_projection [model_dim, model_dim], pre_mlp_norm, mlp.up_projection (+ biases)
+ *               [2 hidden, model_dim], mlp.down_projection (+ biases) [model_dim, hidden]}
+ *   output_norm.scales [model_dim], query_projection.weights.* [target_model_dim, model_dim]
+ */
+typedef struct {
+    uzu_norm_desc pre_attention_norm;
+    uzu_norm_desc pre_mlp_norm;
+    uzu_linear_desc qkv_projection;
+    uzu_linear_desc out_projection;
+    uzu_linear_desc up_projection;
+    uzu_linear_desc down_projection;
+} uzu_weaver_layer_desc;
+
+typedef struct {
+    uint32_t model_dim;
+    uint32_t target_model_dim;
+    uint32_t target_embedding_dim;
+    uint32_t num_layers;
+    uint32_t num_heads;
+    uint32_t hidden_dim;
+    uint32_t max_depth;
+    uint32_t candidate_pool_size; /* 1..512 (CANDIDATES_MAX) */
+    uzu_norm_desc embedding_norm;
+    uzu_linear_desc embedding_projection;
+    uzu_norm_desc hidden_state_norm;
+    uzu_linear_desc hidden_state_projection;
+    uzu_norm_desc output_norm;
+    uzu_linear_desc query_projection;
+    uzu_rope_desc rope; /* head_dim = model_dim / num_heads, max_sequence_length > max_depth */
+    const uzu_weaver_layer_desc* layers;
+} uzu_weaver_desc;
+
+/* WeaverTreeShape (encodable_block/weaver.rs:33-46; dflash_tfm.rs:259-279: max_depth counts the root) */
+typedef struct {
+    uint32_t tree_budget;
+    uint32_t max_depth;
+    uint32_t dflash_depth;
+    uint32_t rounds;
+    uint32_t expand_per_round;
+    uint32_t expand_width;
+} uzu_weaver_tree_shape;
+
 #ifdef __cplusplus
 }
 #endif

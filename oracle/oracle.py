@@ -283,3 +283,39 @@ class OracleDFlash:
         fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         fn(self._h, target._h, C.c_uint32(int(target_output_token)), C.c_uint32(batch_size), p(hidden), p(logits), p(tokens))
         return hidden, logits, tokens
+
+
+class OracleWeaver:
+    """orc_weaver_*: the Weaver tree constructor (encodable_block/weaver.rs:166-676) next to an OracleModel target."""
+
+    def __init__(self, bundle):
+        self.bundle = bundle
+        self._desc = bundle.desc()
+        fn = lib().orc_weaver_create
+        fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p]
+        self._h = fn(C.byref(self._desc))
+        self.max_depth = bundle.max_depth
+
+    def close(self):
+        if self._h:
+            lib().orc_weaver_destroy.argtypes = [C.c_void_p]
+            lib().orc_weaver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def encode_tree(self, target: "OracleModel", target_hidden, draft_hidden, logits, depth_seeds, root_token_id: int, shape):
+        """-> (packed_tree u32 [6, slots], frontier u32 [7, slots * expand_width]), or None for WeaverEncodeError::InvalidTreeInput"""
+        target_hidden = np.ascontiguousarray(target_hidden, dtype=np.uint16)
+        draft_hidden = np.ascontiguousarray(draft_hidden, dtype=np.uint16)
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        seeds = np.ascontiguousarray(depth_seeds, dtype=np.uint64)
+        slots = shape.slot_count()
+        packed = np.zeros((6, slots), dtype=np.uint32)
+        frontier = np.zeros((7, slots * max(shape.expand_width, 1)), dtype=np.uint32)
+        fn = lib().orc_weaver_encode_tree
+        fn.restype = C.c_int32
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = fn(self._h, target._h, p(target_hidden), p(draft_hidden), p(logits), p(seeds), C.c_uint32(seeds.size), C.c_uint32(int(root_token_id)), C.byref(shape), p(packed), p(frontier))
+        return None if rc else (packed, frontier)

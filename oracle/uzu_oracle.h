@@ -280,6 +280,15 @@ const uint16_t* orc_model_hidden_feature(const orc_model* m, uint32_t layer, uin
 const uint16_t* orc_model_final_hidden_rows(const orc_model* m, uint32_t* rows);
 const uzu_model_desc* orc_model_desc(const orc_model* m);
 
+/* ---- Weaver tree constructor (encodable_block/weaver.rs:166-676; uzu_oracle_weaver.c) ---- */
+void orc_radix_top_k_small(const float* input, uint32_t* output_ids, float* output_scores, uint32_t rows, uint32_t columns, uint32_t k); /* cpu/kernel/radix_top_k_small.rs */
+typedef struct orc_weaver orc_weaver;
+orc_weaver* orc_weaver_create(const uzu_weaver_desc* desc); /* keeps the desc's tensor pointers */
+void orc_weaver_destroy(orc_weaver* w);
+/* -> 0, or 1 = WeaverEncodeError::InvalidTreeInput.  packed_tree u32 [6, slots], frontier u32 [7, slots * expand_width], slots = 1 + (rounds - 1) * expand_per_round */
+int orc_weaver_encode_tree(const orc_weaver* w, const orc_model* target, const uint16_t* target_hidden, const uint16_t* draft_hidden, const float* logits, const uint64_t* depth_seeds,
+                           uint32_t depth_seed_count, uint32_t root_token_id, const uzu_weaver_tree_shape* shape, uint32_t* packed_tree, uint32_t* frontier);
+
 /* ---- Mixture of experts (encodable_block/mlp/moe/mod.rs; uzu_oracle_moe.c: which kernels follow a CPU body and which the Metal shader is said there) ---- */
 void orc_moe_router_topk(const void* input, const void* weight, const void* bias, int32_t* topk_ids, void* topk_probs, uint32_t dt, uint32_t t, uint32_t d_model, uint32_t e,
                          uint32_t k, uint32_t renorm);

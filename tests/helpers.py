@@ -217,6 +217,9 @@ class OracleTarget:
     def verify_tree(self, token_ids, nodes, seeds=None):
         return self.om.verify_tree(token_ids, nodes)
 
+    def final_hidden_rows(self):
+        return self.om.final_hidden_rows()
+
     def accept(self, indices):
         self.om.accept(indices)
 

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_every_kernel_has_create_and_encode():
     syms = declared_symbols()
-    creates = {s[: -len("_create")] for s in syms if s.endswith("_create")} - {"uzu_hip_context", "uzu_hip_buffer", "uzu_hip_cmdbuf", "uzu_hip_model", "uzu_hip_tp_comm", "uzu_hip_state", "uzu_hip_sparse_buffer", "uzu_hip_drafter"}
+    creates = {s[: -len("_create")] for s in syms if s.endswith("_create")} - {"uzu_hip_context", "uzu_hip_buffer", "uzu_hip_cmdbuf", "uzu_hip_model", "uzu_hip_tp_comm", "uzu_hip_state", "uzu_hip_sparse_buffer", "uzu_hip_drafter", "uzu_hip_weaver"}
     encodes = {s[: -len("_encode")] for s in syms if s.endswith("_encode")}
     assert creates == encodes and len(creates) >= 25
 

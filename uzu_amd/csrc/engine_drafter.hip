@@ -96,6 +96,17 @@ uzu_status uzu_hip_model_read_features(uzu_hip_model* m, uint32_t index, uint16_
     return UZU_OK;
 }
 
+// DecoderEncodeOutput::final_hidden of the last prefill (1 row: the sampled one) or tree pass (every node): the output-norm rows, bf16 [rows][model_dim]
+// (ForwardPassChaining's output_norm, stream.rs:466-476: the Weaver construction's prefix row 0).  `out` may be null (rows only).
+uzu_status uzu_hip_model_read_final_hidden(uzu_hip_model* m, uint16_t* out, uint32_t capacity_rows, uint32_t* rows) {
+    UZU_REQUIRE(m && m->final_hidden && m->final_hidden_rows, "model_read_final_hidden: no prefill / tree pass has run");
+    UZU_REQUIRE(!out || capacity_rows >= m->final_hidden_rows, "model_read_final_hidden: %u rows, room for %u", m->final_hidden_rows, capacity_rows);
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    if (out) HIPCHK(hipMemcpy(out, m->final_hidden, (size_t)m->final_hidden_rows * m->d.model_dim * 2, hipMemcpyDeviceToHost));
+    if (rows) *rows = m->final_hidden_rows;
+    return UZU_OK;
+}
+
 // ---- the draft model ---------------------------------------------------------------------------------------------------------------------------------
 void uzu_hip_drafter_destroy(uzu_hip_drafter* f) {
     if (!f) return;
@@ -311,6 +322,18 @@ uzu_status uzu_hip_drafter_gpu_ms(uzu_hip_drafter* f, float* accept_ms, float* d
     UZU_REQUIRE(f, "drafter_gpu_ms: null drafter");
     if (accept_ms) *accept_ms = f->last_accept_ms;
     if (draft_ms) *draft_ms = f->last_draft_ms;
+    return UZU_OK;
+}
+
+// engine_weaver.hip: the objects and device buffers a Weaver built on this drafter works with (not part of the public header)
+uzu_status uzu_hip_drafter_internal(uzu_hip_drafter* f, uzu_hip_model** core, uzu_hip_model** target, uint16_t** draft_hidden, float** logits, uint32_t* last_rows, uint32_t* block_size) {
+    UZU_REQUIRE(f, "drafter: null drafter");
+    if (core) *core = f->core;
+    if (target) *target = f->target;
+    if (draft_hidden) *draft_hidden = f->draft_hidden;
+    if (logits) *logits = f->logits;
+    if (last_rows) *last_rows = f->last_rows;
+    if (block_size) *block_size = f->d.block_size;
     return UZU_OK;
 }
 

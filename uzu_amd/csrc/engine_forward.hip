@@ -566,6 +566,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
     if (m->tree.active) {
         // a tree pass: output norm, read-out and greedy sampling of EVERY node (output_range 0..size, stream.rs:618-628), no commit
         norm(e, m->output_norm, hidden, m->tree.normed, sc_cur, 2, count, d);
+        m->final_hidden = m->tree.normed, m->final_hidden_rows = count;
         DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;
         ro.in_signs = m->d.tied_embeddings ? m->embedding.out_signs : m->output_embedding.in_signs;
         ro.out_signs = nullptr;
@@ -604,6 +605,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         if (sample) {
             const size_t last = ((size_t)i * count + count - 1) * d;
             norm(e, m->output_norm, hidden + last, m->last_normed, sc_cur + last, 2, 1, d);
+            m->final_hidden = m->last_normed, m->final_hidden_rows = seqs ? 0 : 1;
             // Embedding::encode_readout (embedding.rs:374-456): the read-out's private InputRht -- a tied table's output signs
             // (embedding.rs:167-173) or the untied output embedding's input signs (embedding.rs:255-274) -- then the plain matmul
             DLinear ro = m->d.tied_embeddings ? m->embedding : m->output_embedding;

@@ -263,6 +263,9 @@ struct uzu_hip_model {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool hidden_ready = false; // row 0 of `hidden` already holds the embedding of the next input token (written by the fused commit)
     uint32_t launches = 0; // kernel launches of the last encoded forward
+    // DecoderEncodeOutput::final_hidden of the last prefill / tree pass: the output-norm rows it sampled from (uzu_hip_model_read_final_hidden)
+    const uint16_t* final_hidden = nullptr;
+    uint32_t final_hidden_rows = 0;
     void* prof_sink = nullptr; // std::vector<ProfEntry>* while profiling one step
     int regime_override = -1; // graph capture: 0 = single-pass attention, 1 = two-pass (else decided by context_length)
 };

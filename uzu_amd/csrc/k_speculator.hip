@@ -326,5 +326,104 @@ uzu_status weaver_top_children(hipStream_t s, const uint16_t* residual_logits, c
     }, "weaver_top_children");
 }
 
+
+// ---------------------------------------------------------------------------------------------- RadixTopKSmall
+// cpu/kernel/radix_top_k_small.rs:25-79: per row the k (<= 512) best of `columns` f32 values, ordered by (value descending under f32::total_cmp, column ascending).
+// One 1024-thread workgroup per row: the key of a value = its total-order integer; four 8-bit radix passes find the k-th largest key T and how many keys are larger;
+// the winners are every key > T plus the LOWEST-column keys == T (ordered compaction, chunk by chunk), then a bitonic sort of <= 512 (key, ~column) pairs in LDS.
+// Integer work throughout: exact.
+namespace {
+__device__ __forceinline__ uint32_t topk_key(float v) { // larger float (total order) <=> larger unsigned key
+    const uint32_t b = f32_to_bits(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ void __launch_bounds__(1024) radix_top_k_small_kernel(const float* input, uint32_t* output_ids, float* output_scores, uint32_t columns, uint32_t k) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_prefix, s_need, s_count, s_wave[16], s_taken;
+    __shared__ unsigned long long s_items[512];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = input + (size_t)blockIdx.x * columns;
+    if (tid == 0) s_prefix = 0, s_need = k, s_count = 0, s_taken = 0;
+    for (uint32_t i = tid; i < 512; i += 1024) s_items[i] = 0ull;
+    __syncthreads();
+    // radix select: after pass p the top 8 (p + 1) bits of T are known; s_need = winners still to be found among the keys that match the prefix
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t c = tid; c < columns; c += 1024) {
+            const uint32_t key = topk_key(row[c]);
+            if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t need = s_need, bin = 255;
+            for (;; --bin) { // from the largest digit down: the bin in which the need-th winner lies
+                const uint32_t h = s_hist[bin];
+                if (h >= need || bin == 0) break;
+                need -= h;
+            }
+            s_need = need;
+            s_prefix = prefix | (bin << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix, need_eq = s_need; // keys > T are all winners; need_eq of the keys == T (lowest columns first)
+    // winners above the threshold: any order (they are sorted below)
+    for (uint32_t c = tid; c < columns; c += 1024) {
+        const uint32_t key = topk_key(row[c]);
+        if (key > T) {
+            const uint32_t slot = atomicAdd(&s_count, 1u);
+            if (slot < 512) s_items[slot] = ((unsigned long long)key << 32) | (uint32_t)~c;
+        }
+    }
+    __syncthreads();
+    const uint32_t above = s_count;
+    // the threshold's own keys in column order: ranks inside a 1024-column chunk from ballots + wave totals
+    for (uint32_t start = 0; start < columns && s_taken < need_eq; start += 1024) {
+        const uint32_t c = start + tid;
+        const bool mine = c < columns && topk_key(row[c]) == T;
+        const unsigned long long ballot = __ballot(mine);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        uint32_t base = s_taken, total = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wave) base += s_wave[w];
+            total += s_wave[w];
+        }
+        const uint32_t rank = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        if (mine && rank < need_eq && above + rank < 512) s_items[above + rank] = ((unsigned long long)T << 32) | (uint32_t)~c;
+        __syncthreads();
+        if (tid == 0) s_taken += total;
+        __syncthreads();
+    }
+    // bitonic sort, descending, of 512 (key, ~column) pairs (unused slots are 0: they sink to the end)
+    for (uint32_t size = 2; size <= 512; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < 256) {
+                const uint32_t lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+                const bool descending = (lo & size) == 0;
+                const unsigned long long a = s_items[lo], b = s_items[hi];
+                if ((a < b) == descending) s_items[lo] = b, s_items[hi] = a;
+            }
+            __syncthreads();
+        }
+    for (uint32_t r = tid; r < k; r += 1024) {
+        const uint32_t c = ~(uint32_t)(s_items[r] & 0xFFFFFFFFull);
+        output_ids[(size_t)blockIdx.x * k + r] = c;
+        output_scores[(size_t)blockIdx.x * k + r] = row[c];
+    }
+}
+} // namespace
+uzu_status radix_top_k_small(hipStream_t s, const float* input, uint32_t* output_ids, float* output_scores, uint32_t rows, uint32_t columns, uint32_t k) {
+    if (!rows) return UZU_OK;
+    if (!k || k > 512 || k > columns) {
+        set_error("radix_top_k_small: k %u outside 1..min(512, columns %u)", k, columns);
+        return UZU_ERR_INVALID_ARGUMENT;
+    }
+    return launch_check([&] { hipLaunchKernelGGL(radix_top_k_small_kernel, dim3(rows), dim3(1024), 0, s, input, output_ids, output_scores, columns, k); }, "radix_top_k_small");
+}
+
 } // namespace k
 } // namespace uzu

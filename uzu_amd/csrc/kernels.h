@@ -305,6 +305,8 @@ uzu_status weaver_frontier_insert_children(hipStream_t s, const uint32_t* packed
 uzu_status weaver_top_children(hipStream_t s, const uint16_t* residual_logits, const float* candidate_logits, const uint32_t* candidate_ids, const uint64_t* depth_seeds,
                                const uint32_t* node_metadata, uint32_t* output_token_ids, float* output_model_logprobs, uint32_t rows, uint32_t candidates,
                                uint32_t expand_width, uint32_t vocab_size);
+// RadixTopKSmall (cpu/kernel/radix_top_k_small.rs:25-79): per row the k <= 512 best columns by (value descending under total_cmp, column ascending); exact
+uzu_status radix_top_k_small(hipStream_t s, const float* input, uint32_t* output_ids, float* output_scores, uint32_t rows, uint32_t columns, uint32_t k);
 // ---- Gated DeltaNet over a speculated token tree (k_deltanet_tree.hip; cpu/kernel/gdn/tree_verify/*.rs, delta_net.rs:334-437) ----
 constexpr uint32_t kDnTreeMaxNodes = 32; // nodes of one verify pass (the reference's stream speculates <= 16: stream.rs:550-554)
 // ConvTreeScan (do_conv) and / or DeltaNetPrefillPrep in its tree instantiation (do_prep: QKT = bf16, log decays, compact v).  in_proj

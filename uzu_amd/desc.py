@@ -376,6 +376,73 @@ class DFlashBundle:
                           self.state_kv_projection.desc(), self.rope.desc(), C.cast(arr, C.POINTER(LayerDesc)), self.output_norm.desc())
 
 
+class WeaverLayerDesc(C.Structure):
+    """include/uzu_model_desc.h::uzu_weaver_layer_desc"""
+    _fields_ = [("pre_attention_norm", NormDesc), ("pre_mlp_norm", NormDesc), ("qkv_projection", LinearDesc), ("out_projection", LinearDesc), ("up_projection", LinearDesc),
+                ("down_projection", LinearDesc)]
+
+
+class WeaverDesc(C.Structure):
+    """include/uzu_model_desc.h::uzu_weaver_desc"""
+    _fields_ = [
+        ("model_dim", C.c_uint32), ("target_model_dim", C.c_uint32), ("target_embedding_dim", C.c_uint32), ("num_layers", C.c_uint32), ("num_heads", C.c_uint32),
+        ("hidden_dim", C.c_uint32), ("max_depth", C.c_uint32), ("candidate_pool_size", C.c_uint32),
+        ("embedding_norm", NormDesc), ("embedding_projection", LinearDesc), ("hidden_state_norm", NormDesc), ("hidden_state_projection", LinearDesc),
+        ("output_norm", NormDesc), ("query_projection", LinearDesc), ("rope", RopeDesc), ("layers", C.POINTER(WeaverLayerDesc)),
+    ]
+
+
+class WeaverTreeShape(C.Structure):
+    """include/uzu_model_desc.h::uzu_weaver_tree_shape (WeaverTreeShape, encodable_block/weaver.rs:33-46)"""
+    _fields_ = [(n, C.c_uint32) for n in ("tree_budget", "max_depth", "dflash_depth", "rounds", "expand_per_round", "expand_width")]
+
+    def slot_count(self) -> int:
+        return 1 + max(self.rounds - 1, 0) * self.expand_per_round
+
+
+@dataclass
+class WeaverLayerWeights:
+    pre_attention_norm: "NormWeights"
+    pre_mlp_norm: "NormWeights"
+    qkv_projection: "LinearWeights"
+    out_projection: "LinearWeights"
+    up_projection: "LinearWeights"    # + biases
+    down_projection: "LinearWeights"  # + biases
+
+    def desc(self) -> WeaverLayerDesc:
+        return WeaverLayerDesc(self.pre_attention_norm.desc(), self.pre_mlp_norm.desc(), self.qkv_projection.desc(), self.out_projection.desc(), self.up_projection.desc(),
+                               self.down_projection.desc())
+
+
+@dataclass
+class WeaverBundle:
+    """The Weaver tree constructor (WeaverConfig, config/weaver.rs:5-17, + the tensors of `speculator.weaver`)."""
+    name: str
+    model_dim: int
+    target_model_dim: int
+    target_embedding_dim: int
+    num_heads: int
+    hidden_dim: int
+    max_depth: int
+    candidate_pool_size: int
+    embedding_norm: "NormWeights"
+    embedding_projection: "LinearWeights"
+    hidden_state_norm: "NormWeights"
+    hidden_state_projection: "LinearWeights"
+    output_norm: "NormWeights"
+    query_projection: "LinearWeights"
+    rope: "RopeConfig"
+    layers: List[WeaverLayerWeights]
+    _keep: list = field(default_factory=list, repr=False)
+
+    def desc(self) -> WeaverDesc:
+        arr = (WeaverLayerDesc * len(self.layers))(*[l.desc() for l in self.layers])
+        self._keep.append(arr)
+        return WeaverDesc(self.model_dim, self.target_model_dim, self.target_embedding_dim, len(self.layers), self.num_heads, self.hidden_dim, self.max_depth,
+                          self.candidate_pool_size, self.embedding_norm.desc(), self.embedding_projection.desc(), self.hidden_state_norm.desc(),
+                          self.hidden_state_projection.desc(), self.output_norm.desc(), self.query_projection.desc(), self.rope.desc(), C.cast(arr, C.POINTER(WeaverLayerDesc)))
+
+
 @dataclass
 class ModelBundle:
     """A whole model: config + weights.  `desc()` returns a ctypes ModelDesc that borrows from self."""

@@ -241,6 +241,14 @@ class HipModel:
             out.append(a)
         return out
 
+    def final_hidden_rows(self) -> np.ndarray:
+        """DecoderEncodeOutput::final_hidden of the last prefill (1 row) / tree pass (one row per node): bf16 bits [rows, model_dim]"""
+        rows = C.c_uint32()
+        call("uzu_hip_model_read_final_hidden", self._h, None, C.c_uint32(0), C.byref(rows))
+        a = np.empty((rows.value, self.model_dim), dtype=np.uint16)
+        call("uzu_hip_model_read_final_hidden", self._h, C.c_void_p(a.ctypes.data), C.c_uint32(rows.value), C.byref(rows))
+        return a
+
     def read_layer_output(self, layer: int) -> np.ndarray:
         rows, capacity = C.c_uint32(), C.c_uint32()
         call("uzu_hip_model_layer_output_rows", self._h, C.byref(rows), C.byref(capacity))  # a prefill pass holds up to `chunk` rows (2048 by default, UZU_PREFILL_CHUNK)
@@ -317,3 +325,53 @@ class HipDrafter:
         a, d = C.c_float(), C.c_float()
         call("uzu_hip_drafter_gpu_ms", self._h, C.byref(a), C.byref(d))
         return a.value, d.value
+
+
+class HipWeaver:
+    """The Weaver tree constructor on a drafter (include/uzu_hip_engine.h: uzu_hip_weaver_*; encodable_block/weaver.rs:166-676): the `weaver` duck type of
+    uzu_amd.speculator.  Close it before its drafter."""
+
+    def __init__(self, ctx: Context, drafter: HipDrafter, bundle):
+        self.ctx, self.drafter, self.bundle = ctx, drafter, bundle
+        self.max_depth = bundle.max_depth
+        desc = bundle.desc()
+        self._h = C.c_void_p()
+        call("uzu_hip_weaver_create", ctx._h, drafter._h, C.byref(desc), C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            fn = _ffi.lib().uzu_hip_weaver_destroy
+            fn.restype, fn.argtypes = None, [C.c_void_p]
+            fn(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h and self.drafter._h:
+                self.close()
+        except Exception:
+            pass
+
+    def encode_tree(self, target, target_hidden, draft_hidden, logits, depth_seeds, root_token_id: int, shape):
+        """-> (packed_tree u32 [6, slots], frontier u32 [7, slots * expand_width]), or None for WeaverEncodeError::InvalidTreeInput.  `draft_hidden` / `logits`
+        belong to the duck type and are ignored: the tree reads the drafter's last draft where it lies in HBM."""
+        row = np.ascontiguousarray(np.asarray(target_hidden, dtype=np.uint16).reshape(-1)[: self.drafter.model_dim])
+        seeds = np.ascontiguousarray(depth_seeds, dtype=np.uint64)
+        slots = shape.slot_count()
+        packed = np.zeros((6, slots), dtype=np.uint32)
+        frontier = np.zeros((7, slots * max(shape.expand_width, 1)), dtype=np.uint32)
+        try:
+            call("uzu_hip_weaver_encode_tree", self._h, C.c_void_p(row.ctypes.data), C.c_void_p(seeds.ctypes.data), C.c_uint32(seeds.size), C.c_uint32(int(root_token_id)),
+                 C.byref(shape), C.c_void_p(packed.ctypes.data), C.c_void_p(frontier.ctypes.data))
+        except _ffi.UzuHipError as err:
+            if "invalid Weaver tree input" in str(err):
+                return None
+            raise
+        return packed, frontier
+
+    @property
+    def stats(self):
+        """(device ms, kernel launches) of the last tree"""
+        ms, n = C.c_float(), C.c_uint32()
+        call("uzu_hip_weaver_stats", self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value

@@ -379,6 +379,29 @@ def build_drafter(target: ModelConfig, num_layers: int = 2, block_size: int = 8,
         state_kv_projection=make_linear(cfg, "state_kv_projection", num_layers * kv_dim, d, gain=1.0), rope=cfg.rope, layers=layers, output_norm=make_norm(cfg, "output_norm", d))
 
 
+def build_weaver(target: ModelConfig, model_dim: int = 0, num_layers: int = 2, num_heads: int = 4, hidden_dim: int = 0, max_depth: int = 16, candidate_pool_size: int = 16) -> "D.WeaverBundle":
+    """A Weaver tree constructor for `target` (WeaverConfig, config/weaver.rs:5-17; tensors of `speculator.weaver`, encodable_block/weaver.rs:166-275)."""
+    d = model_dim or target.model_dim
+    assert d % num_heads == 0
+    hd, hidden = d // num_heads, hidden_dim or target.hidden_dim
+    cfg = replace(target, name=target.name + "-weaver", model_dim=d, hidden_dim=hidden, seed=target.seed + 9001, rht=False, rht_embeddings=False, qlora_rank=0, linear_biases=False,
+                  moe_experts=0)
+    rope = D.RopeConfig(kind=D.ROPE_UNSCALED, head_dim=hd, max_sequence_length=max_depth + 8, base=10000.0)
+    layers = []
+    for i in range(num_layers):
+        p = f"blocks.{i}."
+        layers.append(D.WeaverLayerWeights(
+            pre_attention_norm=make_norm(cfg, p + "pre_attention_norm", d), pre_mlp_norm=make_norm(cfg, p + "pre_mlp_norm", d),
+            qkv_projection=make_linear(cfg, p + "qkv_projection", 3 * d, d), out_projection=make_linear(cfg, p + "out_projection", d, d),
+            up_projection=make_linear(cfg, p + "mlp.up_projection", 2 * hidden, d, out_bias=True), down_projection=make_linear(cfg, p + "mlp.down_projection", d, hidden, gain=1.5, out_bias=True)))
+    td = target.model_dim
+    return D.WeaverBundle(
+        name=cfg.name, model_dim=d, target_model_dim=td, target_embedding_dim=td, num_heads=num_heads, hidden_dim=hidden, max_depth=max_depth, candidate_pool_size=candidate_pool_size,
+        embedding_norm=make_norm(replace(cfg, model_dim=td), "embedding_norm", td), embedding_projection=make_linear(cfg, "embedding_projection", d, td, out_bias=True),
+        hidden_state_norm=make_norm(replace(cfg, model_dim=td), "hidden_state_norm", td), hidden_state_projection=make_linear(cfg, "hidden_state_projection", d, td, out_bias=True),
+        output_norm=make_norm(cfg, "output_norm", d), query_projection=make_linear(cfg, "query_projection", td, d), rope=rope, layers=layers)
+
+
 def synthetic_prompt(length: int, vocab_size: int, variant: int = 0, suffix: int = 16) -> np.ndarray:
     """token ids = (i*7919 + 13) mod vocab.  `variant` != 0 shifts the last `suffix` ids by variant * 15485863 (mod vocab): a
     family of prompts that share all but their tail, used to pick a prompt whose greedy continuation has no near-tie (tools/stream_search.py)."""
