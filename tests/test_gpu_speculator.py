@@ -39,6 +39,22 @@ def test_ancestor_attention_on_the_reference_tests_inputs(hip_ctx):
     check_ancestor_attention(hip_ctx, ancestor_attention_inputs())
 
 
+def test_ancestor_attention_reference_order_form_is_bit_identical(hip_ctx):
+    """uzu_hip_set_exact(1): one sequential dot product per key, one online-softmax chain in key order, glibc-exact exp => the CPU kernel's bits"""
+    import ctypes as C
+    from uzu_amd import _ffi
+    fn = _ffi.lib().uzu_hip_set_exact
+    fn.restype, fn.argtypes = None, [C.c_int32]
+    fn(1)
+    try:
+        for x in (ancestor_attention_inputs(), ancestor_attention_inputs(rows=9, prefix_length=300, ancestor_stride=6, nodes=40, num_heads=4, max_depth=7)):
+            want_out, want_kv = run_ancestor_attention(x)
+            got_out, got_kv = hip_ancestor_attention(hip_ctx, x)
+            assert np.array_equal(got_kv, want_kv) and np.array_equal(got_out, want_out)
+    finally:
+        fn(0)
+
+
 @pytest.mark.parametrize("rows,prefix,stride,heads", [(1, 0, 3, 16), (7, 1, 4, 2), (16, 37, 6, 8), (32, 300, 8, 16)])
 def test_ancestor_attention_shapes(hip_ctx, rows, prefix, stride, heads):
     """no prefix at all (the first drafter step), one prefix row, more keys than one wave's share, a long prefix; random values; the ancestor lists

@@ -35,7 +35,7 @@ def _prompt(cfg, n=24):
     return ((S.synthetic_prompt(n, cfg.vocab_size).astype(np.int64) * 7 + 35) % cfg.vocab_size).astype(np.uint32)
 
 
-WEAVER = dict(model_dim=128, num_layers=2, num_heads=4, hidden_dim=256, max_depth=7, candidate_pool_size=16)
+WEAVER = dict(model_dim=256, num_layers=2, num_heads=2, hidden_dim=256, max_depth=7, candidate_pool_size=16)  # head_dim 128: AncestorAttention's only instantiation
 
 
 def _setup(hip_ctx, cfg, n_prompt=24):

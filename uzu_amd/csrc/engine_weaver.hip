@@ -185,6 +185,7 @@ uzu_status uzu_hip_weaver_create(uzu_hip_context* ctx, uzu_hip_drafter* drafter,
     const uint32_t hd = desc->model_dim / desc->num_heads;
     UZU_REQUIRE(desc->rope.head_dim == hd, "weaver_create: rope head_dim %u does not match model_dim / num_heads = %u", desc->rope.head_dim, hd);
     UZU_REQUIRE(desc->rope.max_sequence_length > desc->max_depth, "weaver_create: rope max_sequence_length %u is too small for max_depth %u", desc->rope.max_sequence_length, desc->max_depth);
+    UZU_UNSUPPORTED(hd != 128, "weaver_create: head_dim %u (AncestorAttention is instantiated for HEAD_DIM = 128 only, as in the reference)", hd);
     UZU_UNSUPPORTED(desc->max_depth + 1 > kMaxRows, "weaver_create: max_depth %u (prefixes of at most %u rows)", desc->max_depth, kMaxRows);
     uzu_hip_model *core = nullptr, *target = nullptr;
     uint32_t block = 0;

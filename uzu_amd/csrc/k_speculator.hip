@@ -115,6 +115,63 @@ __global__ void __launch_bounds__(256) ancestor_attention_kernel(const uint16_t*
     }
 }
 
+// Reference-order form (UZU_HIP_EXACT): the CPU kernel gathers the row's keys / values and runs attention_single_pass.rs:37-127 on them -- per (row, head) one
+// sequential dot product per key (j ascending, multiply then add), one online-softmax chain over the keys in order with glibc-exact exp, o_j updated per key.
+// Workgroup per (row, head), HD threads: thread t computes the scores of keys t, t + HD, ... (each sequential over j), then every thread runs the same chain
+// and owns output element j.  Bit-identical to the CPU kernel.
+constexpr uint32_t kExactMaxKeys = 15360; // the scores of one (row, head) live in dynamic LDS (checked by the launcher)
+template <int HD>
+__global__ void __launch_bounds__(HD) ancestor_attention_exact_kernel(const uint16_t* prefix_kv, const uint16_t* node_kv, const uint16_t* current_qkv, const float* cosines,
+                                                                      const float* sines, const uint32_t* node_metadata, const uint32_t* ancestor_indices,
+                                                                      const uint32_t* ancestor_counts, uint16_t* output, uint32_t rows, uint32_t prefix_length,
+                                                                      uint32_t ancestor_stride, uint32_t node_capacity, float scale, uint32_t num_heads) {
+    __shared__ float s_q[HD], s_k[HD];
+    extern __shared__ float s_score[];
+    const uint32_t row = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, model_dim = num_heads * HD;
+    const uint16_t* cur = current_qkv + (size_t)row * 3 * model_dim;
+    const uint32_t position = node_metadata[(size_t)MD_DEPTH * rows + row] + 1;
+    rotate_head<HD>(cur, cosines, sines, model_dim, head, 0, position, s_q, tid);
+    rotate_head<HD>(cur, cosines, sines, model_dim, head, 1, position, s_k, tid >= HD / 2 ? tid - HD / 2 : HD);
+    __syncthreads();
+    s_q[tid] = scale * s_q[tid];
+    __syncthreads();
+    const uint32_t count = ancestor_counts[row], length = prefix_length + min(count, ancestor_stride) + 1;
+    auto key_row = [&](uint32_t i) -> const uint16_t* {
+        if (i < prefix_length) return prefix_kv + (size_t)i * model_dim + head * HD;
+        const uint32_t anc = min(ancestor_indices[(size_t)row * ancestor_stride + (i - prefix_length)], node_capacity - 1);
+        return node_kv + (size_t)anc * model_dim + head * HD;
+    };
+    for (uint32_t i = tid; i < length; i += HD) {
+        float score = 0.0f;
+        if (i + 1 == length) {
+            for (uint32_t j = 0; j < HD; ++j) score += s_q[j] * s_k[j];
+        } else {
+            const uint16_t* kp = key_row(i);
+            for (uint32_t j = 0; j < HD; ++j) score += s_q[j] * bf16_to_f32(kp[j]);
+        }
+        s_score[i] = score;
+    }
+    __syncthreads();
+    float max_score = -INFINITY, sum_exp_score = 0.0f, o = 0.0f;
+    for (uint32_t i = 0; i < length; ++i) {
+        const float score = s_score[i];
+        const float new_max = fmaxf(max_score, score);
+        const float factor = expf_glibc(max_score - new_max);
+        const float exp_score = expf_glibc(score - new_max);
+        max_score = new_max;
+        sum_exp_score = sum_exp_score * factor + exp_score;
+        float v;
+        if (i + 1 == length) v = bf16_to_f32(cur[2 * (size_t)model_dim + head * HD + tid]);
+        else if (i < prefix_length) v = bf16_to_f32(prefix_kv[(size_t)prefix_length * model_dim + (size_t)i * model_dim + head * HD + tid]);
+        else {
+            const uint32_t anc = min(ancestor_indices[(size_t)row * ancestor_stride + (i - prefix_length)], node_capacity - 1);
+            v = bf16_to_f32(node_kv[(size_t)node_capacity * model_dim + (size_t)anc * model_dim + head * HD + tid]);
+        }
+        o = o * factor + exp_score * v;
+    }
+    output[(size_t)row * model_dim + head * HD + tid] = f32_to_bf16(o / sum_exp_score);
+}
+
 // ------------------------------------------------------------------------------------------------ WeaverFrontierSelect
 // One workgroup.  Per node: every thread scans its slots (tid, tid + 256, ...) for the best (key, parent, token, slot) under the reference's
 // rule -- key descending, parent ascending, token ascending; the sequential scan keeps the FIRST of fully equal slots, i.e. the lower slot --
@@ -283,6 +340,16 @@ uzu_status ancestor_attention(hipStream_t s, const uint16_t* prefix_kv, uint16_t
             hipLaunchKernelGGL(ancestor_store_kernel<128>, dim3(rows, num_heads), dim3(128), 0, s, node_kv, current_qkv, cosines, sines, node_metadata, node_indices, rows,
                                node_capacity, num_heads);
         }, "ancestor_store"));
+    if (exact_mode()) {
+        if (prefix_length + ancestor_stride + 1 > kExactMaxKeys) {
+            set_error("ancestor_attention: reference-order form holds %u keys (prefix %u + ancestors %u + 1)", kExactMaxKeys, prefix_length, ancestor_stride);
+            return UZU_ERR_UNSUPPORTED;
+        }
+        return launch_check([&] {
+            hipLaunchKernelGGL(ancestor_attention_exact_kernel<128>, dim3(rows, num_heads), dim3(128), (prefix_length + ancestor_stride + 1) * sizeof(float), s, prefix_kv, node_kv, current_qkv, cosines, sines, node_metadata,
+                               ancestor_indices, ancestor_counts, output, rows, prefix_length, ancestor_stride, node_capacity ? node_capacity : 1u, scale, num_heads);
+        }, "ancestor_attention_exact");
+    }
     return launch_check([&] {
         hipLaunchKernelGGL(ancestor_attention_kernel<128>, dim3(rows, num_heads), dim3(256), 0, s, prefix_kv, node_kv, current_qkv, cosines, sines, node_metadata,
                            ancestor_indices, ancestor_counts, output, rows, prefix_length, ancestor_stride, node_capacity ? node_capacity : 1u, scale, num_heads);
