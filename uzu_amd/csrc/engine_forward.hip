@@ -669,6 +669,13 @@ void dec_add_norm(k::DecGemvParams& p, const DNorm& N, int mode, const uint16_t*
     p.residual_add = mode == 2;
     p.shortcut_in = mode == 2 ? sc_in : nullptr;
     p.shortcut_out = sc_out;
+    // Lab builds only (WRONG numerics, timing only): UZU_LAB_NORM_NOADD=1 drops the shortcut row load, the add and workgroup 0's residual store from every normed
+    // decode GEMV -- everything a producer-side residual + sum-of-squares split could take out of the consumer's prologue (an upper bound)
+    static const bool no_add = [] {
+        const char* v = lab_env("UZU_LAB_NORM_NOADD");
+        return v && atoi(v) != 0;
+    }();
+    if (no_add) p.residual_add = 0, p.shortcut_in = nullptr, p.shortcut_out = nullptr;
 }
 size_t dec_gemv_bytes(const k::DecGemvParams& p) {
     size_t b = 0;
