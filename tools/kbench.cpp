@@ -111,7 +111,12 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (getenv("KB_GEMM")) { // prefill GEMM on the matrix cores (k_gemm.hip)
-        for (auto sh : std::vector<std::array<uint32_t, 3>>{{1024, 8224, 1024}, {1024, 7168, 1024}, {1024, 1024, 3584}, {1024, 1024, 2048}, {1024, 3072, 1024}, {4096, 14336, 4096}}) {
+        std::vector<std::array<uint32_t, 3>> gemm_shapes{{1024, 8224, 1024}, {1024, 7168, 1024}, {1024, 1024, 3584}, {1024, 1024, 2048}, {1024, 3072, 1024}, {4096, 14336, 4096}};
+        if (const char* e = getenv("KB_GEMM_SHAPES")) { // "m,n,k;m,n,k;..."
+            gemm_shapes.clear();
+            for (const char* q = e; *q;) { unsigned a = 0, b = 0, c = 0; int used = 0; if (sscanf(q, "%u,%u,%u%n", &a, &b, &c, &used) != 3) break; gemm_shapes.push_back({a, b, c}); q += used; if (*q == ';') ++q; }
+        }
+        for (auto sh : gemm_shapes) {
             const uint32_t m = sh[0], n = sh[1], k = sh[2], g = 128;
             uint8_t* w = dalloc<uint8_t>((size_t)n * k / 2, 0x53); uint16_t* sc = dalloc<uint16_t>((size_t)n * k / g, 0x3c); uint16_t* bi = dalloc<uint16_t>((size_t)n * k / g, 0x3c);
             uint16_t* x = dalloc<uint16_t>((size_t)m * k, 0x3f); uint16_t* out = dalloc<uint16_t>((size_t)m * n);

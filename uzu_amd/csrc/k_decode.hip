@@ -1008,7 +1008,11 @@ bool gemv_dec_stripe_supported(const DecGemvParams& p, int num_cus) {
     const uint32_t C = p.k / 32, lpr = 1u << gemv_lpr_log2(p.k), cpl = (C + lpr - 1) / lpr;
     if (cpl > 2 || (32u / (64u / lpr)) % 4) return false; // (a block's batches split evenly over four waves)
     const uint64_t weight_bytes = (uint64_t)p.n[0] * p.k / 2;
-    if (weight_bytes >= (10u << 20)) return false; // the bandwidth regime keeps its wide workgroups (one block per workgroup would idle most of their waves)
+    static const uint64_t max_mb = [] { // UZU_DEC_STRIPE_MAX_MB (lab builds): the largest matrix that takes the stripe epilogue (A/B runs on the bandwidth-regime shapes)
+        const char* e = lab_env("UZU_DEC_STRIPE_MAX_MB");
+        return (uint64_t)(e && atoi(e) > 0 ? atoi(e) : 10);
+    }();
+    if (weight_bytes >= (max_mb << 20)) return false; // the bandwidth regime keeps its wide workgroups (one block per workgroup would idle most of their waves)
     (void)num_cus;
     return true;
 }
