@@ -198,9 +198,9 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
     """M >= 128 takes the 128 x 128 tile kernel (k_gemm128.hip): weights straight from global memory into the MFMA
     operand, the offset term as extra k-steps of bf16 pieces, optional split-K.  Ragged M (300) and N (520)."""
     if splits:
-        monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
+        monkeypatch.setenv("UZU_HIP_TUNE", f"gemm_splits={splits}")
     else:
-        monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+        monkeypatch.delenv("UZU_HIP_TUNE", raising=False)
     rng = np.random.default_rng(bits * 1000 + method * 100 + group_size)
     n, k, m = 520, 2048, 300
     q = quant_matrix(rng, n, k, bits, group_size, method)
@@ -216,17 +216,16 @@ def test_gemm_mfma_large_tile(hip_ctx, bits, method, group_size, splits, monkeyp
 @pytest.mark.parametrize("splits", ["1", "2"])
 @pytest.mark.parametrize("form", ["1", "2"])
 def test_gemm_512_thread_forms_are_bit_identical_to_the_256_thread_form(hip_ctx, bits, method, group_size, n, k, m, splits, form, monkeypatch):
-    """UZU_GEMM_FORM=1 (k_gemm128.hip, ping-pong: a 128 x 256 tile per 512-thread workgroup, convert / MFMA phases half a k-step apart) and
-    UZU_GEMM_FORM=2 (wave-specialised: four consumer waves on the matrix cores, four producer waves converting / staging).  Both run the
+    """UZU_HIP_TUNE=gemm_form=1 (k_gemm128.hip, ping-pong: a 128 x 256 tile per 512-thread workgroup, convert / MFMA phases half a k-step apart) and
+    gemm_form=2 (wave-specialised: four consumer waves on the matrix cores, four producer waves converting / staging).  Both run the
     256-thread form's arithmetic in the same order, so the outputs are equal byte for byte -- ragged M / N, an odd tile count (one half
     idle), split-K -- and hold the oracle tolerance."""
-    monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
     rng = np.random.default_rng(bits * 1000 + method * 100 + group_size + m)
     q = quant_matrix(rng, n, k, bits, group_size, method)
     a = activations(rng, m, k)
-    monkeypatch.setenv("UZU_GEMM_FORM", "0")
+    monkeypatch.setenv("UZU_HIP_TUNE", f"gemm_splits={splits},gemm_form=0")
     base = hip_matmul(hip_ctx, a, q, m)
-    monkeypatch.setenv("UZU_GEMM_FORM", form)
+    monkeypatch.setenv("UZU_HIP_TUNE", f"gemm_splits={splits},gemm_form={form}")
     got = hip_matmul(hip_ctx, a, q, m)
     assert np.array_equal(base, got)
     want = oracle_matmul(a, q, m)
@@ -254,9 +253,9 @@ def test_gemm_mfma_f32_output(hip_ctx, splits, monkeypatch):
     """f32 result buffer (the tensor-parallel row-parallel linears hand f32 partial sums to the all-reduce): the
     large-tile kernel's direct-store epilogue and the split-K reduction, against the oracle rounded to bf16."""
     if splits:
-        monkeypatch.setenv("UZU_GEMM_SPLITS", splits)
+        monkeypatch.setenv("UZU_HIP_TUNE", f"gemm_splits={splits}")
     else:
-        monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+        monkeypatch.delenv("UZU_HIP_TUNE", raising=False)
     rng = np.random.default_rng(77)
     n, k, m = 520, 1024, 200
     q = quant_matrix(rng, n, k, 4, 128, 0)

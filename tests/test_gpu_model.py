@@ -862,7 +862,7 @@ def test_reference_order_kernels_vectorised_forms_are_bit_identical_to_the_scala
     """Round 5 made reference-order mode ~50x cheaper so that it can serve as the proxy oracle at configuration scale: a 16-byte vector of
     codes per 32 elements in the matmul (matmul_ref_vec_kernel), a workgroup per row in the Normalization, a workgroup per (head, query, block)
     in attention (scores per key in parallel, prefix maxima, the one order-dependent chain on one thread).  Every reduction keeps the
-    reference's order, so logits must be BIT-IDENTICAL to the element-by-element kernels (UZU_EXACT_SCALAR=1) -- single-pass and two-pass
+    reference's order, so logits must be BIT-IDENTICAL to the element-by-element kernels (UZU_HIP_TUNE=exact_scalar=1) -- single-pass and two-pass
     attention (context > 1024), prefill rows and decode steps."""
     if "heads" in kw:
         cfg = S.PRESETS[preset](max_context_length=prompt_len + 16, num_heads=kw["heads"], num_groups=kw["groups"])
@@ -875,9 +875,9 @@ def test_reference_order_kernels_vectorised_forms_are_bit_identical_to_the_scala
     try:
         for scalar in (True, False):
             if scalar:
-                os.environ["UZU_EXACT_SCALAR"] = "1"
+                os.environ["UZU_HIP_TUNE"] = "exact_scalar=1"
             else:
-                os.environ.pop("UZU_EXACT_SCALAR", None)
+                os.environ.pop("UZU_HIP_TUNE", None)
             hm = HipModel(hip_ctx, bundle)
             rows = []
             toks = [hm.prefill(prompt[:prompt_len - 9])]
@@ -891,7 +891,7 @@ def test_reference_order_kernels_vectorised_forms_are_bit_identical_to_the_scala
             runs[scalar] = (toks, rows)
             hm.close()
     finally:
-        os.environ.pop("UZU_EXACT_SCALAR", None)
+        os.environ.pop("UZU_HIP_TUNE", None)
         _set_exact(False)
     assert runs[True][0] == runs[False][0]
     for i, (a, b) in enumerate(zip(runs[True][1], runs[False][1])):

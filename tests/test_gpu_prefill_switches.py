@@ -31,9 +31,9 @@ def _leg(tmp_path, name, **env):
 
 def test_prefill_switches_bit_identity_and_tolerance(tmp_path):
     base = _leg(tmp_path, "default")
-    conv1 = _leg(tmp_path, "conv1", UZU_CONV_APPLY4="0")
-    two = _leg(tmp_path, "two_launches", UZU_NORM_PARTIALS="0")
-    chain = _leg(tmp_path, "one_chain", UZU_DN_SPLIT="0")
+    conv1 = _leg(tmp_path, "conv1", UZU_HIP_TUNE="conv_apply4=0")
+    two = _leg(tmp_path, "two_launches", UZU_HIP_TUNE="norm_partials=0")
+    chain = _leg(tmp_path, "one_chain", UZU_HIP_TUNE="dn_split=0")
     assert conv1["logits_sha256"] == base["logits_sha256"] and conv1["tokens"] == base["tokens"]
     assert two["logits_sha256"] == base["logits_sha256"] and two["tokens"] == base["tokens"]
     assert two["prefill_launches"] > base["prefill_launches"], (two["prefill_launches"], base["prefill_launches"])  # the fused path really ran

@@ -429,14 +429,14 @@ def test_few_rows_passes_run_the_normalization_in_the_linears_prologue(hip_ctx, 
     in-projection launch, the pre-MLP Normalization in the fused up | gate + GatedActMul launch (k_gemv_rows.hip, RowsNorm: every workgroup
     normalises the rows it stages, normalization_kernel's element mapping and reduction order; the residual rows ping-pong between two
     buffers).  Logits of every tree node, of a 3-row prefill tail and of the decode steps behind an accept must be BIT-IDENTICAL to the
-    passes with separate Normalization launches (UZU_ROWS_NORM=0), with two launches per layer fewer.  (From four rows on the prologue
+    passes with separate Normalization launches (UZU_HIP_TUNE=rows_norm=0), with two launches per layer fewer.  (From four rows on the prologue
     costs more than the launch it saves -- every workgroup redoes every row -- and the engine keeps the separate kernel: engine_forward.hip::linear_normed.)"""
     cfg = S.PRESETS[preset](max_context_length=256, **kw)
     bundle = S.build_model(cfg)
     prompt = S.synthetic_prompt(50, cfg.vocab_size)
     runs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("UZU_ROWS_NORM", mode)
+        monkeypatch.setenv("UZU_HIP_TUNE", f"rows_norm={mode}")
         hm = HipModel(hip_ctx, bundle)
         hm.prefill(prompt[:47])
         tok = hm.prefill(prompt[47:])  # a 3-row tail

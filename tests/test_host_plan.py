@@ -107,8 +107,7 @@ def test_prefill_gemm_plan_follows_the_measured_ab(monkeypatch):
     """csrc/k_gemm128.hip::gemm128_form through uzu_hip_prefill_gemm_plan (host arithmetic).  The three forms are bit-identical
     (tests/test_gpu_kernels.py); which one runs is the same-box A/B of profiles/r5_gemm_pp_ab.txt: ping-pong on long reductions with at
     least one 128 x 256 tile per CU and a plain epilogue, wave-specialised on the few-tile split-K shapes, the 256-thread form elsewhere."""
-    monkeypatch.delenv("UZU_GEMM_FORM", raising=False)
-    monkeypatch.delenv("UZU_GEMM_SPLITS", raising=False)
+    monkeypatch.delenv("UZU_HIP_TUNE", raising=False)
     # Llama-3-8B at 4096 rows: qkv / out / down on the ping-pong form (x1.05-1.16), the gated up projection on the 256-thread form (x0.95)
     for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):
         p = gemm_plan(4096, n, k)
@@ -126,9 +125,9 @@ def test_prefill_gemm_plan_follows_the_measured_ab(monkeypatch):
     # below 128 rows the large-tile kernel is not used at all
     assert gemm_plan(64, 4096, 4096).large_tile == 0
     # the switch forces a form
-    monkeypatch.setenv("UZU_GEMM_FORM", "0")
+    monkeypatch.setenv("UZU_HIP_TUNE", "gemm_form=0")
     assert gemm_plan(4096, 4096, 4096).form == 0
-    monkeypatch.setenv("UZU_GEMM_FORM", "2")
+    monkeypatch.setenv("UZU_HIP_TUNE", "rows_norm=1,gemm_form=2")  # (a key anywhere in the list)
     assert gemm_plan(4096, 4096, 4096).form == 2
 
 

@@ -2,9 +2,9 @@
 """GPU box: one prefill (+ 8 greedy tokens) of a DeltaNet model, printed as hashes -- run it under different prefill switches of ONE library build
 and compare the lines (tools/ab_prefill_switches.sh):
 
-  UZU_CONV_APPLY4=0     conv: one channel per thread          (the 4-channel kernel is meant to be BIT-IDENTICAL: equal hashes)
-  UZU_NORM_PARTIALS=0   split-K reduction and normalisation as two launches   (one launch is meant to be BIT-IDENTICAL: equal hashes, fewer launches)
-  UZU_DN_SPLIT=0        DeltaNet scan as one chain of chunks  (the two-segment scan sums in another order: logits close, not equal)
+  UZU_HIP_TUNE=conv_apply4=0     conv: one channel per thread          (the 4-channel kernel is meant to be BIT-IDENTICAL: equal hashes)
+  UZU_HIP_TUNE=norm_partials=0   split-K reduction and normalisation as two launches   (one launch is meant to be BIT-IDENTICAL: equal hashes, fewer launches)
+  UZU_HIP_TUNE=dn_split=0        DeltaNet scan as one chain of chunks  (the two-segment scan sums in another order: logits close, not equal)
 
   python tools/ab_prefill_bits.py [--model tiny|qwen3.5-0.8b] [--prompt 2043]
 """
@@ -50,7 +50,7 @@ def main():
     if args.dump:
         np.save(args.dump, logits)
     f = (logits.astype(np.uint32) << 16).view(np.float32)
-    print(json.dumps({"model": cfg.name, "prompt": args.prompt, "switches": {k: os.environ[k] for k in ("UZU_CONV_APPLY4", "UZU_NORM_PARTIALS", "UZU_DN_SPLIT") if k in os.environ},
+    print(json.dumps({"model": cfg.name, "prompt": args.prompt, "switches": os.environ.get("UZU_HIP_TUNE", ""),
                       "prefill_launches": launches, "prefill_ms": round(dt * 1e3, 3), "prompt_tokens_per_s": round(args.prompt / dt, 1), "first_token": int(first),
                       "tokens": [int(t) for t in toks], "logits_sha256": hashlib.sha256(logits.tobytes()).hexdigest()[:16],
                       "logits_rms": float(np.sqrt(np.mean(f.astype(np.float64) ** 2)))}))

@@ -30,3 +30,6 @@ for f in sorted(glob.glob('gpurun_out/final/bench_*.json')):
         print(f, 'ERR', e)
 PY
 timeout 300 python tools/verify_cost.py > $O/verify_cost.json 2> $O/verify_cost.err
+timeout 500 python tools/spec_round_cost.py --out $O/spec_round_cost.json > $O/spec_round_cost.log 2>&1
+timeout 600 python bench.py --exact --steps 32 --warmup 5 --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
+timeout 1500 python tools/parity_census.py --out $O/parity_census_c2.json > $O/parity_census_c2.log 2>&1

@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/gemm_ab; mkdir -p $O
 for r in 1 2 3; do
-  UZU_GEMM_FORM=0 timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/c2_f0_$r.json 2> $O/c2_f0.err
+  UZU_HIP_TUNE=gemm_form=0 timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/c2_f0_$r.json 2> $O/c2_f0.err
   timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/c2_plan_$r.json 2> $O/c2_plan.err
 done
 python - <<'PY'

@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/gemm_ab; mkdir -p $O
 for r in 1 2 3; do
-  UZU_GEMM_FORM=0 timeout 600 python bench.py --config c3 --steps 4 --warmup 1 --no-cpu-baseline > $O/c3_pp0_$r.json 2> $O/c3_pp0.err
+  UZU_HIP_TUNE=gemm_form=0 timeout 600 python bench.py --config c3 --steps 4 --warmup 1 --no-cpu-baseline > $O/c3_pp0_$r.json 2> $O/c3_pp0.err
   timeout 600 python bench.py --config c3 --steps 4 --warmup 1 --no-cpu-baseline > $O/c3_auto_$r.json 2> $O/c3_auto.err
 done
 python - <<'PY'

@@ -2,7 +2,7 @@
 # GPU box: ping-pong GEMM variants (uzu_amd/lib_v/<name>/libuzu_hip.so) against the 256-thread form, tools/kbench KB_GEMM_AB; names ending in t are -DUZU_GEMM_PP_TIMING builds
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/gemm_ab; mkdir -p $O; rm -f $O/kbench_variants.txt
-if [ -n "$PYTEST" ]; then UZU_GEMM_FORM=${FORM:-1} timeout 420 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "gemm or matmul or large_tile" --tb=short 2>&1 | tail -8 > $O/pytest_pp.log; tail -4 $O/pytest_pp.log; fi
+if [ -n "$PYTEST" ]; then UZU_HIP_TUNE=gemm_form=${FORM:-1} timeout 420 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "gemm or matmul or large_tile" --tb=short 2>&1 | tail -8 > $O/pytest_pp.log; tail -4 $O/pytest_pp.log; fi
 for v in ${VARIANTS:-$(ls uzu_amd/lib_v)}; do
   echo "=== variant $v" >> $O/kbench_variants.txt
   T=""; case $v in t*|*t) T=1;; esac

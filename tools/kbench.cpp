@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
             void* gemm_ws = dalloc<uint8_t>(gemm_q_mfma128_workspace_bytes(p, cus) + 65536);
             double us[2];
             for (int pp = 0; pp < 2; ++pp) {
-                setenv("UZU_GEMM_FORM", pp ? (alt == 2 ? "2" : "1") : "0", 1);
+                setenv("UZU_HIP_TUNE", pp ? (alt == 2 ? "gemm_form=2" : "gemm_form=1") : "gemm_form=0", 1);
                 char name[96]; snprintf(name, sizeof name, "gemm %ux%ux%u g%u int%u%s %s", m, n, k, g, sh.bits, sh.gated ? " +act" : "", pp ? (alt == 2 ? "wave-spec" : "ping-pong") : "256-thread");
                 p.d = out[pp];
                 us[pp] = time_graph(name, wb + (size_t)m * k * 2 + on * 2, 8, [&](int) { return gemm_q_mfma128(s, p, cus, gemm_ws); });

@@ -22,7 +22,10 @@ extern "C" {
 
 // A speculated tree that was verified but never accepted is void once the sequence moves on by any other route (prefill / decode advance
 // the context: a later accept would compact KV rows at the new offsets and advance the DeltaNet states from stale tree buffers).
-static void drop_pending_tree(uzu_hip_model* m) { m->tree.size = 0, m->tree.state = nullptr; }
+// Only the tree of the state that moves: another state's pending tree (verify on A, prefill B, bind A, accept) keeps its buffers and its suffix rows.
+static void drop_pending_tree(uzu_hip_model* m, const uzu_hip_state* moving) {
+    if (m->tree.state == moving) m->tree.size = 0, m->tree.state = nullptr;
+}
 
 // LanguageModelStream::new for `nseq` independent sequences at once: `count` prompt tokens each (token_ids row-major
 // [nseq, count]), chunks of <= 1024 tokens per sequence, every chunk pass carrying all sequences (struct Seqs).
@@ -38,7 +41,7 @@ uzu_status uzu_hip_model_prefill_batch(uzu_hip_model* m, uzu_hip_state** states,
     hipStream_t s = m->ctx->stream;
     uzu_hip_state* prev = m->bound;
     m->hidden_ready = false;
-    drop_pending_tree(m);
+    for (uint32_t i = 0; i < nseq; ++i) drop_pending_tree(m, states[i]);
     uint32_t max_heads = 0, max_hd = 0;
     for (auto& L : m->layers)
         if (L.d.mixer_kind == UZU_MIXER_ATTENTION) {
@@ -109,7 +112,7 @@ uzu_status uzu_hip_model_prefill(uzu_hip_model* m, const uint32_t* token_ids, ui
                 m->context_length, count, m->d.max_context_length);
     hipStream_t s = m->ctx->stream;
     m->hidden_ready = false; // the prefill pass uses `hidden` for its own rows
-    drop_pending_tree(m);
+    drop_pending_tree(m, m->bound);
     const uint32_t pass_rows = k::exact_mode() ? kSuffixCapacity : m->chunk; // reference-order mode: the reference's own passes (bit-identical logits)
     for (uint32_t start = 0; start < count; start += pass_rows) {
         const uint32_t n = count - start < pass_rows ? count - start : pass_rows;
@@ -142,7 +145,7 @@ uzu_status uzu_hip_model_decode_enqueue(uzu_hip_model* m, uint32_t steps) {
     UZU_REQUIRE(m, "model_decode: null model");
     UZU_REQUIRE(m->context_length > 0, "model_decode: prefill first (no input token)");
     drop_stale_graphs(m);
-    drop_pending_tree(m);
+    drop_pending_tree(m, m->bound);
     return enqueue_decode(m, steps);
 }
 

@@ -337,6 +337,17 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
         uzu_hip_model_destroy(m);
         return s;
     };
+    if (comm) { // the options a shard cannot carry, from the description alone: refused before anything is uploaded
+        bool options = desc->embedding_norm.present || desc->has_ple;
+        for (uint32_t l = 0; l < desc->num_layers; ++l) {
+            const uzu_layer_desc& h = desc->layers[l];
+            options = options || h.has_post_layer_scalar || h.has_ple || (h.mixer_kind == UZU_MIXER_ATTENTION && (h.is_kv_sharing || h.normalize_values));
+        }
+        if (options) {
+            set_error("model_create: post-layer scalars, embedding norm, KV sharing, value normalisation and per-layer embeddings are not sharded (single GPU only)");
+            return fail(UZU_ERR_UNSUPPORTED);
+        }
+    }
 #define TRY(x) do { st = (x); if (st != UZU_OK) return fail(st); } while (0)
     TRY(upload_linear(m, desc->embedding, &m->embedding, true));
     if (!desc->tied_embeddings) TRY(upload_linear(m, desc->output_embedding, &m->output_embedding, true));
@@ -439,8 +450,9 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
                 // (mixer/attention/mod.rs:166-198, core/single_pass.rs:60-70): only equal geometry is a meaningful configuration
                 const uzu_layer_desc& S = desc->layers[src];
                 if (S.sliding_window_size != h.sliding_window_size || S.num_groups != h.num_groups || S.head_dim != h.head_dim) {
+                    // (a narrowing of this library, not a construction error of the reference: UNSUPPORTED)
                     set_error("model_create: layer %u and its KV source %u differ in window / kv heads / head_dim", l, src);
-                    return fail(UZU_ERR_INVALID_ARGUMENT);
+                    return fail(UZU_ERR_UNSUPPORTED);
                 }
                 m->layers[src].last_reader = l;
                 m->gemma_options = true;
@@ -528,6 +540,22 @@ uzu_status uzu_hip_model_create_tp(uzu_hip_context* ctx, const uzu_model_desc* d
     ALLOC(normed, uint16_t, CB * d);
     m->rowsum_floats = (size_t)(d / 32) * (CB + 4); // groups of >= 32 elements
     ALLOC(rowsum, float, m->rowsum_floats);
+    {   // row sums filed by the producers of `gated` (parts of 64 columns) and `delta_out` (parts of one value head) -- sized at their allocations below
+        uint32_t max_hidden = 0, max_heads = 0;
+        for (uint32_t l = 0; l < desc->num_layers; ++l) {
+            const uzu_layer_desc& h = desc->layers[l];
+            if (h.mlp_kind != UZU_MLP_MOE && h.hidden_dim > max_hidden) max_hidden = h.hidden_dim;
+            if (h.mixer_kind == UZU_MIXER_DELTA_NET && h.dn_num_heads > max_heads) max_heads = h.dn_num_heads;
+        }
+        if (max_hidden >= 64) {
+            m->rs_gated.floats = (size_t)(max_hidden / 64) * (CB + 4);
+            TRY(dev_alloc(m, m->rs_gated.floats * 4, &p, zero_scratch)); m->rs_gated.buf = (float*)p;
+        }
+        if (max_heads) {
+            m->rs_delta.floats = (size_t)max_heads * (CB + 4);
+            TRY(dev_alloc(m, m->rs_delta.floats * 4, &p, zero_scratch)); m->rs_delta.buf = (float*)p;
+        }
+    }
     ALLOC(mixed, uint16_t, CB * d);
     ALLOC(shortcut, uint16_t, CB * d);
     if (max_qkv) {

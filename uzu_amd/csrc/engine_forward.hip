@@ -74,6 +74,31 @@ static void offset_tables(uzu_hip_model* m, const DLinear& L, const uint16_t* in
     if (!enabled || batch < 128) return;
     p->pre_coef = L.coef;
     if (input == m->normed && m->rs_rows == batch && m->rs_k == L.k && m->rs_group == L.group) p->pre_rowsum = m->rowsum;
+    const uzu_hip_model::FiledRowSums* f = input == m->gated ? &m->rs_gated : input == m->delta_out ? &m->rs_delta : nullptr;
+    if (f && f->rows == batch && f->k == L.k && f->part && L.group % f->part == 0) {
+        p->pre_rowsum = f->buf;
+        p->rowsum_parts_log2 = 31u - (uint32_t)__builtin_clz(L.group / f->part);
+    }
+}
+// whether the producer of a prefill GEMM's activation rows should file their row sums in parts of `part` columns for `consumer` (the large-tile kernel reads them
+// instead of launching its pre-pass): same conditions as the normalisation's (norm_params), plus a part that divides the quant group a power-of-two times
+bool rowsum_wanted(const uzu_hip_model* m, const DLinear& consumer, uint32_t rows, uint32_t part, const uzu_hip_model::FiledRowSums& f) {
+    static const bool enabled = [] { // UZU_GEMM_TABLES=0 (lab builds): the GEMM's own pre-pass launch every time
+        const char* v = lab_env("UZU_GEMM_TABLES");
+        return !v || atoi(v) != 0;
+    }();
+    static const int lab_mask = [] { // UZU_LAB_RS_MASK (lab builds): bit 0 = the GatedActMul epilogue files, bit 1 = the DeltaNet norm-gate files
+        const char* v = lab_env("UZU_LAB_RS_MASK");
+        return v ? atoi(v) : 3;
+    }();
+    if (!(lab_mask & (&f == &m->rs_gated ? 1 : 2))) return false;
+    // Measured (tools/rs_llama.sh, profiles/r6_rowsum_producers.txt): at K = 14336 / 4096 (Llama-3-8B) the pre-pass launch is cheaper than it looks -- it leaves the
+    // rows it sums in the Infinity Cache for the GEMM behind it -- and filing the sums elsewhere LOSES 0.2-0.9 % of a pass; at K <= 3584 (the 0.8B's projections) it wins
+    if (consumer.k > 4096) return false;
+    if (!enabled || rows < 128 || !consumer.coef || consumer.in_signs || consumer.lora_rank || k::exact_mode() || !f.buf || !part || consumer.group % part || consumer.k % part) return false;
+    const uint32_t ratio = consumer.group / part;
+    if ((ratio & (ratio - 1)) || ratio > 4) return false;
+    return (size_t)(consumer.k / part) * ((rows + 3) & ~3u) <= f.floats;
 }
 
 void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel, PostNorm* post) {
@@ -113,7 +138,8 @@ void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, u
 
 // up projection + GatedActMul in one kernel (the matrix-core GEMM's epilogue pairs the up and gate columns of an output);
 // false = not available for this shape / mode: the caller runs the two kernels
-bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gated_out, uint32_t batch, uint32_t act_type) {
+bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gated_out, uint32_t batch, uint32_t act_type, const DLinear* consumer) {
+    e.m->rs_gated.rows = 0; // whoever writes `gated` next, the filed sums are stale
     static const bool enabled = [] {
         const char* v = lab_env("UZU_GEMM_ACT");
         return !v || atoi(v) != 0;
@@ -129,10 +155,14 @@ bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gat
     if (!k::matmul_act_mul_supported(e.s, p, e.m->ctx->num_cus)) return false;
     p.act_mul = 1, p.act_type = act_type;
     offset_tables(e.m, L, input, batch, &p);
+    // the down projection's row sums from this epilogue (64 gated columns per workgroup): no pre-pass launch in front of it
+    const bool file = consumer && gated_out == e.m->gated && consumer->k == L.n / 2 && k::gemm_q_mfma128_supported(p, e.m->ctx->num_cus) && rowsum_wanted(e.m, *consumer, batch, 64, e.m->rs_gated);
+    if (file) p.gated_rowsum_out = e.m->rs_gated.buf;
     const char* variant = "matmul";
     e.begin();
     const uzu_status r = k::matmul(e.s, p, e.m->ctx->num_cus, &variant);
     e.run(r, "gemm_q_mfma+act", k::matmul_algorithmic_bytes(p));
+    if (file) e.m->rs_gated.rows = batch, e.m->rs_gated.k = L.n / 2, e.m->rs_gated.part = 64;
     return true;
 }
 
@@ -143,7 +173,7 @@ bool norm_fusable(const DNorm& N);
 // linear.  gated: L is the fused up | gate matrix and `output` = GatedActMul of its halves.  false = not available: the caller runs the separate kernels.
 bool linear_normed(Enc& e, const DNorm& N, int mode, const DLinear& L, const uint16_t* x, const uint16_t* sc_in, uint16_t* sc_out, uint16_t* normed_out, uint16_t* output,
                    uint32_t rows, bool gated, uint32_t act_type) {
-    const char* env = getenv("UZU_ROWS_NORM"); // =0: the separate Normalization launch (A/B runs, tests; read when a pass is encoded or captured)
+    const char* env = tune_env("rows_norm"); // =0: the separate Normalization launch (A/B runs, tests; read when a pass is encoded or captured)
     const bool enabled = !env || atoi(env) != 0;
     uzu_hip_model* m = e.m;
     // rows <= 3 only: EVERY workgroup of the linear normalises all the rows it stages (hundreds of workgroups x rows x two passes through the L2), which
@@ -182,7 +212,8 @@ k::NormParams norm_params(Enc& e, const DNorm& N, const uint16_t* input, uint16_
     p.subtract_mean = N.subtract_mean, p.full_layer = N.full_layer;
     p.copy_to_shortcut = mode != 0, p.residual_add = mode == 2;
     uzu_hip_model* m = e.m;
-    if (consumer && consumer->coef && !consumer->in_signs && !consumer->lora_rank && output == m->normed && rows >= 128 && consumer->k == dim && !k::exact_mode() &&
+    // (dim <= 2048: see rowsum_wanted -- at Llama-3-8B's 4096 the GEMM's own pre-pass, which warms the cache with the rows, is the faster route by 0.7-0.9 % of a pass)
+    if (consumer && consumer->coef && !consumer->in_signs && !consumer->lora_rank && output == m->normed && rows >= 128 && consumer->k == dim && dim <= 2048 && !k::exact_mode() &&
         k::normalization_rowsum_supported(dim, consumer->group) && (size_t)(dim / consumer->group) * ((rows + 3) & ~3u) <= m->rowsum_floats)
         p.rowsum_out = m->rowsum, p.rowsum_group = consumer->group;
     return p;
@@ -305,7 +336,7 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
         RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
 }
 
-void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
+void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t file_rows = 0);
 
 // DeltaNet::encode_tree_verify (delta_net.rs:334-437): conv tree scan + tree prep (one launch), the tree-verify composite, norm-gate;
 // the layer's DeltaNetSuffixStatus::Tree stays in m->tree.layers[layer] for uzu_hip_model_accept
@@ -326,21 +357,27 @@ void delta_net_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
     uzu_hip_model* m = e.m;
     const uint32_t rows = q.rows();
     if (!first_done) linear(e, L.in_proj, hidden, m->in_proj, rows);
+    m->rs_delta.rows = 0;
+    // the norm-gate files the out-projection's row sums (one part per value head) while it writes the rows: no pre-pass launch in front of that GEMM
+    const uint32_t Dv = L.d.dn_value_head_dim;
+    const bool file = !m->tree.active && L.out_proj.k == L.d.dn_num_heads * Dv && rowsum_wanted(m, L.out_proj, rows, Dv, m->rs_delta);
     if (m->tree.active) { // !batch_dim.full_accept() (delta_net.rs:496-502)
         delta_net_tree_core(e, L, (uint32_t)(&L - m->layers.data()), q.count);
     } else if (q.n == 0) {
-        delta_net_core(e, L, q.count, 0);
+        delta_net_core(e, L, q.count, 0, file ? rows : 0);
     } else {
         for (uint32_t i = 0; i < q.n; ++i) {
             bind_state(m, q.st[i]);
-            delta_net_core(e, L, q.count, (size_t)i * q.count);
+            delta_net_core(e, L, q.count, (size_t)i * q.count, file ? rows : 0);
         }
     }
+    if (file) m->rs_delta.rows = rows, m->rs_delta.k = L.out_proj.k, m->rs_delta.part = Dv;
     linear(e, L.out_proj, m->delta_out, out, rows, true, post);
 }
 
-// conv + delta rule + norm-gate over `batch` rows of the bound sequence, starting at row `row0` of in_proj / delta_out
-void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
+// conv + delta rule + norm-gate over `batch` rows of the bound sequence, starting at row `row0` of in_proj / delta_out; file_rows != 0: the pass has that many
+// rows in all and the norm-gate files their sums per value head (rs_delta)
+void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t file_rows) {
     uzu_hip_model* m = e.m;
     const uint32_t Hv = L.d.dn_num_heads, Hk = L.d.dn_num_groups, Dk = L.d.dn_head_dim, Dv = L.d.dn_value_head_dim;
     const uint32_t key_dim = Hk * Dk, value_dim = Hv * Dv, conv_dim = 2 * key_dim + value_dim;
@@ -365,7 +402,10 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
                                                                           key_dim, value_dim, batch));
         else
             RUN("delta_net_prefill", 0, k::delta_net_prefill(e.s, m->qn, m->kn, m->beta, m->decay, in_proj, L.ssm_state, delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim, batch));
-        RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, delta_out, in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch));
+        const uint32_t Mp = (file_rows + 3) & ~3u;
+        const bool last = row0 + batch == file_rows; // the pass's last rows: this launch also zeroes the pad rows
+        RUN("delta_net_norm_gate", 0, k::delta_net_norm_gate(e.s, delta_out, in_proj, L.dn_norm, Hv, Dv, value_dim, conv_dim, total_proj_dim, L.d.dn_norm_epsilon, batch,
+                                                             file_rows && batch > 1 ? m->rs_delta.buf : nullptr, Mp, (uint32_t)row0, last ? Mp : 0));
     }
 }
 
@@ -499,7 +539,7 @@ uzu_status encode_forward(uzu_hip_model* m, hipStream_t s, uint32_t count, bool 
         const bool is_moe = L.d.mlp_kind == UZU_MLP_MOE;
         if (is_moe) {
             moe_mlp(e, L, m->normed, hidden, rows);
-        } else if (!mlp_done && !linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
+        } else if (!mlp_done && !linear_gated(e, L.up, m->normed, m->gated, rows, L.d.activation, &L.down)) { // prefill-sized rows: GatedActMul in the GEMM's epilogue
             linear(e, L.up, m->normed, m->up, rows);
             RUN("gated_act_mul", 0, k::gated_act_mul(s, m->up, nullptr, m->gated, UZU_BF16, L.d.hidden_dim, rows, 0, 0, L.d.activation, 1));
         }

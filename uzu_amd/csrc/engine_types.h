@@ -196,6 +196,13 @@ struct uzu_hip_model {
     float* rowsum = nullptr;
     size_t rowsum_floats = 0;
     uint32_t rs_rows = 0, rs_k = 0, rs_group = 0;
+    // the same for the two other buffers a prefill GEMM reads: `gated` (filed by the up projection's GatedActMul epilogue in parts of 64 columns) and `delta_out`
+    // (filed by the DeltaNet norm-gate in parts of one value head): MatmulParams::pre_rowsum + rowsum_parts_log2 of the down / out projection (round 6)
+    struct FiledRowSums {
+        float* buf = nullptr;
+        size_t floats = 0;
+        uint32_t rows = 0, k = 0, part = 0; // valid for `rows` rows of `k` elements in parts of `part` columns; rows == 0: nothing filed
+    } rs_gated, rs_delta;
     uint32_t rht_max_k = 0;
     uint16_t* lora_scratch = nullptr; // [rows][widest adapter rank]: x down^T of a QLoRA linear
     uint32_t lora_max_rank = 0;
@@ -347,7 +354,8 @@ struct Seqs {
     uint32_t rows() const { return (n ? n : 1) * count; }
 };
 void linear(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* output, uint32_t batch, bool row_parallel = false, PostNorm* post = nullptr);
-bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gated_out, uint32_t batch, uint32_t act_type);
+bool linear_gated(Enc& e, const DLinear& L, const uint16_t* input, uint16_t* gated_out, uint32_t batch, uint32_t act_type, const DLinear* consumer = nullptr);
+bool rowsum_wanted(const uzu_hip_model* m, const DLinear& consumer, uint32_t rows, uint32_t part, const uzu_hip_model::FiledRowSums& f);
 k::NormParams norm_params(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr);
 void norm_issued(uzu_hip_model* m, const k::NormParams& p);
 void norm(Enc& e, const DNorm& N, const uint16_t* input, uint16_t* output, uint16_t* shortcut, int mode, uint32_t rows, uint32_t dim, const DLinear* consumer = nullptr);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -65,10 +66,31 @@ inline bool raise_lds_limit(LdsLimit& st, const void* fn, size_t lds) {
     return true;
 }
 
-// Environment switches.  The shipped library reads twelve, each crossed by a test: UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK,
-// UZU_TP_TIMEOUT_MS, UZU_TP_INJECT_TIMEOUT_AT, UZU_GEMM_FORM, UZU_GEMM_SPLITS, UZU_EXACT_SCALAR, UZU_ROWS_NORM, UZU_CONV_APPLY4, UZU_NORM_PARTIALS, UZU_DN_SPLIT
-// (the last three: tests/test_gpu_prefill_switches.py holds the fused prefill paths to the paths they replace).  Every other knob is a LAB switch of the A/B
-// scripts under tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
+// Environment switches.  The shipped library reads SIX variables: UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK, UZU_TP_TIMEOUT_MS,
+// UZU_TP_INJECT_TIMEOUT_AT and UZU_HIP_TUNE -- one string "key=value,key=value" holding the A/B switches that tests cross in the product build
+// (tune_env below; keys: gemm_form, gemm_splits, exact_scalar, rows_norm, conv_apply4, norm_partials, dn_split -- each documented where it is read;
+// tests/test_gpu_prefill_switches.py holds the fused prefill paths to the paths they replace).  Every other knob is a LAB switch of the A/B scripts under
+// tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
+inline const char* tune_env(const char* key) {
+    static thread_local char value[32];
+    const char* e = getenv("UZU_HIP_TUNE");
+    if (!e) return nullptr;
+    const size_t kl = strlen(key);
+    for (const char* q = e; *q;) {
+        const char* end = strchr(q, ',');
+        const size_t len = end ? (size_t)(end - q) : strlen(q);
+        if (len > kl && !strncmp(q, key, kl) && q[kl] == '=') {
+            size_t vl = len - kl - 1;
+            if (vl >= sizeof value) vl = sizeof value - 1;
+            memcpy(value, q + kl + 1, vl);
+            value[vl] = 0;
+            return value;
+        }
+        q += len;
+        if (*q == ',') ++q;
+    }
+    return nullptr;
+}
 inline const char* lab_env(const char* name) {
 #ifdef UZU_LAB
     return getenv(name);

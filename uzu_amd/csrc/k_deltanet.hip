@@ -342,7 +342,7 @@ uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* c
     UZU_PROPAGATE(launch_check([&] { hipLaunchKernelGGL(conv_halo_kernel, dim3(gh), dim3(256), 0, s, in_proj, state, halo, suffix_len, kernel_size, conv_dim, out_stride, nblocks); },
                                "conv_halo"));
     static const bool wide = [] { // UZU_CONV_APPLY4=0: one channel per thread everywhere (A/B runs)
-        const char* e = getenv("UZU_CONV_APPLY4");
+        const char* e = tune_env("conv_apply4");
         return !e || atoi(e) != 0;
     }();
     if (wide && kernel_size == 4 && conv_dim % 4 == 0 && out_stride % 4 == 0 && (((uintptr_t)in_proj | (uintptr_t)halo) & 15) == 0 &&
@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256) delta_net_norm_gate_kernel(uint16_t* in_o
                                                                   const float* norm_weight, uint32_t num_v_heads,
                                                                   uint32_t head_v_dim, uint32_t value_dim,
                                                                   uint32_t conv_dim, uint32_t total_proj_dim,
-                                                                  float norm_epsilon, uint32_t suffix_len) {
+                                                                  float norm_epsilon, uint32_t suffix_len, float* rowsum_out, uint32_t rowsum_stride,
+                                                                  uint32_t rowsum_row0, uint32_t rowsum_pad_to) {
     __shared__ uint64_t s_exp_tab[32]; // the SiLU's exp table: an LDS read instead of a dependent global load behind the reduction
     if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
     __syncthreads();
@@ -622,21 +623,34 @@ __global__ void __launch_bounds__(256) delta_net_norm_gate_kernel(uint16_t* in_o
     }
     sumsq = wave_sum(sumsq);
     const float inv_rms = 1.0f / sqrtf(sumsq / (float)head_v_dim + norm_epsilon);
+    float row_sum = 0.f;
     for (uint32_t i = lane; i < head_v_dim; i += 64) {
         const float o_i = bf16_to_f32(in_out[base + i]);
         const float z_i = bf16_to_f32(in_proj[(size_t)token * total_proj_dim + conv_dim + hv * head_v_dim + i]);
-        in_out[base + i] = f32_to_bf16(o_i * inv_rms * norm_weight[i] * silu_f32_tab(z_i, s_exp_tab));
+        const uint16_t r = f32_to_bf16(o_i * inv_rms * norm_weight[i] * silu_f32_tab(z_i, s_exp_tab));
+        in_out[base + i] = r;
+        row_sum += bf16_to_f32(r);
+    }
+    if (rowsum_out) { // the out-projection's offset term wants the sums of the rows it will read (k_gemm128.hip): what it reads is the ROUNDED row
+        row_sum = wave_sum(row_sum);
+        if (lane == 0) {
+            float* dst = rowsum_out + (size_t)hv * rowsum_stride + rowsum_row0;
+            dst[token] = row_sum;
+            if (token + 1 == suffix_len)
+                for (uint32_t t = rowsum_row0 + suffix_len; t < rowsum_pad_to; ++t) rowsum_out[(size_t)hv * rowsum_stride + t] = 0.f;
+        }
     }
 }
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
                                uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
-                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len) {
+                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len, float* rowsum_out, uint32_t rowsum_stride, uint32_t rowsum_row0,
+                               uint32_t rowsum_pad_to) {
     const uint32_t waves = suffix_len * num_v_heads;
     if (!waves) return UZU_OK;
     if (exact_mode()) return delta_net_norm_gate_exact(s, in_out, in_proj, norm_weight, num_v_heads, head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
     return launch_check([&] {
         hipLaunchKernelGGL(delta_net_norm_gate_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in_out, in_proj, norm_weight, num_v_heads,
-                           head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len);
+                           head_v_dim, value_dim, conv_dim, total_proj_dim, norm_epsilon, suffix_len, rowsum_out, rowsum_stride, rowsum_row0, rowsum_pad_to);
     }, "delta_net_norm_gate");
 }
 

@@ -52,7 +52,7 @@ struct ScanSplit {
 };
 static uint32_t split_mid_chunk(uint32_t n_chunks, uint32_t head_v_dim) {
     static const uint32_t min_chunks = [] { // UZU_DN_SPLIT: chunks from which the scan is split (0 = never; A/B runs).  Below ~12 chunks the fix-up launch costs more than the shorter chain saves
-        const char* e = getenv("UZU_DN_SPLIT");
+        const char* e = tune_env("dn_split");
         return e ? (uint32_t)atoi(e) : 16u;
     }();
     static const uint32_t pct = [] { // UZU_DN_SPLIT_PCT: segment 0's share of the chunks (its workgroups run ~2.5 us per chunk, segment 1's double groups ~3.4)

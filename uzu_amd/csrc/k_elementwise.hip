@@ -240,7 +240,7 @@ uzu_status normalization(hipStream_t s, const NormParams& p) {
 // Split-K reduction + the GEMM's epilogue + the Normalization of the rows it produces, one launch (normalization_rows_kernel<.., true>).
 bool normalization_from_partials_supported(const NormParams& p, const NormPartials& sp) {
     static const bool on = [] { // UZU_NORM_PARTIALS=0: the reduction and the normalisation as two launches (A/B runs)
-        const char* e = getenv("UZU_NORM_PARTIALS");
+        const char* e = tune_env("norm_partials");
         return !e || atoi(e) != 0;
     }();
     if (!on || exact_mode() || p.io_dt != UZU_BF16 || p.batch_size < 16 || p.element_count % 1024 || (p.affine_dt != UZU_F32 && p.affine_dt != UZU_BF16)) return false;

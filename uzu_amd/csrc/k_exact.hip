@@ -134,7 +134,7 @@ uzu_status normalization_exact(hipStream_t s, const NormParams& p) {
     if (p.batch_size == 0) return UZU_OK;
     // in-place rows whose input IS the output and is not restaged through the shortcut would read elements another thread has already
     // overwritten only if an element depended on its neighbours -- it does not: element i reads and writes index i alone
-    if (p.element_count <= 12288 && getenv("UZU_EXACT_SCALAR") == nullptr) {
+    if (p.element_count <= 12288 && tune_env("exact_scalar") == nullptr) {
         const size_t lds = ((size_t)p.element_count + 2) * 4;
         return UZU_DISPATCH_T(p.io_dt, [&]() -> uzu_status {
             if (p.affine_dt == UZU_F32) return launch_check([&] { hipLaunchKernelGGL((normalization_exact_row_kernel<T, float>), dim3(p.batch_size), dim3(256), lds, s, p); }, "normalization_exact");
@@ -353,7 +353,7 @@ static uzu_status attention_exact_launch(hipStream_t s, const AttentionParams& a
         return UZU_ERR_UNSUPPORTED;
     }
     const size_t total = (size_t)a.num_heads * a.suffix_length * num_blocks;
-    if (total <= 16384 && getenv("UZU_EXACT_SCALAR") == nullptr) // decode steps, tree passes, short suffixes: a workgroup per reduction
+    if (total <= 16384 && tune_env("exact_scalar") == nullptr) // decode steps, tree passes, short suffixes: a workgroup per reduction
         return UZU_DISPATCH_T(a.dt, [&]() -> uzu_status {
             return launch_check([&] {
                 hipLaunchKernelGGL((attention_exact_coop_kernel<T>), dim3((uint32_t)total), dim3(256), 0, s, a, num_blocks, init_max, (T*)out, partials, sums, maxs);
@@ -417,7 +417,7 @@ uzu_status attention_two_pass2_exact(hipStream_t s, const float* partials, const
                                      uint32_t suffix_length) {
     const uint32_t rows = num_heads * suffix_length;
     if (!rows) return UZU_OK;
-    if (rows <= 16384 && getenv("UZU_EXACT_SCALAR") == nullptr)
+    if (rows <= 16384 && tune_env("exact_scalar") == nullptr)
         return UZU_DISPATCH_T(dt, [&]() -> uzu_status {
             return launch_check([&] { hipLaunchKernelGGL((attention_two_pass2_exact_row_kernel<T>), dim3(rows), dim3(256), 0, s, partials, sums, maxs, (T*)out, head_dim); },
                                 "attention_two_pass2_exact");

@@ -689,14 +689,21 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
         uint32_t arow[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) arow[mb] = min(m0 + wm * 64 + mb * 32 + c, Mp - 1);
-        const uint32_t g_end = g_lo + Gz;
+        // (a producer may have filed 2^PL partial sums per group, rows [g << PL, (g + 1) << PL) of `rowsum`: added here in part order -- more loads in flight per
+        // iteration, the same number of iterations and MFMAs; walking the parts as extra iterations cost the long-K down projections more than the pre-pass saved)
+        const uint32_t PL = p.rowsum_parts_log2, g_end = g_lo + Gz;
 #pragma unroll 4
         for (uint32_t g2 = g_lo; g2 < g_end; g2 += 2) {
             const uint32_t g = min(g2 + h, g_end - 1);
             const bool live = g2 + h < g_end;
             float av[2], bv[2];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) av[mb] = rowsum[(size_t)g * Mp + arow[mb]];
+            for (int mb = 0; mb < 2; ++mb) {
+                const float* rp = rowsum + (size_t)(g << PL) * Mp + arow[mb];
+                av[mb] = rp[0];
+                if (PL >= 1) av[mb] += rp[Mp]; // (wave-uniform; PL <= 2: host-checked)
+                if (PL >= 2) av[mb] += rp[2 * (size_t)Mp], av[mb] += rp[3 * (size_t)Mp];
+            }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) bv[nb] = live ? coef[(size_t)g * N + ncol[nb]] : 0.f;
 #pragma unroll
@@ -745,13 +752,24 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) gemm_q_mfma128
                 const uint32_t lr = wn * 32 + pass * 8 + rsub, m = m0 + wm * 64 + lr, n = n_t * 64 + seg * 8;
                 const u32x4_v uv = *(const u32x4_v*)(s_u + lr * 72 + seg * 8), gv = *(const u32x4_v*)(s_g + lr * 72 + seg * 8);
                 u32x4_v ov;
+                float part = 0.f; // the row's sum over this lane's 8 ROUNDED outputs (columns past H count as zero)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const float u0 = bits_to_f32(uv[w] << 16), u1 = bits_to_f32(uv[w] & 0xFFFF0000u);
                     const float g0 = bits_to_f32(gv[w] << 16), g1 = bits_to_f32(gv[w] & 0xFFFF0000u);
                     ov[w] = pack_bf16(u0 * activate_bf16_tab(p.act_type, g0, s_exp_tab), u1 * activate_bf16_tab(p.act_type, g1, s_exp_tab));
+                    part += bits_to_f32(ov[w] << 16);
+                    part += bits_to_f32(ov[w] & 0xFFFF0000u);
                 }
                 if (m < Mst && n < H) *(u32x4_v*)(d + (size_t)m * H + n) = ov;
+                if (p.gated_rowsum_out) { // the 8 lanes of a row segment group are neighbours: three butterfly steps, lane seg 0 files the 64-column sum
+                    if (n >= H) part = 0.f;
+                    part += __shfl_xor(part, 1);
+                    part += __shfl_xor(part, 2);
+                    part += __shfl_xor(part, 4);
+                    const uint32_t Mp = (M + 3) & ~3u;
+                    if (seg == 0 && live && m < Mp) p.gated_rowsum_out[(size_t)n_t * Mp + m] = m < M ? part : 0.f;
+                }
             }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private region: no workgroup barrier needed
@@ -828,7 +846,7 @@ __global__ void __launch_bounds__(256) gemm_split_reduce_kernel(MatmulParams p, 
 bool gemm_q_mfma128_supported(const MatmulParams& p, int num_cus);
 unsigned long long* g_gemm128_dbg = nullptr; // tools/kbench KB_GEMM_DBG: per-workgroup phase timestamps (100 MHz wall clock)
 static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
-    const char* e = getenv("UZU_GEMM_SPLITS"); // read per call: tests/test_gpu_kernels.py pins it to cover both paths
+    const char* e = tune_env("gemm_splits"); // read per call: tests/test_gpu_kernels.py pins it to cover both paths
     const int force = e ? atoi(e) : 0;
     const uint32_t G = p.k / p.group_size, gs = p.group_size / BK;
     const uint32_t tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
@@ -848,7 +866,7 @@ static uint32_t gemm128_splits(const MatmulParams& p, int num_cus) {
 //   * wave-specialised (x1.02-1.05): the few-tile split-K shapes (N = 1024 projections of the 0.8B model);
 //   * the 256-thread form everywhere else (gated epilogues, short reductions with many tiles: x0.6-0.9 for the other two).
 static int gemm128_form(const MatmulParams& p, int num_cus, uint32_t splits) {
-    if (const char* e = getenv("UZU_GEMM_FORM")) return atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
+    if (const char* e = tune_env("gemm_form")) return atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     if (p.act_mul) return 0;
     if (splits > 1) return 2;
     const uint32_t m_tiles = (p.m + BM - 1) / BM, n_tiles = (p.n + BN - 1) / BN;

@@ -163,7 +163,7 @@ static bool matmul_ref_vec_supported(const MatmulParams& p) {
     const uint32_t epv = 128 / p.bits;
     if (p.k % epv || p.group_size % epv || (uintptr_t)p.b % 16 || ((size_t)p.k * p.bits / 8) % 16) return false;
     if (!(p.a_dt == UZU_BF16 || p.a_dt == UZU_F32) || !(p.w_dt == UZU_BF16 || p.w_dt == UZU_F32)) return false;
-    return getenv("UZU_EXACT_SCALAR") == nullptr; // UZU_EXACT_SCALAR=1: the element-by-element kernel (A/B of the two: tests)
+    return tune_env("exact_scalar") == nullptr; // UZU_EXACT_SCALAR=1: the element-by-element kernel (A/B of the two: tests)
 }
 template <int BITS, int MR> static uzu_status launch_ref_vec_r(hipStream_t s, const MatmulParams& p) {
     const dim3 grid((p.n + 255) / 256, (p.m + MR - 1) / MR);

@@ -46,6 +46,12 @@ struct MatmulParams {
     // to 4, pad rows zero = the group row sums of A, written by the kernel that produced A (NormParams::rowsum_out).  Both given: no pre-pass.
     const float* pre_rowsum;
     const float* pre_coef;
+    // pre_rowsum may hold 2^x partial sums per quant group, [groups << x][Mp] (a producer whose workgroups own less than a group of a row: the gated
+    // epilogue's 64 columns, a DeltaNet head narrower than the group): the offset term then walks the parts against the group's coefficient row
+    uint32_t rowsum_parts_log2;
+    // act_mul: the epilogue also files the f32 sums of the 64 gated columns it writes per row, [n / 2 / 64][Mp] (Mp = m rounded up to 4, pad rows zero) --
+    // pre_rowsum (parts of 64 columns) of the GEMM that reads D next, which then needs no pre-pass launch.  The large-tile kernel only; null = not filed.
+    float* gated_rowsum_out;
     // The Normalization that reads D next (engine prefill: out-projection -> pre-MLP norm, down-projection -> the next layer's pre-mixer norm; its
     // `input` is D).  A split-K GEMM then finishes with ONE launch that adds the partial tiles, applies the epilogue, stores D and normalises the rows
     // (normalization_from_partials) and sets *post_norm_done; every other kernel choice ignores it and the caller runs the normalisation itself.
@@ -270,9 +276,12 @@ size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim,
 uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
                                      float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
                                      uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+// rowsum_out (optional; production kernel only): the f32 sum of every (token, head)'s rounded outputs at [head][rowsum_row0 + token], row stride rowsum_stride --
+// MatmulParams::pre_rowsum of the out-projection in parts of head_v_dim columns; rows [rowsum_row0 + suffix_len, rowsum_pad_to) are zeroed (the pad rows)
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
                                uint32_t num_v_heads, uint32_t head_v_dim, uint32_t value_dim, uint32_t conv_dim,
-                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len);
+                               uint32_t total_proj_dim, float norm_epsilon, uint32_t suffix_len, float* rowsum_out = nullptr, uint32_t rowsum_stride = 0,
+                               uint32_t rowsum_row0 = 0, uint32_t rowsum_pad_to = 0);
 
 // ---------------------------------------------------------------- reference-order mode (k_exact.hip, k_matmul.hip::matmul_ref_kernel)
 // UZU_HIP_EXACT=1 / uzu_hip_set_exact(1): every reduction kernel (matmul, Normalization, QKVNorm, attention, DeltaNet) runs one thread
