@@ -4,6 +4,7 @@ process running tools/ab_prefill_bits.py: a 700-token prefill + 8 greedy tokens 
   * four-channel conv apply (k_deltanet.hip::conv_apply4_kernel)                  -- BIT-IDENTICAL logits to the one-channel kernel
   * split-K reduction + Normalization in one launch (normalization_from_partials)  -- BIT-IDENTICAL logits, fewer launches
   * DeltaNet scan as two concurrent segments (k_deltanet_chunk.hip: ScanSplit)     -- another summation order: logits within the parity tolerance
+  * DeltaNetPrefillPrep inside the chunk preparation (round 6: dn_chunk_prep_kernel<true>) -- BIT-IDENTICAL logits to the two launches, fewer launches
 """
 import json
 import os
@@ -34,6 +35,9 @@ def test_prefill_switches_bit_identity_and_tolerance(tmp_path):
     conv1 = _leg(tmp_path, "conv1", UZU_HIP_TUNE="conv_apply4=0")
     two = _leg(tmp_path, "two_launches", UZU_HIP_TUNE="norm_partials=0")
     chain = _leg(tmp_path, "one_chain", UZU_HIP_TUNE="dn_split=0")
+    prep = _leg(tmp_path, "prep_launch", UZU_HIP_TUNE="prep_fused=0")  # DeltaNetPrefillPrep as its own launch in front of the chunk preparation
+    assert prep["logits_sha256"] == base["logits_sha256"] and prep["tokens"] == base["tokens"]
+    assert prep["prefill_launches"] > base["prefill_launches"], (prep["prefill_launches"], base["prefill_launches"])
     assert conv1["logits_sha256"] == base["logits_sha256"] and conv1["tokens"] == base["tokens"]
     assert two["logits_sha256"] == base["logits_sha256"] and two["tokens"] == base["tokens"]
     assert two["prefill_launches"] > base["prefill_launches"], (two["prefill_launches"], base["prefill_launches"])  # the fused path really ran

@@ -13,7 +13,7 @@ from test_oracle_tree_verify import linear_stream, logit_error_sigma, random_tre
 from uzu_amd import _ffi
 from uzu_amd import backend as B
 from uzu_amd import synthetic as S
-from uzu_amd.engine import HipModel
+from uzu_amd.engine import MODEL_BATCH, HipModel
 from uzu_amd.trie import TrieNode
 
 pytestmark = pytest.mark.gpu
@@ -420,6 +420,33 @@ def test_a_pending_tree_is_void_once_the_sequence_moves_on_another_way(hip_ctx):
         hm.verify_tree(flat2.token_ids(), flat2.nodes())  # and a new tree can be verified (it was refused as "already pending" before)
         hm.accept([0])
     hm.close()
+
+
+def test_a_pending_tree_survives_a_pass_over_another_sequence(hip_ctx):
+    """One model, two sequence states: verify a tree on A, prefill B (and a batched prefill over B and C), bind A again, accept -- A's suffix rows and the
+    tree buffers were not touched, so the accept goes through and the stream behind it is the one without the detour (advisor finding, round 5: the pending
+    tree was dropped by ANY pass)."""
+    cfg = S.tiny_qwen()
+    bundle = S.build_model(cfg)
+    prompt = S.synthetic_prompt(15, cfg.vocab_size)
+    other = S.synthetic_prompt(9, cfg.vocab_size, variant=3)
+    runs = []
+    for detour in (False, True):
+        hm = HipModel(hip_ctx, bundle, MODEL_BATCH(2))
+        b, c = hm.new_state(), hm.new_state()
+        tok = hm.prefill(prompt)
+        flat = TrieNode.flat([tok, 5, 6]).linearize()
+        sampled = hm.verify_tree(flat.token_ids(), flat.nodes())
+        if detour:
+            hm.bind(b)
+            hm.prefill(other)
+            hm.prefill_batch([b, c], np.stack([other[:4], other[4:8]]))
+            hm.bind(None)
+        hm.accept([0])
+        nxt, _ = hm.decode(4)
+        runs.append((list(sampled), [int(t) for t in nxt]))
+        b.close(), c.close(), hm.close()
+    assert runs[0] == runs[1]
 
 
 @pytest.mark.parametrize("preset,kw", [("tiny-qwen", {"model_dim": 1024, "group_size": 128}), ("tiny-llama", {"model_dim": 1024, "group_size": 128, "method": 1}),

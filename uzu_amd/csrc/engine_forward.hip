@@ -389,6 +389,8 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t fil
         RUN("delta_net_update", (size_t)2 * Hv * Dv * Dk * 4, k::delta_net_update(e.s, in_proj, L.a_log, L.dt_bias, L.dn_norm, L.ssm_state, delta_out, Hv, Hk, Dk, Dv, key_dim, value_dim,
                                   L.d.dn_norm_epsilon));
     } else {
+        const bool chunked = m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch);
+        const bool prep_fused = chunked && k::delta_net_prefill_prep_fused_enabled(); // DeltaNetPrefillPrep inside the chunk preparation (bit-identical, one launch less)
         if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(m->chunk + 8) * total_proj_dim) {
             RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
         } else {
@@ -396,8 +398,12 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t fil
             RUN("delta_net_conv_scan", 0, k::delta_net_conv_scan(e.s, m->padded, L.conv_w, L.conv_b, in_proj, L.conv_state, batch, ks, total_proj_dim, ks - 1, conv_dim,
                                          total_proj_dim));
         }
-        RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
-        if (m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch))
+        if (!prep_fused)
+            RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
+        if (prep_fused)
+            RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked_fused(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, L.ssm_state, delta_out, m->dn_ws, Hv, Hk, Dv, key_dim,
+                                                                                value_dim, batch));
+        else if (chunked)
             RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, in_proj, L.ssm_state, delta_out, m->dn_ws, Hv, Hk, Dv,
                                                                           key_dim, value_dim, batch));
         else

@@ -71,15 +71,85 @@ size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim,
     return ((size_t)((suffix_len + CC - 1) / CC) * num_v_heads * WS_FLOATS + split_floats(num_v_heads, value_dim, suffix_len)) * sizeof(float);
 }
 
-// grid (chunks, Hv), 256 threads
+// grid (chunks, Hv), 256 threads.
+// FUSED (round 6): DeltaNetPrefillPrep (prefill_prep.rs:30-113; k_deltanet.hip::delta_net_prefill_prep_kernel) runs inside this kernel -- the chunk's q / k rows come
+// straight from the conv'd in-projection rows (bf16), are L2-normalised with that kernel's element mapping and reduction order (a wave per token, two elements per
+// lane, wave_sum: the same bits), land in LDS for the Gram matrices AND in q_norm / k_norm for the scan (written by the first value head of a key head); beta and the
+// decay of the chunk's tokens are computed where they are used.  One launch and one 33 MB read of the f32 rows less per DeltaNet layer (9.85 -> 9.57 ms per 2043-token
+// pass of the 0.8B).  Also convolving the q / k channels here (the conv kernel then rewriting the v channels only) was built, bit-identical, and bought nothing
+// (9.66-9.73 vs 9.60-9.72 ms, profiles/r6_prep_fused_ab.txt): the window loads and 4 SiLUs per token cost this kernel what the conv kernel saved; not kept.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm, const float* k_norm, const float* beta_buf, const float* decay_buf,
-                                                            float* ws, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t key_dim, uint32_t suffix_len) {
+                                                            float* ws, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t key_dim, uint32_t suffix_len,
+                                                            const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out,
+                                                            uint32_t value_dim) {
     __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP];
     __shared__ float sKK[CC * TP], sQK[CC * TP], sM[CC * TP];
     __shared__ float s_lg[CC], s_b[CC];
+    __shared__ uint64_t s_exp_tab[32];
     const int tid = threadIdx.x;
-    const uint32_t chunk = blockIdx.x, hv = blockIdx.y, hk = hv / (num_v_heads / num_k_heads);
+    const uint32_t groups_per_head = num_v_heads / num_k_heads;
+    const uint32_t chunk = blockIdx.x, hv = blockIdx.y, hk = hv / groups_per_head;
     const uint32_t t0 = chunk * CC;
+    if constexpr (FUSED) {
+        if (tid < 32) s_exp_tab[tid] = kExp2fTab[tid];
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t conv_dim = 2 * key_dim + value_dim;
+        const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+        const bool writer = hv % groups_per_head == 0; // one value head per key head files the rows for the scan
+        constexpr int TW = CC / 4; // this wave's 8 tokens: every load requested before the first reduction
+        const uint32_t tl0 = wave * TW;
+        uint32_t qw[TW], kw[TW];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            const uint32_t t = min(t0 + tl0 + i, suffix_len - 1);
+            const uint16_t* row = in_proj + (size_t)t * total_proj_dim + hk * DKC + lane * 2;
+            qw[i] = *(const uint32_t*)row;
+            kw[i] = *(const uint32_t*)(row + key_dim);
+        }
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            const uint32_t tl = tl0 + i, t = t0 + tl;
+            const float qv[2] = {bits_to_f32(qw[i] << 16), bits_to_f32(qw[i] & 0xFFFF0000u)}, kv[2] = {bits_to_f32(kw[i] << 16), bits_to_f32(kw[i] & 0xFFFF0000u)};
+            float q_sq = 0.f, k_sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                q_sq += qv[e] * qv[e];
+                k_sq += kv[e] * kv[e];
+            }
+            q_sq = wave_sum(q_sq);
+            k_sq = wave_sum(k_sq);
+            const float q_inv = 1.0f / sqrtf(q_sq + 1e-6f);
+            const float q_scale = 1.0f / sqrtf((float)DKC);
+            const float k_inv = 1.0f / sqrtf(k_sq + 1e-6f);
+            const bool live = t < suffix_len;
+            float2 qn = make_float2(0.f, 0.f), kn = qn; // zero rows past the end: b = 0, a = 1 there, so they change nothing
+            if (live) qn = make_float2(qv[0] * q_inv * q_scale, qv[1] * q_inv * q_scale), kn = make_float2(kv[0] * k_inv, kv[1] * k_inv);
+            *(float2*)(sQ + tl * KP + lane * 2) = qn;
+            *(float2*)(sK + tl * KP + lane * 2) = kn;
+            if (live && writer) {
+                *(float2*)(q_norm_out + (size_t)t * key_dim + hk * DKC + lane * 2) = qn;
+                *(float2*)(k_norm_out + (size_t)t * key_dim + hk * DKC + lane * 2) = kn;
+            }
+        }
+        __syncthreads(); // (the exp table)
+        if (tid < CC) {
+            const bool live = t0 + tid < suffix_len;
+            float d = 1.0f, b = 0.0f;
+            if (live) {
+                const uint16_t* row = in_proj + (size_t)(t0 + tid) * total_proj_dim + conv_dim + value_dim;
+                const float beta_raw = bf16_to_f32(row[hv]);
+                b = 1.0f / (1.0f + expf_glibc_tab(-beta_raw, s_exp_tab));
+                const float a_raw = bf16_to_f32(row[num_v_heads + hv]);
+                const float sp_in = a_raw + dt_bias[hv];
+                const float sp = sp_in > 20.0f ? sp_in : logf_glibc(1.0f + expf_glibc_tab(sp_in, s_exp_tab));
+                const float log_decay = -expf_glibc_tab(a_log[hv], s_exp_tab) * sp;
+                d = expf_glibc_tab(log_decay, s_exp_tab);
+            }
+            s_lg[tid] = fmaxf(logf_glibc(d), -80.0f);
+            s_b[tid] = b;
+        }
+    } else {
     // K, Q rows of the chunk (zero rows past the end: b = 0, a = 1 there, so they change nothing)
     for (int idx = tid; idx < CC * (DKC / 4); idx += 256) {
         const int t = idx / (DKC / 4), c4 = idx % (DKC / 4);
@@ -96,6 +166,7 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
         const float d = live ? decay_buf[(size_t)(t0 + tid) * num_v_heads + hv] : 1.0f;
         s_lg[tid] = fmaxf(logf_glibc(d), -80.0f); // log a_t (decay 0 => clamped: the state is wiped either way)
         s_b[tid] = live ? beta_buf[(size_t)(t0 + tid) * num_v_heads + hv] : 0.0f;
+    }
     }
     __syncthreads();
     if (tid == 0) { // inclusive prefix sum of 32 logs
@@ -624,14 +695,25 @@ bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_he
     return head_k_dim == DKC && num_k_heads && num_v_heads % num_k_heads == 0 && head_v_dim % 16 == 0 && suffix_len >= min_t;
 }
 
-uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
-                                     float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
-                                     uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
+// prep != null: DeltaNetPrefillPrep fused into the chunk preparation (q_norm / k_norm are then OUTPUTS of this call; beta / decay are not materialised)
+struct FusedPrep {
+    const float *a_log, *dt_bias;
+};
+static uzu_status prefill_chunked(hipStream_t s, float* q_norm, float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
+                                  float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len,
+                                  const FusedPrep* prep) {
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
-    UZU_PROPAGATE(launch_check([&] {
-        hipLaunchKernelGGL(dn_chunk_prep_kernel, dim3(n_chunks, num_v_heads), dim3(256), 0, s, q_norm, k_norm, beta, decay, workspace, num_v_heads, num_k_heads,
-                           key_dim, suffix_len);
-    }, "delta_net_chunk_prep"));
+    if (prep)
+        UZU_PROPAGATE(launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_prep_kernel<true>, dim3(n_chunks, num_v_heads), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, workspace, num_v_heads, num_k_heads, key_dim, suffix_len, in_proj, prep->a_log, prep->dt_bias, q_norm, k_norm, value_dim);
+        }, "delta_net_chunk_prep_fused"));
+    else
+        UZU_PROPAGATE(launch_check([&] {
+            hipLaunchKernelGGL(dn_chunk_prep_kernel<false>, dim3(n_chunks, num_v_heads), dim3(256), 0, s, (const float*)q_norm, (const float*)k_norm, beta, decay, workspace,
+                               num_v_heads, num_k_heads, key_dim, suffix_len, (const uint16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                               (float*)nullptr, value_dim);
+        }, "delta_net_chunk_prep"));
     ScanSplit sp{};
     sp.mid_chunk = value_dim == num_v_heads * head_v_dim ? split_mid_chunk(n_chunks, head_v_dim) : 0u;
     static LdsLimit dual_lds;
@@ -660,6 +742,24 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
         hipLaunchKernelGGL(dn_chunk_fixup_kernel, dim3((t2 + FIX_TOK - 1) / FIX_TOK + DKC / 16, num_v_heads), dim3(256), kFixLdsBytes, s, sp, state, out,
                            num_v_heads, head_v_dim, value_dim, suffix_len);
     }, "delta_net_chunk_fixup");
+}
+
+uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
+                                     float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
+                                     uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len) {
+    return prefill_chunked(s, (float*)q_norm, (float*)k_norm, beta, decay, in_proj, state, out, workspace, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, nullptr);
+}
+// UZU_HIP_TUNE=prep_fused=0: DeltaNetPrefillPrep as its own launch in front (tests/test_gpu_prefill_switches.py holds the fused kernel to it, bit for bit)
+// UZU_HIP_TUNE=prep_fused=0: DeltaNetPrefillPrep as its own launch in front (tests/test_gpu_prefill_switches.py holds the fused kernel to it, bit for bit)
+bool delta_net_prefill_prep_fused_enabled() {
+    const char* e = tune_env("prep_fused");
+    return !e || atoi(e) != 0;
+}
+uzu_status delta_net_prefill_chunked_fused(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* state,
+                                           uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
+                                           uint32_t suffix_len) {
+    const FusedPrep prep{a_log, dt_bias};
+    return prefill_chunked(s, q_norm_out, k_norm_out, nullptr, nullptr, in_proj, state, out, workspace, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, &prep);
 }
 
 } // namespace k

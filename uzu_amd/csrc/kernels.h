@@ -276,6 +276,12 @@ size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim,
 uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj,
                                      float* state, uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim,
                                      uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len);
+// the same with DeltaNetPrefillPrep inside the chunk preparation (round 6): q_norm_out / k_norm_out f32 [suffix_len, key_dim] are written for the scan, beta / decay stay
+// in the kernel; bit-identical to delta_net_prefill_prep + delta_net_prefill_chunked
+bool delta_net_prefill_prep_fused_enabled(); // UZU_HIP_TUNE=prep_fused=0: the separate launch
+uzu_status delta_net_prefill_chunked_fused(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* state,
+                                           uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
+                                           uint32_t suffix_len);
 // rowsum_out (optional; production kernel only): the f32 sum of every (token, head)'s rounded outputs at [head][rowsum_row0 + token], row stride rowsum_stride --
 // MatmulParams::pre_rowsum of the out-projection in parts of head_v_dim columns; rows [rowsum_row0 + suffix_len, rowsum_pad_to) are zeroed (the pad rows)
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
