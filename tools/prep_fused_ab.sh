@@ -1,7 +1,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-for rep in 1 2 3; do for v in 1 0; do
-  UZU_HIP_TUNE=prep_fused=$v timeout 300 python tools/ab_prefill_bits.py --model qwen3.5-0.8b --prompt 2043 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('prep_fused=$v', d['prefill_ms'], d['prefill_launches'], d['logits_sha256'], d['tokens'][:4])"
+for rep in 1 2 3; do for v in conv_oop=1 conv_oop=0 prep_fused=0; do
+  UZU_HIP_TUNE=$v timeout 300 python tools/ab_prefill_bits.py --model qwen3.5-0.8b --prompt 2043 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['prefill_ms'], d['prefill_launches'], d['logits_sha256'], d['tokens'][:4])"
 done; done
 timeout 600 python -m pytest tests/test_gpu_prefill_switches.py tests/test_gpu_tree_verify.py -m gpu -q --tb=short 2>&1 | tail -5
 timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q --tb=short -k "chained_stream or deltanet or delta or batched or prefill" 2>&1 | tail -5

@@ -391,7 +391,14 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t fil
     } else {
         const bool chunked = m->dn_ws && k::delta_net_prefill_chunked_supported(Hv, Hk, Dk, Dv, batch);
         const bool prep_fused = chunked && k::delta_net_prefill_prep_fused_enabled(); // DeltaNetPrefillPrep inside the chunk preparation (bit-identical, one launch less)
-        if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(m->chunk + 8) * total_proj_dim) {
+        // ... and then the conv can run OUT OF PLACE into `padded` (its halo launch goes: the window comes from the rows, which stay raw; the chunk preparation and the
+        // scans read the conv'd channels from there and the preparation writes the carried conv state)
+        uint16_t* conv_rows = (uint16_t*)m->padded;
+        const bool conv_oop = prep_fused && (size_t)batch * conv_dim * 2 <= (size_t)(m->chunk + 8) * total_proj_dim * 4 &&
+                              k::delta_net_conv_out_of_place_supported(in_proj, L.conv_w, L.conv_b, conv_rows, ks, conv_dim, total_proj_dim);
+        if (conv_oop) {
+            RUN("delta_net_conv_oop", 0, k::delta_net_conv_out_of_place(e.s, in_proj, L.conv_w, L.conv_b, L.conv_state, conv_rows, batch, conv_dim, total_proj_dim));
+        } else if (ks <= 8 && k::delta_net_conv_fused_workspace_floats(batch, ks, conv_dim) <= (size_t)(m->chunk + 8) * total_proj_dim) {
             RUN("delta_net_conv_fused", 0, k::delta_net_conv_fused(e.s, in_proj, L.conv_w, L.conv_b, L.conv_state, m->padded, batch, ks, conv_dim, total_proj_dim));
         } else {
             RUN("conv1d_pack", 0, k::conv1d_pack(e.s, L.conv_state, in_proj, m->padded, ks - 1, total_proj_dim, batch, conv_dim));
@@ -402,7 +409,7 @@ void delta_net_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, uint32_t fil
             RUN("delta_net_prefill_prep", 0, k::delta_net_prefill_prep(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, m->beta, m->decay, Hv, Hk, Dk, key_dim, value_dim, batch));
         if (prep_fused)
             RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked_fused(e.s, in_proj, L.a_log, L.dt_bias, m->qn, m->kn, L.ssm_state, delta_out, m->dn_ws, Hv, Hk, Dv, key_dim,
-                                                                                value_dim, batch));
+                                                                                value_dim, batch, conv_oop ? conv_rows : nullptr, L.conv_state));
         else if (chunked)
             RUN("delta_net_prefill_chunked", 0, k::delta_net_prefill_chunked(e.s, m->qn, m->kn, m->beta, m->decay, in_proj, L.ssm_state, delta_out, m->dn_ws, Hv, Hk, Dv,
                                                                           key_dim, value_dim, batch));

@@ -326,6 +326,70 @@ __global__ void __launch_bounds__(256) conv_apply4_kernel(uint16_t* in_proj, con
                 for (uint32_t tap = 0; tap < taps; ++tap) state[(size_t)(c + ch) * taps + tap] = halo[((size_t)nblocks * taps + tap) * conv_dim + c + ch];
     }
 }
+// Out of place (round 6): the conv'd channels go to `conv_out` [suffix_len][conv_dim] bf16 and the in-projection rows stay raw, so a block's window is read from the
+// rows themselves -- no halo launch in front.  Kernel size 4, four channels per thread, the arithmetic and its order are conv_apply4_kernel's (bit-identical rows).
+// The consumers of a chunked prefill (dn_chunk_prep_kernel<true>: q / k; the chunk scans: v) take the rows from conv_out.
+__global__ void __launch_bounds__(256) conv_apply4_oop_kernel(const uint16_t* in_proj, const float* conv_weight, const float* bias, const float* state, uint16_t* conv_out,
+                                                              uint32_t suffix_len, uint32_t conv_dim, uint32_t in_stride, uint32_t nblocks) {
+    __shared__ uint64_t s_exp_tab[32];
+    if (threadIdx.x < 32) s_exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
+    constexpr uint32_t KS = 4, taps = KS - 1;
+    const uint32_t cq = conv_dim / 4;
+    const size_t total = (size_t)nblocks * cq;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(idx % cq) * 4, b = (uint32_t)(idx / cq);
+        const uint32_t t_begin = b * CONV_TBLK, t_end = (b + 1) * CONV_TBLK < suffix_len ? (b + 1) * CONV_TBLK : suffix_len;
+        u32x2_v raw[CONV_TBLK + taps]; // rows t_begin - 3 .. t_begin + 15 (clamped rows are loaded and never consumed)
+#pragma unroll
+        for (int i = 0; i < CONV_TBLK + (int)taps; ++i) {
+            const int ti = (int)t_begin - (int)taps + i;
+            const uint32_t t = (uint32_t)(ti < 0 ? 0 : ti < (int)suffix_len ? ti : (int)suffix_len - 1);
+            raw[i] = *(const u32x2_v*)(in_proj + (size_t)t * in_stride + c);
+        }
+        float w[4][KS], win[4][taps], b0[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const f32x4_v wv = *(const f32x4_v*)(conv_weight + (size_t)(c + ch) * KS);
+            w[ch][0] = wv.x, w[ch][1] = wv.y, w[ch][2] = wv.z, w[ch][3] = wv.w;
+        }
+#pragma unroll
+        for (uint32_t tap = 0; tap < taps; ++tap) { // X[t_begin - 3 + tap]: the carried state in front of the pass, raw rows otherwise
+            const int ti = (int)t_begin - (int)taps + (int)tap;
+            const float x[4] = {bits_to_f32(raw[tap].x << 16), bits_to_f32(raw[tap].x & 0xFFFF0000u), bits_to_f32(raw[tap].y << 16), bits_to_f32(raw[tap].y & 0xFFFF0000u)};
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) win[ch][tap] = ti < 0 ? state[(size_t)(c + ch) * taps + (uint32_t)(ti + (int)taps)] : x[ch];
+        }
+        {
+            const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_v bv = bias ? *(const f32x4_v*)(bias + c) : zero;
+            b0[0] = bv.x, b0[1] = bv.y, b0[2] = bv.z, b0[3] = bv.w;
+        }
+        // (the carried state is READ here by the pass's first blocks and must not be written by this launch: the chunk preparation behind it writes the next state --
+        // dn_chunk_prep_kernel<true>, conv_state argument -- from the raw rows, which stay intact)
+#pragma unroll
+        for (int i = 0; i < CONV_TBLK; ++i) {
+            if (t_begin + i >= t_end) break;
+            const u32x2_v r = raw[i + taps];
+            const float x[4] = {bits_to_f32(r.x << 16), bits_to_f32(r.x & 0xFFFF0000u), bits_to_f32(r.y << 16), bits_to_f32(r.y & 0xFFFF0000u)};
+            uint32_t y[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float acc = b0[ch]; // the reference's order: taps oldest first, the new token last (conv_scan.rs:44-52)
+#pragma unroll
+                for (uint32_t tap = 0; tap < taps; ++tap) acc += w[ch][tap] * win[ch][tap];
+                acc += w[ch][taps] * x[ch];
+                y[ch] = f32_to_bf16(silu_f32_tab(acc, s_exp_tab));
+#pragma unroll
+                for (uint32_t tap = 0; tap + 1 < taps; ++tap) win[ch][tap] = win[ch][tap + 1];
+                win[ch][taps - 1] = x[ch];
+            }
+            u32x2_v o;
+            o.x = y[0] | (y[1] << 16), o.y = y[2] | (y[3] << 16);
+            *(u32x2_v*)(conv_out + (size_t)(t_begin + i) * conv_dim + c) = o;
+        }
+    }
+}
 size_t delta_net_conv_fused_workspace_floats(uint32_t suffix_len, uint32_t kernel_size, uint32_t conv_dim) {
     return (size_t)((suffix_len + CONV_TBLK - 1) / CONV_TBLK + 1) * (kernel_size - 1) * conv_dim;
 }
@@ -354,6 +418,26 @@ uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* c
     }
     return launch_check([&] { hipLaunchKernelGGL(conv_apply_kernel, dim3(ga), dim3(256), 0, s, in_proj, conv_weight, bias, halo, state, suffix_len, kernel_size, conv_dim,
                                                  out_stride, nblocks); }, "conv_apply");
+}
+
+bool delta_net_conv_out_of_place_supported(const uint16_t* in_proj, const float* conv_weight, const float* bias, const uint16_t* conv_out, uint32_t kernel_size, uint32_t conv_dim,
+                                           uint32_t in_stride) {
+    static const bool on = [] { // UZU_HIP_TUNE=conv_oop=0: the in-place conv behind its halo launch (tests/test_gpu_prefill_switches.py: bit-identical)
+        const char* e = tune_env("conv_oop");
+        return !e || atoi(e) != 0;
+    }();
+    return on && !exact_mode() && kernel_size == 4 && conv_dim % 4 == 0 && in_stride % 4 == 0 && (((uintptr_t)in_proj | (uintptr_t)conv_out) & 7) == 0 &&
+           (((uintptr_t)conv_weight | (uintptr_t)bias) & 15) == 0;
+}
+// DeltaNetConvScan of a prefill pass, out of place: conv_out [suffix_len][conv_dim] bf16; `state` is only read (the caller's next kernel writes the next state)
+uzu_status delta_net_conv_out_of_place(hipStream_t s, const uint16_t* in_proj, const float* conv_weight, const float* bias, const float* state, uint16_t* conv_out,
+                                       uint32_t suffix_len, uint32_t conv_dim, uint32_t in_stride) {
+    if (!suffix_len || !conv_dim) return UZU_OK;
+    const uint32_t nblocks = (suffix_len + CONV_TBLK - 1) / CONV_TBLK;
+    const size_t a4 = (size_t)nblocks * (conv_dim / 4);
+    const uint32_t g4 = (uint32_t)((a4 + 255) / 256 > 8192 ? 8192 : (a4 + 255) / 256);
+    return launch_check([&] { hipLaunchKernelGGL(conv_apply4_oop_kernel, dim3(g4), dim3(256), 0, s, in_proj, conv_weight, bias, state, conv_out, suffix_len, conv_dim, in_stride,
+                                                 nblocks); }, "conv_apply4_oop");
 }
 
 // ---------------------------------------------------------------- DeltaNetPrefillPrep (prefill_prep.rs:30-113)

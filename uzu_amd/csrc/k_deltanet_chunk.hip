@@ -82,7 +82,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm, const float* k_norm, const float* beta_buf, const float* decay_buf,
                                                             float* ws, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t key_dim, uint32_t suffix_len,
                                                             const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out,
-                                                            uint32_t value_dim) {
+                                                            uint32_t value_dim, const uint16_t* conv_rows, float* conv_state) {
     __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP];
     __shared__ float sKK[CC * TP], sQK[CC * TP], sM[CC * TP];
     __shared__ float s_lg[CC], s_b[CC];
@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
             const uint32_t t = min(t0 + tl0 + i, suffix_len - 1);
-            const uint16_t* row = in_proj + (size_t)t * total_proj_dim + hk * DKC + lane * 2;
+            // (conv_rows: the conv'd channels were written out of place -- k_deltanet.hip::conv_apply4_oop_kernel -- and the in-projection rows are still raw)
+            const uint16_t* row = (conv_rows ? conv_rows + (size_t)t * conv_dim : in_proj + (size_t)t * total_proj_dim) + hk * DKC + lane * 2;
             qw[i] = *(const uint32_t*)row;
             kw[i] = *(const uint32_t*)(row + key_dim);
         }
@@ -130,6 +131,19 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
             if (live && writer) {
                 *(float2*)(q_norm_out + (size_t)t * key_dim + hk * DKC + lane * 2) = qn;
                 *(float2*)(k_norm_out + (size_t)t * key_dim + hk * DKC + lane * 2) = kn;
+            }
+        }
+        if (conv_state && chunk == 0) { // the next pass's carried conv state X[T - 3 + tap] (X = [state | raw rows]) -- the out-of-place conv kernel only reads the state;
+            // the first chunk's workgroups share the channels; a channel's three values are read before any is written (one thread)
+            for (uint32_t c = hv * 256 + tid; c < conv_dim; c += num_v_heads * 256) {
+                float nx[3];
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int i = (int)suffix_len - 3 + tap;
+                    nx[tap] = i < 0 ? conv_state[(size_t)c * 3 + 3 + i] : bf16_to_f32(in_proj[(size_t)i * total_proj_dim + c]);
+                }
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) conv_state[(size_t)c * 3 + tap] = nx[tap];
             }
         }
         __syncthreads(); // (the exp table)
@@ -234,7 +248,7 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
 // operands, so a lane's operand values are consecutive in memory.
 __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, float* state,
                                                                  uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim,
-                                                                 uint32_t value_dim, uint32_t suffix_len) {
+                                                                 uint32_t value_dim, uint32_t suffix_len, uint32_t v_row_stride) {
     constexpr int DVT = 16, TPP = 36, RPP = 18; // value columns per workgroup; LDS pitches of T / P (16-byte rows) and R / D (conflict-free column walks)
     __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP], sS[DVT * KP];
     __shared__ __attribute__((aligned(16))) float sT[CC * TPP], sP[CC * TPP];
@@ -255,7 +269,8 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_
     }
     const uint32_t dv_base = tile * DVT, hk = hv / (num_v_heads / num_k_heads);
     const uint32_t conv_dim = 2 * key_dim + value_dim;
-    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    // (v_row_stride != 0: `in_proj` is the out-of-place conv buffer, rows of conv_dim channels in the same q | k | v order)
+    const size_t total_proj_dim = v_row_stride ? (size_t)v_row_stride : (size_t)conv_dim + value_dim + 2 * num_v_heads;
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
 
     // state: wave w owns dk tiles 2 w, 2 w + 1 in accumulator layout: creg[tile][r] = S[dv = 4 kq + r][dk = 16 (2 w + tile) + i16]
@@ -400,7 +415,7 @@ __global__ void __launch_bounds__(256) dn_chunk_scan_mfma_kernel(const float* q_
 // chunk in the first form).  Every output goes to an f32 row of its role's buffer AND, rounded, to the output row, through one store path.
 __global__ void __launch_bounds__(512) dn_chunk_scan_dual_kernel(const float* q_norm, const float* k_norm, const uint16_t* in_proj, const float* ws, const float* state,
                                                                  uint16_t* out, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
-                                                                 uint32_t suffix_len, ScanSplit sp) {
+                                                                 uint32_t suffix_len, ScanSplit sp, uint32_t v_row_stride) {
     constexpr int DVT = 16, TPP = 36, RPP = 18;
     extern __shared__ __attribute__((aligned(16))) float dual_smem[];
     float* sK = dual_smem;                 // [CC][KP]
@@ -431,7 +446,8 @@ __global__ void __launch_bounds__(512) dn_chunk_scan_dual_kernel(const float* q_
     const bool homog = seg1 && grp == 1;
     const uint32_t dv_base = tile * DVT, hk = hv / (num_v_heads / num_k_heads);
     const uint32_t conv_dim = 2 * key_dim + value_dim;
-    const size_t total_proj_dim = (size_t)conv_dim + value_dim + 2 * num_v_heads;
+    // (v_row_stride != 0: `in_proj` is the out-of-place conv buffer, rows of conv_dim channels in the same q | k | v order)
+    const size_t total_proj_dim = v_row_stride ? (size_t)v_row_stride : (size_t)conv_dim + value_dim + 2 * num_v_heads;
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
     const uint32_t c_begin = seg1 ? sp.mid_chunk : 0u, c_end = seg1 ? n_chunks : sp.mid_chunk;
     // f32 output row of token t = o32[t * o_stride] (real tiles: the shared [T][Hv Dv] buffer; homogeneous tile: u, whose row 0 is token 32 mid)
@@ -698,21 +714,26 @@ bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_he
 // prep != null: DeltaNetPrefillPrep fused into the chunk preparation (q_norm / k_norm are then OUTPUTS of this call; beta / decay are not materialised)
 struct FusedPrep {
     const float *a_log, *dt_bias;
+    const uint16_t* conv_rows; // non-null: the conv'd q | k | v channels, [suffix_len][conv_dim] (out-of-place conv)
+    float* conv_state;
 };
 static uzu_status prefill_chunked(hipStream_t s, float* q_norm, float* k_norm, const float* beta, const float* decay, const uint16_t* in_proj, float* state, uint16_t* out,
                                   float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim, uint32_t suffix_len,
                                   const FusedPrep* prep) {
     const uint32_t n_chunks = (suffix_len + CC - 1) / CC;
+    const uint16_t* v_rows = prep && prep->conv_rows ? prep->conv_rows : in_proj; // where the scans read the conv'd v channels
+    const uint32_t v_stride = prep && prep->conv_rows ? 2 * key_dim + value_dim : 0u;
     if (prep)
         UZU_PROPAGATE(launch_check([&] {
             hipLaunchKernelGGL(dn_chunk_prep_kernel<true>, dim3(n_chunks, num_v_heads), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                               (const float*)nullptr, workspace, num_v_heads, num_k_heads, key_dim, suffix_len, in_proj, prep->a_log, prep->dt_bias, q_norm, k_norm, value_dim);
+                               (const float*)nullptr, workspace, num_v_heads, num_k_heads, key_dim, suffix_len, in_proj, prep->a_log, prep->dt_bias, q_norm, k_norm, value_dim, prep->conv_rows,
+                               prep->conv_state);
         }, "delta_net_chunk_prep_fused"));
     else
         UZU_PROPAGATE(launch_check([&] {
             hipLaunchKernelGGL(dn_chunk_prep_kernel<false>, dim3(n_chunks, num_v_heads), dim3(256), 0, s, (const float*)q_norm, (const float*)k_norm, beta, decay, workspace,
                                num_v_heads, num_k_heads, key_dim, suffix_len, (const uint16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
-                               (float*)nullptr, value_dim);
+                               (float*)nullptr, value_dim, (const uint16_t*)nullptr, (float*)nullptr);
         }, "delta_net_chunk_prep"));
     ScanSplit sp{};
     sp.mid_chunk = value_dim == num_v_heads * head_v_dim ? split_mid_chunk(n_chunks, head_v_dim) : 0u;
@@ -722,8 +743,8 @@ static uzu_status prefill_chunked(hipStream_t s, float* q_norm, float* k_norm, c
         sp.mid_chunk = 0; // (74 KB / 68 KB of LDS per workgroup)
     if (!sp.mid_chunk)
         return launch_check([&] {
-            hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, in_proj, workspace, state, out,
-                               num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len);
+            hipLaunchKernelGGL(dn_chunk_scan_mfma_kernel, dim3(head_v_dim / 16, num_v_heads), dim3(256), 0, s, q_norm, k_norm, v_rows, workspace, state, out,
+                               num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, v_stride);
         }, "delta_net_chunk_scan");
     { // the split's pieces live behind the T / P matrices (delta_net_chunk_workspace_bytes)
         float* w = workspace + (size_t)n_chunks * num_v_heads * WS_FLOATS;
@@ -734,8 +755,8 @@ static uzu_status prefill_chunked(hipStream_t s, float* q_norm, float* k_norm, c
         sp.u = w;
     }
     UZU_PROPAGATE(launch_check([&] {
-        hipLaunchKernelGGL(dn_chunk_scan_dual_kernel, dim3(2 * (head_v_dim / 16), num_v_heads), dim3(512), kDualLdsBytes, s, q_norm, k_norm, in_proj, workspace,
-                           (const float*)state, out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, sp);
+        hipLaunchKernelGGL(dn_chunk_scan_dual_kernel, dim3(2 * (head_v_dim / 16), num_v_heads), dim3(512), kDualLdsBytes, s, q_norm, k_norm, v_rows, workspace,
+                           (const float*)state, out, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, sp, v_stride);
     }, "delta_net_chunk_scan_dual"));
     const uint32_t t_mid = sp.mid_chunk * CC, t2 = suffix_len - t_mid;
     return launch_check([&] {
@@ -757,8 +778,8 @@ bool delta_net_prefill_prep_fused_enabled() {
 }
 uzu_status delta_net_prefill_chunked_fused(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* state,
                                            uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
-                                           uint32_t suffix_len) {
-    const FusedPrep prep{a_log, dt_bias};
+                                           uint32_t suffix_len, const uint16_t* conv_rows, float* conv_state) {
+    const FusedPrep prep{a_log, dt_bias, conv_rows, conv_rows ? conv_state : nullptr};
     return prefill_chunked(s, q_norm_out, k_norm_out, nullptr, nullptr, in_proj, state, out, workspace, num_v_heads, num_k_heads, head_v_dim, key_dim, value_dim, suffix_len, &prep);
 }
 

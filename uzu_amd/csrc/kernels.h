@@ -270,6 +270,12 @@ uzu_status delta_net_prefill(hipStream_t s, const float* q_norm, const float* k_
 size_t delta_net_conv_fused_workspace_floats(uint32_t suffix_len, uint32_t kernel_size, uint32_t conv_dim);
 uzu_status delta_net_conv_fused(hipStream_t s, uint16_t* in_proj, const float* conv_weight, const float* bias, float* state, float* halo, uint32_t suffix_len,
                                 uint32_t kernel_size, uint32_t conv_dim, uint32_t out_stride);
+// out-of-place form (round 6; kernel size 4): the conv'd channels go to conv_out [suffix_len][conv_dim] bf16, the in-projection rows stay raw, no halo launch; the carried
+// state is only READ -- delta_net_prefill_chunked_fused (its conv_state argument) writes the next one.  Bit-identical rows.
+bool delta_net_conv_out_of_place_supported(const uint16_t* in_proj, const float* conv_weight, const float* bias, const uint16_t* conv_out, uint32_t kernel_size, uint32_t conv_dim,
+                                           uint32_t in_stride);
+uzu_status delta_net_conv_out_of_place(hipStream_t s, const uint16_t* in_proj, const float* conv_weight, const float* bias, const float* state, uint16_t* conv_out,
+                                       uint32_t suffix_len, uint32_t conv_dim, uint32_t in_stride);
 // chunked form (k_deltanet_chunk.hip): 32-token chunks, T / P matrices built in parallel, four dense products per chunk
 bool delta_net_prefill_chunked_supported(uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_k_dim, uint32_t head_v_dim, uint32_t suffix_len);
 size_t delta_net_chunk_workspace_bytes(uint32_t num_v_heads, uint32_t value_dim, uint32_t suffix_len); // T / P matrices + the pieces of a split scan
@@ -279,9 +285,11 @@ uzu_status delta_net_prefill_chunked(hipStream_t s, const float* q_norm, const f
 // the same with DeltaNetPrefillPrep inside the chunk preparation (round 6): q_norm_out / k_norm_out f32 [suffix_len, key_dim] are written for the scan, beta / decay stay
 // in the kernel; bit-identical to delta_net_prefill_prep + delta_net_prefill_chunked
 bool delta_net_prefill_prep_fused_enabled(); // UZU_HIP_TUNE=prep_fused=0: the separate launch
+// conv_rows != null: the conv'd q | k | v channels live there ([suffix_len][2 key_dim + value_dim] bf16: delta_net_conv_out_of_place) instead of in the in-projection rows,
+// and conv_state f32 [conv_dim][3] receives the next pass's carried state X[T - 3 ..] from the raw rows
 uzu_status delta_net_prefill_chunked_fused(hipStream_t s, const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out, float* state,
                                            uint16_t* out, float* workspace, uint32_t num_v_heads, uint32_t num_k_heads, uint32_t head_v_dim, uint32_t key_dim, uint32_t value_dim,
-                                           uint32_t suffix_len);
+                                           uint32_t suffix_len, const uint16_t* conv_rows = nullptr, float* conv_state = nullptr);
 // rowsum_out (optional; production kernel only): the f32 sum of every (token, head)'s rounded outputs at [head][rowsum_row0 + token], row stride rowsum_stride --
 // MatmulParams::pre_rowsum of the out-projection in parts of head_v_dim columns; rows [rowsum_row0 + suffix_len, rowsum_pad_to) are zeroed (the pad rows)
 uzu_status delta_net_norm_gate(hipStream_t s, uint16_t* in_out, const uint16_t* in_proj, const float* norm_weight,
