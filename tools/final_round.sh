@@ -9,6 +9,7 @@ O=gpurun_out/final; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^E    +" | tail -15 > $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err
 timeout 300 python bench.py --model llama-3-8b --steps 64 --warmup 4 --no-cpu-baseline > $O/bench_llama_int4.json 2> $O/bench_llama_int4.err
 timeout 600 python bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
 timeout 300 python bench.py --config c4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
@@ -33,3 +34,19 @@ timeout 300 python tools/verify_cost.py > $O/verify_cost.json 2> $O/verify_cost.
 timeout 500 python tools/spec_round_cost.py --out $O/spec_round_cost.json > $O/spec_round_cost.log 2>&1
 timeout 600 python bench.py --exact --steps 32 --warmup 5 --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
 timeout 1500 python tools/parity_census.py --out $O/parity_census_c2.json > $O/parity_census_c2.log 2>&1
+
+# per-kernel table of the prefill passes alone
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${R}_prefill_trace -- python $ROOT/tools/prefill_profile.py > $ROOT/$O/prefill_trace.log 2>&1
+cd $ROOT
+python - <<PY
+import csv, glob
+f = sorted(glob.glob('gpurun_out/${R}_prefill_trace/**/*kernel_stats.csv', recursive=True))[-1]
+rows = list(csv.DictReader(open(f)))
+out = open('$O/prefill_kernel_stats.csv', 'w')
+out.write('kernel,calls,total_us,avg_us,pct\n')
+for r in rows[:40]:
+    out.write(f"{r['Name'][:100].replace(',', ';')},{r['Calls']},{int(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.3f},{r['Percentage']}\n")
+PY
+find gpurun_out/${R}_prefill_trace -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
+head -16 $O/prefill_kernel_stats.csv | cut -c1-140
