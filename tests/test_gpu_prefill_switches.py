@@ -5,6 +5,7 @@ process running tools/ab_prefill_bits.py: a 700-token prefill + 8 greedy tokens 
   * split-K reduction + Normalization in one launch (normalization_from_partials)  -- BIT-IDENTICAL logits, fewer launches
   * DeltaNet scan as two concurrent segments (k_deltanet_chunk.hip: ScanSplit)     -- another summation order: logits within the parity tolerance
   * DeltaNetPrefillPrep inside the chunk preparation (round 6: dn_chunk_prep_kernel<true>) -- BIT-IDENTICAL logits to the two launches, fewer launches
+  * the head norms inside the AttentionPrepare launch, SigmoidGate inside the key-split merge (round 6)  -- BIT-IDENTICAL logits, fewer launches
   * the conv out of place without its halo launch (round 6: conv_apply4_oop_kernel)          -- BIT-IDENTICAL logits (and the same carried conv state: the decode steps
                                                                                               behind the prefill produce the same tokens)
 """
@@ -40,6 +41,9 @@ def test_prefill_switches_bit_identity_and_tolerance(tmp_path):
     prep = _leg(tmp_path, "prep_launch", UZU_HIP_TUNE="prep_fused=0")  # DeltaNetPrefillPrep as its own launch in front of the chunk preparation
     assert prep["logits_sha256"] == base["logits_sha256"] and prep["tokens"] == base["tokens"]
     assert prep["prefill_launches"] > base["prefill_launches"], (prep["prefill_launches"], base["prefill_launches"])
+    attn = _leg(tmp_path, "attn_separate", UZU_HIP_TUNE="attn_fused=0")  # QKVNorm launches in front of AttentionPrepare, SigmoidGate behind the attention merge
+    assert attn["logits_sha256"] == base["logits_sha256"] and attn["tokens"] == base["tokens"]
+    assert attn["prefill_launches"] > base["prefill_launches"], (attn["prefill_launches"], base["prefill_launches"])
     inplace = _leg(tmp_path, "conv_in_place", UZU_HIP_TUNE="conv_oop=0")  # the conv in place behind its halo launch instead of out of place
     assert inplace["logits_sha256"] == base["logits_sha256"] and inplace["tokens"] == base["tokens"]
     assert conv1["logits_sha256"] == base["logits_sha256"] and conv1["tokens"] == base["tokens"]

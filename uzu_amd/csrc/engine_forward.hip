@@ -266,8 +266,12 @@ uzu_status ensure_partials(uzu_hip_model* m, uint32_t rows, uint32_t head_dim) {
 // streamed once for all sequences), attention / KV append / DeltaNet run per sequence on its own state.  The reference
 // has no cross-sequence batching: per sequence the arithmetic is that of the single-sequence pass.
 
-void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0);
+void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, bool fuse_norms);
 
+static bool attention_fusions_enabled() {
+    const char* e = tune_env("attn_fused");
+    return !e || atoi(e) != 0;
+}
 // `first_done`: the layer's first projection (qkv; the DeltaNet in-projection) has been run with its Normalization prologue already (linear_normed)
 void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, const Seqs& q, PostNorm* post, bool first_done) {
     uzu_hip_model* m = e.m;
@@ -276,26 +280,31 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
     const uint32_t rows = q.rows();
     if (L.d.has_gate) linear(e, L.gate, hidden, m->gate, rows);
     if (!first_done) linear(e, L.qkv, hidden, m->qkv, rows);
+    // passes of more than one row: the head norms ride in the AttentionPrepare launch (attention_prepare_normed_kernel: bit-identical, two launches per layer fewer)
+    // (UZU_HIP_TUNE=attn_fused=0: the separate QKVNorm / SigmoidGate launches; tests/test_gpu_prefill_switches.py)
+    const bool fuse_norms = rows > 1 && attention_fusions_enabled() && k::attention_prepare_normed_supported(hd);
+    if (!fuse_norms) {
     if (L.qn.present)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, rows, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
     if (L.kn.present && nkv)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.kn.scales, rows, total_heads, hd, L.kn.eps, L.kn.offset, nq, nkv, L.kn.full_layer));
     if (L.d.normalize_values && nkv) // AttentionConfig::value_norm_config (config/token_mixer/attention.rs:32-42): eps 1e-6, FullLayer, no scales
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, nullptr, rows, total_heads, hd, 1e-6f, 0.0f, nq + nkv, nkv, 1));
+    }
     if (q.n == 0) {
-        attention_core(e, L, q.count, 0);
+        attention_core(e, L, q.count, 0, fuse_norms);
     } else {
         for (uint32_t i = 0; i < q.n; ++i) {
             bind_state(m, q.st[i]);
-            attention_core(e, L, q.count, (size_t)i * q.count);
+            attention_core(e, L, q.count, (size_t)i * q.count, fuse_norms);
         }
     }
-    if (L.d.has_gate) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate, m->attn_out, UZU_BF16, rows * nq * hd));
+    // (SigmoidGate: attention_core applies it per sequence -- inside the key-split merge of a prefill pass where there is one)
     linear(e, L.out, m->attn_out, out, rows, true, post);
 }
 
 // AttentionPrepare + attention of `batch` rows of the bound sequence, which start at row `row0` of qkv / queries / attn_out
-void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
+void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0, bool fuse_norms) {
     uzu_hip_model* m = e.m;
     const bool has_kv = !L.d.is_kv_sharing; // prepare_queries (mode.rs:234-259): no KV rows are written; the source layer wrote this pass's already
     const uint32_t hd = L.d.head_dim, nq = L.d.num_heads, nkv = L.d.num_groups, total_heads = nq + (has_kv ? 2 * nkv : 0);
@@ -308,8 +317,16 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     // device from the accepted-token count, and the rows enter the ring afterwards (encode_accept, state.rs:200-219).
     const uint32_t W = L.d.sliding_window_size;
     const uint32_t* trie = m->tree.active ? m->tree.d_trie : nullptr; // a speculated tree: RoPE positions = context + height, trie mask (mode.rs:178-192)
-    RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, L.rope_cos, L.rope_sin, nq, nkv, hd, rope_dim, W, batch, has_kv ? 1u : 0u,
-                               m->d_ctx_len, W ? 1u : 0u, trie));
+    if (fuse_norms) {
+        const bool kv = has_kv && nkv;
+        const k::PrepNorm qn{L.qn.scales, L.qn.eps, L.qn.offset, L.qn.full_layer, L.qn.present ? 1u : 0u};
+        const k::PrepNorm kn{L.kn.scales, L.kn.eps, L.kn.offset, L.kn.full_layer, L.kn.present && kv ? 1u : 0u};
+        const k::PrepNorm vn{nullptr, 1e-6f, 0.0f, 1u, L.d.normalize_values && kv ? 1u : 0u}; // AttentionConfig::value_norm_config (config/token_mixer/attention.rs:32-42)
+        RUN("attention_prepare_normed", 0, k::attention_prepare_normed(e.s, qkv, queries, L.keys, L.values, L.rope_cos, L.rope_sin, qn, kn, vn, nq, nkv, hd, rope_dim, W, batch,
+                                                                         has_kv ? 1u : 0u, m->d_ctx_len, W ? 1u : 0u, trie));
+    } else
+        RUN("attention_prepare", 0, k::attention_prepare(e.s, qkv, queries, L.keys, L.values, L.rope_cos, L.rope_sin, nq, nkv, hd, rope_dim, W, batch, has_kv ? 1u : 0u,
+                                   m->d_ctx_len, W ? 1u : 0u, trie));
     k::AttentionParams a{};
     a.queries = queries, a.keys = L.keys, a.values = L.values;
     a.dt = UZU_BF16, a.head_dim = hd, a.gqa_factor = nq / nkv;
@@ -324,14 +341,18 @@ void attention_core(Enc& e, DLayer& L, uint32_t batch, size_t row0) {
     const uint32_t physical_prefix = W ? W : m->context_length; // AttentionStateType::physical_prefix_length (state.rs:26-37)
     const size_t kv_bytes = (size_t)2 * (physical_prefix + batch) * nkv * hd * 2; // K and V rows read once
     const bool two_pass = (m->regime_override >= 0 && !W) ? m->regime_override == 1 : physical_prefix + batch > 1024; // core/mod.rs:89-92
+    bool gated = false;
     if (k::attention_prefill_mfma_supported(a)) { // prefill chunk: flash-attention tiles on the matrix cores, any context length
-        RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, attn_out));
+        uint32_t gate_done = 0; // SigmoidGate inside the key-split merge launch when the pass has one (bit-identical to the separate launch)
+        RUN("attention_prefill_mfma", kv_bytes, k::attention_prefill_mfma(e.s, a, attn_out, L.d.has_gate && attention_fusions_enabled() ? m->gate + row0 * nq * hd : nullptr, &gate_done));
+        gated = gate_done != 0;
     } else if (two_pass) { // core/mod.rs:89-92
         RUN("attention_two_pass1", kv_bytes, k::attention_two_pass1(e.s, a, m->partials, m->sums, m->maxs));
         RUN("attention_two_pass2", 0, k::attention_two_pass2(e.s, m->partials, m->sums, m->maxs, attn_out, UZU_BF16, hd, nq, batch));
     } else {
         RUN("attention_single_pass", kv_bytes, k::attention_single_pass(e.s, a, attn_out));
     }
+    if (L.d.has_gate && !gated) RUN("sigmoid_gate", 0, k::sigmoid_gate(e.s, m->gate + row0 * nq * hd, attn_out, UZU_BF16, batch * nq * hd));
     if (W && !trie && has_kv && L.last_reader == (uint32_t)(&L - m->layers.data()))
         RUN("kv_ring_insert", 0, k::kv_ring_insert(e.s, L.keys, L.values, UZU_BF16, m->d_ctx_len, batch, W, nkv * hd));
 }

@@ -68,7 +68,7 @@ inline bool raise_lds_limit(LdsLimit& st, const void* fn, size_t lds) {
 
 // Environment switches.  The shipped library reads SIX variables: UZU_HIP_EXACT, UZU_HIP_POISON, UZU_PREFILL_CHUNK, UZU_TP_TIMEOUT_MS,
 // UZU_TP_INJECT_TIMEOUT_AT and UZU_HIP_TUNE -- one string "key=value,key=value" holding the A/B switches that tests cross in the product build
-// (tune_env below; keys: gemm_form, gemm_splits, exact_scalar, rows_norm, conv_apply4, norm_partials, dn_split -- each documented where it is read;
+// (tune_env below; keys: gemm_form, gemm_splits, exact_scalar, rows_norm, conv_apply4, conv_oop, norm_partials, dn_split, prep_fused, attn_fused -- each documented where it is read;
 // tests/test_gpu_prefill_switches.py holds the fused prefill paths to the paths they replace).  Every other knob is a LAB switch of the A/B scripts under
 // tools/ and exists only in a library built with `make LAB=1` (-DUZU_LAB): in the product it reads as unset.
 inline const char* tune_env(const char* key) {

@@ -293,7 +293,8 @@ bool attention_prefill_mfma_supported(const AttentionParams& a) {
 // out[q][head][:] = sum_s w_s O_s / sum_s w_s l_s, w_s = exp(m_s - max m) (a split that saw no key has m = -inf, l = 0: weight 0).
 // grid = rows / 4, 256 threads: 64 threads per (query, head) row, HD / 64 elements each.
 template <int HD>
-__global__ void __launch_bounds__(256) attention_prefill_merge_kernel(const float* part_o, const float* part_ml, uint16_t* out, uint32_t rows, uint32_t splits) {
+// gate (optional): SigmoidGate (sigmoid_gate.rs:9-22) on the merged rows in the same launch -- out = bf16(bf16(o) * sigmoid(gate)), the separate kernel's two roundings
+__global__ void __launch_bounds__(256) attention_prefill_merge_kernel(const float* part_o, const float* part_ml, uint16_t* out, uint32_t rows, uint32_t splits, const uint16_t* gate) {
     constexpr int EPT = HD / 64;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), e0 = (threadIdx.x & 63) * EPT;
     if (row >= rows) return;
@@ -314,7 +315,19 @@ __global__ void __launch_bounds__(256) attention_prefill_merge_kernel(const floa
     }
     const float inv = 1.0f / l;
     uint16_t* orow = out + (size_t)row * HD + e0;
-    if constexpr (EPT == 1) {
+    if (gate) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const float o = bf16_to_f32((uint16_t)pack2(acc[e] * inv, 0.f)), g = bf16_to_f32(gate[(size_t)row * HD + e0 + e]);
+            acc[e] = o * (1.0f / (1.0f + expf_glibc(-g)));
+        }
+        if constexpr (EPT == 1) {
+            orow[0] = f32_to_bf16(acc[0]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; e += 2) *(uint32_t*)(orow + e) = (uint32_t)f32_to_bf16(acc[e]) | ((uint32_t)f32_to_bf16(acc[e + 1]) << 16);
+        }
+    } else if constexpr (EPT == 1) {
         orow[0] = (uint16_t)pack2(acc[0] * inv, 0.f);
     } else {
 #pragma unroll
@@ -322,7 +335,8 @@ __global__ void __launch_bounds__(256) attention_prefill_merge_kernel(const floa
     }
 }
 
-uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out) {
+uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void* out, const void* gate, uint32_t* gate_done) {
+    if (gate_done) *gate_done = 0;
     const uint32_t kv_heads = a.num_heads / a.gqa_factor;
     const uint32_t n_tasks = a.gqa_factor * ((a.suffix_length + TQ - 1) / TQ);
     static const uint32_t force_tpw = [] {
@@ -366,7 +380,8 @@ uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& a, void*
             else hipLaunchKernelGGL((attention_prefill_mfma_kernel<H, false>), grid, dim3(256), 0, s, a, (uint16_t*)out, tpw, part_o, part_ml);                    \
         }, "attention_prefill_mfma"));                                                                                                                             \
         if (!part) return UZU_OK;                                                                                                                                  \
-        return launch_check([&] { hipLaunchKernelGGL(attention_prefill_merge_kernel<H>, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, s, part_o, part_ml, (uint16_t*)out, (uint32_t)rows, splits); }, \
+        if (gate && gate_done) *gate_done = 1;                                                                                                                     \
+        return launch_check([&] { hipLaunchKernelGGL(attention_prefill_merge_kernel<H>, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, s, part_o, part_ml, (uint16_t*)out, (uint32_t)rows, splits, gate_done ? (const uint16_t*)gate : nullptr); }, \
                             "attention_prefill_merge");                                                                                                            \
     }
     switch (a.head_dim) {

@@ -368,6 +368,92 @@ uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queri
     }, "attention_prepare");
 }
 
+// QKVNorm (query heads, key heads, value heads) + AttentionPrepare as ONE launch (engine passes of more than one row, round 6): a wave per (row, head) keeps the head's
+// elements in registers -- element i = lane + 64 j, qkv_norm_kernel's mapping, its sum order and its wave_sum, so the normalised values are the same bits -- parks them in
+// a wave-private LDS row for the rotation's partner element and writes the row where attention_prepare_kernel would.  Three launches -> one per attention layer.
+struct HeadNorm {
+    const float* scales; // null: no scales (value normalisation)
+    float epsilon, scale_offset;
+    uint32_t full_layer, present;
+};
+constexpr uint32_t kPrepMaxHeadDim = 512;
+__global__ void __launch_bounds__(256) attention_prepare_normed_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ queries, uint16_t* __restrict__ keys,
+                                                                       uint16_t* __restrict__ values, const float* __restrict__ cosines, const float* __restrict__ sines,
+                                                                       HeadNorm qn, HeadNorm kn, HeadNorm vn, uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                                                                       uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn,
+                                                                       uint32_t kv_rows_fixed, const uint32_t* __restrict__ trie) {
+    __shared__ uint16_t s_row[4][kPrepMaxHeadDim];
+    using T = bf16_t;
+    const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4 + wv;
+    const bool live = wave < batch_dim * total_heads;
+    const uint32_t batch_idx = live ? wave / total_heads : 0, head_idx = live ? wave % total_heads : 0;
+    const uint32_t pos0 = dyn ? *dyn : 0u;
+    const uint32_t kv_row0 = kv_token_offset + (kv_rows_fixed ? 0u : pos0);
+    const bool is_query = !has_kv || head_idx < num_q_heads;
+    const bool is_key = has_kv && head_idx >= num_q_heads && head_idx < num_q_heads + num_kv_heads;
+    const HeadNorm N = is_query ? qn : is_key ? kn : vn;
+    const size_t offset = (size_t)batch_idx * total_heads * head_dim + (size_t)head_idx * head_dim;
+    const T* src = (const T*)qkv;
+    if (N.present) {
+        float total = 0.f;
+        for (uint32_t i = lane; i < head_dim; i += 64) {
+            const float v = ld(src, offset + i);
+            total += v * v;
+        }
+        total = wave_sum(total);
+        const float rms_norm = 1.0f / sqrtf(total / (float)head_dim + N.epsilon);
+        for (uint32_t i = lane; i < head_dim; i += 64) {
+            const float normalized = ld(src, offset + i) * rms_norm;
+            float result;
+            if (!N.scales)
+                result = rnd<T>(normalized);
+            else if (N.full_layer)
+                result = rnd<T>(normalized * (N.scales[i] + N.scale_offset));
+            else
+                result = rnd<T>(rnd<T>(normalized) * rnd<T>(N.scales[i] + N.scale_offset));
+            s_row[wv][i] = f32_to_bf16(result);
+        }
+    } else {
+        for (uint32_t i = lane; i < head_dim; i += 64) s_row[wv][i] = qkv[offset + i];
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint16_t* head = s_row[wv];
+    for (uint32_t d = lane; d < head_dim; d += 64) {
+        uint16_t element = head[d];
+        if (rope_dim && d < rope_dim && (is_query || is_key)) {
+            const uint32_t half = rope_dim / 2;
+            const uint32_t paired_idx = d < half ? d + half : d - half;
+            const float input = bf16_to_f32(head[d]);
+            const float paired = bf16_to_f32(head[paired_idx]);
+            const float signed_paired = d < half ? -paired : paired;
+            const size_t r = (size_t)((trie ? trie[3 * (size_t)batch_idx + 2] : batch_idx) + pos0) * rope_dim + d; // tree: position = base + height
+            element = f32_to_bf16(input * cosines[r] + signed_paired * sines[r]);
+        }
+        if (is_query)
+            queries[(size_t)head_idx * batch_dim * head_dim + (size_t)batch_idx * head_dim + d] = element;
+        else if (is_key)
+            keys[(size_t)(kv_row0 + batch_idx) * num_kv_heads * head_dim + (size_t)(head_idx - num_q_heads) * head_dim + d] = element;
+        else
+            values[(size_t)(kv_row0 + batch_idx) * num_kv_heads * head_dim + (size_t)(head_idx - num_q_heads - num_kv_heads) * head_dim + d] = element;
+    }
+}
+bool attention_prepare_normed_supported(uint32_t head_dim) { return !exact_mode() && head_dim <= kPrepMaxHeadDim; }
+uzu_status attention_prepare_normed(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values, const float* cosines, const float* sines,
+                                    const PrepNorm& qn, const PrepNorm& kn, const PrepNorm& vn, uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim, uint32_t rope_dim,
+                                    uint32_t kv_token_offset, uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed, const uint32_t* trie) {
+    const uint32_t total_heads = has_kv ? num_q_heads + 2 * num_kv_heads : num_q_heads;
+    const uint32_t waves = batch_dim * total_heads;
+    if (!waves) return UZU_OK;
+    auto hn = [](const PrepNorm& p) { return HeadNorm{p.scales, p.epsilon, p.scale_offset, p.full_layer, p.present}; };
+    return launch_check([&] {
+        hipLaunchKernelGGL(attention_prepare_normed_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, qkv, queries, keys, values, cosines, sines, hn(qn), hn(kn), hn(vn), num_q_heads,
+                           num_kv_heads, head_dim, rope_dim, kv_token_offset, batch_dim, has_kv, dyn, kv_rows_fixed, trie);
+    }, "attention_prepare_normed");
+}
+
 // =============================================================== KVCacheUpdate
 // BU/cpu/kernel/attention/kv_cache_update.rs:9-28.  The reference executes copies sequentially per
 // element column; copy lists on this path never chain (ring insert / accept compaction read rows of the

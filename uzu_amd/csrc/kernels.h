@@ -133,6 +133,16 @@ uzu_status attention_prepare(hipStream_t s, const uint16_t* qkv, uint16_t* queri
                              const float* cosines, const float* sines, uint32_t num_q_heads, uint32_t num_kv_heads,
                              uint32_t head_dim, uint32_t rope_dim, uint32_t kv_token_offset, uint32_t batch_dim,
                              uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed = 0, const uint32_t* trie = nullptr);
+// QKVNorm of the query / key / value heads + AttentionPrepare in one launch (k_elementwise.hip::attention_prepare_normed_kernel; bit-identical to the separate launches)
+struct PrepNorm {
+    const float* scales;
+    float epsilon, scale_offset;
+    uint32_t full_layer, present;
+};
+bool attention_prepare_normed_supported(uint32_t head_dim);
+uzu_status attention_prepare_normed(hipStream_t s, const uint16_t* qkv, uint16_t* queries, uint16_t* keys, uint16_t* values, const float* cosines, const float* sines,
+                                    const PrepNorm& qn, const PrepNorm& kn, const PrepNorm& vn, uint32_t num_q_heads, uint32_t num_kv_heads, uint32_t head_dim, uint32_t rope_dim,
+                                    uint32_t kv_token_offset, uint32_t batch_dim, uint32_t has_kv, const uint32_t* dyn, uint32_t kv_rows_fixed = 0, const uint32_t* trie = nullptr);
 // trie (speculated tree, {trie_start, trie_end, height} per row): the RoPE position of row i is the base + height_i (transformer.rs:247)
 // instead of base + i; the K / V rows still go to consecutive cache rows (DFS order)
 // AttentionState::encode_accept on a Ring (state.rs:200-219) for a flat full accept of `batch` suffix rows, driven by the device-resident
@@ -183,7 +193,9 @@ __host__ __device__ inline void attention_resolve_dyn(AttentionParams& a) {
 }
 uzu_status attention_single_pass(hipStream_t s, const AttentionParams& p, void* out);
 bool attention_prefill_mfma_supported(const AttentionParams& p); // k_attention_mfma.hip: causal bf16 prefill tiles on the matrix cores
-uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& p, void* out);
+// gate / gate_done (optional): when the pass ends in the key-split merge, SigmoidGate of `gate` (bf16, the layout of `out`) is applied there and *gate_done = 1
+// (bit-identical to the separate launch); otherwise the caller runs sigmoid_gate itself
+uzu_status attention_prefill_mfma(hipStream_t s, const AttentionParams& p, void* out, const void* gate = nullptr, uint32_t* gate_done = nullptr);
 uzu_status attention_two_pass1(hipStream_t s, const AttentionParams& p, float* partials, float* sums, float* maxs);
 uzu_status attention_two_pass2(hipStream_t s, const float* partials, const float* sums, const float* maxs, void* out,
                                uint32_t dt, uint32_t head_dim, uint32_t num_heads, uint32_t suffix_length);
