@@ -84,7 +84,12 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
                                                             const uint16_t* in_proj, const float* a_log, const float* dt_bias, float* q_norm_out, float* k_norm_out,
                                                             uint32_t value_dim, const uint16_t* conv_rows, float* conv_state) {
     __shared__ __attribute__((aligned(16))) float sK[CC * KP], sQ[CC * KP];
-    __shared__ float sKK[CC * TP], sQK[CC * TP], sM[CC * TP];
+    // the three 32 x 32 matrices live in the Q rows once the Gram products have read them (a barrier in between): 34 KB of LDS per workgroup instead of 47 -- four
+    // workgroups per CU, the whole grid of a 2048-token pass (1024 workgroups) resident at once
+    float* const sKK = sQ;
+    float* const sQK = sQ + CC * TP;
+    float* const sM = sQ + 2 * CC * TP;
+    static_assert(3 * CC * TP <= CC * KP, "the Gram / M matrices fit in the Q rows");
     __shared__ float s_lg[CC], s_b[CC];
     __shared__ uint64_t s_exp_tab[32];
     const int tid = threadIdx.x;
@@ -204,6 +209,7 @@ __global__ void __launch_bounds__(256) dn_chunk_prep_kernel(const float* q_norm,
                 qk[j] = fmaf(qi.x, kj.x, qk[j]), qk[j] = fmaf(qi.y, kj.y, qk[j]), qk[j] = fmaf(qi.z, kj.z, qk[j]), qk[j] = fmaf(qi.w, kj.w, qk[j]);
             }
         }
+        __syncthreads(); // every thread has read its K / Q rows: the Q rows become the matrices
 #pragma unroll
         for (int j = 0; j < 4; ++j) sKK[i * TP + j0 + j] = kk[j], sQK[i * TP + j0 + j] = qk[j];
     }
