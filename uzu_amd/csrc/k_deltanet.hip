@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(256) conv_apply4_kernel(uint16_t* in_proj, con
 // Out of place (round 6): the conv'd channels go to `conv_out` [suffix_len][conv_dim] bf16 and the in-projection rows stay raw, so a block's window is read from the
 // rows themselves -- no halo launch in front.  Kernel size 4, four channels per thread, the arithmetic and its order are conv_apply4_kernel's (bit-identical rows).
 // The consumers of a chunked prefill (dn_chunk_prep_kernel<true>: q / k; the chunk scans: v) take the rows from conv_out.
+template <int TB>
 __global__ void __launch_bounds__(256) conv_apply4_oop_kernel(const uint16_t* in_proj, const float* conv_weight, const float* bias, const float* state, uint16_t* conv_out,
                                                               uint32_t suffix_len, uint32_t conv_dim, uint32_t in_stride, uint32_t nblocks) {
     __shared__ uint64_t s_exp_tab[32];
@@ -339,10 +340,10 @@ __global__ void __launch_bounds__(256) conv_apply4_oop_kernel(const uint16_t* in
     const size_t total = (size_t)nblocks * cq;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const uint32_t c = (uint32_t)(idx % cq) * 4, b = (uint32_t)(idx / cq);
-        const uint32_t t_begin = b * CONV_TBLK, t_end = (b + 1) * CONV_TBLK < suffix_len ? (b + 1) * CONV_TBLK : suffix_len;
-        u32x2_v raw[CONV_TBLK + taps]; // rows t_begin - 3 .. t_begin + 15 (clamped rows are loaded and never consumed)
+        const uint32_t t_begin = b * TB, t_end = (b + 1) * TB < suffix_len ? (b + 1) * TB : suffix_len;
+        u32x2_v raw[TB + taps]; // rows t_begin - 3 .. t_begin + TB - 1 (clamped rows are loaded and never consumed)
 #pragma unroll
-        for (int i = 0; i < CONV_TBLK + (int)taps; ++i) {
+        for (int i = 0; i < TB + (int)taps; ++i) {
             const int ti = (int)t_begin - (int)taps + i;
             const uint32_t t = (uint32_t)(ti < 0 ? 0 : ti < (int)suffix_len ? ti : (int)suffix_len - 1);
             raw[i] = *(const u32x2_v*)(in_proj + (size_t)t * in_stride + c);
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256) conv_apply4_oop_kernel(const uint16_t* in
         // (the carried state is READ here by the pass's first blocks and must not be written by this launch: the chunk preparation behind it writes the next state --
         // dn_chunk_prep_kernel<true>, conv_state argument -- from the raw rows, which stay intact)
 #pragma unroll
-        for (int i = 0; i < CONV_TBLK; ++i) {
+        for (int i = 0; i < TB; ++i) {
             if (t_begin + i >= t_end) break;
             const u32x2_v r = raw[i + taps];
             const float x[4] = {bits_to_f32(r.x << 16), bits_to_f32(r.x & 0xFFFF0000u), bits_to_f32(r.y << 16), bits_to_f32(r.y & 0xFFFF0000u)};
@@ -433,10 +434,18 @@ bool delta_net_conv_out_of_place_supported(const uint16_t* in_proj, const float*
 uzu_status delta_net_conv_out_of_place(hipStream_t s, const uint16_t* in_proj, const float* conv_weight, const float* bias, const float* state, uint16_t* conv_out,
                                        uint32_t suffix_len, uint32_t conv_dim, uint32_t in_stride) {
     if (!suffix_len || !conv_dim) return UZU_OK;
-    const uint32_t nblocks = (suffix_len + CONV_TBLK - 1) / CONV_TBLK;
+    // tokens per thread: 8 (rows 11 / 8 per output from the cache instead of 19 / 16, twice the threads) -- UZU_CONV_OOP_TB (lab builds) = 16 for the A/B
+    static const int tb = [] {
+        const char* e = lab_env("UZU_CONV_OOP_TB");
+        return e && atoi(e) == 16 ? 16 : 8;
+    }();
+    const uint32_t nblocks = (suffix_len + tb - 1) / tb;
     const size_t a4 = (size_t)nblocks * (conv_dim / 4);
-    const uint32_t g4 = (uint32_t)((a4 + 255) / 256 > 8192 ? 8192 : (a4 + 255) / 256);
-    return launch_check([&] { hipLaunchKernelGGL(conv_apply4_oop_kernel, dim3(g4), dim3(256), 0, s, in_proj, conv_weight, bias, state, conv_out, suffix_len, conv_dim, in_stride,
+    const uint32_t g4 = (uint32_t)((a4 + 255) / 256 > 16384 ? 16384 : (a4 + 255) / 256);
+    if (tb == 16)
+        return launch_check([&] { hipLaunchKernelGGL(conv_apply4_oop_kernel<16>, dim3(g4), dim3(256), 0, s, in_proj, conv_weight, bias, state, conv_out, suffix_len, conv_dim, in_stride,
+                                                     nblocks); }, "conv_apply4_oop");
+    return launch_check([&] { hipLaunchKernelGGL(conv_apply4_oop_kernel<8>, dim3(g4), dim3(256), 0, s, in_proj, conv_weight, bias, state, conv_out, suffix_len, conv_dim, in_stride,
                                                  nblocks); }, "conv_apply4_oop");
 }
 
