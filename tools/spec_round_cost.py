@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--context", type=int, default=2043)
     ap.add_argument("--draft-layers", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--weaver-dim", type=int, default=512, help="model_dim of the synthetic Weaver (heads of 128)")
+    ap.add_argument("--weaver-only", action="store_true")
     ap.add_argument("--out", default="gpurun_out/r6_spec_round_cost.json")
     args = ap.parse_args()
     from uzu_amd import synthetic as S
@@ -42,7 +44,7 @@ def main():
     plain_ms = ms / 32
     plain.close()
     out = {"model": cfg.name, "context": args.context, "draft_layers": args.draft_layers, "plain_decode_ms_per_token": round(plain_ms, 4), "nodes": {}}
-    for nodes in (4, 8, 16):
+    for nodes in (() if args.weaver_only else (4, 8, 16)):
         hm = HipModel(ctx, bundle)
         db = S.build_drafter(cfg, num_layers=args.draft_layers, block_size=16, context_capacity=args.context + 1024)
         hd = HipDrafter(ctx, hm, db)
@@ -87,7 +89,7 @@ def main():
     hm = HipModel(ctx, bundle)
     db = S.build_drafter(cfg, num_layers=args.draft_layers, block_size=16, context_capacity=args.context + 1024)
     hd = HipDrafter(ctx, hm, db)
-    wb = S.build_weaver(cfg, model_dim=512, num_layers=2, num_heads=4, hidden_dim=1024, max_depth=15, candidate_pool_size=64)
+    wb = S.build_weaver(cfg, model_dim=args.weaver_dim, num_layers=2, num_heads=args.weaver_dim // 128, hidden_dim=2 * args.weaver_dim, max_depth=15, candidate_pool_size=64)
     hw = HipWeaver(ctx, hd, wb)
     spec = DFlashSpeculator(hd, hw)
     prng = PRng(5)
@@ -119,7 +121,7 @@ def main():
     med = lambda v: round(float(np.median(v)), 4)
     device = med(rec["draft_ms"]) + med(rec["weaver_ms"]) + med(rec["verify_ms"]) + med(rec["drafter_accept_ms"])
     out["weaver_16"] = {
-        "weaver": "model_dim 512, 2 layers, 4 heads x 128, hidden 1024, max_depth 15, candidate pool 64 (synthetic weights); shape rounds 16 x 4 nodes x 4 children",
+        "weaver": f"model_dim {args.weaver_dim}, 2 layers, {args.weaver_dim // 128} heads x 128, hidden {2 * args.weaver_dim}, max_depth 15, candidate pool 64 (synthetic weights); shape rounds 16 x 4 nodes x 4 children",
         "draft_ms": med(rec["draft_ms"]), "weaver_tree_ms": med(rec["weaver_ms"]), "weaver_launches_in_one_graph": int(launches), "verify_ms": med(rec["verify_ms"]),
         "drafter_accept_ms": med(rec["drafter_accept_ms"]), "device_ms_per_round": round(device, 4), "wall_ms_per_round": med(rec["round_wall_ms"]),
         "tree_nodes": med(rec["tree_nodes"]), "break_even_tokens_per_round_device": round(device / plain_ms, 2),
