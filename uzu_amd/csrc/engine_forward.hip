@@ -282,7 +282,8 @@ void attention_mixer(Enc& e, DLayer& L, const uint16_t* hidden, uint16_t* out, c
     if (!first_done) linear(e, L.qkv, hidden, m->qkv, rows);
     // passes of more than one row: the head norms ride in the AttentionPrepare launch (attention_prepare_normed_kernel: bit-identical, two launches per layer fewer)
     // (UZU_HIP_TUNE=attn_fused=0: the separate QKVNorm / SigmoidGate launches; tests/test_gpu_prefill_switches.py)
-    const bool fuse_norms = rows > 1 && attention_fusions_enabled() && k::attention_prepare_normed_supported(hd);
+    // (layers without head norms keep the flat element-wise AttentionPrepare: a wave per (row, head) is the norm's shape, not the copy's)
+    const bool fuse_norms = rows > 1 && (L.qn.present || (L.kn.present && nkv) || (L.d.normalize_values && nkv)) && attention_fusions_enabled() && k::attention_prepare_normed_supported(hd);
     if (!fuse_norms) {
     if (L.qn.present)
         RUN("qkv_norm", 0, k::qkv_norm(e.s, m->qkv, UZU_BF16, L.qn.scales, rows, total_heads, hd, L.qn.eps, L.qn.offset, 0, nq, L.qn.full_layer));
